@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- factor convolutions/sec (N=100) on a Manhattan-3500-shaped graph.
+
+One "step" = one pass of the hot path over the whole graph: every (factor, direction) Pose2Pose2
+convolution (2 x 5453 = 10906) in ONE kernel launch + the PriorPose2 sampling, with the belief
+store already resident in HBM.  One convolution = what IIF `approxConvBelief` does for one factor
+and target: N=100 getSample + inflateCycles(3) x {entropy inflation, 100 per-particle root-finds}.
+
+    python bench.py [--gpus N --steps K --warmup W] [--solver newton|nelder_mead|closed_form]
+
+N>1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns one
+Manhattan-sized segment of a chain of segments; after each sweep the ranks all-gather their
+separator (segment boundary) beliefs over RCCL, exactly the message a Bayes-tree clique boundary
+carries (N x 3 doubles per separator variable).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+BYTES_PER_PARTICLE_P2P2 = 72  # fixed pose 3 + start point u0 3 + solution 3 doubles (in-kernel RNG: no noise read)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--solver", default="newton", choices=["closed_form", "newton", "nelder_mead"])
+    ap.add_argument("--poses", type=int, default=3500)
+    ap.add_argument("--loops", type=int, default=1954)
+    ap.add_argument("--particles", type=int, default=100)
+    ap.add_argument("--g2o", default=None, help="optional g2o file instead of the synthetic generator")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the extra per-solver throughput runs")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import rome_jl_amd as R
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "--gpus must match WORLD_SIZE"
+
+    N = args.particles
+    solver = {"closed_form": R.SOLVER_CLOSED_FORM, "newton": R.SOLVER_NEWTON, "nelder_mead": R.SOLVER_NELDER_MEAD}[args.solver]
+
+    # ---- workload: this rank's Manhattan-shaped segment (+ ghost separators of the neighbours) ----
+    if args.g2o:
+        fg = R.loadG2o(args.g2o, N=N)
+        workload = "g2o:%s" % os.path.basename(args.g2o)
+    else:
+        fg = R.synth_manhattan(P=args.poses, loops=args.loops, seed=0x524F4D45 + rank, N=N)
+        workload = "synth_manhattan(P=%d, loops=%d) [g2o-shaped stand-in for examples/manhattan.g2o]" % (args.poses, args.loops)
+    last = "x%d" % (len(fg.variables) - 1)
+    if world > 1:
+        # cut edges to the neighbouring segments: ghost variables hold the neighbours' separator beliefs
+        cov = np.diag([1 / 44.6, 1 / 399.0, 1 / 9591.0])
+        fg.addVariable("ghost_prev", R.Pose2); fg.addVariable("ghost_next", R.Pose2)
+        fg.addFactor(["ghost_prev", "x0"], R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.0], cov)))
+        fg.addFactor([last, "ghost_next"], R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.0], cov)))
+    R.dead_reckon_init(fg, seed=11 + rank)
+    ctx = R.Context(local)
+    dg = R.DeviceGraph(fg, device=dev, ctx=ctx)
+    dg.upload_beliefs(fg)
+    tb = dg.tab["p2p2"]
+    n_conv_step = tb["C"] + dg.tab["prior2"]["F"]  # convolutions per step on this rank
+    opts = R.make_opts(N=N, solver=solver, seed=0x524F4D45, stream_offset=rank * (1 << 32))
+    prop = torch.empty((tb["C"], 3, N), dtype=torch.float64, device=dev)
+    prior_out = torch.empty((dg.tab["prior2"]["F"], 3, N), dtype=torch.float64, device=dev)
+
+    pk = dg.packed
+    if world > 1:
+        sep_send = torch.empty((2, 3, N), dtype=torch.float64, device=dev)      # this rank's first/last pose beliefs
+        sep_all = torch.empty((world, 2, 3, N), dtype=torch.float64, device=dev)
+        i_first, i_last = pk.index["x0"], pk.index[last]
+        g_prev, g_next = pk.index["ghost_prev"], pk.index["ghost_next"]
+        # proposal rows that carry the updated separator estimates (odometry convs targeting them)
+        conv_first = 2 * 0 + 1   # factor 0 (x0->x1), dir 1 -> target x0
+        conv_last = 2 * (args.poses - 2) + 0 if not args.g2o else 0
+
+    def step():
+        dg.sweep_pose2pose2(opts, out=prop)
+        dg.sample_priors(opts, "prior2", out=prior_out)
+        if world > 1:
+            sep_send[0].copy_(prop[conv_first]); sep_send[1].copy_(prop[conv_last])
+            dist.all_gather_into_tensor(sep_all, sep_send)
+            dg.bel[R.Pose2][g_prev].copy_(sep_all[(rank - 1) % world, 1])
+            dg.bel[R.Pose2][g_next].copy_(sep_all[(rank + 1) % world, 0])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # per-launch duration of the dominant kernel: HIP events on the launch stream (torch's current stream,
+    # which DeviceGraph binds the rome_ctx to), collected inside the timed region
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        dg.sweep_pose2pose2(opts, out=prop)
+        ev[k][1].record()
+        dg.sample_priors(opts, "prior2", out=prior_out)
+        if world > 1:
+            sep_send[0].copy_(prop[conv_first]); sep_send[1].copy_(prop[conv_last])
+            dist.all_gather_into_tensor(sep_all, sep_send)
+            dg.bel[R.Pose2][g_prev].copy_(sep_all[(rank - 1) % world, 1])
+            dg.bel[R.Pose2][g_next].copy_(sep_all[(rank + 1) % world, 0])
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    total_conv = n_conv_step * world * args.steps
+    value = total_conv / elapsed
+    alg_bytes = tb["C"] * N * BYTES_PER_PARTICLE_P2P2
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "factor convolutions/sec (N=100) on Manhattan-3500; solveTree! wall-clock",
+        "value": value, "unit": "convolutions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload, "poses_per_gpu": len(pk.labels[R.Pose2]), "pose2pose2_factors_per_gpu": tb["F"],
+                   "convolutions_per_step_per_gpu": n_conv_step, "particles": N, "solver": args.solver,
+                   "inflate_cycles": int(opts.inflate_cycles), "inflation": float(opts.inflation), "noise": "in-kernel philox",
+                   "parallelism": "1 graph segment per GPU, separator all_gather" if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": "rome::k_conv<P2P2,%s,PPL=2>" % args.solver,
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms, "traffic": None},
+    }
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            with open(tfile) as f:
+                tj = json.load(f)
+            if tj.get("solver") == args.solver and tj.get("n_conv") == tb["C"]:
+                out["roofline"]["traffic"] = tj.get("bytes_per_launch")
+                out["roofline"]["traffic_source"] = tj.get("source")
+        except Exception:
+            pass
+
+    if rank == 0 and world == 1 and not args.no_modes:
+        modes = {}
+        for name, sv in (("closed_form", R.SOLVER_CLOSED_FORM), ("newton", R.SOLVER_NEWTON), ("nelder_mead", R.SOLVER_NELDER_MEAD)):
+            o2 = R.make_opts(N=N, solver=sv, seed=0x524F4D45)
+            reps = 5 if sv == R.SOLVER_NELDER_MEAD else 50
+            dg.sweep_pose2pose2(o2, out=prop); torch.cuda.synchronize()
+            a = time.perf_counter()
+            for _ in range(reps):
+                dg.sweep_pose2pose2(o2, out=prop)
+            torch.cuda.synchronize()
+            modes[name] = tb["C"] * reps / (time.perf_counter() - a)
+        out["gpu_convolutions_per_s_by_solver"] = modes
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(R, pk, fg, N, args.cpu_seconds)
+        if "gpu_convolutions_per_s_by_solver" in out:
+            out["cpu_baseline"]["gpu_nelder_mead_over_cpu_nelder_mead"] = \
+                out["gpu_convolutions_per_s_by_solver"]["nelder_mead"] / out["cpu_baseline"]["value"]
+        out["cpu_baseline"]["gpu_value_over_cpu"] = value / out["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(R, pk, fg, N, budget_s):
+    """The oracle (C port of the reference algorithm: Optim-default Nelder-Mead per particle, 3 inflate
+    cycles) on the host cores of this box, OpenMP over convolutions, on a bounded prefix of the SAME
+    convolution table.  Reported baseline only -- never part of the product path."""
+    import oracle as ro
+    factor, dr, fixed, target = R.PackedGraph.conv_table(pk.p2p2)
+    L = R.cholesky_lower(pk.p2p2["cov"])
+    bel = pk.beliefs(fg, R.Pose2)
+    o = ro.make_opts(N=N, solver=ro.SOLVER_NELDER_MEAD, seed=0x524F4D45)
+    cores = ro.num_threads()
+
+    def run(n):
+        t = time.perf_counter()
+        ro.conv_pose2pose2(o, pk.p2p2["mu"], L, bel, fixed[:n], target[:n], dr[:n], factor=factor[:n])
+        return time.perf_counter() - t
+
+    n0 = min(len(factor), 64 * cores)
+    t0 = run(n0)
+    n = int(min(len(factor), max(n0, n0 * budget_s / max(t0, 1e-3))))
+    t = run(n)
+    return {"value": n / t, "unit": "convolutions/s", "cores": cores, "kind": "port",
+            "algorithm": "Optim.jl-default Nelder-Mead per particle (reference algorithm), inflate_cycles=3",
+            "sample": "first %d of %d (factor,direction) convolutions of the same graph, N=%d, %.1f s" % (n, len(factor), N, t)}
+
+
+if __name__ == "__main__":
+    main()

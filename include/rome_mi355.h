@@ -1,0 +1,181 @@
+/* rome_mi355.h -- C ABI of librome_mi355.so: MI355X (gfx950) factor convolutions for RoME.jl.
+ *
+ * Drop-in boundary for ONE hot path of RoME.jl + IncrementalInference.jl: the per-particle
+ * residual + numerical root-find inside `approxConvBelief` (IIF `computeAcrossHypothesis!` ->
+ * `_solveCCWNumeric!` -> `_solveLambdaNumeric`) for the factors
+ *     Pose2Pose2                 src/factors/Pose2D.jl:30-67
+ *     PriorPose2                 src/factors/PriorPose2.jl:13-47
+ *     Pose2Point2BearingRange    src/factors/BearingRange2D.jl:10-64
+ *     Pose3Pose3                 src/factors/Pose3Pose3.jl:9-29      (+ PriorPose3, src/factors/Pose3D.jl:15-19)
+ * (paths relative to the RoME.jl v0.24.6 checkout).  Each entry point names the reference
+ * interface it replaces.  Plain pointers and sizes only; no exceptions cross the ABI; the library
+ * never retains caller pointers past a call.  There is NO CPU fallback: without a HIP device
+ * rome_ctx_create fails with ROME_ERR_NO_DEVICE.
+ *
+ * Conventions
+ *   - FP64 everywhere (the reference computes in Float64).
+ *   - Pose2 coordinates (x, y, θ)  <->  point ((x,y), R(θ))      (src/variables/VariableTypes.jl:35)
+ *     Point2 coordinates (x, y)                                  (src/variables/VariableTypes.jl:13)
+ *     Pose3 coordinates (x, y, z, ωx, ωy, ωz) <-> (t, Exp(ω))    (src/variables/VariableTypes.jl:47,
+ *                                                                 coordinate order src/services/g2oParser.jl:166)
+ *   - a "block" is one belief of N particles; ROME_LAYOUT_SOA: [block][dim][N] (device-native),
+ *     ROME_LAYOUT_AOS: [block][N][dim] (what a Julia Vector of coordinate SVectors looks like).
+ *   - dir = 0 solves for the factor's 2nd variable given the 1st (x_i -> x_j / pose -> landmark),
+ *     dir = 1 solves for the 1st given the 2nd.
+ *   - return value: ROME_OK (0) or a negative ROME_ERR_*; per-particle non-convergence is reported
+ *     through the optional `status` array (0 = converged, 1 = iteration cap reached).
+ *   - a rome_ctx is not thread-safe; distinct contexts are (one HIP stream each).
+ */
+#ifndef ROME_MI355_H
+#define ROME_MI355_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ROME_MI355_VERSION 100 /* 0.1.0 */
+
+enum {
+  ROME_OK = 0,
+  ROME_ERR_INVALID_ARG = -1,
+  ROME_ERR_NO_DEVICE = -2,
+  ROME_ERR_HIP = -3,         /* see rome_last_hip_error() */
+  ROME_ERR_NOT_POSDEF = -4,  /* a covariance has no Cholesky factor */
+  ROME_ERR_UNSUPPORTED_N = -5, /* n_particles > ROME_MAX_PARTICLES */
+  ROME_ERR_ALLOC = -6
+};
+
+#define ROME_MAX_PARTICLES 256
+
+/* Solvers for the per-particle root-find (replaces Optim.optimize(cost, X0c, NelderMead()) in IIF
+ * `_solveLambdaNumeric`, called for every particle of every convolution):
+ *   CLOSED_FORM  analytic root; start point / inflation only matter for the
+ *                under-determined bearing-range -> pose direction
+ *   NEWTON       iterate on the actual residual functor with analytic group Jacobians until
+ *                max|r| <= tol  (default)
+ *   NELDER_MEAD  Optim.jl's NelderMead() with its defaults on Σ r², i.e. the reference's algorithm  */
+enum { ROME_SOLVER_CLOSED_FORM = 0, ROME_SOLVER_NEWTON = 1, ROME_SOLVER_NELDER_MEAD = 2 };
+enum { ROME_LAYOUT_SOA = 0, ROME_LAYOUT_AOS = 1 };
+
+/* Mirrors the IIF SolverParams fields that reach this path (N, inflateCycles, inflation). */
+typedef struct rome_opts {
+  int32_t n_particles;    /* N, IIF default 100 (src/canonical/GenerateHexagonal.jl:30)               */
+  int32_t solver;         /* ROME_SOLVER_*                                                             */
+  int32_t max_iters;      /* NEWTON default 20 ; NELDER_MEAD default 1000 (Optim iterations)           */
+  int32_t inflate_cycles; /* IIF inflateCycles, default 3                                              */
+  double  tol;            /* NEWTON: max|r| <= tol (1e-12) ; NELDER_MEAD: Optim g_tol (1e-8)           */
+  double  inflation;      /* IIF inflation (kappa) for the entropy added before each cycle, default 5.0 */
+  uint64_t seed;          /* Philox4x32-10 key                                                         */
+  uint64_t stream_offset; /* Philox stream of convolution c = stream_offset + c  (global conv id when sharded) */
+  int32_t layout;         /* host-pointer entry points only: ROME_LAYOUT_*                             */
+  int32_t reserved;
+} rome_opts;
+
+typedef struct rome_ctx rome_ctx; /* opaque: device id, HIP stream, staging buffers */
+
+int  rome_version(void);
+const char* rome_strerror(int code);
+int  rome_last_hip_error(const rome_ctx* ctx); /* raw hipError_t of the last failing HIP call */
+const char* rome_last_hip_error_string(const rome_ctx* ctx);
+
+void rome_opts_default(rome_opts* o, int32_t solver);
+int  rome_ctx_create(rome_ctx** out, int device);
+void rome_ctx_destroy(rome_ctx* ctx);
+int  rome_ctx_set_stream(rome_ctx* ctx, void* hip_stream); /* launch on a caller-owned hipStream_t (NULL -> own stream) */
+int  rome_ctx_synchronize(rome_ctx* ctx);
+int  rome_device_count(void);
+
+/* Σ (d x d row-major, n of them) -> row-packed lower Cholesky factors (n x d(d+1)/2), host side.
+ * Replaces the PDMat factorisation MvNormal(μ, Σ) performs at factor construction
+ * (src/services/g2oParser.jl:103-121).                                                           */
+int rome_cholesky_lower(int32_t d, int32_t n, const double* cov, double* L);
+
+/* ---------------------------------------------------------------------------------------------
+ * Residual-only entry points (host pointers, n rows of coordinates).  Replace one call of the
+ * CalcFactor functor each:
+ *   rome_residual_pose2pose2      (cf::CalcFactor{<:Pose2Pose2})(X, p, q)            Pose2D.jl:51-67
+ *   rome_residual_priorpose2      (cf::CalcFactor{<:PriorPose2})(m, p)               PriorPose2.jl:37-47
+ *   rome_residual_pose2point2br   (cf::CalcFactor{<:Pose2Point2BearingRange})(z,p,l) BearingRange2D.jl:48-64
+ *   rome_residual_pose3pose3      (cf::CalcFactor{<:Pose3Pose3})(X, p, q)            Pose3Pose3.jl:17-29
+ *   rome_residual_priorpose3      (cf::CalcFactor{<:PriorPose3})(m, p)               Pose3D.jl:15-19
+ * z: measurement tangent coordinates; p, q, m: pose coordinates; l: landmark.
+ * The *_pt variants take the reference's native point layouts (Pose2: [tx,ty,R11,R21,R12,R22];
+ * Pose3: [t(3), R column-major(9)]) so a Julia caller can pass pointer(vals) without conversion. */
+int rome_residual_pose2pose2(rome_ctx*, int32_t n, const double* z /*n*3*/, const double* p /*n*3*/, const double* q /*n*3*/, double* r /*n*3*/);
+int rome_residual_priorpose2(rome_ctx*, int32_t n, const double* m /*n*3*/, const double* p /*n*3*/, double* r /*n*3*/);
+int rome_residual_pose2point2br(rome_ctx*, int32_t n, const double* z /*n*2 (bearing,range)*/, const double* p /*n*3*/, const double* l /*n*2*/, double* r /*n*2*/);
+int rome_residual_pose2point2br_pt(rome_ctx*, int32_t n, const double* z /*n*2*/, const double* p_pt /*n*6*/, const double* l /*n*2*/, double* r /*n*2*/);
+int rome_residual_pose3pose3(rome_ctx*, int32_t n, const double* z /*n*6*/, const double* p /*n*6*/, const double* q /*n*6*/, double* r /*n*6*/);
+int rome_residual_pose3pose3_pt(rome_ctx*, int32_t n, const double* z /*n*6*/, const double* p_pt /*n*12*/, const double* q_pt /*n*12*/, double* r /*n*6*/);
+int rome_residual_priorpose3(rome_ctx*, int32_t n, const double* m /*n*6*/, const double* p /*n*6*/, double* r /*n*6*/);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched factor convolutions, HOST pointers: C independent convolutions x N particles.
+ * Each replaces C calls of IIF `approxConvBelief(dfg, factor, target)` up to (not including) the
+ * `manikde!` wrap: N x getSample, then inflate_cycles x { addEntropyOnManifold!, N x _solveCCWNumeric! }.
+ *   dir    [C] or NULL (all 0)
+ *   mu     [C][dz]   measurement mean             cov [C][dz*dz] row-major covariance Σ
+ *   fixed  C blocks of the fixed variable's particles (layout per opts->layout)
+ *   noise  C blocks [.][dz] of standard-normal ξ (z = μ + chol(Σ) ξ), or NULL -> in-kernel Philox
+ *   target_inout  C blocks: start points u0 (current belief of the target) in, solutions out
+ *   status [C][N] or NULL                                                                        */
+int rome_conv_pose2pose2(rome_ctx*, const rome_opts*, int32_t C, const int32_t* dir,
+                         const double* mu /*C*3*/, const double* cov /*C*9*/,
+                         const double* fixed /*C*N*3*/, const double* noise /*C*N*3 or NULL*/,
+                         double* target_inout /*C*N*3*/, int32_t* status);
+/* dir (scalar): 0 = fixed poses (3) -> target landmarks (2); 1 = fixed landmarks (2) -> target poses (3).
+ * mu = (mean bearing, mean range), sigma = (σ_b, σ_ρ) of the two Normal() fields
+ * (src/factors/BearingRange2D.jl:10-13); getSample :17-27.                                       */
+int rome_conv_pose2point2br(rome_ctx*, const rome_opts*, int32_t C, int32_t dir,
+                            const double* mu /*C*2*/, const double* sigma /*C*2*/,
+                            const double* fixed, const double* noise /*C*N*2 or NULL*/,
+                            double* target_inout, int32_t* status);
+int rome_conv_pose3pose3(rome_ctx*, const rome_opts*, int32_t C, const int32_t* dir,
+                         const double* mu /*C*6*/, const double* cov /*C*36*/,
+                         const double* fixed /*C*N*6*/, const double* noise /*C*N*6 or NULL*/,
+                         double* target_inout /*C*N*6*/, int32_t* status);
+/* Prior "convolution" = N samples of the prior as points: IIF samplePoint on PriorPose2.Z / PriorPose3.Z
+ * (src/factors/PriorPose2.jl:13-17, src/factors/Pose3D.jl:8-12).                                 */
+int rome_sample_priorpose2(rome_ctx*, const rome_opts*, int32_t C, const double* mu /*C*3*/, const double* cov /*C*9*/,
+                           const double* noise /*C*N*3 or NULL*/, double* out /*C*N*3*/);
+int rome_sample_priorpose3(rome_ctx*, const rome_opts*, int32_t C, const double* mu /*C*6*/, const double* cov /*C*36*/,
+                           const double* noise /*C*N*6 or NULL*/, double* out /*C*N*6*/);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph-indexed DEVICE-pointer variant: beliefs stay resident in HBM (SoA blocks [var][dim][N]),
+ * one launch sweeps a whole table of (factor, direction) convolutions.  This is what a clique /
+ * whole-graph sweep of `solveTree!` (examples/ManhattanDatasetBatch.jl:43) issues.
+ * All pointers below are device pointers valid on the context's device.                          */
+typedef struct rome_conv_dev {
+  int32_t n_conv;            /* C */
+  int32_t dir_all;           /* used when dir == NULL (bearing-range: always)                     */
+  const int32_t* factor;     /* [C] row of mu/L, NULL -> c                                        */
+  const int32_t* dir;        /* [C], NULL -> dir_all                                              */
+  const int32_t* fixed_var;  /* [C] block index into bel_fixed, NULL -> c                         */
+  const int32_t* target_var; /* [C] block index into bel_target, NULL -> c                        */
+  const double* mu;          /* [F][dz]                                                           */
+  const double* L;           /* [F][dz(dz+1)/2] packed lower Cholesky (bearing-range: [F][2] sigmas) */
+  const double* bel_fixed;   /* blocks of the fixed variable type                                 */
+  const double* bel_target;  /* blocks of the target variable type (start points)                 */
+  const double* noise;       /* [C][dz][N] or NULL                                                */
+  double* out;               /* [C][dt][N] proposals                                              */
+  int32_t* status;           /* [C][N] or NULL                                                    */
+} rome_conv_dev;
+
+int rome_conv_pose2pose2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);
+int rome_conv_pose2point2br_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);
+int rome_conv_pose3pose3_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);
+int rome_sample_priorpose2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*); /* uses factor, mu, L, noise, out */
+int rome_sample_priorpose3_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);
+
+/* thin device-memory helpers for callers without their own HIP runtime binding (e.g. the Julia shim) */
+int rome_dev_alloc(rome_ctx*, uint64_t bytes, void** out);
+int rome_dev_free(rome_ctx*, void* p);
+int rome_dev_upload(rome_ctx*, void* dst_dev, const void* src_host, uint64_t bytes);
+int rome_dev_download(rome_ctx*, void* dst_host, const void* src_dev, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROME_MI355_H */

@@ -1,0 +1,878 @@
+/* rome_oracle.c -- TEST INFRASTRUCTURE ONLY (see rome_oracle.h).
+ *
+ * Plain-C FP64 restatement of RoME.jl's factor residuals and of the
+ * per-particle root-find loop IncrementalInference.jl runs around them inside
+ * approxConvBelief.  `path:line` = /root/reference/path:line.
+ *
+ * PARITY PIN STATUS
+ *   residuals ............ pinned by test/testParametricSimulated.jl:33-46,105-144,
+ *                          test/testBearingRange2D.jl:44-253,
+ *                          test/threeDimLinearProductTest.jl:150-167,
+ *                          test/testPartialPose3.jl:390-436  (tests/golden/residual_kats.json)
+ *   optimiser/RNG/entropy  PARITY UNPINNED by the reference (no seeds, no iterate checks);
+ *                          restated from IIF 0.35 / Optim 1.x / Manifolds 0.10.1 (not vendored).
+ */
+#include "rome_oracle.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define RO_PI 3.141592653589793238462643383279502884
+#define RO_MAXN 6
+
+/* ======================================================================== */
+/* Philox4x32-10 (Salmon et al. 2011, Random123) -- integer, bit-exact        */
+/* ======================================================================== */
+void ro_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+enum { RO_DOMAIN_NOISE = 1, RO_DOMAIN_ENTROPY = 2 };
+
+static inline double u53(uint32_t hi, uint32_t lo) { /* (0,1] */
+  uint64_t x = ((uint64_t)hi << 32) | lo;
+  return (double)((x >> 11) + 1) * (1.0 / 9007199254740992.0);
+}
+
+/* d standard normals for (seed, stream, particle): Box-Muller on Philox words.
+ * Replaces `rand(MvNormal)` of ⚠IIF sampleTangent / RoME getSample
+ * (src/factors/BearingRange2D.jl:17-27); the reference's stream is unseeded -> unpinned. */
+void ro_rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, int d, double* out) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  int nblk = (d + 1) / 2;
+  for (int b = 0; b < nblk; ++b) {
+    uint32_t ctr[4] = {particle, (uint32_t)stream, (uint32_t)(stream >> 32),
+                       ((uint32_t)RO_DOMAIN_NOISE << 16) | (uint32_t)b};
+    uint32_t w[4];
+    ro_philox4x32_10(ctr, key, w);
+    double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
+    double rr = sqrt(-2.0 * log(u1));
+    double a = 2.0 * RO_PI * u2;
+    out[2 * b] = rr * cos(a);
+    if (2 * b + 1 < d) out[2 * b + 1] = rr * sin(a);
+  }
+}
+
+/* d uniforms in (0,1) for the entropy inflation of cycle `cycle` (32-bit resolution). */
+void ro_rng_entropy(uint64_t seed, uint64_t stream, uint32_t particle, int cycle, int d, double* out) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  int nblk = (d + 3) / 4;
+  for (int b = 0; b < nblk; ++b) {
+    uint32_t ctr[4] = {particle, (uint32_t)stream, (uint32_t)(stream >> 32),
+                       ((uint32_t)RO_DOMAIN_ENTROPY << 16) | ((uint32_t)cycle << 8) | (uint32_t)b};
+    uint32_t w[4];
+    ro_philox4x32_10(ctr, key, w);
+    for (int k = 0; k < 4 && 4 * b + k < d; ++k)
+      out[4 * b + k] = ((double)w[k] + 0.5) * (1.0 / 4294967296.0);
+  }
+}
+
+/* ======================================================================== */
+/* Manifold primitives                                    */
+/* ======================================================================== */
+
+/* ⚠Manifolds sym_rem(x) = (x ≈ π ? -π : rem(x, 2π, RoundNearest)); used at
+ * src/factors/BearingRange2D.jl:60. isapprox default rtol = sqrt(eps). */
+double ro_sym_rem(double x) {
+  const double rtol = 1.4901161193847656e-8;
+  double m = fabs(x) > RO_PI ? fabs(x) : RO_PI;
+  if (fabs(x - RO_PI) <= rtol * m) return -RO_PI;
+  return remainder(x, 2.0 * RO_PI);
+}
+
+/* getPoint(Pose2, c) = exp_ϵ(hat(c)) : ((x,y), R(θ)); layout src/variables/VariableTypes.jl:35 */
+void ro_pose2_point_from_coords(const double c[3], double pt[6]) {
+  double s = sin(c[2]), co = cos(c[2]);
+  pt[0] = c[0]; pt[1] = c[1];
+  pt[2] = co; pt[3] = s; pt[4] = -s; pt[5] = co; /* col-major [R11 R21 R12 R22] */
+}
+/* vee(log(ϵ, p)) : (x, y, atan2(R21, R11)) */
+void ro_pose2_coords_from_point(const double pt[6], double c[3]) {
+  c[0] = pt[0]; c[1] = pt[1]; c[2] = atan2(pt[3], pt[2]);
+}
+
+static inline void mat3_mul(const double* A, const double* B, double* C) { /* col-major */
+  for (int j = 0; j < 3; ++j)
+    for (int i = 0; i < 3; ++i)
+      C[i + 3 * j] = A[i] * B[3 * j] + A[i + 3] * B[1 + 3 * j] + A[i + 6] * B[2 + 3 * j];
+}
+static inline void mat3_tmul(const double* A, const double* B, double* C) { /* C = Aᵀ B */
+  for (int j = 0; j < 3; ++j)
+    for (int i = 0; i < 3; ++i)
+      C[i + 3 * j] = A[3 * i] * B[3 * j] + A[3 * i + 1] * B[1 + 3 * j] + A[3 * i + 2] * B[2 + 3 * j];
+}
+static inline void mat3_vec(const double* A, const double* v, double* o) {
+  for (int i = 0; i < 3; ++i) o[i] = A[i] * v[0] + A[i + 3] * v[1] + A[i + 6] * v[2];
+}
+
+/* ⚠Manifolds exp!(::Rotations{3}, q, p=I, X): θ = ‖ω‖; a = sinθ/θ; b = (1-cosθ)/θ²; I + aX + bX². */
+void ro_so3_exp(const double w[3], double R[9]) {
+  double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double th = sqrt(th2);
+  double a, b;
+  if (th == 0.0) { a = 1.0; b = 0.0; }
+  else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+  double x = w[0], y = w[1], z = w[2];
+  /* X = [0 -z y; z 0 -x; -y x 0];  X² = w wᵀ - θ² I */
+  R[0] = 1.0 + b * (x * x - th2); R[3] = -a * z + b * x * y;      R[6] = a * y + b * x * z;
+  R[1] = a * z + b * x * y;       R[4] = 1.0 + b * (y * y - th2); R[7] = -a * x + b * y * z;
+  R[2] = -a * y + b * x * z;      R[5] = a * x + b * y * z;       R[8] = 1.0 + b * (z * z - th2);
+}
+
+/* ⚠Manifolds log!(::Rotations{3}, X, p=I, U): cosθ=(tr U-1)/2; X = U/usinc_from_cos(cosθ) projected to skew;
+ * cosθ ≈ -1 branch: axis of the +1 eigenvector times π (axis sign unpinned: chosen here from the
+ * largest diagonal column of (U+I)/2 with the sign of the residual skew part when it is non-zero). */
+void ro_so3_log(const double U[9], double w[3]) {
+  double c = 0.5 * (U[0] + U[4] + U[8] - 1.0);
+  double sx = U[5] - U[7], sy = U[6] - U[2], sz = U[1] - U[3]; /* (U - Uᵀ) vee: (U32-U23, U13-U31, U21-U12) */
+  if (fabs(c + 1.0) <= 1.4901161193847656e-8) {
+    double d0 = 0.5 * (U[0] + 1.0), d1 = 0.5 * (U[4] + 1.0), d2 = 0.5 * (U[8] + 1.0);
+    double ax[3];
+    if (d0 >= d1 && d0 >= d2) { ax[0] = d0; ax[1] = 0.25 * (U[1] + U[3]); ax[2] = 0.25 * (U[2] + U[6]); }
+    else if (d1 >= d2)        { ax[0] = 0.25 * (U[1] + U[3]); ax[1] = d1; ax[2] = 0.25 * (U[5] + U[7]); }
+    else                      { ax[0] = 0.25 * (U[2] + U[6]); ax[1] = 0.25 * (U[5] + U[7]); ax[2] = d2; }
+    double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    double sgn = (ax[0] * sx + ax[1] * sy + ax[2] * sz) < 0.0 ? -1.0 : 1.0;
+    double k = sgn * RO_PI / n;
+    w[0] = k * ax[0]; w[1] = k * ax[1]; w[2] = k * ax[2];
+    return;
+  }
+  double usinc; /* sinθ/θ from cosθ */
+  if (c >= 1.0) usinc = 1.0;
+  else if (c <= -1.0) usinc = 0.0;
+  else usinc = sqrt(1.0 - c * c) / acos(c);
+  double k = 0.5 / usinc;
+  w[0] = k * sx; w[1] = k * sy; w[2] = k * sz;
+}
+
+void ro_pose3_point_from_coords(const double c[6], double pt[12]) {
+  pt[0] = c[0]; pt[1] = c[1]; pt[2] = c[2];
+  ro_so3_exp(c + 3, pt + 3);
+}
+void ro_pose3_coords_from_point(const double pt[12], double c[6]) {
+  c[0] = pt[0]; c[1] = pt[1]; c[2] = pt[2];
+  ro_so3_log(pt + 3, c + 3);
+}
+
+/* Rotations.jl RotXYZ(r,p,y) = Rx(r) Ry(p) Rz(y)  (test/testPartialPose3.jl:420) */
+void ro_rotxyz(double r, double p, double y, double R[9]) {
+  double cr = cos(r), sr = sin(r), cp = cos(p), sp = sin(p), cy = cos(y), sy = sin(y);
+  double Rx[9] = {1, 0, 0, 0, cr, sr, 0, -sr, cr};
+  double Ry[9] = {cp, 0, -sp, 0, 1, 0, sp, 0, cp};
+  double Rz[9] = {cy, sy, 0, -sy, cy, 0, 0, 0, 1};
+  double T[9];
+  mat3_mul(Rx, Ry, T);
+  mat3_mul(T, Rz, R);
+}
+
+/* ======================================================================== */
+/* Residual functors on native points                                         */
+/* ======================================================================== */
+
+/* src/factors/Pose2D.jl:51-67 with _compose/_vee of src/factors/PriorPose2.jl:19-25.
+ * X tangent container [Xt(2), skew(4)] -> θ = X.R[2,1];  p,q points [t(2), R col-major(4)]. */
+void ro_residual_pose2pose2_pt(const double X[6], const double p[6], const double q[6], double r[3]) {
+  /* ϵX = exp(M, ϵ0, X) :60 */
+  double th = X[3];
+  double s = sin(th), c = cos(th);
+  double eXt0 = X[0], eXt1 = X[1];
+  /* q̂ = _compose(M, p, ϵX) :62 -> (p.t + p.R ϵX.t , p.R ϵX.R) */
+  double qh_t0 = p[0] + p[2] * eXt0 + p[4] * eXt1;
+  double qh_t1 = p[1] + p[3] * eXt0 + p[5] * eXt1;
+  double qh_R11 = p[2] * c + p[4] * s;
+  double qh_R21 = p[3] * c + p[5] * s;
+  /* X̂ = log(M, q, q̂) :63 -> (q̂.t - q.t , log_SO2(q.R, q̂.R)) ; U = q.Rᵀ q̂.R */
+  double U11 = q[2] * qh_R11 + q[3] * qh_R21;
+  double U21 = q[4] * qh_R11 + q[5] * qh_R21;
+  /* _vee :65 */
+  r[0] = qh_t0 - q[0];
+  r[1] = qh_t1 - q[1];
+  r[2] = atan2(U21, U11);
+}
+
+/* src/factors/PriorPose2.jl:37-47 : _vee(log(M, p, m)) */
+void ro_residual_priorpose2_pt(const double m[6], const double p[6], double r[3]) {
+  double U11 = p[2] * m[2] + p[3] * m[3];
+  double U21 = p[4] * m[2] + p[5] * m[3];
+  r[0] = m[0] - p[0];
+  r[1] = m[1] - p[1];
+  r[2] = atan2(U21, U11);
+}
+
+/* src/factors/BearingRange2D.jl:48-64. meas = [skew(4) col-major, ρ] -> b = measX.x[1][2] */
+void ro_residual_pose2point2br_pt(const double meas[5], const double p[6], const double l[2], double r[2]) {
+  double dx = l[0] - p[0], dy = l[1] - p[1];
+  /* pl = transpose(p.R) * (l - p.t) :57 */
+  double plx = p[2] * dx + p[3] * dy;
+  double ply = p[4] * dx + p[5] * dy;
+  r[0] = ro_sym_rem(meas[1] - atan2(ply, plx)); /* :60 */
+  r[1] = meas[4] - sqrt(plx * plx + ply * ply); /* :61 */
+}
+
+/* src/factors/Pose3Pose3.jl:17-29 : q̂ = compose(p, exp_ϵ(X)); coords(log(q, q̂)) */
+void ro_residual_pose3pose3_pt(const double X[12], const double p[12], const double q[12], double r[6]) {
+  double w[3] = {X[3 + 5], X[3 + 6], X[3 + 1]}; /* vee of the skew part: (X32, X13, X21) */
+  double E[9], Rh[9], U[9], t[3];
+  ro_so3_exp(w, E);
+  mat3_mul(p + 3, E, Rh);      /* q̂.R = p.R ϵX.R */
+  mat3_vec(p + 3, X, t);       /* p.R ϵX.t        */
+  mat3_tmul(q + 3, Rh, U);     /* q.Rᵀ q̂.R        */
+  r[0] = p[0] + t[0] - q[0];
+  r[1] = p[1] + t[1] - q[1];
+  r[2] = p[2] + t[2] - q[2];
+  ro_so3_log(U, r + 3);
+}
+
+/* src/factors/Pose3D.jl:15-19 : vee(M, p, log(M, p, m)) */
+void ro_residual_priorpose3_pt(const double m[12], const double p[12], double r[6]) {
+  double U[9];
+  mat3_tmul(p + 3, m + 3, U);
+  r[0] = m[0] - p[0]; r[1] = m[1] - p[1]; r[2] = m[2] - p[2];
+  ro_so3_log(U, r + 3);
+}
+
+/* ---- batched on coordinates ---- */
+static inline void se2_hat(const double z[3], double X[6]) { /* ⚠Manifolds hat: ((x,y),[0 -θ; θ 0]) */
+  X[0] = z[0]; X[1] = z[1]; X[2] = 0.0; X[3] = z[2]; X[4] = -z[2]; X[5] = 0.0;
+}
+static inline void se3_hat(const double z[6], double X[12]) {
+  X[0] = z[0]; X[1] = z[1]; X[2] = z[2];
+  double x = z[3], y = z[4], w = z[5];
+  X[3] = 0;  X[4] = w;  X[5] = -y;
+  X[6] = -w; X[7] = 0;  X[8] = x;
+  X[9] = y;  X[10] = -x; X[11] = 0;
+}
+void ro_residual_pose2pose2(int n, const double* z, const double* p, const double* q, double* r) {
+  for (int i = 0; i < n; ++i) {
+    double X[6], P[6], Q[6];
+    se2_hat(z + 3 * i, X);
+    ro_pose2_point_from_coords(p + 3 * i, P);
+    ro_pose2_point_from_coords(q + 3 * i, Q);
+    ro_residual_pose2pose2_pt(X, P, Q, r + 3 * i);
+  }
+}
+void ro_residual_priorpose2(int n, const double* m, const double* p, double* r) {
+  for (int i = 0; i < n; ++i) {
+    double M[6], P[6];
+    ro_pose2_point_from_coords(m + 3 * i, M);
+    ro_pose2_point_from_coords(p + 3 * i, P);
+    ro_residual_priorpose2_pt(M, P, r + 3 * i);
+  }
+}
+void ro_residual_pose2point2br(int n, const double* z, const double* p, const double* l, double* r) {
+  for (int i = 0; i < n; ++i) {
+    double meas[5] = {0.0, z[2 * i], -z[2 * i], 0.0, z[2 * i + 1]};
+    double P[6];
+    ro_pose2_point_from_coords(p + 3 * i, P);
+    ro_residual_pose2point2br_pt(meas, P, l + 2 * i, r + 2 * i);
+  }
+}
+void ro_residual_pose3pose3(int n, const double* z, const double* p, const double* q, double* r) {
+  for (int i = 0; i < n; ++i) {
+    double X[12], P[12], Q[12];
+    se3_hat(z + 6 * i, X);
+    ro_pose3_point_from_coords(p + 6 * i, P);
+    ro_pose3_point_from_coords(q + 6 * i, Q);
+    ro_residual_pose3pose3_pt(X, P, Q, r + 6 * i);
+  }
+}
+void ro_residual_priorpose3(int n, const double* m, const double* p, double* r) {
+  for (int i = 0; i < n; ++i) {
+    double M[12], P[12];
+    ro_pose3_point_from_coords(m + 6 * i, M);
+    ro_pose3_point_from_coords(p + 6 * i, P);
+    ro_residual_priorpose3_pt(M, P, r + 6 * i);
+  }
+}
+
+/* ======================================================================== */
+/* helpers                                                                    */
+/* ======================================================================== */
+
+/* Σ = L Lᵀ, lower, row-packed (what Distributions' MvNormal unwhitens with). */
+int ro_cholesky_lower(int d, const double* cov, double* Lp) {
+  double L[RO_MAXN * RO_MAXN];
+  memset(L, 0, sizeof(L));
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = cov[i * d + j];
+      for (int k = 0; k < j; ++k) s -= L[i * d + k] * L[j * d + k];
+      if (i == j) { if (s <= 0.0) return -1; L[i * d + i] = sqrt(s); }
+      else L[i * d + j] = s / L[j * d + j];
+    }
+  int k = 0;
+  for (int i = 0; i < d; ++i) for (int j = 0; j <= i; ++j) Lp[k++] = L[i * d + j];
+  return 0;
+}
+
+/* ⚠IIF calcStdBasicSpread: per-coordinate std of the tangent coordinates at the manifold mean
+ * (n-1 normalisation).  Mean: arithmetic for translations, extrinsic circular mean for θ (unpinned). */
+void ro_belief_spread_se2(int N, const double* x, const double* y, const double* th, double* mean3, double* std3) {
+  double sx = 0, sy = 0, ss = 0, sc = 0;
+  for (int i = 0; i < N; ++i) { sx += x[i]; sy += y[i]; ss += sin(th[i]); sc += cos(th[i]); }
+  double mx = sx / N, my = sy / N, mt = atan2(ss, sc);
+  double vx = 0, vy = 0, vt = 0;
+  double sm = sin(mt), cm = cos(mt);
+  for (int i = 0; i < N; ++i) {
+    double dx = x[i] - mx, dy = y[i] - my;
+    double s = sin(th[i]), c = cos(th[i]);
+    double dt = atan2(cm * s - sm * c, cm * c + sm * s); /* log_SO2(R(mt), R(th)) */
+    vx += dx * dx; vy += dy * dy; vt += dt * dt;
+  }
+  double den = N > 1 ? (double)(N - 1) : 1.0;
+  mean3[0] = mx; mean3[1] = my; mean3[2] = mt;
+  std3[0] = sqrt(vx / den); std3[1] = sqrt(vy / den); std3[2] = sqrt(vt / den);
+}
+void ro_belief_spread_r2(int N, const double* x, const double* y, double* mean2, double* std2) {
+  double sx = 0, sy = 0;
+  for (int i = 0; i < N; ++i) { sx += x[i]; sy += y[i]; }
+  double mx = sx / N, my = sy / N, vx = 0, vy = 0;
+  for (int i = 0; i < N; ++i) { double dx = x[i] - mx, dy = y[i] - my; vx += dx * dx; vy += dy * dy; }
+  double den = N > 1 ? (double)(N - 1) : 1.0;
+  mean2[0] = mx; mean2[1] = my; std2[0] = sqrt(vx / den); std2[1] = sqrt(vy / den);
+}
+/* SE(3): rotation mean = particle 0 refined by 2 Karcher steps μ ← μ Exp(mean Log(μᵀ R_i)) (unpinned). */
+void ro_belief_spread_se3(int N, const double* blk, double* mean6, double* std6) {
+  double st[3] = {0, 0, 0};
+  for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) st[k] += blk[k * N + i];
+  for (int k = 0; k < 3; ++k) mean6[k] = st[k] / N;
+  double Rm[9];
+  { double w0[3] = {blk[3 * N], blk[4 * N], blk[5 * N]}; ro_so3_exp(w0, Rm); }
+  for (int it = 0; it < 2; ++it) {
+    double acc[3] = {0, 0, 0};
+    for (int i = 0; i < N; ++i) {
+      double w[3] = {blk[3 * N + i], blk[4 * N + i], blk[5 * N + i]}, R[9], U[9], d[3];
+      ro_so3_exp(w, R); mat3_tmul(Rm, R, U); ro_so3_log(U, d);
+      acc[0] += d[0]; acc[1] += d[1]; acc[2] += d[2];
+    }
+    double dm[3] = {acc[0] / N, acc[1] / N, acc[2] / N}, E[9], T[9];
+    ro_so3_exp(dm, E); mat3_mul(Rm, E, T); memcpy(Rm, T, sizeof(T));
+  }
+  ro_so3_log(Rm, mean6 + 3);
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < N; ++i) {
+    for (int k = 0; k < 3; ++k) { double d = blk[k * N + i] - mean6[k]; v[k] += d * d; }
+    double w[3] = {blk[3 * N + i], blk[4 * N + i], blk[5 * N + i]}, R[9], U[9], d[3];
+    ro_so3_exp(w, R); mat3_tmul(Rm, R, U); ro_so3_log(U, d);
+    for (int k = 0; k < 3; ++k) v[3 + k] += d[k] * d[k];
+  }
+  double den = N > 1 ? (double)(N - 1) : 1.0;
+  for (int k = 0; k < 6; ++k) std6[k] = sqrt(v[k] / den);
+}
+
+/* ======================================================================== */
+/* Nelder-Mead, Optim.jl defaults (⚠Optim: NelderMead(AdaptiveParameters(),   */
+/* AffineSimplexer()); g_tol 1e-8)                         */
+/* ======================================================================== */
+static void nm_sortperm(int m, const double* f, int* order) { /* stable: ties by storage index */
+  for (int i = 0; i < m; ++i) order[i] = i;
+  for (int i = 1; i < m; ++i) {
+    int k = order[i], j = i - 1;
+    while (j >= 0 && f[order[j]] > f[k]) { order[j + 1] = order[j]; --j; }
+    order[j + 1] = k;
+  }
+}
+static void nm_centroid(int n, int m, double simplex[][RO_MAXN], int skip, double* c) {
+  for (int k = 0; k < n; ++k) c[k] = 0.0;
+  for (int i = 0; i < m; ++i) if (i != skip) for (int k = 0; k < n; ++k) c[k] += simplex[i][k];
+  double inv = 1.0 / n;
+  for (int k = 0; k < n; ++k) c[k] *= inv;
+}
+static double nm_objective(int n, int m, const double* f) { /* sqrt(var(f) * n/m), var corrected */
+  double mean = 0; for (int i = 0; i < m; ++i) mean += f[i]; mean /= m;
+  double v = 0; for (int i = 0; i < m; ++i) { double d = f[i] - mean; v += d * d; }
+  v /= (m - 1);
+  return sqrt(v * ((double)n / (double)m));
+}
+
+int ro_nelder_mead(int n, ro_cost_fn f, void* ctx, double* x, int max_iters, double g_tol, int* n_evals) {
+  const int m = n + 1;
+  const double alpha = 1.0, beta = 1.0 + 2.0 / n, gamma = 0.75 - 1.0 / (2.0 * n), delta = 1.0 - 1.0 / n;
+  double simplex[RO_MAXN + 1][RO_MAXN], fs[RO_MAXN + 1];
+  int order[RO_MAXN + 1];
+  int evals = 0;
+  /* AffineSimplexer(a=0.025, b=0.5) */
+  for (int i = 0; i < m; ++i) for (int k = 0; k < n; ++k) simplex[i][k] = x[k];
+  for (int j = 0; j < n; ++j) simplex[j + 1][j] = (1.0 + 0.5) * simplex[j + 1][j] + 0.025;
+  for (int i = 0; i < m; ++i) { fs[i] = f(simplex[i], ctx); ++evals; }
+  nm_sortperm(m, fs, order);
+  double nm_x = nm_objective(n, m, fs);
+  int iter = 0, converged = nm_x <= g_tol;
+  double xc[RO_MAXN], xr[RO_MAXN], xt[RO_MAXN], xl[RO_MAXN];
+  while (!converged && iter < max_iters) {
+    ++iter;
+    int shrink = 0;
+    int ih = order[m - 1];
+    nm_centroid(n, m, simplex, ih, xc);
+    for (int k = 0; k < n; ++k) xl[k] = simplex[order[0]][k];
+    double f_lowest = fs[order[0]], f_second = fs[order[n - 1]], f_highest = fs[ih];
+    for (int k = 0; k < n; ++k) xr[k] = xc[k] + alpha * (xc[k] - simplex[ih][k]);
+    double f_reflect = f(xr, ctx); ++evals;
+    if (f_reflect < f_lowest) {
+      for (int k = 0; k < n; ++k) xt[k] = xc[k] + beta * (xr[k] - xc[k]);
+      double f_expand = f(xt, ctx); ++evals;
+      if (f_expand < f_reflect) { memcpy(simplex[ih], xt, n * sizeof(double)); fs[ih] = f_expand; }
+      else                      { memcpy(simplex[ih], xr, n * sizeof(double)); fs[ih] = f_reflect; }
+      for (int i = m - 1; i >= 1; --i) order[i] = order[i - 1];
+      order[0] = ih;
+    } else if (f_reflect < f_second) {
+      memcpy(simplex[ih], xr, n * sizeof(double)); fs[ih] = f_reflect;
+      nm_sortperm(m, fs, order);
+    } else {
+      if (f_reflect < f_highest) { /* outside contraction */
+        for (int k = 0; k < n; ++k) xt[k] = xc[k] + gamma * (xr[k] - xc[k]);
+        double fo = f(xt, ctx); ++evals;
+        if (fo < f_reflect) { memcpy(simplex[ih], xt, n * sizeof(double)); fs[ih] = fo; nm_sortperm(m, fs, order); }
+        else shrink = 1;
+      } else {                     /* inside contraction */
+        for (int k = 0; k < n; ++k) xt[k] = xc[k] - gamma * (xr[k] - xc[k]);
+        double fi = f(xt, ctx); ++evals;
+        if (fi < f_highest) { memcpy(simplex[ih], xt, n * sizeof(double)); fs[ih] = fi; nm_sortperm(m, fs, order); }
+        else shrink = 1;
+      }
+    }
+    if (shrink) {
+      for (int i = 1; i < m; ++i) {
+        int o = order[i];
+        for (int k = 0; k < n; ++k) simplex[o][k] = xl[k] + delta * (simplex[o][k] - xl[k]);
+        fs[o] = f(simplex[o], ctx); ++evals;
+      }
+      nm_sortperm(m, fs, order);
+    }
+    nm_x = nm_objective(n, m, fs);
+    converged = nm_x <= g_tol;
+  }
+  /* after_while!: best vertex, or the centroid of the n best if it is lower */
+  nm_sortperm(m, fs, order);
+  nm_centroid(n, m, simplex, order[m - 1], xc);
+  double fc = f(xc, ctx); ++evals;
+  int imin = 0; for (int i = 1; i < m; ++i) if (fs[i] < fs[imin]) imin = i;
+  if (fc < fs[imin]) memcpy(x, xc, n * sizeof(double));
+  else memcpy(x, simplex[imin], n * sizeof(double));
+  if (n_evals) *n_evals = evals;
+  return converged ? 0 : 1;
+}
+
+/* ======================================================================== */
+/* per-particle solves (⚠IIF _solveLambdaNumeric for AbstractManifoldMinimize: */
+/* minimise Σ r(exp_ϵ(hat Xc))² over identity-chart coords Xc, start vee(log(ϵ,u0))) */
+/* ======================================================================== */
+typedef struct { double z[3]; double fixed_pt[6]; int dir; } p2p2_ctx;
+static double p2p2_cost(const double* xc, void* vctx) {
+  const p2p2_ctx* c = (const p2p2_ctx*)vctx;
+  double X[6], T[6], r[3];
+  se2_hat(c->z, X);
+  ro_pose2_point_from_coords(xc, T); /* p = exp_ϵ(hat Xc) */
+  if (c->dir == 0) ro_residual_pose2pose2_pt(X, c->fixed_pt, T, r);
+  else             ro_residual_pose2pose2_pt(X, T, c->fixed_pt, r);
+  return r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+}
+static void p2p2_resid_coords(const double z[3], const double fx[3], const double t[3], int dir, double r[3]) {
+  if (dir == 0) ro_residual_pose2pose2(1, z, fx, t, r); else ro_residual_pose2pose2(1, z, t, fx, r);
+}
+/* SURVEY A.5 */
+static void p2p2_closed(const double z[3], const double fx[3], int dir, double t[3]) {
+  if (dir == 0) {
+    double s = sin(fx[2]), c = cos(fx[2]);
+    t[0] = fx[0] + c * z[0] - s * z[1]; t[1] = fx[1] + s * z[0] + c * z[1]; t[2] = fx[2] + z[2];
+  } else {
+    double th = fx[2] - z[2];
+    double s = sin(th), c = cos(th);
+    t[0] = fx[0] - (c * z[0] - s * z[1]); t[1] = fx[1] - (s * z[0] + c * z[1]); t[2] = th;
+  }
+}
+static int p2p2_newton(const double z[3], const double fx[3], int dir, double t[3], int max_iters, double tol) {
+  for (int it = 0; it < max_iters; ++it) {
+    double r[3];
+    p2p2_resid_coords(z, fx, t, dir, r);
+    double m = fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2])));
+    if (m <= tol) return 0;
+    if (dir == 0) { t[0] += r[0]; t[1] += r[1]; t[2] += r[2]; }
+    else {
+      double s = sin(t[2]), c = cos(t[2]);
+      double J13 = -s * z[0] - c * z[1], J23 = c * z[0] - s * z[1];
+      double dth = -r[2];
+      t[0] += -r[0] - J13 * dth; t[1] += -r[1] - J23 * dth; t[2] += dth;
+    }
+  }
+  return 1;
+}
+static inline double wrap_pi(double th) { return atan2(sin(th), cos(th)); }
+
+/* entropy: u0 ← u0 ∘ exp_ϵ(hat(spread·(U-½)))  (⚠IIF addEntropyOnManifold!, compose form) */
+static void se2_add_entropy(double t[3], double spread, const double u[3]) {
+  double ex = spread * (u[0] - 0.5), ey = spread * (u[1] - 0.5), et = spread * (u[2] - 0.5);
+  double s = sin(t[2]), c = cos(t[2]);
+  t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] += et;
+}
+
+static inline int get_idx(const int32_t* a, int c) { return a ? a[c] : c; }
+
+int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int32_t* dir,
+                       const int32_t* fixed_var, const int32_t* target_var,
+                       const double* mu, const double* L, const double* bel, const double* noise,
+                       double* out, int32_t* status) {
+  const int N = o->n_particles;
+  if (N <= 0 || C < 0) return -1;
+  int cycles = o->inflate_cycles < 1 ? 1 : o->inflate_cycles;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int c = 0; c < C; ++c) {
+    const int f = get_idx(factor, c), dr = dir ? dir[c] : 0;
+    const double* fb = bel + (size_t)get_idx(fixed_var, c) * 3 * N;
+    const double* tb = bel + (size_t)get_idx(target_var, c) * 3 * N;
+    const double* m = mu + 3 * f; const double* Lf = L + 6 * f;
+    double* ob = out + (size_t)c * 3 * N;
+    double* zs = (double*)malloc(sizeof(double) * 3 * N);
+    for (int i = 0; i < N; ++i) {
+      double xi[3];
+      if (noise) { xi[0] = noise[(size_t)c * 3 * N + i]; xi[1] = noise[(size_t)c * 3 * N + N + i]; xi[2] = noise[(size_t)c * 3 * N + 2 * N + i]; }
+      else ro_rng_normals(o->seed, o->stream_offset + (uint64_t)c, (uint32_t)i, 3, xi);
+      zs[3 * i + 0] = m[0] + Lf[0] * xi[0];
+      zs[3 * i + 1] = m[1] + Lf[1] * xi[0] + Lf[2] * xi[1];
+      zs[3 * i + 2] = m[2] + Lf[3] * xi[0] + Lf[4] * xi[1] + Lf[5] * xi[2];
+      ob[i] = tb[i]; ob[N + i] = tb[N + i]; ob[2 * N + i] = wrap_pi(tb[2 * N + i]); /* X0c = vee(log(ϵ,u0)) */
+      if (status) status[(size_t)c * N + i] = 0;
+    }
+    if (o->solver == RO_SOLVER_CLOSED_FORM) {
+      for (int i = 0; i < N; ++i) {
+        double fx[3] = {fb[i], fb[N + i], fb[2 * N + i]}, t[3];
+        p2p2_closed(zs + 3 * i, fx, dr, t);
+        ob[i] = t[0]; ob[N + i] = t[1]; ob[2 * N + i] = wrap_pi(t[2]);
+      }
+    } else {
+      for (int cyc = 0; cyc < cycles; ++cyc) {
+        double spread = 0.0;
+        if (o->inflation > 0.0 && N > 1) {
+          double mean3[3], std3[3];
+          ro_belief_spread_se2(N, ob, ob + N, ob + 2 * N, mean3, std3);
+          spread = o->inflation * (std3[0] + std3[1] + std3[2]) / 3.0;
+        }
+        for (int i = 0; i < N; ++i) {
+          double fx[3] = {fb[i], fb[N + i], fb[2 * N + i]};
+          double t[3] = {ob[i], ob[N + i], ob[2 * N + i]};
+          if (spread > 0.0) {
+            double u[3];
+            ro_rng_entropy(o->seed, o->stream_offset + (uint64_t)c, (uint32_t)i, cyc, 3, u);
+            se2_add_entropy(t, spread, u);
+            t[2] = wrap_pi(t[2]);
+          }
+          int st;
+          if (o->solver == RO_SOLVER_NEWTON) st = p2p2_newton(zs + 3 * i, fx, dr, t, o->max_iters, o->tol);
+          else {
+            p2p2_ctx cx; memcpy(cx.z, zs + 3 * i, sizeof(cx.z)); cx.dir = dr;
+            ro_pose2_point_from_coords(fx, cx.fixed_pt);
+            st = ro_nelder_mead(3, p2p2_cost, &cx, t, o->max_iters, o->tol, NULL);
+          }
+          ob[i] = t[0]; ob[N + i] = t[1]; ob[2 * N + i] = wrap_pi(t[2]);
+          if (status && st) status[(size_t)c * N + i] = st;
+        }
+      }
+    }
+    free(zs);
+  }
+  return 0;
+}
+
+/* ---- PriorPose2: N samples exp_ϵ(hat(μ + Lξ)) (⚠IIF samplePoint; src/factors/PriorPose2.jl:13-17) ---- */
+int ro_sample_priorpose2(const ro_opts* o, int C, const int32_t* factor, const double* mu, const double* L,
+                         const double* noise, double* out) {
+  const int N = o->n_particles;
+#pragma omp parallel for
+  for (int c = 0; c < C; ++c) {
+    const int f = get_idx(factor, c);
+    const double* m = mu + 3 * f; const double* Lf = L + 6 * f;
+    double* ob = out + (size_t)c * 3 * N;
+    for (int i = 0; i < N; ++i) {
+      double xi[3];
+      if (noise) { xi[0] = noise[(size_t)c * 3 * N + i]; xi[1] = noise[(size_t)c * 3 * N + N + i]; xi[2] = noise[(size_t)c * 3 * N + 2 * N + i]; }
+      else ro_rng_normals(o->seed, o->stream_offset + (uint64_t)c, (uint32_t)i, 3, xi);
+      ob[i] = m[0] + Lf[0] * xi[0];
+      ob[N + i] = m[1] + Lf[1] * xi[0] + Lf[2] * xi[1];
+      ob[2 * N + i] = wrap_pi(m[2] + Lf[3] * xi[0] + Lf[4] * xi[1] + Lf[5] * xi[2]);
+    }
+  }
+  return 0;
+}
+
+/* ---- Pose2Point2BearingRange ---- */
+typedef struct { double z[2]; double fixed[3]; int dir; } br_ctx;
+static void br_resid(const double z[2], const double pose[3], const double l[2], double r[2]) {
+  ro_residual_pose2point2br(1, z, pose, l, r);
+}
+static double br_cost(const double* xc, void* vctx) {
+  const br_ctx* c = (const br_ctx*)vctx;
+  double r[2];
+  if (c->dir == 0) br_resid(c->z, c->fixed, xc, r);       /* target = landmark (TranslationGroup(2): exp_ϵ(hat Xc) = Xc) */
+  else             br_resid(c->z, xc, c->fixed, r);       /* target = pose, fixed = landmark (fixed[0..1]) */
+  return r[0] * r[0] + r[1] * r[1];
+}
+static int br_newton(const double z[2], const double* fx, int dir, double* t, int max_iters, double tol) {
+  for (int it = 0; it < max_iters; ++it) {
+    double r[2];
+    if (dir == 0) br_resid(z, fx, t, r); else br_resid(z, t, fx, r);
+    if (fmax(fabs(r[0]), fabs(r[1])) <= tol) return 0;
+    if (dir == 0) {
+      /* Newton step in the pose-frame polar chart of the landmark: (φ, n) += (r0, r1) */
+      double s = sin(fx[2]), c = cos(fx[2]);
+      double dx = t[0] - fx[0], dy = t[1] - fx[1];
+      double plx = c * dx + s * dy, ply = -s * dx + c * dy;
+      double n = sqrt(plx * plx + ply * ply), phi = atan2(ply, plx);
+      double nn = n + r[1], a = phi + r[0];
+      double qx = nn * cos(a), qy = nn * sin(a);
+      t[0] = fx[0] + c * qx - s * qy; t[1] = fx[1] + s * qx + c * qy;
+    } else {
+      /* minimum-norm Gauss-Newton step δ = -Jᵀ (J Jᵀ)⁻¹ r for the 2-eq / 3-unknown pose direction */
+      double s = sin(t[2]), c = cos(t[2]);
+      double dx = fx[0] - t[0], dy = fx[1] - t[1];
+      double plx = c * dx + s * dy, ply = -s * dx + c * dy;
+      double n2 = plx * plx + ply * ply, n = sqrt(n2);
+      if (n < 1e-300) { t[0] += 1e-6; continue; }
+      double y0 = -r[0] / (1.0 / n2 + 1.0), y1 = -r[1];
+      double ax = ply * y0 / n2 - plx * y1 / n;   /* Aᵀ y */
+      double ay = -plx * y0 / n2 - ply * y1 / n;
+      /* δt = -R Aᵀ y ; δθ = y0 */
+      t[0] += -(c * ax - s * ay); t[1] += -(s * ax + c * ay); t[2] += y0;
+    }
+  }
+  return 1;
+}
+static void br_closed(const double z[2], const double* fx, int dir, double* t) {
+  if (dir == 0) { /* l = p.t + ρ R(θ)(cos b, sin b) */
+    double a = fx[2] + z[0];
+    t[0] = fx[0] + z[1] * cos(a); t[1] = fx[1] + z[1] * sin(a);
+  } else {        /* member of the ring nearest (in translation) to the start point t */
+    double dx = fx[0] - t[0], dy = fx[1] - t[1];
+    double n = sqrt(dx * dx + dy * dy);
+    double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
+    t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy;
+    t[2] = atan2(uy, ux) - z[0];
+  }
+}
+
+int ro_conv_pose2point2br(const ro_opts* o, int C, const int32_t* factor, int dir,
+                          const int32_t* fixed_var, const int32_t* target_var,
+                          const double* mu, const double* sigma,
+                          const double* bel_fixed, const double* bel_target,
+                          const double* noise, double* out, int32_t* status) {
+  const int N = o->n_particles;
+  const int df = dir == 0 ? 3 : 2, dt = dir == 0 ? 2 : 3;
+  int cycles = o->inflate_cycles < 1 ? 1 : o->inflate_cycles;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int c = 0; c < C; ++c) {
+    const int f = get_idx(factor, c);
+    const double* fb = bel_fixed + (size_t)get_idx(fixed_var, c) * df * N;
+    const double* tb = bel_target + (size_t)get_idx(target_var, c) * dt * N;
+    double* ob = out + (size_t)c * dt * N;
+    double* zs = (double*)malloc(sizeof(double) * 2 * N);
+    for (int i = 0; i < N; ++i) {
+      double xi[2];
+      if (noise) { xi[0] = noise[(size_t)c * 2 * N + i]; xi[1] = noise[(size_t)c * 2 * N + N + i]; }
+      else ro_rng_normals(o->seed, o->stream_offset + (uint64_t)c, (uint32_t)i, 2, xi);
+      zs[2 * i] = mu[2 * f] + sigma[2 * f] * xi[0];          /* rand(bearing) src/factors/BearingRange2D.jl:23 */
+      zs[2 * i + 1] = mu[2 * f + 1] + sigma[2 * f + 1] * xi[1]; /* rand(range) */
+      for (int k = 0; k < dt; ++k) ob[k * N + i] = tb[k * N + i];
+      if (dt == 3) ob[2 * N + i] = wrap_pi(ob[2 * N + i]);
+      if (status) status[(size_t)c * N + i] = 0;
+    }
+    int ncyc = (o->solver == RO_SOLVER_CLOSED_FORM && dir == 0) ? 1 : cycles;
+    for (int cyc = 0; cyc < ncyc; ++cyc) {
+      double spread = 0.0;
+      if (o->inflation > 0.0 && N > 1 && !(o->solver == RO_SOLVER_CLOSED_FORM && dir == 0)) {
+        if (dt == 3) { double m3[3], s3[3]; ro_belief_spread_se2(N, ob, ob + N, ob + 2 * N, m3, s3); spread = o->inflation * (s3[0] + s3[1] + s3[2]) / 3.0; }
+        else         { double m2[2], s2[2]; ro_belief_spread_r2(N, ob, ob + N, m2, s2); spread = o->inflation * (s2[0] + s2[1]) / 2.0; }
+      }
+      for (int i = 0; i < N; ++i) {
+        double fx[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+        for (int k = 0; k < df; ++k) fx[k] = fb[k * N + i];
+        for (int k = 0; k < dt; ++k) t[k] = ob[k * N + i];
+        if (spread > 0.0) {
+          double u[3];
+          ro_rng_entropy(o->seed, o->stream_offset + (uint64_t)c, (uint32_t)i, cyc, dt, u);
+          if (dt == 3) { se2_add_entropy(t, spread, u); t[2] = wrap_pi(t[2]); }
+          else { t[0] += spread * (u[0] - 0.5); t[1] += spread * (u[1] - 0.5); }
+        }
+        int st = 0;
+        if (o->solver == RO_SOLVER_CLOSED_FORM) br_closed(zs + 2 * i, fx, dir, t);
+        else if (o->solver == RO_SOLVER_NEWTON) st = br_newton(zs + 2 * i, fx, dir, t, o->max_iters, o->tol);
+        else {
+          br_ctx cx; cx.z[0] = zs[2 * i]; cx.z[1] = zs[2 * i + 1]; cx.dir = dir;
+          cx.fixed[0] = fx[0]; cx.fixed[1] = fx[1]; cx.fixed[2] = fx[2];
+          st = ro_nelder_mead(dt, br_cost, &cx, t, o->max_iters, o->tol, NULL);
+        }
+        for (int k = 0; k < dt; ++k) ob[k * N + i] = t[k];
+        if (dt == 3) ob[2 * N + i] = wrap_pi(t[2]);
+        if (status && st) status[(size_t)c * N + i] = st;
+      }
+    }
+    free(zs);
+  }
+  return 0;
+}
+
+/* ---- Pose3Pose3 ---- */
+typedef struct { double X[12]; double fixed_pt[12]; int dir; } p3p3_ctx;
+static double p3p3_cost(const double* xc, void* vctx) {
+  const p3p3_ctx* c = (const p3p3_ctx*)vctx;
+  double T[12], r[6];
+  ro_pose3_point_from_coords(xc, T);
+  if (c->dir == 0) ro_residual_pose3pose3_pt(c->X, c->fixed_pt, T, r);
+  else             ro_residual_pose3pose3_pt(c->X, T, c->fixed_pt, r);
+  double s = 0; for (int k = 0; k < 6; ++k) s += r[k] * r[k];
+  return s;
+}
+static void p3p3_closed_pt(const double z[6], const double F[12], int dir, double T[12]) {
+  double Z[9];
+  ro_so3_exp(z + 3, Z);
+  if (dir == 0) { /* R_q = R_p Exp(z_ω), q.t = p.t + R_p z_t */
+    double v[3]; mat3_mul(F + 3, Z, T + 3); mat3_vec(F + 3, z, v);
+    for (int k = 0; k < 3; ++k) T[k] = F[k] + v[k];
+  } else {        /* R_p = R_q Exp(z_ω)ᵀ, p.t = q.t - R_p z_t */
+    double Zt[9]; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Zt[i + 3 * j] = Z[j + 3 * i];
+    double v[3]; mat3_mul(F + 3, Zt, T + 3); mat3_vec(T + 3, z, v);
+    for (int k = 0; k < 3; ++k) T[k] = F[k] - v[k];
+  }
+}
+/* Newton on the group: right-perturbation updates that zero the residual */
+static int p3p3_newton_pt(const double z[6], const double F[12], int dir, double T[12], int max_iters, double tol) {
+  double X[12], Z[9];
+  se3_hat(z, X); ro_so3_exp(z + 3, Z);
+  for (int it = 0; it < max_iters; ++it) {
+    double r[6];
+    if (dir == 0) ro_residual_pose3pose3_pt(X, F, T, r); else ro_residual_pose3pose3_pt(X, T, F, r);
+    double m = 0; for (int k = 0; k < 6; ++k) m = fmax(m, fabs(r[k]));
+    if (m <= tol) return 0;
+    if (dir == 0) {
+      double E[9], Rn[9];
+      ro_so3_exp(r + 3, E); mat3_mul(T + 3, E, Rn); memcpy(T + 3, Rn, sizeof(Rn));
+      T[0] += r[0]; T[1] += r[1]; T[2] += r[2];
+    } else {
+      double d[3], E[9], Rn[9], v[3];
+      mat3_vec(Z, r + 3, d); d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2];   /* δ = -Z r_ω */
+      ro_so3_exp(d, E); mat3_mul(T + 3, E, Rn); memcpy(T + 3, Rn, sizeof(Rn));
+      mat3_vec(T + 3, z, v);
+      for (int k = 0; k < 3; ++k) T[k] = F[k] - v[k];                     /* t_p ← t_q - R_p z_t */
+    }
+  }
+  return 1;
+}
+static void se3_add_entropy_pt(double T[12], double spread, const double u[6]) {
+  double e[6]; for (int k = 0; k < 6; ++k) e[k] = spread * (u[k] - 0.5);
+  double E[9], Rn[9], v[3];
+  mat3_vec(T + 3, e, v);
+  T[0] += v[0]; T[1] += v[1]; T[2] += v[2];
+  ro_so3_exp(e + 3, E); mat3_mul(T + 3, E, Rn); memcpy(T + 3, Rn, sizeof(Rn));
+}
+
+int ro_conv_pose3pose3(const ro_opts* o, int C, const int32_t* factor, const int32_t* dir,
+                       const int32_t* fixed_var, const int32_t* target_var,
+                       const double* mu, const double* L, const double* bel, const double* noise,
+                       double* out, int32_t* status) {
+  const int N = o->n_particles;
+  int cycles = o->inflate_cycles < 1 ? 1 : o->inflate_cycles;
+#pragma omp parallel for schedule(dynamic, 2)
+  for (int c = 0; c < C; ++c) {
+    const int f = get_idx(factor, c), dr = dir ? dir[c] : 0;
+    const double* fb = bel + (size_t)get_idx(fixed_var, c) * 6 * N;
+    const double* tb = bel + (size_t)get_idx(target_var, c) * 6 * N;
+    const double* m = mu + 6 * f; const double* Lf = L + 21 * f;
+    double* ob = out + (size_t)c * 6 * N;
+    double* zs = (double*)malloc(sizeof(double) * 6 * N);
+    for (int i = 0; i < N; ++i) {
+      double xi[6];
+      if (noise) for (int k = 0; k < 6; ++k) xi[k] = noise[(size_t)c * 6 * N + k * N + i];
+      else ro_rng_normals(o->seed, o->stream_offset + (uint64_t)c, (uint32_t)i, 6, xi);
+      int p = 0;
+      for (int k = 0; k < 6; ++k) { double s = m[k]; for (int j = 0; j <= k; ++j) s += Lf[p++] * xi[j]; zs[6 * i + k] = s; }
+      /* X0c = vee(log(ϵ,u0)): canonicalise the stored rotation vector through Exp/Log */
+      double c0[6], P[12];
+      for (int k = 0; k < 6; ++k) c0[k] = tb[k * N + i];
+      ro_pose3_point_from_coords(c0, P); ro_pose3_coords_from_point(P, c0);
+      for (int k = 0; k < 6; ++k) ob[k * N + i] = c0[k];
+      if (status) status[(size_t)c * N + i] = 0;
+    }
+    int ncyc = o->solver == RO_SOLVER_CLOSED_FORM ? 1 : cycles;
+    for (int cyc = 0; cyc < ncyc; ++cyc) {
+      double spread = 0.0;
+      if (o->inflation > 0.0 && N > 1 && o->solver != RO_SOLVER_CLOSED_FORM) {
+        double m6[6], s6[6]; ro_belief_spread_se3(N, ob, m6, s6);
+        spread = o->inflation * (s6[0] + s6[1] + s6[2] + s6[3] + s6[4] + s6[5]) / 6.0;
+      }
+      for (int i = 0; i < N; ++i) {
+        double fx[6], t[6], F[12], T[12];
+        for (int k = 0; k < 6; ++k) { fx[k] = fb[k * N + i]; t[k] = ob[k * N + i]; }
+        ro_pose3_point_from_coords(fx, F);
+        ro_pose3_point_from_coords(t, T);
+        if (spread > 0.0) {
+          double u[6];
+          ro_rng_entropy(o->seed, o->stream_offset + (uint64_t)c, (uint32_t)i, cyc, 6, u);
+          se3_add_entropy_pt(T, spread, u);
+        }
+        int st = 0;
+        if (o->solver == RO_SOLVER_CLOSED_FORM) p3p3_closed_pt(zs + 6 * i, F, dr, T);
+        else if (o->solver == RO_SOLVER_NEWTON) st = p3p3_newton_pt(zs + 6 * i, F, dr, T, o->max_iters, o->tol);
+        else {
+          p3p3_ctx cx; se3_hat(zs + 6 * i, cx.X); memcpy(cx.fixed_pt, F, sizeof(F)); cx.dir = dr;
+          double x0[6]; ro_pose3_coords_from_point(T, x0);
+          st = ro_nelder_mead(6, p3p3_cost, &cx, x0, o->max_iters, o->tol, NULL);
+          ro_pose3_point_from_coords(x0, T);
+        }
+        ro_pose3_coords_from_point(T, t);
+        for (int k = 0; k < 6; ++k) ob[k * N + i] = t[k];
+        if (status && st) status[(size_t)c * N + i] = st;
+      }
+    }
+    free(zs);
+  }
+  return 0;
+}
+
+int ro_sample_priorpose3(const ro_opts* o, int C, const int32_t* factor, const double* mu, const double* L,
+                         const double* noise, double* out) {
+  const int N = o->n_particles;
+#pragma omp parallel for
+  for (int c = 0; c < C; ++c) {
+    const int f = get_idx(factor, c);
+    const double* m = mu + 6 * f; const double* Lf = L + 21 * f;
+    double* ob = out + (size_t)c * 6 * N;
+    for (int i = 0; i < N; ++i) {
+      double xi[6], zc[6], P[12];
+      if (noise) for (int k = 0; k < 6; ++k) xi[k] = noise[(size_t)c * 6 * N + k * N + i];
+      else ro_rng_normals(o->seed, o->stream_offset + (uint64_t)c, (uint32_t)i, 6, xi);
+      int p = 0;
+      for (int k = 0; k < 6; ++k) { double s = m[k]; for (int j = 0; j <= k; ++j) s += Lf[p++] * xi[j]; zc[k] = s; }
+      ro_pose3_point_from_coords(zc, P); ro_pose3_coords_from_point(P, zc);
+      for (int k = 0; k < 6; ++k) ob[k * N + i] = zc[k];
+    }
+  }
+  return 0;
+}
+
+int ro_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void ro_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}

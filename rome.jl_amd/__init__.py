@@ -1,0 +1,27 @@
+"""rome_jl_amd -- MI355X (gfx950) factor convolutions behind RoME.jl's factor plugin surface.
+
+Scope: ONE hot path of RoME.jl + IncrementalInference.jl -- the per-particle residual + root-find
+inside `approxConvBelief` for Pose2Pose2, PriorPose2, Pose2Point2BearingRange and Pose3Pose3 --
+as hand-written HIP kernels in librome_mi355.so (C ABI: include/rome_mi355.h).  This package is the
+host-side mirror of the reference interface; it contains no compute and no CPU fallback.
+"""
+from . import _lib
+from ._lib import (Context, Opts, RomeError, SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD,
+                   LAYOUT_SOA, LAYOUT_AOS, MAX_PARTICLES)
+from .factors import (MvNormal, Normal, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
+                      Pose3Pose3, PriorPose3, getMeasurementParametric, getPoint, getCoordinates, pack_factor,
+                      unpack_factor)
+from .api import (calcFactorResidualTemporary, make_opts, cholesky_lower, default_context,
+                  residual_pose2pose2, residual_priorpose2, residual_pose2point2br, residual_pose2point2br_pt,
+                  residual_pose3pose3, residual_pose3pose3_pt, residual_priorpose3,
+                  conv_pose2pose2, conv_pose2point2br, conv_pose3pose3, sample_priorpose2, sample_priorpose3)
+from .graph import (FactorGraph, initfg, importG2o, parseG2oInstruction, loadG2o, synth_manhattan,
+                    synth_manhattan_edges, synth_helix3d, generateGraph_Circle, generateGraph_Hexagonal,
+                    PackedGraph, dead_reckon_init)
+from .convolution import approxConv, approxConvBelief
+from .device import DeviceGraph
+
+
+def build(force=False, verbose=False):
+    from . import _build
+    return _build.build(force=force, verbose=verbose)

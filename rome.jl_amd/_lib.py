@@ -1,0 +1,146 @@
+"""ctypes binding of librome_mi355.so -- one Python signature per symbol of include/rome_mi355.h.
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is present when a
+Context is created, this raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "librome_mi355.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED_N, ERR_ALLOC = -1, -2, -3, -4, -5, -6
+SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD = 0, 1, 2
+LAYOUT_SOA, LAYOUT_AOS = 0, 1
+MAX_PARTICLES = 256
+
+
+class RomeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("librome_mi355: %s (code %d)" % (msg, code))
+        self.code = code
+
+
+class Opts(C.Structure):
+    _fields_ = [("n_particles", C.c_int32), ("solver", C.c_int32), ("max_iters", C.c_int32),
+                ("inflate_cycles", C.c_int32), ("tol", C.c_double), ("inflation", C.c_double),
+                ("seed", C.c_uint64), ("stream_offset", C.c_uint64), ("layout", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class ConvDev(C.Structure):
+    _fields_ = [("n_conv", C.c_int32), ("dir_all", C.c_int32),
+                ("factor", C.c_void_p), ("dir", C.c_void_p), ("fixed_var", C.c_void_p), ("target_var", C.c_void_p),
+                ("mu", C.c_void_p), ("L", C.c_void_p), ("bel_fixed", C.c_void_p), ("bel_target", C.c_void_p),
+                ("noise", C.c_void_p), ("out", C.c_void_p), ("status", C.c_void_p)]
+
+
+_PD = C.POINTER(C.c_double)
+_PI = C.POINTER(C.c_int32)
+_CTX = C.c_void_p
+_PO = C.POINTER(Opts)
+_PT = C.POINTER(ConvDev)
+
+# symbol -> (restype, argtypes): EXACTLY the declarations of include/rome_mi355.h
+SIGNATURES = {
+    "rome_version": (C.c_int, []),
+    "rome_strerror": (C.c_char_p, [C.c_int]),
+    "rome_last_hip_error": (C.c_int, [_CTX]),
+    "rome_last_hip_error_string": (C.c_char_p, [_CTX]),
+    "rome_opts_default": (None, [_PO, C.c_int32]),
+    "rome_ctx_create": (C.c_int, [C.POINTER(_CTX), C.c_int]),
+    "rome_ctx_destroy": (None, [_CTX]),
+    "rome_ctx_set_stream": (C.c_int, [_CTX, C.c_void_p]),
+    "rome_ctx_synchronize": (C.c_int, [_CTX]),
+    "rome_device_count": (C.c_int, []),
+    "rome_cholesky_lower": (C.c_int, [C.c_int32, C.c_int32, _PD, _PD]),
+    "rome_residual_pose2pose2": (C.c_int, [_CTX, C.c_int32, _PD, _PD, _PD, _PD]),
+    "rome_residual_priorpose2": (C.c_int, [_CTX, C.c_int32, _PD, _PD, _PD]),
+    "rome_residual_pose2point2br": (C.c_int, [_CTX, C.c_int32, _PD, _PD, _PD, _PD]),
+    "rome_residual_pose2point2br_pt": (C.c_int, [_CTX, C.c_int32, _PD, _PD, _PD, _PD]),
+    "rome_residual_pose3pose3": (C.c_int, [_CTX, C.c_int32, _PD, _PD, _PD, _PD]),
+    "rome_residual_pose3pose3_pt": (C.c_int, [_CTX, C.c_int32, _PD, _PD, _PD, _PD]),
+    "rome_residual_priorpose3": (C.c_int, [_CTX, C.c_int32, _PD, _PD, _PD]),
+    "rome_conv_pose2pose2": (C.c_int, [_CTX, _PO, C.c_int32, _PI, _PD, _PD, _PD, _PD, _PD, _PI]),
+    "rome_conv_pose2point2br": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PI]),
+    "rome_conv_pose3pose3": (C.c_int, [_CTX, _PO, C.c_int32, _PI, _PD, _PD, _PD, _PD, _PD, _PI]),
+    "rome_sample_priorpose2": (C.c_int, [_CTX, _PO, C.c_int32, _PD, _PD, _PD, _PD]),
+    "rome_sample_priorpose3": (C.c_int, [_CTX, _PO, C.c_int32, _PD, _PD, _PD, _PD]),
+    "rome_conv_pose2pose2_dev": (C.c_int, [_CTX, _PO, _PT]),
+    "rome_conv_pose2point2br_dev": (C.c_int, [_CTX, _PO, _PT]),
+    "rome_conv_pose3pose3_dev": (C.c_int, [_CTX, _PO, _PT]),
+    "rome_sample_priorpose2_dev": (C.c_int, [_CTX, _PO, _PT]),
+    "rome_sample_priorpose3_dev": (C.c_int, [_CTX, _PO, _PT]),
+    "rome_dev_alloc": (C.c_int, [_CTX, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "rome_dev_free": (C.c_int, [_CTX, C.c_void_p]),
+    "rome_dev_upload": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "rome_dev_download": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint64]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen librome_mi355.so and bind every declared symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise RuntimeError(
+            "librome_mi355.so is not built (%s). Run `python __graft_entry__.py` or "
+            "`python rome.jl_amd/_build.py`; there is no CPU fallback." % SO)
+    lib = C.CDLL(SO)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, ctx=None):
+    if code == OK:
+        return
+    lib = load()
+    msg = lib.rome_strerror(code).decode()
+    if code == ERR_HIP and ctx is not None:
+        msg += ": " + lib.rome_last_hip_error_string(ctx).decode()
+    raise RomeError(code, msg)
+
+
+def default_opts(solver=SOLVER_NEWTON, **kw):
+    o = Opts()
+    load().rome_opts_default(C.byref(o), solver)
+    for k, v in kw.items():
+        if v is not None:
+            setattr(o, k, v)
+    return o
+
+
+class Context:
+    """Owns a rome_ctx (device id + HIP stream + staging buffers)."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = _CTX()
+        check(self._lib.rome_ctx_create(C.byref(h), int(device)))
+        self.handle = h
+        self.device = int(device)
+
+    def set_stream(self, hip_stream_ptr):
+        check(self._lib.rome_ctx_set_stream(self.handle, C.c_void_p(hip_stream_ptr or 0)), self.handle)
+
+    def synchronize(self):
+        check(self._lib.rome_ctx_synchronize(self.handle), self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.rome_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,213 @@
+"""numpy-facing wrappers of the host-pointer C-ABI entry points (include/rome_mi355.h).
+
+`calcFactorResidualTemporary` mirrors the IIF helper the reference's known-answer tests use
+(test/testBearingRange2D.jl:64, test/testParametricSimulated.jl:40, test/testPartialPose3.jl:430).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .factors import (Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange, Pose3Pose3,
+                      PriorPose3, getCoordinates)
+
+_PD = C.POINTER(C.c_double)
+_PI = C.POINTER(C.c_int32)
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide Context on device 0 (raises without a GPU: no CPU fallback)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = _lib.Context(0)
+    return _default_ctx
+
+
+def _d(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError("expected array of shape %s, got %s" % (tuple(shape), a.shape))
+    return a
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_PD)
+
+
+def _pi(a):
+    return None if a is None else a.ctypes.data_as(_PI)
+
+
+# ------------------------------------------------------------------ residuals
+def _rows(fn, ctx, ins, widths, out_w):
+    ctx = ctx or default_context()
+    arrs = [np.atleast_2d(_d(a)) for a in ins]
+    n = arrs[0].shape[0]
+    for a, w in zip(arrs, widths):
+        if a.shape != (n, w):
+            raise ValueError("expected (%d,%d) rows, got %s" % (n, w, a.shape))
+    out = np.empty((n, out_w))
+    _lib.check(fn(ctx.handle, n, *[_p(a) for a in arrs], _p(out)), ctx.handle)
+    return out
+
+
+def residual_pose2pose2(z, p, q, ctx=None):
+    return _rows(_lib.load().rome_residual_pose2pose2, ctx, (z, p, q), (3, 3, 3), 3)
+
+
+def residual_priorpose2(m, p, ctx=None):
+    return _rows(_lib.load().rome_residual_priorpose2, ctx, (m, p), (3, 3), 3)
+
+
+def residual_pose2point2br(z, p, l, ctx=None):
+    return _rows(_lib.load().rome_residual_pose2point2br, ctx, (z, p, l), (2, 3, 2), 2)
+
+
+def residual_pose2point2br_pt(z, p_pt, l, ctx=None):
+    return _rows(_lib.load().rome_residual_pose2point2br_pt, ctx, (z, p_pt, l), (2, 6, 2), 2)
+
+
+def residual_pose3pose3(z, p, q, ctx=None):
+    return _rows(_lib.load().rome_residual_pose3pose3, ctx, (z, p, q), (6, 6, 6), 6)
+
+
+def residual_pose3pose3_pt(z, p_pt, q_pt, ctx=None):
+    return _rows(_lib.load().rome_residual_pose3pose3_pt, ctx, (z, p_pt, q_pt), (6, 12, 12), 6)
+
+
+def residual_priorpose3(m, p, ctx=None):
+    return _rows(_lib.load().rome_residual_priorpose3, ctx, (m, p), (6, 6), 6)
+
+
+def _meas_coords(factor, meas):
+    """Accepts the reference's tangent containers (hat form) or plain coordinates."""
+    m = np.asarray(meas, dtype=np.float64).ravel()
+    if isinstance(factor, (Pose2Pose2, PriorPose2)):
+        if m.size == 3:
+            return m
+        if m.size == 6:  # ((x,y), [0 -θ; θ 0]) column-major
+            return np.array([m[0], m[1], m[3]])
+    elif isinstance(factor, Pose2Point2BearingRange):
+        if m.size == 2:
+            return m
+        if m.size == 5:  # ([0 -b; b 0], [ρ])
+            return np.array([m[1], m[4]])
+    elif isinstance(factor, (Pose3Pose3, PriorPose3)):
+        if m.size == 6:
+            return m
+        if m.size == 12:  # (t, skew) -> (X32, X13, X21)
+            return np.array([m[0], m[1], m[2], m[3 + 5], m[3 + 6], m[3 + 1]])
+    raise ValueError("measurement of unexpected length %d for %s" % (m.size, type(factor).__name__))
+
+
+def calcFactorResidualTemporary(factor, vartypes, meas, points, ctx=None):
+    """Residual of `factor` for one measurement and one point per variable (native point layouts,
+    or coordinate vectors of the variable's dimension)."""
+    z = _meas_coords(factor, meas)
+    pts = [np.asarray(p, dtype=np.float64).ravel() for p in points]
+    if isinstance(factor, Pose2Pose2):
+        c = [p if p.size == 3 else getCoordinates(Pose2, p) for p in pts]
+        return residual_pose2pose2([z], [c[0]], [c[1]], ctx)[0]
+    if isinstance(factor, PriorPose2):
+        # prior residual is evaluated between the sampled measurement POINT and the variable
+        c = pts[0] if pts[0].size == 3 else getCoordinates(Pose2, pts[0])
+        return residual_priorpose2([z], [c], ctx)[0]
+    if isinstance(factor, Pose2Point2BearingRange):
+        if pts[0].size == 6:
+            return residual_pose2point2br_pt([z], [pts[0]], [pts[1]], ctx)[0]
+        return residual_pose2point2br([z], [pts[0]], [pts[1]], ctx)[0]
+    if isinstance(factor, Pose3Pose3):
+        if pts[0].size == 12:
+            return residual_pose3pose3_pt([z], [pts[0]], [pts[1]], ctx)[0]
+        return residual_pose3pose3([z], [pts[0]], [pts[1]], ctx)[0]
+    if isinstance(factor, PriorPose3):
+        c = pts[0] if pts[0].size == 6 else getCoordinates(Pose3, pts[0])
+        return residual_priorpose3([z], [c], ctx)[0]
+    raise TypeError("unsupported factor type %s" % type(factor).__name__)
+
+
+# ------------------------------------------------------------------ helpers
+def cholesky_lower(cov):
+    """n covariances (n,d,d) or one (d,d) -> packed lower factors (n, d(d+1)/2)."""
+    cov = _d(cov)
+    single = cov.ndim == 2
+    if single:
+        cov = cov[None]
+    n, d, _ = cov.shape
+    L = np.empty((n, d * (d + 1) // 2))
+    _lib.check(_lib.load().rome_cholesky_lower(d, n, _p(cov), _p(L)))
+    return L[0] if single else L
+
+
+def make_opts(N=100, solver=_lib.SOLVER_NEWTON, max_iters=None, inflate_cycles=None, tol=None, inflation=None,
+              seed=None, stream_offset=None, layout=None):
+    return _lib.default_opts(solver, n_particles=N, max_iters=max_iters, inflate_cycles=inflate_cycles, tol=tol,
+                             inflation=inflation, seed=seed, stream_offset=stream_offset, layout=layout)
+
+
+def _blocks(a, C_, N, d, layout):
+    shape = (C_, d, N) if layout == _lib.LAYOUT_SOA else (C_, N, d)
+    return _d(a, shape)
+
+
+# ------------------------------------------------------------------ host-pointer convolutions
+def conv_pose2pose2(opts, mu, cov, fixed, target, dirs=None, noise=None, want_status=False, ctx=None):
+    ctx = ctx or default_context()
+    mu = np.atleast_2d(_d(mu)); C_ = mu.shape[0]; N = opts.n_particles
+    cov = _d(cov, (C_, 3, 3))
+    fixed = _blocks(fixed, C_, N, 3, opts.layout)
+    out = _blocks(target, C_, N, 3, opts.layout).copy()
+    noise = None if noise is None else _blocks(noise, C_, N, 3, opts.layout)
+    dirs = None if dirs is None else np.ascontiguousarray(dirs, dtype=np.int32)
+    st = np.zeros((C_, N), dtype=np.int32) if want_status else None
+    _lib.check(_lib.load().rome_conv_pose2pose2(ctx.handle, C.byref(opts), C_, _pi(dirs), _p(mu), _p(cov), _p(fixed),
+                                               _p(noise), _p(out), _pi(st)), ctx.handle)
+    return (out, st) if want_status else out
+
+
+def conv_pose2point2br(opts, direction, mu, sigma, fixed, target, noise=None, want_status=False, ctx=None):
+    ctx = ctx or default_context()
+    mu = np.atleast_2d(_d(mu)); C_ = mu.shape[0]; N = opts.n_particles
+    sigma = _d(sigma, (C_, 2))
+    df, dt = (3, 2) if direction == 0 else (2, 3)
+    fixed = _blocks(fixed, C_, N, df, opts.layout)
+    out = _blocks(target, C_, N, dt, opts.layout).copy()
+    noise = None if noise is None else _blocks(noise, C_, N, 2, opts.layout)
+    st = np.zeros((C_, N), dtype=np.int32) if want_status else None
+    _lib.check(_lib.load().rome_conv_pose2point2br(ctx.handle, C.byref(opts), C_, int(direction), _p(mu), _p(sigma),
+                                                  _p(fixed), _p(noise), _p(out), _pi(st)), ctx.handle)
+    return (out, st) if want_status else out
+
+
+def conv_pose3pose3(opts, mu, cov, fixed, target, dirs=None, noise=None, want_status=False, ctx=None):
+    ctx = ctx or default_context()
+    mu = np.atleast_2d(_d(mu)); C_ = mu.shape[0]; N = opts.n_particles
+    cov = _d(cov, (C_, 6, 6))
+    fixed = _blocks(fixed, C_, N, 6, opts.layout)
+    out = _blocks(target, C_, N, 6, opts.layout).copy()
+    noise = None if noise is None else _blocks(noise, C_, N, 6, opts.layout)
+    dirs = None if dirs is None else np.ascontiguousarray(dirs, dtype=np.int32)
+    st = np.zeros((C_, N), dtype=np.int32) if want_status else None
+    _lib.check(_lib.load().rome_conv_pose3pose3(ctx.handle, C.byref(opts), C_, _pi(dirs), _p(mu), _p(cov), _p(fixed),
+                                               _p(noise), _p(out), _pi(st)), ctx.handle)
+    return (out, st) if want_status else out
+
+
+def _sample_prior(fn, d, opts, mu, cov, noise, ctx):
+    ctx = ctx or default_context()
+    mu = np.atleast_2d(_d(mu)); C_ = mu.shape[0]; N = opts.n_particles
+    cov = _d(cov, (C_, d, d))
+    noise = None if noise is None else _blocks(noise, C_, N, d, opts.layout)
+    out = np.empty((C_, d, N) if opts.layout == _lib.LAYOUT_SOA else (C_, N, d))
+    _lib.check(fn(ctx.handle, C.byref(opts), C_, _p(mu), _p(cov), _p(noise), _p(out)), ctx.handle)
+    return out
+
+
+def sample_priorpose2(opts, mu, cov, noise=None, ctx=None):
+    return _sample_prior(_lib.load().rome_sample_priorpose2, 3, opts, mu, cov, noise, ctx)
+
+
+def sample_priorpose3(opts, mu, cov, noise=None, ctx=None):
+    return _sample_prior(_lib.load().rome_sample_priorpose3, 6, opts, mu, cov, noise, ctx)

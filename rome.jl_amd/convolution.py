@@ -1,0 +1,37 @@
+"""`approxConvBelief` / `approxConv` mirror (IIF API as used by the reference:
+test/testBasicPose2Conv.jl:25, test/TestPoseAndPoint2Constraints.jl:36,97)."""
+import numpy as np
+
+from . import _lib, api
+from .factors import Pose2Pose2, PriorPose2, Pose2Point2BearingRange, Pose3Pose3, PriorPose3
+
+
+def approxConv(fg, flabel, target, solver=_lib.SOLVER_NEWTON, seed=None, ctx=None, **optkw):
+    """N proposal points (dim, N) for variable `target` through factor `flabel`, convolving the
+    factor's measurement model with the current belief of its other variable."""
+    _, labels, f = fg.getFactor(flabel)
+    if target not in labels:
+        raise KeyError("%s is not connected to factor %s" % (target, flabel))
+    opts = api.make_opts(N=fg.N, solver=solver, seed=seed, **optkw)
+    if isinstance(f, PriorPose2):
+        return api.sample_priorpose2(opts, [f.Z.mu], [f.Z.cov], ctx=ctx)[0]
+    if isinstance(f, PriorPose3):
+        return api.sample_priorpose3(opts, [f.Z.mu], [f.Z.cov], ctx=ctx)[0]
+    direction = 0 if labels[1] == target else 1
+    other = labels[0] if direction == 0 else labels[1]
+    if not fg.isInitialized(other):
+        raise ValueError("approxConv: variable %s has no belief yet" % other)
+    fixed = fg.getVal(other)[None]
+    tt = fg.variables[target]
+    u0 = fg.getVal(target)[None] if fg.isInitialized(target) else np.zeros((1, tt.dim, fg.N))
+    if isinstance(f, Pose2Pose2):
+        return api.conv_pose2pose2(opts, [f.Z.mu], [f.Z.cov], fixed, u0, dirs=[direction], ctx=ctx)[0]
+    if isinstance(f, Pose3Pose3):
+        return api.conv_pose3pose3(opts, [f.Z.mu], [f.Z.cov], fixed, u0, dirs=[direction], ctx=ctx)[0]
+    if isinstance(f, Pose2Point2BearingRange):
+        return api.conv_pose2point2br(opts, direction, [[f.bearing.mu, f.range.mu]], [[f.bearing.sigma, f.range.sigma]],
+                                      fixed, u0, ctx=ctx)[0]
+    raise TypeError("unsupported factor type %s" % type(f).__name__)
+
+
+approxConvBelief = approxConv

@@ -1,0 +1,426 @@
+// rome_capi.hip -- extern "C" boundary of librome_mi355.so (see include/rome_mi355.h).
+// Host-side plumbing only: argument checks, Cholesky of the measurement covariances, layout
+// conversion + staging for the host-pointer entry points, kernel launches.  No CPU compute path.
+#include "../../include/rome_mi355.h"
+#include "rome_kernels.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+struct rome_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipError_t last_hip = hipSuccess;
+  static constexpr int kBufs = 10;
+  void* dbuf[kBufs] = {nullptr};
+  size_t dcap[kBufs] = {0};
+};
+
+namespace {
+
+inline int hip_fail(rome_ctx* c, hipError_t e) {
+  if (c) c->last_hip = e;
+  return ROME_ERR_HIP;
+}
+#define ROME_HIP(ctx, expr)                                   \
+  do {                                                        \
+    hipError_t _e = (expr);                                   \
+    if (_e != hipSuccess) return hip_fail((ctx), _e);         \
+  } while (0)
+
+int ensure(rome_ctx* c, int idx, size_t bytes, void** out) {
+  if (bytes == 0) bytes = 8;
+  if (c->dcap[idx] < bytes) {
+    if (c->dbuf[idx]) { hipError_t e = hipFree(c->dbuf[idx]); if (e != hipSuccess) return hip_fail(c, e); c->dbuf[idx] = nullptr; c->dcap[idx] = 0; }
+    size_t cap = bytes + bytes / 4;
+    hipError_t e = hipMalloc(&c->dbuf[idx], cap);
+    if (e != hipSuccess) return hip_fail(c, e);
+    c->dcap[idx] = cap;
+  }
+  *out = c->dbuf[idx];
+  return ROME_OK;
+}
+
+int check_opts(const rome_opts* o) {
+  if (!o) return ROME_ERR_INVALID_ARG;
+  if (o->n_particles < 1) return ROME_ERR_INVALID_ARG;
+  if (o->n_particles > ROME_MAX_PARTICLES) return ROME_ERR_UNSUPPORTED_N;
+  if (o->solver < ROME_SOLVER_CLOSED_FORM || o->solver > ROME_SOLVER_NELDER_MEAD) return ROME_ERR_INVALID_ARG;
+  if (o->max_iters < 1 || o->inflate_cycles < 0 || o->inflate_cycles > 255) return ROME_ERR_INVALID_ARG;
+  if (!(o->tol >= 0.0) || !(o->inflation >= 0.0)) return ROME_ERR_INVALID_ARG;
+  if (o->layout != ROME_LAYOUT_SOA && o->layout != ROME_LAYOUT_AOS) return ROME_ERR_INVALID_ARG;
+  return ROME_OK;
+}
+
+void fill_args(rome::ConvArgs& a, const rome_opts* o) {
+  std::memset(&a, 0, sizeof(a));
+  a.N = o->n_particles;
+  a.max_iters = o->max_iters;
+  a.cycles = o->inflate_cycles;
+  a.tol = o->tol;
+  a.inflation = o->inflation;
+  a.seed = o->seed;
+  a.stream_offset = o->stream_offset;
+}
+
+void args_from_dev(rome::ConvArgs& a, const rome_opts* o, const rome_conv_dev* t) {
+  fill_args(a, o);
+  a.n_conv = t->n_conv; a.dir_all = t->dir_all;
+  a.factor = t->factor; a.dir = t->dir; a.fixed_var = t->fixed_var; a.target_var = t->target_var;
+  a.mu = t->mu; a.L = t->L; a.bel_fixed = t->bel_fixed; a.bel_target = t->bel_target;
+  a.noise = t->noise; a.out = t->out; a.status = t->status;
+}
+
+int cholesky_one(int d, const double* cov, double* Lp) {
+  double L[36];
+  std::memset(L, 0, sizeof(L));
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = cov[i * d + j];
+      for (int k = 0; k < j; ++k) s -= L[i * d + k] * L[j * d + k];
+      if (i == j) { if (!(s > 0.0)) return ROME_ERR_NOT_POSDEF; L[i * d + i] = std::sqrt(s); }
+      else L[i * d + j] = s / L[j * d + j];
+    }
+  int k = 0;
+  for (int i = 0; i < d; ++i) for (int j = 0; j <= i; ++j) Lp[k++] = L[i * d + j];
+  return ROME_OK;
+}
+
+// host blocks [C][N][d] (AoS) or [C][d][N] (SoA)  ->  SoA staging vector
+void to_soa(const double* src, int C, int N, int d, int layout, std::vector<double>& dst) {
+  dst.resize((size_t)C * N * d);
+  if (layout == ROME_LAYOUT_SOA) { std::memcpy(dst.data(), src, dst.size() * sizeof(double)); return; }
+  for (int c = 0; c < C; ++c) {
+    const double* s = src + (size_t)c * N * d; double* o = dst.data() + (size_t)c * N * d;
+    for (int i = 0; i < N; ++i) for (int k = 0; k < d; ++k) o[(size_t)k * N + i] = s[(size_t)i * d + k];
+  }
+}
+void from_soa(const std::vector<double>& src, int C, int N, int d, int layout, double* dst) {
+  if (layout == ROME_LAYOUT_SOA) { std::memcpy(dst, src.data(), src.size() * sizeof(double)); return; }
+  for (int c = 0; c < C; ++c) {
+    const double* s = src.data() + (size_t)c * N * d; double* o = dst + (size_t)c * N * d;
+    for (int i = 0; i < N; ++i) for (int k = 0; k < d; ++k) o[(size_t)i * d + k] = s[(size_t)k * N + i];
+  }
+}
+
+enum FactorKind { kP2P2, kBR, kP3P3, kPrior2, kPrior3 };
+
+// common host-pointer path: stage -> launch -> fetch
+int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const int32_t* dir, int dir_all,
+              int dz, int df, int dt, const double* mu, const double* Ltab /*[C][nL]*/, int nL,
+              const double* fixed, const double* noise, double* target_inout, int32_t* status) {
+  const int N = o->n_particles;
+  ROME_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  std::vector<double> h_fixed, h_target, h_noise;
+  const bool has_fixed = (kind != kPrior2 && kind != kPrior3);
+  if (has_fixed) { to_soa(fixed, C, N, df, o->layout, h_fixed); to_soa(target_inout, C, N, dt, o->layout, h_target); }
+  if (noise) to_soa(noise, C, N, dz, o->layout, h_noise);
+
+  void *d_mu, *d_L, *d_fixed = nullptr, *d_target = nullptr, *d_noise = nullptr, *d_out, *d_dir = nullptr, *d_status = nullptr;
+  int rc;
+  if ((rc = ensure(ctx, 0, sizeof(double) * C * dz, &d_mu))) return rc;
+  if ((rc = ensure(ctx, 1, sizeof(double) * C * nL, &d_L))) return rc;
+  if ((rc = ensure(ctx, 2, sizeof(double) * (size_t)C * N * dt, &d_out))) return rc;
+  ROME_HIP(ctx, hipMemcpyAsync(d_mu, mu, sizeof(double) * C * dz, hipMemcpyHostToDevice, s));
+  ROME_HIP(ctx, hipMemcpyAsync(d_L, Ltab, sizeof(double) * C * nL, hipMemcpyHostToDevice, s));
+  if (has_fixed) {
+    if ((rc = ensure(ctx, 3, sizeof(double) * h_fixed.size(), &d_fixed))) return rc;
+    if ((rc = ensure(ctx, 4, sizeof(double) * h_target.size(), &d_target))) return rc;
+    ROME_HIP(ctx, hipMemcpyAsync(d_fixed, h_fixed.data(), sizeof(double) * h_fixed.size(), hipMemcpyHostToDevice, s));
+    ROME_HIP(ctx, hipMemcpyAsync(d_target, h_target.data(), sizeof(double) * h_target.size(), hipMemcpyHostToDevice, s));
+  }
+  if (noise) {
+    if ((rc = ensure(ctx, 5, sizeof(double) * h_noise.size(), &d_noise))) return rc;
+    ROME_HIP(ctx, hipMemcpyAsync(d_noise, h_noise.data(), sizeof(double) * h_noise.size(), hipMemcpyHostToDevice, s));
+  }
+  if (dir) {
+    if ((rc = ensure(ctx, 6, sizeof(int32_t) * C, &d_dir))) return rc;
+    ROME_HIP(ctx, hipMemcpyAsync(d_dir, dir, sizeof(int32_t) * C, hipMemcpyHostToDevice, s));
+  }
+  if (status) { if ((rc = ensure(ctx, 7, sizeof(int32_t) * (size_t)C * N, &d_status))) return rc; }
+
+  rome::ConvArgs a;
+  fill_args(a, o);
+  a.n_conv = C; a.dir_all = dir_all; a.dir = (const int32_t*)d_dir;
+  a.mu = (const double*)d_mu; a.L = (const double*)d_L;
+  a.bel_fixed = (const double*)d_fixed; a.bel_target = (const double*)d_target;
+  a.noise = (const double*)d_noise; a.out = (double*)d_out; a.status = (int32_t*)d_status;
+  hipError_t e = hipSuccess;
+  switch (kind) {
+    case kP2P2: e = rome::launch_conv_pose2pose2(a, o->solver, s); break;
+    case kBR: e = rome::launch_conv_bearingrange(a, o->solver, s); break;
+    case kP3P3: e = rome::launch_conv_pose3pose3(a, o->solver, s); break;
+    case kPrior2: e = rome::launch_sample_priorpose2(a, s); break;
+    case kPrior3: e = rome::launch_sample_priorpose3(a, s); break;
+  }
+  ROME_HIP(ctx, e);
+  std::vector<double> h_out((size_t)C * N * dt);
+  ROME_HIP(ctx, hipMemcpyAsync(h_out.data(), d_out, sizeof(double) * h_out.size(), hipMemcpyDeviceToHost, s));
+  if (status) ROME_HIP(ctx, hipMemcpyAsync(status, d_status, sizeof(int32_t) * (size_t)C * N, hipMemcpyDeviceToHost, s));
+  ROME_HIP(ctx, hipStreamSynchronize(s));
+  from_soa(h_out, C, N, dt, o->layout, target_inout);
+  return ROME_OK;
+}
+
+// rows of doubles: upload inputs, run, download
+struct RowBuf { const double* host; int width; };
+template <class Launch>
+int host_rows(rome_ctx* ctx, int n, const RowBuf* in, int n_in, double* out, int out_width, Launch&& launch) {
+  if (!ctx || n < 0 || !out) return ROME_ERR_INVALID_ARG;
+  for (int k = 0; k < n_in; ++k) if (!in[k].host && n > 0) return ROME_ERR_INVALID_ARG;
+  if (n == 0) return ROME_OK;
+  ROME_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  void* d[4] = {nullptr, nullptr, nullptr, nullptr};
+  int rc;
+  for (int k = 0; k < n_in; ++k) {
+    if ((rc = ensure(ctx, k, sizeof(double) * (size_t)n * in[k].width, &d[k]))) return rc;
+    ROME_HIP(ctx, hipMemcpyAsync(d[k], in[k].host, sizeof(double) * (size_t)n * in[k].width, hipMemcpyHostToDevice, s));
+  }
+  void* dout;
+  if ((rc = ensure(ctx, 8, sizeof(double) * (size_t)n * out_width, &dout))) return rc;
+  ROME_HIP(ctx, launch((const double*)d[0], (const double*)d[1], (const double*)d[2], (double*)dout, s));
+  ROME_HIP(ctx, hipMemcpyAsync(out, dout, sizeof(double) * (size_t)n * out_width, hipMemcpyDeviceToHost, s));
+  ROME_HIP(ctx, hipStreamSynchronize(s));
+  return ROME_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rome_version(void) { return ROME_MI355_VERSION; }
+
+const char* rome_strerror(int code) {
+  switch (code) {
+    case ROME_OK: return "ok";
+    case ROME_ERR_INVALID_ARG: return "invalid argument";
+    case ROME_ERR_NO_DEVICE: return "no HIP device available (librome_mi355 has no CPU fallback)";
+    case ROME_ERR_HIP: return "HIP runtime error (see rome_last_hip_error_string)";
+    case ROME_ERR_NOT_POSDEF: return "covariance is not positive definite";
+    case ROME_ERR_UNSUPPORTED_N: return "n_particles exceeds ROME_MAX_PARTICLES";
+    case ROME_ERR_ALLOC: return "host allocation failed";
+    default: return "unknown error";
+  }
+}
+int rome_last_hip_error(const rome_ctx* ctx) { return ctx ? (int)ctx->last_hip : 0; }
+const char* rome_last_hip_error_string(const rome_ctx* ctx) { return hipGetErrorString(ctx ? ctx->last_hip : hipSuccess); }
+
+void rome_opts_default(rome_opts* o, int32_t solver) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->n_particles = 100;
+  o->solver = solver;
+  o->max_iters = solver == ROME_SOLVER_NELDER_MEAD ? 1000 : 20;
+  o->inflate_cycles = 3;
+  o->tol = solver == ROME_SOLVER_NELDER_MEAD ? 1e-8 : 1e-12;
+  o->inflation = 5.0;
+  o->seed = 0x524F4D45ull; /* "ROME" */
+  o->stream_offset = 0;
+  o->layout = ROME_LAYOUT_SOA;
+}
+
+int rome_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rome_ctx_create(rome_ctx** out, int device) {
+  if (!out) return ROME_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ROME_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return ROME_ERR_INVALID_ARG;
+  rome_ctx* c = new (std::nothrow) rome_ctx();
+  if (!c) return ROME_ERR_ALLOC;
+  c->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return ROME_ERR_HIP; }
+  c->stream = c->own_stream;
+  *out = c;
+  return ROME_OK;
+}
+
+void rome_ctx_destroy(rome_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int i = 0; i < rome_ctx::kBufs; ++i) if (c->dbuf[i]) (void)hipFree(c->dbuf[i]);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int rome_ctx_set_stream(rome_ctx* c, void* hip_stream) {
+  if (!c) return ROME_ERR_INVALID_ARG;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return ROME_OK;
+}
+int rome_ctx_synchronize(rome_ctx* c) {
+  if (!c) return ROME_ERR_INVALID_ARG;
+  ROME_HIP(c, hipStreamSynchronize(c->stream));
+  return ROME_OK;
+}
+
+int rome_cholesky_lower(int32_t d, int32_t n, const double* cov, double* L) {
+  if (d < 1 || d > 6 || n < 0 || (n > 0 && (!cov || !L))) return ROME_ERR_INVALID_ARG;
+  const int nL = d * (d + 1) / 2;
+  for (int i = 0; i < n; ++i) {
+    int rc = cholesky_one(d, cov + (size_t)i * d * d, L + (size_t)i * nL);
+    if (rc) return rc;
+  }
+  return ROME_OK;
+}
+
+/* ---- residual entry points ---- */
+int rome_residual_pose2pose2(rome_ctx* c, int32_t n, const double* z, const double* p, const double* q, double* r) {
+  RowBuf in[3] = {{z, 3}, {p, 3}, {q, 3}};
+  return host_rows(c, n, in, 3, r, 3, [&](const double* a, const double* b, const double* d, double* o, hipStream_t s) {
+    return rome::launch_residual_pose2pose2(n, a, b, d, o, s); });
+}
+int rome_residual_priorpose2(rome_ctx* c, int32_t n, const double* m, const double* p, double* r) {
+  RowBuf in[2] = {{m, 3}, {p, 3}};
+  return host_rows(c, n, in, 2, r, 3, [&](const double* a, const double* b, const double*, double* o, hipStream_t s) {
+    return rome::launch_residual_priorpose2(n, a, b, o, s); });
+}
+int rome_residual_pose2point2br(rome_ctx* c, int32_t n, const double* z, const double* p, const double* l, double* r) {
+  RowBuf in[3] = {{z, 2}, {p, 3}, {l, 2}};
+  return host_rows(c, n, in, 3, r, 2, [&](const double* a, const double* b, const double* d, double* o, hipStream_t s) {
+    return rome::launch_residual_bearingrange(n, a, b, 0, d, o, s); });
+}
+int rome_residual_pose2point2br_pt(rome_ctx* c, int32_t n, const double* z, const double* p, const double* l, double* r) {
+  RowBuf in[3] = {{z, 2}, {p, 6}, {l, 2}};
+  return host_rows(c, n, in, 3, r, 2, [&](const double* a, const double* b, const double* d, double* o, hipStream_t s) {
+    return rome::launch_residual_bearingrange(n, a, b, 1, d, o, s); });
+}
+int rome_residual_pose3pose3(rome_ctx* c, int32_t n, const double* z, const double* p, const double* q, double* r) {
+  RowBuf in[3] = {{z, 6}, {p, 6}, {q, 6}};
+  return host_rows(c, n, in, 3, r, 6, [&](const double* a, const double* b, const double* d, double* o, hipStream_t s) {
+    return rome::launch_residual_pose3pose3(n, a, b, d, 0, o, s); });
+}
+int rome_residual_pose3pose3_pt(rome_ctx* c, int32_t n, const double* z, const double* p, const double* q, double* r) {
+  RowBuf in[3] = {{z, 6}, {p, 12}, {q, 12}};
+  return host_rows(c, n, in, 3, r, 6, [&](const double* a, const double* b, const double* d, double* o, hipStream_t s) {
+    return rome::launch_residual_pose3pose3(n, a, b, d, 1, o, s); });
+}
+int rome_residual_priorpose3(rome_ctx* c, int32_t n, const double* m, const double* p, double* r) {
+  RowBuf in[2] = {{m, 6}, {p, 6}};
+  return host_rows(c, n, in, 2, r, 6, [&](const double* a, const double* b, const double*, double* o, hipStream_t s) {
+    return rome::launch_residual_priorpose3(n, a, b, o, s); });
+}
+
+/* ---- host-pointer convolutions ---- */
+int rome_conv_pose2pose2(rome_ctx* c, const rome_opts* o, int32_t C, const int32_t* dir, const double* mu, const double* cov,
+                         const double* fixed, const double* noise, double* target_inout, int32_t* status) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || C < 0 || (C > 0 && (!mu || !cov || !fixed || !target_inout))) return ROME_ERR_INVALID_ARG;
+  if (C == 0) return ROME_OK;
+  std::vector<double> L((size_t)C * 6);
+  if ((rc = rome_cholesky_lower(3, C, cov, L.data()))) return rc;
+  return host_conv(c, o, kP2P2, C, dir, 0, 3, 3, 3, mu, L.data(), 6, fixed, noise, target_inout, status);
+}
+int rome_conv_pose2point2br(rome_ctx* c, const rome_opts* o, int32_t C, int32_t dir, const double* mu, const double* sigma,
+                            const double* fixed, const double* noise, double* target_inout, int32_t* status) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || C < 0 || (dir != 0 && dir != 1) || (C > 0 && (!mu || !sigma || !fixed || !target_inout))) return ROME_ERR_INVALID_ARG;
+  if (C == 0) return ROME_OK;
+  for (int i = 0; i < 2 * C; ++i) if (!(sigma[i] >= 0.0)) return ROME_ERR_NOT_POSDEF;
+  return host_conv(c, o, kBR, C, nullptr, dir, 2, dir == 0 ? 3 : 2, dir == 0 ? 2 : 3, mu, sigma, 2, fixed, noise, target_inout, status);
+}
+int rome_conv_pose3pose3(rome_ctx* c, const rome_opts* o, int32_t C, const int32_t* dir, const double* mu, const double* cov,
+                         const double* fixed, const double* noise, double* target_inout, int32_t* status) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || C < 0 || (C > 0 && (!mu || !cov || !fixed || !target_inout))) return ROME_ERR_INVALID_ARG;
+  if (C == 0) return ROME_OK;
+  std::vector<double> L((size_t)C * 21);
+  if ((rc = rome_cholesky_lower(6, C, cov, L.data()))) return rc;
+  return host_conv(c, o, kP3P3, C, dir, 0, 6, 6, 6, mu, L.data(), 21, fixed, noise, target_inout, status);
+}
+int rome_sample_priorpose2(rome_ctx* c, const rome_opts* o, int32_t C, const double* mu, const double* cov, const double* noise, double* out) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || C < 0 || (C > 0 && (!mu || !cov || !out))) return ROME_ERR_INVALID_ARG;
+  if (C == 0) return ROME_OK;
+  std::vector<double> L((size_t)C * 6);
+  if ((rc = rome_cholesky_lower(3, C, cov, L.data()))) return rc;
+  return host_conv(c, o, kPrior2, C, nullptr, 0, 3, 3, 3, mu, L.data(), 6, nullptr, noise, out, nullptr);
+}
+int rome_sample_priorpose3(rome_ctx* c, const rome_opts* o, int32_t C, const double* mu, const double* cov, const double* noise, double* out) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || C < 0 || (C > 0 && (!mu || !cov || !out))) return ROME_ERR_INVALID_ARG;
+  if (C == 0) return ROME_OK;
+  std::vector<double> L((size_t)C * 21);
+  if ((rc = rome_cholesky_lower(6, C, cov, L.data()))) return rc;
+  return host_conv(c, o, kPrior3, C, nullptr, 0, 6, 6, 6, mu, L.data(), 21, nullptr, noise, out, nullptr);
+}
+
+/* ---- device-pointer convolutions ---- */
+static int dev_common(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t, bool need_beliefs) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || !t || t->n_conv < 0) return ROME_ERR_INVALID_ARG;
+  if (t->n_conv > 0 && (!t->mu || !t->L || !t->out)) return ROME_ERR_INVALID_ARG;
+  if (t->n_conv > 0 && need_beliefs && (!t->bel_fixed || !t->bel_target)) return ROME_ERR_INVALID_ARG;
+  return ROME_OK;
+}
+int rome_conv_pose2pose2_dev(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t) {
+  int rc = dev_common(c, o, t, true); if (rc) return rc;
+  rome::ConvArgs a; args_from_dev(a, o, t);
+  ROME_HIP(c, rome::launch_conv_pose2pose2(a, o->solver, c->stream));
+  return ROME_OK;
+}
+int rome_conv_pose2point2br_dev(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t) {
+  int rc = dev_common(c, o, t, true); if (rc) return rc;
+  if (t->dir != nullptr || (t->dir_all != 0 && t->dir_all != 1)) return ROME_ERR_INVALID_ARG;
+  rome::ConvArgs a; args_from_dev(a, o, t);
+  ROME_HIP(c, rome::launch_conv_bearingrange(a, o->solver, c->stream));
+  return ROME_OK;
+}
+int rome_conv_pose3pose3_dev(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t) {
+  int rc = dev_common(c, o, t, true); if (rc) return rc;
+  rome::ConvArgs a; args_from_dev(a, o, t);
+  ROME_HIP(c, rome::launch_conv_pose3pose3(a, o->solver, c->stream));
+  return ROME_OK;
+}
+int rome_sample_priorpose2_dev(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t) {
+  int rc = dev_common(c, o, t, false); if (rc) return rc;
+  rome::ConvArgs a; args_from_dev(a, o, t);
+  ROME_HIP(c, rome::launch_sample_priorpose2(a, c->stream));
+  return ROME_OK;
+}
+int rome_sample_priorpose3_dev(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t) {
+  int rc = dev_common(c, o, t, false); if (rc) return rc;
+  rome::ConvArgs a; args_from_dev(a, o, t);
+  ROME_HIP(c, rome::launch_sample_priorpose3(a, c->stream));
+  return ROME_OK;
+}
+
+/* ---- device memory helpers ---- */
+int rome_dev_alloc(rome_ctx* c, uint64_t bytes, void** out) {
+  if (!c || !out) return ROME_ERR_INVALID_ARG;
+  ROME_HIP(c, hipSetDevice(c->device));
+  ROME_HIP(c, hipMalloc(out, bytes ? bytes : 8));
+  return ROME_OK;
+}
+int rome_dev_free(rome_ctx* c, void* p) {
+  if (!c) return ROME_ERR_INVALID_ARG;
+  if (p) ROME_HIP(c, hipFree(p));
+  return ROME_OK;
+}
+int rome_dev_upload(rome_ctx* c, void* dst, const void* src, uint64_t bytes) {
+  if (!c || (bytes && (!dst || !src))) return ROME_ERR_INVALID_ARG;
+  ROME_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  ROME_HIP(c, hipStreamSynchronize(c->stream));
+  return ROME_OK;
+}
+int rome_dev_download(rome_ctx* c, void* dst, const void* src, uint64_t bytes) {
+  if (!c || (bytes && (!dst || !src))) return ROME_ERR_INVALID_ARG;
+  ROME_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  ROME_HIP(c, hipStreamSynchronize(c->stream));
+  return ROME_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// rome_device_math.hpp -- gfx950 device-side FP64 math for the factor-convolution hot path.
+//
+// SE(2)/SE(3) hybrid-representation group ops, the four RoME residual functors, a counter-based
+// RNG and the per-particle solvers, all as per-lane register code (3x3 / 6x6 objects: no MFMA).
+// Reference behaviour being reproduced (paths relative to the RoME.jl checkout):
+//   src/factors/Pose2D.jl:51-67          Pose2Pose2 residual
+//   src/factors/PriorPose2.jl:19-47      _vee / _compose / PriorPose2 residual
+//   src/factors/BearingRange2D.jl:17-64  getSample + Pose2Point2BearingRange residual
+//   src/factors/Pose3Pose3.jl:17-29      Pose3Pose3 residual
+//   src/factors/Pose3D.jl:15-19          PriorPose3 residual
+// plus the (unvendored) IncrementalInference `_solveLambdaNumeric` loop and Optim.jl
+// Nelder-Mead defaults it runs around them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rome {
+
+constexpr double kPi = 3.141592653589793238462643383279502884;
+constexpr double kSqrtEps = 1.4901161193847656e-8;  // Julia isapprox default rtol for Float64
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 (Random123).  Integer only -> bit-identical to any other conforming implementation.
+// ------------------------------------------------------------------------------------------
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = u32x4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+enum : uint32_t { kDomainNoise = 1u, kDomainEntropy = 2u };
+
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {  // (0,1]
+  const uint64_t x = ((uint64_t)hi << 32) | lo;
+  return (double)((x >> 11) + 1) * (1.0 / 9007199254740992.0);
+}
+
+// D standard normals for (seed, stream, particle): Box-Muller on Philox words.
+template <int D>
+__device__ __forceinline__ void rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, double (&out)[D]) {
+  constexpr int NB = (D + 1) / 2;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const u32x4 w = philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32), (kDomainNoise << 16) | (uint32_t)b},
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double u1 = u53(w.x, w.y), u2 = u53(w.z, w.w);
+    const double rr = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincos(2.0 * kPi * u2, &s, &c);
+    out[2 * b] = rr * c;
+    if (2 * b + 1 < D) out[2 * b + 1] = rr * s;
+  }
+}
+
+// D uniforms in (0,1) (32-bit resolution) for the entropy inflation of cycle `cycle`.
+template <int D>
+__device__ __forceinline__ void rng_entropy(uint64_t seed, uint64_t stream, uint32_t particle, int cycle, double (&out)[D]) {
+  constexpr int NB = (D + 3) / 4;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const u32x4 w = philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32),
+                                        (kDomainEntropy << 16) | ((uint32_t)cycle << 8) | (uint32_t)b},
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (4 * b + k < D) out[4 * b + k] = ((double)ww[k] + 0.5) * (1.0 / 4294967296.0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wave64 reductions (all lanes end with the same bits: xor-butterfly of commutative adds)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+template <int K>
+__device__ __forceinline__ void wave_sum_n(double (&v)[K]) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += __shfl_xor(v[k], off, 64);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// SE(2)
+// ------------------------------------------------------------------------------------------
+struct Se2 { double x, y, c, s; };  // point ((x,y), R=[c -s; s c])
+
+__device__ __forceinline__ Se2 se2_from_coords(double x, double y, double th) {
+  Se2 p; p.x = x; p.y = y; sincos(th, &p.s, &p.c); return p;
+}
+__device__ __forceinline__ double wrap_pi(double th) { double s, c; sincos(th, &s, &c); return atan2(s, c); }
+
+// Manifolds.sym_rem: (x ≈ π ? -π : rem(x, 2π, RoundNearest))
+__device__ __forceinline__ double sym_rem(double x) {
+  const double m = fabs(x) > kPi ? fabs(x) : kPi;
+  if (fabs(x - kPi) <= kSqrtEps * m) return -kPi;
+  return remainder(x, 2.0 * kPi);
+}
+
+// Pose2Pose2: r = vee(log(q, p ∘ exp_ϵ(X)));  X = ((zx,zy), skew(zθ)) with (cz,sz)=cos/sin(zθ)
+__device__ __forceinline__ void residual_pose2pose2(double zx, double zy, double cz, double sz,
+                                                    const Se2& p, const Se2& q, double (&r)[3]) {
+  const double qhx = p.x + p.c * zx - p.s * zy;
+  const double qhy = p.y + p.s * zx + p.c * zy;
+  const double h11 = p.c * cz - p.s * sz;
+  const double h21 = p.s * cz + p.c * sz;
+  const double U11 = q.c * h11 + q.s * h21;
+  const double U21 = q.c * h21 - q.s * h11;
+  r[0] = qhx - q.x; r[1] = qhy - q.y; r[2] = atan2(U21, U11);
+}
+// PriorPose2: r = vee(log(p, m))
+__device__ __forceinline__ void residual_priorpose2(const Se2& m, const Se2& p, double (&r)[3]) {
+  const double U11 = p.c * m.c + p.s * m.s;
+  const double U21 = p.c * m.s - p.s * m.c;
+  r[0] = m.x - p.x; r[1] = m.y - p.y; r[2] = atan2(U21, U11);
+}
+// Pose2Point2BearingRange: pl = p.Rᵀ (l - p.t);  r = (sym_rem(b - atan2(pl)), ρ - ‖pl‖)
+__device__ __forceinline__ void residual_bearingrange(double b, double rho, const Se2& p, double lx, double ly,
+                                                      double (&r)[2]) {
+  const double dx = lx - p.x, dy = ly - p.y;
+  const double plx = p.c * dx + p.s * dy;
+  const double ply = p.c * dy - p.s * dx;
+  r[0] = sym_rem(b - atan2(ply, plx));
+  r[1] = rho - sqrt(plx * plx + ply * ply);
+}
+
+// entropy: u ← u ∘ exp_ϵ(hat(e))
+__device__ __forceinline__ void se2_add_entropy(double (&t)[3], double spread, const double (&u)[3]) {
+  const double ex = spread * (u[0] - 0.5), ey = spread * (u[1] - 0.5), et = spread * (u[2] - 0.5);
+  double s, c; sincos(t[2], &s, &c);
+  t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] += et;
+}
+
+// ------------------------------------------------------------------------------------------
+// SO(3)/SE(3) (column-major 3x3)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mat3_mul(const double* A, const double* B, double* C) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) C[i + 3 * j] = A[i] * B[3 * j] + A[i + 3] * B[1 + 3 * j] + A[i + 6] * B[2 + 3 * j];
+}
+__device__ __forceinline__ void mat3_tmul(const double* A, const double* B, double* C) {  // Aᵀ B
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      C[i + 3 * j] = A[3 * i] * B[3 * j] + A[3 * i + 1] * B[1 + 3 * j] + A[3 * i + 2] * B[2 + 3 * j];
+}
+__device__ __forceinline__ void mat3_vec(const double* A, const double* v, double* o) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = A[i] * v[0] + A[i + 3] * v[1] + A[i + 6] * v[2];
+}
+
+// Rodrigues as Manifolds' exp!(::Rotations{3}): a = sinθ/θ, b = (1-cosθ)/θ², I + aX + bX²
+__device__ __forceinline__ void so3_exp(const double* w, double* R) {
+  const double x = w[0], y = w[1], z = w[2];
+  const double th2 = x * x + y * y + z * z;
+  const double th = sqrt(th2);
+  double a = 1.0, b = 0.0;
+  if (th != 0.0) { double s, c; sincos(th, &s, &c); a = s / th; b = (1.0 - c) / th2; }
+  R[0] = 1.0 + b * (x * x - th2); R[3] = -a * z + b * x * y;      R[6] = a * y + b * x * z;
+  R[1] = a * z + b * x * y;       R[4] = 1.0 + b * (y * y - th2); R[7] = -a * x + b * y * z;
+  R[2] = -a * y + b * x * z;      R[5] = a * x + b * y * z;       R[8] = 1.0 + b * (z * z - th2);
+}
+// Manifolds' log!(::Rotations{3}) incl. the cosθ ≈ -1 branch
+__device__ __forceinline__ void so3_log(const double* U, double* w) {
+  const double c = 0.5 * (U[0] + U[4] + U[8] - 1.0);
+  const double sx = U[5] - U[7], sy = U[6] - U[2], sz = U[1] - U[3];
+  if (fabs(c + 1.0) <= kSqrtEps) {
+    const double d0 = 0.5 * (U[0] + 1.0), d1 = 0.5 * (U[4] + 1.0), d2 = 0.5 * (U[8] + 1.0);
+    double ax, ay, az;
+    if (d0 >= d1 && d0 >= d2) { ax = d0; ay = 0.25 * (U[1] + U[3]); az = 0.25 * (U[2] + U[6]); }
+    else if (d1 >= d2)        { ax = 0.25 * (U[1] + U[3]); ay = d1; az = 0.25 * (U[5] + U[7]); }
+    else                      { ax = 0.25 * (U[2] + U[6]); ay = 0.25 * (U[5] + U[7]); az = d2; }
+    const double n = sqrt(ax * ax + ay * ay + az * az);
+    const double sgn = (ax * sx + ay * sy + az * sz) < 0.0 ? -1.0 : 1.0;
+    const double k = sgn * kPi / n;
+    w[0] = k * ax; w[1] = k * ay; w[2] = k * az;
+    return;
+  }
+  double usinc;
+  if (c >= 1.0) usinc = 1.0;
+  else if (c <= -1.0) usinc = 0.0;
+  else usinc = sqrt(1.0 - c * c) / acos(c);
+  const double k = 0.5 / usinc;
+  w[0] = k * sx; w[1] = k * sy; w[2] = k * sz;
+}
+
+struct Se3 { double t[3]; double R[9]; };
+__device__ __forceinline__ void se3_from_coords(const double* c, Se3& p) {
+  p.t[0] = c[0]; p.t[1] = c[1]; p.t[2] = c[2]; so3_exp(c + 3, p.R);
+}
+__device__ __forceinline__ void se3_to_coords(const Se3& p, double* c) {
+  c[0] = p.t[0]; c[1] = p.t[1]; c[2] = p.t[2]; so3_log(p.R, c + 3);
+}
+// Pose3Pose3: r = coords(log(q, p ∘ exp_ϵ(X)));  zt = X translation, Z = Exp(z_ω)
+__device__ __forceinline__ void residual_pose3pose3(const double* zt, const double* Z, const Se3& p, const Se3& q,
+                                                    double (&r)[6]) {
+  double Rh[9], U[9], v[3];
+  mat3_mul(p.R, Z, Rh);
+  mat3_vec(p.R, zt, v);
+  mat3_tmul(q.R, Rh, U);
+  r[0] = p.t[0] + v[0] - q.t[0]; r[1] = p.t[1] + v[1] - q.t[1]; r[2] = p.t[2] + v[2] - q.t[2];
+  so3_log(U, &r[3]);
+}
+__device__ __forceinline__ void residual_priorpose3(const Se3& m, const Se3& p, double (&r)[6]) {
+  double U[9];
+  mat3_tmul(p.R, m.R, U);
+  r[0] = m.t[0] - p.t[0]; r[1] = m.t[1] - p.t[1]; r[2] = m.t[2] - p.t[2];
+  so3_log(U, &r[3]);
+}
+__device__ __forceinline__ void se3_add_entropy(Se3& T, double spread, const double (&u)[6]) {
+  double e[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) e[k] = spread * (u[k] - 0.5);
+  double E[9], Rn[9], v[3];
+  mat3_vec(T.R, e, v);
+  T.t[0] += v[0]; T.t[1] += v[1]; T.t[2] += v[2];
+  so3_exp(e + 3, E); mat3_mul(T.R, E, Rn);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) T.R[k] = Rn[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// Nelder-Mead with Optim.jl's defaults (AdaptiveParameters, AffineSimplexer(0.025, 0.5), g_tol test
+// on sqrt(var(f)·n/(n+1)), best-vertex-or-centroid result).  The simplex is kept SORTED in fixed
+// register slots (compile-time indices only -> no scratch); ties are broken by the vertex's storage
+// slot exactly like sortperm's stable order.
+// ------------------------------------------------------------------------------------------
+template <int n>
+struct NmVertex { double f; int slot; double x[n]; };
+
+template <int n>
+__device__ __forceinline__ bool nm_less(const NmVertex<n>& a, const NmVertex<n>& b) {
+  return (a.f < b.f) || (a.f == b.f && a.slot < b.slot);
+}
+template <int n>
+__device__ __forceinline__ void nm_cswap(NmVertex<n>& a, NmVertex<n>& b) {  // ensure a <= b
+  const bool sw = nm_less<n>(b, a);
+  const double fa = sw ? b.f : a.f, fb = sw ? a.f : b.f;
+  const int sa = sw ? b.slot : a.slot, sb = sw ? a.slot : b.slot;
+  a.f = fa; b.f = fb; a.slot = sa; b.slot = sb;
+#pragma unroll
+  for (int k = 0; k < n; ++k) { const double xa = sw ? b.x[k] : a.x[k], xb = sw ? a.x[k] : b.x[k]; a.x[k] = xa; b.x[k] = xb; }
+}
+
+template <int n, class Cost>
+__device__ __forceinline__ int nelder_mead(const Cost& cost, double (&x)[n], int max_iters, double g_tol) {
+  constexpr int m = n + 1;
+  const double alpha = 1.0, beta = 1.0 + 2.0 / n, gamma = 0.75 - 1.0 / (2.0 * n), delta = 1.0 - 1.0 / n;
+  NmVertex<n> S[m];
+#pragma unroll
+  for (int i = 0; i < m; ++i) {
+#pragma unroll
+    for (int k = 0; k < n; ++k) S[i].x[k] = x[k];
+    if (i > 0) S[i].x[i - 1] = (1.0 + 0.5) * S[i].x[i - 1] + 0.025;
+    S[i].slot = i;
+    S[i].f = cost(S[i].x);
+  }
+  // full sort (insertion network)
+#pragma unroll
+  for (int i = 1; i < m; ++i)
+#pragma unroll
+    for (int j = i; j > 0; --j) nm_cswap<n>(S[j - 1], S[j]);
+
+  auto objective = [&]() {
+    double mean = 0.0;
+#pragma unroll
+    for (int i = 0; i < m; ++i) mean += S[i].f;
+    mean /= m;
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < m; ++i) { const double d = S[i].f - mean; v += d * d; }
+    v /= (m - 1);
+    return sqrt(v * ((double)n / (double)m));
+  };
+  auto centroid = [&](double (&c)[n]) {  // of all but the highest
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < m - 1; ++i) s += S[i].x[k];
+      c[k] = s * (1.0 / n);
+    }
+  };
+
+  bool converged = objective() <= g_tol;
+  int iter = 0;
+  while (!converged && iter < max_iters) {
+    ++iter;
+    double xc[n], xr[n], xt[n];
+    centroid(xc);
+    const double f_lowest = S[0].f, f_second = S[m - 2].f, f_highest = S[m - 1].f;
+#pragma unroll
+    for (int k = 0; k < n; ++k) xr[k] = xc[k] + alpha * (xc[k] - S[m - 1].x[k]);
+    const double f_reflect = cost(xr);
+    bool shrink = false;
+    if (f_reflect < f_lowest) {
+#pragma unroll
+      for (int k = 0; k < n; ++k) xt[k] = xc[k] + beta * (xr[k] - xc[k]);
+      const double f_expand = cost(xt);
+      const bool ex = f_expand < f_reflect;
+      S[m - 1].f = ex ? f_expand : f_reflect;
+#pragma unroll
+      for (int k = 0; k < n; ++k) S[m - 1].x[k] = ex ? xt[k] : xr[k];
+    } else if (f_reflect < f_second) {
+      S[m - 1].f = f_reflect;
+#pragma unroll
+      for (int k = 0; k < n; ++k) S[m - 1].x[k] = xr[k];
+    } else {
+      const bool outside = f_reflect < f_highest;
+      const double sg = outside ? gamma : -gamma;
+#pragma unroll
+      for (int k = 0; k < n; ++k) xt[k] = xc[k] + sg * (xr[k] - xc[k]);
+      const double fc = cost(xt);
+      if (fc < (outside ? f_reflect : f_highest)) {
+        S[m - 1].f = fc;
+#pragma unroll
+        for (int k = 0; k < n; ++k) S[m - 1].x[k] = xt[k];
+      } else shrink = true;
+    }
+    if (shrink) {
+#pragma unroll
+      for (int i = 1; i < m; ++i) {
+#pragma unroll
+        for (int k = 0; k < n; ++k) S[i].x[k] = S[0].x[k] + delta * (S[i].x[k] - S[0].x[k]);
+        S[i].f = cost(S[i].x);
+      }
+#pragma unroll
+      for (int i = 1; i < m; ++i)
+#pragma unroll
+        for (int j = i; j > 0; --j) nm_cswap<n>(S[j - 1], S[j]);
+    } else {
+      // only the last vertex changed: bubble it into place
+#pragma unroll
+      for (int j = m - 1; j > 0; --j) nm_cswap<n>(S[j - 1], S[j]);
+    }
+    converged = objective() <= g_tol;
+  }
+  double xc[n];
+  centroid(xc);
+  const double fcen = cost(xc);
+  const bool usec = fcen < S[0].f;
+#pragma unroll
+  for (int k = 0; k < n; ++k) x[k] = usec ? xc[k] : S[0].x[k];
+  return converged ? 0 : 1;
+}
+
+}  // namespace rome

@@ -1,0 +1,46 @@
+// rome_kernels.h -- internal interface between the C-ABI host layer and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rome {
+
+enum { kSolverClosedForm = 0, kSolverNewton = 1, kSolverNelderMead = 2 };
+
+// All pointers are DEVICE pointers.  Belief / proposal blocks are SoA: [block][dim][N].
+struct ConvArgs {
+  int n_conv;                 // C convolutions (= waves)
+  int N;                      // particles per belief
+  const int32_t* factor;      // [C] row of mu/L, or nullptr (identity)
+  const int32_t* dir;         // [C] 0: solve 2nd ("to") variable, 1: solve 1st ("from"); nullptr -> dir_all
+  const int32_t* fixed_var;   // [C] block of bel_fixed, or nullptr (identity)
+  const int32_t* target_var;  // [C] block of bel_target (start points u0), or nullptr (identity)
+  const double* mu;           // [F][dz]
+  const double* L;            // [F][dz(dz+1)/2] row-packed lower Cholesky of Σ  (bearing-range: [F][2] sigmas)
+  const double* bel_fixed;
+  const double* bel_target;
+  const double* noise;        // [C][dz][N] standard normals, or nullptr -> in-kernel Philox
+  double* out;                // [C][dt][N]
+  int32_t* status;            // [C][N] or nullptr
+  int dir_all;
+  int max_iters;
+  int cycles;
+  double tol;
+  double inflation;
+  uint64_t seed;
+  uint64_t stream_offset;
+};
+
+hipError_t launch_conv_pose2pose2(const ConvArgs& a, int solver, hipStream_t s);
+hipError_t launch_conv_bearingrange(const ConvArgs& a, int solver, hipStream_t s);
+hipError_t launch_conv_pose3pose3(const ConvArgs& a, int solver, hipStream_t s);
+hipError_t launch_sample_priorpose2(const ConvArgs& a, hipStream_t s);
+hipError_t launch_sample_priorpose3(const ConvArgs& a, hipStream_t s);
+
+hipError_t launch_residual_pose2pose2(int n, const double* z, const double* p, const double* q, double* r, hipStream_t s);
+hipError_t launch_residual_priorpose2(int n, const double* m, const double* p, double* r, hipStream_t s);
+hipError_t launch_residual_bearingrange(int n, const double* z, const double* p, int p_is_point, const double* l, double* r, hipStream_t s);
+hipError_t launch_residual_pose3pose3(int n, const double* z, const double* p, const double* q, int pts, double* r, hipStream_t s);
+hipError_t launch_residual_priorpose3(int n, const double* m, const double* p, double* r, hipStream_t s);
+
+}  // namespace rome

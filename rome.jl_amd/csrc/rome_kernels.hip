@@ -1,0 +1,635 @@
+// rome_kernels.hip -- batched factor-convolution kernels for gfx950 (MI355X).
+//
+// One convolution = approxConvBelief for one (factor, direction): N particle root-finds
+// (IncrementalInference `computeAcrossHypothesis!` -> `_solveCCWNumeric!`)
+// around the RoME residual functors (rows a2/a4/a6/a8).
+//
+// Mapping: ONE WAVEFRONT PER CONVOLUTION.  Lane l owns particles l, l+64, ... (PPL per lane, in
+// registers), so
+//   * the belief blocks are SoA [var][dim][N]: a wave reads/writes contiguous runs -> coalesced;
+//   * per-factor constants (μ, chol Σ, var ids, direction) are wave-uniform -> scalar loads / SGPRs;
+//   * the per-cycle belief statistics IIF needs for the entropy inflation (std of the N target
+//     points) are pure wave64 xor-butterflies -- no LDS round trip, no __syncthreads();
+//   * waves of a workgroup never wait for each other (Nelder-Mead trip counts differ per wave).
+// Blocks are 256 threads = 4 convolutions; blockIdx is remapped so that each XCD (own L2) works on
+// a contiguous range of the convolution table (neighbouring factors share variables).
+#include "rome_device_math.hpp"
+#include "rome_kernels.h"
+
+namespace rome {
+
+// block b runs on XCD b % 8 (observed dispatch rule; only used for L2 locality, never correctness).
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
+// ------------------------------------------------------------------------------------------
+// factor policies
+// ------------------------------------------------------------------------------------------
+struct P2P2Cost {
+  double zx, zy, cz, sz; Se2 fx; int dir;
+  __device__ __forceinline__ double operator()(const double (&x)[3]) const {
+    const Se2 T = se2_from_coords(x[0], x[1], x[2]);  // p = exp_ϵ(hat Xc)
+    double r[3];
+    if (dir == 0) residual_pose2pose2(zx, zy, cz, sz, fx, T, r);
+    else          residual_pose2pose2(zx, zy, cz, sz, T, fx, r);
+    return r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  }
+};
+
+struct P2P2 {
+  static constexpr int DF = 3, DT = 3, DZ = 3, NL = 6;
+  struct Consts { double mu[3]; double L[6]; int dir; };
+  __device__ static __forceinline__ Consts load(const ConvArgs& a, int f, int dr) {
+    Consts K;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) K.mu[k] = a.mu[3 * f + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) K.L[k] = a.L[6 * f + k];
+    K.dir = dr;
+    return K;
+  }
+  __device__ static __forceinline__ void measurement(const Consts& K, const double (&xi)[3], double (&z)[3]) {
+    z[0] = K.mu[0] + K.L[0] * xi[0];
+    z[1] = K.mu[1] + K.L[1] * xi[0] + K.L[2] * xi[1];
+    z[2] = K.mu[2] + K.L[3] * xi[0] + K.L[4] * xi[1] + K.L[5] * xi[2];
+  }
+  __device__ static __forceinline__ void canonical(double (&t)[3]) { t[2] = wrap_pi(t[2]); }
+  __device__ static __forceinline__ bool needs_cycles(int solver, const Consts&) { return solver != kSolverClosedForm; }
+
+  template <int PPL>
+  __device__ static __forceinline__ double spread(const double (&t)[PPL][3], const bool (&act)[PPL], int N) {
+    double s[4] = {0, 0, 0, 0};
+    double sn[PPL], cs[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      sincos(t[k][2], &sn[k], &cs[k]);
+      if (act[k]) { s[0] += t[k][0]; s[1] += t[k][1]; s[2] += sn[k]; s[3] += cs[k]; }
+    }
+    wave_sum_n<4>(s);
+    const double mx = s[0] / N, my = s[1] / N, mt = atan2(s[2], s[3]);
+    double sm, cm; sincos(mt, &sm, &cm);
+    double v[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      const double dx = t[k][0] - mx, dy = t[k][1] - my;
+      const double dt = atan2(cm * sn[k] - sm * cs[k], cm * cs[k] + sm * sn[k]);
+      if (act[k]) { v[0] += dx * dx; v[1] += dy * dy; v[2] += dt * dt; }
+    }
+    wave_sum_n<3>(v);
+    const double den = N > 1 ? (double)(N - 1) : 1.0;
+    return (sqrt(v[0] / den) + sqrt(v[1] / den) + sqrt(v[2] / den)) / 3.0;
+  }
+  __device__ static __forceinline__ void add_entropy(double (&t)[3], double spread, uint64_t seed, uint64_t stream,
+                                                     uint32_t i, int cyc) {
+    double u[3];
+    rng_entropy<3>(seed, stream, i, cyc, u);
+    se2_add_entropy(t, spread, u);
+    t[2] = wrap_pi(t[2]);
+  }
+
+  template <int SOLVER>
+  __device__ static __forceinline__ int solve(const Consts& K, const double (&z)[3], const double (&fxc)[3],
+                                              double (&t)[3], int max_iters, double tol) {
+    int st = 0;
+    if constexpr (SOLVER == kSolverClosedForm) {
+      if (K.dir == 0) {
+        double s, c; sincos(fxc[2], &s, &c);
+        t[0] = fxc[0] + c * z[0] - s * z[1]; t[1] = fxc[1] + s * z[0] + c * z[1]; t[2] = fxc[2] + z[2];
+      } else {
+        const double th = fxc[2] - z[2];
+        double s, c; sincos(th, &s, &c);
+        t[0] = fxc[0] - (c * z[0] - s * z[1]); t[1] = fxc[1] - (s * z[0] + c * z[1]); t[2] = th;
+      }
+    } else {
+      const Se2 F = se2_from_coords(fxc[0], fxc[1], fxc[2]);
+      double sz, cz; sincos(z[2], &sz, &cz);
+      if constexpr (SOLVER == kSolverNewton) {
+        st = 1;
+        for (int it = 0; it < max_iters; ++it) {
+          const Se2 T = se2_from_coords(t[0], t[1], t[2]);
+          double r[3];
+          if (K.dir == 0) residual_pose2pose2(z[0], z[1], cz, sz, F, T, r);
+          else            residual_pose2pose2(z[0], z[1], cz, sz, T, F, r);
+          if (fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2]))) <= tol) { st = 0; break; }
+          if (K.dir == 0) { t[0] += r[0]; t[1] += r[1]; t[2] += r[2]; }
+          else {
+            const double J13 = -T.s * z[0] - T.c * z[1], J23 = T.c * z[0] - T.s * z[1];
+            const double dth = -r[2];
+            t[0] += -r[0] - J13 * dth; t[1] += -r[1] - J23 * dth; t[2] += dth;
+          }
+        }
+      } else {
+        P2P2Cost cost{z[0], z[1], cz, sz, F, K.dir};
+        st = nelder_mead<3>(cost, t, max_iters, tol);
+      }
+    }
+    t[2] = wrap_pi(t[2]);
+    return st;
+  }
+};
+
+// ---- Pose2Point2BearingRange; DIR 0: pose fixed -> landmark target, DIR 1: landmark fixed -> pose target
+template <int DIR>
+struct BRCost {
+  double b, rho; double fx[3];
+  __device__ __forceinline__ double operator()(const double (&x)[DIR == 0 ? 2 : 3]) const {
+    double r[2];
+    if constexpr (DIR == 0) {
+      const Se2 P = se2_from_coords(fx[0], fx[1], fx[2]);
+      residual_bearingrange(b, rho, P, x[0], x[1], r);
+    } else {
+      const Se2 P = se2_from_coords(x[0], x[1], x[2]);
+      residual_bearingrange(b, rho, P, fx[0], fx[1], r);
+    }
+    return r[0] * r[0] + r[1] * r[1];
+  }
+};
+
+template <int DIR>
+struct BR {
+  static constexpr int DF = DIR == 0 ? 3 : 2, DT = DIR == 0 ? 2 : 3, DZ = 2;
+  struct Consts { double mu[2]; double sg[2]; };
+  __device__ static __forceinline__ Consts load(const ConvArgs& a, int f, int) {
+    Consts K; K.mu[0] = a.mu[2 * f]; K.mu[1] = a.mu[2 * f + 1]; K.sg[0] = a.L[2 * f]; K.sg[1] = a.L[2 * f + 1];
+    return K;
+  }
+  __device__ static __forceinline__ void measurement(const Consts& K, const double (&xi)[2], double (&z)[2]) {
+    z[0] = K.mu[0] + K.sg[0] * xi[0];  // rand(bearing)  BearingRange2D.jl:23
+    z[1] = K.mu[1] + K.sg[1] * xi[1];  // rand(range)
+  }
+  __device__ static __forceinline__ void canonical(double (&t)[DT]) { if constexpr (DT == 3) t[2] = wrap_pi(t[2]); }
+  __device__ static __forceinline__ bool needs_cycles(int solver, const Consts&) {
+    return !(solver == kSolverClosedForm && DIR == 0);
+  }
+  template <int PPL>
+  __device__ static __forceinline__ double spread(const double (&t)[PPL][DT], const bool (&act)[PPL], int N) {
+    if constexpr (DT == 3) return P2P2::spread<PPL>(t, act, N);
+    else {
+      double s[2] = {0, 0};
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) if (act[k]) { s[0] += t[k][0]; s[1] += t[k][1]; }
+      wave_sum_n<2>(s);
+      const double mx = s[0] / N, my = s[1] / N;
+      double v[2] = {0, 0};
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) { const double dx = t[k][0] - mx, dy = t[k][1] - my; if (act[k]) { v[0] += dx * dx; v[1] += dy * dy; } }
+      wave_sum_n<2>(v);
+      const double den = N > 1 ? (double)(N - 1) : 1.0;
+      return (sqrt(v[0] / den) + sqrt(v[1] / den)) / 2.0;
+    }
+  }
+  __device__ static __forceinline__ void add_entropy(double (&t)[DT], double spread, uint64_t seed, uint64_t stream,
+                                                     uint32_t i, int cyc) {
+    double u[DT];
+    rng_entropy<DT>(seed, stream, i, cyc, u);
+    if constexpr (DT == 3) { se2_add_entropy(t, spread, u); t[2] = wrap_pi(t[2]); }
+    else { t[0] += spread * (u[0] - 0.5); t[1] += spread * (u[1] - 0.5); }
+  }
+  template <int SOLVER>
+  __device__ static __forceinline__ int solve(const Consts&, const double (&z)[2], const double (&fx)[DF],
+                                              double (&t)[DT], int max_iters, double tol) {
+    int st = 0;
+    if constexpr (SOLVER == kSolverClosedForm) {
+      if constexpr (DIR == 0) {
+        double s, c; sincos(fx[2] + z[0], &s, &c);
+        t[0] = fx[0] + z[1] * c; t[1] = fx[1] + z[1] * s;
+      } else {
+        const double dx = fx[0] - t[0], dy = fx[1] - t[1];
+        const double n = sqrt(dx * dx + dy * dy);
+        const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
+        t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = atan2(uy, ux) - z[0];
+      }
+    } else if constexpr (SOLVER == kSolverNewton) {
+      st = 1;
+      for (int it = 0; it < max_iters; ++it) {
+        double r[2];
+        if constexpr (DIR == 0) {
+          const Se2 P = se2_from_coords(fx[0], fx[1], fx[2]);
+          residual_bearingrange(z[0], z[1], P, t[0], t[1], r);
+          if (fmax(fabs(r[0]), fabs(r[1])) <= tol) { st = 0; break; }
+          const double dx = t[0] - fx[0], dy = t[1] - fx[1];
+          const double plx = P.c * dx + P.s * dy, ply = -P.s * dx + P.c * dy;
+          const double n = sqrt(plx * plx + ply * ply), phi = atan2(ply, plx);
+          const double nn = n + r[1];
+          double sa, ca; sincos(phi + r[0], &sa, &ca);
+          const double qx = nn * ca, qy = nn * sa;
+          t[0] = fx[0] + P.c * qx - P.s * qy; t[1] = fx[1] + P.s * qx + P.c * qy;
+        } else {
+          const Se2 P = se2_from_coords(t[0], t[1], t[2]);
+          residual_bearingrange(z[0], z[1], P, fx[0], fx[1], r);
+          if (fmax(fabs(r[0]), fabs(r[1])) <= tol) { st = 0; break; }
+          const double dx = fx[0] - t[0], dy = fx[1] - t[1];
+          const double plx = P.c * dx + P.s * dy, ply = -P.s * dx + P.c * dy;
+          const double n2 = plx * plx + ply * ply, n = sqrt(n2);
+          if (n < 1e-300) { t[0] += 1e-6; continue; }
+          const double y0 = -r[0] / (1.0 / n2 + 1.0), y1 = -r[1];
+          const double ax = ply * y0 / n2 - plx * y1 / n;
+          const double ay = -plx * y0 / n2 - ply * y1 / n;
+          t[0] += -(P.c * ax - P.s * ay); t[1] += -(P.s * ax + P.c * ay); t[2] += y0;
+        }
+      }
+    } else {
+      BRCost<DIR> cost{z[0], z[1], {fx[0], fx[1], DF == 3 ? fx[DF - 1] : 0.0}};
+      st = nelder_mead<DT>(cost, t, max_iters, tol);
+    }
+    if constexpr (DT == 3) t[2] = wrap_pi(t[2]);
+    return st;
+  }
+};
+
+// ---- Pose3Pose3 (belief blocks hold coordinates (t, ω); points are rebuilt per solve)
+struct P3P3Cost {
+  double zt[3]; double Z[9]; Se3 F; int dir;
+  __device__ __forceinline__ double operator()(const double (&x)[6]) const {
+    Se3 T; se3_from_coords(x, T);
+    double r[6];
+    if (dir == 0) residual_pose3pose3(zt, Z, F, T, r); else residual_pose3pose3(zt, Z, T, F, r);
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += r[k] * r[k];
+    return s;
+  }
+};
+
+struct P3P3 {
+  static constexpr int DF = 6, DT = 6, DZ = 6;
+  struct Consts { double mu[6]; const double* L; int dir; };
+  __device__ static __forceinline__ Consts load(const ConvArgs& a, int f, int dr) {
+    Consts K;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) K.mu[k] = a.mu[6 * f + k];
+    K.L = a.L + 21 * (size_t)f;  // 21 wave-uniform doubles, read through the scalar cache at use
+    K.dir = dr;
+    return K;
+  }
+  __device__ static __forceinline__ void measurement(const Consts& K, const double (&xi)[6], double (&z)[6]) {
+    int p = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      double s = K.mu[k];
+#pragma unroll
+      for (int j = 0; j <= k; ++j) s += K.L[p++] * xi[j];
+      z[k] = s;
+    }
+  }
+  __device__ static __forceinline__ void canonical(double (&t)[6]) { Se3 P; se3_from_coords(t, P); se3_to_coords(P, t); }
+  __device__ static __forceinline__ bool needs_cycles(int solver, const Consts&) { return solver != kSolverClosedForm; }
+
+  template <int PPL>
+  __device__ static __forceinline__ double spread(const double (&t)[PPL][6], const bool (&act)[PPL], int N) {
+    double st[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) if (act[k]) { st[0] += t[k][0]; st[1] += t[k][1]; st[2] += t[k][2]; }
+    wave_sum_n<3>(st);
+    const double mt[3] = {st[0] / N, st[1] / N, st[2] / N};
+    // rotation mean: particle 0 refined by 2 Karcher steps
+    double Rm[9];
+    {
+      double w0[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w0[k] = __shfl(t[0][3 + k], 0, 64);
+      so3_exp(w0, Rm);
+    }
+    for (int it = 0; it < 2; ++it) {
+      double acc[3] = {0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        double R[9], U[9], d[3];
+        so3_exp(&t[k][3], R); mat3_tmul(Rm, R, U); so3_log(U, d);
+        if (act[k]) { acc[0] += d[0]; acc[1] += d[1]; acc[2] += d[2]; }
+      }
+      wave_sum_n<3>(acc);
+      const double dm[3] = {acc[0] / N, acc[1] / N, acc[2] / N};
+      double E[9], Tn[9];
+      so3_exp(dm, E); mat3_mul(Rm, E, Tn);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rm[k] = Tn[k];
+    }
+    double v[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      double R[9], U[9], d[3];
+      so3_exp(&t[k][3], R); mat3_tmul(Rm, R, U); so3_log(U, d);
+      if (act[k]) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const double e = t[k][j] - mt[j]; v[j] += e * e; v[3 + j] += d[j] * d[j]; }
+      }
+    }
+    wave_sum_n<6>(v);
+    const double den = N > 1 ? (double)(N - 1) : 1.0;
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s += sqrt(v[j] / den);
+    return s / 6.0;
+  }
+  __device__ static __forceinline__ void add_entropy(double (&t)[6], double spread, uint64_t seed, uint64_t stream,
+                                                     uint32_t i, int cyc) {
+    double u[6];
+    rng_entropy<6>(seed, stream, i, cyc, u);
+    Se3 T; se3_from_coords(t, T);
+    se3_add_entropy(T, spread, u);
+    se3_to_coords(T, t);
+  }
+  template <int SOLVER>
+  __device__ static __forceinline__ int solve(const Consts& K, const double (&z)[6], const double (&fxc)[6],
+                                              double (&t)[6], int max_iters, double tol) {
+    int st = 0;
+    Se3 F, T;
+    se3_from_coords(fxc, F);
+    double Z[9];
+    so3_exp(&z[3], Z);
+    if constexpr (SOLVER == kSolverClosedForm) {
+      double v[3];
+      if (K.dir == 0) {
+        mat3_mul(F.R, Z, T.R); mat3_vec(F.R, z, v);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) T.t[k] = F.t[k] + v[k];
+      } else {
+        double Zt[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) Zt[i + 3 * j] = Z[j + 3 * i];
+        mat3_mul(F.R, Zt, T.R); mat3_vec(T.R, z, v);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) T.t[k] = F.t[k] - v[k];
+      }
+      se3_to_coords(T, t);
+    } else if constexpr (SOLVER == kSolverNewton) {
+      se3_from_coords(t, T);
+      st = 1;
+      for (int it = 0; it < max_iters; ++it) {
+        double r[6];
+        if (K.dir == 0) residual_pose3pose3(z, Z, F, T, r); else residual_pose3pose3(z, Z, T, F, r);
+        double m = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m = fmax(m, fabs(r[k]));
+        if (m <= tol) { st = 0; break; }
+        double E[9], Rn[9];
+        if (K.dir == 0) {
+          so3_exp(&r[3], E); mat3_mul(T.R, E, Rn);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) T.R[k] = Rn[k];
+          T.t[0] += r[0]; T.t[1] += r[1]; T.t[2] += r[2];
+        } else {
+          double d[3], v[3];
+          mat3_vec(Z, &r[3], d); d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2];
+          so3_exp(d, E); mat3_mul(T.R, E, Rn);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) T.R[k] = Rn[k];
+          mat3_vec(T.R, z, v);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) T.t[k] = F.t[k] - v[k];
+        }
+      }
+      se3_to_coords(T, t);
+    } else {
+      P3P3Cost cost;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cost.zt[k] = z[k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cost.Z[k] = Z[k];
+      cost.F = F; cost.dir = K.dir;
+      // X0c = vee(log(ϵ,u0)) : t is already canonical (Exp/Log) coordinates
+      st = nelder_mead<6>(cost, t, max_iters, tol);
+      se3_from_coords(t, T); se3_to_coords(T, t);
+    }
+    return st;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// the convolution kernel
+// ------------------------------------------------------------------------------------------
+template <class FP, int SOLVER, int PPL>
+__global__ void __launch_bounds__(256) k_conv(const ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int c = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (int)(threadIdx.x >> 6));
+  if (c >= a.n_conv) return;
+  const int N = a.N;
+  const int f = a.factor ? a.factor[c] : c;
+  const int dr = a.dir ? a.dir[c] : a.dir_all;
+  const int fv = a.fixed_var ? a.fixed_var[c] : c;
+  const int tv = a.target_var ? a.target_var[c] : c;
+  const typename FP::Consts K = FP::load(a, f, dr);
+  const double* __restrict__ fb = a.bel_fixed + (size_t)fv * FP::DF * N;
+  const double* __restrict__ tb = a.bel_target + (size_t)tv * FP::DT * N;
+  double* __restrict__ ob = a.out + (size_t)c * FP::DT * N;
+  const uint64_t stream = a.stream_offset + (uint64_t)c;
+
+  double fx[PPL][FP::DF], t[PPL][FP::DT], z[PPL][FP::DZ];
+  bool act[PPL];
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const int i = lane + 64 * k;
+    act[k] = i < N;
+    const int ii = act[k] ? i : 0;  // idle lanes shadow particle 0 (keeps the math finite, never stored)
+#pragma unroll
+    for (int d = 0; d < FP::DF; ++d) fx[k][d] = fb[d * N + ii];
+#pragma unroll
+    for (int d = 0; d < FP::DT; ++d) t[k][d] = tb[d * N + ii];
+    double xi[FP::DZ];
+    if (a.noise) {
+      const double* nb = a.noise + (size_t)c * FP::DZ * N;
+#pragma unroll
+      for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
+    } else {
+      rng_normals<FP::DZ>(a.seed, stream, (uint32_t)ii, xi);
+    }
+    FP::measurement(K, xi, z[k]);
+    FP::canonical(t[k]);
+  }
+
+  int st[PPL];
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) st[k] = 0;
+
+  const bool cyc_on = FP::needs_cycles(SOLVER, K);
+  const int ncyc = cyc_on ? (a.cycles < 1 ? 1 : a.cycles) : 1;
+  for (int cyc = 0; cyc < ncyc; ++cyc) {
+    double spread = 0.0;
+    if (cyc_on && a.inflation > 0.0 && N > 1) spread = a.inflation * FP::template spread<PPL>(t, act, N);
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      if (act[k]) {
+        if (spread > 0.0) FP::add_entropy(t[k], spread, a.seed, stream, (uint32_t)(lane + 64 * k), cyc);
+        st[k] = FP::template solve<SOLVER>(K, z[k], fx[k], t[k], a.max_iters, a.tol);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const int i = lane + 64 * k;
+    if (act[k]) {
+#pragma unroll
+      for (int d = 0; d < FP::DT; ++d) ob[d * N + i] = t[k][d];
+      if (a.status) a.status[(size_t)c * N + i] = st[k];
+    }
+  }
+}
+
+// ---- prior sampling: out = coords(exp_ϵ(hat(μ + Lξ))) ; one wave per prior
+template <int D, int PPL>
+__global__ void __launch_bounds__(256) k_sample_prior(const ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int c = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (c >= a.n_conv) return;
+  const int N = a.N;
+  const int f = a.factor ? a.factor[c] : c;
+  constexpr int NL = D * (D + 1) / 2;
+  const double* mu = a.mu + (size_t)D * f;
+  const double* L = a.L + (size_t)NL * f;
+  double* ob = a.out + (size_t)c * D * N;
+  const uint64_t stream = a.stream_offset + (uint64_t)c;
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const int i = lane + 64 * k;
+    if (i < N) {
+      double xi[D], zc[D];
+      if (a.noise) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) xi[d] = a.noise[(size_t)c * D * N + d * N + i];
+      } else rng_normals<D>(a.seed, stream, (uint32_t)i, xi);
+      int p = 0;
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        double s = mu[r];
+#pragma unroll
+        for (int j = 0; j <= r; ++j) s += L[p++] * xi[j];
+        zc[r] = s;
+      }
+      if constexpr (D == 3) zc[2] = wrap_pi(zc[2]);
+      else { Se3 P; se3_from_coords(zc, P); se3_to_coords(P, zc); }
+#pragma unroll
+      for (int d = 0; d < D; ++d) ob[d * N + i] = zc[d];
+    }
+  }
+}
+
+// ---- residual-only kernels (rows of AoS coordinates), used by the KAT entry points
+__global__ void k_residual_pose2pose2(int n, const double* z, const double* p, const double* q, double* r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Se2 P = se2_from_coords(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+  const Se2 Q = se2_from_coords(q[3 * i], q[3 * i + 1], q[3 * i + 2]);
+  double sz, cz; sincos(z[3 * i + 2], &sz, &cz);
+  double rr[3];
+  residual_pose2pose2(z[3 * i], z[3 * i + 1], cz, sz, P, Q, rr);
+  r[3 * i] = rr[0]; r[3 * i + 1] = rr[1]; r[3 * i + 2] = rr[2];
+}
+__global__ void k_residual_priorpose2(int n, const double* m, const double* p, double* r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Se2 M = se2_from_coords(m[3 * i], m[3 * i + 1], m[3 * i + 2]);
+  const Se2 P = se2_from_coords(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+  double rr[3];
+  residual_priorpose2(M, P, rr);
+  r[3 * i] = rr[0]; r[3 * i + 1] = rr[1]; r[3 * i + 2] = rr[2];
+}
+// p_is_point: 0 -> p rows are coords (x,y,θ); 1 -> native points [tx,ty,R11,R21,R12,R22]
+__global__ void k_residual_bearingrange(int n, const double* z, const double* p, int p_is_point, const double* l, double* r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Se2 P;
+  if (p_is_point) { P.x = p[6 * i]; P.y = p[6 * i + 1]; P.c = p[6 * i + 2]; P.s = p[6 * i + 3]; }
+  else P = se2_from_coords(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+  double rr[2];
+  residual_bearingrange(z[2 * i], z[2 * i + 1], P, l[2 * i], l[2 * i + 1], rr);
+  r[2 * i] = rr[0]; r[2 * i + 1] = rr[1];
+}
+// p,q rows are native points (12 doubles: t, R col-major) when pts != 0, else coords (6)
+__global__ void k_residual_pose3pose3(int n, const double* z, const double* p, const double* q, int pts, double* r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Se3 P, Q;
+  if (pts) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { P.t[k] = p[12 * i + k]; Q.t[k] = q[12 * i + k]; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { P.R[k] = p[12 * i + 3 + k]; Q.R[k] = q[12 * i + 3 + k]; }
+  } else { se3_from_coords(p + 6 * i, P); se3_from_coords(q + 6 * i, Q); }
+  double Z[9], rr[6];
+  so3_exp(z + 6 * i + 3, Z);
+  residual_pose3pose3(z + 6 * i, Z, P, Q, rr);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) r[6 * i + k] = rr[k];
+}
+__global__ void k_residual_priorpose3(int n, const double* m, const double* p, double* r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Se3 M, P;
+  se3_from_coords(m + 6 * i, M); se3_from_coords(p + 6 * i, P);
+  double rr[6];
+  residual_priorpose3(M, P, rr);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) r[6 * i + k] = rr[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+template <class FP, int SOLVER>
+static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
+  const int nb = (a.n_conv + 3) / 4;
+  if (nb == 0) return hipSuccess;
+  if (a.N <= 64)       hipLaunchKernelGGL((k_conv<FP, SOLVER, 1>), dim3(nb), dim3(256), 0, s, a);
+  else if (a.N <= 128) hipLaunchKernelGGL((k_conv<FP, SOLVER, 2>), dim3(nb), dim3(256), 0, s, a);
+  else if (a.N <= 256) hipLaunchKernelGGL((k_conv<FP, SOLVER, 4>), dim3(nb), dim3(256), 0, s, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+template <class FP>
+static hipError_t launch_solver(const ConvArgs& a, int solver, hipStream_t s) {
+  switch (solver) {
+    case kSolverClosedForm: return launch_ppl<FP, kSolverClosedForm>(a, s);
+    case kSolverNewton:     return launch_ppl<FP, kSolverNewton>(a, s);
+    case kSolverNelderMead: return launch_ppl<FP, kSolverNelderMead>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_conv_pose2pose2(const ConvArgs& a, int solver, hipStream_t s) { return launch_solver<P2P2>(a, solver, s); }
+hipError_t launch_conv_pose3pose3(const ConvArgs& a, int solver, hipStream_t s) { return launch_solver<P3P3>(a, solver, s); }
+hipError_t launch_conv_bearingrange(const ConvArgs& a, int solver, hipStream_t s) {
+  return a.dir_all == 0 ? launch_solver<BR<0>>(a, solver, s) : launch_solver<BR<1>>(a, solver, s);
+}
+template <int D>
+static hipError_t launch_prior(const ConvArgs& a, hipStream_t s) {
+  const int nb = (a.n_conv + 3) / 4;
+  if (nb == 0) return hipSuccess;
+  if (a.N <= 64)       hipLaunchKernelGGL((k_sample_prior<D, 1>), dim3(nb), dim3(256), 0, s, a);
+  else if (a.N <= 128) hipLaunchKernelGGL((k_sample_prior<D, 2>), dim3(nb), dim3(256), 0, s, a);
+  else if (a.N <= 256) hipLaunchKernelGGL((k_sample_prior<D, 4>), dim3(nb), dim3(256), 0, s, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+hipError_t launch_sample_priorpose2(const ConvArgs& a, hipStream_t s) { return launch_prior<3>(a, s); }
+hipError_t launch_sample_priorpose3(const ConvArgs& a, hipStream_t s) { return launch_prior<6>(a, s); }
+
+static inline dim3 rows_grid(int n) { return dim3((n + 255) / 256); }
+hipError_t launch_residual_pose2pose2(int n, const double* z, const double* p, const double* q, double* r, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_residual_pose2pose2, rows_grid(n), dim3(256), 0, s, n, z, p, q, r);
+  return hipGetLastError();
+}
+hipError_t launch_residual_priorpose2(int n, const double* m, const double* p, double* r, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_residual_priorpose2, rows_grid(n), dim3(256), 0, s, n, m, p, r);
+  return hipGetLastError();
+}
+hipError_t launch_residual_bearingrange(int n, const double* z, const double* p, int p_is_point, const double* l, double* r, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_residual_bearingrange, rows_grid(n), dim3(256), 0, s, n, z, p, p_is_point, l, r);
+  return hipGetLastError();
+}
+hipError_t launch_residual_pose3pose3(int n, const double* z, const double* p, const double* q, int pts, double* r, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_residual_pose3pose3, rows_grid(n), dim3(256), 0, s, n, z, p, q, pts, r);
+  return hipGetLastError();
+}
+hipError_t launch_residual_priorpose3(int n, const double* m, const double* p, double* r, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_residual_priorpose3, rows_grid(n), dim3(256), 0, s, n, m, p, r);
+  return hipGetLastError();
+}
+
+}  // namespace rome

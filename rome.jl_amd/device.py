@@ -1,0 +1,120 @@
+"""Device-resident belief store + graph-indexed convolution sweeps (torch = device memory/streams only).
+
+One `sweep_*` call = one kernel launch over a whole table of (factor, direction) convolutions with
+the beliefs staying in HBM -- what a clique/whole-graph pass of `solveTree!`
+(examples/ManhattanDatasetBatch.jl:43; IIF upGibbsCliqueDensity -> approxConvBelief) issues.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .factors import Pose2, Point2, Pose3
+from .graph import PackedGraph
+from .api import cholesky_lower
+
+
+def _require_torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("rome_jl_amd.device needs a HIP device (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+    return torch
+
+
+class DeviceGraph:
+    def __init__(self, fg_or_packed, device="cuda:0", ctx=None):
+        torch = _require_torch_cuda()
+        self.torch = torch
+        self.device = torch.device(device)
+        pk = fg_or_packed if isinstance(fg_or_packed, PackedGraph) else PackedGraph(fg_or_packed)
+        self.packed = pk
+        self.N = pk.N
+        self.ctx = ctx or _lib.Context(self.device.index or 0)
+        self._lib = _lib.load()
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=self.device)
+        f64, i32 = torch.float64, torch.int32
+        self.bel = {Pose2: torch.zeros((len(pk.labels[Pose2]), 3, self.N), dtype=f64, device=self.device),
+                    Point2: torch.zeros((len(pk.labels[Point2]), 2, self.N), dtype=f64, device=self.device),
+                    Pose3: torch.zeros((len(pk.labels[Pose3]), 6, self.N), dtype=f64, device=self.device)}
+        self.tab = {}
+        for name, tab, d in (("p2p2", pk.p2p2, 3), ("p3p3", pk.p3p3, 6)):
+            if tab["F"] == 0:
+                continue
+            factor, dr, fixed, target = PackedGraph.conv_table(tab)
+            self.tab[name] = dict(F=tab["F"], C=2 * tab["F"], mu=t(tab["mu"], f64), L=t(cholesky_lower(tab["cov"]), f64),
+                                  factor=t(factor, i32), dir=t(dr, i32), fixed=t(fixed, i32), target=t(target, i32))
+        if pk.br["F"]:
+            b = pk.br
+            self.tab["br"] = dict(F=b["F"], mu=t(b["mu"], f64), sigma=t(b["sigma"], f64), pose=t(b["pose"], i32), point=t(b["point"], i32))
+        for name, tab, d in (("prior2", pk.prior2, 3), ("prior3", pk.prior3, 6)):
+            if tab["F"]:
+                self.tab[name] = dict(F=tab["F"], mu=t(tab["mu"], f64), L=t(cholesky_lower(tab["cov"]), f64), var=t(tab["var"], i32))
+
+    # ---- belief store ----
+    def upload_beliefs(self, fg):
+        for vt in (Pose2, Point2, Pose3):
+            if len(self.packed.labels[vt]):
+                self.bel[vt].copy_(self.torch.as_tensor(self.packed.beliefs(fg, vt)))
+
+    def _bind_stream(self):
+        self.ctx.set_stream(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _ptr(x):
+        return None if x is None else C.c_void_p(x.data_ptr())
+
+    def _launch(self, fn, opts, **kw):
+        self._bind_stream()
+        cd = _lib.ConvDev()
+        for k, v in kw.items():
+            setattr(cd, k, v if isinstance(v, int) else (v.data_ptr() if v is not None else None))
+        _lib.check(fn(self.ctx.handle, C.byref(opts), C.byref(cd)), self.ctx.handle)
+
+    # ---- sweeps ----
+    def sweep_pose2pose2(self, opts, out=None, noise=None, status=None, conv_slice=None):
+        """All (factor, direction) Pose2Pose2 convolutions -> proposals [2F, 3, N] (conv 2f+dir)."""
+        tb = self.tab["p2p2"]
+        lo, hi = (0, tb["C"]) if conv_slice is None else conv_slice
+        n = hi - lo
+        if out is None:
+            out = self.torch.empty((n, 3, self.N), dtype=self.torch.float64, device=self.device)
+        o = _lib.Opts.from_buffer_copy(opts); o.stream_offset = opts.stream_offset + lo
+        self._launch(self._lib.rome_conv_pose2pose2_dev, o, n_conv=n, dir_all=0,
+                     factor=tb["factor"][lo:hi], dir=tb["dir"][lo:hi], fixed_var=tb["fixed"][lo:hi], target_var=tb["target"][lo:hi],
+                     mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Pose2],
+                     noise=noise, out=out, status=status)
+        return out
+
+    def sweep_pose3pose3(self, opts, out=None, noise=None, status=None):
+        tb = self.tab["p3p3"]
+        if out is None:
+            out = self.torch.empty((tb["C"], 6, self.N), dtype=self.torch.float64, device=self.device)
+        self._launch(self._lib.rome_conv_pose3pose3_dev, opts, n_conv=tb["C"], dir_all=0,
+                     factor=tb["factor"], dir=tb["dir"], fixed_var=tb["fixed"], target_var=tb["target"],
+                     mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose3], bel_target=self.bel[Pose3],
+                     noise=noise, out=out, status=status)
+        return out
+
+    def sweep_bearingrange(self, opts, direction, out=None, noise=None, status=None):
+        """direction 0: poses -> landmark proposals [F,2,N]; 1: landmarks -> pose proposals [F,3,N]."""
+        tb = self.tab["br"]
+        dt = 2 if direction == 0 else 3
+        if out is None:
+            out = self.torch.empty((tb["F"], dt, self.N), dtype=self.torch.float64, device=self.device)
+        fixed, target = (tb["pose"], tb["point"]) if direction == 0 else (tb["point"], tb["pose"])
+        bf, bt = (self.bel[Pose2], self.bel[Point2]) if direction == 0 else (self.bel[Point2], self.bel[Pose2])
+        self._launch(self._lib.rome_conv_pose2point2br_dev, opts, n_conv=tb["F"], dir_all=int(direction),
+                     factor=None, dir=None, fixed_var=fixed, target_var=target, mu=tb["mu"], L=tb["sigma"],
+                     bel_fixed=bf, bel_target=bt, noise=noise, out=out, status=status)
+        return out
+
+    def sample_priors(self, opts, kind="prior2", out=None, noise=None):
+        tb = self.tab[kind]
+        d = 3 if kind == "prior2" else 6
+        if out is None:
+            out = self.torch.empty((tb["F"], d, self.N), dtype=self.torch.float64, device=self.device)
+        fn = self._lib.rome_sample_priorpose2_dev if kind == "prior2" else self._lib.rome_sample_priorpose3_dev
+        self._launch(fn, opts, n_conv=tb["F"], dir_all=0, factor=None, dir=None, fixed_var=None, target_var=None,
+                     mu=tb["mu"], L=tb["L"], bel_fixed=None, bel_target=None, noise=noise, out=out, status=None)
+        return out

@@ -1,0 +1,368 @@
+"""Factor-graph container, g2o import and synthetic g2o-shaped generators (host side).
+
+Mirrors the slice of the DistributedFactorGraphs / RoME API the hot path is driven through:
+  initfg / addVariable! / addFactor! / initVariable! / getVal      (used all over test/*.jl)
+  importG2o, parseG2oInstruction!                                  src/services/g2oParser.jl:39-171
+  generateGraph_Hexagonal / generateGraph_Circle                   src/canonical/GenerateCircular.jl:31-94
+and packs a graph into the flat factor / convolution tables the device sweep consumes.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from .factors import (MvNormal, Normal, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
+                      Pose3Pose3, PriorPose3)
+
+
+class FactorGraph:
+    def __init__(self, N=100):
+        self.N = int(N)                      # getSolverParams(fg).N
+        self.variables = OrderedDict()       # label -> vartype
+        self.factors = []                    # (label, [var labels], factor)
+        self.vals = {}                       # label -> (dim, N) coordinates (belief particles)
+
+    # -- DFG-style API --
+    def addVariable(self, label, vartype):
+        if label in self.variables:
+            raise KeyError("variable %s already exists" % label)
+        self.variables[label] = vartype
+        return label
+
+    def exists(self, label):
+        return label in self.variables
+
+    def ls(self):
+        return list(self.variables)
+
+    def addFactor(self, labels, factor):
+        labels = list(labels)
+        for l, t in zip(labels, factor.variable_types):
+            if l not in self.variables:
+                raise KeyError("addFactor: unknown variable %s" % l)
+            if self.variables[l] is not t:
+                raise TypeError("addFactor: %s expects %s for %s" % (type(factor).__name__, t, l))
+        if len(labels) != len(factor.variable_types):
+            raise ValueError("addFactor: wrong number of variables")
+        flabel = "".join(labels) + "f%d" % (1 + sum(1 for f in self.factors if f[1] == labels))
+        self.factors.append((flabel, labels, factor))
+        return flabel
+
+    def getFactor(self, flabel):
+        for f in self.factors:
+            if f[0] == flabel:
+                return f
+        raise KeyError(flabel)
+
+    def initVariable(self, label, coords):
+        """coords: (dim, N) particle coordinates."""
+        t = self.variables[label]
+        a = np.ascontiguousarray(coords, dtype=np.float64)
+        if a.shape != (t.dim, self.N):
+            raise ValueError("initVariable(%s): expected %s, got %s" % (label, (t.dim, self.N), a.shape))
+        self.vals[label] = a
+
+    def getVal(self, label):
+        return self.vals[label]
+
+    def isInitialized(self, label):
+        return label in self.vals
+
+
+def initfg(N=100):
+    return FactorGraph(N)
+
+
+# ------------------------------------------------------------------------------------------ g2o
+def importG2o(path):
+    """Every line split on blanks (src/services/g2oParser.jl:39-49)."""
+    out = []
+    with open(path) as f:
+        for ln in f:
+            pieces = ln.split()
+            if pieces:
+                out.append(pieces)
+    return out
+
+
+def parseG2oInstruction(fg, ins):
+    """EDGE_SE2 / VERTEX_SE2 semantics of src/services/g2oParser.jl:62-122:
+    μ = fields 4-6, Λ from the upper triangle (fields 7-12), Σ = inv(Λ) symmetrised."""
+    if ins[0] == "VERTEX_SE2":
+        lbl = "x" + ins[1]
+        if not fg.exists(lbl):
+            fg.addVariable(lbl, Pose2)
+        fg.vertex_init = getattr(fg, "vertex_init", {})
+        fg.vertex_init[lbl] = np.array([float(ins[2]), float(ins[3]), float(ins[4])])
+    elif ins[0] == "EDGE_SE2":
+        a, b = "x" + ins[1], "x" + ins[2]
+        v = [float(x) for x in ins[3:12]]
+        mu = np.array(v[0:3])
+        info = np.array([[v[3], v[4], v[5]], [v[4], v[6], v[7]], [v[5], v[7], v[8]]])
+        cov = np.linalg.inv(info)
+        cov = (cov + cov.T) / 2.0
+        for l in (a, b):
+            if not fg.exists(l):
+                fg.addVariable(l, Pose2)
+        fg.addFactor([a, b], Pose2Pose2(MvNormal(mu, cov)))
+    elif ins[0] in ("VERTEX_SE3:QUAT", "EDGE_SE3:QUAT"):
+        raise NotImplementedError("SE3 g2o records are outside the round-1 scope")
+    return fg
+
+
+def loadG2o(path, N=100, prior_sigma=(0.1, 0.1, 0.05), max_edges=None):
+    """Manhattan-style batch graph: :x0 + PriorPose2(N(0, diag(σ²))) then every g2o line
+    (examples/ManhattanDatasetBatch.jl:28-37)."""
+    fg = initfg(N)
+    fg.addVariable("x0", Pose2)
+    fg.addFactor(["x0"], PriorPose2(MvNormal(np.zeros(3), np.diag(np.square(prior_sigma)))))
+    for k, ins in enumerate(importG2o(path)):
+        if max_edges is not None and k >= max_edges:
+            break
+        parseG2oInstruction(fg, ins)
+    return fg
+
+
+def stringG2oEdgeSE2(i, j, mu, info):
+    u = [info[0, 0], info[0, 1], info[0, 2], info[1, 1], info[1, 2], info[2, 2]]
+    return "EDGE_SE2 %d %d %.6f %.6f %.6f " % (i, j, mu[0], mu[1], mu[2]) + " ".join("%.6f" % x for x in u)
+
+
+# ------------------------------------------------------------------------------------------ generators
+def se2_compose(a, b):
+    c, s = np.cos(a[2]), np.sin(a[2])
+    return np.array([a[0] + c * b[0] - s * b[1], a[1] + s * b[0] + c * b[1], a[2] + b[2]])
+
+
+def se2_between(a, b):
+    """a⁻¹ ∘ b"""
+    c, s = np.cos(a[2]), np.sin(a[2])
+    dx, dy = b[0] - a[0], b[1] - a[1]
+    th = b[2] - a[2]
+    return np.array([c * dx + s * dy, -s * dx + c * dy, np.arctan2(np.sin(th), np.cos(th))])
+
+
+def synth_manhattan_edges(P=3500, loops=1954, seed=0x524F4D45, grid=24):
+    """Deterministic g2o-shaped stand-in for examples/manhattan.g2o: unit steps
+    on an integer grid with turns in {0, ±π/2}, `loops` closures between poses ≤ 1 cell apart,
+    information ≈ the file's (odometry diag ≈ (44.6, 399, 9591) with Λ12 ≠ 0; closures ≈ (175, 416, 1504)).
+    -> (edges [(i, j, μ(3), Λ(3,3))...], ground-truth poses (P,3))"""
+    rng = np.random.default_rng(seed)
+    gt = np.zeros((P, 3))
+    pos = np.array([0, 0]); hd = 0  # heading index 0..3
+    dirs = np.array([[1, 0], [0, 1], [-1, 0], [0, -1]])
+    cells = {}
+    for k in range(P):
+        gt[k] = [pos[0], pos[1], hd * np.pi / 2]
+        cells.setdefault((int(pos[0]), int(pos[1])), []).append(k)
+        if k == P - 1:
+            break
+        turn = rng.choice([0, 1, -1], p=[0.7, 0.15, 0.15])
+        nh = (hd + turn) % 4
+        nxt = pos + dirs[nh]
+        tries = 0
+        while (abs(nxt[0]) > grid or abs(nxt[1]) > grid) and tries < 8:
+            turn = rng.choice([1, -1]); nh = (hd + turn) % 4; nxt = pos + dirs[nh]; tries += 1
+        if abs(nxt[0]) > grid or abs(nxt[1]) > grid:
+            nh = (hd + 2) % 4; nxt = pos + dirs[nh]
+        # the pose first turns in place then steps: relative motion = R(turn) then 1 forward
+        hd = nh; pos = nxt
+    gt[:, 2] = np.arctan2(np.sin(gt[:, 2]), np.cos(gt[:, 2]))
+
+    def noisy(i, j, diag, off):
+        rel = se2_between(gt[i], gt[j])
+        d = diag * rng.uniform(0.9, 1.1, 3)
+        info = np.diag(d)
+        info[0, 1] = info[1, 0] = off * rng.uniform(-1, 1) * np.sqrt(d[0] * d[1])
+        cov = np.linalg.inv(info)
+        mu = rel + np.linalg.cholesky(cov) @ rng.standard_normal(3)
+        return (i, j, mu, info)
+
+    edges = [noisy(k, k + 1, np.array([44.6, 399.0, 9591.0]), 0.12) for k in range(P - 1)]
+    cand = []
+    for (cx, cy), ks in cells.items():
+        near = list(ks)
+        for dxy in ((1, 0), (0, 1)):
+            near += cells.get((cx + dxy[0], cy + dxy[1]), [])
+        near = sorted(set(near))
+        for a in ks:
+            for b in near:
+                if b - a >= 4:
+                    cand.append((a, b))
+    cand = sorted(set(cand))
+    if len(cand) < loops:
+        raise RuntimeError("synthetic Manhattan walk produced only %d loop-closure candidates" % len(cand))
+    pick = rng.choice(len(cand), size=loops, replace=False)
+    for idx in sorted(pick):
+        a, b = cand[idx]
+        edges.append(noisy(a, b, np.array([175.0, 416.0, 1504.0]), 0.1))
+    return edges, gt
+
+
+def synth_manhattan(P=3500, loops=1954, seed=0x524F4D45, N=100, prior_sigma=(0.1, 0.1, 0.05)):
+    edges, gt = synth_manhattan_edges(P, loops, seed)
+    fg = initfg(N)
+    fg.addVariable("x0", Pose2)
+    fg.addFactor(["x0"], PriorPose2(MvNormal(np.zeros(3), np.diag(np.square(prior_sigma)))))
+    for i, j, mu, info in edges:
+        cov = np.linalg.inv(info); cov = (cov + cov.T) / 2
+        for l in ("x%d" % i, "x%d" % j):
+            if not fg.exists(l):
+                fg.addVariable(l, Pose2)
+        fg.addFactor(["x%d" % i, "x%d" % j], Pose2Pose2(MvNormal(mu, cov)))
+    fg.ground_truth = {"x%d" % k: gt[k] for k in range(P)}
+    return fg
+
+
+def generateGraph_Circle(poses=6, N=100, landmark=True, loopClosure=True, kappaOdo=1.0, biasTurn=0.0):
+    """src/canonical/GenerateCircular.jl:31-94"""
+    fg = initfg(N)
+    fg.addVariable("x0", Pose2)
+    fg.addFactor(["x0"], PriorPose2(MvNormal(np.zeros(3), 0.01 * np.eye(3))))
+    for i in range(poses):
+        fg.addVariable("x%d" % (i + 1), Pose2)
+        pp = Pose2Pose2(MvNormal([10.0, 0.0, 2 * np.pi / poses + biasTurn], np.diag((kappaOdo * np.array([0.1, 0.1, 0.1])) ** 2)))
+        fg.addFactor(["x%d" % i, "x%d" % (i + 1)], pp)
+    if landmark:
+        fg.addVariable("l1", Point2)
+        fg.addFactor(["x0", "l1"], Pose2Point2BearingRange(Normal(0, 0.1), Normal(20.0, 1.0)))
+        if loopClosure:
+            fg.addFactor(["x%d" % poses, "l1"], Pose2Point2BearingRange(Normal(0, 0.1), Normal(20.0, 1.0)))
+    return fg
+
+
+def generateGraph_Hexagonal(N=100, **kw):
+    """src/canonical/GenerateHexagonal.jl:27-42"""
+    return generateGraph_Circle(6, N=N, **kw)
+
+
+def synth_helix3d(P=10000, N=100, seed=0x524F4D45, radius=10.0, per_turn=20, pitch=1.0):
+    """Synthetic SE(3) helix (BASELINE.json configs[4]): P Pose3 on a helix, Pose3Pose3 odometry with
+    Σ = diag(0.1²x3, 0.01²x3) (test/testPose3.jl:35) + closures between adjacent turns every 5th pose."""
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(seed)
+    fg = initfg(N)
+    T = []
+    for k in range(P):
+        a = 2 * np.pi * k / per_turn
+        t = np.array([radius * np.cos(a), radius * np.sin(a), pitch * k / per_turn])
+        R = Rot.from_euler("z", a + np.pi / 2).as_matrix()
+        T.append((t, R))
+    cov = np.diag([0.1 ** 2] * 3 + [0.01 ** 2] * 3)
+    Lc = np.linalg.cholesky(cov)
+    fg.addVariable("x0", Pose3)
+    fg.addFactor(["x0"], PriorPose3(MvNormal(np.concatenate([T[0][0], Rot.from_matrix(T[0][1]).as_rotvec()]), cov)))
+
+    def rel(i, j):
+        ti, Ri = T[i]; tj, Rj = T[j]
+        return np.concatenate([Ri.T @ (tj - ti), Rot.from_matrix(Ri.T @ Rj).as_rotvec()])
+
+    for k in range(1, P):
+        fg.addVariable("x%d" % k, Pose3)
+        fg.addFactor(["x%d" % (k - 1), "x%d" % k], Pose3Pose3(MvNormal(rel(k - 1, k) + Lc @ rng.standard_normal(6), cov)))
+    for k in range(per_turn, P, 5):
+        fg.addFactor(["x%d" % (k - per_turn), "x%d" % k], Pose3Pose3(MvNormal(rel(k - per_turn, k) + Lc @ rng.standard_normal(6), cov)))
+    fg.ground_truth = {"x%d" % k: np.concatenate([T[k][0], Rot.from_matrix(T[k][1]).as_rotvec()]) for k in range(P)}
+    return fg
+
+
+# ------------------------------------------------------------------------------------------ packing
+class PackedGraph:
+    """Flat tables for the device sweep.  Variables are numbered per type in insertion order."""
+
+    def __init__(self, fg):
+        self.N = fg.N
+        self.labels = {Pose2: [], Point2: [], Pose3: []}
+        self.index = {}
+        for l, t in fg.variables.items():
+            self.index[l] = len(self.labels[t])
+            self.labels[t].append(l)
+        p2, br, p3, pr2, pr3 = [], [], [], [], []
+        for flabel, labels, f in fg.factors:
+            ids = [self.index[l] for l in labels]
+            if isinstance(f, Pose2Pose2): p2.append((ids, f, flabel))
+            elif isinstance(f, Pose2Point2BearingRange): br.append((ids, f, flabel))
+            elif isinstance(f, Pose3Pose3): p3.append((ids, f, flabel))
+            elif isinstance(f, PriorPose2): pr2.append((ids, f, flabel))
+            elif isinstance(f, PriorPose3): pr3.append((ids, f, flabel))
+            else: raise TypeError("factor type %s is outside the hot path" % type(f).__name__)
+
+        def rel_tables(items, d):
+            F = len(items)
+            mu = np.zeros((F, d)); cov = np.zeros((F, d, d))
+            vfrom = np.zeros(F, dtype=np.int32); vto = np.zeros(F, dtype=np.int32)
+            for k, (ids, f, _) in enumerate(items):
+                mu[k] = f.Z.mu; cov[k] = f.Z.cov; vfrom[k], vto[k] = ids
+            return dict(F=F, mu=mu, cov=cov, var_from=vfrom, var_to=vto, labels=[it[2] for it in items])
+
+        self.p2p2 = rel_tables(p2, 3)
+        self.p3p3 = rel_tables(p3, 6)
+        Fb = len(br)
+        self.br = dict(F=Fb, mu=np.array([[f.bearing.mu, f.range.mu] for _, f, _ in br]).reshape(Fb, 2),
+                       sigma=np.array([[f.bearing.sigma, f.range.sigma] for _, f, _ in br]).reshape(Fb, 2),
+                       pose=np.array([ids[0] for ids, _, _ in br], dtype=np.int32),
+                       point=np.array([ids[1] for ids, _, _ in br], dtype=np.int32),
+                       labels=[it[2] for it in br])
+
+        def prior_tables(items, d):
+            F = len(items)
+            return dict(F=F, mu=np.array([f.Z.mu for _, f, _ in items]).reshape(F, d),
+                        cov=np.array([f.Z.cov for _, f, _ in items]).reshape(F, d, d),
+                        var=np.array([ids[0] for ids, _, _ in items], dtype=np.int32),
+                        labels=[it[2] for it in items])
+
+        self.prior2 = prior_tables(pr2, 3)
+        self.prior3 = prior_tables(pr3, 6)
+
+    @staticmethod
+    def conv_table(tab):
+        """Both directions of every relative factor, interleaved in factor order:
+        conv 2f = (f, dir 0: fixed=from, target=to), conv 2f+1 = (f, dir 1: fixed=to, target=from)."""
+        F = tab["F"]
+        factor = np.repeat(np.arange(F, dtype=np.int32), 2)
+        d = np.tile(np.array([0, 1], dtype=np.int32), F)
+        fixed = np.empty(2 * F, dtype=np.int32); target = np.empty(2 * F, dtype=np.int32)
+        fixed[0::2] = tab["var_from"]; target[0::2] = tab["var_to"]
+        fixed[1::2] = tab["var_to"]; target[1::2] = tab["var_from"]
+        return factor, d, fixed, target
+
+    def beliefs(self, fg, vartype):
+        """(V, dim, N) SoA blocks from fg.vals (all variables of the type must be initialised)."""
+        ls = self.labels[vartype]
+        out = np.zeros((len(ls), vartype.dim, self.N))
+        for k, l in enumerate(ls):
+            out[k] = fg.vals[l]
+        return out
+
+
+def dead_reckon_init(fg, seed=1, sigma=(0.1, 0.1, 0.05)):
+    """Initialise every Pose2 belief from the prior mean composed along the first incoming odometry
+    factor, plus N(0, diag σ²) per particle (bench/test input preparation)."""
+    rng = np.random.default_rng(seed)
+    mean = {}
+    for _, labels, f in fg.factors:
+        if isinstance(f, PriorPose2):
+            mean[labels[0]] = f.Z.mu.copy()
+    if not mean:
+        first = next(l for l, t in fg.variables.items() if t is Pose2)
+        mean[first] = np.zeros(3)
+    pending = [(labels, f) for _, labels, f in fg.factors if isinstance(f, Pose2Pose2)]
+    progress = True
+    while pending and progress:
+        progress = False
+        rest = []
+        for labels, f in pending:
+            a, b = labels
+            if a in mean and b not in mean:
+                mean[b] = se2_compose(mean[a], f.Z.mu); progress = True
+            elif b in mean and a not in mean:
+                inv = se2_between(f.Z.mu, np.zeros(3))
+                mean[a] = se2_compose(mean[b], inv); progress = True
+            elif a not in mean:
+                rest.append((labels, f))
+        pending = rest
+    for l, t in fg.variables.items():
+        if t is Pose2:
+            m = mean.get(l, np.zeros(3))
+            pts = m[:, None] + np.asarray(sigma)[:, None] * rng.standard_normal((3, fg.N))
+            fg.initVariable(l, pts)
+    return fg
