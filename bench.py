@@ -2,8 +2,8 @@
 """bench.py -- factor convolutions/sec (N=100) on a Manhattan-3500-shaped graph.
 
 One "step" = one pass of the hot path over the whole graph: every (factor, direction) Pose2Pose2
-convolution (2 x 5453 = 10906) in ONE kernel launch + the PriorPose2 sampling, with the belief
-store already resident in HBM.  One convolution = what IIF `approxConvBelief` does for one factor
+convolution (2 x 5453 = 10906) plus the PriorPose2 row in ONE kernel launch, with the belief store
+already resident in HBM.  One convolution = what IIF `approxConvBelief` does for one factor
 and target: N=100 getSample + inflateCycles(3) x {entropy inflation, 100 per-particle root-finds}.
 
     python bench.py [--gpus N --steps K --warmup W] [--solver newton|nelder_mead|closed_form]
@@ -85,29 +85,29 @@ def main():
     dg = R.DeviceGraph(fg, device=dev, ctx=ctx)
     dg.upload_beliefs(fg)
     tb = dg.tab["p2p2"]
-    n_conv_step = tb["C"] + dg.tab["prior2"]["F"]  # convolutions per step on this rank
+    n_conv_step = tb["C"]  # convolutions per step on this rank: 2 x F relative + the PriorPose2 row(s), ONE launch
     opts = R.make_opts(N=N, solver=solver, seed=0x524F4D45, stream_offset=rank * (1 << 32))
     prop = torch.empty((tb["C"], 3, N), dtype=torch.float64, device=dev)
-    prior_out = torch.empty((dg.tab["prior2"]["F"], 3, N), dtype=torch.float64, device=dev)
+    sweep = dg.plan_sweep_pose2pose2(opts, prop)   # pre-built launch descriptor: one hipLaunchKernel per call
 
     pk = dg.packed
     if world > 1:
         sep_send = torch.empty((2, 3, N), dtype=torch.float64, device=dev)      # this rank's first/last pose beliefs
         sep_all = torch.empty((world, 2, 3, N), dtype=torch.float64, device=dev)
-        i_first, i_last = pk.index["x0"], pk.index[last]
         g_prev, g_next = pk.index["ghost_prev"], pk.index["ghost_next"]
-        # proposal rows that carry the updated separator estimates (odometry convs targeting them)
-        conv_first = 2 * 0 + 1   # factor 0 (x0->x1), dir 1 -> target x0
-        conv_last = 2 * (args.poses - 2) + 0 if not args.g2o else 0
+        # proposal rows that carry the updated separator estimates (odometry convolutions targeting them)
+        conv_first = 2 * 0 + 1                                   # factor 0 (x0->x1), dir 1 -> target x0
+        conv_last = 2 * (args.poses - 2) + 0 if not args.g2o else 0  # factor P-2 (x_{P-2}->x_{P-1}), dir 0
+        bel = dg.bel[R.Pose2]
 
-    def step():
-        dg.sweep_pose2pose2(opts, out=prop)
-        dg.sample_priors(opts, "prior2", out=prior_out)
-        if world > 1:
+        def exchange():
             sep_send[0].copy_(prop[conv_first]); sep_send[1].copy_(prop[conv_last])
             dist.all_gather_into_tensor(sep_all, sep_send)
-            dg.bel[R.Pose2][g_prev].copy_(sep_all[(rank - 1) % world, 1])
-            dg.bel[R.Pose2][g_next].copy_(sep_all[(rank + 1) % world, 0])
+            bel[g_prev].copy_(sep_all[(rank - 1) % world, 1])
+            bel[g_next].copy_(sep_all[(rank + 1) % world, 0])
+    else:
+        def exchange():
+            pass
 
     def barrier():
         if world > 1:
@@ -115,23 +115,19 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        sweep(); exchange()
     barrier()
     # per-launch duration of the dominant kernel: HIP events on the launch stream (torch's current stream,
-    # which DeviceGraph binds the rome_ctx to), collected inside the timed region
+    # which the launch plan binds the rome_ctx to), recorded around every launch of the timed region
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        dg.sweep_pose2pose2(opts, out=prop)
-        ev[k][1].record()
-        dg.sample_priors(opts, "prior2", out=prior_out)
-        if world > 1:
-            sep_send[0].copy_(prop[conv_first]); sep_send[1].copy_(prop[conv_last])
-            dist.all_gather_into_tensor(sep_all, sep_send)
-            dg.bel[R.Pose2][g_prev].copy_(sep_all[(rank - 1) % world, 1])
-            dg.bel[R.Pose2][g_next].copy_(sep_all[(rank + 1) % world, 0])
+        e0, e1 = ev[k]
+        e0.record()
+        sweep()
+        e1.record()
+        exchange()
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -143,7 +139,7 @@ def main():
 
     total_conv = n_conv_step * world * args.steps
     value = total_conv / elapsed
-    alg_bytes = tb["C"] * N * BYTES_PER_PARTICLE_P2P2
+    alg_bytes = tb["C_rel"] * N * BYTES_PER_PARTICLE_P2P2 + tb["P"] * N * 24
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     out = {
@@ -174,11 +170,12 @@ def main():
         modes = {}
         for name, sv in (("closed_form", R.SOLVER_CLOSED_FORM), ("newton", R.SOLVER_NEWTON), ("nelder_mead", R.SOLVER_NELDER_MEAD)):
             o2 = R.make_opts(N=N, solver=sv, seed=0x524F4D45)
-            reps = 5 if sv == R.SOLVER_NELDER_MEAD else 50
-            dg.sweep_pose2pose2(o2, out=prop); torch.cuda.synchronize()
+            reps = 5 if sv == R.SOLVER_NELDER_MEAD else 100
+            pl = dg.plan_sweep_pose2pose2(o2, prop)
+            pl(); torch.cuda.synchronize()
             a = time.perf_counter()
             for _ in range(reps):
-                dg.sweep_pose2pose2(o2, out=prop)
+                pl()
             torch.cuda.synchronize()
             modes[name] = tb["C"] * reps / (time.perf_counter() - a)
         out["gpu_convolutions_per_s_by_solver"] = modes
@@ -215,7 +212,8 @@ def cpu_baseline(R, pk, fg, N, budget_s):
     n0 = min(len(factor), 64 * cores)
     t0 = run(n0)
     n = int(min(len(factor), max(n0, n0 * budget_s / max(t0, 1e-3))))
-    t = run(n)
+    reps = max(1, int(budget_s / max(1e-3, t0 * n / n0)))  # repeat the (possibly whole-table) sample up to the budget
+    t = min(run(n) for _ in range(min(reps, 5)))
     return {"value": n / t, "unit": "convolutions/s", "cores": cores, "kind": "port",
             "algorithm": "Optim.jl-default Nelder-Mead per particle (reference algorithm), inflate_cycles=3",
             "sample": "first %d of %d (factor,direction) convolutions of the same graph, N=%d, %.1f s" % (n, len(factor), N, t)}

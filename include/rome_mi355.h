@@ -21,7 +21,9 @@
  *   - a "block" is one belief of N particles; ROME_LAYOUT_SOA: [block][dim][N] (device-native),
  *     ROME_LAYOUT_AOS: [block][N][dim] (what a Julia Vector of coordinate SVectors looks like).
  *   - dir = 0 solves for the factor's 2nd variable given the 1st (x_i -> x_j / pose -> landmark),
- *     dir = 1 solves for the 1st given the 2nd.
+ *     dir = 1 solves for the 1st given the 2nd.  In the Pose2Pose2 / Pose3Pose3 tables dir = 2
+ *     (ROME_DIR_PRIOR) marks a PriorPose2 / PriorPose3 row: no fixed variable, the proposal is the
+ *     prior sample itself, so a whole-graph sweep (relative factors + priors) is ONE launch.
  *   - return value: ROME_OK (0) or a negative ROME_ERR_*; per-particle non-convergence is reported
  *     through the optional `status` array (0 = converged, 1 = iteration cap reached).
  *   - a rome_ctx is not thread-safe; distinct contexts are (one HIP stream each).
@@ -57,6 +59,7 @@ enum {
  *   NELDER_MEAD  Optim.jl's NelderMead() with its defaults on Σ r², i.e. the reference's algorithm  */
 enum { ROME_SOLVER_CLOSED_FORM = 0, ROME_SOLVER_NEWTON = 1, ROME_SOLVER_NELDER_MEAD = 2 };
 enum { ROME_LAYOUT_SOA = 0, ROME_LAYOUT_AOS = 1 };
+enum { ROME_DIR_TO = 0, ROME_DIR_FROM = 1, ROME_DIR_PRIOR = 2 };
 
 /* Mirrors the IIF SolverParams fields that reach this path (N, inflateCycles, inflation). */
 typedef struct rome_opts {
@@ -82,7 +85,8 @@ const char* rome_last_hip_error_string(const rome_ctx* ctx);
 void rome_opts_default(rome_opts* o, int32_t solver);
 int  rome_ctx_create(rome_ctx** out, int device);
 void rome_ctx_destroy(rome_ctx* ctx);
-int  rome_ctx_set_stream(rome_ctx* ctx, void* hip_stream); /* launch on a caller-owned hipStream_t (NULL -> own stream) */
+int  rome_ctx_set_stream(rome_ctx* ctx, void* hip_stream); /* launch on a caller-owned hipStream_t; NULL = HIP's default (null) stream */
+int  rome_ctx_use_own_stream(rome_ctx* ctx);               /* back to the context's private non-blocking stream (the default) */
 int  rome_ctx_synchronize(rome_ctx* ctx);
 int  rome_device_count(void);
 

@@ -68,17 +68,26 @@ void ro_rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, int d, do
   }
 }
 
-/* d uniforms in (0,1) for the entropy inflation of cycle `cycle` (32-bit resolution). */
+/* d uniforms in (0,1) for the entropy inflation of cycle `cycle` (⚠IIF addEntropyOnManifold!:
+ * spread·(rand(d) .- 0.5); RNG stream unpinned).  Narrow uniforms packed into one Philox call:
+ *   d <= 3 : 14-bit fields, 3 cycles per call (call = cycle/3, field index (cycle%3)*3 + k)
+ *   d == 6 : 21-bit fields, 1 cycle per call  (call = cycle, field index k)
+ * u = (field + 0.5) / 2^bits.  Same definition as the HIP path (rome_device_math.hpp). */
 void ro_rng_entropy(uint64_t seed, uint64_t stream, uint32_t particle, int cycle, int d, double* out) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  int nblk = (d + 3) / 4;
-  for (int b = 0; b < nblk; ++b) {
-    uint32_t ctr[4] = {particle, (uint32_t)stream, (uint32_t)(stream >> 32),
-                       ((uint32_t)RO_DOMAIN_ENTROPY << 16) | ((uint32_t)cycle << 8) | (uint32_t)b};
-    uint32_t w[4];
-    ro_philox4x32_10(ctr, key, w);
-    for (int k = 0; k < 4 && 4 * b + k < d; ++k)
-      out[4 * b + k] = ((double)w[k] + 0.5) * (1.0 / 4294967296.0);
+  const int bits = d <= 3 ? 14 : 21;
+  const int cpc = d <= 3 ? 3 : 1;
+  const int call = cycle / cpc, slot = cycle % cpc;
+  uint32_t ctr[4] = {particle, (uint32_t)stream, (uint32_t)(stream >> 32),
+                     ((uint32_t)RO_DOMAIN_ENTROPY << 16) | (uint32_t)call};
+  uint32_t w[4];
+  ro_philox4x32_10(ctr, key, w);
+  for (int k = 0; k < d; ++k) {
+    const int pos = (slot * 3 * (d <= 3) + k) * bits;
+    const int wi = pos >> 5, sh = pos & 31;
+    uint64_t two = (uint64_t)w[wi] | ((uint64_t)(wi + 1 < 4 ? w[wi + 1] : 0u) << 32);
+    uint32_t f = (uint32_t)((two >> sh) & ((1ull << bits) - 1));
+    out[k] = ((double)f + 0.5) / (double)(1u << bits);
   }
 }
 
@@ -320,59 +329,51 @@ int ro_cholesky_lower(int d, const double* cov, double* Lp) {
   return 0;
 }
 
-/* ⚠IIF calcStdBasicSpread: per-coordinate std of the tangent coordinates at the manifold mean
- * (n-1 normalisation).  Mean: arithmetic for translations, extrinsic circular mean for θ (unpinned). */
+/* ⚠IIF calcStdBasicSpread: per-coordinate std (n-1 normalisation) of the belief's tangent coordinates.
+ * Unpinned by the reference; definition shared with the HIP path: the tangent coordinates are taken about
+ * particle 0, d_i = vee(log(x_0, x_i)) (translations: differences; SO(2): wrap(θ_i-θ_0); SO(3):
+ * Log(R_0ᵀR_i)), and std_k = sqrt(var_i(d_i[k])).  `mean` = x_0 ⊕ mean_i(d_i) (one Karcher step from x_0). */
+static void moments(int N, const double* d, double* mean, double* sd) {
+  double m = 0; for (int i = 0; i < N; ++i) m += d[i]; m /= N;
+  double v = 0; for (int i = 0; i < N; ++i) { double e = d[i] - m; v += e * e; }
+  *mean = m; *sd = sqrt(v / (N > 1 ? (double)(N - 1) : 1.0));
+}
 void ro_belief_spread_se2(int N, const double* x, const double* y, const double* th, double* mean3, double* std3) {
-  double sx = 0, sy = 0, ss = 0, sc = 0;
-  for (int i = 0; i < N; ++i) { sx += x[i]; sy += y[i]; ss += sin(th[i]); sc += cos(th[i]); }
-  double mx = sx / N, my = sy / N, mt = atan2(ss, sc);
-  double vx = 0, vy = 0, vt = 0;
-  double sm = sin(mt), cm = cos(mt);
-  for (int i = 0; i < N; ++i) {
-    double dx = x[i] - mx, dy = y[i] - my;
-    double s = sin(th[i]), c = cos(th[i]);
-    double dt = atan2(cm * s - sm * c, cm * c + sm * s); /* log_SO2(R(mt), R(th)) */
-    vx += dx * dx; vy += dy * dy; vt += dt * dt;
-  }
-  double den = N > 1 ? (double)(N - 1) : 1.0;
-  mean3[0] = mx; mean3[1] = my; mean3[2] = mt;
-  std3[0] = sqrt(vx / den); std3[1] = sqrt(vy / den); std3[2] = sqrt(vt / den);
+  double* d = (double*)malloc(sizeof(double) * N);
+  double m;
+  for (int i = 0; i < N; ++i) d[i] = x[i] - x[0];
+  moments(N, d, &m, &std3[0]); mean3[0] = x[0] + m;
+  for (int i = 0; i < N; ++i) d[i] = y[i] - y[0];
+  moments(N, d, &m, &std3[1]); mean3[1] = y[0] + m;
+  double s0 = sin(th[0]), c0 = cos(th[0]);
+  for (int i = 0; i < N; ++i) { double s = sin(th[i]), c = cos(th[i]); d[i] = atan2(c0 * s - s0 * c, c0 * c + s0 * s); } /* log_SO2(R(th0), R(th_i)) */
+  moments(N, d, &m, &std3[2]); mean3[2] = th[0] + m;
+  free(d);
 }
 void ro_belief_spread_r2(int N, const double* x, const double* y, double* mean2, double* std2) {
-  double sx = 0, sy = 0;
-  for (int i = 0; i < N; ++i) { sx += x[i]; sy += y[i]; }
-  double mx = sx / N, my = sy / N, vx = 0, vy = 0;
-  for (int i = 0; i < N; ++i) { double dx = x[i] - mx, dy = y[i] - my; vx += dx * dx; vy += dy * dy; }
-  double den = N > 1 ? (double)(N - 1) : 1.0;
-  mean2[0] = mx; mean2[1] = my; std2[0] = sqrt(vx / den); std2[1] = sqrt(vy / den);
+  double* d = (double*)malloc(sizeof(double) * N);
+  double m;
+  for (int i = 0; i < N; ++i) d[i] = x[i] - x[0];
+  moments(N, d, &m, &std2[0]); mean2[0] = x[0] + m;
+  for (int i = 0; i < N; ++i) d[i] = y[i] - y[0];
+  moments(N, d, &m, &std2[1]); mean2[1] = y[0] + m;
+  free(d);
 }
-/* SE(3): rotation mean = particle 0 refined by 2 Karcher steps μ ← μ Exp(mean Log(μᵀ R_i)) (unpinned). */
 void ro_belief_spread_se3(int N, const double* blk, double* mean6, double* std6) {
-  double st[3] = {0, 0, 0};
-  for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) st[k] += blk[k * N + i];
-  for (int k = 0; k < 3; ++k) mean6[k] = st[k] / N;
-  double Rm[9];
-  { double w0[3] = {blk[3 * N], blk[4 * N], blk[5 * N]}; ro_so3_exp(w0, Rm); }
-  for (int it = 0; it < 2; ++it) {
-    double acc[3] = {0, 0, 0};
-    for (int i = 0; i < N; ++i) {
-      double w[3] = {blk[3 * N + i], blk[4 * N + i], blk[5 * N + i]}, R[9], U[9], d[3];
-      ro_so3_exp(w, R); mat3_tmul(Rm, R, U); ro_so3_log(U, d);
-      acc[0] += d[0]; acc[1] += d[1]; acc[2] += d[2];
-    }
-    double dm[3] = {acc[0] / N, acc[1] / N, acc[2] / N}, E[9], T[9];
-    ro_so3_exp(dm, E); mat3_mul(Rm, E, T); memcpy(Rm, T, sizeof(T));
-  }
-  ro_so3_log(Rm, mean6 + 3);
-  double v[6] = {0, 0, 0, 0, 0, 0};
+  double* d = (double*)malloc(sizeof(double) * 6 * N);
+  double R0[9];
+  { double w0[3] = {blk[3 * N], blk[4 * N], blk[5 * N]}; ro_so3_exp(w0, R0); }
   for (int i = 0; i < N; ++i) {
-    for (int k = 0; k < 3; ++k) { double d = blk[k * N + i] - mean6[k]; v[k] += d * d; }
-    double w[3] = {blk[3 * N + i], blk[4 * N + i], blk[5 * N + i]}, R[9], U[9], d[3];
-    ro_so3_exp(w, R); mat3_tmul(Rm, R, U); ro_so3_log(U, d);
-    for (int k = 0; k < 3; ++k) v[3 + k] += d[k] * d[k];
+    for (int k = 0; k < 3; ++k) d[k * N + i] = blk[k * N + i] - blk[k * N];
+    double w[3] = {blk[3 * N + i], blk[4 * N + i], blk[5 * N + i]}, R[9], U[9], l[3];
+    ro_so3_exp(w, R); mat3_tmul(R0, R, U); ro_so3_log(U, l);
+    for (int k = 0; k < 3; ++k) d[(3 + k) * N + i] = l[k];
   }
-  double den = N > 1 ? (double)(N - 1) : 1.0;
-  for (int k = 0; k < 6; ++k) std6[k] = sqrt(v[k] / den);
+  double md[6];
+  for (int k = 0; k < 6; ++k) moments(N, d + k * N, &md[k], &std6[k]);
+  for (int k = 0; k < 3; ++k) mean6[k] = blk[k * N] + md[k];
+  { double E[9], Rm[9]; ro_so3_exp(md + 3, E); mat3_mul(R0, E, Rm); ro_so3_log(Rm, mean6 + 3); }
+  free(d);
 }
 
 /* ======================================================================== */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "rome_ctx_create": (C.c_int, [C.POINTER(_CTX), C.c_int]),
     "rome_ctx_destroy": (None, [_CTX]),
     "rome_ctx_set_stream": (C.c_int, [_CTX, C.c_void_p]),
+    "rome_ctx_use_own_stream": (C.c_int, [_CTX]),
     "rome_ctx_synchronize": (C.c_int, [_CTX]),
     "rome_device_count": (C.c_int, []),
     "rome_cholesky_lower": (C.c_int, [C.c_int32, C.c_int32, _PD, _PD]),
@@ -86,6 +87,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch (when installed) bundles its own HIP runtime; it has to be the one this process maps
+    # FIRST so that librome_mi355's libamdhip64 dependency resolves to the same runtime and device
+    # pointers / streams can be shared.  Without torch the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(SO):
         raise RuntimeError(
             "librome_mi355.so is not built (%s). Run `python __graft_entry__.py` or "
@@ -130,6 +138,9 @@ class Context:
 
     def set_stream(self, hip_stream_ptr):
         check(self._lib.rome_ctx_set_stream(self.handle, C.c_void_p(hip_stream_ptr or 0)), self.handle)
+
+    def use_own_stream(self):
+        check(self._lib.rome_ctx_use_own_stream(self.handle), self.handle)
 
     def synchronize(self):
         check(self._lib.rome_ctx_synchronize(self.handle), self.handle)

@@ -258,7 +258,12 @@ void rome_ctx_destroy(rome_ctx* c) {
 
 int rome_ctx_set_stream(rome_ctx* c, void* hip_stream) {
   if (!c) return ROME_ERR_INVALID_ARG;
-  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  c->stream = (hipStream_t)hip_stream;  // NULL is HIP's default (null) stream, e.g. torch's default stream
+  return ROME_OK;
+}
+int rome_ctx_use_own_stream(rome_ctx* c) {
+  if (!c) return ROME_ERR_INVALID_ARG;
+  c->stream = c->own_stream;
   return ROME_OK;
 }
 int rome_ctx_synchronize(rome_ctx* c) {

@@ -20,6 +20,40 @@ constexpr double kPi = 3.141592653589793238462643383279502884;
 constexpr double kSqrtEps = 1.4901161193847656e-8;  // Julia isapprox default rtol for Float64
 
 // ------------------------------------------------------------------------------------------
+// elementary functions tuned for this path
+// ------------------------------------------------------------------------------------------
+// sin/cos with a two-term Cody-Waite reduction by π/2 (FMA) and the fdlibm kernel polynomials:
+// < 1 ulp-ish (abs error ~1e-16) for |x| <= 1e5; larger arguments take the library path.
+__device__ __forceinline__ void fast_sincos(double x, double* sn, double* cs) {
+  if (__builtin_expect(!(fabs(x) <= 1.0e5), 0)) { sincos(x, sn, cs); return; }
+  const double n = rint(x * 0.63661977236758134308);  // 2/π
+  double r = fma(-n, 1.5707963267948966, x);
+  r = fma(-n, 6.123233995736766e-17, r);
+  const int q = (int)n;
+  const double z = r * r;
+  const double ps = r + r * z * fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                              2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                                           8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double pc = fma(z * z, fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                              -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                           -1.38888888888741095749e-03), 4.16666666666666019037e-02),
+                        fma(-0.5, z, 1.0));
+  const double s0 = (q & 1) ? pc : ps;
+  const double c0 = (q & 1) ? ps : pc;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// θ -> [-π, π]: same value as atan2(sin θ, cos θ) up to an ulp (and the ±π tie), without transcendentals.
+__device__ __forceinline__ double wrap_pi(double th) {
+  const double k = rint(th * 0.15915494309189533577);  // 1/(2π)
+  double r = fma(-k, 6.283185307179586, th);
+  r = fma(-k, 2.4492935982947064e-16, r);
+  return r;
+}
+
+
+// ------------------------------------------------------------------------------------------
 // Philox4x32-10 (Random123).  Integer only -> bit-identical to any other conforming implementation.
 // ------------------------------------------------------------------------------------------
 struct u32x4 { uint32_t x, y, z, w; };
@@ -53,44 +87,78 @@ __device__ __forceinline__ void rng_normals(uint64_t seed, uint64_t stream, uint
     const double u1 = u53(w.x, w.y), u2 = u53(w.z, w.w);
     const double rr = sqrt(-2.0 * log(u1));
     double s, c;
-    sincos(2.0 * kPi * u2, &s, &c);
+    fast_sincos(2.0 * kPi * u2, &s, &c);
     out[2 * b] = rr * c;
     if (2 * b + 1 < D) out[2 * b + 1] = rr * s;
   }
 }
 
-// D uniforms in (0,1) (32-bit resolution) for the entropy inflation of cycle `cycle`.
+// Entropy-inflation uniforms (IIF addEntropyOnManifold!: spread·(rand(d) .- 0.5)).  The jitter only
+// seeds the next root-find, so narrow uniforms are drawn and ONE Philox call is shared by several cycles:
+//   D <= 3 : 14-bit fields, 3 cycles per call   (call index = cycle / 3, 42 bits per cycle)
+//   D == 6 : 21-bit fields, 1 cycle  per call   (126 bits)
+// u = (field + 0.5) / 2^bits  in (0,1).
+struct EntropyWords { uint32_t w[4]; };
+__device__ __forceinline__ EntropyWords rng_entropy_words(uint64_t seed, uint64_t stream, uint32_t particle, int call) {
+  const u32x4 w = philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32), (kDomainEntropy << 16) | (uint32_t)call},
+                                (uint32_t)seed, (uint32_t)(seed >> 32));
+  return EntropyWords{{w.x, w.y, w.z, w.w}};
+}
+__device__ __forceinline__ uint32_t bitfield128(const EntropyWords& e, int pos, int bits) {  // pos, bits compile-time after unroll
+  const int wi = pos >> 5, sh = pos & 31;
+  uint64_t two = (uint64_t)e.w[wi] | ((uint64_t)(wi + 1 < 4 ? e.w[wi + 1] : 0u) << 32);
+  return (uint32_t)((two >> sh) & ((1ull << bits) - 1));
+}
 template <int D>
-__device__ __forceinline__ void rng_entropy(uint64_t seed, uint64_t stream, uint32_t particle, int cycle, double (&out)[D]) {
-  constexpr int NB = (D + 3) / 4;
+__device__ __forceinline__ void rng_entropy_from_words(const EntropyWords& e, int slot, double (&out)[D]) {
+  constexpr int BITS = D <= 3 ? 14 : 21;
+  // slot = cycle % 3 for D<=3 (0 for D==6); select with constant positions to keep everything in registers
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const u32x4 w = philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32),
-                                        (kDomainEntropy << 16) | ((uint32_t)cycle << 8) | (uint32_t)b},
-                                  (uint32_t)seed, (uint32_t)(seed >> 32));
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (4 * b + k < D) out[4 * b + k] = ((double)ww[k] + 0.5) * (1.0 / 4294967296.0);
+  for (int k = 0; k < D; ++k) {
+    uint32_t f;
+    if constexpr (D <= 3) {
+      const uint32_t f0 = bitfield128(e, (0 * 3 + k) * BITS, BITS), f1 = bitfield128(e, (1 * 3 + k) * BITS, BITS),
+                     f2 = bitfield128(e, (2 * 3 + k) * BITS, BITS);
+      f = slot == 0 ? f0 : (slot == 1 ? f1 : f2);
+    } else {
+      f = bitfield128(e, k * BITS, BITS);
+    }
+    out[k] = ((double)f + 0.5) * (1.0 / (double)(1u << BITS));
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // wave64 reductions (all lanes end with the same bits: xor-butterfly of commutative adds)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+// Row (16-lane) butterflies are DPP moves (quad_perm / row_half_mirror / row_mirror); the four row sums
+// are then combined through v_readlane in a fixed order.  ~4x cheaper than ds_bpermute shuffles.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
 }
 template <int K>
 __device__ __forceinline__ void wave_sum_n(double (&v)[K]) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov<0xB1>(v[k]);   // quad_perm [1,0,3,2]
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] += __shfl_xor(v[k], off, 64);
-  }
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov<0x4E>(v[k]);   // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov<0x141>(v[k]);  // row_half_mirror
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov<0x140>(v[k]);  // row_mirror
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    v[k] = (readlane_f64(v[k], 0) + readlane_f64(v[k], 16)) + (readlane_f64(v[k], 32) + readlane_f64(v[k], 48));
 }
+__device__ __forceinline__ double wave_sum(double v) { double a[1] = {v}; wave_sum_n<1>(a); return a[0]; }
 
 // ------------------------------------------------------------------------------------------
 // SE(2)
@@ -98,10 +166,8 @@ __device__ __forceinline__ void wave_sum_n(double (&v)[K]) {
 struct Se2 { double x, y, c, s; };  // point ((x,y), R=[c -s; s c])
 
 __device__ __forceinline__ Se2 se2_from_coords(double x, double y, double th) {
-  Se2 p; p.x = x; p.y = y; sincos(th, &p.s, &p.c); return p;
+  Se2 p; p.x = x; p.y = y; fast_sincos(th, &p.s, &p.c); return p;
 }
-__device__ __forceinline__ double wrap_pi(double th) { double s, c; sincos(th, &s, &c); return atan2(s, c); }
-
 // Manifolds.sym_rem: (x ≈ π ? -π : rem(x, 2π, RoundNearest))
 __device__ __forceinline__ double sym_rem(double x) {
   const double m = fabs(x) > kPi ? fabs(x) : kPi;
@@ -139,7 +205,7 @@ __device__ __forceinline__ void residual_bearingrange(double b, double rho, cons
 // entropy: u ← u ∘ exp_ϵ(hat(e))
 __device__ __forceinline__ void se2_add_entropy(double (&t)[3], double spread, const double (&u)[3]) {
   const double ex = spread * (u[0] - 0.5), ey = spread * (u[1] - 0.5), et = spread * (u[2] - 0.5);
-  double s, c; sincos(t[2], &s, &c);
+  double s, c; fast_sincos(t[2], &s, &c);
   t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] += et;
 }
 
@@ -170,7 +236,7 @@ __device__ __forceinline__ void so3_exp(const double* w, double* R) {
   const double th2 = x * x + y * y + z * z;
   const double th = sqrt(th2);
   double a = 1.0, b = 0.0;
-  if (th != 0.0) { double s, c; sincos(th, &s, &c); a = s / th; b = (1.0 - c) / th2; }
+  if (th != 0.0) { double s, c; fast_sincos(th, &s, &c); a = s / th; b = (1.0 - c) / th2; }
   R[0] = 1.0 + b * (x * x - th2); R[3] = -a * z + b * x * y;      R[6] = a * y + b * x * z;
   R[1] = a * z + b * x * y;       R[4] = 1.0 + b * (y * y - th2); R[7] = -a * x + b * y * z;
   R[2] = -a * y + b * x * z;      R[5] = a * x + b * y * z;       R[8] = 1.0 + b * (z * z - th2);

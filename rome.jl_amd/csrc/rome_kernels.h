@@ -6,6 +6,7 @@
 namespace rome {
 
 enum { kSolverClosedForm = 0, kSolverNewton = 1, kSolverNelderMead = 2 };
+enum { kDirTo = 0, kDirFrom = 1, kDirPrior = 2 };  // kDirPrior: row is a prior (no fixed variable): proposal = sample
 
 // All pointers are DEVICE pointers.  Belief / proposal blocks are SoA: [block][dim][N].
 struct ConvArgs {

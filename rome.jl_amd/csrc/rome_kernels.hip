@@ -28,16 +28,56 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
 // ------------------------------------------------------------------------------------------
 // factor policies
 // ------------------------------------------------------------------------------------------
+// Coordinate form of the Pose2Pose2 residual (same function as
+// src/factors/Pose2D.jl:51-67 evaluated through exp/compose/log on points):
+//   r(z; p, q) = ( p.t + R(θp) z_t - q.t ,  wrap(θp + zθ - θq) )
+// dir 0 (solve q): q̂ = p ∘ exp(z) is constant -> r = (q̂.t - q.t, wrap(q̂θ - qθ)): no transcendental per evaluation.
+// dir 1 (solve p): one sincos(θp) per evaluation.
 struct P2P2Cost {
-  double zx, zy, cz, sz; Se2 fx; int dir;
+  double zx, zy, a0, a1, a2; int dir;  // dir0: a = q̂ (x,y,θ) ; dir1: a = (q.x, q.y, qθ - zθ)
   __device__ __forceinline__ double operator()(const double (&x)[3]) const {
-    const Se2 T = se2_from_coords(x[0], x[1], x[2]);  // p = exp_ϵ(hat Xc)
-    double r[3];
-    if (dir == 0) residual_pose2pose2(zx, zy, cz, sz, fx, T, r);
-    else          residual_pose2pose2(zx, zy, cz, sz, T, fx, r);
-    return r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    double r0, r1, r2;
+    if (dir == 0) { r0 = a0 - x[0]; r1 = a1 - x[1]; r2 = wrap_pi(a2 - x[2]); }
+    else {
+      double s, c; fast_sincos(x[2], &s, &c);
+      r0 = x[0] + c * zx - s * zy - a0; r1 = x[1] + s * zx + c * zy - a1; r2 = wrap_pi(x[2] - a2);
+    }
+    return r0 * r0 + r1 * r1 + r2 * r2;
   }
 };
+
+// std of the belief's tangent coordinates about particle 0 (shifted one-pass moments): SE(2)
+template <int PPL>
+__device__ __forceinline__ double spread_se2(const double (&t)[PPL][3], const bool (&act)[PPL], int N) {
+  const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0), th0 = readlane_f64(t[0][2], 0);
+  double s[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const double dx = t[k][0] - x0, dy = t[k][1] - y0, dt = wrap_pi(t[k][2] - th0);
+    if (act[k]) { s[0] += dx; s[1] += dx * dx; s[2] += dy; s[3] += dy * dy; s[4] += dt; s[5] += dt * dt; }
+  }
+  wave_sum_n<6>(s);
+  const double inv = 1.0 / N, den = N > 1 ? 1.0 / (double)(N - 1) : 1.0;
+  const double vx = fmax(0.0, (s[1] - s[0] * s[0] * inv) * den);
+  const double vy = fmax(0.0, (s[3] - s[2] * s[2] * inv) * den);
+  const double vt = fmax(0.0, (s[5] - s[4] * s[4] * inv) * den);
+  return (sqrt(vx) + sqrt(vy) + sqrt(vt)) * (1.0 / 3.0);
+}
+template <int PPL>
+__device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const bool (&act)[PPL], int N) {
+  const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0);
+  double s[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const double dx = t[k][0] - x0, dy = t[k][1] - y0;
+    if (act[k]) { s[0] += dx; s[1] += dx * dx; s[2] += dy; s[3] += dy * dy; }
+  }
+  wave_sum_n<4>(s);
+  const double inv = 1.0 / N, den = N > 1 ? 1.0 / (double)(N - 1) : 1.0;
+  const double vx = fmax(0.0, (s[1] - s[0] * s[0] * inv) * den);
+  const double vy = fmax(0.0, (s[3] - s[2] * s[2] * inv) * den);
+  return (sqrt(vx) + sqrt(vy)) * 0.5;
+}
 
 struct P2P2 {
   static constexpr int DF = 3, DT = 3, DZ = 3, NL = 6;
@@ -57,35 +97,14 @@ struct P2P2 {
     z[2] = K.mu[2] + K.L[3] * xi[0] + K.L[4] * xi[1] + K.L[5] * xi[2];
   }
   __device__ static __forceinline__ void canonical(double (&t)[3]) { t[2] = wrap_pi(t[2]); }
-  __device__ static __forceinline__ bool needs_cycles(int solver, const Consts&) { return solver != kSolverClosedForm; }
-
+  __device__ static __forceinline__ bool needs_cycles(int solver, const Consts& K) {
+    return solver != kSolverClosedForm && K.dir != kDirPrior;
+  }
   template <int PPL>
   __device__ static __forceinline__ double spread(const double (&t)[PPL][3], const bool (&act)[PPL], int N) {
-    double s[4] = {0, 0, 0, 0};
-    double sn[PPL], cs[PPL];
-#pragma unroll
-    for (int k = 0; k < PPL; ++k) {
-      sincos(t[k][2], &sn[k], &cs[k]);
-      if (act[k]) { s[0] += t[k][0]; s[1] += t[k][1]; s[2] += sn[k]; s[3] += cs[k]; }
-    }
-    wave_sum_n<4>(s);
-    const double mx = s[0] / N, my = s[1] / N, mt = atan2(s[2], s[3]);
-    double sm, cm; sincos(mt, &sm, &cm);
-    double v[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < PPL; ++k) {
-      const double dx = t[k][0] - mx, dy = t[k][1] - my;
-      const double dt = atan2(cm * sn[k] - sm * cs[k], cm * cs[k] + sm * sn[k]);
-      if (act[k]) { v[0] += dx * dx; v[1] += dy * dy; v[2] += dt * dt; }
-    }
-    wave_sum_n<3>(v);
-    const double den = N > 1 ? (double)(N - 1) : 1.0;
-    return (sqrt(v[0] / den) + sqrt(v[1] / den) + sqrt(v[2] / den)) / 3.0;
+    return spread_se2<PPL>(t, act, N);
   }
-  __device__ static __forceinline__ void add_entropy(double (&t)[3], double spread, uint64_t seed, uint64_t stream,
-                                                     uint32_t i, int cyc) {
-    double u[3];
-    rng_entropy<3>(seed, stream, i, cyc, u);
+  __device__ static __forceinline__ void add_entropy(double (&t)[3], double spread, const double (&u)[3]) {
     se2_add_entropy(t, spread, u);
     t[2] = wrap_pi(t[2]);
   }
@@ -94,35 +113,44 @@ struct P2P2 {
   __device__ static __forceinline__ int solve(const Consts& K, const double (&z)[3], const double (&fxc)[3],
                                               double (&t)[3], int max_iters, double tol) {
     int st = 0;
-    if constexpr (SOLVER == kSolverClosedForm) {
-      if (K.dir == 0) {
-        double s, c; sincos(fxc[2], &s, &c);
-        t[0] = fxc[0] + c * z[0] - s * z[1]; t[1] = fxc[1] + s * z[0] + c * z[1]; t[2] = fxc[2] + z[2];
-      } else {
-        const double th = fxc[2] - z[2];
-        double s, c; sincos(th, &s, &c);
-        t[0] = fxc[0] - (c * z[0] - s * z[1]); t[1] = fxc[1] - (s * z[0] + c * z[1]); t[2] = th;
-      }
-    } else {
-      const Se2 F = se2_from_coords(fxc[0], fxc[1], fxc[2]);
-      double sz, cz; sincos(z[2], &sz, &cz);
-      if constexpr (SOLVER == kSolverNewton) {
+    if (K.dir == kDirPrior) {  // PriorPose2 row: the sample exp_ϵ(hat(μ + Lξ)) itself is the proposal
+      t[0] = z[0]; t[1] = z[1]; t[2] = wrap_pi(z[2]);
+      return 0;
+    }
+    if (K.dir == 0) {
+      // q̂ = p ∘ exp_ϵ(z)
+      double s, c; fast_sincos(fxc[2], &s, &c);
+      const double qx = fxc[0] + c * z[0] - s * z[1], qy = fxc[1] + s * z[0] + c * z[1], qth = fxc[2] + z[2];
+      if constexpr (SOLVER == kSolverClosedForm) { t[0] = qx; t[1] = qy; t[2] = qth; }
+      else if constexpr (SOLVER == kSolverNewton) {
         st = 1;
         for (int it = 0; it < max_iters; ++it) {
-          const Se2 T = se2_from_coords(t[0], t[1], t[2]);
-          double r[3];
-          if (K.dir == 0) residual_pose2pose2(z[0], z[1], cz, sz, F, T, r);
-          else            residual_pose2pose2(z[0], z[1], cz, sz, T, F, r);
-          if (fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2]))) <= tol) { st = 0; break; }
-          if (K.dir == 0) { t[0] += r[0]; t[1] += r[1]; t[2] += r[2]; }
-          else {
-            const double J13 = -T.s * z[0] - T.c * z[1], J23 = T.c * z[0] - T.s * z[1];
-            const double dth = -r[2];
-            t[0] += -r[0] - J13 * dth; t[1] += -r[1] - J23 * dth; t[2] += dth;
-          }
+          const double r0 = qx - t[0], r1 = qy - t[1], r2 = wrap_pi(qth - t[2]);
+          if (fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol) { st = 0; break; }
+          t[0] += r0; t[1] += r1; t[2] += r2;   // J = -I
         }
       } else {
-        P2P2Cost cost{z[0], z[1], cz, sz, F, K.dir};
+        P2P2Cost cost{z[0], z[1], qx, qy, qth, 0};
+        st = nelder_mead<3>(cost, t, max_iters, tol);
+      }
+    } else {
+      const double pth = fxc[2] - z[2];  // θp = θq - zθ
+      if constexpr (SOLVER == kSolverClosedForm) {
+        double s, c; fast_sincos(pth, &s, &c);
+        t[0] = fxc[0] - (c * z[0] - s * z[1]); t[1] = fxc[1] - (s * z[0] + c * z[1]); t[2] = pth;
+      } else if constexpr (SOLVER == kSolverNewton) {
+        st = 1;
+        for (int it = 0; it < max_iters; ++it) {
+          double s, c; fast_sincos(t[2], &s, &c);
+          const double r0 = t[0] + c * z[0] - s * z[1] - fxc[0], r1 = t[1] + s * z[0] + c * z[1] - fxc[1];
+          const double r2 = wrap_pi(t[2] - pth);
+          if (fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol) { st = 0; break; }
+          const double J13 = -s * z[0] - c * z[1], J23 = c * z[0] - s * z[1];
+          const double dth = -r2;
+          t[0] += -r0 - J13 * dth; t[1] += -r1 - J23 * dth; t[2] += dth;
+        }
+      } else {
+        P2P2Cost cost{z[0], z[1], fxc[0], fxc[1], pth, 1};
         st = nelder_mead<3>(cost, t, max_iters, tol);
       }
     }
@@ -166,25 +194,10 @@ struct BR {
   }
   template <int PPL>
   __device__ static __forceinline__ double spread(const double (&t)[PPL][DT], const bool (&act)[PPL], int N) {
-    if constexpr (DT == 3) return P2P2::spread<PPL>(t, act, N);
-    else {
-      double s[2] = {0, 0};
-#pragma unroll
-      for (int k = 0; k < PPL; ++k) if (act[k]) { s[0] += t[k][0]; s[1] += t[k][1]; }
-      wave_sum_n<2>(s);
-      const double mx = s[0] / N, my = s[1] / N;
-      double v[2] = {0, 0};
-#pragma unroll
-      for (int k = 0; k < PPL; ++k) { const double dx = t[k][0] - mx, dy = t[k][1] - my; if (act[k]) { v[0] += dx * dx; v[1] += dy * dy; } }
-      wave_sum_n<2>(v);
-      const double den = N > 1 ? (double)(N - 1) : 1.0;
-      return (sqrt(v[0] / den) + sqrt(v[1] / den)) / 2.0;
-    }
+    if constexpr (DT == 3) return spread_se2<PPL>(t, act, N);
+    else return spread_r2<PPL>(t, act, N);
   }
-  __device__ static __forceinline__ void add_entropy(double (&t)[DT], double spread, uint64_t seed, uint64_t stream,
-                                                     uint32_t i, int cyc) {
-    double u[DT];
-    rng_entropy<DT>(seed, stream, i, cyc, u);
+  __device__ static __forceinline__ void add_entropy(double (&t)[DT], double spread, const double (&u)[DT]) {
     if constexpr (DT == 3) { se2_add_entropy(t, spread, u); t[2] = wrap_pi(t[2]); }
     else { t[0] += spread * (u[0] - 0.5); t[1] += spread * (u[1] - 0.5); }
   }
@@ -194,7 +207,7 @@ struct BR {
     int st = 0;
     if constexpr (SOLVER == kSolverClosedForm) {
       if constexpr (DIR == 0) {
-        double s, c; sincos(fx[2] + z[0], &s, &c);
+        double s, c; fast_sincos(fx[2] + z[0], &s, &c);
         t[0] = fx[0] + z[1] * c; t[1] = fx[1] + z[1] * s;
       } else {
         const double dx = fx[0] - t[0], dy = fx[1] - t[1];
@@ -214,7 +227,7 @@ struct BR {
           const double plx = P.c * dx + P.s * dy, ply = -P.s * dx + P.c * dy;
           const double n = sqrt(plx * plx + ply * ply), phi = atan2(ply, plx);
           const double nn = n + r[1];
-          double sa, ca; sincos(phi + r[0], &sa, &ca);
+          double sa, ca; fast_sincos(phi + r[0], &sa, &ca);
           const double qx = nn * ca, qy = nn * sa;
           t[0] = fx[0] + P.c * qx - P.s * qy; t[1] = fx[1] + P.s * qx + P.c * qy;
         } else {
@@ -276,59 +289,38 @@ struct P3P3 {
     }
   }
   __device__ static __forceinline__ void canonical(double (&t)[6]) { Se3 P; se3_from_coords(t, P); se3_to_coords(P, t); }
-  __device__ static __forceinline__ bool needs_cycles(int solver, const Consts&) { return solver != kSolverClosedForm; }
+  __device__ static __forceinline__ bool needs_cycles(int solver, const Consts& K) {
+    return solver != kSolverClosedForm && K.dir != kDirPrior;
+  }
 
+  // std of the tangent coordinates about particle 0: translation differences and Log(R0ᵀ R_i)
   template <int PPL>
   __device__ static __forceinline__ double spread(const double (&t)[PPL][6], const bool (&act)[PPL], int N) {
-    double st[3] = {0, 0, 0};
+    double c0[6], R0[9];
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) if (act[k]) { st[0] += t[k][0]; st[1] += t[k][1]; st[2] += t[k][2]; }
-    wave_sum_n<3>(st);
-    const double mt[3] = {st[0] / N, st[1] / N, st[2] / N};
-    // rotation mean: particle 0 refined by 2 Karcher steps
-    double Rm[9];
-    {
-      double w0[3];
+    for (int k = 0; k < 6; ++k) c0[k] = readlane_f64(t[0][k], 0);
+    so3_exp(c0 + 3, R0);
+    double s[12];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) w0[k] = __shfl(t[0][3 + k], 0, 64);
-      so3_exp(w0, Rm);
-    }
-    for (int it = 0; it < 2; ++it) {
-      double acc[3] = {0, 0, 0};
-#pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        double R[9], U[9], d[3];
-        so3_exp(&t[k][3], R); mat3_tmul(Rm, R, U); so3_log(U, d);
-        if (act[k]) { acc[0] += d[0]; acc[1] += d[1]; acc[2] += d[2]; }
-      }
-      wave_sum_n<3>(acc);
-      const double dm[3] = {acc[0] / N, acc[1] / N, acc[2] / N};
-      double E[9], Tn[9];
-      so3_exp(dm, E); mat3_mul(Rm, E, Tn);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) Rm[k] = Tn[k];
-    }
-    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < 12; ++j) s[j] = 0.0;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
-      double R[9], U[9], d[3];
-      so3_exp(&t[k][3], R); mat3_tmul(Rm, R, U); so3_log(U, d);
+      double R[9], U[9], d[6];
+      so3_exp(&t[k][3], R); mat3_tmul(R0, R, U); so3_log(U, d + 3);
+      d[0] = t[k][0] - c0[0]; d[1] = t[k][1] - c0[1]; d[2] = t[k][2] - c0[2];
       if (act[k]) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { const double e = t[k][j] - mt[j]; v[j] += e * e; v[3 + j] += d[j] * d[j]; }
+        for (int j = 0; j < 6; ++j) { s[2 * j] += d[j]; s[2 * j + 1] += d[j] * d[j]; }
       }
     }
-    wave_sum_n<6>(v);
-    const double den = N > 1 ? (double)(N - 1) : 1.0;
-    double s = 0;
+    wave_sum_n<12>(s);
+    const double inv = 1.0 / N, den = N > 1 ? 1.0 / (double)(N - 1) : 1.0;
+    double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) s += sqrt(v[j] / den);
-    return s / 6.0;
+    for (int j = 0; j < 6; ++j) acc += sqrt(fmax(0.0, (s[2 * j + 1] - s[2 * j] * s[2 * j] * inv) * den));
+    return acc * (1.0 / 6.0);
   }
-  __device__ static __forceinline__ void add_entropy(double (&t)[6], double spread, uint64_t seed, uint64_t stream,
-                                                     uint32_t i, int cyc) {
-    double u[6];
-    rng_entropy<6>(seed, stream, i, cyc, u);
+  __device__ static __forceinline__ void add_entropy(double (&t)[6], double spread, const double (&u)[6]) {
     Se3 T; se3_from_coords(t, T);
     se3_add_entropy(T, spread, u);
     se3_to_coords(T, t);
@@ -338,6 +330,10 @@ struct P3P3 {
                                               double (&t)[6], int max_iters, double tol) {
     int st = 0;
     Se3 F, T;
+    if (K.dir == kDirPrior) {  // PriorPose3 row
+      se3_from_coords(z, T); se3_to_coords(T, t);
+      return 0;
+    }
     se3_from_coords(fxc, F);
     double Z[9];
     so3_exp(&z[3], Z);
@@ -449,13 +445,25 @@ __global__ void __launch_bounds__(256) k_conv(const ConvArgs a) {
 
   const bool cyc_on = FP::needs_cycles(SOLVER, K);
   const int ncyc = cyc_on ? (a.cycles < 1 ? 1 : a.cycles) : 1;
+  constexpr int CPC = FP::DT <= 3 ? 3 : 1;  // inflation cycles served by one Philox call
+  EntropyWords ew[PPL];
+  int have_call = -1;
   for (int cyc = 0; cyc < ncyc; ++cyc) {
     double spread = 0.0;
     if (cyc_on && a.inflation > 0.0 && N > 1) spread = a.inflation * FP::template spread<PPL>(t, act, N);
+    if (spread > 0.0 && have_call != cyc / CPC) {  // wave-uniform
+      have_call = cyc / CPC;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) ew[k] = rng_entropy_words(a.seed, stream, (uint32_t)(lane + 64 * k), have_call);
+    }
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       if (act[k]) {
-        if (spread > 0.0) FP::add_entropy(t[k], spread, a.seed, stream, (uint32_t)(lane + 64 * k), cyc);
+        if (spread > 0.0) {
+          double u[FP::DT];
+          rng_entropy_from_words<FP::DT>(ew[k], cyc % CPC, u);
+          FP::add_entropy(t[k], spread, u);
+        }
         st[k] = FP::template solve<SOLVER>(K, z[k], fx[k], t[k], a.max_iters, a.tol);
       }
     }
@@ -516,7 +524,7 @@ __global__ void k_residual_pose2pose2(int n, const double* z, const double* p, c
   if (i >= n) return;
   const Se2 P = se2_from_coords(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
   const Se2 Q = se2_from_coords(q[3 * i], q[3 * i + 1], q[3 * i + 2]);
-  double sz, cz; sincos(z[3 * i + 2], &sz, &cz);
+  double sz, cz; fast_sincos(z[3 * i + 2], &sz, &cz);
   double rr[3];
   residual_pose2pose2(z[3 * i], z[3 * i + 1], cz, sz, P, Q, rr);
   r[3 * i] = rr[0]; r[3 * i + 1] = rr[1]; r[3 * i + 2] = rr[2];

@@ -38,11 +38,19 @@ class DeviceGraph:
                     Point2: torch.zeros((len(pk.labels[Point2]), 2, self.N), dtype=f64, device=self.device),
                     Pose3: torch.zeros((len(pk.labels[Pose3]), 6, self.N), dtype=f64, device=self.device)}
         self.tab = {}
-        for name, tab, d in (("p2p2", pk.p2p2, 3), ("p3p3", pk.p3p3, 6)):
-            if tab["F"] == 0:
+        # relative factors: both directions interleaved, then one ROME_DIR_PRIOR row per prior factor, so a
+        # whole-graph sweep of one variable family is a single launch
+        for name, tab, ptab, d in (("p2p2", pk.p2p2, pk.prior2, 3), ("p3p3", pk.p3p3, pk.prior3, 6)):
+            if tab["F"] == 0 and ptab["F"] == 0:
                 continue
             factor, dr, fixed, target = PackedGraph.conv_table(tab)
-            self.tab[name] = dict(F=tab["F"], C=2 * tab["F"], mu=t(tab["mu"], f64), L=t(cholesky_lower(tab["cov"]), f64),
+            F, P = tab["F"], ptab["F"]
+            mu = np.concatenate([tab["mu"].reshape(F, d), ptab["mu"].reshape(P, d)])
+            cov = np.concatenate([tab["cov"].reshape(F, d, d), ptab["cov"].reshape(P, d, d)])
+            factor = np.concatenate([factor, F + np.arange(P, dtype=np.int32)])
+            dr = np.concatenate([dr, np.full(P, 2, dtype=np.int32)])
+            fixed = np.concatenate([fixed, ptab["var"]]); target = np.concatenate([target, ptab["var"]])
+            self.tab[name] = dict(F=F, P=P, C_rel=2 * F, C=2 * F + P, mu=t(mu, f64), L=t(cholesky_lower(cov), f64),
                                   factor=t(factor, i32), dir=t(dr, i32), fixed=t(fixed, i32), target=t(target, i32))
         if pk.br["F"]:
             b = pk.br
@@ -65,15 +73,65 @@ class DeviceGraph:
         return None if x is None else C.c_void_p(x.data_ptr())
 
     def _launch(self, fn, opts, **kw):
-        self._bind_stream()
+        self._plan(fn, opts, **kw)()
+
+    def _plan(self, fn, opts, **kw):
+        """Pre-builds the rome_conv_dev descriptor once; the returned callable only binds the current
+        torch stream and issues the launch (what a captured / replayed step calls)."""
         cd = _lib.ConvDev()
+        keep = []
         for k, v in kw.items():
-            setattr(cd, k, v if isinstance(v, int) else (v.data_ptr() if v is not None else None))
-        _lib.check(fn(self.ctx.handle, C.byref(opts), C.byref(cd)), self.ctx.handle)
+            if isinstance(v, int):
+                setattr(cd, k, v)
+            elif v is not None:
+                keep.append(v)
+                setattr(cd, k, v.data_ptr())
+        o = _lib.Opts.from_buffer_copy(opts)
+        ctx, check, cur = self.ctx, _lib.check, self.torch.cuda.current_stream
+        h = ctx.handle
+        po, pc = C.byref(o), C.byref(cd)
+
+        def launch():
+            ctx.set_stream(cur(self.device).cuda_stream)
+            rc = fn(h, po, pc)
+            if rc:
+                check(rc, h)
+        launch._keep = (keep, o, cd)
+        return launch
+
+    def plan_sweep_pose2pose2(self, opts, out, noise=None, status=None):
+        tb = self.tab["p2p2"]
+        return self._plan(self._lib.rome_conv_pose2pose2_dev, opts, n_conv=tb["C"], dir_all=0,
+                          factor=tb["factor"], dir=tb["dir"], fixed_var=tb["fixed"], target_var=tb["target"],
+                          mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Pose2],
+                          noise=noise, out=out, status=status)
+
+    def plan_sample_priors(self, opts, out, kind="prior2", noise=None):
+        tb = self.tab[kind]
+        fn = self._lib.rome_sample_priorpose2_dev if kind == "prior2" else self._lib.rome_sample_priorpose3_dev
+        return self._plan(fn, opts, n_conv=tb["F"], dir_all=0, mu=tb["mu"], L=tb["L"], noise=noise, out=out)
+
+    def capture(self, fn, warmup=2):
+        """Capture `fn` (a sequence of launches on the current stream) into a hipGraph; returns the
+        torch.cuda.CUDAGraph (call .replay()).  Launch-bound inner loops (one sweep is ~10-20 µs of GPU
+        time) are replayed without per-launch host cost."""
+        torch = self.torch
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            fn()
+        return g
 
     # ---- sweeps ----
     def sweep_pose2pose2(self, opts, out=None, noise=None, status=None, conv_slice=None):
-        """All (factor, direction) Pose2Pose2 convolutions -> proposals [2F, 3, N] (conv 2f+dir)."""
+        """All (factor, direction) Pose2Pose2 convolutions (row 2f+dir) followed by the PriorPose2 rows
+        -> proposals [2F+P, 3, N], one launch."""
         tb = self.tab["p2p2"]
         lo, hi = (0, tb["C"]) if conv_slice is None else conv_slice
         n = hi - lo
