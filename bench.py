@@ -92,19 +92,15 @@ def main():
 
     pk = dg.packed
     if world > 1:
-        sep_send = torch.empty((2, 3, N), dtype=torch.float64, device=dev)      # this rank's first/last pose beliefs
-        sep_all = torch.empty((world, 2, 3, N), dtype=torch.float64, device=dev)
-        g_prev, g_next = pk.index["ghost_prev"], pk.index["ghost_next"]
+        from rome_jl_amd.distributed import chain_segment_exchange
+        bel = dg.bel[R.Pose2]
+        ex = chain_segment_exchange(torch, dist, world, rank, N, dev, pk.index["ghost_prev"], pk.index["ghost_next"])
         # proposal rows that carry the updated separator estimates (odometry convolutions targeting them)
         conv_first = 2 * 0 + 1                                   # factor 0 (x0->x1), dir 1 -> target x0
         conv_last = 2 * (args.poses - 2) + 0 if not args.g2o else 0  # factor P-2 (x_{P-2}->x_{P-1}), dir 0
-        bel = dg.bel[R.Pose2]
 
         def exchange():
-            sep_send[0].copy_(prop[conv_first]); sep_send[1].copy_(prop[conv_last])
-            dist.all_gather_into_tensor(sep_all, sep_send)
-            bel[g_prev].copy_(sep_all[(rank - 1) % world, 1])
-            bel[g_next].copy_(sep_all[(rank + 1) % world, 0])
+            ex.exchange([prop[conv_first], prop[conv_last]], bel)
     else:
         def exchange():
             pass

@@ -20,6 +20,7 @@ from .graph import (FactorGraph, initfg, importG2o, parseG2oInstruction, loadG2o
                     PackedGraph, dead_reckon_init)
 from .convolution import approxConv, approxConvBelief
 from .device import DeviceGraph
+from . import distributed
 
 
 def build(force=False, verbose=False):

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "librome_mi355.so")
+SO = os.environ.get("ROME_MI355_LIB") or os.path.join(HERE, "librome_mi355.so")  # override: kernel A/B experiments
 
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED_N, ERR_ALLOC = -1, -2, -3, -4, -5, -6

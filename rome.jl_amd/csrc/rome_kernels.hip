@@ -400,8 +400,11 @@ struct P3P3 {
 // ------------------------------------------------------------------------------------------
 // the convolution kernel
 // ------------------------------------------------------------------------------------------
+#ifndef ROME_MIN_WAVES
+#define ROME_MIN_WAVES 1
+#endif
 template <class FP, int SOLVER, int PPL>
-__global__ void __launch_bounds__(256) k_conv(const ConvArgs a) {
+__global__ void __launch_bounds__(256, ROME_MIN_WAVES) k_conv(const ConvArgs a) {
   const int lane = threadIdx.x & 63;
   const int c = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (int)(threadIdx.x >> 6));
   if (c >= a.n_conv) return;

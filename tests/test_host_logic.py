@@ -1,0 +1,208 @@
+"""CPU-only tests: C-ABI surface, host-side mirror of the reference interface, graph packing,
+g2o import (reference fixture test/octagon.g2o), generators, oracle self-consistency."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as ro
+import rome_jl_amd as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rome_mi355.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rome_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = R._lib.load()
+    for name in declared:
+        assert hasattr(lib, name), "librome_mi355.so does not export %s" % name
+    assert declared == set(R._lib.SIGNATURES), declared ^ set(R._lib.SIGNATURES)
+    assert lib.rome_version() == 100
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(R._lib.Opts) == 56
+    assert ctypes.sizeof(R._lib.ConvDev) == 8 + 11 * 8
+    o = R.make_opts(solver=R.SOLVER_NELDER_MEAD)
+    assert (o.n_particles, o.max_iters, o.inflate_cycles, o.tol, o.inflation) == (100, 1000, 3, 1e-8, 5.0)
+    o = R.make_opts(N=64)
+    assert (o.solver, o.max_iters, o.tol, o.seed) == (R.SOLVER_NEWTON, 20, 1e-12, 0x524F4D45)
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product path must fail loudly (never route through the oracle)."""
+    if _has_gpu():
+        pytest.skip("GPU present")
+    with pytest.raises(R.RomeError) as e:
+        R.Context(0)
+    assert e.value.code == R._lib.ERR_NO_DEVICE
+    with pytest.raises(RuntimeError):
+        R.DeviceGraph(R.generateGraph_Hexagonal())
+    with pytest.raises(R.RomeError):
+        R.residual_pose2pose2([[0, 0, 0]], [[0, 0, 0]], [[0, 0, 0]])
+    src = "".join(open(os.path.join(ROOT, "rome.jl_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "rome.jl_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_cholesky_host_helper_matches_oracle_and_numpy():
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((5, 6, 6)); cov = A @ A.transpose(0, 2, 1) + np.eye(6)
+    L = R.cholesky_lower(cov)
+    for k in range(5):
+        assert np.allclose(L[k], ro.cholesky_lower(cov[k]), atol=0)
+        Lf = np.linalg.cholesky(cov[k])
+        assert np.allclose(L[k], Lf[np.tril_indices(6)], atol=1e-13)
+    with pytest.raises(R.RomeError) as e:
+        R.cholesky_lower(-np.eye(3))
+    assert e.value.code == R._lib.ERR_NOT_POSDEF
+
+
+# ------------------------------------------------------------------ factors / plugin surface
+def test_factor_constructors_and_defaults():
+    f = R.Pose2Pose2()
+    assert np.array_equal(f.Z.cov, np.eye(3))                      # Pose2D.jl:31
+    assert np.array_equal(R.PriorPose2().Z.cov, np.diag([1, 1, 0.1]))   # PriorPose2.jl:14
+    assert np.allclose(np.diag(R.Pose3Pose3().Z.cov), [0.01] * 3 + [0.0001] * 3)  # Pose3Pose3.jl:10
+    with pytest.raises(ValueError):
+        R.Pose2Pose2(R.MvNormal(np.zeros(2), np.eye(2)))
+    with pytest.raises(TypeError):
+        R.Pose2Point2BearingRange(R.MvNormal(np.zeros(3), np.eye(3)), R.Normal(1, 1))
+
+
+def test_getMeasurementParametric_bearingrange():
+    # src/factors/BearingRange2D.jl:30-37
+    mu, iS = R.getMeasurementParametric(R.Pose2Point2BearingRange(R.Normal(0.3, 0.1), R.Normal(20.0, 2.0)))
+    assert np.allclose(mu, [0.3, 20.0]) and np.allclose(iS, np.diag([100.0, 0.25]))
+
+
+def test_packed_factor_roundtrip():
+    # test/testpackingconverters.jl:51-132 (Packed* <-> factor for the hot-path factors)
+    fs = [R.Pose2Pose2(R.MvNormal([1, 2, 0.3], np.diag([0.1, 0.2, 0.3]))), R.PriorPose2(R.MvNormal([0, 0, 0], 0.01 * np.eye(3))),
+          R.Pose2Point2BearingRange(R.Normal(0.1, 0.05), R.Normal(20, 1)), R.Pose3Pose3(), R.PriorPose3()]
+    for f in fs:
+        g = R.unpack_factor(json.loads(json.dumps(R.pack_factor(f))))
+        assert type(g) is type(f)
+        if hasattr(f, "Z"):
+            assert np.array_equal(g.Z.mu, f.Z.mu) and np.array_equal(g.Z.cov, f.Z.cov)
+        else:
+            assert (g.bearing.mu, g.bearing.sigma, g.range.mu, g.range.sigma) == (f.bearing.mu, f.bearing.sigma, f.range.mu, f.range.sigma)
+
+
+def test_point_coordinate_layouts():
+    c = np.array([1.0, -2.0, 0.7])
+    p = R.getPoint(R.Pose2, c)
+    assert np.allclose(p, ro.pose2_point(c)) and np.allclose(R.getCoordinates(R.Pose2, p), c)
+    c6 = np.array([1.0, 2.0, 3.0, 0.3, -0.2, 0.5])
+    p6 = R.getPoint(R.Pose3, c6)
+    assert np.allclose(p6, ro.pose3_point(c6), atol=1e-15) and np.allclose(R.getCoordinates(R.Pose3, p6), c6)
+
+
+# ------------------------------------------------------------------ g2o + graph packing
+def test_g2o_import_octagon_fixture():
+    # test/testG2oParser.jl:4-20 on the reference's own data file
+    ins = R.importG2o(os.path.join(GOLDEN, "octagon.g2o"))
+    assert ins[0][0] == "EDGE_SE2" and ins[6][0] == "EDGE_SE2"
+    assert ins[5][11] == "6541.252776" and ins[2][6] == "1211.201664"
+    assert len(ins) == 8 and len(ins[1]) == 12
+    fg = R.initfg()
+    for i in ins:
+        R.parseG2oInstruction(fg, i)
+    assert len(fg.variables) == 8 and len(fg.factors) == 8
+    _, labels, f = fg.factors[0]
+    assert labels == ["x0", "x1"] and np.allclose(f.Z.mu, [1.0, 0.0, 0.785])
+    info = np.array([[3533.219465, 13825.498244, 0.0], [13825.498244, 54832.844537, 0.0], [0.0, 0.0, 6065.357771]])
+    cov = np.linalg.inv(info); cov = (cov + cov.T) / 2           # src/services/g2oParser.jl:103-109
+    assert np.allclose(f.Z.cov, cov, rtol=1e-12) and np.array_equal(f.Z.cov, f.Z.cov.T)
+
+
+def test_hexagonal_generator_matches_reference_shape():
+    # src/canonical/GenerateCircular.jl:56-90 ; BASELINE.json configs[0]
+    fg = R.generateGraph_Hexagonal()
+    assert [l for l in fg.variables] == ["x0", "x1", "x2", "x3", "x4", "x5", "x6", "l1"]
+    kinds = [type(f).__name__ for _, _, f in fg.factors]
+    assert kinds == ["PriorPose2"] + ["Pose2Pose2"] * 6 + ["Pose2Point2BearingRange"] * 2
+    _, _, pp = fg.factors[1]
+    assert np.allclose(pp.Z.mu, [10.0, 0.0, np.pi / 3]) and np.allclose(pp.Z.cov, np.diag([0.01] * 3))
+    assert fg.factors[-1][1] == ["x6", "l1"]
+
+
+def test_synth_manhattan_shape_and_tables():
+    fg = R.synth_manhattan()
+    assert len(fg.variables) == 3500 and len(fg.factors) == 5454
+    pk = R.PackedGraph(fg)
+    assert pk.p2p2["F"] == 5453 and pk.prior2["F"] == 1
+    assert (pk.p2p2["var_to"][:3499] - pk.p2p2["var_from"][:3499] == 1).all()      # odometry chain
+    assert ((pk.p2p2["var_to"][3499:] - pk.p2p2["var_from"][3499:]) >= 4).all()     # closures i<j
+    factor, dr, fixed, target = R.PackedGraph.conv_table(pk.p2p2)
+    assert len(factor) == 10906 and dr[:4].tolist() == [0, 1, 0, 1]
+    assert fixed[0] == pk.p2p2["var_from"][0] and target[0] == pk.p2p2["var_to"][0]
+    assert fixed[1] == pk.p2p2["var_to"][0] and target[1] == pk.p2p2["var_from"][0]
+    for k in range(5453):                                              # every Σ positive definite
+        np.linalg.cholesky(pk.p2p2["cov"][k])
+    fg2 = R.synth_manhattan()
+    assert np.array_equal(R.PackedGraph(fg2).p2p2["mu"], pk.p2p2["mu"])  # deterministic
+
+
+def test_dead_reckon_init_follows_odometry():
+    fg = R.generateGraph_Hexagonal(N=50)
+    R.dead_reckon_init(fg, sigma=(0, 0, 0))
+    assert np.allclose(fg.getVal("x1")[:, 0], [10, 0, np.pi / 3])
+    assert np.allclose(fg.getVal("x3")[:2, 0], [10, 17.320508], atol=1e-5)   # test/testParametricSimulated.jl:152
+
+
+# ------------------------------------------------------------------ oracle self-consistency (solvers agree)
+def test_oracle_solvers_agree_pose2pose2():
+    rng = np.random.default_rng(4)
+    N, V = 100, 12
+    bel = rng.standard_normal((V, 3, N)) * np.array([0.2, 0.2, 0.05])[None, :, None] + rng.standard_normal((V, 3, 1)) * [[5], [5], [2]]
+    F = V - 1
+    mu = rng.standard_normal((F, 3)); L = np.tile(ro.cholesky_lower(np.diag([0.02, 0.01, 0.003])), (F, 1))
+    fv = np.repeat(np.arange(F), 2); tv = fv.copy(); dr = np.tile([0, 1], F)
+    fv[0::2] = np.arange(F); tv[0::2] = np.arange(F) + 1; fv[1::2] = np.arange(F) + 1; tv[1::2] = np.arange(F)
+    fa = np.repeat(np.arange(F), 2)
+    outs = [ro.conv_pose2pose2(ro.make_opts(N=N, solver=s, seed=9), mu, L, bel, fv, tv, dr, factor=fa) for s in (0, 1, 2)]
+    d01 = outs[0] - outs[1]; d01[:, 2] = np.arctan2(np.sin(d01[:, 2]), np.cos(d01[:, 2]))
+    assert np.abs(d01).max() < 1e-11
+    d02 = outs[0] - outs[2]; d02[:, 2] = np.arctan2(np.sin(d02[:, 2]), np.cos(d02[:, 2]))
+    assert np.median(np.abs(d02).max(axis=1)) < 5e-4      # Optim NM accuracy ~1e-4
+
+
+def test_oracle_bearingrange_constraint_and_ring():
+    # test/TestPoseAndPoint2Constraints.jl:97-105 analogue: landmark proposals lie on the range ring
+    N = 100
+    rng = np.random.default_rng(2)
+    pose = np.zeros((1, 3, N)); pose[0, :2] = 0.01 * rng.standard_normal((2, N))
+    lm0 = np.zeros((1, 2, N))
+    out = ro.conv_pose2point2br(ro.make_opts(N=N, solver=1), 0, [[0.0, 10.0]], [[3.0, 1.0]], pose, lm0, [0], [0])
+    r = np.hypot(out[0, 0], out[0, 1])
+    assert (r > 5).all() and (r < 15).all()
+
+
+def test_oracle_nelder_mead_on_rosenbrock():
+    # Optim.jl README example: NelderMead on Rosenbrock from (0,0) converges to (1,1)
+    f = lambda x: (1 - x[0]) ** 2 + 100 * (x[1] - x[0] ** 2) ** 2
+    x, rc, ne = ro.nelder_mead(f, [0.0, 0.0])
+    assert rc == 0 and np.allclose(x, [1, 1], atol=1e-3) and 50 < ne < 400
+
+
+def test_entropy_rng_definition():
+    u = ro.rng_entropy(7, 3, 5, 0, 3); v = ro.rng_entropy(7, 3, 5, 1, 3); w = ro.rng_entropy(7, 3, 5, 3, 3)
+    assert ((u > 0) & (u < 1)).all() and not np.allclose(u, v) and not np.allclose(u, w)
+    assert np.allclose(u * 16384 - 0.5, np.round(u * 16384 - 0.5))     # 14-bit fields
+    u6 = ro.rng_entropy(7, 3, 5, 2, 6)
+    assert np.allclose(u6 * (1 << 21) - 0.5, np.round(u6 * (1 << 21) - 0.5))
+    allu = np.array([ro.rng_entropy(1, 0, i, c, 3) for i in range(400) for c in range(6)])
+    assert abs(allu.mean() - 0.5) < 0.02 and abs(allu.std() - 12 ** -0.5) < 0.02
