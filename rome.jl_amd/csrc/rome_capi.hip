@@ -62,6 +62,8 @@ void fill_args(rome::ConvArgs& a, const rome_opts* o) {
   a.cycles = o->inflate_cycles;
   a.tol = o->tol;
   a.inflation = o->inflation;
+  a.inv_n = 1.0 / (double)o->n_particles;
+  a.inv_nm1 = o->n_particles > 1 ? 1.0 / (double)(o->n_particles - 1) : 1.0;
   a.seed = o->seed;
   a.stream_offset = o->stream_offset;
 }

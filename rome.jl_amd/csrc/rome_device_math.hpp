@@ -54,6 +54,39 @@ __device__ __forceinline__ double wrap_pi(double th) {
 }
 
 
+// sqrt(x), x >= 0 finite: v_rsq_f64 seed + one coupled Goldschmidt step + one residual correction
+// (≈ 45 SIMD-cycles per wave instead of ≈ 100 for the library call; ≤ 1 ulp on normal inputs).
+__device__ __forceinline__ double fast_sqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  const double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  return x > 0.0 ? g : 0.0;
+}
+// log(u) for normal positive doubles (used on u in (0,1]): fdlibm's e_log.c kernel (< 1 ulp).
+__device__ __forceinline__ double fast_log(double x) {
+  const long long bits = __double_as_longlong(x);
+  int hx = (int)(bits >> 32);
+  const unsigned lx = (unsigned)bits;
+  int k = (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  const int i = (hx + 0x95f64) & 0x100000;
+  k += i >> 20;
+  const double m = __longlong_as_double(((long long)(hx | (i ^ 0x3ff00000)) << 32) | lx);
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                            6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)k;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
 // ------------------------------------------------------------------------------------------
 // Philox4x32-10 (Random123).  Integer only -> bit-identical to any other conforming implementation.
 // ------------------------------------------------------------------------------------------
@@ -86,7 +119,7 @@ __device__ __forceinline__ void rng_normals(uint64_t seed, uint64_t stream, uint
     const u32x4 w = philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32), (kDomainNoise << 16) | (uint32_t)b},
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
     const double u1 = u53(w.x, w.y), u2 = u53(w.z, w.w);
-    const double rr = sqrt(-2.0 * log(u1));
+    const double rr = fast_sqrt(-2.0 * fast_log(u1));
     double s, c;
     fast_sincos(2.0 * kPi * u2, &s, &c);
     out[2 * b] = rr * c;

@@ -28,6 +28,8 @@ struct ConvArgs {
   int cycles;
   double tol;
   double inflation;
+  double inv_n;               // 1/N and 1/(N-1) (host-computed: no FP64 divide in the kernel)
+  double inv_nm1;
   uint64_t seed;
   uint64_t stream_offset;
 };

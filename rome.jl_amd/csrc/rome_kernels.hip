@@ -48,7 +48,7 @@ struct P2P2Cost {
 
 // std of the belief's tangent coordinates about particle 0 (shifted one-pass moments): SE(2)
 template <int PPL>
-__device__ __forceinline__ double spread_se2(const double (&t)[PPL][3], const bool (&act)[PPL], int N) {
+__device__ __forceinline__ double spread_se2(const double (&t)[PPL][3], const bool (&act)[PPL], double inv, double den) {
   const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0), th0 = readlane_f64(t[0][2], 0);
   double s[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -57,14 +57,13 @@ __device__ __forceinline__ double spread_se2(const double (&t)[PPL][3], const bo
     if (act[k]) { s[0] += dx; s[1] += dx * dx; s[2] += dy; s[3] += dy * dy; s[4] += dt; s[5] += dt * dt; }
   }
   wave_sum_n<6>(s);
-  const double inv = 1.0 / N, den = N > 1 ? 1.0 / (double)(N - 1) : 1.0;
   const double vx = fmax(0.0, (s[1] - s[0] * s[0] * inv) * den);
   const double vy = fmax(0.0, (s[3] - s[2] * s[2] * inv) * den);
   const double vt = fmax(0.0, (s[5] - s[4] * s[4] * inv) * den);
-  return (sqrt(vx) + sqrt(vy) + sqrt(vt)) * (1.0 / 3.0);
+  return (fast_sqrt(vx) + fast_sqrt(vy) + fast_sqrt(vt)) * (1.0 / 3.0);
 }
 template <int PPL>
-__device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const bool (&act)[PPL], int N) {
+__device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const bool (&act)[PPL], double inv, double den) {
   const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0);
   double s[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -73,10 +72,9 @@ __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const boo
     if (act[k]) { s[0] += dx; s[1] += dx * dx; s[2] += dy; s[3] += dy * dy; }
   }
   wave_sum_n<4>(s);
-  const double inv = 1.0 / N, den = N > 1 ? 1.0 / (double)(N - 1) : 1.0;
   const double vx = fmax(0.0, (s[1] - s[0] * s[0] * inv) * den);
   const double vy = fmax(0.0, (s[3] - s[2] * s[2] * inv) * den);
-  return (sqrt(vx) + sqrt(vy)) * 0.5;
+  return (fast_sqrt(vx) + fast_sqrt(vy)) * 0.5;
 }
 
 struct P2P2 {
@@ -101,26 +99,37 @@ struct P2P2 {
     return solver != kSolverClosedForm && K.dir != kDirPrior;
   }
   template <int PPL>
-  __device__ static __forceinline__ double spread(const double (&t)[PPL][3], const bool (&act)[PPL], int N) {
-    return spread_se2<PPL>(t, act, N);
+  __device__ static __forceinline__ double spread(const double (&t)[PPL][3], const bool (&act)[PPL], double inv, double den) {
+    return spread_se2<PPL>(t, act, inv, den);
   }
   __device__ static __forceinline__ void add_entropy(double (&t)[3], double spread, const double (&u)[3]) {
     se2_add_entropy(t, spread, u);
     t[2] = wrap_pi(t[2]);
   }
 
+  // per-particle constants of the root-find, computed once (not once per inflation cycle):
+  //   dir 0: a = q̂ = p ∘ exp_ϵ(z) ; dir 1: a = (q.x, q.y, θq - zθ) ; prior row: a = z
+  struct Prep { double a0, a1, a2; };
+  __device__ static __forceinline__ Prep prepare(const Consts& K, const double (&z)[3], const double (&fxc)[3]) {
+    Prep P;
+    if (K.dir == 0) {
+      double s, c; fast_sincos(fxc[2], &s, &c);
+      P.a0 = fxc[0] + c * z[0] - s * z[1]; P.a1 = fxc[1] + s * z[0] + c * z[1]; P.a2 = fxc[2] + z[2];
+    } else if (K.dir == 1) { P.a0 = fxc[0]; P.a1 = fxc[1]; P.a2 = fxc[2] - z[2]; }
+    else { P.a0 = z[0]; P.a1 = z[1]; P.a2 = z[2]; }
+    return P;
+  }
+
   template <int SOLVER>
-  __device__ static __forceinline__ int solve(const Consts& K, const double (&z)[3], const double (&fxc)[3],
+  __device__ static __forceinline__ int solve(const Consts& K, const Prep& P, const double (&z)[3], const double (&fxc)[3],
                                               double (&t)[3], int max_iters, double tol) {
     int st = 0;
     if (K.dir == kDirPrior) {  // PriorPose2 row: the sample exp_ϵ(hat(μ + Lξ)) itself is the proposal
-      t[0] = z[0]; t[1] = z[1]; t[2] = wrap_pi(z[2]);
+      t[0] = P.a0; t[1] = P.a1; t[2] = wrap_pi(P.a2);
       return 0;
     }
     if (K.dir == 0) {
-      // q̂ = p ∘ exp_ϵ(z)
-      double s, c; fast_sincos(fxc[2], &s, &c);
-      const double qx = fxc[0] + c * z[0] - s * z[1], qy = fxc[1] + s * z[0] + c * z[1], qth = fxc[2] + z[2];
+      const double qx = P.a0, qy = P.a1, qth = P.a2;
       if constexpr (SOLVER == kSolverClosedForm) { t[0] = qx; t[1] = qy; t[2] = qth; }
       else if constexpr (SOLVER == kSolverNewton) {
         st = 1;
@@ -134,15 +143,15 @@ struct P2P2 {
         st = nelder_mead<3>(cost, t, max_iters, tol);
       }
     } else {
-      const double pth = fxc[2] - z[2];  // θp = θq - zθ
+      const double qx0 = P.a0, qy0 = P.a1, pth = P.a2;  // θp = θq - zθ
       if constexpr (SOLVER == kSolverClosedForm) {
         double s, c; fast_sincos(pth, &s, &c);
-        t[0] = fxc[0] - (c * z[0] - s * z[1]); t[1] = fxc[1] - (s * z[0] + c * z[1]); t[2] = pth;
+        t[0] = qx0 - (c * z[0] - s * z[1]); t[1] = qy0 - (s * z[0] + c * z[1]); t[2] = pth;
       } else if constexpr (SOLVER == kSolverNewton) {
         st = 1;
         for (int it = 0; it < max_iters; ++it) {
           double s, c; fast_sincos(t[2], &s, &c);
-          const double r0 = t[0] + c * z[0] - s * z[1] - fxc[0], r1 = t[1] + s * z[0] + c * z[1] - fxc[1];
+          const double r0 = t[0] + c * z[0] - s * z[1] - qx0, r1 = t[1] + s * z[0] + c * z[1] - qy0;
           const double r2 = wrap_pi(t[2] - pth);
           if (fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol) { st = 0; break; }
           const double J13 = -s * z[0] - c * z[1], J23 = c * z[0] - s * z[1];
@@ -150,7 +159,7 @@ struct P2P2 {
           t[0] += -r0 - J13 * dth; t[1] += -r1 - J23 * dth; t[2] += dth;
         }
       } else {
-        P2P2Cost cost{z[0], z[1], fxc[0], fxc[1], pth, 1};
+        P2P2Cost cost{z[0], z[1], qx0, qy0, pth, 1};
         st = nelder_mead<3>(cost, t, max_iters, tol);
       }
     }
@@ -193,16 +202,18 @@ struct BR {
     return !(solver == kSolverClosedForm && DIR == 0);
   }
   template <int PPL>
-  __device__ static __forceinline__ double spread(const double (&t)[PPL][DT], const bool (&act)[PPL], int N) {
-    if constexpr (DT == 3) return spread_se2<PPL>(t, act, N);
-    else return spread_r2<PPL>(t, act, N);
+  __device__ static __forceinline__ double spread(const double (&t)[PPL][DT], const bool (&act)[PPL], double inv, double den) {
+    if constexpr (DT == 3) return spread_se2<PPL>(t, act, inv, den);
+    else return spread_r2<PPL>(t, act, inv, den);
   }
   __device__ static __forceinline__ void add_entropy(double (&t)[DT], double spread, const double (&u)[DT]) {
     if constexpr (DT == 3) { se2_add_entropy(t, spread, u); t[2] = wrap_pi(t[2]); }
     else { t[0] += spread * (u[0] - 0.5); t[1] += spread * (u[1] - 0.5); }
   }
+  struct Prep {};
+  __device__ static __forceinline__ Prep prepare(const Consts&, const double (&)[2], const double (&)[DF]) { return Prep{}; }
   template <int SOLVER>
-  __device__ static __forceinline__ int solve(const Consts&, const double (&z)[2], const double (&fx)[DF],
+  __device__ static __forceinline__ int solve(const Consts&, const Prep&, const double (&z)[2], const double (&fx)[DF],
                                               double (&t)[DT], int max_iters, double tol) {
     int st = 0;
     if constexpr (SOLVER == kSolverClosedForm) {
@@ -295,7 +306,7 @@ struct P3P3 {
 
   // std of the tangent coordinates about particle 0: translation differences and Log(R0ᵀ R_i)
   template <int PPL>
-  __device__ static __forceinline__ double spread(const double (&t)[PPL][6], const bool (&act)[PPL], int N) {
+  __device__ static __forceinline__ double spread(const double (&t)[PPL][6], const bool (&act)[PPL], double inv, double den) {
     double c0[6], R0[9];
 #pragma unroll
     for (int k = 0; k < 6; ++k) c0[k] = readlane_f64(t[0][k], 0);
@@ -314,10 +325,9 @@ struct P3P3 {
       }
     }
     wave_sum_n<12>(s);
-    const double inv = 1.0 / N, den = N > 1 ? 1.0 / (double)(N - 1) : 1.0;
     double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) acc += sqrt(fmax(0.0, (s[2 * j + 1] - s[2 * j] * s[2 * j] * inv) * den));
+    for (int j = 0; j < 6; ++j) acc += fast_sqrt(fmax(0.0, (s[2 * j + 1] - s[2 * j] * s[2 * j] * inv) * den));
     return acc * (1.0 / 6.0);
   }
   __device__ static __forceinline__ void add_entropy(double (&t)[6], double spread, const double (&u)[6]) {
@@ -325,8 +335,10 @@ struct P3P3 {
     se3_add_entropy(T, spread, u);
     se3_to_coords(T, t);
   }
+  struct Prep {};
+  __device__ static __forceinline__ Prep prepare(const Consts&, const double (&)[6], const double (&)[6]) { return Prep{}; }
   template <int SOLVER>
-  __device__ static __forceinline__ int solve(const Consts& K, const double (&z)[6], const double (&fxc)[6],
+  __device__ static __forceinline__ int solve(const Consts& K, const Prep&, const double (&z)[6], const double (&fxc)[6],
                                               double (&t)[6], int max_iters, double tol) {
     int st = 0;
     Se3 F, T;
@@ -420,6 +432,7 @@ __global__ void __launch_bounds__(256, ROME_MIN_WAVES) k_conv(const ConvArgs a) 
   const uint64_t stream = a.stream_offset + (uint64_t)c;
 
   double fx[PPL][FP::DF], t[PPL][FP::DT], z[PPL][FP::DZ];
+  typename FP::Prep prep[PPL];
   bool act[PPL];
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
@@ -440,6 +453,7 @@ __global__ void __launch_bounds__(256, ROME_MIN_WAVES) k_conv(const ConvArgs a) 
     }
     FP::measurement(K, xi, z[k]);
     FP::canonical(t[k]);
+    prep[k] = FP::prepare(K, z[k], fx[k]);
   }
 
   int st[PPL];
@@ -453,7 +467,7 @@ __global__ void __launch_bounds__(256, ROME_MIN_WAVES) k_conv(const ConvArgs a) 
   int have_call = -1;
   for (int cyc = 0; cyc < ncyc; ++cyc) {
     double spread = 0.0;
-    if (cyc_on && a.inflation > 0.0 && N > 1) spread = a.inflation * FP::template spread<PPL>(t, act, N);
+    if (cyc_on && a.inflation > 0.0 && N > 1) spread = a.inflation * FP::template spread<PPL>(t, act, a.inv_n, a.inv_nm1);
     if (spread > 0.0 && have_call != cyc / CPC) {  // wave-uniform
       have_call = cyc / CPC;
 #pragma unroll
@@ -467,7 +481,7 @@ __global__ void __launch_bounds__(256, ROME_MIN_WAVES) k_conv(const ConvArgs a) 
           rng_entropy_from_words<FP::DT>(ew[k], cyc % CPC, u);
           FP::add_entropy(t[k], spread, u);
         }
-        st[k] = FP::template solve<SOLVER>(K, z[k], fx[k], t[k], a.max_iters, a.tol);
+        st[k] = FP::template solve<SOLVER>(K, prep[k], z[k], fx[k], t[k], a.max_iters, a.tol);
       }
     }
   }

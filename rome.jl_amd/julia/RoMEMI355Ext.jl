@@ -1,0 +1,123 @@
+# RoMEMI355Ext.jl -- thin `ccall` shim binding librome_mi355.so behind RoME.jl's factor plugin surface.
+#
+# WRITTEN BLIND: this container has no Julia toolchain (and IncrementalInference/Manifolds/Optim are not
+# vendored with the reference), so this file has never been executed.  It mirrors include/rome_mi355.h 1:1
+# and is the binding a RoME maintainer would drop into `ext/` (weak-dependency extension, like
+# ext/RoMEFluxExt.jl).  Nothing below redefines a factor: the RoME structs, `CalcFactor` functors,
+# `getSample` and `getManifold` stay as they are (src/factors/Pose2D.jl:30-67, PriorPose2.jl:13-47,
+# BearingRange2D.jl:10-64, Pose3Pose3.jl:9-29); only the batch loop IIF runs around them is replaced.
+module RoMEMI355Ext
+
+using RoME
+using IncrementalInference
+import IncrementalInference: approxConvBelief
+using StaticArrays, RecursiveArrayTools, Distributions, LinearAlgebra
+
+const LIB = get(ENV, "ROME_MI355_LIB", "librome_mi355.so")
+
+# ---- rome_opts (include/rome_mi355.h) -------------------------------------------------------------
+struct RomeOpts
+  n_particles::Int32
+  solver::Int32          # 0 closed form, 1 Newton (default), 2 Nelder-Mead (Optim defaults)
+  max_iters::Int32
+  inflate_cycles::Int32
+  tol::Float64
+  inflation::Float64
+  seed::UInt64
+  stream_offset::UInt64
+  layout::Int32          # 0 SoA [block][dim][N], 1 AoS [block][N][dim]
+  reserved::Int32
+end
+
+function default_opts(fg::AbstractDFG; solver::Integer=1, seed::Integer=rand(UInt64), stream_offset::Integer=0)
+  o = Ref{RomeOpts}()
+  ccall((:rome_opts_default, LIB), Cvoid, (Ref{RomeOpts}, Int32), o, solver)
+  p = getSolverParams(fg)
+  d = o[]
+  RomeOpts(p.N, d.solver, d.max_iters, p.inflateCycles, d.tol, p.inflation, seed, stream_offset, 1 #=AoS=#, 0)
+end
+
+# ---- context ---------------------------------------------------------------------------------------
+mutable struct RomeCtx
+  h::Ptr{Cvoid}
+  function RomeCtx(device::Integer=0)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:rome_ctx_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint), r, device)
+    rc == 0 || error("rome_ctx_create: " * unsafe_string(ccall((:rome_strerror, LIB), Cstring, (Cint,), rc)))
+    c = new(r[])
+    finalizer(c -> ccall((:rome_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.h), c)
+  end
+end
+const _ctx = Ref{Union{Nothing,RomeCtx}}(nothing)   # one context per Julia thread/clique task in a real deployment
+ctx() = (_ctx[] === nothing && (_ctx[] = RomeCtx()); _ctx[]::RomeCtx)
+
+check(rc) = rc == 0 ? nothing : error("librome_mi355: " * unsafe_string(ccall((:rome_strerror, LIB), Cstring, (Cint,), rc)))
+
+# ---- layout helpers: Vector of manifold points <-> N x dim coordinate matrix (AoS rows) -----------------
+coords(::Type{Pose2}, pts) = reduce(hcat, [SA[p.x[1][1], p.x[1][2], atan(p.x[2][2,1], p.x[2][1,1])] for p in pts])  # 3 x N (column = particle = AoS row)
+coords(::Type{Point2}, pts) = reduce(hcat, pts)
+points(::Type{Pose2}, C) = [getPoint(Pose2, C[:, i]) for i in axes(C, 2)]
+points(::Type{Point2}, C) = [SVector{2}(C[:, i]) for i in axes(C, 2)]
+
+# ---- batch convolution: replaces N x (getSample + _solveCCWNumeric!) inside approxConvBelief ------------
+function conv_pose2pose2(fg, f::Pose2Pose2, fixedpts, u0pts, dir::Integer; solver=1)
+  o = default_opts(fg; solver)
+  N = Int(o.n_particles)
+  μ = collect(Float64, mean(f.Z)); Σ = collect(Float64, cov(f.Z))'     # row-major
+  fixed = coords(Pose2, fixedpts); target = coords(Pose2, u0pts)          # 3 x N column-major == N x 3 row-major
+  d = Int32[dir]
+  GC.@preserve μ Σ fixed target d begin
+    check(ccall((:rome_conv_pose2pose2, LIB), Cint,
+      (Ptr{Cvoid}, Ref{RomeOpts}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+      ctx().h, o, 1, d, μ, Σ, fixed, C_NULL, target, C_NULL))
+  end
+  points(Pose2, target)
+end
+
+function conv_bearingrange(fg, f::Pose2Point2BearingRange{<:Normal,<:Normal}, fixedpts, u0pts, dir::Integer; solver=1)
+  o = default_opts(fg; solver)
+  μ = Float64[mean(f.bearing), mean(f.range)]; σ = Float64[std(f.bearing), std(f.range)]
+  Tf, Tt = dir == 0 ? (Pose2, Point2) : (Point2, Pose2)
+  fixed = coords(Tf, fixedpts); target = coords(Tt, u0pts)
+  GC.@preserve μ σ fixed target begin
+    check(ccall((:rome_conv_pose2point2br, LIB), Cint,
+      (Ptr{Cvoid}, Ref{RomeOpts}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+      ctx().h, o, 1, dir, μ, σ, fixed, C_NULL, target, C_NULL))
+  end
+  points(Tt, target)
+end
+
+# ---- the drop-in: specialise IIF's entry for the accelerated factor types -------------------------------
+# IIF 0.35: approxConvBelief(dfg, fc::DFGFactor, target::Symbol, measurement; solveKey, N, ...) -> ManifoldKernelDensity.
+# Everything not matched here falls through to IIF's per-sample path (the RoME functors are untouched).
+function approxConvBelief(dfg::AbstractDFG, fc::DFGFactor{<:CommonConvWrapper{<:Pose2Pose2}}, target::Symbol,
+                          measurement::AbstractVector=Tuple[]; solveKey::Symbol=:default, kw...)
+  vars = getVariableOrder(fc)
+  dir = vars[2] == target ? 0 : 1
+  other = dir == 0 ? vars[1] : vars[2]
+  pts = conv_pose2pose2(dfg, getFactorType(fc), getVal(dfg, other; solveKey), getVal(dfg, target; solveKey), dir)
+  return manikde!(getManifold(Pose2), pts)     # KDE wrap stays in AMP (SURVEY 8(a) row a11: not part of the unit)
+end
+
+function approxConvBelief(dfg::AbstractDFG, fc::DFGFactor{<:CommonConvWrapper{<:Pose2Point2BearingRange{<:Normal,<:Normal}}},
+                          target::Symbol, measurement::AbstractVector=Tuple[]; solveKey::Symbol=:default, kw...)
+  vars = getVariableOrder(fc)
+  dir = vars[2] == target ? 0 : 1
+  other = dir == 0 ? vars[1] : vars[2]
+  pts = conv_bearingrange(dfg, getFactorType(fc), getVal(dfg, other; solveKey), getVal(dfg, target; solveKey), dir)
+  return manikde!(getManifold(getVariableType(dfg, target)), pts)
+end
+
+# Pose3Pose3 / PriorPose2 / PriorPose3 follow the same pattern with rome_conv_pose3pose3,
+# rome_sample_priorpose2 and rome_sample_priorpose3 (coordinates (t, ω) via
+# get_coordinates(M, ϵ, log(M, ϵ, p), DefaultOrthogonalBasis())).
+
+# ---- residual KATs through the library (mirrors calcFactorResidualTemporary) ---------------------------
+function residual_pose2pose2(z::AbstractMatrix, p::AbstractMatrix, q::AbstractMatrix)   # 3 x n each
+  r = similar(z)
+  check(ccall((:rome_residual_pose2pose2, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+              ctx().h, size(z, 2), z, p, q, r))
+  r
+end
+
+end # module
