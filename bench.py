@@ -115,15 +115,16 @@ def main():
     barrier()
     # per-launch duration of the dominant kernel: HIP events on the launch stream (torch's current stream,
     # which the launch plan binds the rome_ctx to), recorded around every launch of the timed region
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # (one event per launch: ev[k] is recorded right before sweep k, ev[K] after the last one; consecutive
+    # events bracket exactly one launch of the dominant kernel [+ the separator exchange when N>1])
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        e0, e1 = ev[k]
-        e0.record()
+        ev[k].record()
         sweep()
-        e1.record()
         exchange()
+    ev[args.steps].record()
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -131,7 +132,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]))
 
     total_conv = n_conv_step * world * args.steps
     value = total_conv / elapsed
