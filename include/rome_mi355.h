@@ -173,6 +173,29 @@ int rome_conv_pose3pose3_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);
 int rome_sample_priorpose2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*); /* uses factor, mu, L, noise, out */
 int rome_sample_priorpose3_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);
 
+/* ---------------------------------------------------------------------------------------------
+ * Parametric path: batched whitened residuals + analytic Jacobians at the
+ * measurement mean.  Replaces the per-factor residual/Jacobian evaluation IIF.solveGraphParametric!
+ * does through the same RoME functors (call sites src/services/AdditionalUtils.jl:22,37;
+ * getMeasurementParametric src/factors/BearingRange2D.jl:30-37):  cost = Σ_f ‖W_f r_f(μ_f; x)‖², WᵀW = Σ⁻¹.
+ * Rows are per factor: mu [F][dz], W [F][dr*dr] row-major whitening matrix, xa/xb [F][da|db] the
+ * coordinates of the factor's 1st/2nd variable (gathered by the caller), outputs r [F][dr],
+ * Ja [F][dr*da], Jb [F][dr*db] (row-major; Jb/xb NULL for priors).  Perturbations: Pose2 (δx,δy,δθ)
+ * with x⊕δ = ((t+δt), R(θ+δθ)); Point2 additive; Pose3 (δt, δω) with x⊕δ = ((t+δt), R·Exp(δω)).
+ *   kind            dz dr da db   residual (reference file:line)
+ *   PRIORPOSE2       3  3  3  -   src/factors/PriorPose2.jl:37-47
+ *   POSE2POSE2       3  3  3  3   src/factors/Pose2D.jl:51-67
+ *   POSE2POINT2BR    2  2  3  2   src/factors/BearingRange2D.jl:48-64
+ *   PRIORPOINT2      2  2  2  -   src/factors/Point2D.jl:14-18
+ *   POSE3POSE3       6  6  6  6   src/factors/Pose3Pose3.jl:17-29
+ *   PRIORPOSE3       6  6  6  -   src/factors/Pose3D.jl:15-19                                     */
+enum { ROME_FACTOR_PRIORPOSE2 = 0, ROME_FACTOR_POSE2POSE2 = 1, ROME_FACTOR_POSE2POINT2BR = 2,
+       ROME_FACTOR_PRIORPOINT2 = 3, ROME_FACTOR_POSE3POSE3 = 4, ROME_FACTOR_PRIORPOSE3 = 5 };
+int rome_linearize(rome_ctx*, int32_t kind, int32_t F, const double* mu, const double* W,
+                   const double* xa, const double* xb, double* r, double* Ja, double* Jb);      /* host pointers   */
+int rome_linearize_dev(rome_ctx*, int32_t kind, int32_t F, const double* mu, const double* W,
+                       const double* xa, const double* xb, double* r, double* Ja, double* Jb);  /* device pointers */
+
 /* thin device-memory helpers for callers without their own HIP runtime binding (e.g. the Julia shim) */
 int rome_dev_alloc(rome_ctx*, uint64_t bytes, void** out);
 int rome_dev_free(rome_ctx*, void* p);

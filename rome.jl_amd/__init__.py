@@ -9,9 +9,9 @@ from . import _lib
 from ._lib import (Context, Opts, RomeError, SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD,
                    LAYOUT_SOA, LAYOUT_AOS, MAX_PARTICLES)
 from .factors import (MvNormal, Normal, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
-                      Pose3Pose3, PriorPose3, getMeasurementParametric, getPoint, getCoordinates, pack_factor,
+                      Pose3Pose3, PriorPose3, PriorPoint2, getMeasurementParametric, getPoint, getCoordinates, pack_factor,
                       unpack_factor)
-from .api import (calcFactorResidualTemporary, make_opts, cholesky_lower, default_context,
+from .api import (linearize, calcFactorResidualTemporary, make_opts, cholesky_lower, default_context,
                   residual_pose2pose2, residual_priorpose2, residual_pose2point2br, residual_pose2point2br_pt,
                   residual_pose3pose3, residual_pose3pose3_pt, residual_priorpose3,
                   conv_pose2pose2, conv_pose2point2br, conv_pose3pose3, sample_priorpose2, sample_priorpose3)
@@ -19,6 +19,7 @@ from .graph import (FactorGraph, initfg, importG2o, parseG2oInstruction, loadG2o
                     synth_manhattan_edges, synth_helix3d, generateGraph_Circle, generateGraph_Hexagonal,
                     PackedGraph, dead_reckon_init)
 from .convolution import approxConv, approxConvBelief
+from .parametric import solveGraphParametric, initParametric
 from .device import DeviceGraph
 from . import distributed
 

@@ -14,6 +14,7 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED_N, ERR_
 SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD = 0, 1, 2
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 MAX_PARTICLES = 256
+FACTOR_PRIORPOSE2, FACTOR_POSE2POSE2, FACTOR_POSE2POINT2BR, FACTOR_PRIORPOINT2, FACTOR_POSE3POSE3, FACTOR_PRIORPOSE3 = range(6)
 
 
 class RomeError(RuntimeError):
@@ -73,6 +74,8 @@ SIGNATURES = {
     "rome_conv_pose3pose3_dev": (C.c_int, [_CTX, _PO, _PT]),
     "rome_sample_priorpose2_dev": (C.c_int, [_CTX, _PO, _PT]),
     "rome_sample_priorpose3_dev": (C.c_int, [_CTX, _PO, _PT]),
+    "rome_linearize": (C.c_int, [_CTX, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
+    "rome_linearize_dev": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rome_dev_alloc": (C.c_int, [_CTX, C.c_uint64, C.POINTER(C.c_void_p)]),
     "rome_dev_free": (C.c_int, [_CTX, C.c_void_p]),
     "rome_dev_upload": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint64]),

@@ -128,6 +128,27 @@ def calcFactorResidualTemporary(factor, vartypes, meas, points, ctx=None):
     raise TypeError("unsupported factor type %s" % type(factor).__name__)
 
 
+# ------------------------------------------------------------------ parametric linearisation
+_LIN_DIMS = {_lib.FACTOR_PRIORPOSE2: (3, 3, 3, 0), _lib.FACTOR_POSE2POSE2: (3, 3, 3, 3), _lib.FACTOR_POSE2POINT2BR: (2, 2, 3, 2),
+             _lib.FACTOR_PRIORPOINT2: (2, 2, 2, 0), _lib.FACTOR_POSE3POSE3: (6, 6, 6, 6), _lib.FACTOR_PRIORPOSE3: (6, 6, 6, 0)}
+
+
+def linearize(kind, mu, W, xa, xb=None, ctx=None):
+    """Whitened residuals and Jacobians of F factors of one kind (rome_linearize):
+    -> r (F,dr), Ja (F,dr,da), Jb (F,dr,db) or None."""
+    ctx = ctx or default_context()
+    dz, dr, da, db = _LIN_DIMS[kind]
+    mu = np.atleast_2d(_d(mu)); F = mu.shape[0]
+    mu = _d(mu, (F, dz)); W = _d(W, (F, dr, dr)); xa = _d(xa, (F, da))
+    r = np.empty((F, dr)); Ja = np.empty((F, dr, da))
+    if db:
+        xb = _d(xb, (F, db)); Jb = np.empty((F, dr, db))
+    else:
+        xb = None; Jb = None
+    _lib.check(_lib.load().rome_linearize(ctx.handle, int(kind), F, _p(mu), _p(W), _p(xa), _p(xb), _p(r), _p(Ja), _p(Jb)), ctx.handle)
+    return r, Ja, Jb
+
+
 # ------------------------------------------------------------------ helpers
 def cholesky_lower(cov):
     """n covariances (n,d,d) or one (d,d) -> packed lower factors (n, d(d+1)/2)."""

@@ -405,6 +405,59 @@ int rome_sample_priorpose3_dev(rome_ctx* c, const rome_opts* o, const rome_conv_
   return ROME_OK;
 }
 
+/* ---- parametric linearisation ---- */
+static bool lin_dims_host(int kind, int& dz, int& dr, int& da, int& db) {
+  switch (kind) {
+    case ROME_FACTOR_PRIORPOSE2: dz = 3; dr = 3; da = 3; db = 0; return true;
+    case ROME_FACTOR_POSE2POSE2: dz = 3; dr = 3; da = 3; db = 3; return true;
+    case ROME_FACTOR_POSE2POINT2BR: dz = 2; dr = 2; da = 3; db = 2; return true;
+    case ROME_FACTOR_PRIORPOINT2: dz = 2; dr = 2; da = 2; db = 0; return true;
+    case ROME_FACTOR_POSE3POSE3: dz = 6; dr = 6; da = 6; db = 6; return true;
+    case ROME_FACTOR_PRIORPOSE3: dz = 6; dr = 6; da = 6; db = 0; return true;
+    default: return false;
+  }
+}
+int rome_linearize_dev(rome_ctx* c, int32_t kind, int32_t F, const double* mu, const double* W, const double* xa,
+                       const double* xb, double* r, double* Ja, double* Jb) {
+  int dz, dr, da, db;
+  if (!c || F < 0 || !lin_dims_host(kind, dz, dr, da, db)) return ROME_ERR_INVALID_ARG;
+  if (F > 0 && (!mu || !W || !xa || !r || !Ja || (db > 0 && (!xb || !Jb)))) return ROME_ERR_INVALID_ARG;
+  ROME_HIP(c, rome::launch_linearize(kind, F, mu, W, xa, xb, r, Ja, Jb, c->stream));
+  return ROME_OK;
+}
+int rome_linearize(rome_ctx* c, int32_t kind, int32_t F, const double* mu, const double* W, const double* xa,
+                   const double* xb, double* r, double* Ja, double* Jb) {
+  int dz, dr, da, db;
+  if (!c || F < 0 || !lin_dims_host(kind, dz, dr, da, db)) return ROME_ERR_INVALID_ARG;
+  if (F == 0) return ROME_OK;
+  if (!mu || !W || !xa || !r || !Ja || (db > 0 && (!xb || !Jb))) return ROME_ERR_INVALID_ARG;
+  ROME_HIP(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  void *d_mu, *d_W, *d_xa, *d_xb = nullptr, *d_r, *d_Ja, *d_Jb = nullptr;
+  int rc;
+  const size_t n = (size_t)F;
+  if ((rc = ensure(c, 0, 8 * n * dz, &d_mu))) return rc;
+  if ((rc = ensure(c, 1, 8 * n * dr * dr, &d_W))) return rc;
+  if ((rc = ensure(c, 2, 8 * n * da, &d_xa))) return rc;
+  if ((rc = ensure(c, 4, 8 * n * dr, &d_r))) return rc;
+  if ((rc = ensure(c, 5, 8 * n * dr * da, &d_Ja))) return rc;
+  ROME_HIP(c, hipMemcpyAsync(d_mu, mu, 8 * n * dz, hipMemcpyHostToDevice, s));
+  ROME_HIP(c, hipMemcpyAsync(d_W, W, 8 * n * dr * dr, hipMemcpyHostToDevice, s));
+  ROME_HIP(c, hipMemcpyAsync(d_xa, xa, 8 * n * da, hipMemcpyHostToDevice, s));
+  if (db > 0) {
+    if ((rc = ensure(c, 3, 8 * n * db, &d_xb))) return rc;
+    if ((rc = ensure(c, 6, 8 * n * dr * db, &d_Jb))) return rc;
+    ROME_HIP(c, hipMemcpyAsync(d_xb, xb, 8 * n * db, hipMemcpyHostToDevice, s));
+  }
+  ROME_HIP(c, rome::launch_linearize(kind, F, (const double*)d_mu, (const double*)d_W, (const double*)d_xa,
+                                     (const double*)d_xb, (double*)d_r, (double*)d_Ja, (double*)d_Jb, s));
+  ROME_HIP(c, hipMemcpyAsync(r, d_r, 8 * n * dr, hipMemcpyDeviceToHost, s));
+  ROME_HIP(c, hipMemcpyAsync(Ja, d_Ja, 8 * n * dr * da, hipMemcpyDeviceToHost, s));
+  if (db > 0) ROME_HIP(c, hipMemcpyAsync(Jb, d_Jb, 8 * n * dr * db, hipMemcpyDeviceToHost, s));
+  ROME_HIP(c, hipStreamSynchronize(s));
+  return ROME_OK;
+}
+
 /* ---- device memory helpers ---- */
 int rome_dev_alloc(rome_ctx* c, uint64_t bytes, void** out) {
   if (!c || !out) return ROME_ERR_INVALID_ARG;

@@ -148,15 +148,18 @@ struct P2P2 {
         double s, c; fast_sincos(pth, &s, &c);
         t[0] = qx0 - (c * z[0] - s * z[1]); t[1] = qy0 - (s * z[0] + c * z[1]); t[2] = pth;
       } else if constexpr (SOLVER == kSolverNewton) {
+        // The Jacobian is block-triangular (r_θ depends on θ only): Newton on θ first, then on the
+        // translation with R(θ) at the UPDATED heading (block Gauss-Seidel/Newton).  sin/cos are only
+        // recomputed when θ moved, so a converging solve costs one sincos instead of three.
         st = 1;
+        double s = 0.0, c = 1.0, th_sc = __builtin_nan("");
         for (int it = 0; it < max_iters; ++it) {
-          double s, c; fast_sincos(t[2], &s, &c);
-          const double r0 = t[0] + c * z[0] - s * z[1] - qx0, r1 = t[1] + s * z[0] + c * z[1] - qy0;
           const double r2 = wrap_pi(t[2] - pth);
+          if (fabs(r2) > tol) t[2] -= r2;  // else θ is converged: (r0, r1, r2) below is the residual at the returned point
+          if (t[2] != th_sc) { fast_sincos(t[2], &s, &c); th_sc = t[2]; }
+          const double r0 = t[0] + c * z[0] - s * z[1] - qx0, r1 = t[1] + s * z[0] + c * z[1] - qy0;
           if (fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol) { st = 0; break; }
-          const double J13 = -s * z[0] - c * z[1], J23 = c * z[0] - s * z[1];
-          const double dth = -r2;
-          t[0] += -r0 - J13 * dth; t[1] += -r1 - J23 * dth; t[2] += dth;
+          t[0] -= r0; t[1] -= r1;
         }
       } else {
         P2P2Cost cost{z[0], z[1], qx0, qy0, pth, 1};

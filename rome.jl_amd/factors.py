@@ -128,6 +128,17 @@ class PriorPose3(_PriorFactor):
             raise ValueError("PriorPose3 needs a 6-dimensional belief")
 
 
+class PriorPoint2(_PriorFactor):
+    """Direction observation information of a `Point2` variable (src/factors/Point2D.jl:9-18).  Only the
+    parametric path uses it here (it anchors landmarks in the reference's parametric tests)."""
+    variable_types = (Point2,)
+
+    def __init__(self, Z=None):
+        self.Z = Z if Z is not None else MvNormal(np.zeros(2), np.diag([0.01, 0.01]))  # Point2D.jl:10
+        if self.Z.mu.size != 2:
+            raise ValueError("PriorPoint2 needs a 2-dimensional belief")
+
+
 def getMeasurementParametric(f):
     """(μ, iΣ) as IIF.getMeasurementParametric; BearingRange override at BearingRange2D.jl:30-37."""
     if isinstance(f, Pose2Point2BearingRange):
@@ -160,7 +171,8 @@ def unpack_factor(d):
     t = d["fnctype"]
     if t == "Pose2Point2BearingRange":
         return Pose2Point2BearingRange(_unpack_belief(d["bearstr"]), _unpack_belief(d["rangstr"]))
-    cls = {"Pose2Pose2": Pose2Pose2, "PriorPose2": PriorPose2, "Pose3Pose3": Pose3Pose3, "PriorPose3": PriorPose3}[t]
+    cls = {"Pose2Pose2": Pose2Pose2, "PriorPose2": PriorPose2, "Pose3Pose3": Pose3Pose3, "PriorPose3": PriorPose3,
+           "PriorPoint2": PriorPoint2}[t]
     return cls(_unpack_belief(d["Z"]))
 
 

@@ -11,7 +11,7 @@ from collections import OrderedDict
 import numpy as np
 
 from .factors import (MvNormal, Normal, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
-                      Pose3Pose3, PriorPose3)
+                      Pose3Pose3, PriorPose3, PriorPoint2)
 
 
 class FactorGraph:
@@ -276,7 +276,7 @@ class PackedGraph:
         for l, t in fg.variables.items():
             self.index[l] = len(self.labels[t])
             self.labels[t].append(l)
-        p2, br, p3, pr2, pr3 = [], [], [], [], []
+        p2, br, p3, pr2, pr3, prpt = [], [], [], [], [], []
         for flabel, labels, f in fg.factors:
             ids = [self.index[l] for l in labels]
             if isinstance(f, Pose2Pose2): p2.append((ids, f, flabel))
@@ -284,6 +284,7 @@ class PackedGraph:
             elif isinstance(f, Pose3Pose3): p3.append((ids, f, flabel))
             elif isinstance(f, PriorPose2): pr2.append((ids, f, flabel))
             elif isinstance(f, PriorPose3): pr3.append((ids, f, flabel))
+            elif isinstance(f, PriorPoint2): prpt.append((ids, f, flabel))
             else: raise TypeError("factor type %s is outside the hot path" % type(f).__name__)
 
         def rel_tables(items, d):
@@ -312,6 +313,7 @@ class PackedGraph:
 
         self.prior2 = prior_tables(pr2, 3)
         self.prior3 = prior_tables(pr3, 6)
+        self.priorpt2 = prior_tables(prpt, 2)   # parametric path only (no sweep kernel row yet)
 
     @staticmethod
     def conv_table(tab):
