@@ -196,6 +196,19 @@ int rome_linearize(rome_ctx*, int32_t kind, int32_t F, const double* mu, const d
 int rome_linearize_dev(rome_ctx*, int32_t kind, int32_t F, const double* mu, const double* W,
                        const double* xa, const double* xb, double* r, double* Ja, double* Jb);  /* device pointers */
 
+/* ---------------------------------------------------------------------------------------------
+ * Belief summaries and proposal product, DEVICE pointers, SoA blocks.
+ * rome_belief_stats*: manifold mean and per-coordinate std of V beliefs ([V][dim][N]; dim 2 Point2, 3 Pose2,
+ *   6 Pose3) -> mean [V][dim], std [V][dim].  Replaces `mean(M, pts)` / `std(vartype, pts)` as used for PPEs
+ *   (examples/ManhattanBatchAnalysis.jl:59-62) and for IIF's inflation spread (calcStdBasicSpread).
+ * rome_product_dev: new belief of every variable from the proposals that target it (CSR prop_ptr[V+1] /
+ *   prop_rows into prop [rows][dim][N]); variables without proposals keep bel_in.  STAND-IN for
+ *   AMP.manifoldProduct (unvendored): importance-sampling product of the proposal KDEs, see DESIGN.md §10. */
+int rome_belief_stats_dev(rome_ctx*, int32_t dim, int32_t V, int32_t N, const double* bel, double* mean, double* std);
+int rome_belief_stats(rome_ctx*, int32_t dim, int32_t V, int32_t N, const double* bel, double* mean, double* std); /* host pointers */
+int rome_product_dev(rome_ctx*, const rome_opts*, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
+                     const double* prop, const double* bel_in, double* bel_out);
+
 /* thin device-memory helpers for callers without their own HIP runtime binding (e.g. the Julia shim) */
 int rome_dev_alloc(rome_ctx*, uint64_t bytes, void** out);
 int rome_dev_free(rome_ctx*, void* p);

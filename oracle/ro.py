@@ -228,6 +228,15 @@ def sample_priorpose3(opts, mu, L, factor=None, noise=None, C_=None):
     return out
 
 
+def product(opts, dim, prop_ptr, prop_rows, prop, bel_in):
+    pp, ppp = _i(prop_ptr); pr, ppr = _i(prop_rows); P, pP = _d(prop); B, pB = _d(bel_in)
+    V = len(pp) - 1
+    out = np.zeros_like(B)
+    rc = lib().ro_product(C.byref(opts), int(dim), V, ppp, ppr, pP, pB, out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    return out
+
+
 def num_threads():
     return lib().ro_num_threads()
 

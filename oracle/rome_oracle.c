@@ -877,3 +877,102 @@ void ro_set_num_threads(int n) {
   (void)n;
 #endif
 }
+
+/* ======================================================================== */
+/* Product of proposals (stand-in for ⚠AMP manifoldProduct)          */
+/* ======================================================================== */
+/* NOT a restatement of ApproxManifoldProducts' multiscale Gibbs product (unvendored, unpinned): a
+ * regularised importance-sampling product of the K proposal KDEs, defined once here and in the HIP path
+ * (csrc/rome_product.hip):
+ *   proposal l: N points, diagonal Gaussian kernels, bandwidth h_lk = max(c_N std_lk, 1e-6),
+ *               c_N = (4/((d+2)N))^(1/(d+4)) (Silverman), std about particle 0 (ro_belief_spread_*)
+ *   base b    : the proposal with the smallest Σ_k log h_lk (ties: lowest l) -- the tightest one
+ *   candidates: the N points of b; log w_i = Σ_{l≠b} log Σ_j exp(-½ Σ_k ((x_i - y_lj)_k / h_lk)²)
+ *   systematic resampling of N candidates with one uniform u (Philox domain 3), then kernel jitter
+ *   x ⊕ (h_prod ⊙ ξ), 1/h_prod,k² = Σ_l 1/h_lk²  (ξ: ro_rng_normals on the variable's stream).
+ *   K = 1: the proposal is copied; K = 0: the belief is kept.
+ * dim = 2 (Point2) or 3 (Pose2: third coordinate is an angle, differences wrapped).                  */
+static double wrap_diff(double a) { return atan2(sin(a), cos(a)); }
+
+int ro_product(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const int32_t* prop_rows,
+               const double* prop /*[rows][dim][N]*/, const double* bel_in /*[V][dim][N]*/, double* bel_out) {
+  const int N = o->n_particles;
+  if (dim != 2 && dim != 3) return -1;
+  const double cN = pow(4.0 / ((dim + 2.0) * N), 1.0 / (dim + 4.0));
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int v = 0; v < V; ++v) {
+    const int K = prop_ptr[v + 1] - prop_ptr[v];
+    const int32_t* rows = prop_rows + prop_ptr[v];
+    double* ob = bel_out + (size_t)v * dim * N;
+    if (K == 0) { memcpy(ob, bel_in + (size_t)v * dim * N, sizeof(double) * dim * N); continue; }
+    if (K == 1) { memcpy(ob, prop + (size_t)rows[0] * dim * N, sizeof(double) * dim * N); continue; }
+    double* h = (double*)malloc(sizeof(double) * K * dim);
+    int base = 0; double best = INFINITY;
+    for (int l = 0; l < K; ++l) {
+      const double* P = prop + (size_t)rows[l] * dim * N;
+      double mean[3], sd[3];
+      if (dim == 3) ro_belief_spread_se2(N, P, P + N, P + 2 * N, mean, sd);
+      else ro_belief_spread_r2(N, P, P + N, mean, sd);
+      double ln = 0.0;
+      for (int k = 0; k < dim; ++k) { h[l * dim + k] = fmax(cN * sd[k], 1e-6); ln += log(h[l * dim + k]); }
+      if (ln < best) { best = ln; base = l; }
+    }
+    const int M = N;
+    const double* Pb = prop + (size_t)rows[base] * dim * N;
+    double* logw = (double*)malloc(sizeof(double) * M);
+    double lwmax = -INFINITY;
+    for (int m = 0; m < M; ++m) {
+      double x[3]; for (int k = 0; k < dim; ++k) x[k] = Pb[k * N + m];
+      double acc = 0.0;
+      for (int l = 0; l < K; ++l) {
+        if (l == base) continue;
+        const double* P = prop + (size_t)rows[l] * dim * N;
+        double qmin = INFINITY;
+        for (int j = 0; j < N; ++j) {
+          double q = 0.0;
+          for (int k = 0; k < dim; ++k) {
+            double d = x[k] - P[k * N + j];
+            if (dim == 3 && k == 2) d = wrap_diff(d);
+            d /= h[l * dim + k]; q += d * d;
+          }
+          if (q < qmin) qmin = q;
+        }
+        double sacc = 0.0;
+        for (int j = 0; j < N; ++j) {
+          double q = 0.0;
+          for (int k = 0; k < dim; ++k) {
+            double d = x[k] - P[k * N + j];
+            if (dim == 3 && k == 2) d = wrap_diff(d);
+            d /= h[l * dim + k]; q += d * d;
+          }
+          sacc += exp(-0.5 * (q - qmin));
+        }
+        acc += -0.5 * qmin + log(sacc);
+      }
+      logw[m] = acc;
+      if (acc > lwmax) lwmax = acc;
+    }
+    double* cum = (double*)malloc(sizeof(double) * M);
+    double T = 0.0;
+    for (int m = 0; m < M; ++m) { T += exp(logw[m] - lwmax); cum[m] = T; }
+    double hp[3];
+    for (int k = 0; k < dim; ++k) { double a = 0.0; for (int l = 0; l < K; ++l) a += 1.0 / (h[l * dim + k] * h[l * dim + k]); hp[k] = 1.0 / sqrt(a); }
+    double u;
+    { uint32_t key[2] = {(uint32_t)o->seed, (uint32_t)(o->seed >> 32)};
+      uint64_t st = o->stream_offset + (uint64_t)v;
+      uint32_t ctr[4] = {0xFFFFFFFFu, (uint32_t)st, (uint32_t)(st >> 32), (3u << 16)}; uint32_t w[4];
+      ro_philox4x32_10(ctr, key, w);
+      u = ((double)w[0] + 0.5) * (1.0 / 4294967296.0); }
+    int m = 0;
+    for (int i = 0; i < N; ++i) {
+      const double tau = (i + u) * T / N;
+      while (m < M - 1 && !(cum[m] > tau)) ++m;
+      double xi[3];
+      ro_rng_normals(o->seed, o->stream_offset + (uint64_t)v, (uint32_t)i, dim, xi);
+      for (int k = 0; k < dim; ++k) ob[k * N + i] = Pb[k * N + m] + hp[k] * xi[k];
+      if (dim == 3) ob[2 * N + i] = wrap_diff(ob[2 * N + i]);
+    }
+    free(h); free(logw); free(cum);
+  }
+  return 0;
+}

@@ -100,6 +100,10 @@ int ro_conv_pose3pose3(const ro_opts* o, int C, const int32_t* factor, const int
 int ro_sample_priorpose3(const ro_opts* o, int C, const int32_t* factor,
                          const double* mu, const double* L, const double* noise, double* out /*[C][6][N]*/);
 
+/* product of K proposal beliefs per variable (stand-in for AMP manifoldProduct; see rome_oracle.c) */
+int ro_product(const ro_opts* o, int dim, int V, const int32_t* prop_ptr /*[V+1]*/, const int32_t* prop_rows,
+               const double* prop /*[rows][dim][N]*/, const double* bel_in /*[V][dim][N]*/, double* bel_out);
+
 int ro_num_threads(void);
 void ro_set_num_threads(int n);
 

@@ -76,6 +76,9 @@ SIGNATURES = {
     "rome_sample_priorpose3_dev": (C.c_int, [_CTX, _PO, _PT]),
     "rome_linearize": (C.c_int, [_CTX, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
     "rome_linearize_dev": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rome_belief_stats_dev": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rome_belief_stats": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32, _PD, _PD, _PD]),
+    "rome_product_dev": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rome_dev_alloc": (C.c_int, [_CTX, C.c_uint64, C.POINTER(C.c_void_p)]),
     "rome_dev_free": (C.c_int, [_CTX, C.c_void_p]),
     "rome_dev_upload": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint64]),

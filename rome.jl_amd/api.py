@@ -149,6 +149,16 @@ def linearize(kind, mu, W, xa, xb=None, ctx=None):
     return r, Ja, Jb
 
 
+def belief_stats(bel, ctx=None):
+    """bel (V, dim, N) host array -> (mean (V,dim), std (V,dim)) via rome_belief_stats."""
+    ctx = ctx or default_context()
+    bel = _d(bel)
+    V, d, N = bel.shape
+    mean = np.empty((V, d)); sd = np.empty((V, d))
+    _lib.check(_lib.load().rome_belief_stats(ctx.handle, d, V, N, _p(bel), _p(mean), _p(sd)), ctx.handle)
+    return mean, sd
+
+
 # ------------------------------------------------------------------ helpers
 def cholesky_lower(cov):
     """n covariances (n,d,d) or one (d,d) -> packed lower factors (n, d(d+1)/2)."""

@@ -458,6 +458,39 @@ int rome_linearize(rome_ctx* c, int32_t kind, int32_t F, const double* mu, const
   return ROME_OK;
 }
 
+/* ---- belief statistics / product ---- */
+int rome_belief_stats_dev(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, double* mean, double* sd) {
+  if (!c || V < 0 || N < 1 || (dim != 2 && dim != 3 && dim != 6) || (V > 0 && (!bel || !mean || !sd))) return ROME_ERR_INVALID_ARG;
+  ROME_HIP(c, rome::launch_belief_stats(dim, V, N, bel, mean, sd, c->stream));
+  return ROME_OK;
+}
+int rome_belief_stats(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, double* mean, double* sd) {
+  if (!c || V < 0 || N < 1 || (dim != 2 && dim != 3 && dim != 6) || (V > 0 && (!bel || !mean || !sd))) return ROME_ERR_INVALID_ARG;
+  if (V == 0) return ROME_OK;
+  ROME_HIP(c, hipSetDevice(c->device));
+  void *d_b, *d_m, *d_s; int rc;
+  const size_t nb = 8ull * V * dim * N, nm = 8ull * V * dim;
+  if ((rc = ensure(c, 0, nb, &d_b))) return rc;
+  if ((rc = ensure(c, 1, nm, &d_m))) return rc;
+  if ((rc = ensure(c, 2, nm, &d_s))) return rc;
+  ROME_HIP(c, hipMemcpyAsync(d_b, bel, nb, hipMemcpyHostToDevice, c->stream));
+  ROME_HIP(c, rome::launch_belief_stats(dim, V, N, (const double*)d_b, (double*)d_m, (double*)d_s, c->stream));
+  ROME_HIP(c, hipMemcpyAsync(mean, d_m, nm, hipMemcpyDeviceToHost, c->stream));
+  ROME_HIP(c, hipMemcpyAsync(sd, d_s, nm, hipMemcpyDeviceToHost, c->stream));
+  ROME_HIP(c, hipStreamSynchronize(c->stream));
+  return ROME_OK;
+}
+int rome_product_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
+                     const double* prop, const double* bel_in, double* bel_out) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || V < 0 || (dim != 2 && dim != 3)) return ROME_ERR_INVALID_ARG;
+  if (V > 0 && (!prop_ptr || !bel_in || !bel_out)) return ROME_ERR_INVALID_ARG;
+  const int N = o->n_particles;
+  const double c_n = std::pow(4.0 / ((dim + 2.0) * N), 1.0 / (dim + 4.0));
+  ROME_HIP(c, rome::launch_product(dim, V, N, prop_ptr, prop_rows, prop, bel_in, bel_out, c_n, o->seed, o->stream_offset, c->stream));
+  return ROME_OK;
+}
+
 /* ---- device memory helpers ---- */
 int rome_dev_alloc(rome_ctx* c, uint64_t bytes, void** out) {
   if (!c || !out) return ROME_ERR_INVALID_ARG;

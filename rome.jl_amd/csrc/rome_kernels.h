@@ -49,4 +49,8 @@ hipError_t launch_residual_priorpose3(int n, const double* m, const double* p, d
 hipError_t launch_linearize(int kind, int F, const double* mu, const double* W, const double* xa, const double* xb,
                             double* r, double* Ja, double* Jb, hipStream_t s);
 
+hipError_t launch_belief_stats(int dim, int V, int N, const double* bel, double* mean, double* sdev, hipStream_t s);
+hipError_t launch_product(int dim, int V, int N, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
+                          const double* bel_in, double* bel_out, double c_n, uint64_t seed, uint64_t stream_offset, hipStream_t s);
+
 }  // namespace rome

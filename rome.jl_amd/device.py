@@ -59,6 +59,31 @@ class DeviceGraph:
             if tab["F"]:
                 self.tab[name] = dict(F=tab["F"], mu=t(tab["mu"], f64), L=t(cholesky_lower(tab["cov"]), f64), var=t(tab["var"], i32))
 
+        self._build_solve_tables(t, i32)
+
+    # ---- proposal buffers + CSR (variable -> proposal rows) for the product / solve loop ----
+    def _build_solve_tables(self, t, i32):
+        torch, pk = self.torch, self.packed
+        f64 = torch.float64
+        C2 = self.tab["p2p2"]["C"] if "p2p2" in self.tab else 0
+        Fb = self.tab["br"]["F"] if "br" in self.tab else 0
+        self.n_prop = {Pose2: C2 + Fb, Point2: Fb}
+        self.prop = {Pose2: torch.zeros((max(C2 + Fb, 1), 3, self.N), dtype=f64, device=self.device),
+                     Point2: torch.zeros((max(Fb, 1), 2, self.N), dtype=f64, device=self.device)}
+        self.bel_next = {Pose2: torch.zeros_like(self.bel[Pose2]), Point2: torch.zeros_like(self.bel[Point2])}
+        tgt2 = [self.tab["p2p2"]["target"].cpu().numpy()] if C2 else []
+        if Fb:
+            tgt2.append(pk.br["pose"])
+        self.csr = {}
+        for vt, tg, nv in ((Pose2, np.concatenate(tgt2) if tgt2 else np.zeros(0, np.int32), len(pk.labels[Pose2])),
+                           (Point2, pk.br["point"] if Fb else np.zeros(0, np.int32), len(pk.labels[Point2]))):
+            order = np.argsort(tg, kind="stable").astype(np.int32)
+            ptr = np.zeros(nv + 1, dtype=np.int32)
+            np.add.at(ptr, np.asarray(tg, dtype=np.int64) + 1, 1)
+            ptr = np.cumsum(ptr).astype(np.int32)
+            self.csr[vt] = dict(ptr=t(ptr, i32), rows=t(order if len(order) else np.zeros(1, np.int32), i32),
+                                ptr_h=ptr, rows_h=order)
+
     # ---- belief store ----
     def upload_beliefs(self, fg):
         for vt in (Pose2, Point2, Pose3):
@@ -110,6 +135,64 @@ class DeviceGraph:
         tb = self.tab[kind]
         fn = self._lib.rome_sample_priorpose2_dev if kind == "prior2" else self._lib.rome_sample_priorpose3_dev
         return self._plan(fn, opts, n_conv=tb["F"], dir_all=0, mu=tb["mu"], L=tb["L"], noise=noise, out=out)
+
+    # ---- solve loop pieces ----
+    STREAM_P2P2, STREAM_BR1, STREAM_BR0, STREAM_PROD2, STREAM_PRODL = 0, 1 << 28, 2 << 28, 3 << 28, 4 << 28
+
+    def _opts_at(self, opts, offset):
+        o = _lib.Opts.from_buffer_copy(opts)
+        o.stream_offset = opts.stream_offset + offset
+        return o
+
+    def conv_step(self, opts, sweep=0):
+        """All factor convolutions of the graph with the current beliefs -> self.prop (one launch per factor
+        family/direction).  Philox streams: base + sweep·2³² + family offset + row."""
+        base = sweep << 32
+        C2 = self.tab["p2p2"]["C"] if "p2p2" in self.tab else 0
+        if C2:
+            self.sweep_pose2pose2(self._opts_at(opts, base + self.STREAM_P2P2), out=self.prop[Pose2][:C2])
+        if "br" in self.tab:
+            Fb = self.tab["br"]["F"]
+            self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR1), 1, out=self.prop[Pose2][C2:C2 + Fb])
+            self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR0), 0, out=self.prop[Point2][:Fb])
+
+    def product_step(self, opts, sweep=0):
+        """bel <- product of the proposals targeting each variable (Jacobi update, double-buffered)."""
+        self._bind_stream()
+        base = sweep << 32
+        for vt, dim, off in ((Pose2, 3, self.STREAM_PROD2), (Point2, 2, self.STREAM_PRODL)):
+            V = self.bel[vt].shape[0]
+            if V == 0:
+                continue
+            o = self._opts_at(opts, base + off)
+            c = self.csr[vt]
+            _lib.check(self._lib.rome_product_dev(self.ctx.handle, C.byref(o), dim, V, c["ptr"].data_ptr(), c["rows"].data_ptr(),
+                                                  self.prop[vt].data_ptr(), self.bel[vt].data_ptr(), self.bel_next[vt].data_ptr()),
+                       self.ctx.handle)
+            self.bel[vt], self.bel_next[vt] = self.bel_next[vt], self.bel[vt]
+
+    def solve(self, opts, n_sweeps=10):
+        """n_sweeps x (convolution sweep, product): whole-graph nonparametric inference stand-in for the
+        clique-by-clique Gibbs of `solveTree!` (no Bayes tree)."""
+        for s in range(n_sweeps):
+            self.conv_step(opts, s)
+            self.product_step(opts, s)
+
+    def belief_stats(self, vartype):
+        """(mean [V,dim], std [V,dim]) of every belief of one variable type, on device."""
+        self._bind_stream()
+        b = self.bel[vartype]
+        V, d, N = b.shape
+        mean = self.torch.empty((V, d), dtype=self.torch.float64, device=self.device)
+        sd = self.torch.empty((V, d), dtype=self.torch.float64, device=self.device)
+        _lib.check(self._lib.rome_belief_stats_dev(self.ctx.handle, d, V, N, b.data_ptr(), mean.data_ptr(), sd.data_ptr()), self.ctx.handle)
+        return mean, sd
+
+    def download_beliefs(self, fg):
+        for vt in (Pose2, Point2, Pose3):
+            h = self.bel[vt].cpu().numpy()
+            for k, l in enumerate(self.packed.labels[vt]):
+                fg.vals[l] = h[k].copy()
 
     def capture(self, fn, warmup=2):
         """Capture `fn` (a sequence of launches on the current stream) into a hipGraph; returns the

@@ -367,4 +367,10 @@ def dead_reckon_init(fg, seed=1, sigma=(0.1, 0.1, 0.05)):
             m = mean.get(l, np.zeros(3))
             pts = m[:, None] + np.asarray(sigma)[:, None] * rng.standard_normal((3, fg.N))
             fg.initVariable(l, pts)
+    # landmarks: first sighting, particle by particle (pose particle ∘ measurement mean)
+    for _, labels, f in fg.factors:
+        if isinstance(f, Pose2Point2BearingRange) and not fg.isInitialized(labels[1]) and fg.isInitialized(labels[0]):
+            p = fg.getVal(labels[0])
+            a = p[2] + f.bearing.mu
+            fg.initVariable(labels[1], np.stack([p[0] + f.range.mu * np.cos(a), p[1] + f.range.mu * np.sin(a)]))
     return fg

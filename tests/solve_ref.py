@@ -1,0 +1,47 @@
+"""Oracle-side restatement of DeviceGraph.solve (test infrastructure): same schedule, same Philox
+streams, all compute through oracle/ (CPU)."""
+import numpy as np
+
+import oracle as ro
+
+
+def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1):
+    pk = R.PackedGraph(fg)
+    bel2 = pk.beliefs(fg, R.Pose2)
+    bell = pk.beliefs(fg, R.Point2) if len(pk.labels[R.Point2]) else np.zeros((0, 2, N))
+    factor, dr, fixed, target = R.PackedGraph.conv_table(pk.p2p2)
+    F, P = pk.p2p2["F"], pk.prior2["F"]
+    mu = np.concatenate([pk.p2p2["mu"].reshape(F, 3), pk.prior2["mu"].reshape(P, 3)])
+    cov = np.concatenate([pk.p2p2["cov"].reshape(F, 3, 3), pk.prior2["cov"].reshape(P, 3, 3)])
+    L = np.array([ro.cholesky_lower(c) for c in cov])
+    factor = np.concatenate([factor, F + np.arange(P)]); dr = np.concatenate([dr, np.full(P, 2)])
+    fixed = np.concatenate([fixed, pk.prior2["var"]]); target = np.concatenate([target, pk.prior2["var"]])
+    C2 = 2 * F + P
+    Fb = pk.br["F"]
+    tg2 = np.concatenate([target, pk.br["pose"]]) if Fb else target
+    tgl = pk.br["point"] if Fb else np.zeros(0, np.int32)
+
+    def csr(tg, nv):
+        order = np.argsort(tg, kind="stable").astype(np.int32)
+        ptr = np.zeros(nv + 1, dtype=np.int64); np.add.at(ptr, np.asarray(tg, dtype=np.int64) + 1, 1)
+        return np.cumsum(ptr).astype(np.int32), order
+    ptr2, rows2 = csr(tg2, bel2.shape[0]); ptrl, rowsl = csr(tgl, bell.shape[0])
+    S = dict(P2P2=0, BR1=1 << 28, BR0=2 << 28, PROD2=3 << 28, PRODL=4 << 28)
+    for s in range(n_sweeps):
+        base = s << 32
+        mk = lambda off: ro.make_opts(N=N, solver=solver, seed=seed, stream_offset=base + off)
+        rel = dr != 2
+        prop2 = np.zeros((C2 + Fb, 3, N))
+        prop2[:C2][rel] = ro.conv_pose2pose2(mk(S["P2P2"]), mu, L, bel2, fixed[rel], target[rel], dr[rel], factor=factor[rel])
+        # prior rows: stream id = row index
+        for k in range(P):
+            o = ro.make_opts(N=N, seed=seed, stream_offset=base + S["P2P2"] + 2 * F + k)
+            prop2[2 * F + k] = ro.sample_priorpose2(o, mu[F + k], L[F + k])[0]
+        propl = np.zeros((Fb, 2, N))
+        if Fb:
+            prop2[C2:] = ro.conv_pose2point2br(mk(S["BR1"]), 1, pk.br["mu"], pk.br["sigma"], bell, bel2, pk.br["point"], pk.br["pose"])
+            propl[:] = ro.conv_pose2point2br(mk(S["BR0"]), 0, pk.br["mu"], pk.br["sigma"], bel2, bell, pk.br["pose"], pk.br["point"])
+        bel2 = ro.product(mk(S["PROD2"]), 3, ptr2, rows2, prop2, bel2)
+        if Fb:
+            bell = ro.product(mk(S["PRODL"]), 2, ptrl, rowsl, propl, bell)
+    return bel2, bell

@@ -1,0 +1,114 @@
+"""Belief statistics, proposal product and the whole-graph solve loop on the GPU vs the oracle, plus the
+reference's statistical hexagon windows (test/testHexagonal2D_CliqByCliq.jl:37-79)."""
+import numpy as np
+import pytest
+
+import oracle as ro
+from solve_ref import solve_ref
+
+pytestmark = pytest.mark.gpu
+R = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _pkg():
+    global R
+    import rome_jl_amd
+    R = rome_jl_amd
+    R.default_context()
+    yield
+
+
+def test_belief_stats_vs_oracle():
+    rng = np.random.default_rng(0)
+    for d, N in ((3, 100), (2, 100), (6, 77), (3, 256), (3, 1)):
+        V = 9
+        sc = {2: [3, 3], 3: [3, 3, 0.4], 6: [3, 3, 3, 0.2, 0.2, 0.2]}[d]
+        bel = rng.standard_normal((V, d, N)) * np.array(sc)[None, :, None] + rng.standard_normal((V, d, 1)) * 2
+        if d == 3:
+            bel[0, 2] = np.pi + 0.1 * rng.standard_normal(N)   # cluster straddling the ±π cut
+        mean, sd = R.belief_stats(bel)
+        for v in range(V):
+            m, s = ro.belief_spread(bel[v])
+            dm = mean[v] - m
+            if d == 3:
+                dm[2] = np.arctan2(np.sin(dm[2]), np.cos(dm[2]))
+            assert np.abs(dm).max() < 1e-10 and np.abs(sd[v] - s).max() < 1e-10, (d, N, v)
+
+
+def test_product_vs_oracle_and_gaussian_product():
+    import torch
+    rng = np.random.default_rng(3)
+    N = 100
+    # 5 Pose2 variables with 0,1,2,3,4 proposals each; Gaussian proposals so the exact product is known
+    ptr = np.array([0, 0, 1, 3, 6, 10], dtype=np.int32); rows = np.arange(10, dtype=np.int32)
+    sig = rng.uniform(0.3, 1.0, (10, 3)) * [1, 1, 0.2]
+    mus = np.array([2.0, -1.0, 0.3]) + 0.4 * sig * rng.standard_normal((10, 3))   # mutually consistent proposals
+    prop = mus[:, :, None] + sig[:, :, None] * rng.standard_normal((10, 3, N))
+    bel = rng.standard_normal((5, 3, N))
+    fg = R.initfg(N); fg.addVariable("x0", R.Pose2); fg.addFactor(["x0"], R.PriorPose2())
+    dg = R.DeviceGraph(fg)
+    o = R.make_opts(N=N, seed=99, stream_offset=1234)
+    t = lambda a, dt: torch.as_tensor(a, dtype=dt, device="cuda")
+    out = torch.empty((5, 3, N), dtype=torch.float64, device="cuda")
+    import ctypes as C
+    d_ptr, d_rows, d_prop, d_bel = t(ptr, torch.int32), t(rows, torch.int32), t(prop, torch.float64), t(bel, torch.float64)
+    torch.cuda.synchronize()
+    R._lib.check(dg._lib.rome_product_dev(dg.ctx.handle, C.byref(o), 3, 5, d_ptr.data_ptr(), d_rows.data_ptr(),
+                                          d_prop.data_ptr(), d_bel.data_ptr(), out.data_ptr()), dg.ctx.handle)
+    dg.ctx.synchronize()
+    got = out.cpu().numpy()
+    ref = ro.product(ro.make_opts(N=N, seed=99, stream_offset=1234), 3, ptr, rows, prop, bel)
+    d = got - ref; d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    assert np.array_equal(got[0], bel[0]) and np.array_equal(got[1], prop[0])        # K=0 keeps, K=1 copies
+    assert np.mean(np.abs(d).max(axis=1) < 1e-9) > 0.99                                # same picks (bar measure-zero ties)
+    # statistical: product of Gaussians -> precision-weighted mean (loose window: N=100, KDE smoothing)
+    for v, (a, b) in enumerate(zip(ptr[:-1], ptr[1:])):
+        if b - a >= 2:
+            w = 1.0 / sig[a:b] ** 2
+            mexact = (w * mus[a:b]).sum(0) / w.sum(0); sexact = w.sum(0) ** -0.5
+            assert (np.abs(got[v].mean(axis=1) - mexact) < 4 * sexact + 0.05).all(), (v, got[v].mean(axis=1), mexact)
+            assert (got[v].std(axis=1) < 2.5 * sexact).all() and (got[v].std(axis=1) > 0.4 * sexact).all()
+
+
+def _hex_graph(N=100):
+    fg = R.generateGraph_Hexagonal(N=N)
+    R.dead_reckon_init(fg, seed=5)
+    return fg
+
+
+def test_solve_loop_vs_oracle_hexagonal():
+    """Pose means of the device solve within 1e-3 of the oracle's restatement under the shared RNG
+    (north_star tolerance); in practice the particle sets are identical to ~1e-9."""
+    N, S = 100, 6
+    fg = _hex_graph(N)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.solve(R.make_opts(N=N, solver=1, seed=77), n_sweeps=S)
+    m2, _ = dg.belief_stats(R.Pose2); ml, _ = dg.belief_stats(R.Point2)
+    b2, bl = solve_ref(R, fg, S, N, seed=77)
+    got2 = dg.bel[R.Pose2].cpu().numpy(); gotl = dg.bel[R.Point2].cpu().numpy()
+    for v in range(b2.shape[0]):
+        mo, _ = ro.belief_spread(b2[v])
+        dm = m2[v].cpu().numpy() - mo; dm[2] = np.arctan2(np.sin(dm[2]), np.cos(dm[2]))
+        assert np.abs(dm).max() < 1e-3, (v, dm)
+    mo, _ = ro.belief_spread(bl[0])
+    assert np.abs(ml[0].cpu().numpy() - mo).max() < 1e-3
+    d = got2 - b2; d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    assert np.mean(np.abs(d) < 1e-8) > 0.95
+
+
+def test_solve_hexagonal_statistical_windows():
+    """x0≈(0,0,0), x1≈(10,0,π/3), x2≈(15,8.66,2π/3), x3≈(10,17.32,±π), x4≈(0,17.32,-2π/3),
+    x5≈(-5,8.66,-π/3), x6≈(0,0,0), l1≈(20,0); boxes ±3 m / ±0.3 rad hold > 35 of 100 particles."""
+    N = 100
+    fg = _hex_graph(N)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.solve(R.make_opts(N=N, solver=1, seed=2026), n_sweeps=12)
+    b = dg.bel[R.Pose2].cpu().numpy(); l = dg.bel[R.Point2].cpu().numpy()
+    truth = [(0, 0, 0), (10, 0, np.pi / 3), (15, 8.66, 2 * np.pi / 3), (10, 17.32, np.pi), (0, 17.32, -2 * np.pi / 3),
+             (-5, 8.66, -np.pi / 3), (0, 0, 0)]
+    for k, (x, y, th) in enumerate(truth):
+        dth = np.arctan2(np.sin(b[k, 2] - th), np.cos(b[k, 2] - th))
+        inbox = (np.abs(b[k, 0] - x) < 3) & (np.abs(b[k, 1] - y) < 3) & (np.abs(dth) < 0.3)
+        assert inbox.sum() > 35, (k, inbox.sum(), b[k].mean(axis=1))
+    assert ((np.abs(l[0, 0] - 20) < 3) & (np.abs(l[0, 1]) < 3)).sum() > 35
