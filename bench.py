@@ -11,7 +11,9 @@ and target: N=100 getSample + inflateCycles(3) x {entropy inflation, 100 per-par
 N>1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns one
 Manhattan-sized segment of a chain of segments; after each sweep the ranks all-gather their
 separator (segment boundary) beliefs over RCCL, exactly the message a Bayes-tree clique boundary
-carries (N x 3 doubles per separator variable).
+carries (N x 3 doubles per separator variable).  The sweep kernel writes the separator rows straight
+into the send buffer, the collective lands straight in ghost blocks of the belief store, both
+double-buffered so that collective k-1 overlaps sweep k (rome_jl_amd.distributed.PipelinedSegmentSweep).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -58,8 +60,14 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # ROME_BENCH_FORCE_EXCHANGE=1: exercise the multi-GPU code path (process group, ghost variables,
+    # separator all_gather) even with a single rank -- used to smoke-test the RCCL path on a 1-GPU box
+    multi = world > 1 or os.environ.get("ROME_BENCH_FORCE_EXCHANGE") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if world == 1:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, "--gpus must match WORLD_SIZE"
 
@@ -74,7 +82,7 @@ def main():
         fg = R.synth_manhattan(P=args.poses, loops=args.loops, seed=0x524F4D45 + rank, N=N)
         workload = "synth_manhattan(P=%d, loops=%d) [g2o-shaped stand-in for examples/manhattan.g2o]" % (args.poses, args.loops)
     last = "x%d" % (len(fg.variables) - 1)
-    if world > 1:
+    if multi:
         # cut edges to the neighbouring segments: ghost variables hold the neighbours' separator beliefs
         cov = np.diag([1 / 44.6, 1 / 399.0, 1 / 9591.0])
         fg.addVariable("ghost_prev", R.Pose2); fg.addVariable("ghost_next", R.Pose2)
@@ -91,27 +99,22 @@ def main():
     sweep = dg.plan_sweep_pose2pose2(opts, prop)   # pre-built launch descriptor: one hipLaunchKernel per call
 
     pk = dg.packed
-    if world > 1:
-        from rome_jl_amd.distributed import chain_segment_exchange
-        bel = dg.bel[R.Pose2]
-        ex = chain_segment_exchange(torch, dist, world, rank, N, dev, pk.index["ghost_prev"], pk.index["ghost_next"])
+    if multi:
+        from rome_jl_amd.distributed import PipelinedSegmentSweep
         # proposal rows that carry the updated separator estimates (odometry convolutions targeting them)
         conv_first = 2 * 0 + 1                                   # factor 0 (x0->x1), dir 1 -> target x0
         conv_last = 2 * (args.poses - 2) + 0 if not args.g2o else 0  # factor P-2 (x_{P-2}->x_{P-1}), dir 0
-
-        def exchange():
-            ex.exchange([prop[conv_first], prop[conv_last]], bel)
-    else:
-        def exchange():
-            pass
+        pipe = PipelinedSegmentSweep(dg, opts, dist, world, rank, [conv_first, conv_last],
+                                     pk.index["ghost_prev"], pk.index["ghost_next"], always_collective=(world == 1))
+        sweep = pipe.step
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        sweep(); exchange()
+        sweep()
     barrier()
     # per-launch duration of the dominant kernel: HIP events on the launch stream (torch's current stream,
     # which the launch plan binds the rome_ctx to), recorded around every launch of the timed region
@@ -123,12 +126,13 @@ def main():
     for k in range(args.steps):
         ev[k].record()
         sweep()
-        exchange()
     ev[args.steps].record()
+    if multi:
+        pipe.drain()
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -147,7 +151,7 @@ def main():
         "config": {"workload": workload, "poses_per_gpu": len(pk.labels[R.Pose2]), "pose2pose2_factors_per_gpu": tb["F"],
                    "convolutions_per_step_per_gpu": n_conv_step, "particles": N, "solver": args.solver,
                    "inflate_cycles": int(opts.inflate_cycles), "inflation": float(opts.inflation), "noise": "in-kernel philox",
-                   "parallelism": "1 graph segment per GPU, separator all_gather" if world > 1 else "single GPU"},
+                   "parallelism": "1 graph segment per GPU, separator all_gather" if multi else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "rome::k_conv<P2P2,%s,PPL=2>" % args.solver,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms, "traffic": None},
@@ -186,7 +190,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

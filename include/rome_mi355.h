@@ -165,6 +165,12 @@ typedef struct rome_conv_dev {
   const double* noise;       /* [C][dz][N] or NULL                                                */
   double* out;               /* [C][dt][N] proposals                                              */
   int32_t* status;           /* [C][N] or NULL                                                    */
+  /* optional: up to 4 convolution rows whose proposal block is ALSO written to mirror_out[m] ([dt][N] each),
+   * e.g. separator beliefs straight into an RCCL send buffer (no gather kernel between sweep and collective) */
+  int32_t n_mirror;
+  int32_t mirror_row[4];
+  int32_t reserved;
+  double* mirror_out;
 } rome_conv_dev;
 
 int rome_conv_pose2pose2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);

@@ -34,7 +34,8 @@ class ConvDev(C.Structure):
     _fields_ = [("n_conv", C.c_int32), ("dir_all", C.c_int32),
                 ("factor", C.c_void_p), ("dir", C.c_void_p), ("fixed_var", C.c_void_p), ("target_var", C.c_void_p),
                 ("mu", C.c_void_p), ("L", C.c_void_p), ("bel_fixed", C.c_void_p), ("bel_target", C.c_void_p),
-                ("noise", C.c_void_p), ("out", C.c_void_p), ("status", C.c_void_p)]
+                ("noise", C.c_void_p), ("out", C.c_void_p), ("status", C.c_void_p),
+                ("n_mirror", C.c_int32), ("mirror_row", C.c_int32 * 4), ("reserved", C.c_int32), ("mirror_out", C.c_void_p)]
 
 
 _PD = C.POINTER(C.c_double)

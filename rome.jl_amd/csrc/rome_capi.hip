@@ -74,6 +74,9 @@ void args_from_dev(rome::ConvArgs& a, const rome_opts* o, const rome_conv_dev* t
   a.factor = t->factor; a.dir = t->dir; a.fixed_var = t->fixed_var; a.target_var = t->target_var;
   a.mu = t->mu; a.L = t->L; a.bel_fixed = t->bel_fixed; a.bel_target = t->bel_target;
   a.noise = t->noise; a.out = t->out; a.status = t->status;
+  a.n_mirror = t->mirror_out ? (t->n_mirror < 0 ? 0 : (t->n_mirror > 4 ? 4 : t->n_mirror)) : 0;
+  for (int m = 0; m < 4; ++m) a.mirror_row[m] = t->mirror_row[m];
+  a.mirror_out = t->mirror_out;
 }
 
 int cholesky_one(int d, const double* cov, double* Lp) {

@@ -23,6 +23,9 @@ struct ConvArgs {
   const double* noise;        // [C][dz][N] standard normals, or nullptr -> in-kernel Philox
   double* out;                // [C][dt][N]
   int32_t* status;            // [C][N] or nullptr
+  int n_mirror;               // rows additionally written to mirror_out[m] (separator beliefs -> send buffer)
+  int mirror_row[4];
+  double* mirror_out;
   int dir_all;
   int max_iters;
   int cycles;

@@ -498,6 +498,19 @@ __global__ void __launch_bounds__(256, ROME_MIN_WAVES) k_conv(const ConvArgs a) 
       if (a.status) a.status[(size_t)c * N + i] = st[k];
     }
   }
+  for (int m = 0; m < a.n_mirror; ++m) {  // wave-uniform: separator rows are duplicated into the exchange buffer
+    if (a.mirror_row[m] == c) {
+      double* mb = a.mirror_out + (size_t)m * FP::DT * N;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const int i = lane + 64 * k;
+        if (act[k]) {
+#pragma unroll
+          for (int d = 0; d < FP::DT; ++d) mb[d * N + i] = t[k][d];
+        }
+      }
+    }
+  }
 }
 
 // ---- prior sampling: out = coords(exp_ϵ(hat(μ + Lξ))) ; one wave per prior

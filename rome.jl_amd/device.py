@@ -106,7 +106,10 @@ class DeviceGraph:
         cd = _lib.ConvDev()
         keep = []
         for k, v in kw.items():
-            if isinstance(v, int):
+            if k == "mirror_row":
+                for m, r in enumerate(v):
+                    cd.mirror_row[m] = int(r)
+            elif isinstance(v, int):
                 setattr(cd, k, v)
             elif v is not None:
                 keep.append(v)

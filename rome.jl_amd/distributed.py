@@ -6,7 +6,10 @@ variables and runs the convolutions that TARGET its variables -- no collective o
 sweep.  The one real exchange step is the separator message of the Bayes tree (IIF `LikelihoodMessage`
 holding a `TreeBelief` of N points per separator variable; SURVEY.md §5 "distributed communication
 backend"): after a sweep every rank publishes the beliefs of its boundary variables and receives the
-ones its cut factors read (`SeparatorExchange`).  Messages are N x dim doubles (2.4 kB per Pose2).
+ones its cut factors read (`SeparatorExchange`).  Messages are N x dim doubles (2.4 kB per Pose2), i.e.
+latency-bound: the collective is posted asynchronously right after a sweep and completed just before the
+next one, so it overlaps with the next sweep's launch instead of serialising with it (the cut factors then
+read separator beliefs that are one sweep old -- the same asynchrony IIF's clique tasks have).
 """
 import numpy as np
 
@@ -36,39 +39,118 @@ def shard_convolutions_by_target(target_var, n_vars, world, rank):
 class SeparatorExchange:
     """All-gather of separator beliefs between graph segments.
 
-    Every rank contributes `n_sep` belief blocks (each [dim, N]); `plan` lists, for each ghost block this
-    rank keeps, which (source rank, source slot) feeds it.  One `all_gather_into_tensor` per exchange:
-    the payload is tiny (latency-bound), so a single fixed-size collective beats per-edge send/recv.
+    Every rank publishes `n_sep` belief blocks (rows `publish_rows` of a source tensor [rows, dim, N]);
+    `ghosts` lists, for each ghost block this rank keeps, which (source rank, source slot) feeds it.
+    One fixed-size `all_gather_into_tensor` per exchange (the payload is tiny, so one collective beats
+    per-edge send/recv).  `post()` launches it asynchronously, `complete()` waits and scatters.
     """
 
-    def __init__(self, torch, dist, world, rank, n_sep, dim, N, device, dtype=None):
+    def __init__(self, torch, dist, world, rank, publish_rows, ghosts, dim, N, device, dtype=None, always_collective=False):
         self.torch, self.dist = torch, dist
         self.world, self.rank = world, rank
+        self.always_collective = always_collective  # issue the collective even for world == 1 (smoke tests)
         dtype = dtype or torch.float64
+        n_sep = len(publish_rows)
+        self.publish_rows = torch.as_tensor(np.asarray(publish_rows, dtype=np.int64), device=device)
         self.send = torch.zeros((n_sep, dim, N), dtype=dtype, device=device)
-        self.recv = torch.zeros((world, n_sep, dim, N), dtype=dtype, device=device)
-        self.plan = []  # (ghost_block_index, src_rank, src_slot)
+        self.recv = torch.zeros((world * n_sep, dim, N), dtype=dtype, device=device)
+        self.ghost_blocks = torch.as_tensor(np.asarray([g[0] for g in ghosts], dtype=np.int64), device=device)
+        self.ghost_src = torch.as_tensor(np.asarray([(g[1] % world) * n_sep + g[2] for g in ghosts], dtype=np.int64), device=device)
+        self.pending = None
+        self.have_data = False
 
-    def add_ghost(self, ghost_block, src_rank, src_slot):
-        self.plan.append((int(ghost_block), int(src_rank) % self.world, int(src_slot)))
-
-    def exchange(self, publish, beliefs):
-        """publish: list of [dim,N] tensors (this rank's separator beliefs, slot order);
-        beliefs: the rank's belief store [V, dim, N]; ghost blocks are overwritten in place."""
-        for k, blk in enumerate(publish):
-            self.send[k].copy_(blk)
-        if self.world > 1:
-            self.dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))  # flat: same for gloo and nccl
+    def post(self, source):
+        """Gather this rank's separator rows from `source` and launch the collective (asynchronously)."""
+        self.torch.index_select(source, 0, self.publish_rows, out=self.send)
+        if self.world > 1 or self.always_collective:
+            self.pending = self.dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), async_op=True)
         else:
-            self.recv[0].copy_(self.send)
-        for ghost, src, slot in self.plan:
-            beliefs[ghost].copy_(self.recv[src, slot])
+            self.recv.copy_(self.send)
+        self.have_data = True
+
+    def complete(self, beliefs):
+        """Wait for the posted collective (if any) and overwrite the ghost blocks of `beliefs` [V, dim, N]."""
+        if not self.have_data:
+            return
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+        beliefs.index_copy_(0, self.ghost_blocks, self.recv.index_select(0, self.ghost_src))
+        self.have_data = False
+
+    def exchange(self, source, beliefs):
+        """Synchronous form: post + complete."""
+        self.post(source)
+        self.complete(beliefs)
 
 
-def chain_segment_exchange(torch, dist, world, rank, N, device, ghost_prev, ghost_next):
-    """The exchange used by bench.py / the weak-scaling layout: segments in a ring, each rank publishes
-    (first pose, last pose) of its segment; ghost_prev <- previous rank's last, ghost_next <- next rank's first."""
-    ex = SeparatorExchange(torch, dist, world, rank, n_sep=2, dim=3, N=N, device=device)
-    ex.add_ghost(ghost_prev, rank - 1, 1)
-    ex.add_ghost(ghost_next, rank + 1, 0)
-    return ex
+def chain_segment_exchange(torch, dist, world, rank, N, device, publish_rows, ghost_prev, ghost_next, always_collective=False):
+    """The exchange used by bench.py / the weak-scaling layout: segments in a ring; every rank publishes two
+    rows of its proposal table (slot 0: its first pose, slot 1: its last pose);
+    ghost_prev <- previous rank's slot 1, ghost_next <- next rank's slot 0."""
+    return SeparatorExchange(torch, dist, world, rank, publish_rows,
+                             [(ghost_prev, rank - 1, 1), (ghost_next, rank + 1, 0)], 3, N, device,
+                             always_collective=always_collective)
+
+
+class PipelinedSegmentSweep:
+    """Weak-scaling sweep driver with the separator exchange fully off the critical path.
+
+    * the sweep kernel itself mirrors this rank's separator proposals into the RCCL send buffer
+      (`rome_conv_dev.mirror_*`: no gather kernel);
+    * `all_gather_into_tensor` writes straight into ghost blocks that live in the TAIL of the belief store
+      (no scatter kernel): the cut factors' `fixed_var`/`target_var` entries simply point there;
+    * send and ghost buffers are double-buffered: sweep k reads the separators gathered after sweep k-2 while
+      collective k-1 is still in flight, so nothing races and the result is deterministic for a fixed schedule.
+    Host work per step: wait (no-op in steady state) + one kernel launch + one async collective.
+    """
+
+    def __init__(self, dg, opts, dist, world, rank, sep_rows, ghost_prev, ghost_next, always_collective=False):
+        from .factors import Pose2
+        torch = dg.torch
+        self.dg, self.dist, self.world, self.rank = dg, dist, world, rank
+        self.collective = world > 1 or always_collective
+        tb = dg.tab["p2p2"]
+        N, n_sep = dg.N, len(sep_rows)
+        old = dg.bel[Pose2]
+        V = old.shape[0]
+        per = world * n_sep
+        store = torch.zeros((V + 2 * per, 3, N), dtype=old.dtype, device=old.device)
+        store[:V].copy_(old)
+        dg.bel[Pose2] = store
+        self.store, self.V = store, V
+        self.recv = [store[V + b * per: V + (b + 1) * per] for b in range(2)]
+        self.send = [torch.zeros((n_sep, 3, N), dtype=old.dtype, device=old.device) for _ in range(2)]
+        self.prop = torch.empty((tb["C"], 3, N), dtype=old.dtype, device=old.device)
+        self.works = [None, None]
+        self.plans = []
+        for b in range(2):
+            gp = V + b * per + ((rank - 1) % world) * n_sep + 1   # previous segment's LAST pose (slot 1)
+            gn = V + b * per + ((rank + 1) % world) * n_sep + 0   # next segment's FIRST pose (slot 0)
+            store[gp].copy_(old[ghost_prev]); store[gn].copy_(old[ghost_next])
+            fixed = tb["fixed"].clone(); target = tb["target"].clone()
+            for arr in (fixed, target):
+                arr[arr == ghost_prev] = gp
+                arr[arr == ghost_next] = gn
+            self.plans.append(dg._plan(dg._lib.rome_conv_pose2pose2_dev, opts, n_conv=tb["C"], dir_all=0,
+                                       factor=tb["factor"], dir=tb["dir"], fixed_var=fixed, target_var=target,
+                                       mu=tb["mu"], L=tb["L"], bel_fixed=store, bel_target=store, out=self.prop,
+                                       n_mirror=n_sep, mirror_row=tuple(int(r) for r in sep_rows), mirror_out=self.send[b]))
+        self.k = 0
+
+    def step(self):
+        b = self.k & 1
+        w = self.works[b]
+        if w is not None:
+            w.wait()
+        self.plans[b]()
+        if self.collective:
+            self.works[b] = self.dist.all_gather_into_tensor(self.recv[b].view(-1), self.send[b].view(-1), async_op=True)
+        else:
+            self.recv[b].copy_(self.send[b])
+        self.k += 1
+
+    def drain(self):
+        for b in range(2):
+            if self.works[b] is not None:
+                self.works[b].wait(); self.works[b] = None

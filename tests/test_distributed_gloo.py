@@ -30,12 +30,19 @@ def _worker(rank, world, port, ret):
         # ---- (a) separator exchange between chained segments ----
         V = 6  # 4 owned poses + ghost_prev (4) + ghost_next (5)
         bel = torch.full((V, 3, N), float(rank), dtype=torch.float64)
-        first = torch.full((3, N), 100.0 + rank, dtype=torch.float64)
-        last = torch.full((3, N), 200.0 + rank, dtype=torch.float64)
-        ex = chain_segment_exchange(torch, dist, world, rank, N, "cpu", ghost_prev=4, ghost_next=5)
-        ex.exchange([first, last], bel)
-        ok_a = bool((bel[4] == 200.0 + (rank - 1) % world).all() and (bel[5] == 100.0 + (rank + 1) % world).all()
-                    and (bel[:4] == float(rank)).all())
+        prop = torch.zeros((7, 3, N), dtype=torch.float64)       # proposal table: row 2 = first pose, row 5 = last pose
+        prop[2] = 100.0 + rank; prop[5] = 200.0 + rank
+        ex = chain_segment_exchange(torch, dist, world, rank, N, "cpu", [2, 5], ghost_prev=4, ghost_next=5)
+        ex.complete(bel)                                           # nothing posted yet: no-op
+        ok_a = bool((bel == float(rank)).all())
+        ex.post(prop)                                              # asynchronous collective ...
+        prop[2] = -1.0                                             # ... is not affected by later writes to the source
+        ex.complete(bel)
+        ok_a = ok_a and bool((bel[4] == 200.0 + (rank - 1) % world).all() and (bel[5] == 100.0 + (rank + 1) % world).all()
+                             and (bel[:4] == float(rank)).all())
+        prop[2] = 300.0 + rank
+        ex.exchange(prop, bel)                                     # synchronous form
+        ok_a = ok_a and bool((bel[5] == 300.0 + (rank + 1) % world).all())
         # ---- (b) strong-scaling shard of one graph by target ownership == unsharded sweep ----
         fg = R.synth_manhattan(P=60, loops=25, seed=5, N=N)
         R.dead_reckon_init(fg, seed=2)
