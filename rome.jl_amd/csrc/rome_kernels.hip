@@ -102,22 +102,34 @@ struct P2P2 {
   __device__ static __forceinline__ double spread(const double (&t)[PPL][3], const bool (&act)[PPL], double inv, double den) {
     return spread_se2<PPL>(t, act, inv, den);
   }
-  __device__ static __forceinline__ void add_entropy(double (&t)[3], double spread, const double (&u)[3]) {
-    se2_add_entropy(t, spread, u);
-    t[2] = wrap_pi(t[2]);
+  __device__ static __forceinline__ void add_entropy(double (&t)[3], double spread, const double (&u)[3], double s, double c) {
+    const double ex = spread * (u[0] - 0.5), ey = spread * (u[1] - 0.5), et = spread * (u[2] - 0.5);
+    t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] = wrap_pi(t[2] + et);
   }
 
   // per-particle constants of the root-find, computed once (not once per inflation cycle):
   //   dir 0: a = q̂ = p ∘ exp_ϵ(z) ; dir 1: a = (q.x, q.y, θq - zθ) ; prior row: a = z
-  struct Prep { double a0, a1, a2; };
+  //   (fs, fc) = sin/cos of the root heading for dir 1 (θp = θq - zθ is known before solving): the Newton
+  //   iterations and the entropy of the later inflation cycles reuse it instead of re-evaluating sincos.
+  struct Prep { double a0, a1, a2, fs, fc; };
   __device__ static __forceinline__ Prep prepare(const Consts& K, const double (&z)[3], const double (&fxc)[3]) {
     Prep P;
+    P.fs = 0.0; P.fc = 1.0;
     if (K.dir == 0) {
       double s, c; fast_sincos(fxc[2], &s, &c);
       P.a0 = fxc[0] + c * z[0] - s * z[1]; P.a1 = fxc[1] + s * z[0] + c * z[1]; P.a2 = fxc[2] + z[2];
-    } else if (K.dir == 1) { P.a0 = fxc[0]; P.a1 = fxc[1]; P.a2 = fxc[2] - z[2]; }
-    else { P.a0 = z[0]; P.a1 = z[1]; P.a2 = z[2]; }
+    } else if (K.dir == 1) {
+      P.a0 = fxc[0]; P.a1 = fxc[1]; P.a2 = fxc[2] - z[2];
+      fast_sincos(P.a2, &P.fs, &P.fc);
+    } else { P.a0 = z[0]; P.a1 = z[1]; P.a2 = z[2]; }
     return P;
+  }
+  // sin/cos of the current target heading for the entropy step (u0 ∘ exp_ϵ(jitter))
+  template <int SOLVER>
+  __device__ static __forceinline__ void heading_sincos(const Consts& K, const Prep& P, int st, int cyc, const double (&t)[3],
+                                                        double* s, double* c) {
+    if (SOLVER == kSolverNewton && K.dir == 1 && cyc > 0 && st == 0) { *s = P.fs; *c = P.fc; }  // t[2] ≡ θp after a converged solve
+    else fast_sincos(t[2], s, c);
   }
 
   template <int SOLVER>
@@ -152,11 +164,10 @@ struct P2P2 {
         // translation with R(θ) at the UPDATED heading (block Gauss-Seidel/Newton).  sin/cos are only
         // recomputed when θ moved, so a converging solve costs one sincos instead of three.
         st = 1;
-        double s = 0.0, c = 1.0, th_sc = __builtin_nan("");
+        const double s = P.fs, c = P.fc;  // sin/cos(θp): after the θ step below t[2] ≡ θp (mod 2π) up to rounding / tol
         for (int it = 0; it < max_iters; ++it) {
           const double r2 = wrap_pi(t[2] - pth);
           if (fabs(r2) > tol) t[2] -= r2;  // else θ is converged: (r0, r1, r2) below is the residual at the returned point
-          if (t[2] != th_sc) { fast_sincos(t[2], &s, &c); th_sc = t[2]; }
           const double r0 = t[0] + c * z[0] - s * z[1] - qx0, r1 = t[1] + s * z[0] + c * z[1] - qy0;
           if (fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol) { st = 0; break; }
           t[0] -= r0; t[1] -= r1;
@@ -209,12 +220,18 @@ struct BR {
     if constexpr (DT == 3) return spread_se2<PPL>(t, act, inv, den);
     else return spread_r2<PPL>(t, act, inv, den);
   }
-  __device__ static __forceinline__ void add_entropy(double (&t)[DT], double spread, const double (&u)[DT]) {
-    if constexpr (DT == 3) { se2_add_entropy(t, spread, u); t[2] = wrap_pi(t[2]); }
-    else { t[0] += spread * (u[0] - 0.5); t[1] += spread * (u[1] - 0.5); }
+  __device__ static __forceinline__ void add_entropy(double (&t)[DT], double spread, const double (&u)[DT], double s, double c) {
+    if constexpr (DT == 3) {
+      const double ex = spread * (u[0] - 0.5), ey = spread * (u[1] - 0.5), et = spread * (u[2] - 0.5);
+      t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] = wrap_pi(t[2] + et);
+    } else { t[0] += spread * (u[0] - 0.5); t[1] += spread * (u[1] - 0.5); }
   }
   struct Prep {};
   __device__ static __forceinline__ Prep prepare(const Consts&, const double (&)[2], const double (&)[DF]) { return Prep{}; }
+  template <int SOLVER>
+  __device__ static __forceinline__ void heading_sincos(const Consts&, const Prep&, int, int, const double (&t)[DT], double* s, double* c) {
+    if constexpr (DT == 3) fast_sincos(t[2], s, c); else { *s = 0.0; *c = 1.0; }
+  }
   template <int SOLVER>
   __device__ static __forceinline__ int solve(const Consts&, const Prep&, const double (&z)[2], const double (&fx)[DF],
                                               double (&t)[DT], int max_iters, double tol) {
@@ -333,13 +350,17 @@ struct P3P3 {
     for (int j = 0; j < 6; ++j) acc += fast_sqrt(fmax(0.0, (s[2 * j + 1] - s[2 * j] * s[2 * j] * inv) * den));
     return acc * (1.0 / 6.0);
   }
-  __device__ static __forceinline__ void add_entropy(double (&t)[6], double spread, const double (&u)[6]) {
+  struct Prep {};
+  __device__ static __forceinline__ Prep prepare(const Consts&, const double (&)[6], const double (&)[6]) { return Prep{}; }
+  template <int SOLVER>
+  __device__ static __forceinline__ void heading_sincos(const Consts&, const Prep&, int, int, const double (&)[6], double* s, double* c) {
+    *s = 0.0; *c = 1.0;
+  }
+  __device__ static __forceinline__ void add_entropy(double (&t)[6], double spread, const double (&u)[6], double, double) {
     Se3 T; se3_from_coords(t, T);
     se3_add_entropy(T, spread, u);
     se3_to_coords(T, t);
   }
-  struct Prep {};
-  __device__ static __forceinline__ Prep prepare(const Consts&, const double (&)[6], const double (&)[6]) { return Prep{}; }
   template <int SOLVER>
   __device__ static __forceinline__ int solve(const Consts& K, const Prep&, const double (&z)[6], const double (&fxc)[6],
                                               double (&t)[6], int max_iters, double tol) {
@@ -482,7 +503,9 @@ __global__ void __launch_bounds__(256, ROME_MIN_WAVES) k_conv(const ConvArgs a) 
         if (spread > 0.0) {
           double u[FP::DT];
           rng_entropy_from_words<FP::DT>(ew[k], cyc % CPC, u);
-          FP::add_entropy(t[k], spread, u);
+          double hs, hc;
+          FP::template heading_sincos<SOLVER>(K, prep[k], st[k], cyc, t[k], &hs, &hc);
+          FP::add_entropy(t[k], spread, u, hs, hc);
         }
         st[k] = FP::template solve<SOLVER>(K, prep[k], z[k], fx[k], t[k], a.max_iters, a.tol);
       }
