@@ -181,6 +181,19 @@ class DeviceGraph:
             self.conv_step(opts, s)
             self.product_step(opts, s)
 
+    def init_from_means(self, means, sigma=None, seed=3):
+        """Beliefs = per-variable mean ⊕ N(0, diag σ²) jitter: e.g. means from solveGraphParametric (IIF can
+        initialise the nonparametric solve from the parametric one: initParametricFrom!/autoinit)."""
+        rng = np.random.default_rng(seed)
+        for vt in (Pose2, Point2):
+            ls = self.packed.labels[vt]
+            if not ls:
+                continue
+            sg = np.asarray(sigma[vt] if sigma is not None else ([0.05, 0.05, 0.01] if vt is Pose2 else [0.1, 0.1]))
+            m = np.stack([np.asarray(means[l], dtype=float) for l in ls])
+            b = m[:, :, None] + sg[None, :, None] * rng.standard_normal((len(ls), vt.dim, self.N))
+            self.bel[vt][:len(ls)].copy_(self.torch.as_tensor(b))
+
     def belief_stats(self, vartype):
         """(mean [V,dim], std [V,dim]) of every belief of one variable type, on device."""
         self._bind_stream()

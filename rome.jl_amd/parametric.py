@@ -87,11 +87,15 @@ def initParametric(fg):
 
 
 class _Problem:
+    """Flat state vector + precomputed gather indices and sparsity pattern (all per-iteration work is
+    vectorised numpy around one `rome_linearize` call per factor kind)."""
+
     def __init__(self, fg):
         self.fg = fg
         self.labels = list(fg.variables)
         self.vt = [fg.variables[l] for l in self.labels]
-        self.off = np.concatenate([[0], np.cumsum([t.dim for t in self.vt])])
+        self.off = np.concatenate([[0], np.cumsum([t.dim for t in self.vt])]).astype(np.int64)
+        self.n = int(self.off[-1])
         self.index = {l: i for i, l in enumerate(self.labels)}
         groups = {}
         for _, labels, f in fg.factors:
@@ -102,64 +106,98 @@ class _Problem:
             g = groups.setdefault(k, dict(mu=[], W=[], a=[], b=[]))
             g["mu"].append(mu); g["W"].append(_whitening(info)); g["a"].append(self.index[labels[0]])
             g["b"].append(self.index[labels[1]] if len(labels) > 1 else -1)
-        self.groups = {k: {n: np.asarray(v) for n, v in g.items()} for k, g in groups.items()}
+        self.groups = {}
+        rows, cols = [], []
+        m = 0
+        for k, g in groups.items():
+            g = {n_: np.asarray(v) for n_, v in g.items()}
+            dz, dr, da, db = api._LIN_DIMS[k]
+            F = len(g["a"])
+            g["ia"] = self.off[g["a"]][:, None] + np.arange(da)[None, :]
+            g["ib"] = self.off[g["b"]][:, None] + np.arange(db)[None, :] if db else None
+            ridx = m + np.arange(F * dr).reshape(F, dr)
+            g["rslice"] = slice(m, m + F * dr)
+            for idx, dv in ((g["ia"], da), (g["ib"], db)):
+                if idx is None:
+                    continue
+                rows.append(np.repeat(ridx[:, :, None], dv, axis=2).ravel())
+                cols.append(np.repeat(idx[:, None, :], dr, axis=1).ravel())
+            m += F * dr
+            self.groups[k] = g
+        self.m = m
+        self.rows = np.concatenate(rows); self.cols = np.concatenate(cols)
+        # retraction index sets
+        self.pose2_th = np.array([self.off[i] + 2 for i, t in enumerate(self.vt) if t is Pose2], dtype=np.int64)
+        self.pose3_w = np.array([self.off[i] + 3 for i, t in enumerate(self.vt) if t is Pose3], dtype=np.int64)
 
-    def linearize(self, x, ctx=None):
+    def pack(self, xdict):
+        X = np.zeros(self.n)
+        for i, l in enumerate(self.labels):
+            X[self.off[i]:self.off[i + 1]] = xdict[l]
+        return X
+
+    def unpack(self, X):
+        return {l: X[self.off[i]:self.off[i + 1]].copy() for i, l in enumerate(self.labels)}
+
+    def retract(self, X, d):
+        Y = X + d
+        if len(self.pose2_th):
+            Y[self.pose2_th] = np.arctan2(np.sin(Y[self.pose2_th]), np.cos(Y[self.pose2_th]))
+        if len(self.pose3_w):
+            from scipy.spatial.transform import Rotation as Rot
+            idx = self.pose3_w[:, None] + np.arange(3)[None, :]
+            Y[idx] = (Rot.from_rotvec(X[idx]) * Rot.from_rotvec(d[idx])).as_rotvec()
+        return Y
+
+    def linearize(self, X, ctx=None):
         """-> (r (m,), J scipy.sparse.csr (m, n))"""
         import scipy.sparse as sp
-        rows, cols, vals, rs = [], [], [], []
-        m = 0
+        r = np.empty(self.m); vals = []
         for k, g in self.groups.items():
-            xa = np.stack([x[i] for i in g["a"]])
-            xb = np.stack([x[i] for i in g["b"]]) if g["b"][0] >= 0 else None
-            r, Ja, Jb = api.linearize(k, g["mu"], g["W"], xa, xb, ctx=ctx)
-            F, dr = r.shape
-            ridx = m + np.arange(F * dr).reshape(F, dr)
-            rs.append(r.ravel())
-            for J, vidx in ((Ja, g["a"]), (Jb, g["b"])):
-                if J is None:
-                    continue
-                dv = J.shape[2]
-                cidx = self.off[vidx][:, None] + np.arange(dv)[None, :]
-                rows.append(np.repeat(ridx[:, :, None], dv, axis=2).ravel())
-                cols.append(np.repeat(cidx[:, None, :], dr, axis=1).ravel())
-                vals.append(J.ravel())
-            m += F * dr
-        J = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(m, self.off[-1]))
-        return np.concatenate(rs), J
+            xa = X[g["ia"]]
+            xb = X[g["ib"]] if g["ib"] is not None else None
+            rk, Ja, Jb = api.linearize(k, g["mu"], g["W"], xa, xb, ctx=ctx)
+            r[g["rslice"]] = rk.ravel()
+            vals.append(Ja.ravel())
+            if Jb is not None:
+                vals.append(Jb.ravel())
+        J = sp.csr_matrix((np.concatenate(vals), (self.rows, self.cols)), shape=(self.m, self.n))
+        return r, J
 
 
-def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-12, ctx=None, return_cov=False):
-    """-> {label: coordinates} (and, if return_cov, {label: marginal covariance block} from (JᵀJ)⁻¹)."""
+def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, return_cov=False, verbose=False):
+    """-> {label: coordinates} (and, if return_cov, {label: marginal covariance block} from (JᵀJ)⁻¹).
+    Stops when the relative cost decrease of an accepted step falls below `tol` (small graphs converge
+    quadratically; the low-frequency modes of a weakly anchored 3500-pose graph creep at 1e-4/iteration
+    long after the pose error has reached the measurement-noise floor) or the step is below 1e-8."""
     import scipy.sparse as sp
     from scipy.sparse.linalg import spsolve
     P = _Problem(fg)
-    x0 = initParametric(fg) if init is None else init
-    x = [np.array(x0[l], dtype=float) for l in P.labels]
+    X = P.pack(initParametric(fg) if init is None else init)
     lam = 1e-6
-    r, J = P.linearize(x, ctx)
+    r, J = P.linearize(X, ctx)
     cost = float(r @ r)
-    for _ in range(max_iters):
+    for it in range(max_iters):
+        if verbose:
+            print('LM iter %d cost %.6g lambda %.1e' % (it, cost, lam))
         H = (J.T @ J).tocsc(); g = J.T @ r
         D = sp.diags(H.diagonal() + 1e-12)
         while True:
             d = spsolve((H + lam * D).tocsc(), -g)
-            xn = [_retract(P.vt[i], x[i], d[P.off[i]:P.off[i + 1]]) for i in range(len(x))]
-            rn, Jn = P.linearize(xn, ctx)
+            Xn = P.retract(X, d)
+            rn, Jn = P.linearize(Xn, ctx)
             cn = float(rn @ rn)
             if cn <= cost or lam > 1e12:
                 break
             lam *= 10.0
-        done = (cost - cn) <= tol * max(1.0, cost) and np.abs(d).max() < 1e-9
-        x, r, J, cost = xn, rn, Jn, cn
+        done = (cost - cn) <= tol * max(1.0, cost) or np.abs(d).max() < 1e-8
+        X, r, J, cost = Xn, rn, Jn, cn
         lam = max(lam / 10.0, 1e-12)
         if done:
             break
-    out = {l: x[i] for i, l in enumerate(P.labels)}
-    out_info = dict(cost=cost)
+    out = P.unpack(X)
     if return_cov:
-        Hd = (J.T @ J).toarray()
-        C = np.linalg.inv(Hd)
+        C = np.linalg.inv((J.T @ J).toarray())
         cov = {l: C[P.off[i]:P.off[i + 1], P.off[i]:P.off[i + 1]] for i, l in enumerate(P.labels)}
-        return out, cov, out_info
+        return out, cov, dict(cost=cost)
     return out

@@ -28,3 +28,14 @@ for chunk in (5, 5, 10, 20, 40, 80):
     tot += chunk
     m, sd = dg.belief_stats(R.Pose2)
     print("sweeps %3d  %.2f ms/sweep  rms %.3f  mean std %s" % (tot, 1e3 * dt / chunk, kabsch_rms(m.cpu().numpy()[:, :2], gt), sd.mean(0).cpu().numpy().round(3)))
+
+# ---- pipeline as IIF allows it: parametric solve first, nonparametric sweeps initialised from it ----
+t = time.perf_counter(); xp = R.solveGraphParametric(fg); tp = time.perf_counter() - t
+mp = np.array([xp["x%d" % k][:2] for k in range(P)])
+print("parametric solve: %.2f s, rms %.3f" % (tp, kabsch_rms(mp, gt)))
+dg.init_from_means(xp)
+torch.cuda.synchronize(); t = time.perf_counter()
+dg.solve(o, n_sweeps=10)
+torch.cuda.synchronize(); dt = time.perf_counter() - t
+m, sd = dg.belief_stats(R.Pose2)
+print("parametric init + 10 sweeps: %.2f ms, rms %.3f, mean std %s" % (1e3 * dt, kabsch_rms(m.cpu().numpy()[:, :2], gt), sd.mean(0).cpu().numpy().round(3)))

@@ -112,3 +112,30 @@ def test_solve_hexagonal_statistical_windows():
         inbox = (np.abs(b[k, 0] - x) < 3) & (np.abs(b[k, 1] - y) < 3) & (np.abs(dth) < 0.3)
         assert inbox.sum() > 35, (k, inbox.sum(), b[k].mean(axis=1))
     assert ((np.abs(l[0, 0] - 20) < 3) & (np.abs(l[0, 1]) < 3)).sum() > 35
+
+
+def test_manhattan_pipeline_parametric_init_then_sweeps():
+    """Config-2-shaped graph end to end on the device: parametric solve (batched Jacobians) -> beliefs around
+    it -> nonparametric sweeps; the PPE means stay at the measurement-noise floor w.r.t. the generator's
+    ground truth (gauge removed by a rigid alignment)."""
+    P = 600
+    fg = R.synth_manhattan(P=P, loops=300, seed=9)
+    gt = np.array([fg.ground_truth["x%d" % k][:2] for k in range(P)])
+
+    def rms(A):
+        ca, cb = A.mean(0), gt.mean(0)
+        U, _, Vt = np.linalg.svd((A - ca).T @ (gt - cb))
+        Rm = (U @ np.diag([1, np.sign(np.linalg.det(U @ Vt))]) @ Vt).T
+        return np.sqrt(np.mean(np.sum(((A - ca) @ Rm.T + cb - gt) ** 2, axis=1)))
+    xp = R.solveGraphParametric(fg)
+    e_param = rms(np.array([xp["x%d" % k][:2] for k in range(P)]))
+    R.dead_reckon_init(fg, seed=1)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    m0, _ = dg.belief_stats(R.Pose2)
+    e_init = rms(m0.cpu().numpy()[:, :2])
+    dg.init_from_means(xp)
+    dg.solve(R.make_opts(N=100, solver=1, seed=5), n_sweeps=8)
+    m, sd = dg.belief_stats(R.Pose2)
+    e = rms(m.cpu().numpy()[:, :2])
+    assert e_param < 0.3 and e < 1.3 * e_param + 0.05 and e < 0.5 * e_init, (e_init, e_param, e)
+    assert (sd.cpu().numpy() > 0).all()
