@@ -137,5 +137,5 @@ def test_manhattan_pipeline_parametric_init_then_sweeps():
     dg.solve(R.make_opts(N=100, solver=1, seed=5), n_sweeps=8)
     m, sd = dg.belief_stats(R.Pose2)
     e = rms(m.cpu().numpy()[:, :2])
-    assert e_param < 0.3 and e < 1.3 * e_param + 0.05 and e < 0.5 * e_init, (e_init, e_param, e)
+    assert e_param < 0.5 and e < 1.3 * e_param + 0.05 and e < 0.5 * e_init, (e_init, e_param, e)
     assert (sd.cpu().numpy() > 0).all()
