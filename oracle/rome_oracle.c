@@ -637,17 +637,14 @@ static int br_newton(const double z[2], const double* fx, int dir, double* t, in
       double qx = nn * cos(a), qy = nn * sin(a);
       t[0] = fx[0] + c * qx - s * qy; t[1] = fx[1] + s * qx + c * qy;
     } else {
-      /* minimum-norm Gauss-Newton step δ = -Jᵀ (J Jᵀ)⁻¹ r for the 2-eq / 3-unknown pose direction */
-      double s = sin(t[2]), c = cos(t[2]);
+      /* under-determined (2 eq / 3 unknowns): exact block step that keeps the ray landmark->pose --
+       * move along the ray to the measured range, then rotate to the measured bearing (for ranges >> 1 this is
+       * the minimum-norm Gauss-Newton step, which spends the bearing error on the heading) */
       double dx = fx[0] - t[0], dy = fx[1] - t[1];
-      double plx = c * dx + s * dy, ply = -s * dx + c * dy;
-      double n2 = plx * plx + ply * ply, n = sqrt(n2);
-      if (n < 1e-300) { t[0] += 1e-6; continue; }
-      double y0 = -r[0] / (1.0 / n2 + 1.0), y1 = -r[1];
-      double ax = ply * y0 / n2 - plx * y1 / n;   /* Aᵀ y */
-      double ay = -plx * y0 / n2 - ply * y1 / n;
-      /* δt = -R Aᵀ y ; δθ = y0 */
-      t[0] += -(c * ax - s * ay); t[1] += -(s * ax + c * ay); t[2] += y0;
+      double n = sqrt(dx * dx + dy * dy);
+      double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
+      t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy;
+      t[2] = atan2(uy, ux) - z[0];
     }
   }
   return 1;

@@ -265,14 +265,12 @@ struct BR {
           const Se2 P = se2_from_coords(t[0], t[1], t[2]);
           residual_bearingrange(z[0], z[1], P, fx[0], fx[1], r);
           if (fmax(fabs(r[0]), fabs(r[1])) <= tol) { st = 0; break; }
+          // under-determined (2 eq / 3 unknowns): exact block step that keeps the ray landmark->pose: move along
+          // the ray to the measured range, then rotate to the measured bearing
           const double dx = fx[0] - t[0], dy = fx[1] - t[1];
-          const double plx = P.c * dx + P.s * dy, ply = -P.s * dx + P.c * dy;
-          const double n2 = plx * plx + ply * ply, n = sqrt(n2);
-          if (n < 1e-300) { t[0] += 1e-6; continue; }
-          const double y0 = -r[0] / (1.0 / n2 + 1.0), y1 = -r[1];
-          const double ax = ply * y0 / n2 - plx * y1 / n;
-          const double ay = -plx * y0 / n2 - ply * y1 / n;
-          t[0] += -(P.c * ax - P.s * ay); t[1] += -(P.s * ax + P.c * ay); t[2] += y0;
+          const double n = fast_sqrt(dx * dx + dy * dy);
+          const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
+          t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = atan2(uy, ux) - z[0];
         }
       }
     } else {

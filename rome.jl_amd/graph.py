@@ -265,6 +265,64 @@ def synth_helix3d(P=10000, N=100, seed=0x524F4D45, radius=10.0, per_turn=20, pit
     return fg
 
 
+def synth_mit_br(P=808, n_landmarks=120, N=100, seed=0x524F4D45, step=2.0):
+    """BASELINE.json configs[2] stand-in (the shipped MIT.g2o has no landmarks): a P-pose planar
+    random walk (steps ≈ 2 m, MIT.g2o odometry statistics σ ≈ (0.75, 0.61, 0.053) scaled down 5x so the walk
+    stays informative) plus landmarks, each sighted by the 2-4 nearest poses with Pose2Point2BearingRange
+    (σ_b = 0.03, σ_ρ = 0.5 as in src/canonical/GenerateHoneycomb.jl:69)."""
+    rng = np.random.default_rng(seed)
+    gt = np.zeros((P, 3))
+    for k in range(1, P):
+        dth = rng.choice([0.0, 0.0, 0.0, np.pi / 2, -np.pi / 2]) + 0.05 * rng.standard_normal()
+        gt[k] = se2_compose(gt[k - 1], np.array([step, 0.0, dth]))
+        if np.hypot(gt[k, 0], gt[k, 1]) > 60:   # steer back towards the origin
+            gt[k, 2] = np.arctan2(-gt[k, 1], -gt[k, 0]) + 0.3 * rng.standard_normal()
+    gt[:, 2] = np.arctan2(np.sin(gt[:, 2]), np.cos(gt[:, 2]))
+    fg = initfg(N)
+    fg.addVariable("x0", Pose2)
+    fg.addFactor(["x0"], PriorPose2(MvNormal(gt[0], np.diag(np.square([0.1, 0.1, 0.05])))))
+    cov = np.diag(np.square([0.15, 0.12, 0.0106]))
+    Lc = np.linalg.cholesky(cov)
+    for k in range(1, P):
+        fg.addVariable("x%d" % k, Pose2)
+        fg.addFactor(["x%d" % (k - 1), "x%d" % k], Pose2Pose2(MvNormal(se2_between(gt[k - 1], gt[k]) + Lc @ rng.standard_normal(3), cov)))
+    lm = gt[rng.choice(P, n_landmarks, replace=False), :2] + rng.uniform(-8, 8, (n_landmarks, 2))
+    truth = {"x%d" % k: gt[k] for k in range(P)}
+    for j in range(n_landmarks):
+        d = np.hypot(gt[:, 0] - lm[j, 0], gt[:, 1] - lm[j, 1])
+        d[d < 3.0] = np.inf                      # keep sightings ≥ 6 σ_ρ away: a sampled range must stay positive
+        near = np.argsort(d)[:rng.integers(2, 5)]
+        fg.addVariable("l%d" % j, Point2)
+        truth["l%d" % j] = lm[j]
+        for k in sorted(near):
+            dx, dy = lm[j] - gt[k, :2]
+            b = np.arctan2(dy, dx) - gt[k, 2] + 0.03 * rng.standard_normal()
+            r = np.hypot(dx, dy) + 0.5 * rng.standard_normal()
+            fg.addFactor(["x%d" % k, "l%d" % j], Pose2Point2BearingRange(Normal(np.arctan2(np.sin(b), np.cos(b)), 0.03), Normal(max(r, 0.1), 0.5)))
+    fg.ground_truth = truth
+    return fg
+
+
+def dead_reckon_init_pose3(fg, seed=1, sigma=(0.1, 0.1, 0.1, 0.01, 0.01, 0.01)):
+    """Pose3 counterpart of dead_reckon_init: prior mean composed along the first incoming Pose3Pose3."""
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(seed)
+    mean = {}
+    for _, labels, f in fg.factors:
+        if isinstance(f, PriorPose3):
+            mean[labels[0]] = f.Z.mu.copy()
+    for _, labels, f in fg.factors:
+        if isinstance(f, Pose3Pose3) and labels[0] in mean and labels[1] not in mean:
+            a = mean[labels[0]]
+            Ra = Rot.from_rotvec(a[3:])
+            mean[labels[1]] = np.concatenate([a[:3] + Ra.apply(f.Z.mu[:3]), (Ra * Rot.from_rotvec(f.Z.mu[3:])).as_rotvec()])
+    for l, t in fg.variables.items():
+        if t is Pose3:
+            m = mean.get(l, np.zeros(6))
+            fg.initVariable(l, m[:, None] + np.asarray(sigma)[:, None] * rng.standard_normal((6, fg.N)))
+    return fg
+
+
 # ------------------------------------------------------------------------------------------ packing
 class PackedGraph:
     """Flat tables for the device sweep.  Variables are numbered per type in insertion order."""
