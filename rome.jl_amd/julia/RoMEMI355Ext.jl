@@ -108,9 +108,58 @@ function approxConvBelief(dfg::AbstractDFG, fc::DFGFactor{<:CommonConvWrapper{<:
   return manikde!(getManifold(getVariableType(dfg, target)), pts)
 end
 
-# Pose3Pose3 / PriorPose2 / PriorPose3 follow the same pattern with rome_conv_pose3pose3,
-# rome_sample_priorpose2 and rome_sample_priorpose3 (coordinates (t, ω) via
-# get_coordinates(M, ϵ, log(M, ϵ, p), DefaultOrthogonalBasis())).
+# ---- Pose3Pose3: coordinates (t, ω) = get_coordinates(M, ϵ, log(M, ϵ, p), DefaultOrthogonalBasis()) ----------
+const M3 = getManifold(Pose3)
+coords(::Type{Pose3}, pts) = reduce(hcat, [get_coordinates(M3, getPointIdentity(M3), log(M3, getPointIdentity(M3), p), DefaultOrthogonalBasis()) for p in pts])
+points(::Type{Pose3}, C) = [getPoint(Pose3, C[:, i]) for i in axes(C, 2)]
+
+function conv_pose3pose3(fg, f::Pose3Pose3, fixedpts, u0pts, dir::Integer; solver=1)
+  o = default_opts(fg; solver)
+  μ = collect(Float64, mean(f.Z)); Σ = collect(Float64, cov(f.Z))'
+  fixed = coords(Pose3, fixedpts); target = coords(Pose3, u0pts)
+  d = Int32[dir]
+  GC.@preserve μ Σ fixed target d begin
+    check(ccall((:rome_conv_pose3pose3, LIB), Cint,
+      (Ptr{Cvoid}, Ref{RomeOpts}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+      ctx().h, o, 1, d, μ, Σ, fixed, C_NULL, target, C_NULL))
+  end
+  points(Pose3, target)
+end
+
+function approxConvBelief(dfg::AbstractDFG, fc::DFGFactor{<:CommonConvWrapper{<:Pose3Pose3}}, target::Symbol,
+                          measurement::AbstractVector=Tuple[]; solveKey::Symbol=:default, kw...)
+  vars = getVariableOrder(fc)
+  dir = vars[2] == target ? 0 : 1
+  other = dir == 0 ? vars[1] : vars[2]
+  pts = conv_pose3pose3(dfg, getFactorType(fc), getVal(dfg, other; solveKey), getVal(dfg, target; solveKey), dir)
+  return manikde!(M3, pts)
+end
+
+# ---- priors: N samples of the prior as points (IIF samplePoint) ------------------------------------------------
+function sample_prior(fg, f::Union{PriorPose2,PriorPose3})
+  T, sym, d = f isa PriorPose2 ? (Pose2, :rome_sample_priorpose2, 3) : (Pose3, :rome_sample_priorpose3, 6)
+  o = default_opts(fg)
+  μ = collect(Float64, mean(f.Z)); Σ = collect(Float64, cov(f.Z))'
+  out = Matrix{Float64}(undef, d, Int(o.n_particles))
+  GC.@preserve μ Σ out begin
+    check(ccall((sym, LIB), Cint, (Ptr{Cvoid}, Ref{RomeOpts}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                ctx().h, o, 1, μ, Σ, C_NULL, out))
+  end
+  points(T, out)
+end
+
+# ---- parametric path: batched whitened residuals + Jacobians (rome_linearize) ------------------------------
+# kind: 0 PriorPose2, 1 Pose2Pose2, 2 Pose2Point2BearingRange, 3 PriorPoint2, 4 Pose3Pose3, 5 PriorPose3
+function linearize(kind::Integer, μ::Matrix{Float64}, W::Array{Float64,3}, xa::Matrix{Float64}, xb::Union{Nothing,Matrix{Float64}})
+  dz, dr, da, db = ((3,3,3,0), (3,3,3,3), (2,2,3,2), (2,2,2,0), (6,6,6,6), (6,6,6,0))[kind + 1]
+  F = size(μ, 2)                                  # columns = factors (column-major == row-major F x d on the C side)
+  r = Matrix{Float64}(undef, dr, F); Ja = Array{Float64}(undef, da, dr, F)
+  Jb = db > 0 ? Array{Float64}(undef, db, dr, F) : nothing
+  check(ccall((:rome_linearize, LIB), Cint,
+    (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+    ctx().h, kind, F, μ, W, xa, xb === nothing ? C_NULL : xb, r, Ja, Jb === nothing ? C_NULL : Jb))
+  r, Ja, Jb                                       # Ja[:, :, f] is the TRANSPOSE of factor f's row-major dr x da block
+end
 
 # ---- residual KATs through the library (mirrors calcFactorResidualTemporary) ---------------------------
 function residual_pose2pose2(z::AbstractMatrix, p::AbstractMatrix, q::AbstractMatrix)   # 3 x n each
