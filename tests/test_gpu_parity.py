@@ -326,3 +326,31 @@ def test_manhattan_sweep_device_vs_oracle_and_properties():
     # closed-form and Newton agree everywhere
     prop0 = dg.sweep_pose2pose2(R.make_opts(N=100, solver=0, seed=2024)).cpu().numpy()
     assert np.abs(wrapdiff(prop0, prop_h, [2])).max() < 1e-9
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The C ABI driven by a plain-C program (no Python, no torch): what the Julia ccall shim sees."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.check_call(["gcc", os.path.join(root, "tests", "c", "abi_smoke.c"), "-I" + os.path.join(root, "include"),
+                           "-L" + os.path.join(root, "rome.jl_amd"), "-lrome_mi355", "-lm",
+                           "-Wl,-rpath," + os.path.join(root, "rome.jl_amd"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "abi_smoke ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_hipgraph_capture_replays_the_sweep():
+    """DeviceGraph.capture: a captured single-launch sweep replays bit-identically (launch-bound loops)."""
+    import torch
+    fg = R.generateGraph_Hexagonal(N=100); R.dead_reckon_init(fg, seed=1)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    o = R.make_opts(N=100, solver=1, seed=3)
+    out_eager = dg.sweep_pose2pose2(o).clone()
+    out = torch.zeros_like(out_eager)
+    plan = dg.plan_sweep_pose2pose2(o, out)
+    g = dg.capture(plan)
+    out.zero_(); g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out, out_eager)
+    out.zero_(); g.replay(); g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out, out_eager)
