@@ -438,9 +438,12 @@ struct P3P3 {
 #define ROME_MIN_WAVES 1
 #endif
 template <class FP, int SOLVER, int PPL>
-__global__ void __launch_bounds__(256, ROME_MIN_WAVES) k_conv(const ConvArgs a) {
+#ifndef ROME_WPB
+#define ROME_WPB 4   // wavefronts (= convolutions) per workgroup
+#endif
+__global__ void __launch_bounds__(64 * ROME_WPB, ROME_MIN_WAVES) k_conv(const ConvArgs a) {
   const int lane = threadIdx.x & 63;
-  const int c = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (int)(threadIdx.x >> 6));
+  const int c = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * ROME_WPB + (int)(threadIdx.x >> 6));
   if (c >= a.n_conv) return;
   const int N = a.N;
   const int f = a.factor ? a.factor[c] : c;
@@ -636,11 +639,11 @@ __global__ void k_residual_priorpose3(int n, const double* m, const double* p, d
 // ------------------------------------------------------------------------------------------
 template <class FP, int SOLVER>
 static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
-  const int nb = (a.n_conv + 3) / 4;
+  const int nb = (a.n_conv + ROME_WPB - 1) / ROME_WPB;
   if (nb == 0) return hipSuccess;
-  if (a.N <= 64)       hipLaunchKernelGGL((k_conv<FP, SOLVER, 1>), dim3(nb), dim3(256), 0, s, a);
-  else if (a.N <= 128) hipLaunchKernelGGL((k_conv<FP, SOLVER, 2>), dim3(nb), dim3(256), 0, s, a);
-  else if (a.N <= 256) hipLaunchKernelGGL((k_conv<FP, SOLVER, 4>), dim3(nb), dim3(256), 0, s, a);
+  if (a.N <= 64)       hipLaunchKernelGGL((k_conv<FP, SOLVER, 1>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  else if (a.N <= 128) hipLaunchKernelGGL((k_conv<FP, SOLVER, 2>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  else if (a.N <= 256) hipLaunchKernelGGL((k_conv<FP, SOLVER, 4>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

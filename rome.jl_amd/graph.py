@@ -373,6 +373,28 @@ class PackedGraph:
         self.prior3 = prior_tables(pr3, 6)
         self.priorpt2 = prior_tables(prpt, 2)   # parametric path only (no sweep kernel row yet)
 
+    @classmethod
+    def from_pose2_tables(cls, N, n_poses, mu, cov, var_from, var_to, prior_mu=None, prior_cov=None, prior_var=None):
+        """Packed graph of a Pose2 / Pose2Pose2 / PriorPose2 problem straight from arrays (no per-factor Python
+        objects): what a bulk loader hands over for the 2^16 / 2^20-factor scaling sets of SURVEY §8(d)-6."""
+        self = cls.__new__(cls)
+        self.N = int(N)
+        self.labels = {Pose2: ["x%d" % k for k in range(n_poses)], Point2: [], Pose3: []}
+        self.index = {}   # labels -> index is the identity here; not materialised for large graphs
+        F = len(var_from)
+        self.p2p2 = dict(F=F, mu=np.asarray(mu, dtype=np.float64).reshape(F, 3), cov=np.asarray(cov, dtype=np.float64).reshape(F, 3, 3),
+                         var_from=np.asarray(var_from, dtype=np.int32), var_to=np.asarray(var_to, dtype=np.int32), labels=[])
+        e3 = dict(F=0, mu=np.zeros((0, 6)), cov=np.zeros((0, 6, 6)), var_from=np.zeros(0, np.int32), var_to=np.zeros(0, np.int32), labels=[])
+        self.p3p3 = e3
+        self.br = dict(F=0, mu=np.zeros((0, 2)), sigma=np.zeros((0, 2)), pose=np.zeros(0, np.int32), point=np.zeros(0, np.int32), labels=[])
+        P = 0 if prior_var is None else len(prior_var)
+        self.prior2 = dict(F=P, mu=np.asarray(prior_mu if P else np.zeros((0, 3)), dtype=np.float64).reshape(P, 3),
+                           cov=np.asarray(prior_cov if P else np.zeros((0, 3, 3)), dtype=np.float64).reshape(P, 3, 3),
+                           var=np.asarray(prior_var if P else np.zeros(0), dtype=np.int32), labels=[])
+        self.prior3 = dict(F=0, mu=np.zeros((0, 6)), cov=np.zeros((0, 6, 6)), var=np.zeros(0, np.int32), labels=[])
+        self.priorpt2 = dict(F=0, mu=np.zeros((0, 2)), cov=np.zeros((0, 2, 2)), var=np.zeros(0, np.int32), labels=[])
+        return self
+
     @staticmethod
     def conv_table(tab):
         """Both directions of every relative factor, interleaved in factor order:
@@ -392,6 +414,33 @@ class PackedGraph:
         for k, l in enumerate(ls):
             out[k] = fg.vals[l]
         return out
+
+
+def synth_pose2_tables(n_factors, seed=0x524F4D45, loop_fraction=0.358, N=100):
+    """Vectorised g2o-shaped Pose2Pose2 problem with `n_factors` edges in Manhattan proportions (SURVEY Appendix D:
+    64 % odometry, 36 % closures with spans ~ median 64): -> (PackedGraph, initial beliefs [P,3,N]).  Geometry is a
+    unit-step walk; the tables are what the scaling runs F ∈ {2^16, 2^20} sweep over."""
+    rng = np.random.default_rng(seed)
+    n_loops = int(round(n_factors * loop_fraction))
+    P = n_factors - n_loops + 1
+    turn = rng.choice([0.0, np.pi / 2, -np.pi / 2], size=P, p=[0.7, 0.15, 0.15]); turn[0] = 0.0
+    th = np.cumsum(turn)
+    pos = np.concatenate([[[0.0, 0.0]], np.cumsum(np.stack([np.cos(th[1:]), np.sin(th[1:])], 1), axis=0)])
+    gt = np.column_stack([pos, np.arctan2(np.sin(th), np.cos(th))])
+    i_od = np.arange(P - 1); j_od = i_od + 1
+    span = np.minimum(np.maximum(4, rng.lognormal(np.log(64), 1.0, n_loops).astype(np.int64)), P - 1)
+    i_lc = rng.integers(0, P - span); j_lc = i_lc + span
+    vf = np.concatenate([i_od, i_lc]).astype(np.int32); vt = np.concatenate([j_od, j_lc]).astype(np.int32)
+    c, s_ = np.cos(gt[vf, 2]), np.sin(gt[vf, 2])
+    d = gt[vt, :2] - gt[vf, :2]
+    rel = np.column_stack([c * d[:, 0] + s_ * d[:, 1], -s_ * d[:, 0] + c * d[:, 1], np.arctan2(np.sin(gt[vt, 2] - gt[vf, 2]), np.cos(gt[vt, 2] - gt[vf, 2]))])
+    sig = np.where((np.arange(n_factors) < P - 1)[:, None], [[0.15, 0.05, 0.0102]], [[0.076, 0.049, 0.0258]])
+    mu = rel + sig * rng.standard_normal((n_factors, 3))
+    cov = np.zeros((n_factors, 3, 3)); cov[:, 0, 0] = sig[:, 0] ** 2; cov[:, 1, 1] = sig[:, 1] ** 2; cov[:, 2, 2] = sig[:, 2] ** 2
+    cov[:, 0, 1] = cov[:, 1, 0] = 0.1 * sig[:, 0] * sig[:, 1]
+    pk = PackedGraph.from_pose2_tables(N, P, mu, cov, vf, vt, prior_mu=[[0, 0, 0]], prior_cov=[np.diag([0.01, 0.01, 0.0025])], prior_var=[0])
+    bel = gt[:, :, None] + np.array([0.1, 0.1, 0.05])[None, :, None] * rng.standard_normal((P, 3, N))
+    return pk, bel
 
 
 def dead_reckon_init(fg, seed=1, sigma=(0.1, 0.1, 0.05)):
