@@ -73,6 +73,7 @@ typedef struct rome_opts {
   uint64_t stream_offset; /* Philox stream of convolution c = stream_offset + c  (global conv id when sharded) */
   int32_t layout;         /* host-pointer entry points only: ROME_LAYOUT_*                             */
   int32_t reserved;
+  double  spread_nh;      /* IIF spreadNH (default 3.0): entropy scale for particles of the other hypothesis (multihypo) */
 } rome_opts;
 
 typedef struct rome_ctx rome_ctx; /* opaque: device id, HIP stream, staging buffers */
@@ -135,6 +136,14 @@ int rome_conv_pose2point2br(rome_ctx*, const rome_opts*, int32_t C, int32_t dir,
                             const double* mu /*C*2*/, const double* sigma /*C*2*/,
                             const double* fixed, const double* noise /*C*N*2 or NULL*/,
                             double* target_inout, int32_t* status);
+/* same with IIF `multihypo=[1, w, 1-w]` over two landmark candidates (addFactor!(fg, [:x0;:l1;:l2], p2br,
+ * multihypo=[1.0;0.5;0.5]), test/testMultimodalRangeBearing.jl:53): `alt` holds C blocks of the OTHER landmark's
+ * particles, hypo_w[c] the probability of the primary one.  dir 1: per particle the fixed landmark is drawn from
+ * (primary, alt); dir 0: target_inout is the primary landmark, particles drawn for `alt` only get spreadNH entropy. */
+int rome_conv_pose2point2br_mh(rome_ctx*, const rome_opts*, int32_t C, int32_t dir,
+                               const double* mu /*C*2*/, const double* sigma /*C*2*/,
+                               const double* fixed, const double* alt /*C*N*2*/, const double* hypo_w /*C*/,
+                               const double* noise /*C*N*2 or NULL*/, double* target_inout, int32_t* status);
 int rome_conv_pose3pose3(rome_ctx*, const rome_opts*, int32_t C, const int32_t* dir,
                          const double* mu /*C*6*/, const double* cov /*C*36*/,
                          const double* fixed /*C*N*6*/, const double* noise /*C*N*6 or NULL*/,
@@ -171,6 +180,11 @@ typedef struct rome_conv_dev {
   int32_t mirror_row[4];
   int32_t reserved;
   double* mirror_out;
+  /* optional, bearing-range only: `multihypo=[1, w, 1-w]` over two landmark candidates (IIF addFactor! kwarg,
+   * test/testMultimodalRangeBearing.jl:53).  alt_var[c] = block of the OTHER landmark (-1: ordinary row),
+   * hypo_w[c] = probability that the row's own landmark (fixed_var for dir 1, target_var for dir 0) is the sighted one. */
+  const int32_t* alt_var;
+  const double* hypo_w;
 } rome_conv_dev;
 
 int rome_conv_pose2pose2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);

@@ -184,14 +184,17 @@ def conv_pose2pose2(opts, mu, L, bel, fixed_var, target_var, dirs, factor=None, 
 
 
 def conv_pose2point2br(opts, direction, mu, sigma, bel_fixed, bel_target, fixed_var, target_var, factor=None,
-                       noise=None, want_status=False):
+                       noise=None, want_status=False, alt_var=None, hypo_w=None, spread_nh=3.0):
     mu, pmu = _d(mu); sg, psg = _d(sigma); bf, pbf = _d(bel_fixed); bt, pbt = _d(bel_target)
     fv, pfv = _i(fixed_var); tv, ptv = _i(target_var); fa, pfa = _i(factor)
     Cn = len(fv); N = opts.n_particles; dt = 2 if direction == 0 else 3
     nz, pn = (None, None) if noise is None else _d(noise)
     out = np.zeros((Cn, dt, N)); st = np.zeros((Cn, N), dtype=np.int32)
-    rc = lib().ro_conv_pose2point2br(C.byref(opts), Cn, pfa, int(direction), pfv, ptv, pmu, psg, pbf, pbt, pn,
-                                     out.ctypes.data_as(C.POINTER(C.c_double)), st.ctypes.data_as(C.POINTER(C.c_int32)))
+    av, pav = _i(alt_var)
+    hw, phw = (None, None) if hypo_w is None else _d(hypo_w)
+    rc = lib().ro_conv_pose2point2br_mh(C.byref(opts), Cn, pfa, int(direction), pfv, ptv, pmu, psg, pbf, pbt, pn,
+                                        out.ctypes.data_as(C.POINTER(C.c_double)), st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        pav, phw, C.c_double(spread_nh))
     assert rc == 0
     return (out, st) if want_status else out
 

@@ -662,11 +662,32 @@ static void br_closed(const double z[2], const double* fx, int dir, double* t) {
   }
 }
 
+/* multihypo (⚠IIF computeAcrossHypothesis!, `multihypo=[1, w, 1-w]` over two landmark candidates,
+ * test/testMultimodalRangeBearing.jl:53): alt_var[c] = the other landmark (-1 none), hypo_w[c] = probability of
+ * the row's own landmark.  Per particle a categorical draw (Philox domain 4, word 0) picks the hypothesis.
+ * dir 1: the fixed landmark particle is taken from the drawn landmark.  dir 0: particles of the other hypothesis
+ * are not solved; after the cycles they receive entropy spread_nh · ‖mean(target) - mean(alt)‖ · (U-½)
+ * (words 1,2 of the same call).  Unpinned by the reference; definition shared with the HIP path. */
+int ro_conv_pose2point2br_mh(const ro_opts* o, int C, const int32_t* factor, int dir,
+                             const int32_t* fixed_var, const int32_t* target_var,
+                             const double* mu, const double* sigma,
+                             const double* bel_fixed, const double* bel_target,
+                             const double* noise, double* out, int32_t* status,
+                             const int32_t* alt_var, const double* hypo_w, double spread_nh);
 int ro_conv_pose2point2br(const ro_opts* o, int C, const int32_t* factor, int dir,
                           const int32_t* fixed_var, const int32_t* target_var,
                           const double* mu, const double* sigma,
                           const double* bel_fixed, const double* bel_target,
                           const double* noise, double* out, int32_t* status) {
+  return ro_conv_pose2point2br_mh(o, C, factor, dir, fixed_var, target_var, mu, sigma, bel_fixed, bel_target, noise, out, status,
+                                  NULL, NULL, 3.0);
+}
+int ro_conv_pose2point2br_mh(const ro_opts* o, int C, const int32_t* factor, int dir,
+                             const int32_t* fixed_var, const int32_t* target_var,
+                             const double* mu, const double* sigma,
+                             const double* bel_fixed, const double* bel_target,
+                             const double* noise, double* out, int32_t* status,
+                             const int32_t* alt_var, const double* hypo_w, double spread_nh) {
   const int N = o->n_particles;
   const int df = dir == 0 ? 3 : 2, dt = dir == 0 ? 2 : 3;
   int cycles = o->inflate_cycles < 1 ? 1 : o->inflate_cycles;
@@ -677,6 +698,21 @@ int ro_conv_pose2point2br(const ro_opts* o, int C, const int32_t* factor, int di
     const double* tb = bel_target + (size_t)get_idx(target_var, c) * dt * N;
     double* ob = out + (size_t)c * dt * N;
     double* zs = (double*)malloc(sizeof(double) * 2 * N);
+    const int av = (alt_var && hypo_w) ? alt_var[c] : -1;
+    unsigned char* sel = (unsigned char*)malloc(N);
+    double* nhu = (double*)malloc(sizeof(double) * 2 * N);
+    const double* ab = av >= 0 ? ((dir == 1 ? bel_fixed : bel_target) + (size_t)av * (dir == 1 ? df : dt) * N) : NULL;
+    for (int i = 0; i < N; ++i) {
+      sel[i] = 1;
+      if (av >= 0) {
+        uint32_t key[2] = {(uint32_t)o->seed, (uint32_t)(o->seed >> 32)};
+        uint64_t stq = o->stream_offset + (uint64_t)c;
+        uint32_t ctr[4] = {(uint32_t)i, (uint32_t)stq, (uint32_t)(stq >> 32), (4u << 16)}, w4[4];
+        ro_philox4x32_10(ctr, key, w4);
+        sel[i] = (((double)w4[0] + 0.5) * (1.0 / 4294967296.0)) < hypo_w[c];
+        nhu[2 * i] = ((double)w4[1] + 0.5) * (1.0 / 4294967296.0); nhu[2 * i + 1] = ((double)w4[2] + 0.5) * (1.0 / 4294967296.0);
+      }
+    }
     for (int i = 0; i < N; ++i) {
       double xi[2];
       if (noise) { xi[0] = noise[(size_t)c * 2 * N + i]; xi[1] = noise[(size_t)c * 2 * N + N + i]; }
@@ -696,7 +732,8 @@ int ro_conv_pose2point2br(const ro_opts* o, int C, const int32_t* factor, int di
       }
       for (int i = 0; i < N; ++i) {
         double fx[3] = {0, 0, 0}, t[3] = {0, 0, 0};
-        for (int k = 0; k < df; ++k) fx[k] = fb[k * N + i];
+        if (dir == 0 && !sel[i]) continue;                       /* other hypothesis: not constrained by this factor */
+        for (int k = 0; k < df; ++k) fx[k] = (dir == 1 && !sel[i]) ? ab[k * N + i] : fb[k * N + i];
         for (int k = 0; k < dt; ++k) t[k] = ob[k * N + i];
         if (spread > 0.0) {
           double u[3];
@@ -717,7 +754,17 @@ int ro_conv_pose2point2br(const ro_opts* o, int C, const int32_t* factor, int di
         if (status && st) status[(size_t)c * N + i] = st;
       }
     }
-    free(zs);
+    if (av >= 0 && dir == 0) {
+      /* means use the ORIGINAL target belief (start points) and the alternative landmark's belief */
+      double mx = 0, my = 0, ax = 0, ay = 0;
+      for (int i = 0; i < N; ++i) { mx += tb[i]; my += tb[N + i]; ax += ab[i]; ay += ab[N + i]; }
+      double dxm = (mx - ax) / N, dym = (my - ay) / N;
+      double nh = spread_nh * sqrt(dxm * dxm + dym * dym);
+      for (int i = 0; i < N; ++i) if (!sel[i]) {
+        ob[i] += nh * (nhu[2 * i] - 0.5); ob[N + i] += nh * (nhu[2 * i + 1] - 0.5);
+      }
+    }
+    free(zs); free(sel); free(nhu);
   }
   return 0;
 }

@@ -91,6 +91,12 @@ int ro_conv_pose2point2br(const ro_opts* o, int C, const int32_t* factor, int di
                           const double* bel_fixed /*dir0: poses [V][3][N]; dir1: points [V][2][N]*/,
                           const double* bel_target /*dir0: points; dir1: poses*/,
                           const double* noise, double* out, int32_t* status);
+int ro_conv_pose2point2br_mh(const ro_opts* o, int C, const int32_t* factor, int dir,
+                             const int32_t* fixed_var, const int32_t* target_var,
+                             const double* mu, const double* sigma,
+                             const double* bel_fixed, const double* bel_target,
+                             const double* noise, double* out, int32_t* status,
+                             const int32_t* alt_var /*[C] or NULL*/, const double* hypo_w /*[C]*/, double spread_nh);
 int ro_sample_priorpose2(const ro_opts* o, int C, const int32_t* factor,
                          const double* mu, const double* L, const double* noise, double* out /*[C][3][N]*/);
 int ro_conv_pose3pose3(const ro_opts* o, int C, const int32_t* factor, const int32_t* dir,

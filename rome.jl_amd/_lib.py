@@ -27,7 +27,7 @@ class Opts(C.Structure):
     _fields_ = [("n_particles", C.c_int32), ("solver", C.c_int32), ("max_iters", C.c_int32),
                 ("inflate_cycles", C.c_int32), ("tol", C.c_double), ("inflation", C.c_double),
                 ("seed", C.c_uint64), ("stream_offset", C.c_uint64), ("layout", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("spread_nh", C.c_double)]
 
 
 class ConvDev(C.Structure):
@@ -35,7 +35,8 @@ class ConvDev(C.Structure):
                 ("factor", C.c_void_p), ("dir", C.c_void_p), ("fixed_var", C.c_void_p), ("target_var", C.c_void_p),
                 ("mu", C.c_void_p), ("L", C.c_void_p), ("bel_fixed", C.c_void_p), ("bel_target", C.c_void_p),
                 ("noise", C.c_void_p), ("out", C.c_void_p), ("status", C.c_void_p),
-                ("n_mirror", C.c_int32), ("mirror_row", C.c_int32 * 4), ("reserved", C.c_int32), ("mirror_out", C.c_void_p)]
+                ("n_mirror", C.c_int32), ("mirror_row", C.c_int32 * 4), ("reserved", C.c_int32), ("mirror_out", C.c_void_p),
+                ("alt_var", C.c_void_p), ("hypo_w", C.c_void_p)]
 
 
 _PD = C.POINTER(C.c_double)
@@ -67,6 +68,7 @@ SIGNATURES = {
     "rome_residual_priorpose3": (C.c_int, [_CTX, C.c_int32, _PD, _PD, _PD]),
     "rome_conv_pose2pose2": (C.c_int, [_CTX, _PO, C.c_int32, _PI, _PD, _PD, _PD, _PD, _PD, _PI]),
     "rome_conv_pose2point2br": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PI]),
+    "rome_conv_pose2point2br_mh": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PI]),
     "rome_conv_pose3pose3": (C.c_int, [_CTX, _PO, C.c_int32, _PI, _PD, _PD, _PD, _PD, _PD, _PI]),
     "rome_sample_priorpose2": (C.c_int, [_CTX, _PO, C.c_int32, _PD, _PD, _PD, _PD]),
     "rome_sample_priorpose3": (C.c_int, [_CTX, _PO, C.c_int32, _PD, _PD, _PD, _PD]),

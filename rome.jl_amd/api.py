@@ -198,7 +198,9 @@ def conv_pose2pose2(opts, mu, cov, fixed, target, dirs=None, noise=None, want_st
     return (out, st) if want_status else out
 
 
-def conv_pose2point2br(opts, direction, mu, sigma, fixed, target, noise=None, want_status=False, ctx=None):
+def conv_pose2point2br(opts, direction, mu, sigma, fixed, target, noise=None, want_status=False, ctx=None,
+                       alt=None, hypo_w=None):
+    """alt / hypo_w: multihypo over two landmark candidates (blocks of the other landmark, P(primary))."""
     ctx = ctx or default_context()
     mu = np.atleast_2d(_d(mu)); C_ = mu.shape[0]; N = opts.n_particles
     sigma = _d(sigma, (C_, 2))
@@ -207,8 +209,13 @@ def conv_pose2point2br(opts, direction, mu, sigma, fixed, target, noise=None, wa
     out = _blocks(target, C_, N, dt, opts.layout).copy()
     noise = None if noise is None else _blocks(noise, C_, N, 2, opts.layout)
     st = np.zeros((C_, N), dtype=np.int32) if want_status else None
-    _lib.check(_lib.load().rome_conv_pose2point2br(ctx.handle, C.byref(opts), C_, int(direction), _p(mu), _p(sigma),
-                                                  _p(fixed), _p(noise), _p(out), _pi(st)), ctx.handle)
+    if alt is None:
+        _lib.check(_lib.load().rome_conv_pose2point2br(ctx.handle, C.byref(opts), C_, int(direction), _p(mu), _p(sigma),
+                                                      _p(fixed), _p(noise), _p(out), _pi(st)), ctx.handle)
+    else:
+        alt = _blocks(alt, C_, N, 2, opts.layout); hypo_w = _d(hypo_w, (C_,))
+        _lib.check(_lib.load().rome_conv_pose2point2br_mh(ctx.handle, C.byref(opts), C_, int(direction), _p(mu), _p(sigma),
+                                                         _p(fixed), _p(alt), _p(hypo_w), _p(noise), _p(out), _pi(st)), ctx.handle)
     return (out, st) if want_status else out
 
 

@@ -17,6 +17,17 @@ def approxConv(fg, flabel, target, solver=_lib.SOLVER_NEWTON, seed=None, ctx=Non
         return api.sample_priorpose2(opts, [f.Z.mu], [f.Z.cov], ctx=ctx)[0]
     if isinstance(f, PriorPose3):
         return api.sample_priorpose3(opts, [f.Z.mu], [f.Z.cov], ctx=ctx)[0]
+    mh = fg.multihypo.get(flabel)
+    if mh is not None:   # Pose2Point2BearingRange over [pose, l1, l2]
+        pose, l1, l2 = labels
+        opts.layout = _lib.LAYOUT_SOA
+        z2 = lambda l: fg.getVal(l)[None] if fg.isInitialized(l) else np.zeros((1, 2, fg.N))
+        args = ([[f.bearing.mu, f.range.mu]], [[f.bearing.sigma, f.range.sigma]])
+        if target == pose:
+            u0 = fg.getVal(pose)[None] if fg.isInitialized(pose) else np.zeros((1, 3, fg.N))
+            return api.conv_pose2point2br(opts, 1, *args, z2(l1), u0, alt=z2(l2), hypo_w=[mh[0]], ctx=ctx)[0]
+        prim, alt, w = (l1, l2, mh[0]) if target == l1 else (l2, l1, mh[1])
+        return api.conv_pose2point2br(opts, 0, *args, fg.getVal(pose)[None], z2(prim), alt=z2(alt), hypo_w=[w], ctx=ctx)[0]
     direction = 0 if labels[1] == target else 1
     other = labels[0] if direction == 0 else labels[1]
     if not fg.isInitialized(other):

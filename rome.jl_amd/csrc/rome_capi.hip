@@ -50,7 +50,7 @@ int check_opts(const rome_opts* o) {
   if (o->n_particles > ROME_MAX_PARTICLES) return ROME_ERR_UNSUPPORTED_N;
   if (o->solver < ROME_SOLVER_CLOSED_FORM || o->solver > ROME_SOLVER_NELDER_MEAD) return ROME_ERR_INVALID_ARG;
   if (o->max_iters < 1 || o->inflate_cycles < 0 || o->inflate_cycles > 255) return ROME_ERR_INVALID_ARG;
-  if (!(o->tol >= 0.0) || !(o->inflation >= 0.0)) return ROME_ERR_INVALID_ARG;
+  if (!(o->tol >= 0.0) || !(o->inflation >= 0.0) || !(o->spread_nh >= 0.0)) return ROME_ERR_INVALID_ARG;
   if (o->layout != ROME_LAYOUT_SOA && o->layout != ROME_LAYOUT_AOS) return ROME_ERR_INVALID_ARG;
   return ROME_OK;
 }
@@ -66,6 +66,7 @@ void fill_args(rome::ConvArgs& a, const rome_opts* o) {
   a.inv_nm1 = o->n_particles > 1 ? 1.0 / (double)(o->n_particles - 1) : 1.0;
   a.seed = o->seed;
   a.stream_offset = o->stream_offset;
+  a.spread_nh = o->spread_nh;
 }
 
 void args_from_dev(rome::ConvArgs& a, const rome_opts* o, const rome_conv_dev* t) {
@@ -77,6 +78,8 @@ void args_from_dev(rome::ConvArgs& a, const rome_opts* o, const rome_conv_dev* t
   a.n_mirror = t->mirror_out ? (t->n_mirror < 0 ? 0 : (t->n_mirror > 4 ? 4 : t->n_mirror)) : 0;
   for (int m = 0; m < 4; ++m) a.mirror_row[m] = t->mirror_row[m];
   a.mirror_out = t->mirror_out;
+  a.alt_var = t->hypo_w ? t->alt_var : nullptr;
+  a.hypo_w = t->hypo_w;
 }
 
 int cholesky_one(int d, const double* cov, double* Lp) {
@@ -116,7 +119,8 @@ enum FactorKind { kP2P2, kBR, kP3P3, kPrior2, kPrior3 };
 // common host-pointer path: stage -> launch -> fetch
 int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const int32_t* dir, int dir_all,
               int dz, int df, int dt, const double* mu, const double* Ltab /*[C][nL]*/, int nL,
-              const double* fixed, const double* noise, double* target_inout, int32_t* status) {
+              const double* fixed, const double* noise, double* target_inout, int32_t* status,
+              const double* alt = nullptr /*C blocks of the other landmark candidate*/, const double* hypo_w = nullptr) {
   const int N = o->n_particles;
   ROME_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -124,6 +128,16 @@ int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const i
   const bool has_fixed = (kind != kPrior2 && kind != kPrior3);
   if (has_fixed) { to_soa(fixed, C, N, df, o->layout, h_fixed); to_soa(target_inout, C, N, dt, o->layout, h_target); }
   if (noise) to_soa(noise, C, N, dz, o->layout, h_noise);
+  std::vector<int32_t> h_alt;
+  if (alt && hypo_w) {  // multihypo: the alternative landmark blocks are appended behind the landmark-side array
+    std::vector<double> h_a;
+    const int dl = dir_all == 1 ? df : dt;
+    to_soa(alt, C, N, dl, o->layout, h_a);
+    std::vector<double>& side = dir_all == 1 ? h_fixed : h_target;
+    side.insert(side.end(), h_a.begin(), h_a.end());
+    h_alt.resize(C);
+    for (int c = 0; c < C; ++c) h_alt[c] = C + c;
+  }
 
   void *d_mu, *d_L, *d_fixed = nullptr, *d_target = nullptr, *d_noise = nullptr, *d_out, *d_dir = nullptr, *d_status = nullptr;
   int rc;
@@ -148,8 +162,16 @@ int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const i
   }
   if (status) { if ((rc = ensure(ctx, 7, sizeof(int32_t) * (size_t)C * N, &d_status))) return rc; }
 
+  void *d_alt = nullptr, *d_hw = nullptr;
+  if (!h_alt.empty()) {
+    if ((rc = ensure(ctx, 8, sizeof(int32_t) * C, &d_alt))) return rc;
+    if ((rc = ensure(ctx, 9, sizeof(double) * C, &d_hw))) return rc;
+    ROME_HIP(ctx, hipMemcpyAsync(d_alt, h_alt.data(), sizeof(int32_t) * C, hipMemcpyHostToDevice, s));
+    ROME_HIP(ctx, hipMemcpyAsync(d_hw, hypo_w, sizeof(double) * C, hipMemcpyHostToDevice, s));
+  }
   rome::ConvArgs a;
   fill_args(a, o);
+  a.alt_var = (const int32_t*)d_alt; a.hypo_w = (const double*)d_hw;
   a.n_conv = C; a.dir_all = dir_all; a.dir = (const int32_t*)d_dir;
   a.mu = (const double*)d_mu; a.L = (const double*)d_L;
   a.bel_fixed = (const double*)d_fixed; a.bel_target = (const double*)d_target;
@@ -163,7 +185,7 @@ int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const i
     case kPrior3: e = rome::launch_sample_priorpose3(a, s); break;
   }
   ROME_HIP(ctx, e);
-  std::vector<double> h_out((size_t)C * N * dt);
+  std::vector<double> h_out((size_t)C * N * dt);   // (with multihypo the target staging holds 2C blocks; the first C are the result)
   ROME_HIP(ctx, hipMemcpyAsync(h_out.data(), d_out, sizeof(double) * h_out.size(), hipMemcpyDeviceToHost, s));
   if (status) ROME_HIP(ctx, hipMemcpyAsync(status, d_status, sizeof(int32_t) * (size_t)C * N, hipMemcpyDeviceToHost, s));
   ROME_HIP(ctx, hipStreamSynchronize(s));
@@ -227,6 +249,7 @@ void rome_opts_default(rome_opts* o, int32_t solver) {
   o->seed = 0x524F4D45ull; /* "ROME" */
   o->stream_offset = 0;
   o->layout = ROME_LAYOUT_SOA;
+  o->spread_nh = 3.0;
 }
 
 int rome_device_count(void) {
@@ -341,6 +364,16 @@ int rome_conv_pose2point2br(rome_ctx* c, const rome_opts* o, int32_t C, int32_t 
   if (C == 0) return ROME_OK;
   for (int i = 0; i < 2 * C; ++i) if (!(sigma[i] >= 0.0)) return ROME_ERR_NOT_POSDEF;
   return host_conv(c, o, kBR, C, nullptr, dir, 2, dir == 0 ? 3 : 2, dir == 0 ? 2 : 3, mu, sigma, 2, fixed, noise, target_inout, status);
+}
+int rome_conv_pose2point2br_mh(rome_ctx* c, const rome_opts* o, int32_t C, int32_t dir, const double* mu, const double* sigma,
+                               const double* fixed, const double* alt, const double* hypo_w, const double* noise,
+                               double* target_inout, int32_t* status) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || C < 0 || (dir != 0 && dir != 1) || (C > 0 && (!mu || !sigma || !fixed || !alt || !hypo_w || !target_inout))) return ROME_ERR_INVALID_ARG;
+  if (C == 0) return ROME_OK;
+  for (int i = 0; i < 2 * C; ++i) if (!(sigma[i] >= 0.0)) return ROME_ERR_NOT_POSDEF;
+  for (int i = 0; i < C; ++i) if (!(hypo_w[i] >= 0.0 && hypo_w[i] <= 1.0)) return ROME_ERR_INVALID_ARG;
+  return host_conv(c, o, kBR, C, nullptr, dir, 2, dir == 0 ? 3 : 2, dir == 0 ? 2 : 3, mu, sigma, 2, fixed, noise, target_inout, status, alt, hypo_w);
 }
 int rome_conv_pose3pose3(rome_ctx* c, const rome_opts* o, int32_t C, const int32_t* dir, const double* mu, const double* cov,
                          const double* fixed, const double* noise, double* target_inout, int32_t* status) {

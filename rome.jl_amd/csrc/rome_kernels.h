@@ -23,6 +23,9 @@ struct ConvArgs {
   const double* noise;        // [C][dz][N] standard normals, or nullptr -> in-kernel Philox
   double* out;                // [C][dt][N]
   int32_t* status;            // [C][N] or nullptr
+  const int32_t* alt_var;     // [C] bearing-range multihypo: the other landmark candidate (-1: single hypothesis), or nullptr
+  const double* hypo_w;       // [C] probability that the table's own landmark is the sighted one
+  double spread_nh;           // IIF SolverParams.spreadNH
   int n_mirror;               // rows additionally written to mirror_out[m] (separator beliefs -> send buffer)
   int mirror_row[4];
   double* mirror_out;

@@ -79,6 +79,7 @@ __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const boo
 
 struct P2P2 {
   static constexpr int DF = 3, DT = 3, DZ = 3, NL = 6;
+  static constexpr int kHypoDir = -1;  // no multihypo support
   struct Consts { double mu[3]; double L[6]; int dir; };
   __device__ static __forceinline__ Consts load(const ConvArgs& a, int f, int dr) {
     Consts K;
@@ -202,6 +203,7 @@ struct BRCost {
 template <int DIR>
 struct BR {
   static constexpr int DF = DIR == 0 ? 3 : 2, DT = DIR == 0 ? 2 : 3, DZ = 2;
+  static constexpr int kHypoDir = DIR;  // multihypo over the landmark slot: DIR 0 target is fractional, DIR 1 fixed is fractional
   struct Consts { double mu[2]; double sg[2]; };
   __device__ static __forceinline__ Consts load(const ConvArgs& a, int f, int) {
     Consts K; K.mu[0] = a.mu[2 * f]; K.mu[1] = a.mu[2 * f + 1]; K.sg[0] = a.L[2 * f]; K.sg[1] = a.L[2 * f + 1];
@@ -298,6 +300,7 @@ struct P3P3Cost {
 
 struct P3P3 {
   static constexpr int DF = 6, DT = 6, DZ = 6;
+  static constexpr int kHypoDir = -1;
   struct Consts { double mu[6]; const double* L; int dir; };
   __device__ static __forceinline__ Consts load(const ConvArgs& a, int f, int dr) {
     Consts K;
@@ -485,6 +488,50 @@ __global__ void __launch_bounds__(64 * ROME_WPB, ROME_MIN_WAVES) k_conv(const Co
 #pragma unroll
   for (int k = 0; k < PPL; ++k) st[k] = 0;
 
+  // ---- multihypo (IIF `multihypo=[1, w, 1-w]` on the landmark slot of a bearing-range factor; ⚠IIF
+  //      computeAcrossHypothesis!): per particle a categorical draw decides which landmark the sighting belongs to.
+  //      DIR 1 (solve the pose): the fixed landmark particle comes from the drawn hypothesis.
+  //      DIR 0 (solve this landmark): particles of the other hypothesis are not constrained by the factor: they keep
+  //      their value and only receive entropy  spreadNH · ‖mean(this) - mean(other)‖ · (U-½)  (applied after the cycles).
+  bool sel[PPL];
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) sel[k] = true;
+  double nh_spread = 0.0;
+  uint32_t nh_w1[PPL], nh_w2[PPL];
+  if constexpr (FP::kHypoDir >= 0) {
+    const int av = a.alt_var ? a.alt_var[c] : -1;
+    if (av >= 0) {  // wave-uniform
+      const double w = a.hypo_w[c];
+      const double* __restrict__ ab = (FP::kHypoDir == 1 ? a.bel_fixed : a.bel_target) + (size_t)av * (FP::kHypoDir == 1 ? FP::DF : FP::DT) * N;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const int i = lane + 64 * k, ii = act[k] ? i : 0;
+        const u32x4 hw = philox4x32_10(u32x4{(uint32_t)ii, (uint32_t)stream, (uint32_t)(stream >> 32), (4u << 16)},
+                                       (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+        const bool primary = ((double)hw.x + 0.5) * (1.0 / 4294967296.0) < w;
+        nh_w1[k] = hw.y; nh_w2[k] = hw.z;
+        if constexpr (FP::kHypoDir == 1) {
+          if (!primary) {
+#pragma unroll
+            for (int d = 0; d < FP::DF; ++d) fx[k][d] = ab[d * N + ii];
+            prep[k] = FP::prepare(K, z[k], fx[k]);
+          }
+        } else sel[k] = primary;
+      }
+      if constexpr (FP::kHypoDir == 0) {
+        double sm[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) if (act[k]) {
+          const int i = lane + 64 * k;
+          sm[0] += t[k][0]; sm[1] += t[k][1]; sm[2] += ab[i]; sm[3] += ab[N + i];
+        }
+        wave_sum_n<4>(sm);
+        const double dx = (sm[0] - sm[2]) * a.inv_n, dy = (sm[1] - sm[3]) * a.inv_n;
+        nh_spread = a.spread_nh * fast_sqrt(dx * dx + dy * dy);
+      }
+    }
+  }
+
   const bool cyc_on = FP::needs_cycles(SOLVER, K);
   const int ncyc = cyc_on ? (a.cycles < 1 ? 1 : a.cycles) : 1;
   constexpr int CPC = FP::DT <= 3 ? 3 : 1;  // inflation cycles served by one Philox call
@@ -500,7 +547,7 @@ __global__ void __launch_bounds__(64 * ROME_WPB, ROME_MIN_WAVES) k_conv(const Co
     }
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
-      if (act[k]) {
+      if (act[k] && sel[k]) {
         if (spread > 0.0) {
           double u[FP::DT];
           rng_entropy_from_words<FP::DT>(ew[k], cyc % CPC, u);
@@ -513,6 +560,15 @@ __global__ void __launch_bounds__(64 * ROME_WPB, ROME_MIN_WAVES) k_conv(const Co
     }
   }
 
+  if constexpr (FP::kHypoDir == 0) {
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+      if (act[k] && !sel[k]) {  // the other hypothesis holds for this particle: entropy only
+        t[k][0] += nh_spread * (((double)nh_w1[k] + 0.5) * (1.0 / 4294967296.0) - 0.5);
+        t[k][1] += nh_spread * (((double)nh_w2[k] + 0.5) * (1.0 / 4294967296.0) - 0.5);
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     const int i = lane + 64 * k;

@@ -54,7 +54,12 @@ class DeviceGraph:
                                   factor=t(factor, i32), dir=t(dr, i32), fixed=t(fixed, i32), target=t(target, i32))
         if pk.br["F"]:
             b = pk.br
-            self.tab["br"] = dict(F=b["F"], mu=t(b["mu"], f64), sigma=t(b["sigma"], f64), pose=t(b["pose"], i32), point=t(b["point"], i32))
+            r0 = b["rows0"]
+            mh = bool((b["alt"] >= 0).any())
+            self.tab["br"] = dict(F=b["F"], F0=len(r0["factor"]), mh=mh, mu=t(b["mu"], f64), sigma=t(b["sigma"], f64),
+                                  pose=t(b["pose"], i32), point=t(b["point"], i32), alt=t(b["alt"], i32), w=t(b["w"], f64),
+                                  factor0=t(r0["factor"], i32), pose0=t(r0["pose"], i32), point0=t(r0["point"], i32),
+                                  alt0=t(r0["alt"], i32), w0=t(r0["w"], f64))
         for name, tab, d in (("prior2", pk.prior2, 3), ("prior3", pk.prior3, 6)):
             if tab["F"]:
                 self.tab[name] = dict(F=tab["F"], mu=t(tab["mu"], f64), L=t(cholesky_lower(tab["cov"]), f64), var=t(tab["var"], i32))
@@ -67,16 +72,17 @@ class DeviceGraph:
         f64 = torch.float64
         C2 = self.tab["p2p2"]["C"] if "p2p2" in self.tab else 0
         Fb = self.tab["br"]["F"] if "br" in self.tab else 0
-        self.n_prop = {Pose2: C2 + Fb, Point2: Fb}
+        Fb0 = self.tab["br"]["F0"] if "br" in self.tab else 0
+        self.n_prop = {Pose2: C2 + Fb, Point2: Fb0}
         self.prop = {Pose2: torch.zeros((max(C2 + Fb, 1), 3, self.N), dtype=f64, device=self.device),
-                     Point2: torch.zeros((max(Fb, 1), 2, self.N), dtype=f64, device=self.device)}
+                     Point2: torch.zeros((max(Fb0, 1), 2, self.N), dtype=f64, device=self.device)}
         self.bel_next = {Pose2: torch.zeros_like(self.bel[Pose2]), Point2: torch.zeros_like(self.bel[Point2])}
         tgt2 = [self.tab["p2p2"]["target"].cpu().numpy()] if C2 else []
         if Fb:
             tgt2.append(pk.br["pose"])
         self.csr = {}
         for vt, tg, nv in ((Pose2, np.concatenate(tgt2) if tgt2 else np.zeros(0, np.int32), len(pk.labels[Pose2])),
-                           (Point2, pk.br["point"] if Fb else np.zeros(0, np.int32), len(pk.labels[Point2]))):
+                           (Point2, pk.br["rows0"]["point"] if Fb else np.zeros(0, np.int32), len(pk.labels[Point2]))):
             order = np.argsort(tg, kind="stable").astype(np.int32)
             ptr = np.zeros(nv + 1, dtype=np.int32)
             np.add.at(ptr, np.asarray(tg, dtype=np.int64) + 1, 1)
@@ -155,9 +161,9 @@ class DeviceGraph:
         if C2:
             self.sweep_pose2pose2(self._opts_at(opts, base + self.STREAM_P2P2), out=self.prop[Pose2][:C2])
         if "br" in self.tab:
-            Fb = self.tab["br"]["F"]
+            Fb, Fb0 = self.tab["br"]["F"], self.tab["br"]["F0"]
             self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR1), 1, out=self.prop[Pose2][C2:C2 + Fb])
-            self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR0), 0, out=self.prop[Point2][:Fb])
+            self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR0), 0, out=self.prop[Point2][:Fb0])
 
     def product_step(self, opts, sweep=0):
         """bel <- product of the proposals targeting each variable (Jacobi update, double-buffered)."""
@@ -254,16 +260,23 @@ class DeviceGraph:
         return out
 
     def sweep_bearingrange(self, opts, direction, out=None, noise=None, status=None):
-        """direction 0: poses -> landmark proposals [F,2,N]; 1: landmarks -> pose proposals [F,3,N]."""
+        """direction 0: poses -> landmark proposals [F0,2,N] (one row per (factor, candidate landmark));
+        1: landmarks -> pose proposals [F,3,N].  Multihypo factors draw the landmark per particle."""
         tb = self.tab["br"]
         dt = 2 if direction == 0 else 3
+        nrow = tb["F0"] if direction == 0 else tb["F"]
         if out is None:
-            out = self.torch.empty((tb["F"], dt, self.N), dtype=self.torch.float64, device=self.device)
-        fixed, target = (tb["pose"], tb["point"]) if direction == 0 else (tb["point"], tb["pose"])
-        bf, bt = (self.bel[Pose2], self.bel[Point2]) if direction == 0 else (self.bel[Point2], self.bel[Pose2])
-        self._launch(self._lib.rome_conv_pose2point2br_dev, opts, n_conv=tb["F"], dir_all=int(direction),
-                     factor=None, dir=None, fixed_var=fixed, target_var=target, mu=tb["mu"], L=tb["sigma"],
-                     bel_fixed=bf, bel_target=bt, noise=noise, out=out, status=status)
+            out = self.torch.empty((nrow, dt, self.N), dtype=self.torch.float64, device=self.device)
+        if direction == 0:
+            kw = dict(factor=tb["factor0"], fixed_var=tb["pose0"], target_var=tb["point0"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Point2])
+            if tb["mh"]:
+                kw.update(alt_var=tb["alt0"], hypo_w=tb["w0"])
+        else:
+            kw = dict(factor=None, fixed_var=tb["point"], target_var=tb["pose"], bel_fixed=self.bel[Point2], bel_target=self.bel[Pose2])
+            if tb["mh"]:
+                kw.update(alt_var=tb["alt"], hypo_w=tb["w"])
+        self._launch(self._lib.rome_conv_pose2point2br_dev, opts, n_conv=nrow, dir_all=int(direction), dir=None,
+                     mu=tb["mu"], L=tb["sigma"], noise=noise, out=out, status=status, **kw)
         return out
 
     def sample_priors(self, opts, kind="prior2", out=None, noise=None):

@@ -20,6 +20,7 @@ class FactorGraph:
         self.variables = OrderedDict()       # label -> vartype
         self.factors = []                    # (label, [var labels], factor)
         self.vals = {}                       # label -> (dim, N) coordinates (belief particles)
+        self.multihypo = {}                  # factor label -> (w1, w2)
 
     # -- DFG-style API --
     def addVariable(self, label, vartype):
@@ -34,17 +35,32 @@ class FactorGraph:
     def ls(self):
         return list(self.variables)
 
-    def addFactor(self, labels, factor):
+    def addFactor(self, labels, factor, multihypo=None):
+        """multihypo=[1.0, w1, w2] (IIF kwarg, test/testMultimodalRangeBearing.jl:53): a Pose2Point2BearingRange
+        whose landmark is l1 with probability w1 or l2 with probability w2 -- labels = [pose, l1, l2]."""
         labels = list(labels)
-        for l, t in zip(labels, factor.variable_types):
+        if multihypo is not None:
+            if not isinstance(factor, Pose2Point2BearingRange) or len(labels) != 3 or len(multihypo) != 3:
+                raise ValueError("multihypo is supported for Pose2Point2BearingRange over [pose, l1, l2]")
+            w = [float(x) for x in multihypo]
+            if w[0] != 1.0 or abs(w[1] + w[2] - 1.0) > 1e-12 or min(w[1:]) < 0:
+                raise ValueError("multihypo must be [1.0, w1, w2] with w1 + w2 = 1")
+            if self.variables.get(labels[2]) is not Point2:
+                raise TypeError("multihypo: %s must be a Point2 variable" % labels[2])
+            extra, labels_chk = labels[2], labels[:2]
+        else:
+            extra, labels_chk = None, labels
+        for l, t in zip(labels_chk, factor.variable_types):
             if l not in self.variables:
                 raise KeyError("addFactor: unknown variable %s" % l)
             if self.variables[l] is not t:
                 raise TypeError("addFactor: %s expects %s for %s" % (type(factor).__name__, t, l))
-        if len(labels) != len(factor.variable_types):
+        if len(labels_chk) != len(factor.variable_types):
             raise ValueError("addFactor: wrong number of variables")
         flabel = "".join(labels) + "f%d" % (1 + sum(1 for f in self.factors if f[1] == labels))
         self.factors.append((flabel, labels, factor))
+        if extra is not None:
+            self.multihypo[flabel] = (w[1], w[2])
         return flabel
 
     def getFactor(self, flabel):
@@ -338,7 +354,7 @@ class PackedGraph:
         for flabel, labels, f in fg.factors:
             ids = [self.index[l] for l in labels]
             if isinstance(f, Pose2Pose2): p2.append((ids, f, flabel))
-            elif isinstance(f, Pose2Point2BearingRange): br.append((ids, f, flabel))
+            elif isinstance(f, Pose2Point2BearingRange): br.append((ids, f, flabel, fg.multihypo.get(flabel)))
             elif isinstance(f, Pose3Pose3): p3.append((ids, f, flabel))
             elif isinstance(f, PriorPose2): pr2.append((ids, f, flabel))
             elif isinstance(f, PriorPose3): pr3.append((ids, f, flabel))
@@ -356,10 +372,20 @@ class PackedGraph:
         self.p2p2 = rel_tables(p2, 3)
         self.p3p3 = rel_tables(p3, 6)
         Fb = len(br)
-        self.br = dict(F=Fb, mu=np.array([[f.bearing.mu, f.range.mu] for _, f, _ in br]).reshape(Fb, 2),
-                       sigma=np.array([[f.bearing.sigma, f.range.sigma] for _, f, _ in br]).reshape(Fb, 2),
-                       pose=np.array([ids[0] for ids, _, _ in br], dtype=np.int32),
-                       point=np.array([ids[1] for ids, _, _ in br], dtype=np.int32),
+        # dir 1 (landmark -> pose): one row per factor, `point` = primary landmark, `alt` = other candidate (-1), `w` = P(primary)
+        # dir 0 (pose -> landmark): `rows0`, one row per (factor, candidate landmark)
+        r0 = dict(factor=[], pose=[], point=[], alt=[], w=[])
+        for k, (ids, f, _, mh) in enumerate(br):
+            cands = [(ids[1], -1, 1.0)] if mh is None else [(ids[1], ids[2], mh[0]), (ids[2], ids[1], mh[1])]
+            for pt, al, w in cands:
+                r0["factor"].append(k); r0["pose"].append(ids[0]); r0["point"].append(pt); r0["alt"].append(al); r0["w"].append(w)
+        self.br = dict(F=Fb, mu=np.array([[f.bearing.mu, f.range.mu] for _, f, _, _ in br]).reshape(Fb, 2),
+                       sigma=np.array([[f.bearing.sigma, f.range.sigma] for _, f, _, _ in br]).reshape(Fb, 2),
+                       pose=np.array([ids[0] for ids, _, _, _ in br], dtype=np.int32),
+                       point=np.array([ids[1] for ids, _, _, _ in br], dtype=np.int32),
+                       alt=np.array([(-1 if mh is None else ids[2]) for ids, _, _, mh in br], dtype=np.int32),
+                       w=np.array([(1.0 if mh is None else mh[0]) for _, _, _, mh in br], dtype=np.float64),
+                       rows0={k: np.asarray(v, dtype=(np.float64 if k == "w" else np.int32)) for k, v in r0.items()},
                        labels=[it[2] for it in br])
 
         def prior_tables(items, d):
@@ -386,7 +412,9 @@ class PackedGraph:
                          var_from=np.asarray(var_from, dtype=np.int32), var_to=np.asarray(var_to, dtype=np.int32), labels=[])
         e3 = dict(F=0, mu=np.zeros((0, 6)), cov=np.zeros((0, 6, 6)), var_from=np.zeros(0, np.int32), var_to=np.zeros(0, np.int32), labels=[])
         self.p3p3 = e3
-        self.br = dict(F=0, mu=np.zeros((0, 2)), sigma=np.zeros((0, 2)), pose=np.zeros(0, np.int32), point=np.zeros(0, np.int32), labels=[])
+        z32 = np.zeros(0, np.int32)
+        self.br = dict(F=0, mu=np.zeros((0, 2)), sigma=np.zeros((0, 2)), pose=z32, point=z32, alt=z32, w=np.zeros(0),
+                       rows0=dict(factor=z32, pose=z32, point=z32, alt=z32, w=np.zeros(0)), labels=[])
         P = 0 if prior_var is None else len(prior_var)
         self.prior2 = dict(F=P, mu=np.asarray(prior_mu if P else np.zeros((0, 3)), dtype=np.float64).reshape(P, 3),
                            cov=np.asarray(prior_cov if P else np.zeros((0, 3, 3)), dtype=np.float64).reshape(P, 3, 3),

@@ -27,6 +27,7 @@ struct RomeOpts
   stream_offset::UInt64
   layout::Int32          # 0 SoA [block][dim][N], 1 AoS [block][N][dim]
   reserved::Int32
+  spread_nh::Float64     # IIF spreadNH
 end
 
 function default_opts(fg::AbstractDFG; solver::Integer=1, seed::Integer=rand(UInt64), stream_offset::Integer=0)
@@ -34,7 +35,7 @@ function default_opts(fg::AbstractDFG; solver::Integer=1, seed::Integer=rand(UIn
   ccall((:rome_opts_default, LIB), Cvoid, (Ref{RomeOpts}, Int32), o, solver)
   p = getSolverParams(fg)
   d = o[]
-  RomeOpts(p.N, d.solver, d.max_iters, p.inflateCycles, d.tol, p.inflation, seed, stream_offset, 1 #=AoS=#, 0)
+  RomeOpts(p.N, d.solver, d.max_iters, p.inflateCycles, d.tol, p.inflation, seed, stream_offset, 1 #=AoS=#, 0, p.spreadNH)
 end
 
 # ---- context ---------------------------------------------------------------------------------------

@@ -19,7 +19,9 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1):
     C2 = 2 * F + P
     Fb = pk.br["F"]
     tg2 = np.concatenate([target, pk.br["pose"]]) if Fb else target
-    tgl = pk.br["point"] if Fb else np.zeros(0, np.int32)
+    r0 = pk.br["rows0"]; Fb0 = len(r0["factor"])
+    tgl = r0["point"] if Fb else np.zeros(0, np.int32)
+    mh = bool((pk.br["alt"] >= 0).any()) if Fb else False
 
     def csr(tg, nv):
         order = np.argsort(tg, kind="stable").astype(np.int32)
@@ -37,10 +39,12 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1):
         for k in range(P):
             o = ro.make_opts(N=N, seed=seed, stream_offset=base + S["P2P2"] + 2 * F + k)
             prop2[2 * F + k] = ro.sample_priorpose2(o, mu[F + k], L[F + k])[0]
-        propl = np.zeros((Fb, 2, N))
+        propl = np.zeros((Fb0, 2, N))
         if Fb:
-            prop2[C2:] = ro.conv_pose2point2br(mk(S["BR1"]), 1, pk.br["mu"], pk.br["sigma"], bell, bel2, pk.br["point"], pk.br["pose"])
-            propl[:] = ro.conv_pose2point2br(mk(S["BR0"]), 0, pk.br["mu"], pk.br["sigma"], bel2, bell, pk.br["pose"], pk.br["point"])
+            prop2[C2:] = ro.conv_pose2point2br(mk(S["BR1"]), 1, pk.br["mu"], pk.br["sigma"], bell, bel2, pk.br["point"], pk.br["pose"],
+                                               alt_var=pk.br["alt"] if mh else None, hypo_w=pk.br["w"] if mh else None)
+            propl[:] = ro.conv_pose2point2br(mk(S["BR0"]), 0, pk.br["mu"], pk.br["sigma"], bel2, bell, r0["pose"], r0["point"], factor=r0["factor"],
+                                             alt_var=r0["alt"] if mh else None, hypo_w=r0["w"] if mh else None)
         bel2 = ro.product(mk(S["PROD2"]), 3, ptr2, rows2, prop2, bel2)
         if Fb:
             bell = ro.product(mk(S["PRODL"]), 2, ptrl, rowsl, propl, bell)

@@ -1,0 +1,105 @@
+"""`multihypo=[1, w1, w2]` bearing-range factors (IIF addFactor! kwarg; test/testMultimodalRangeBearing.jl:53,108):
+HIP path vs oracle, and the reference test's statistical expectations at the convolution level."""
+import numpy as np
+import pytest
+
+import oracle as ro
+
+pytestmark = pytest.mark.gpu
+R = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _pkg():
+    global R
+    import rome_jl_amd
+    R = rome_jl_amd
+    R.default_context()
+    yield
+
+
+def _wd(a, b):
+    d = a - b
+    d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    return d
+
+
+@pytest.mark.parametrize("direction", [0, 1])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_multihypo_vs_oracle(direction, solver):
+    rng = np.random.default_rng(5 + direction)
+    C_, N = 11, 100
+    mu = np.stack([rng.uniform(-3, 3, C_), rng.uniform(8, 25, C_)], 1); sigma = np.stack([rng.uniform(0.01, 0.1, C_), rng.uniform(0.2, 1.0, C_)], 1)
+    pose = rng.standard_normal((C_, 3, N)) * np.array([0.3, 0.3, 0.1])[None, :, None] + rng.standard_normal((C_, 3, 1)) * [[10], [10], [3]]
+    l1 = rng.standard_normal((C_, 2, N)) * 0.5 + rng.standard_normal((C_, 2, 1)) * 15
+    l2 = rng.standard_normal((C_, 2, N)) * 0.5 + rng.standard_normal((C_, 2, 1)) * 15
+    w = rng.uniform(0.2, 0.8, C_)
+    o = R.make_opts(N=N, solver=solver, seed=17, stream_offset=5)
+    oo = ro.make_opts(N=N, solver=solver, seed=17, stream_offset=5)
+    if direction == 1:   # solve the pose: the landmark is drawn per particle
+        out, st = R.conv_pose2point2br(o, 1, mu, sigma, l1, pose, alt=l2, hypo_w=w, want_status=True)
+        ref, rst = ro.conv_pose2point2br(oo, 1, mu, sigma, np.concatenate([l1, l2]), pose, np.arange(C_), np.arange(C_),
+                                         alt_var=C_ + np.arange(C_), hypo_w=w, want_status=True)
+        assert np.abs(_wd(out, ref)).max() < 1e-8 and (st == rst).all()
+        # each pose proposal satisfies the sighting against ONE of the two landmarks, in proportion ~w
+        d1 = np.hypot(out[:, 0] - l1[:, 0], out[:, 1] - l1[:, 1]); d2 = np.hypot(out[:, 0] - l2[:, 0], out[:, 1] - l2[:, 1])
+        near1 = np.abs(d1 - mu[:, 1:2]) < 6 * sigma[:, 1:2]; near2 = np.abs(d2 - mu[:, 1:2]) < 6 * sigma[:, 1:2]
+        assert (near1 | near2).mean() > 0.999
+        excl = (near1 ^ near2).mean(axis=1) > 0.9          # rows where the two rings do not overlap
+        f1 = (near1 & ~near2).sum(axis=1) / np.maximum((near1 ^ near2).sum(axis=1), 1)
+        assert excl.sum() >= 3 and np.abs(f1[excl] - w[excl]).max() < 0.25
+    else:                # solve landmark l1: particles of the other hypothesis only get spreadNH entropy
+        out = R.conv_pose2point2br(o, 0, mu, sigma, pose, l1, alt=l2, hypo_w=w)
+        ref = ro.conv_pose2point2br(oo, 0, mu, sigma, pose, np.concatenate([l1, l2]), np.arange(C_), np.arange(C_),
+                                    alt_var=C_ + np.arange(C_), hypo_w=w)
+        assert np.abs(out - ref).max() < 1e-8
+        rngs = np.hypot(out[:, 0] - pose[:, 0], out[:, 1] - pose[:, 1])
+        on_ring = np.abs(rngs - mu[:, 1:2]) < 6 * sigma[:, 1:2]
+        assert (on_ring.mean(axis=1) > w - 0.25).all()      # the selected share is on the ring (the rest may land there by chance)
+
+
+def test_reference_multimodal_setup_statistics():
+    """test/testMultimodalRangeBearing.jl:27-82 at the convolution level: l1 ~ N((10,0),I), l2 ~ N((30,0),I),
+    p2br = (bearing N(0,0.1), range N(20,1)), multihypo=[1;0.5;0.5]: pose proposals land on the 20 m rings around BOTH
+    landmarks; with the heading near 0 that is x ≈ -10 and x ≈ +10 (the reference asserts ≥ 2 of its 4 x-windows are hit)."""
+    N = 100
+    rng = np.random.default_rng(1)
+    fg = R.initfg(N)
+    fg.addVariable("l1", R.Point2); fg.addVariable("l2", R.Point2); fg.addVariable("x0", R.Pose2)
+    fg.initVariable("l1", np.array([[10.0], [0.0]]) + rng.standard_normal((2, N)))
+    fg.initVariable("l2", np.array([[30.0], [0.0]]) + rng.standard_normal((2, N)))
+    fg.initVariable("x0", np.array([[0.0], [0.0], [0.0]]) + rng.standard_normal((3, N)) * np.array([[20.0], [1.0], [0.05]]))
+    fl = fg.addFactor(["x0", "l1", "l2"], R.Pose2Point2BearingRange(R.Normal(0, 0.1), R.Normal(20.0, 1.0)), multihypo=[1.0, 0.5, 0.5])
+    X0 = R.approxConv(fg, fl, "x0", solver=R.SOLVER_NEWTON, seed=3)
+    wins = [(-20, 0), (0, 20), (20, 40), (40, 60)]
+    assert sum(int(((X0[0] > a) & (X0[0] < b)).sum() > 0) for a, b in wins) >= 2
+    d1 = np.hypot(X0[0] - fg.getVal("l1")[0], X0[1] - fg.getVal("l1")[1]); d2 = np.hypot(X0[0] - fg.getVal("l2")[0], X0[1] - fg.getVal("l2")[1])
+    on1 = np.abs(d1 - 20) < 5; on2 = np.abs(d2 - 20) < 5
+    assert 20 < on1.sum() < 80 and 20 < on2.sum() < 80 and (on1 | on2).all()
+    # landmark direction (second testset of the reference, :108-130): some but not all of the l2 proposals sit 20 m from x0
+    fg.initVariable("x0", rng.standard_normal((3, N)) * np.array([[1.0], [1.0], [0.01]]))
+    L2 = R.approxConv(fg, fl, "l2", solver=R.SOLVER_NEWTON, seed=4)
+    m = ((L2[0] > 10) & (L2[0] < 30)).sum()
+    assert 5 < m < 95
+
+
+def test_multihypo_in_device_graph_solve_vs_oracle():
+    from solve_ref import solve_ref
+    N = 100
+    rng = np.random.default_rng(2)
+    fg = R.initfg(N)
+    fg.addVariable("x0", R.Pose2); fg.addFactor(["x0"], R.PriorPose2(R.MvNormal([0.0, 0, 0], np.diag([1.0, 1.0, 0.01]) ** 2)))
+    fg.addVariable("x1", R.Pose2); fg.addFactor(["x0", "x1"], R.Pose2Pose2(R.MvNormal([5.0, 0, 0], np.diag([0.1, 0.1, 0.01]) ** 2)))
+    fg.addVariable("l1", R.Point2); fg.addVariable("l2", R.Point2)
+    fg.addFactor(["x0", "l1"], R.Pose2Point2BearingRange(R.Normal(0, 0.05), R.Normal(20.0, 0.5)))
+    fg.addFactor(["x1", "l1", "l2"], R.Pose2Point2BearingRange(R.Normal(0, 0.05), R.Normal(15.0, 0.5)), multihypo=[1.0, 0.7, 0.3])
+    R.dead_reckon_init(fg, seed=3)
+    fg.initVariable("l2", np.array([[35.0], [3.0]]) + rng.standard_normal((2, N)))
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    assert dg.tab["br"]["F"] == 2 and dg.tab["br"]["F0"] == 3 and dg.tab["br"]["mh"]
+    dg.solve(R.make_opts(N=N, solver=1, seed=21), n_sweeps=3)
+    b2, bl = solve_ref(R, fg, 3, N, seed=21)
+    g2 = dg.bel[R.Pose2].cpu().numpy(); gl = dg.bel[R.Point2].cpu().numpy()
+    assert np.mean(np.abs(_wd(g2, b2)) < 1e-7) > 0.97 and np.mean(np.abs(gl - bl) < 1e-7) > 0.97
+    m2, _ = R.belief_stats(g2); mo, _ = R.belief_stats(b2)
+    assert np.abs(m2[:, :2] - mo[:, :2]).max() < 1e-3
