@@ -49,22 +49,26 @@ static inline double u53(uint32_t hi, uint32_t lo) { /* (0,1] */
   return (double)((x >> 11) + 1) * (1.0 / 9007199254740992.0);
 }
 
-/* d standard normals for (seed, stream, particle): Box-Muller on Philox words.
+/* d standard normals for (seed, stream, particle): Box-Muller on Philox words, two pairs per Philox call
+ * (32-bit uniforms: u1 = (w+1)/2^32 in (0,1], u2 = (w+0.5)/2^32; |n| <= 6.66 sigma).
  * Replaces `rand(MvNormal)` of ⚠IIF sampleTangent / RoME getSample
  * (src/factors/BearingRange2D.jl:17-27); the reference's stream is unseeded -> unpinned. */
 void ro_rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, int d, double* out) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  int nblk = (d + 1) / 2;
-  for (int b = 0; b < nblk; ++b) {
+  int ncall = (d + 3) / 4;
+  for (int b = 0; b < ncall; ++b) {
     uint32_t ctr[4] = {particle, (uint32_t)stream, (uint32_t)(stream >> 32),
                        ((uint32_t)RO_DOMAIN_NOISE << 16) | (uint32_t)b};
     uint32_t w[4];
     ro_philox4x32_10(ctr, key, w);
-    double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
-    double rr = sqrt(-2.0 * log(u1));
-    double a = 2.0 * RO_PI * u2;
-    out[2 * b] = rr * cos(a);
-    if (2 * b + 1 < d) out[2 * b + 1] = rr * sin(a);
+    for (int p = 0; p < 2 && 4 * b + 2 * p < d; ++p) {
+      double u1 = ((double)w[2 * p] + 1.0) * (1.0 / 4294967296.0);
+      double u2 = ((double)w[2 * p + 1] + 0.5) * (1.0 / 4294967296.0);
+      double rr = sqrt(-2.0 * log(u1));
+      double a = 2.0 * RO_PI * u2;
+      out[4 * b + 2 * p] = rr * cos(a);
+      if (4 * b + 2 * p + 1 < d) out[4 * b + 2 * p + 1] = rr * sin(a);
+    }
   }
 }
 

@@ -110,20 +110,28 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {  // (0,1]
   return (double)((x >> 11) + 1) * (1.0 / 9007199254740992.0);
 }
 
-// D standard normals for (seed, stream, particle): Box-Muller on Philox words.
+// D standard normals for (seed, stream, particle): Box-Muller on Philox words, two pairs per Philox call
+// (32-bit uniforms: u1 = (w+1)/2^32 in (0,1], u2 = (w+0.5)/2^32; |n| <= 6.66 σ).  One call serves Pose2 / Point2.
 template <int D>
 __device__ __forceinline__ void rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, double (&out)[D]) {
-  constexpr int NB = (D + 1) / 2;
+  constexpr int NC = (D + 3) / 4;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
+  for (int b = 0; b < NC; ++b) {
     const u32x4 w = philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32), (kDomainNoise << 16) | (uint32_t)b},
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
-    const double u1 = u53(w.x, w.y), u2 = u53(w.z, w.w);
-    const double rr = fast_sqrt(-2.0 * fast_log(u1));
-    double s, c;
-    fast_sincos(2.0 * kPi * u2, &s, &c);
-    out[2 * b] = rr * c;
-    if (2 * b + 1 < D) out[2 * b + 1] = rr * s;
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (4 * b + 2 * p < D) {
+        const double u1 = ((double)ww[2 * p] + 1.0) * (1.0 / 4294967296.0);
+        const double u2 = ((double)ww[2 * p + 1] + 0.5) * (1.0 / 4294967296.0);
+        const double rr = fast_sqrt(-2.0 * fast_log(u1));
+        double s, c;
+        fast_sincos(2.0 * kPi * u2, &s, &c);
+        out[4 * b + 2 * p] = rr * c;
+        if (4 * b + 2 * p + 1 < D) out[4 * b + 2 * p + 1] = rr * s;
+      }
+    }
   }
 }
 
