@@ -19,7 +19,10 @@
  *     Pose3 coordinates (x, y, z, ωx, ωy, ωz) <-> (t, Exp(ω))    (src/variables/VariableTypes.jl:47,
  *                                                                 coordinate order src/services/g2oParser.jl:166)
  *   - a "block" is one belief of N particles; ROME_LAYOUT_SOA: [block][dim][N] (device-native),
- *     ROME_LAYOUT_AOS: [block][N][dim] (what a Julia Vector of coordinate SVectors looks like).
+ *     ROME_LAYOUT_AOS: [block][N][dim] (what a Julia Vector of coordinate SVectors looks like);
+ *     ROME_LAYOUT_AOS_POINTS: [block][N][point_len], the reference's NATIVE point containers (Pose2
+ *     ArrayPartition = [tx,ty,R11,R21,R12,R22], Point2 = [x,y], Pose3 = [t(3), R column-major(9)]): a Julia
+ *     caller passes pointer(getVal(...)) unchanged; noise blocks stay [block][N][dz] coordinates.
  *   - dir = 0 solves for the factor's 2nd variable given the 1st (x_i -> x_j / pose -> landmark),
  *     dir = 1 solves for the 1st given the 2nd.  In the Pose2Pose2 / Pose3Pose3 tables dir = 2
  *     (ROME_DIR_PRIOR) marks a PriorPose2 / PriorPose3 row: no fixed variable, the proposal is the
@@ -58,7 +61,7 @@ enum {
  *                max|r| <= tol  (default)
  *   NELDER_MEAD  Optim.jl's NelderMead() with its defaults on Σ r², i.e. the reference's algorithm  */
 enum { ROME_SOLVER_CLOSED_FORM = 0, ROME_SOLVER_NEWTON = 1, ROME_SOLVER_NELDER_MEAD = 2 };
-enum { ROME_LAYOUT_SOA = 0, ROME_LAYOUT_AOS = 1 };
+enum { ROME_LAYOUT_SOA = 0, ROME_LAYOUT_AOS = 1, ROME_LAYOUT_AOS_POINTS = 2 };
 enum { ROME_DIR_TO = 0, ROME_DIR_FROM = 1, ROME_DIR_PRIOR = 2 };
 
 /* Mirrors the IIF SolverParams fields that reach this path (N, inflateCycles, inflation). */
@@ -90,6 +93,12 @@ int  rome_ctx_set_stream(rome_ctx* ctx, void* hip_stream); /* launch on a caller
 int  rome_ctx_use_own_stream(rome_ctx* ctx);               /* back to the context's private non-blocking stream (the default) */
 int  rome_ctx_synchronize(rome_ctx* ctx);
 int  rome_device_count(void);
+
+/* Native point containers <-> coordinates, n rows (dim 3: Pose2 6 doubles, dim 6: Pose3 12 doubles, dim 2: copy):
+ * getCoordinates(Pose2, p) = vee(log(ϵ, p)) and getPoint(Pose2, c) = exp_ϵ(hat(c)) of the reference
+ * (src/variables/VariableTypes.jl:35,47), evaluated on the device.  Host pointers.                    */
+int rome_points_to_coords(rome_ctx*, int32_t dim, int32_t n, const double* pts, double* coords);
+int rome_coords_to_points(rome_ctx*, int32_t dim, int32_t n, const double* coords, double* pts);
 
 /* Σ (d x d row-major, n of them) -> row-packed lower Cholesky factors (n x d(d+1)/2), host side.
  * Replaces the PDMat factorisation MvNormal(μ, Σ) performs at factor construction

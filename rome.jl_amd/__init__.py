@@ -7,11 +7,11 @@ host-side mirror of the reference interface; it contains no compute and no CPU f
 """
 from . import _lib
 from ._lib import (Context, Opts, RomeError, SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD,
-                   LAYOUT_SOA, LAYOUT_AOS, MAX_PARTICLES)
+                   LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS, MAX_PARTICLES)
 from .factors import (MvNormal, Normal, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
                       Pose3Pose3, PriorPose3, PriorPoint2, getMeasurementParametric, getPoint, getCoordinates, pack_factor,
                       unpack_factor)
-from .api import (linearize, belief_stats, calcFactorResidualTemporary, make_opts, cholesky_lower, default_context,
+from .api import (linearize, belief_stats, points_to_coords, coords_to_points, calcFactorResidualTemporary, make_opts, cholesky_lower, default_context,
                   residual_pose2pose2, residual_priorpose2, residual_pose2point2br, residual_pose2point2br_pt,
                   residual_pose3pose3, residual_pose3pose3_pt, residual_priorpose3,
                   conv_pose2pose2, conv_pose2point2br, conv_pose3pose3, sample_priorpose2, sample_priorpose3)

@@ -12,7 +12,7 @@ SO = os.environ.get("ROME_MI355_LIB") or os.path.join(HERE, "librome_mi355.so") 
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED_N, ERR_ALLOC = -1, -2, -3, -4, -5, -6
 SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD = 0, 1, 2
-LAYOUT_SOA, LAYOUT_AOS = 0, 1
+LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS = 0, 1, 2
 MAX_PARTICLES = 256
 FACTOR_PRIORPOSE2, FACTOR_POSE2POSE2, FACTOR_POSE2POINT2BR, FACTOR_PRIORPOINT2, FACTOR_POSE3POSE3, FACTOR_PRIORPOSE3 = range(6)
 
@@ -58,6 +58,8 @@ SIGNATURES = {
     "rome_ctx_use_own_stream": (C.c_int, [_CTX]),
     "rome_ctx_synchronize": (C.c_int, [_CTX]),
     "rome_device_count": (C.c_int, []),
+    "rome_points_to_coords": (C.c_int, [_CTX, C.c_int32, C.c_int32, _PD, _PD]),
+    "rome_coords_to_points": (C.c_int, [_CTX, C.c_int32, C.c_int32, _PD, _PD]),
     "rome_cholesky_lower": (C.c_int, [C.c_int32, C.c_int32, _PD, _PD]),
     "rome_residual_pose2pose2": (C.c_int, [_CTX, C.c_int32, _PD, _PD, _PD, _PD]),
     "rome_residual_priorpose2": (C.c_int, [_CTX, C.c_int32, _PD, _PD, _PD]),

@@ -178,9 +178,27 @@ def make_opts(N=100, solver=_lib.SOLVER_NEWTON, max_iters=None, inflate_cycles=N
                              inflation=inflation, seed=seed, stream_offset=stream_offset, layout=layout)
 
 
-def _blocks(a, C_, N, d, layout):
+def _blocks(a, C_, N, d, layout, points_ok=True):
+    if layout == _lib.LAYOUT_AOS_POINTS and points_ok:
+        d = {3: 6, 6: 12}.get(d, d)
     shape = (C_, d, N) if layout == _lib.LAYOUT_SOA else (C_, N, d)
     return _d(a, shape)
+
+
+def points_to_coords(dim, pts, ctx=None):
+    ctx = ctx or default_context()
+    pts = np.atleast_2d(_d(pts)); n = pts.shape[0]
+    out = np.empty((n, dim))
+    _lib.check(_lib.load().rome_points_to_coords(ctx.handle, dim, n, _p(pts), _p(out)), ctx.handle)
+    return out
+
+
+def coords_to_points(dim, coords, ctx=None):
+    ctx = ctx or default_context()
+    coords = np.atleast_2d(_d(coords)); n = coords.shape[0]
+    out = np.empty((n, {3: 6, 6: 12}.get(dim, dim)))
+    _lib.check(_lib.load().rome_coords_to_points(ctx.handle, dim, n, _p(coords), _p(out)), ctx.handle)
+    return out
 
 
 # ------------------------------------------------------------------ host-pointer convolutions
@@ -190,7 +208,7 @@ def conv_pose2pose2(opts, mu, cov, fixed, target, dirs=None, noise=None, want_st
     cov = _d(cov, (C_, 3, 3))
     fixed = _blocks(fixed, C_, N, 3, opts.layout)
     out = _blocks(target, C_, N, 3, opts.layout).copy()
-    noise = None if noise is None else _blocks(noise, C_, N, 3, opts.layout)
+    noise = None if noise is None else _blocks(noise, C_, N, 3, opts.layout, points_ok=False)
     dirs = None if dirs is None else np.ascontiguousarray(dirs, dtype=np.int32)
     st = np.zeros((C_, N), dtype=np.int32) if want_status else None
     _lib.check(_lib.load().rome_conv_pose2pose2(ctx.handle, C.byref(opts), C_, _pi(dirs), _p(mu), _p(cov), _p(fixed),
@@ -207,7 +225,7 @@ def conv_pose2point2br(opts, direction, mu, sigma, fixed, target, noise=None, wa
     df, dt = (3, 2) if direction == 0 else (2, 3)
     fixed = _blocks(fixed, C_, N, df, opts.layout)
     out = _blocks(target, C_, N, dt, opts.layout).copy()
-    noise = None if noise is None else _blocks(noise, C_, N, 2, opts.layout)
+    noise = None if noise is None else _blocks(noise, C_, N, 2, opts.layout, points_ok=False)
     st = np.zeros((C_, N), dtype=np.int32) if want_status else None
     if alt is None:
         _lib.check(_lib.load().rome_conv_pose2point2br(ctx.handle, C.byref(opts), C_, int(direction), _p(mu), _p(sigma),
@@ -225,7 +243,7 @@ def conv_pose3pose3(opts, mu, cov, fixed, target, dirs=None, noise=None, want_st
     cov = _d(cov, (C_, 6, 6))
     fixed = _blocks(fixed, C_, N, 6, opts.layout)
     out = _blocks(target, C_, N, 6, opts.layout).copy()
-    noise = None if noise is None else _blocks(noise, C_, N, 6, opts.layout)
+    noise = None if noise is None else _blocks(noise, C_, N, 6, opts.layout, points_ok=False)
     dirs = None if dirs is None else np.ascontiguousarray(dirs, dtype=np.int32)
     st = np.zeros((C_, N), dtype=np.int32) if want_status else None
     _lib.check(_lib.load().rome_conv_pose3pose3(ctx.handle, C.byref(opts), C_, _pi(dirs), _p(mu), _p(cov), _p(fixed),
@@ -237,8 +255,9 @@ def _sample_prior(fn, d, opts, mu, cov, noise, ctx):
     ctx = ctx or default_context()
     mu = np.atleast_2d(_d(mu)); C_ = mu.shape[0]; N = opts.n_particles
     cov = _d(cov, (C_, d, d))
-    noise = None if noise is None else _blocks(noise, C_, N, d, opts.layout)
-    out = np.empty((C_, d, N) if opts.layout == _lib.LAYOUT_SOA else (C_, N, d))
+    noise = None if noise is None else _blocks(noise, C_, N, d, opts.layout, points_ok=False)
+    pl = {3: 6, 6: 12}[d] if opts.layout == _lib.LAYOUT_AOS_POINTS else d
+    out = np.empty((C_, d, N) if opts.layout == _lib.LAYOUT_SOA else (C_, N, pl))
     _lib.check(fn(ctx.handle, C.byref(opts), C_, _p(mu), _p(cov), _p(noise), _p(out)), ctx.handle)
     return out
 

@@ -51,7 +51,7 @@ int check_opts(const rome_opts* o) {
   if (o->solver < ROME_SOLVER_CLOSED_FORM || o->solver > ROME_SOLVER_NELDER_MEAD) return ROME_ERR_INVALID_ARG;
   if (o->max_iters < 1 || o->inflate_cycles < 0 || o->inflate_cycles > 255) return ROME_ERR_INVALID_ARG;
   if (!(o->tol >= 0.0) || !(o->inflation >= 0.0) || !(o->spread_nh >= 0.0)) return ROME_ERR_INVALID_ARG;
-  if (o->layout != ROME_LAYOUT_SOA && o->layout != ROME_LAYOUT_AOS) return ROME_ERR_INVALID_ARG;
+  if (o->layout != ROME_LAYOUT_SOA && o->layout != ROME_LAYOUT_AOS && o->layout != ROME_LAYOUT_AOS_POINTS) return ROME_ERR_INVALID_ARG;
   return ROME_OK;
 }
 
@@ -116,12 +116,50 @@ void from_soa(const std::vector<double>& src, int C, int N, int d, int layout, d
 
 enum FactorKind { kP2P2, kBR, kP3P3, kPrior2, kPrior3 };
 
+inline int point_len(int dim) { return dim == 3 ? 6 : (dim == 6 ? 12 : dim); }
+
+// rows of native points -> rows of coordinates (and back) on the device; host pointers
+int convert_rows(rome_ctx* c, int dim, size_t n, const double* src, double* dst, bool to_coords) {
+  if (n == 0) return ROME_OK;
+  const int pl = point_len(dim);
+  if (dim == 2) { std::memcpy(dst, src, sizeof(double) * n * 2); return ROME_OK; }
+  ROME_HIP(c, hipSetDevice(c->device));
+  void *d_in, *d_out; int rc;
+  const size_t nin = sizeof(double) * n * (to_coords ? pl : dim), nout = sizeof(double) * n * (to_coords ? dim : pl);
+  if ((rc = ensure(c, 3, nin, &d_in))) return rc;
+  if ((rc = ensure(c, 4, nout, &d_out))) return rc;
+  ROME_HIP(c, hipMemcpyAsync(d_in, src, nin, hipMemcpyHostToDevice, c->stream));
+  ROME_HIP(c, to_coords ? rome::launch_points_to_coords((int)n, dim, (const double*)d_in, (double*)d_out, c->stream)
+                        : rome::launch_coords_to_points((int)n, dim, (const double*)d_in, (double*)d_out, c->stream));
+  ROME_HIP(c, hipMemcpyAsync(dst, d_out, nout, hipMemcpyDeviceToHost, c->stream));
+  ROME_HIP(c, hipStreamSynchronize(c->stream));
+  return ROME_OK;
+}
+
 // common host-pointer path: stage -> launch -> fetch
 int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const int32_t* dir, int dir_all,
               int dz, int df, int dt, const double* mu, const double* Ltab /*[C][nL]*/, int nL,
               const double* fixed, const double* noise, double* target_inout, int32_t* status,
               const double* alt = nullptr /*C blocks of the other landmark candidate*/, const double* hypo_w = nullptr) {
   const int N = o->n_particles;
+  if (o->layout == ROME_LAYOUT_AOS_POINTS) {
+    // the reference's native point containers: convert to AoS coordinates on the device, run, convert back
+    rome_opts oc = *o; oc.layout = ROME_LAYOUT_AOS;
+    const bool has_fx = (kind != kPrior2 && kind != kPrior3);
+    const size_t rows = (size_t)C * N;
+    std::vector<double> cf, ct(rows * dt), ca;
+    int rc2;
+    if (has_fx) {
+      cf.resize(rows * df);
+      if ((rc2 = convert_rows(ctx, df, rows, fixed, cf.data(), true))) return rc2;
+      if ((rc2 = convert_rows(ctx, dt, rows, target_inout, ct.data(), true))) return rc2;
+    }
+    if (alt) { const int dl = dir_all == 1 ? df : dt; ca.resize(rows * dl); if ((rc2 = convert_rows(ctx, dl, rows, alt, ca.data(), true))) return rc2; }
+    rc2 = host_conv(ctx, &oc, kind, C, dir, dir_all, dz, df, dt, mu, Ltab, nL, has_fx ? cf.data() : nullptr, noise, ct.data(), status,
+                    alt ? ca.data() : nullptr, hypo_w);
+    if (rc2) return rc2;
+    return convert_rows(ctx, dt, rows, ct.data(), target_inout, false);
+  }
   ROME_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   std::vector<double> h_fixed, h_target, h_noise;
@@ -439,6 +477,16 @@ int rome_sample_priorpose3_dev(rome_ctx* c, const rome_opts* o, const rome_conv_
   rome::ConvArgs a; args_from_dev(a, o, t);
   ROME_HIP(c, rome::launch_sample_priorpose3(a, c->stream));
   return ROME_OK;
+}
+
+/* ---- native point containers <-> coordinates ---- */
+int rome_points_to_coords(rome_ctx* c, int32_t dim, int32_t n, const double* pts, double* coords) {
+  if (!c || n < 0 || (dim != 2 && dim != 3 && dim != 6) || (n > 0 && (!pts || !coords))) return ROME_ERR_INVALID_ARG;
+  return convert_rows(c, dim, (size_t)n, pts, coords, true);
+}
+int rome_coords_to_points(rome_ctx* c, int32_t dim, int32_t n, const double* coords, double* pts) {
+  if (!c || n < 0 || (dim != 2 && dim != 3 && dim != 6) || (n > 0 && (!pts || !coords))) return ROME_ERR_INVALID_ARG;
+  return convert_rows(c, dim, (size_t)n, coords, pts, false);
 }
 
 /* ---- parametric linearisation ---- */

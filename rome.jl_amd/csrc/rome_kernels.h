@@ -52,6 +52,8 @@ hipError_t launch_residual_bearingrange(int n, const double* z, const double* p,
 hipError_t launch_residual_pose3pose3(int n, const double* z, const double* p, const double* q, int pts, double* r, hipStream_t s);
 hipError_t launch_residual_priorpose3(int n, const double* m, const double* p, double* r, hipStream_t s);
 
+hipError_t launch_points_to_coords(int n, int dim, const double* pts, double* c, hipStream_t s);
+hipError_t launch_coords_to_points(int n, int dim, const double* c, double* pts, hipStream_t s);
 hipError_t launch_linearize(int kind, int F, const double* mu, const double* W, const double* xa, const double* xb,
                             double* r, double* Ja, double* Jb, hipStream_t s);
 

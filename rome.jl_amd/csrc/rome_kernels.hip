@@ -690,9 +690,49 @@ __global__ void k_residual_priorpose3(int n, const double* m, const double* p, d
   for (int k = 0; k < 6; ++k) r[6 * i + k] = rr[k];
 }
 
+// ---- native point layouts <-> coordinates (rows): Pose2 [tx,ty,R11,R21,R12,R22] <-> (x,y,θ);
+//      Pose3 [t(3), R col-major(9)] <-> (t, ω).  vee(log(ϵ,p)) / exp_ϵ(hat c) of src/variables/VariableTypes.jl:35,47.
+__global__ void k_points_to_coords(int n, int dim, const double* __restrict__ pts, double* __restrict__ c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (dim == 3) {
+    c[3 * i] = pts[6 * i]; c[3 * i + 1] = pts[6 * i + 1]; c[3 * i + 2] = atan2(pts[6 * i + 3], pts[6 * i + 2]);
+  } else {
+    c[6 * i] = pts[12 * i]; c[6 * i + 1] = pts[12 * i + 1]; c[6 * i + 2] = pts[12 * i + 2];
+    double R[9], w[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = pts[12 * i + 3 + k];
+    so3_log(R, w);
+    c[6 * i + 3] = w[0]; c[6 * i + 4] = w[1]; c[6 * i + 5] = w[2];
+  }
+}
+__global__ void k_coords_to_points(int n, int dim, const double* __restrict__ c, double* __restrict__ pts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (dim == 3) {
+    double s, co; fast_sincos(c[3 * i + 2], &s, &co);
+    pts[6 * i] = c[3 * i]; pts[6 * i + 1] = c[3 * i + 1];
+    pts[6 * i + 2] = co; pts[6 * i + 3] = s; pts[6 * i + 4] = -s; pts[6 * i + 5] = co;
+  } else {
+    pts[12 * i] = c[6 * i]; pts[12 * i + 1] = c[6 * i + 1]; pts[12 * i + 2] = c[6 * i + 2];
+    double R[9];
+    so3_exp(c + 6 * i + 3, R);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pts[12 * i + 3 + k] = R[k];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+hipError_t launch_points_to_coords(int n, int dim, const double* pts, double* c, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_points_to_coords, dim3((n + 255) / 256), dim3(256), 0, s, n, dim, pts, c);
+  return hipGetLastError();
+}
+hipError_t launch_coords_to_points(int n, int dim, const double* c, double* pts, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_coords_to_points, dim3((n + 255) / 256), dim3(256), 0, s, n, dim, c, pts);
+  return hipGetLastError();
+}
 template <class FP, int SOLVER>
 static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
   const int nb = (a.n_conv + ROME_WPB - 1) / ROME_WPB;

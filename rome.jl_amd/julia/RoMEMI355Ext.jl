@@ -75,6 +75,21 @@ function conv_pose2pose2(fg, f::Pose2Pose2, fixedpts, u0pts, dir::Integer; solve
   points(Pose2, target)
 end
 
+# Zero-conversion variant: Vector{ArrayPartition{Float64,Tuple{SVector{2},SMatrix{2,2}}}} is isbits, i.e. 6 contiguous
+# doubles [tx,ty,R11,R21,R12,R22] per point == ROME_LAYOUT_AOS_POINTS (layout = 2): pass the belief vectors as they are.
+function conv_pose2pose2!(fg, f::Pose2Pose2, fixedpts::Vector{P}, u0pts::Vector{P}, dir::Integer; solver=1) where {P}
+  d0 = default_opts(fg; solver)
+  o = RomeOpts(d0.n_particles, d0.solver, d0.max_iters, d0.inflate_cycles, d0.tol, d0.inflation, d0.seed, d0.stream_offset, 2, 0, d0.spread_nh)
+  μ = collect(Float64, mean(f.Z)); Σ = collect(Float64, cov(f.Z))'
+  d = Int32[dir]
+  GC.@preserve μ Σ fixedpts u0pts d begin
+    check(ccall((:rome_conv_pose2pose2, LIB), Cint,
+      (Ptr{Cvoid}, Ref{RomeOpts}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+      ctx().h, o, 1, d, μ, Σ, Ptr{Float64}(pointer(fixedpts)), C_NULL, Ptr{Float64}(pointer(u0pts)), C_NULL))
+  end
+  u0pts   # overwritten in place with the N solution points
+end
+
 function conv_bearingrange(fg, f::Pose2Point2BearingRange{<:Normal,<:Normal}, fixedpts, u0pts, dir::Integer; solver=1)
   o = default_opts(fg; solver)
   μ = Float64[mean(f.bearing), mean(f.range)]; σ = Float64[std(f.bearing), std(f.range)]

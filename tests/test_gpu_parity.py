@@ -354,3 +354,32 @@ def test_hipgraph_capture_replays_the_sweep():
     assert torch.equal(out, out_eager)
     out.zero_(); g.replay(); g.replay(); torch.cuda.synchronize()
     assert torch.equal(out, out_eager)
+
+
+def test_native_point_layout_roundtrip_and_convolution():
+    """ROME_LAYOUT_AOS_POINTS: the reference's native point containers in, native points out."""
+    rng = np.random.default_rng(12)
+    c3 = rng.standard_normal((50, 3)) * [5, 5, 2]; c6 = rng.standard_normal((50, 6)) * [5, 5, 5, 0.8, 0.8, 0.8]
+    assert np.abs(R.coords_to_points(3, c3) - np.array([ro.pose2_point(c) for c in c3])).max() < 1e-15
+    assert np.abs(R.coords_to_points(6, c6) - np.array([ro.pose3_point(c) for c in c6])).max() < 1e-14
+    back = R.points_to_coords(3, R.coords_to_points(3, c3))
+    assert np.abs(np.arctan2(np.sin(back - c3), np.cos(back - c3))[:, 2]).max() < 1e-14 and np.abs(back[:, :2] - c3[:, :2]).max() == 0
+    assert np.abs(R.points_to_coords(6, R.coords_to_points(6, c6)) - c6).max() < 1e-12
+    C_, N = 9, 100
+    mu, cov, fixed, target, dirs, noise = _p2_inputs(C_, N, 77)
+    o = R.make_opts(N=N, solver=1)
+    ref = R.conv_pose2pose2(o, mu, cov, fixed, target, dirs=dirs, noise=noise)
+    op = R.make_opts(N=N, solver=1, layout=R.LAYOUT_AOS_POINTS)
+    to_pts = lambda b: np.ascontiguousarray(R.getPoint(R.Pose2, b.transpose(0, 2, 1)))
+    out_pts = R.conv_pose2pose2(op, mu, cov, to_pts(fixed), to_pts(target), dirs=dirs, noise=np.ascontiguousarray(noise.transpose(0, 2, 1)))
+    assert out_pts.shape == (C_, N, 6)
+    got = R.getCoordinates(R.Pose2, out_pts).transpose(0, 2, 1)
+    assert np.abs(wrapdiff(got, ref, [2])).max() < 1e-12
+    # Pose3Pose3 through native 12-double points
+    mu6, cov6, f6, t6, d6, n6 = _p3_inputs(4, N, 5)
+    ref6 = R.conv_pose3pose3(R.make_opts(N=N, solver=1), mu6, cov6, f6, t6, dirs=d6, noise=n6)
+    to6 = lambda b: np.ascontiguousarray(R.getPoint(R.Pose3, b.transpose(0, 2, 1)))
+    out6 = R.conv_pose3pose3(R.make_opts(N=N, solver=1, layout=R.LAYOUT_AOS_POINTS), mu6, cov6, to6(f6), to6(t6), dirs=d6,
+                             noise=np.ascontiguousarray(n6.transpose(0, 2, 1)))
+    got6 = R.getCoordinates(R.Pose3, out6).transpose(0, 2, 1)
+    assert _so3_dist(got6, ref6) < 1e-9
