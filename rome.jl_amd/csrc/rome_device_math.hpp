@@ -386,16 +386,18 @@ __device__ __forceinline__ int nelder_mead(const Cost& cost, double (&x)[n], int
 #pragma unroll
     for (int j = i; j > 0; --j) nm_cswap<n>(S[j - 1], S[j]);
 
-  auto objective = [&]() {
+  // Optim's stopping statistic is sqrt(var(f)·n/(n+1)) <= g_tol with the corrected variance; evaluated here as
+  // Σ(f-mean)² <= g_tol²·(n+1)  (same decision, no FP64 divide / sqrt in the loop: ≈ 250 SIMD-cycles per iteration)
+  const double thr2 = g_tol * g_tol * (double)m;
+  auto objective2 = [&]() {
     double mean = 0.0;
 #pragma unroll
     for (int i = 0; i < m; ++i) mean += S[i].f;
-    mean /= m;
+    mean *= (1.0 / m);
     double v = 0.0;
 #pragma unroll
     for (int i = 0; i < m; ++i) { const double d = S[i].f - mean; v += d * d; }
-    v /= (m - 1);
-    return sqrt(v * ((double)n / (double)m));
+    return v;
   };
   auto centroid = [&](double (&c)[n]) {  // of all but the highest
 #pragma unroll
@@ -407,7 +409,7 @@ __device__ __forceinline__ int nelder_mead(const Cost& cost, double (&x)[n], int
     }
   };
 
-  bool converged = objective() <= g_tol;
+  bool converged = objective2() <= thr2;
   int iter = 0;
   while (!converged && iter < max_iters) {
     ++iter;
@@ -417,30 +419,23 @@ __device__ __forceinline__ int nelder_mead(const Cost& cost, double (&x)[n], int
 #pragma unroll
     for (int k = 0; k < n; ++k) xr[k] = xc[k] + alpha * (xc[k] - S[m - 1].x[k]);
     const double f_reflect = cost(xr);
-    bool shrink = false;
-    if (f_reflect < f_lowest) {
+    // One second trial point per iteration with a per-lane coefficient (expansion β, outside contraction γ,
+    // inside contraction -γ; unused when the reflection is simply accepted): the four Optim branches become
+    // selects, so lanes of a wave taking different branches do not serialise two extra cost evaluations.
+    const bool expand = f_reflect < f_lowest;
+    const bool accept_reflect = !expand && f_reflect < f_second;
+    const bool outside = f_reflect < f_highest;
+    const double kcoef = expand ? beta : (outside ? gamma : -gamma);
 #pragma unroll
-      for (int k = 0; k < n; ++k) xt[k] = xc[k] + beta * (xr[k] - xc[k]);
-      const double f_expand = cost(xt);
-      const bool ex = f_expand < f_reflect;
-      S[m - 1].f = ex ? f_expand : f_reflect;
+    for (int k = 0; k < n; ++k) xt[k] = xc[k] + kcoef * (xr[k] - xc[k]);
+    const double f_trial = cost(xt);
+    const bool take_trial = expand ? (f_trial < f_reflect) : (!accept_reflect && f_trial < (outside ? f_reflect : f_highest));
+    const bool take_reflect = (expand && !take_trial) || accept_reflect;
+    const bool shrink = !take_trial && !take_reflect;
+    if (!shrink) {
+      S[m - 1].f = take_trial ? f_trial : f_reflect;
 #pragma unroll
-      for (int k = 0; k < n; ++k) S[m - 1].x[k] = ex ? xt[k] : xr[k];
-    } else if (f_reflect < f_second) {
-      S[m - 1].f = f_reflect;
-#pragma unroll
-      for (int k = 0; k < n; ++k) S[m - 1].x[k] = xr[k];
-    } else {
-      const bool outside = f_reflect < f_highest;
-      const double sg = outside ? gamma : -gamma;
-#pragma unroll
-      for (int k = 0; k < n; ++k) xt[k] = xc[k] + sg * (xr[k] - xc[k]);
-      const double fc = cost(xt);
-      if (fc < (outside ? f_reflect : f_highest)) {
-        S[m - 1].f = fc;
-#pragma unroll
-        for (int k = 0; k < n; ++k) S[m - 1].x[k] = xt[k];
-      } else shrink = true;
+      for (int k = 0; k < n; ++k) S[m - 1].x[k] = take_trial ? xt[k] : xr[k];
     }
     if (shrink) {
 #pragma unroll
@@ -458,7 +453,7 @@ __device__ __forceinline__ int nelder_mead(const Cost& cost, double (&x)[n], int
 #pragma unroll
       for (int j = m - 1; j > 0; --j) nm_cswap<n>(S[j - 1], S[j]);
     }
-    converged = objective() <= g_tol;
+    converged = objective2() <= thr2;
   }
   double xc[n];
   centroid(xc);
