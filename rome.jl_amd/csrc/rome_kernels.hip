@@ -444,7 +444,10 @@ template <class FP, int SOLVER, int PPL>
 #ifndef ROME_WPB
 #define ROME_WPB 4   // wavefronts (= convolutions) per workgroup
 #endif
-__global__ void __launch_bounds__(64 * ROME_WPB, ROME_MIN_WAVES) k_conv(const ConvArgs a) {
+// Nelder-Mead on the 2-D/3-D factors is latency-bound (long dependent select/compare chains): asking for 4 waves/SIMD
+// (<= 128 VGPRs) is 5 % faster there; the Newton / closed-form kernels are issue-bound and lose 5-40 % when capped.
+__global__ void __launch_bounds__(64 * ROME_WPB, (SOLVER == kSolverNelderMead && FP::DT <= 3) ? 4 : ROME_MIN_WAVES)
+k_conv(const ConvArgs a) {
   const int lane = threadIdx.x & 63;
   const int c = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * ROME_WPB + (int)(threadIdx.x >> 6));
   if (c >= a.n_conv) return;
