@@ -140,7 +140,8 @@ int rome_conv_pose2pose2(rome_ctx*, const rome_opts*, int32_t C, const int32_t* 
                          double* target_inout /*C*N*3*/, int32_t* status);
 /* dir (scalar): 0 = fixed poses (3) -> target landmarks (2); 1 = fixed landmarks (2) -> target poses (3).
  * mu = (mean bearing, mean range), sigma = (σ_b, σ_ρ) of the two Normal() fields
- * (src/factors/BearingRange2D.jl:10-13); getSample :17-27.                                       */
+ * (src/factors/BearingRange2D.jl:10-13); getSample :17-27.  A negative sigma encodes a Uniform belief on
+ * [mu - |sigma|, mu + |sigma|] (test/TestPoseAndPoint2Constraints.jl:95 uses Uniform(-pi,pi) bearings).                                      */
 int rome_conv_pose2point2br(rome_ctx*, const rome_opts*, int32_t C, int32_t dir,
                             const double* mu /*C*2*/, const double* sigma /*C*2*/,
                             const double* fixed, const double* noise /*C*N*2 or NULL*/,

@@ -721,8 +721,12 @@ int ro_conv_pose2point2br_mh(const ro_opts* o, int C, const int32_t* factor, int
       double xi[2];
       if (noise) { xi[0] = noise[(size_t)c * 2 * N + i]; xi[1] = noise[(size_t)c * 2 * N + N + i]; }
       else ro_rng_normals(o->seed, o->stream_offset + (uint64_t)c, (uint32_t)i, 2, xi);
-      zs[2 * i] = mu[2 * f] + sigma[2 * f] * xi[0];          /* rand(bearing) src/factors/BearingRange2D.jl:23 */
-      zs[2 * i + 1] = mu[2 * f + 1] + sigma[2 * f + 1] * xi[1]; /* rand(range) */
+      /* rand(bearing), rand(range) src/factors/BearingRange2D.jl:23.  sigma >= 0: Normal(mu, sigma);
+       * sigma < 0: Uniform(mu - |sigma|, mu + |sigma|) via the normal CDF of the same xi (u = erfc(-xi/√2)/2) */
+      for (int k = 0; k < 2; ++k) {
+        double sg = sigma[2 * f + k];
+        zs[2 * i + k] = sg >= 0.0 ? mu[2 * f + k] + sg * xi[k] : mu[2 * f + k] - sg * (erfc(-xi[k] * 0.70710678118654752440) - 1.0);
+      }
       for (int k = 0; k < dt; ++k) ob[k * N + i] = tb[k * N + i];
       if (dt == 3) ob[2 * N + i] = wrap_pi(ob[2 * N + i]);
       if (status) status[(size_t)c * N + i] = 0;

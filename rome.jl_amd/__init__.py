@@ -8,7 +8,7 @@ host-side mirror of the reference interface; it contains no compute and no CPU f
 from . import _lib
 from ._lib import (Context, Opts, RomeError, SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD,
                    LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS, MAX_PARTICLES)
-from .factors import (MvNormal, Normal, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
+from .factors import (MvNormal, Normal, Uniform, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
                       Pose3Pose3, PriorPose3, PriorPoint2, getMeasurementParametric, getPoint, getCoordinates, pack_factor,
                       unpack_factor)
 from .api import (linearize, belief_stats, points_to_coords, coords_to_points, calcFactorResidualTemporary, make_opts, cholesky_lower, default_context,

@@ -400,7 +400,7 @@ int rome_conv_pose2point2br(rome_ctx* c, const rome_opts* o, int32_t C, int32_t 
   int rc = check_opts(o); if (rc) return rc;
   if (!c || C < 0 || (dir != 0 && dir != 1) || (C > 0 && (!mu || !sigma || !fixed || !target_inout))) return ROME_ERR_INVALID_ARG;
   if (C == 0) return ROME_OK;
-  for (int i = 0; i < 2 * C; ++i) if (!(sigma[i] >= 0.0)) return ROME_ERR_NOT_POSDEF;
+  for (int i = 0; i < 2 * C; ++i) if (sigma[i] != sigma[i]) return ROME_ERR_NOT_POSDEF;  /* sigma < 0 encodes Uniform(mu ± |sigma|) */
   return host_conv(c, o, kBR, C, nullptr, dir, 2, dir == 0 ? 3 : 2, dir == 0 ? 2 : 3, mu, sigma, 2, fixed, noise, target_inout, status);
 }
 int rome_conv_pose2point2br_mh(rome_ctx* c, const rome_opts* o, int32_t C, int32_t dir, const double* mu, const double* sigma,
@@ -409,7 +409,7 @@ int rome_conv_pose2point2br_mh(rome_ctx* c, const rome_opts* o, int32_t C, int32
   int rc = check_opts(o); if (rc) return rc;
   if (!c || C < 0 || (dir != 0 && dir != 1) || (C > 0 && (!mu || !sigma || !fixed || !alt || !hypo_w || !target_inout))) return ROME_ERR_INVALID_ARG;
   if (C == 0) return ROME_OK;
-  for (int i = 0; i < 2 * C; ++i) if (!(sigma[i] >= 0.0)) return ROME_ERR_NOT_POSDEF;
+  for (int i = 0; i < 2 * C; ++i) if (sigma[i] != sigma[i]) return ROME_ERR_NOT_POSDEF;
   for (int i = 0; i < C; ++i) if (!(hypo_w[i] >= 0.0 && hypo_w[i] <= 1.0)) return ROME_ERR_INVALID_ARG;
   return host_conv(c, o, kBR, C, nullptr, dir, 2, dir == 0 ? 3 : 2, dir == 0 ? 2 : 3, mu, sigma, 2, fixed, noise, target_inout, status, alt, hypo_w);
 }

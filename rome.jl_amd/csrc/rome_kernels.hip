@@ -210,8 +210,14 @@ struct BR {
     return K;
   }
   __device__ static __forceinline__ void measurement(const Consts& K, const double (&xi)[2], double (&z)[2]) {
-    z[0] = K.mu[0] + K.sg[0] * xi[0];  // rand(bearing)  BearingRange2D.jl:23
-    z[1] = K.mu[1] + K.sg[1] * xi[1];  // rand(range)
+    // rand(bearing), rand(range)  (BearingRange2D.jl:23).  sg >= 0: Normal(mu, sg).  sg < 0: Uniform(mu - |sg|, mu + |sg|)
+    // (test/TestPoseAndPoint2Constraints.jl:95 uses Uniform(-π, π) bearings): the standard normal ξ is mapped through
+    // its CDF, u = ½ erfc(-ξ/√2).
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (K.sg[k] >= 0.0) z[k] = K.mu[k] + K.sg[k] * xi[k];
+      else z[k] = K.mu[k] - K.sg[k] * (erfc(-xi[k] * 0.70710678118654752440) - 1.0);
+    }
   }
   __device__ static __forceinline__ void canonical(double (&t)[DT]) { if constexpr (DT == 3) t[2] = wrap_pi(t[2]); }
   __device__ static __forceinline__ bool needs_cycles(int solver, const Consts&) {

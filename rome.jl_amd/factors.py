@@ -46,6 +46,20 @@ class Normal:
         return "Normal(μ=%r, σ=%r)" % (self.mu, self.sigma)
 
 
+class Uniform:
+    """Uniform(a, b) (Distributions.jl); accepted for the bearing / range beliefs of Pose2Point2BearingRange."""
+
+    def __init__(self, a, b):
+        if not b > a:
+            raise ValueError("Uniform: need a < b")
+        self.a, self.b = float(a), float(b)
+        self.mu = 0.5 * (self.a + self.b)
+        self.sigma = -0.5 * (self.b - self.a)   # library encoding: negative "sigma" = half-width of a uniform
+
+    def __repr__(self):
+        return "Uniform(a=%r, b=%r)" % (self.a, self.b)
+
+
 # ---- variable types ----
 class _VarType:
     dim = 0        # manifold dimension (tangent coordinates)
@@ -104,8 +118,8 @@ class Pose2Point2BearingRange(_RelativeFactor):
     variable_types = (Pose2, Point2)
 
     def __init__(self, bearing, range):  # noqa: A002  (mirrors the reference field name)
-        if not isinstance(bearing, Normal) or not isinstance(range, Normal):
-            raise TypeError("Pose2Point2BearingRange: this build supports Normal bearing and range beliefs")
+        if not isinstance(bearing, (Normal, Uniform)) or not isinstance(range, (Normal, Uniform)):
+            raise TypeError("Pose2Point2BearingRange: this build supports Normal / Uniform bearing and range beliefs")
         self.bearing = bearing
         self.range = range
 
@@ -142,6 +156,8 @@ class PriorPoint2(_PriorFactor):
 def getMeasurementParametric(f):
     """(μ, iΣ) as IIF.getMeasurementParametric; BearingRange override at BearingRange2D.jl:30-37."""
     if isinstance(f, Pose2Point2BearingRange):
+        if not isinstance(f.bearing, Normal) or not isinstance(f.range, Normal):
+            raise TypeError("getMeasurementParametric(::Pose2Point2BearingRange{<:Normal,<:Normal}) only (BearingRange2D.jl:30)")
         return (np.array([f.bearing.mu, f.range.mu]),
                 np.diag([1.0 / f.bearing.sigma ** 2, 1.0 / f.range.sigma ** 2]))
     return f.Z.mu.copy(), np.linalg.inv(f.Z.cov)
@@ -151,12 +167,16 @@ def getMeasurementParametric(f):
 def _pack_belief(b):
     if isinstance(b, Normal):
         return {"_type": "Normal", "mu": b.mu, "sigma": b.sigma}
+    if isinstance(b, Uniform):
+        return {"_type": "Uniform", "a": b.a, "b": b.b}
     return {"_type": "FullNormal", "mu": b.mu.tolist(), "cov": b.cov.tolist()}
 
 
 def _unpack_belief(d):
     if d["_type"] == "Normal":
         return Normal(d["mu"], d["sigma"])
+    if d["_type"] == "Uniform":
+        return Uniform(d["a"], d["b"])
     return MvNormal(d["mu"], np.asarray(d["cov"]))
 
 

@@ -1,0 +1,65 @@
+"""The reference's statistical convolution tests (SURVEY §8(c) "Conv-stat" rows) run against the HIP path:
+test/testBasicPose2Conv.jl:8-44 and test/TestPoseAndPoint2Constraints.jl:10-42,88-121 (convolution level)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+R = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _pkg():
+    global R
+    import rome_jl_amd
+    R = rome_jl_amd
+    R.default_context()
+    yield
+
+
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_basic_pose2_convolution(solver):
+    # testBasicPose2Conv.jl: x0 ~ 100 points 0.01*randn(3) about identity; Pose2Pose2(MvNormal([10;0;pi], 0.1*I))
+    N = 100
+    rng = np.random.default_rng(0)
+    fg = R.initfg(N)
+    fg.addVariable("x0", R.Pose2); fg.initVariable("x0", 0.01 * rng.standard_normal((3, N)))
+    fg.addVariable("x1", R.Pose2)
+    fl = fg.addFactor(["x0", "x1"], R.Pose2Pose2(R.MvNormal([10, 0, np.pi], 0.1 * np.eye(3))))
+    X1 = R.approxConv(fg, fl, "x1", solver=solver, seed=123)
+    mean, sd = R.belief_stats(X1[None])
+    Rm = np.array([[np.cos(mean[0, 2]), -np.sin(mean[0, 2])], [np.sin(mean[0, 2]), np.cos(mean[0, 2])]])
+    assert np.allclose(mean[0, :2], [10, 0], atol=0.2)                       # :28
+    assert np.allclose(Rm, [[-1, 0], [0, -1]], atol=0.2)                     # :29
+    assert np.allclose(np.diag(sd[0] ** 2), 0.15 * np.eye(3), atol=0.4)      # :31
+    psi = X1[2]
+    assert 20 < (psi > 2).sum() and 20 < (psi < -2).sum()                    # :38-39  bimodal at ±π
+    # :41 asserts no sample in (-2, 2): with σ_θ = √0.1 that window starts 3.6 σ from ±π, i.e. the reference's own test
+    # fails ~3 % of the time; allow one stray sample here.  :43 (|ψ| ≤ π on-manifold) is exact.
+    assert ((psi > -2) & (psi < 2)).sum() <= 1 and (np.abs(psi) > 3.15).sum() < 1
+
+
+def test_pose_and_point_convolutions():
+    # TestPoseAndPoint2Constraints.jl:19-42 and :88-121
+    N = 100
+    fg = R.initfg(N)
+    fg.addVariable("x0", R.Pose2)
+    f1 = fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.zeros(3), np.diag([0.03, 0.03, 0.001]))))
+    fg.initVariable("x0", R.approxConv(fg, f1, "x0", seed=1))
+    fg.addVariable("x1", R.Pose2)
+    f2 = fg.addFactor(["x0", "x1"], R.Pose2Pose2(R.MvNormal([50.0, 0.0, np.pi / 2], np.diag([3.0, 3.0, 0.01]))))
+    pts = R.approxConv(fg, f2, "x1", seed=2)
+    mean, _ = R.belief_stats(pts[None])
+    assert np.allclose(mean[0, :2], [50, 0], atol=1)                         # :40
+    th = mean[0, 2]
+    assert np.allclose([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]], [[0, -1], [1, 0]], atol=0.5)   # :41
+    # bearing-range with a Uniform(-pi, pi) bearing: all landmark proposals lie in a ring around (0,0)
+    fg.addVariable("l1", R.Point2)
+    f4 = fg.addFactor(["x0", "l1"], R.Pose2Point2BearingRange(R.Uniform(-np.pi, np.pi), R.Normal(10.0, 1.0)))
+    lp = R.approxConv(fg, f4, "l1", seed=3)
+    r = np.hypot(lp[0], lp[1])
+    assert (r < 5.0).sum() == 0 and (r < 15.0).sum() == N                    # :104-105
+    assert np.ptp(np.arctan2(lp[1], lp[0])) > 5.0                            # bearings cover the circle
+    # ... and the pose direction runs (the reference only checks it does not throw, :108)
+    fg.initVariable("l1", lp)
+    xp = R.approxConv(fg, f4, "x0", seed=4)
+    assert np.isfinite(xp).all()
