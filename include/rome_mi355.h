@@ -77,6 +77,7 @@ typedef struct rome_opts {
   int32_t layout;         /* host-pointer entry points only: ROME_LAYOUT_*                             */
   int32_t reserved;
   double  spread_nh;      /* IIF spreadNH (default 3.0): entropy scale for particles of the other hypothesis (multihypo) */
+  double  nullhypo;       /* host-pointer entry points only: IIF nullhypo= probability applied to every row of the call */
 } rome_opts;
 
 typedef struct rome_ctx rome_ctx; /* opaque: device id, HIP stream, staging buffers */
@@ -195,6 +196,10 @@ typedef struct rome_conv_dev {
    * hypo_w[c] = probability that the row's own landmark (fixed_var for dir 1, target_var for dir 0) is the sighted one. */
   const int32_t* alt_var;
   const double* hypo_w;
+  /* optional: IIF `nullhypo=p` per row (addFactor!(fg, [:x3;:x1], odoc3, nullhypo=0.5), test/testPose3Pose3NH.jl:118):
+   * with probability nullhypo[c] a particle is not constrained by the factor: it keeps its start value and gets
+   * spread_nh · mean-std entropy.  NULL -> 0 everywhere. */
+  const double* nullhypo;
 } rome_conv_dev;
 
 int rome_conv_pose2pose2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);

@@ -23,16 +23,16 @@ def build(force=False):
 class Opts(C.Structure):
     _fields_ = [("n_particles", C.c_int32), ("solver", C.c_int32), ("max_iters", C.c_int32),
                 ("inflate_cycles", C.c_int32), ("tol", C.c_double), ("inflation", C.c_double),
-                ("seed", C.c_uint64), ("stream_offset", C.c_uint64)]
+                ("seed", C.c_uint64), ("stream_offset", C.c_uint64), ("nullhypo", C.c_double), ("spread_nh", C.c_double)]
 
 
 def make_opts(N=100, solver=SOLVER_NEWTON, max_iters=None, inflate_cycles=3, tol=None, inflation=5.0,
-              seed=0x524F4D45, stream_offset=0):
+              seed=0x524F4D45, stream_offset=0, nullhypo=0.0, spread_nh=3.0):
     if max_iters is None:
         max_iters = 1000 if solver == SOLVER_NELDER_MEAD else 20
     if tol is None:
         tol = 1e-8 if solver == SOLVER_NELDER_MEAD else 1e-12
-    return Opts(N, solver, max_iters, inflate_cycles, tol, inflation, seed, stream_offset)
+    return Opts(N, solver, max_iters, inflate_cycles, tol, inflation, seed, stream_offset, nullhypo, spread_nh)
 
 
 _lib = None

@@ -528,6 +528,22 @@ static void se2_add_entropy(double t[3], double spread, const double u[3]) {
 
 static inline int get_idx(const int32_t* a, int c) { return a ? a[c] : c; }
 
+/* nullhypo draw for particle i of stream st: -> 1 if the factor does NOT apply; u[0..d-1] entropy uniforms
+ * (Philox domain 5; block 0: word0 = selector, words 1-3 = u0..u2; block 1: words 0-2 = u3..u5) */
+static int nullhypo_draw(const ro_opts* o, uint64_t st, uint32_t i, int d, double* u) {
+  uint32_t key[2] = {(uint32_t)o->seed, (uint32_t)(o->seed >> 32)};
+  uint32_t ctr[4] = {i, (uint32_t)st, (uint32_t)(st >> 32), (5u << 16)}, w[4];
+  ro_philox4x32_10(ctr, key, w);
+  int isnull = (((double)w[0] + 0.5) * (1.0 / 4294967296.0)) < o->nullhypo;
+  for (int k = 0; k < d && k < 3; ++k) u[k] = ((double)w[1 + k] + 0.5) * (1.0 / 4294967296.0);
+  if (d > 3) {
+    ctr[3] = (5u << 16) | 1u;
+    ro_philox4x32_10(ctr, key, w);
+    for (int k = 3; k < d; ++k) u[k] = ((double)w[k - 3] + 0.5) * (1.0 / 4294967296.0);
+  }
+  return isnull;
+}
+
 int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int32_t* dir,
                        const int32_t* fixed_var, const int32_t* target_var,
                        const double* mu, const double* L, const double* bel, const double* noise,
@@ -553,8 +569,18 @@ int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int
       ob[i] = tb[i]; ob[N + i] = tb[N + i]; ob[2 * N + i] = wrap_pi(tb[2 * N + i]); /* X0c = vee(log(ϵ,u0)) */
       if (status) status[(size_t)c * N + i] = 0;
     }
+    unsigned char* nullh = (unsigned char*)calloc(N, 1);
+    double* nhu = (double*)malloc(sizeof(double) * 3 * N);
+    double nh_spread = 0.0;
+    if (o->nullhypo > 0.0) {
+      double m3[3], s3[3];
+      ro_belief_spread_se2(N, ob, ob + N, ob + 2 * N, m3, s3);
+      nh_spread = N > 1 ? o->spread_nh * (s3[0] + s3[1] + s3[2]) / 3.0 : 0.0;
+      for (int i = 0; i < N; ++i) nullh[i] = (unsigned char)nullhypo_draw(o, o->stream_offset + (uint64_t)c, (uint32_t)i, 3, nhu + 3 * i);
+    }
     if (o->solver == RO_SOLVER_CLOSED_FORM) {
       for (int i = 0; i < N; ++i) {
+        if (nullh[i]) continue;
         double fx[3] = {fb[i], fb[N + i], fb[2 * N + i]}, t[3];
         p2p2_closed(zs + 3 * i, fx, dr, t);
         ob[i] = t[0]; ob[N + i] = t[1]; ob[2 * N + i] = wrap_pi(t[2]);
@@ -568,6 +594,7 @@ int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int
           spread = o->inflation * (std3[0] + std3[1] + std3[2]) / 3.0;
         }
         for (int i = 0; i < N; ++i) {
+          if (nullh[i]) continue;
           double fx[3] = {fb[i], fb[N + i], fb[2 * N + i]};
           double t[3] = {ob[i], ob[N + i], ob[2 * N + i]};
           if (spread > 0.0) {
@@ -588,7 +615,13 @@ int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int
         }
       }
     }
-    free(zs);
+    if (nh_spread > 0.0)
+      for (int i = 0; i < N; ++i) if (nullh[i]) {
+        double t[3] = {ob[i], ob[N + i], ob[2 * N + i]};
+        se2_add_entropy(t, nh_spread, nhu + 3 * i);
+        ob[i] = t[0]; ob[N + i] = t[1]; ob[2 * N + i] = wrap_pi(t[2]);
+      }
+    free(zs); free(nullh); free(nhu);
   }
   return 0;
 }
@@ -858,6 +891,14 @@ int ro_conv_pose3pose3(const ro_opts* o, int C, const int32_t* factor, const int
       for (int k = 0; k < 6; ++k) ob[k * N + i] = c0[k];
       if (status) status[(size_t)c * N + i] = 0;
     }
+    unsigned char* nullh = (unsigned char*)calloc(N, 1);
+    double* nhu = (double*)malloc(sizeof(double) * 6 * N);
+    double nh_spread = 0.0;
+    if (o->nullhypo > 0.0) {
+      double m6[6], s6[6]; ro_belief_spread_se3(N, ob, m6, s6);
+      nh_spread = N > 1 ? o->spread_nh * (s6[0] + s6[1] + s6[2] + s6[3] + s6[4] + s6[5]) / 6.0 : 0.0;
+      for (int i = 0; i < N; ++i) nullh[i] = (unsigned char)nullhypo_draw(o, o->stream_offset + (uint64_t)c, (uint32_t)i, 6, nhu + 6 * i);
+    }
     int ncyc = o->solver == RO_SOLVER_CLOSED_FORM ? 1 : cycles;
     for (int cyc = 0; cyc < ncyc; ++cyc) {
       double spread = 0.0;
@@ -867,6 +908,7 @@ int ro_conv_pose3pose3(const ro_opts* o, int C, const int32_t* factor, const int
       }
       for (int i = 0; i < N; ++i) {
         double fx[6], t[6], F[12], T[12];
+        if (nullh[i]) continue;
         for (int k = 0; k < 6; ++k) { fx[k] = fb[k * N + i]; t[k] = ob[k * N + i]; }
         ro_pose3_point_from_coords(fx, F);
         ro_pose3_point_from_coords(t, T);
@@ -889,7 +931,16 @@ int ro_conv_pose3pose3(const ro_opts* o, int C, const int32_t* factor, const int
         if (status && st) status[(size_t)c * N + i] = st;
       }
     }
-    free(zs);
+    if (nh_spread > 0.0)
+      for (int i = 0; i < N; ++i) if (nullh[i]) {
+        double t[6], T[12];
+        for (int k = 0; k < 6; ++k) t[k] = ob[k * N + i];
+        ro_pose3_point_from_coords(t, T);
+        se3_add_entropy_pt(T, nh_spread, nhu + 6 * i);
+        ro_pose3_coords_from_point(T, t);
+        for (int k = 0; k < 6; ++k) ob[k * N + i] = t[k];
+      }
+    free(zs); free(nullh); free(nhu);
   }
   return 0;
 }

@@ -35,6 +35,8 @@ typedef struct {
   double  inflation;      /* IIF SolverParams.inflation (kappa), default 5.0 ; 0 = off     */
   uint64_t seed;          /* Philox key                                                    */
   uint64_t stream_offset; /* Philox stream id = stream_offset + global convolution index   */
+  double  nullhypo;       /* IIF nullhypo= probability applied to every row of the call (0 = off) */
+  double  spread_nh;      /* IIF spreadNH (3.0)                                              */
 } ro_opts;
 
 /* ---- counter-based RNG (shared definition with the HIP path) ---- */

@@ -27,7 +27,7 @@ class Opts(C.Structure):
     _fields_ = [("n_particles", C.c_int32), ("solver", C.c_int32), ("max_iters", C.c_int32),
                 ("inflate_cycles", C.c_int32), ("tol", C.c_double), ("inflation", C.c_double),
                 ("seed", C.c_uint64), ("stream_offset", C.c_uint64), ("layout", C.c_int32),
-                ("reserved", C.c_int32), ("spread_nh", C.c_double)]
+                ("reserved", C.c_int32), ("spread_nh", C.c_double), ("nullhypo", C.c_double)]
 
 
 class ConvDev(C.Structure):
@@ -36,7 +36,7 @@ class ConvDev(C.Structure):
                 ("mu", C.c_void_p), ("L", C.c_void_p), ("bel_fixed", C.c_void_p), ("bel_target", C.c_void_p),
                 ("noise", C.c_void_p), ("out", C.c_void_p), ("status", C.c_void_p),
                 ("n_mirror", C.c_int32), ("mirror_row", C.c_int32 * 4), ("reserved", C.c_int32), ("mirror_out", C.c_void_p),
-                ("alt_var", C.c_void_p), ("hypo_w", C.c_void_p)]
+                ("alt_var", C.c_void_p), ("hypo_w", C.c_void_p), ("nullhypo", C.c_void_p)]
 
 
 _PD = C.POINTER(C.c_double)

@@ -173,9 +173,10 @@ def cholesky_lower(cov):
 
 
 def make_opts(N=100, solver=_lib.SOLVER_NEWTON, max_iters=None, inflate_cycles=None, tol=None, inflation=None,
-              seed=None, stream_offset=None, layout=None):
+              seed=None, stream_offset=None, layout=None, spread_nh=None, nullhypo=None):
     return _lib.default_opts(solver, n_particles=N, max_iters=max_iters, inflate_cycles=inflate_cycles, tol=tol,
-                             inflation=inflation, seed=seed, stream_offset=stream_offset, layout=layout)
+                             inflation=inflation, seed=seed, stream_offset=stream_offset, layout=layout,
+                             spread_nh=spread_nh, nullhypo=nullhypo)
 
 
 def _blocks(a, C_, N, d, layout, points_ok=True):

@@ -14,7 +14,7 @@ struct rome_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipError_t last_hip = hipSuccess;
-  static constexpr int kBufs = 10;
+  static constexpr int kBufs = 11;
   void* dbuf[kBufs] = {nullptr};
   size_t dcap[kBufs] = {0};
 };
@@ -51,6 +51,7 @@ int check_opts(const rome_opts* o) {
   if (o->solver < ROME_SOLVER_CLOSED_FORM || o->solver > ROME_SOLVER_NELDER_MEAD) return ROME_ERR_INVALID_ARG;
   if (o->max_iters < 1 || o->inflate_cycles < 0 || o->inflate_cycles > 255) return ROME_ERR_INVALID_ARG;
   if (!(o->tol >= 0.0) || !(o->inflation >= 0.0) || !(o->spread_nh >= 0.0)) return ROME_ERR_INVALID_ARG;
+  if (!(o->nullhypo >= 0.0 && o->nullhypo <= 1.0)) return ROME_ERR_INVALID_ARG;
   if (o->layout != ROME_LAYOUT_SOA && o->layout != ROME_LAYOUT_AOS && o->layout != ROME_LAYOUT_AOS_POINTS) return ROME_ERR_INVALID_ARG;
   return ROME_OK;
 }
@@ -80,6 +81,7 @@ void args_from_dev(rome::ConvArgs& a, const rome_opts* o, const rome_conv_dev* t
   a.mirror_out = t->mirror_out;
   a.alt_var = t->hypo_w ? t->alt_var : nullptr;
   a.hypo_w = t->hypo_w;
+  a.nullhypo = t->nullhypo;
 }
 
 int cholesky_one(int d, const double* cov, double* Lp) {
@@ -207,8 +209,16 @@ int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const i
     ROME_HIP(ctx, hipMemcpyAsync(d_alt, h_alt.data(), sizeof(int32_t) * C, hipMemcpyHostToDevice, s));
     ROME_HIP(ctx, hipMemcpyAsync(d_hw, hypo_w, sizeof(double) * C, hipMemcpyHostToDevice, s));
   }
+  void* d_nh = nullptr;
+  if (o->nullhypo > 0.0 && has_fixed) {
+    std::vector<double> h_nh((size_t)C, o->nullhypo);
+    if ((rc = ensure(ctx, 10, sizeof(double) * C, &d_nh))) return rc;
+    ROME_HIP(ctx, hipMemcpyAsync(d_nh, h_nh.data(), sizeof(double) * C, hipMemcpyHostToDevice, s));
+    ROME_HIP(ctx, hipStreamSynchronize(s));  // h_nh goes out of scope
+  }
   rome::ConvArgs a;
   fill_args(a, o);
+  a.nullhypo = (const double*)d_nh;
   a.alt_var = (const int32_t*)d_alt; a.hypo_w = (const double*)d_hw;
   a.n_conv = C; a.dir_all = dir_all; a.dir = (const int32_t*)d_dir;
   a.mu = (const double*)d_mu; a.L = (const double*)d_L;

@@ -26,6 +26,7 @@ struct ConvArgs {
   const int32_t* alt_var;     // [C] bearing-range multihypo: the other landmark candidate (-1: single hypothesis), or nullptr
   const double* hypo_w;       // [C] probability that the table's own landmark is the sighted one
   double spread_nh;           // IIF SolverParams.spreadNH
+  const double* nullhypo;     // [C] probability that the factor does not apply to a particle (IIF nullhypo=), or nullptr
   int n_mirror;               // rows additionally written to mirror_out[m] (separator beliefs -> send buffer)
   int mirror_row[4];
   double* mirror_out;

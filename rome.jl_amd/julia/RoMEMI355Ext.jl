@@ -28,6 +28,7 @@ struct RomeOpts
   layout::Int32          # 0 SoA [block][dim][N], 1 AoS [block][N][dim]
   reserved::Int32
   spread_nh::Float64     # IIF spreadNH
+  nullhypo::Float64      # IIF nullhypo= of the factor(s) in the call
 end
 
 function default_opts(fg::AbstractDFG; solver::Integer=1, seed::Integer=rand(UInt64), stream_offset::Integer=0)
@@ -35,7 +36,7 @@ function default_opts(fg::AbstractDFG; solver::Integer=1, seed::Integer=rand(UIn
   ccall((:rome_opts_default, LIB), Cvoid, (Ref{RomeOpts}, Int32), o, solver)
   p = getSolverParams(fg)
   d = o[]
-  RomeOpts(p.N, d.solver, d.max_iters, p.inflateCycles, d.tol, p.inflation, seed, stream_offset, 1 #=AoS=#, 0, p.spreadNH)
+  RomeOpts(p.N, d.solver, d.max_iters, p.inflateCycles, d.tol, p.inflation, seed, stream_offset, 1 #=AoS=#, 0, p.spreadNH, 0.0)
 end
 
 # ---- context ---------------------------------------------------------------------------------------
@@ -79,7 +80,7 @@ end
 # doubles [tx,ty,R11,R21,R12,R22] per point == ROME_LAYOUT_AOS_POINTS (layout = 2): pass the belief vectors as they are.
 function conv_pose2pose2!(fg, f::Pose2Pose2, fixedpts::Vector{P}, u0pts::Vector{P}, dir::Integer; solver=1) where {P}
   d0 = default_opts(fg; solver)
-  o = RomeOpts(d0.n_particles, d0.solver, d0.max_iters, d0.inflate_cycles, d0.tol, d0.inflation, d0.seed, d0.stream_offset, 2, 0, d0.spread_nh)
+  o = RomeOpts(d0.n_particles, d0.solver, d0.max_iters, d0.inflate_cycles, d0.tol, d0.inflation, d0.seed, d0.stream_offset, 2, 0, d0.spread_nh, d0.nullhypo)
   μ = collect(Float64, mean(f.Z)); Σ = collect(Float64, cov(f.Z))'
   d = Int32[dir]
   GC.@preserve μ Σ fixedpts u0pts d begin

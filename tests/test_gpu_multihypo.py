@@ -103,3 +103,39 @@ def test_multihypo_in_device_graph_solve_vs_oracle():
     assert np.mean(np.abs(_wd(g2, b2)) < 1e-7) > 0.97 and np.mean(np.abs(gl - bl) < 1e-7) > 0.97
     m2, _ = R.belief_stats(g2); mo, _ = R.belief_stats(b2)
     assert np.abs(m2[:, :2] - mo[:, :2]).max() < 1e-3
+
+
+@pytest.mark.parametrize("kind", ["p2p2", "p3p3"])
+def test_nullhypo_vs_oracle_and_fraction(kind):
+    """IIF nullhypo=0.5 (test/testPose3Pose3NH.jl:118): about half of the proposals follow the factor, the rest keep
+    their start value plus spreadNH entropy.  GPU = oracle on the same Philox streams."""
+    rng = np.random.default_rng(3)
+    C_, N = 6, 100
+    if kind == "p2p2":
+        mu = np.tile([-35.0, 0, 0], (C_, 1)); cov = np.tile(np.diag([0.5, 0.5, 0.01]), (C_, 1, 1))
+        fixed = rng.standard_normal((C_, 3, N)) * np.array([1.0, 1.0, 0.05])[None, :, None] + np.array([50.0, 0, 0])[None, :, None]
+        target = rng.standard_normal((C_, 3, N)) * np.array([1.0, 1.0, 0.05])[None, :, None]
+        dirs = np.zeros(C_, np.int32)
+        out = R.conv_pose2pose2(R.make_opts(N=N, solver=1, seed=9, nullhypo=0.5), mu, cov, fixed, target, dirs=dirs)
+        L = np.array([ro.cholesky_lower(c) for c in cov])
+        ref = ro.conv_pose2pose2(ro.make_opts(N=N, solver=1, seed=9, nullhypo=0.5), mu, L, np.concatenate([fixed, target]),
+                                 np.arange(C_), C_ + np.arange(C_), dirs)
+        d = out - ref; d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+        assert np.abs(d).max() < 1e-9
+        follows = np.abs(out[:, 0] - 15.0) < 6.0           # 50 - 35 = 15 along x
+    else:
+        mu = np.tile([-35.0, 0, 0, 0, 0, 0], (C_, 1)); cov = np.tile(np.diag([0.5] * 3 + [0.01] * 3), (C_, 1, 1))
+        sc = np.array([1.0, 1.0, 1.0, 0.05, 0.05, 0.05])[None, :, None]
+        fixed = rng.standard_normal((C_, 6, N)) * sc + np.array([50.0, 0, 0, 0, 0, 0])[None, :, None]
+        target = rng.standard_normal((C_, 6, N)) * sc
+        dirs = np.zeros(C_, np.int32)
+        out = R.conv_pose3pose3(R.make_opts(N=N, solver=1, seed=9, nullhypo=0.5), mu, cov, fixed, target, dirs=dirs)
+        L = np.array([ro.cholesky_lower(c) for c in cov])
+        ref = ro.conv_pose3pose3(ro.make_opts(N=N, solver=1, seed=9, nullhypo=0.5), mu, L, np.concatenate([fixed, target]),
+                                 np.arange(C_), C_ + np.arange(C_), dirs)
+        assert np.abs(out - ref).max() < 1e-8
+        follows = np.abs(out[:, 0] - 15.0) < 6.0
+    frac = follows.mean(axis=1)
+    assert (frac > 0.3).all() and (frac < 0.7).all()
+    # the null-hypothesis share stays spread around the START belief (x ≈ 0), not at the factor's solution
+    assert (np.abs(out[:, 0][~follows]).mean() < 8.0)
