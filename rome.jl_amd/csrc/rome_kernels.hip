@@ -547,7 +547,6 @@ k_conv(const ConvArgs a) {
 #pragma unroll
   for (int k = 0; k < PPL; ++k) nullh[k] = false;
   double nh0_spread = 0.0;
-  double nh_u[PPL][FP::DT];
   const double p_null = a.nullhypo ? a.nullhypo[c] : 0.0;
   if (p_null > 0.0) {  // wave-uniform
     nh0_spread = a.spread_nh * FP::template spread<PPL>(t, act, a.inv_n, a.inv_nm1);
@@ -555,17 +554,8 @@ k_conv(const ConvArgs a) {
     for (int k = 0; k < PPL; ++k) {
       const uint32_t ii = (uint32_t)(act[k] ? lane + 64 * k : 0);
       const u32x4 w0 = philox4x32_10(u32x4{ii, (uint32_t)stream, (uint32_t)(stream >> 32), (5u << 16)}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-      nullh[k] = ((double)w0.x + 0.5) * (1.0 / 4294967296.0) < p_null;
-      const uint32_t e0[3] = {w0.y, w0.z, w0.w};
-#pragma unroll
-      for (int d = 0; d < (FP::DT < 3 ? FP::DT : 3); ++d) nh_u[k][d] = ((double)e0[d] + 0.5) * (1.0 / 4294967296.0);
-      if constexpr (FP::DT > 3) {
-        const u32x4 w1 = philox4x32_10(u32x4{ii, (uint32_t)stream, (uint32_t)(stream >> 32), (5u << 16) | 1u}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-        const uint32_t e1[3] = {w1.x, w1.y, w1.z};
-#pragma unroll
-        for (int d = 3; d < FP::DT; ++d) nh_u[k][d] = ((double)e1[d - 3] + 0.5) * (1.0 / 4294967296.0);
-      }
-    }
+      nullh[k] = ((double)w0.x + 0.5) * (1.0 / 4294967296.0) < p_null;   // (the entropy words are re-drawn after the cycles:
+    }                                                                      //  nothing but this flag stays live across the solve)
   }
 
   const bool cyc_on = FP::needs_cycles(SOLVER, K);
@@ -596,13 +586,25 @@ k_conv(const ConvArgs a) {
     }
   }
 
-  if (p_null > 0.0) {
+  if (p_null > 0.0 && nh0_spread > 0.0) {
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
-      if (act[k] && nullh[k] && nh0_spread > 0.0) {
+      if (act[k] && nullh[k]) {
+        const uint32_t ii = (uint32_t)(lane + 64 * k);
+        const u32x4 w0 = philox4x32_10(u32x4{ii, (uint32_t)stream, (uint32_t)(stream >> 32), (5u << 16)}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+        double u[FP::DT];
+        const uint32_t e0[3] = {w0.y, w0.z, w0.w};
+#pragma unroll
+        for (int d = 0; d < (FP::DT < 3 ? FP::DT : 3); ++d) u[d] = ((double)e0[d] + 0.5) * (1.0 / 4294967296.0);
+        if constexpr (FP::DT > 3) {
+          const u32x4 w1 = philox4x32_10(u32x4{ii, (uint32_t)stream, (uint32_t)(stream >> 32), (5u << 16) | 1u}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+          const uint32_t e1[3] = {w1.x, w1.y, w1.z};
+#pragma unroll
+          for (int d = 3; d < FP::DT; ++d) u[d] = ((double)e1[d - 3] + 0.5) * (1.0 / 4294967296.0);
+        }
         double hs, hc;
         FP::template heading_sincos<SOLVER>(K, prep[k], 1, 0, t[k], &hs, &hc);
-        FP::add_entropy(t[k], nh0_spread, nh_u[k], hs, hc);
+        FP::add_entropy(t[k], nh0_spread, u, hs, hc);
       }
     }
   }
