@@ -90,3 +90,119 @@ def test_shard_helpers_cover_and_balance():
             for i in range(0, n, max(1, n // 50)):
                 a, b = spans[owner_of(i, n, w)]
                 assert a <= i < b
+
+
+# ---------------------------------------------------------------------------------------------------------
+# PipelinedSegmentSweep (the bench's N>1 driver) on CPU: a stand-in "device graph" whose launch plan runs the
+# ORACLE on torch CPU tensors (test infrastructure), so the double-buffered separator pipeline -- mirror rows ->
+# send buffer -> all_gather -> ghost blocks in the tail of the belief store -> cut factors -- is exercised for real
+# over gloo with 2 ranks and compared with a single-process emulation of the same schedule.
+def _segment_problem(R, rank, N):
+    fg = R.synth_manhattan(P=40, loops=3, seed=100 + rank, N=N)
+    cov = np.diag([1 / 44.6, 1 / 399.0, 1 / 9591.0])
+    fg.addVariable("ghost_prev", R.Pose2); fg.addVariable("ghost_next", R.Pose2)
+    fg.addFactor(["ghost_prev", "x0"], R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.0], cov)))
+    fg.addFactor(["x39", "ghost_next"], R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.0], cov)))
+    R.dead_reckon_init(fg, seed=11 + rank)
+    return fg
+
+
+class _OracleDG:
+    """Just enough of DeviceGraph for PipelinedSegmentSweep, on CPU tensors, compute through the oracle."""
+
+    def __init__(self, R, fg, stream_base):
+        import oracle as ro
+        self.torch, self.N, self.R, self.ro = torch, fg.N, R, ro
+        pk = R.PackedGraph(fg)
+        self.packed = pk
+        factor, dr, fixed, target = R.PackedGraph.conv_table(pk.p2p2)
+        F, P = pk.p2p2["F"], pk.prior2["F"]
+        self.mu = np.concatenate([pk.p2p2["mu"], pk.prior2["mu"]]); cov = np.concatenate([pk.p2p2["cov"], pk.prior2["cov"]])
+        self.L = np.array([ro.cholesky_lower(c) for c in cov])
+        i32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.int32))
+        self.tab = {"p2p2": dict(F=F, P=P, C=2 * F + P, C_rel=2 * F, factor=i32(np.concatenate([factor, F + np.arange(P)])),
+                                 dir=i32(np.concatenate([dr, np.full(P, 2)])), fixed=i32(np.concatenate([fixed, pk.prior2["var"]])),
+                                 target=i32(np.concatenate([target, pk.prior2["var"]])), mu=None, L=None)}
+        self.bel = {R.Pose2: torch.as_tensor(pk.beliefs(fg, R.Pose2))}
+        self._lib = type("L", (), {"rome_conv_pose2pose2_dev": None})()
+        self.stream_base = stream_base
+
+    def _plan(self, fn, opts, **kw):
+        ro, N = self.ro, self.N
+        fixed, target, store, out = kw["fixed_var"].numpy(), kw["target_var"].numpy(), kw["bel_fixed"], kw["out"]
+        factor, dr = kw["factor"].numpy(), kw["dir"].numpy()
+        mirror_rows, mirror_out = kw["mirror_row"], kw["mirror_out"]
+        rel = dr != 2
+
+        def launch():
+            o = ro.make_opts(N=N, solver=ro.SOLVER_NEWTON, seed=5, stream_offset=self.stream_base)
+            res = np.zeros((len(dr), 3, N))
+            res[rel] = ro.conv_pose2pose2(o, self.mu, self.L, store.numpy(), fixed[rel], target[rel], dr[rel], factor=factor[rel])
+            # conv_pose2pose2 numbers its Philox streams by position in the call: re-run the prior rows on their own ids
+            for k in np.nonzero(~rel)[0]:
+                ok = ro.make_opts(N=N, seed=5, stream_offset=self.stream_base + int(k))
+                res[k] = ro.sample_priorpose2(ok, self.mu[factor[k]], self.L[factor[k]])[0]
+            out.copy_(torch.as_tensor(res))
+            for m, r in enumerate(mirror_rows):
+                mirror_out[m].copy_(out[r])
+        return launch
+
+
+def _pipe_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import rome_jl_amd as R
+        from rome_jl_amd.distributed import PipelinedSegmentSweep
+        N = 16
+        fg = _segment_problem(R, rank, N)
+        dg = _OracleDG(R, fg, stream_base=rank << 32)
+        pk = dg.packed
+        sep_rows = [1, 2 * (40 - 2)]       # x0 <- (x0->x1, dir 1) ; x39 <- (x38->x39, dir 0)
+        pipe = PipelinedSegmentSweep(dg, None, dist, world, rank, sep_rows, pk.index["ghost_prev"], pk.index["ghost_next"])
+        hist = []
+        for k in range(5):
+            pipe.step()
+            hist.append(pipe.prop.clone())
+        pipe.drain()
+        ret[rank] = [h.numpy() for h in hist]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_pipelined_segment_sweep_two_ranks_matches_single_process_emulation():
+    world = 2
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_pipe_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    # single-process emulation of the same schedule: sweep k of rank r reads the separators its neighbours produced in sweep k-2
+    sys.path.insert(0, ROOT)
+    import rome_jl_amd as R
+    N = 16
+    dgs = []
+    for r in range(world):
+        fg = _segment_problem(R, r, N)
+        dgs.append(_OracleDG(R, fg, stream_base=r << 32))
+    sep_rows = [1, 2 * (40 - 2)]
+    init_ghost = [(d.bel[R.Pose2][d.packed.index["ghost_prev"]].clone(), d.bel[R.Pose2][d.packed.index["ghost_next"]].clone()) for d in dgs]
+    props = [[] for _ in range(world)]
+    for k in range(5):
+        for r, d in enumerate(dgs):
+            pk = d.packed
+            store = d.bel[R.Pose2].clone()
+            if k >= 2:
+                store[pk.index["ghost_prev"]] = torch.as_tensor(props[(r - 1) % world][k - 2][sep_rows[1]])
+                store[pk.index["ghost_next"]] = torch.as_tensor(props[(r + 1) % world][k - 2][sep_rows[0]])
+            else:
+                store[pk.index["ghost_prev"]], store[pk.index["ghost_next"]] = init_ghost[r]
+            tb = d.tab["p2p2"]
+            out = torch.zeros((tb["C"], 3, N), dtype=torch.float64)
+            d._plan(None, None, fixed_var=tb["fixed"], target_var=tb["target"], factor=tb["factor"], dir=tb["dir"],
+                    bel_fixed=store, out=out, mirror_row=(), mirror_out=None)()
+            props[r].append(out.numpy())
+    for r in range(world):
+        for k in range(5):
+            assert np.array_equal(ret[r][k], props[r][k]), (r, k)
+    # the cut factors really see the neighbour: sweep 2 differs from what the initial ghosts would give
+    assert not np.array_equal(ret[0][2], ret[0][0])
