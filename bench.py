@@ -167,6 +167,17 @@ def main():
         except Exception:
             pass
 
+    sfile = os.path.join(ROOT, "profiles", "sq_counters.json")
+    if args.solver == "newton" and os.path.exists(sfile):
+        try:
+            with open(sfile) as f:
+                sj = json.load(f)
+            # context for the low HBM fraction: the kernel is VALU-issue bound (SQ counters, separate rocprofv3 pass)
+            out["roofline"]["valu_busy_frac_pmc"] = sj["derived"]["valu_busy_fraction"]
+            out["roofline"]["valu_instructions_per_wave_pmc"] = sj["derived"]["valu_instructions_per_wave"]
+        except Exception:
+            pass
+
     if rank == 0 and world == 1 and not args.no_modes:
         modes = {}
         for name, sv in (("closed_form", R.SOLVER_CLOSED_FORM), ("newton", R.SOLVER_NEWTON), ("nelder_mead", R.SOLVER_NELDER_MEAD)):
