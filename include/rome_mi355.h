@@ -51,7 +51,7 @@ enum {
   ROME_ERR_ALLOC = -6
 };
 
-#define ROME_MAX_PARTICLES 256
+#define ROME_MAX_PARTICLES 512
 
 /* Solvers for the per-particle root-find (replaces Optim.optimize(cost, X0c, NelderMead()) in IIF
  * `_solveLambdaNumeric`, called for every particle of every convolution):

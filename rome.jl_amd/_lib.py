@@ -13,7 +13,7 @@ OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED_N, ERR_ALLOC = -1, -2, -3, -4, -5, -6
 SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD = 0, 1, 2
 LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS = 0, 1, 2
-MAX_PARTICLES = 256
+MAX_PARTICLES = 512
 FACTOR_PRIORPOSE2, FACTOR_POSE2POSE2, FACTOR_POSE2POINT2BR, FACTOR_PRIORPOINT2, FACTOR_POSE3POSE3, FACTOR_PRIORPOSE3 = range(6)
 
 

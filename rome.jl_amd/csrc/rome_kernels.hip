@@ -788,6 +788,7 @@ static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
   if (a.N <= 64)       hipLaunchKernelGGL((k_conv<FP, SOLVER, 1>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
   else if (a.N <= 128) hipLaunchKernelGGL((k_conv<FP, SOLVER, 2>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
   else if (a.N <= 256) hipLaunchKernelGGL((k_conv<FP, SOLVER, 4>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  else if (a.N <= 512) hipLaunchKernelGGL((k_conv<FP, SOLVER, 8>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -813,6 +814,7 @@ static hipError_t launch_prior(const ConvArgs& a, hipStream_t s) {
   if (a.N <= 64)       hipLaunchKernelGGL((k_sample_prior<D, 1>), dim3(nb), dim3(256), 0, s, a);
   else if (a.N <= 128) hipLaunchKernelGGL((k_sample_prior<D, 2>), dim3(nb), dim3(256), 0, s, a);
   else if (a.N <= 256) hipLaunchKernelGGL((k_sample_prior<D, 4>), dim3(nb), dim3(256), 0, s, a);
+  else if (a.N <= 512) hipLaunchKernelGGL((k_sample_prior<D, 8>), dim3(nb), dim3(256), 0, s, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -15,7 +15,8 @@
 
 namespace rome {
 
-constexpr int kProdMaxN = 256;
+constexpr int kProdMaxN = 512;
+constexpr int kProdSlots = kProdMaxN / 64;
 
 template <int D>
 __device__ __forceinline__ double tangent_diff(int k, double a, double b) {
@@ -130,10 +131,11 @@ __global__ void __launch_bounds__(64) k_product(const ProductArgs a) {
     if (ln < best) { best = ln; base = l; }
   }
   const double* Pb = a.prop + (size_t)a.prop_rows[r0 + base] * D * N;
-  // pass 2: log weights of the base particles (lane owns particles lane, lane+64, ...; N <= 256 -> 4 slots)
-  double x[4][D], lw[4];
+  // pass 2: log weights of the base particles (lane owns particles lane, lane+64, ...; N <= 512 -> 8 slots)
+  constexpr int S = kProdSlots;
+  double x[S][D], lw[S];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < S; ++s) {
     const int i = lane + 64 * s;
     lw[s] = 0.0;
 #pragma unroll
@@ -152,15 +154,15 @@ __global__ void __launch_bounds__(64) k_product(const ProductArgs a) {
       for (int k = 0; k < D; ++k) pts[k][i] = P[k * N + i];
     }
     __syncthreads();
-    double qmin[4], sacc[4];
+    double qmin[S], sacc[S];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { qmin[s] = __builtin_inf(); sacc[s] = 0.0; }
+    for (int s = 0; s < S; ++s) { qmin[s] = __builtin_inf(); sacc[s] = 0.0; }
     for (int j = 0; j < N; ++j) {
       double y[D];
 #pragma unroll
       for (int k = 0; k < D; ++k) y[k] = pts[k][j];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < S; ++s) {
         double q = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) { const double d = tangent_diff<D>(k, x[s][k], y[k]) * ih[k]; q += d * d; }
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(64) k_product(const ProductArgs a) {
 #pragma unroll
       for (int k = 0; k < D; ++k) y[k] = pts[k][j];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < S; ++s) {
         if (lane + 64 * s < N) {  // skip idle slots (keeps exp() off them)
           double q = 0.0;
 #pragma unroll
@@ -182,17 +184,17 @@ __global__ void __launch_bounds__(64) k_product(const ProductArgs a) {
       }
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) if (lane + 64 * s < N) lw[s] += -0.5 * qmin[s] + log(sacc[s]);
+    for (int s = 0; s < S; ++s) if (lane + 64 * s < N) lw[s] += -0.5 * qmin[s] + log(sacc[s]);
   }
   // normalise, publish weights in particle order
   double mx = -__builtin_inf();
 #pragma unroll
-  for (int s = 0; s < 4; ++s) if (lane + 64 * s < N) mx = fmax(mx, lw[s]);
+  for (int s = 0; s < S; ++s) if (lane + 64 * s < N) mx = fmax(mx, lw[s]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
   __syncthreads();
 #pragma unroll
-  for (int s = 0; s < 4; ++s) if (lane + 64 * s < N) wts[lane + 64 * s] = exp(lw[s] - mx);
+  for (int s = 0; s < S; ++s) if (lane + 64 * s < N) wts[lane + 64 * s] = exp(lw[s] - mx);
   __syncthreads();
   // systematic resampling: sequential scan in particle order (same arithmetic order as a CPU loop)
   double T = 0.0;
@@ -201,17 +203,17 @@ __global__ void __launch_bounds__(64) k_product(const ProductArgs a) {
   const u32x4 uw = philox4x32_10(u32x4{0xFFFFFFFFu, (uint32_t)stream, (uint32_t)(stream >> 32), (3u << 16)},
                                  (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
   const double u = ((double)uw.x + 0.5) * (1.0 / 4294967296.0);
-  double tau[4]; int pick[4]; bool found[4];
+  double tau[S]; int pick[S]; bool found[S];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) { tau[s] = ((double)(lane + 64 * s) + u) * T / (double)N; pick[s] = N - 1; found[s] = false; }
+  for (int s = 0; s < S; ++s) { tau[s] = ((double)(lane + 64 * s) + u) * T / (double)N; pick[s] = N - 1; found[s] = false; }
   double cum = 0.0;
   for (int m = 0; m < N; ++m) {
     cum += wts[m];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) if (!found[s] && cum > tau[s]) { pick[s] = m; found[s] = true; }
+    for (int s = 0; s < S; ++s) if (!found[s] && cum > tau[s]) { pick[s] = m; found[s] = true; }
   }
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < S; ++s) {
     const int i = lane + 64 * s;
     if (i < N) {
       double xi[D];

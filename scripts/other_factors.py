@@ -21,7 +21,7 @@ for name, sv, reps in (("closed_form", 0, 20), ("newton", 1, 20), ("nelder_mead"
     ms = timeit(lambda: dg.sweep_pose3pose3(o, out=out), reps)
     print("Pose3Pose3 helix: %6d convs %-11s %9.3f ms/sweep  %.3e conv/s  %7.1f GB/s algorithmic" % (tb["C"], name, ms, tb["C"] / ms * 1e3, tb["C_rel"] * 100 * 144 / ms / 1e6))
 del dg
-fg = R.synth_mit_br(P=808, n_landmarks=2000, N=100); R.dead_reckon_init(fg, seed=4)
+fg = R.synth_mit_br(P=8080, n_landmarks=2000, N=100); R.dead_reckon_init(fg, seed=4)
 dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
 F = dg.tab["br"]["F"]
 for d in (0, 1):

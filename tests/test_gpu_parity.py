@@ -102,7 +102,7 @@ def _oracle_p2(solver, N, mu, cov, fixed, target, dirs, noise, **kw):
     return ro.conv_pose2pose2(o, mu, L, bel, np.arange(C_), C_ + np.arange(C_), dirs, noise=noise, want_status=True)
 
 
-@pytest.mark.parametrize("N", [1, 7, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("N", [1, 7, 64, 100, 128, 200, 256, 300, 512])
 @pytest.mark.parametrize("solver", [0, 1])
 def test_pose2pose2_presampled_vs_oracle(N, solver):
     C_ = 37
