@@ -1,0 +1,114 @@
+"""The reference's own solved factor graph (tests/golden/manhattan500_reference_solve.npz, extracted from the data artefact
+examples/fg-after-solve.tar.gz by tests/golden/make_manhattan500_fixture.py; SURVEY §8(c) row "Artefact") against the HIP
+path.  361 Pose2 beliefs x 100 posterior particles from a reference `solveTree!`, 500 Pose2Pose2 + 1 PriorPose2 factors.
+
+The reference posterior is a particle approximation from an early solver version (its point estimates leave 74 of the 500
+factors with a whitened residual² > 20), so it pins the path statistically, at the level the hot path works at: convolving
+the reference's belief of one variable through a factor must give a proposal that the reference's belief of the other
+variable is consistent with."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+R = None
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manhattan500_reference_solve.npz")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _pkg():
+    global R
+    import rome_jl_amd
+    R = rome_jl_amd
+    R.default_context()
+    yield
+
+
+def wrap(a):
+    return np.arctan2(np.sin(a), np.cos(a))
+
+
+def stats(P):
+    """P [..., 3, N] -> mean [..., 3], std [..., 3] with a circular third coordinate."""
+    th = np.arctan2(np.sin(P[..., 2, :]).mean(-1), np.cos(P[..., 2, :]).mean(-1))
+    m = np.stack([P[..., 0, :].mean(-1), P[..., 1, :].mean(-1), th], -1)
+    sd = np.stack([P[..., 0, :].std(-1), P[..., 1, :].std(-1), wrap(P[..., 2, :] - th[..., None]).std(-1)], -1)
+    return m, sd
+
+
+def _graph():
+    d = np.load(FIX)
+    ref = np.ascontiguousarray(d["particles"].astype(np.float64).transpose(0, 2, 1))  # [V, 3, N]
+    V, _, N = ref.shape
+    pk = R.PackedGraph.from_pose2_tables(N, V, d["mu"], d["cov"], d["edges"][:, 0], d["edges"][:, 1],
+                                         prior_mu=d["prior_mu"][None], prior_cov=d["prior_cov"][None], prior_var=[0])
+    return d, ref, pk
+
+
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_convolutions_of_reference_beliefs_are_consistent_with_reference_posterior(solver):
+    import torch
+    d, ref, pk = _graph()
+    V, _, N = ref.shape
+    dg = R.DeviceGraph(pk)
+    dg.bel[R.Pose2][:V].copy_(torch.as_tensor(ref))
+    tb = dg.tab["p2p2"]
+    C = tb["C"]
+    out = torch.empty((C, 3, N), dtype=torch.float64, device="cuda")
+    status = torch.zeros((C, N), dtype=torch.int32, device="cuda")
+    dg.sweep_pose2pose2(R.make_opts(N=N, solver=solver, seed=2020), out=out, status=status)
+    torch.cuda.synchronize()
+    assert int(status.sum()) == 0
+    prop = out.cpu().numpy()
+    target = tb["target"].cpu().numpy()
+    rel = np.nonzero(tb["dir"].cpu().numpy() != 2)[0]   # the fused prior row is checked separately below
+    assert len(rel) == 1000
+    m_prop, sd_prop = stats(prop[rel])
+    m_post, sd_post = stats(ref[target[rel]])
+    dz = m_post - m_prop
+    dz[:, 2] = wrap(dz[:, 2])
+    z = np.abs(dz) / sd_prop
+    # reference posterior means sit inside the proposals: measured median |z| ≈ (0.25, 0.23, 0.33), 95 % ≈ (0.9, 0.9, 1.8)
+    assert (np.median(z, axis=0) < 0.6).all(), np.median(z, axis=0)
+    assert (np.percentile(z, 95, axis=0) < 2.5).all(), np.percentile(z, 95, axis=0)
+    assert (z < 3.0).mean() > 0.98
+    # a posterior is a product of (on average two to three) such proposals: tighter than one of them, not collapsed
+    ratio = np.median(sd_post / sd_prop, axis=0)
+    assert (ratio > 0.5).all() and (ratio < 0.95).all(), ratio
+    # prior row: samples of the PriorPose2 on x0 against the reference's x0 belief
+    pr = np.nonzero(tb["dir"].cpu().numpy() == 2)[0]
+    assert len(pr) == 1 and target[pr[0]] == 0
+    m0, s0 = stats(prop[pr[0]])
+    assert np.allclose(m0, d["prior_mu"], atol=4 * np.sqrt(np.diag(d["prior_cov"]) / N).max() + 1e-3)
+    mref, _ = stats(ref[0])
+    assert (np.abs(mref - m0) < 1.0 * np.sqrt(np.diag(d["prior_cov"]))).all()
+
+
+def test_parametric_solution_explains_the_factors_better_than_the_reference_point_estimates():
+    d, ref, _ = _graph()
+    V, _, N = ref.shape
+    fg = R.initfg(N)
+    for k in range(V):
+        fg.addVariable("x%d" % k, R.Pose2)
+    fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(d["prior_mu"], d["prior_cov"])))
+    for (i, j), m, c in zip(d["edges"], d["mu"], d["cov"]):
+        fg.addFactor(["x%d" % i, "x%d" % j], R.Pose2Pose2(R.MvNormal(m, c)))
+    R.dead_reckon_init(fg, seed=1)
+    xp = R.solveGraphParametric(fg)
+    X = np.array([xp["x%d" % k] for k in range(V)])
+
+    def chi2(X):
+        p, q = X[d["edges"][:, 0]], X[d["edges"][:, 1]]
+        c, s = np.cos(p[:, 2]), np.sin(p[:, 2])
+        r = np.stack([p[:, 0] + c * d["mu"][:, 0] - s * d["mu"][:, 1] - q[:, 0],
+                      p[:, 1] + s * d["mu"][:, 0] + c * d["mu"][:, 1] - q[:, 1], wrap(p[:, 2] + d["mu"][:, 2] - q[:, 2])], 1)
+        return np.einsum("fi,fij,fj->f", r, np.linalg.inv(d["cov"]), r)
+
+    ours, theirs = chi2(X), chi2(d["ppe"][:, 0])
+    assert theirs.sum() > 1e5            # 3.8e5: the reference solve is not a converged MAP estimate
+    assert ours.sum() < 0.05 * theirs.sum()
+    # the two solutions describe the same trajectory (prior-anchored at x0; the reference drifts by metres, not tens)
+    dxy = X[:, :2] - d["ppe"][:, 0, :2]
+    assert np.sqrt((dxy ** 2).sum(1).mean()) < 3.0
+    assert np.abs(wrap(X[:, 2] - d["ppe"][:, 0, 2])).max() < 0.4
