@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import (Context, Opts, RomeError, SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD,
                    LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS, MAX_PARTICLES)
 from .factors import (MvNormal, Normal, Uniform, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
-                      Pose3Pose3, PriorPose3, PriorPoint2, getMeasurementParametric, getPoint, getCoordinates, pack_factor,
+                      Pose3Pose3, PriorPose3, PriorPoint2, Point2Point2, getMeasurementParametric, getPoint, getCoordinates, pack_factor,
                       unpack_factor)
 from .api import (linearize, belief_stats, points_to_coords, coords_to_points, calcFactorResidualTemporary, make_opts, cholesky_lower, default_context,
                   residual_pose2pose2, residual_priorpose2, residual_pose2point2br, residual_pose2point2br_pt,
@@ -18,6 +18,9 @@ from .api import (linearize, belief_stats, points_to_coords, coords_to_points, c
 from .graph import (FactorGraph, initfg, importG2o, parseG2oInstruction, loadG2o, synth_manhattan,
                     synth_manhattan_edges, synth_pose2_tables, synth_helix3d, synth_mit_br, dead_reckon_init_pose3, generateGraph_Circle, generateGraph_Hexagonal,
                     PackedGraph, dead_reckon_init)
+from .canonical import (generateGraph_ZeroPose, buildGraphChain, generateGraph_TwoPoseOdo, calcHelix_T, generateGraph_Helix2D,
+                        generateGraph_Helix2DSlew, generateGraph_Helix2DSpiral, generateGraph_Boxes2D, generateGraph_Beehive,
+                        generateGraph_Honeycomb, exportG2o, stringG2o, getPPE)
 from .convolution import approxConv, approxConvBelief
 from .parametric import solveGraphParametric, initParametric
 from .device import DeviceGraph

@@ -153,6 +153,18 @@ class PriorPoint2(_PriorFactor):
             raise ValueError("PriorPoint2 needs a 2-dimensional belief")
 
 
+class Point2Point2(_RelativeFactor):
+    """Translation between two `Point2` variables (src/factors/Point2D.jl:23-43).  Host-side type only: the box
+    generator builds graphs with it; it is not one of the hot-path factor kinds, so packing a graph that holds one for
+    the device raises."""
+    variable_types = (Point2, Point2)
+
+    def __init__(self, Z=None):
+        self.Z = Z if Z is not None else MvNormal(np.zeros(2), np.eye(2))
+        if self.Z.mu.size != 2:
+            raise ValueError("Point2Point2 needs a 2-dimensional belief")
+
+
 def getMeasurementParametric(f):
     """(μ, iΣ) as IIF.getMeasurementParametric; BearingRange override at BearingRange2D.jl:30-37."""
     if isinstance(f, Pose2Point2BearingRange):
