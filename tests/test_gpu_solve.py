@@ -139,3 +139,31 @@ def test_manhattan_pipeline_parametric_init_then_sweeps():
     e = rms(m.cpu().numpy()[:, :2])
     assert e_param < 0.5 and e < 1.3 * e_param + 0.05 and e < 0.5 * e_init, (e_init, e_param, e)
     assert (sd.cpu().numpy() > 0).all()
+
+
+def test_honeycomb_grow_and_solve_windows():
+    """test/testBeehiveGrow.jl:20-48: honeycomb grown 7 -> 14 -> 21 poses (16 landmarks sighted at bearing 0 / 20 m,
+    re-sighted on every lap), solved on the device after each growth step; the reference's acceptance windows:
+    l11 ≈ (5, 10 sin π/3) ± 6, l0 ≈ (20, 0) ± 4, l7 ≈ (20, −20 sin π/3) ± 6, x21 ≈ (10, −20 sin π/3) ± 4 (skipped there)."""
+    N = 100
+    fg = None
+    for target in (7, 14, 21):
+        fg = R.generateGraph_Honeycomb(target, fg=fg, N=N)
+        R.dead_reckon_init(fg, seed=target)
+        dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+        dg.solve(R.make_opts(N=N, solver=1, seed=100 + target), n_sweeps=15)
+        dg.download_beliefs(fg)
+    lm, _ = dg.belief_stats(R.Point2); pm, _ = dg.belief_stats(R.Pose2)
+    lm, pm = lm.cpu().numpy(), pm.cpu().numpy()
+    li = {l: k for k, l in enumerate(dg.packed.labels[R.Point2])}
+    pi = {l: k for k, l in enumerate(dg.packed.labels[R.Pose2])}
+    s3 = np.sin(np.pi / 3)
+    assert np.allclose(lm[li["l11"]], [5, 10 * s3], atol=6)
+    assert np.allclose(lm[li["l0"]], [20, 0], atol=4)
+    assert np.allclose(lm[li["l7"]], [20, -20 * s3], atol=6)
+    assert np.allclose(pm[pi["x21"]][:2], [10, -20 * s3], atol=4)
+    # and every estimate is near its simulated position (much tighter than the reference's windows)
+    for l, k in li.items():
+        assert np.hypot(*(lm[k] - R.getPPE(fg, l))) < 2.5, (l, lm[k], R.getPPE(fg, l))
+    for l, k in pi.items():
+        assert np.hypot(*(pm[k][:2] - R.getPPE(fg, l)[:2])) < 2.5, (l, pm[k], R.getPPE(fg, l))
