@@ -1030,25 +1030,19 @@ int ro_product(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const 
       for (int l = 0; l < K; ++l) {
         if (l == base) continue;
         const double* P = prop + (size_t)rows[l] * dim * N;
-        double qmin = INFINITY;
+        /* running log-sum-exp in particle order: sacc = Σ_j exp(-½(q_j - qmin)), qmin = smallest q so far */
+        double qmin = INFINITY, sacc = 0.0;
         for (int j = 0; j < N; ++j) {
           double q = 0.0;
           for (int k = 0; k < dim; ++k) {
             double d = x[k] - P[k * N + j];
             if (dim == 3 && k == 2) d = wrap_diff(d);
-            d /= h[l * dim + k]; q += d * d;
+            d *= 1.0 / h[l * dim + k]; q += d * d;
           }
+          const double dq = q - qmin;
+          const double e = exp(-0.5 * fabs(dq));
+          sacc = dq < 0.0 ? fma(sacc, e, 1.0) : sacc + e;
           if (q < qmin) qmin = q;
-        }
-        double sacc = 0.0;
-        for (int j = 0; j < N; ++j) {
-          double q = 0.0;
-          for (int k = 0; k < dim; ++k) {
-            double d = x[k] - P[k * N + j];
-            if (dim == 3 && k == 2) d = wrap_diff(d);
-            d /= h[l * dim + k]; q += d * d;
-          }
-          sacc += exp(-0.5 * (q - qmin));
         }
         acc += -0.5 * qmin + log(sacc);
       }

@@ -87,6 +87,30 @@ __device__ __forceinline__ double fast_log(double x) {
   return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
+// exp(x) for x <= 0 (kernel-density weights): k = rint(x·log2 e), r = x − k·ln2 (two-part), degree-12 Taylor on
+// |r| <= ln2/2 (truncation 1.7e-16), scaled by 2^k with v_ldexp_f64.  ≈ 20 VALU instructions, <= 2 ulp;
+// arguments below −750 (including −inf) return 0.
+__device__ __forceinline__ double fast_exp_neg(double x) {
+  x = fmax(x, -750.0);
+  const double k = rint(x * 1.4426950408889634);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 2.08767569878680989792e-09;                 // 1/12!
+  p = fma(p, r, 2.50521083854417187751e-08);             // 1/11!
+  p = fma(p, r, 2.75573192239858906526e-07);             // 1/10!
+  p = fma(p, r, 2.75573192239858906526e-06);             // 1/9!
+  p = fma(p, r, 2.48015873015873015873e-05);             // 1/8!
+  p = fma(p, r, 1.98412698412698412698e-04);             // 1/7!
+  p = fma(p, r, 1.38888888888888888889e-03);             // 1/6!
+  p = fma(p, r, 8.33333333333333333333e-03);             // 1/5!
+  p = fma(p, r, 4.16666666666666666667e-02);             // 1/4!
+  p = fma(p, r, 1.66666666666666666667e-01);             // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)k);
+}
+
 // ------------------------------------------------------------------------------------------
 // Philox4x32-10 (Random123).  Integer only -> bit-identical to any other conforming implementation.
 // ------------------------------------------------------------------------------------------

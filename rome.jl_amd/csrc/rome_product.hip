@@ -7,16 +7,14 @@
 //    of the K kernel density estimates.  This is a STAND-IN for ApproxManifoldProducts.manifoldProduct
 //    (unvendored multiscale Gibbs product): the definition is the one in
 //    oracle/rome_oracle.c (ro_product) and is only claimed statistically against the reference.
-// One wave (64-thread block) per variable; kernel points of one proposal are staged in LDS and read back with
-// wave-uniform (broadcast) addresses; weights are scanned in particle order so the resampling picks are the
-// same as a sequential CPU scan.
+// Belief statistics: one wave (64-thread block) per variable.  Product: one 256-thread block per variable (see
+// k_product); weights are scanned in particle order so the resampling picks are the same as a sequential CPU scan.
 #include "rome_device_math.hpp"
 #include "rome_kernels.h"
 
 namespace rome {
 
 constexpr int kProdMaxN = 512;
-constexpr int kProdSlots = kProdMaxN / 64;
 
 template <int D>
 __device__ __forceinline__ double tangent_diff(int k, double a, double b) {
@@ -101,120 +99,180 @@ struct ProductArgs {
   uint64_t seed, stream_offset;
 };
 
-template <int D>
-__global__ void __launch_bounds__(64) k_product(const ProductArgs a) {
-  __shared__ double pts[D][kProdMaxN];
-  __shared__ double wts[kProdMaxN];
+// One 256-thread block (4 wavefronts) per variable.  The K-1 non-base proposals are dealt round-robin to the four
+// waves -- a variable with many proposals (loop-closure hubs: K up to ~11 on Manhattan) no longer serialises them in
+// one wave.  Inside a wave, lane l owns base particles l, l+64, ... (S slots, N <= 64·S) and walks the N kernel points
+// of its proposal with wave-uniform (scalar-cache) loads; the per-proposal log-weight contributions go to LDS and are
+// summed per particle in proposal order, so the arithmetic order -- and the resampling picks -- are those of the
+// sequential definition in oracle/rome_oracle.c (ro_product).
+constexpr int kProdWaves = 4;
+constexpr int kProdChunk = 8;   // proposals whose contributions are buffered in LDS at a time
+constexpr int kProdMaxK = 32;   // proposals whose bandwidths are kept in LDS (more: recomputed where needed)
+
+template <int D, int S>
+__global__ void __launch_bounds__(64 * kProdWaves) k_product(const ProductArgs a) {
+  constexpr int T4 = (S + kProdWaves - 1) / kProdWaves;   // particles per thread in the block-wide phases
+  constexpr bool kStage = S <= 4;   // N <= 256: every wave stages the points of its proposal in its own LDS region
+  __shared__ double pts[kStage ? kProdWaves : 1][D][kStage ? 64 * S : 1];
+  __shared__ double contrib[kProdChunk][64 * S];
+  __shared__ double wts[64 * S];
+  __shared__ double red[kProdWaves];
+  __shared__ double ihbuf[kProdMaxK][D];
+  __shared__ double lnbuf[kProdMaxK];
   const int v = blockIdx.x;
   if (v >= a.V) return;
-  const int lane = threadIdx.x, N = a.N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), N = a.N;
   const int r0 = a.prop_ptr[v], K = a.prop_ptr[v + 1] - r0;
   double* ob = a.bel_out + (size_t)v * D * N;
   if (K <= 1) {
     const double* src = K == 0 ? a.bel_in + (size_t)v * D * N : a.prop + (size_t)a.prop_rows[r0] * D * N;
-    for (int i = lane; i < D * N; i += 64) ob[i] = src[i];
+    for (int i = tid; i < D * N; i += 64 * kProdWaves) ob[i] = src[i];
     return;
   }
-  // pass 1: bandwidths, base proposal, product bandwidth
+  // pass 1: bandwidths (proposals dealt to the waves, exchanged through LDS), base proposal, product bandwidth
   int base = 0;
   double best = __builtin_inf();
   double hp_acc[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) hp_acc[k] = 0.0;
-  for (int l = 0; l < K; ++l) {
-    const double* P = a.prop + (size_t)a.prop_rows[r0 + l] * D * N;
-    double x0[D], moff[D], sd[D];
-    block_stats<D>(P, N, a.inv_n, a.inv_nm1, lane, x0, moff, sd);
-    double ln = 0.0;
+  for (int l0 = 0; l0 < K; l0 += kProdMaxK) {
+    const int cnt = min(kProdMaxK, K - l0);
+    for (int c = wave; c < cnt; c += kProdWaves) {
+      const double* P = a.prop + (size_t)a.prop_rows[r0 + l0 + c] * D * N;
+      double x0[D], moff[D], sd[D];
+      block_stats<D>(P, N, a.inv_n, a.inv_nm1, lane, x0, moff, sd);
+      double ln = 0.0;
 #pragma unroll
-    for (int k = 0; k < D; ++k) { const double h = fmax(a.c_n * sd[k], 1e-6); ln += log(h); hp_acc[k] += 1.0 / (h * h); }
-    if (ln < best) { best = ln; base = l; }
+      for (int k = 0; k < D; ++k) {
+        const double h = fmax(a.c_n * sd[k], 1e-6);
+        ln += fast_log(h);
+        if (lane == 0) ihbuf[c][k] = 1.0 / h;
+      }
+      if (lane == 0) lnbuf[c] = ln;
+    }
+    __syncthreads();
+    for (int c = 0; c < cnt; ++c) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) { const double ih = ihbuf[c][k]; hp_acc[k] = fma(ih, ih, hp_acc[k]); }
+      const double ln = lnbuf[c];
+      if (ln < best) { best = ln; base = l0 + c; }
+    }
+    if (l0 + kProdMaxK < K) __syncthreads();   // the buffers are reused by the next chunk
   }
-  const double* Pb = a.prop + (size_t)a.prop_rows[r0 + base] * D * N;
-  // pass 2: log weights of the base particles (lane owns particles lane, lane+64, ...; N <= 512 -> 8 slots)
-  constexpr int S = kProdSlots;
-  double x[S][D], lw[S];
+  const bool h_cached = K <= kProdMaxK;        // single chunk: ihbuf still holds every proposal's 1/h
+  const double* __restrict__ Pb = a.prop + (size_t)a.prop_rows[r0 + base] * D * N;
+  // pass 2: log weights of the base particles
+  double x[S][D];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int i = lane + 64 * s;
-    lw[s] = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) x[s][k] = Pb[k * N + (i < N ? i : 0)];
   }
-  for (int l = 0; l < K; ++l) {
-    if (l == base) continue;
-    const double* P = a.prop + (size_t)a.prop_rows[r0 + l] * D * N;
-    double x0[D], moff[D], sd[D], ih[D];
-    block_stats<D>(P, N, a.inv_n, a.inv_nm1, lane, x0, moff, sd);
+  double lw[T4];
 #pragma unroll
-    for (int k = 0; k < D; ++k) ih[k] = 1.0 / fmax(a.c_n * sd[k], 1e-6);
-    __syncthreads();
-    for (int i = lane; i < N; i += 64) {
+  for (int s = 0; s < T4; ++s) lw[s] = 0.0;
+  for (int c0 = 0; c0 < K - 1; c0 += kProdChunk) {          // chunk of non-base proposals c0 .. c0+cnt-1
+    const int cnt = min(kProdChunk, K - 1 - c0);
+    for (int c = wave; c < cnt; c += kProdWaves) {
+      const int nb = c0 + c, l = nb < base ? nb : nb + 1;   // nb-th non-base proposal
+      const double* __restrict__ P = a.prop + (size_t)a.prop_rows[r0 + l] * D * N;
+      double ih[D];
+      if (h_cached) {
 #pragma unroll
-      for (int k = 0; k < D; ++k) pts[k][i] = P[k * N + i];
-    }
-    __syncthreads();
-    double qmin[S], sacc[S];
+        for (int k = 0; k < D; ++k) ih[k] = ihbuf[l][k];
+      } else {
+        double x0[D], moff[D], sd[D];
+        block_stats<D>(P, N, a.inv_n, a.inv_nm1, lane, x0, moff, sd);
 #pragma unroll
-    for (int s = 0; s < S; ++s) { qmin[s] = __builtin_inf(); sacc[s] = 0.0; }
-    for (int j = 0; j < N; ++j) {
-      double y[D];
-#pragma unroll
-      for (int k = 0; k < D; ++k) y[k] = pts[k][j];
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        double q = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) { const double d = tangent_diff<D>(k, x[s][k], y[k]) * ih[k]; q += d * d; }
-        qmin[s] = fmin(qmin[s], q);
+        for (int k = 0; k < D; ++k) ih[k] = 1.0 / fmax(a.c_n * sd[k], 1e-6);
       }
-    }
-    for (int j = 0; j < N; ++j) {
-      double y[D];
+      double qmin[S], sacc[S];
 #pragma unroll
-      for (int k = 0; k < D; ++k) y[k] = pts[k][j];
+      for (int s = 0; s < S; ++s) { qmin[s] = __builtin_inf(); sacc[s] = 0.0; }
+      // one pass, running log-sum-exp: sacc = Σ_j exp(-½(q_j - qmin)) with qmin the smallest q seen so far
+      if constexpr (kStage) {   // wave-private LDS region: only wave-level ordering is needed
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-        if (lane + 64 * s < N) {  // skip idle slots (keeps exp() off them)
-          double q = 0.0;
+        for (int s = 0; s < S; ++s) {
+          const int i = lane + 64 * s;
+          if (i < N) {
 #pragma unroll
-          for (int k = 0; k < D; ++k) { const double d = tangent_diff<D>(k, x[s][k], y[k]) * ih[k]; q += d * d; }
-          sacc[s] += exp(-0.5 * (q - qmin[s]));
+            for (int k = 0; k < D; ++k) pts[wave][k][i] = P[k * N + i];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      }
+      for (int j = 0; j < N; ++j) {
+        double y[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) y[k] = kStage ? pts[kStage ? wave : 0][k][kStage ? j : 0] : P[k * N + j];   // wave-uniform address
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          if (lane + 64 * s < N) {  // skip idle slots (keeps exp() off them)
+            double q = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) { const double d = tangent_diff<D>(k, x[s][k], y[k]) * ih[k]; q += d * d; }
+            const double dq = q - qmin[s];
+            const double e = fast_exp_neg(-0.5 * fabs(dq));
+            sacc[s] = dq < 0.0 ? fma(sacc[s], e, 1.0) : sacc[s] + e;
+            qmin[s] = fmin(qmin[s], q);
+          }
         }
       }
-    }
 #pragma unroll
-    for (int s = 0; s < S; ++s) if (lane + 64 * s < N) lw[s] += -0.5 * qmin[s] + log(sacc[s]);
+      for (int s = 0; s < S; ++s) if (lane + 64 * s < N) contrib[c][lane + 64 * s] = -0.5 * qmin[s] + fast_log(sacc[s]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < T4; ++s) {
+      const int i = tid + 64 * kProdWaves * s;
+      if (i < N) for (int c = 0; c < cnt; ++c) lw[s] += contrib[c][i];   // proposal order
+    }
+    __syncthreads();
   }
   // normalise, publish weights in particle order
   double mx = -__builtin_inf();
 #pragma unroll
-  for (int s = 0; s < S; ++s) if (lane + 64 * s < N) mx = fmax(mx, lw[s]);
+  for (int s = 0; s < T4; ++s) if (tid + 64 * kProdWaves * s < N) mx = fmax(mx, lw[s]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  if (lane == 0) red[wave] = mx;
   __syncthreads();
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 #pragma unroll
-  for (int s = 0; s < S; ++s) if (lane + 64 * s < N) wts[lane + 64 * s] = exp(lw[s] - mx);
+  for (int s = 0; s < T4; ++s) { const int i = tid + 64 * kProdWaves * s; if (i < N) wts[i] = exp(lw[s] - mx); }
   __syncthreads();
-  // systematic resampling: sequential scan in particle order (same arithmetic order as a CPU loop)
-  double T = 0.0;
-  for (int m = 0; m < N; ++m) T += wts[m];
+  // systematic resampling: cumulative weights by a sequential scan in particle order (one wave; same arithmetic
+  // order as a CPU loop), then every thread looks its picks up by bisection (first m with cum[m] > τ, else N-1)
+  if (wave == 0) {
+    double cum = 0.0;
+    for (int m = 0; m < N; ++m) {
+      cum += wts[m];
+      if (lane == (m & 63)) contrib[0][m] = cum;   // contrib is free again: reuse its first row
+    }
+  }
+  __syncthreads();
+  const double* cumw = contrib[0];
+  const double T = cumw[N - 1];
   const uint64_t stream = a.stream_offset + (uint64_t)v;
   const u32x4 uw = philox4x32_10(u32x4{0xFFFFFFFFu, (uint32_t)stream, (uint32_t)(stream >> 32), (3u << 16)},
                                  (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
   const double u = ((double)uw.x + 0.5) * (1.0 / 4294967296.0);
-  double tau[S]; int pick[S]; bool found[S];
+  int pick[T4];
 #pragma unroll
-  for (int s = 0; s < S; ++s) { tau[s] = ((double)(lane + 64 * s) + u) * T / (double)N; pick[s] = N - 1; found[s] = false; }
-  double cum = 0.0;
-  for (int m = 0; m < N; ++m) {
-    cum += wts[m];
-#pragma unroll
-    for (int s = 0; s < S; ++s) if (!found[s] && cum > tau[s]) { pick[s] = m; found[s] = true; }
+  for (int s = 0; s < T4; ++s) {
+    const double tau = ((double)(tid + 64 * kProdWaves * s) + u) * T / (double)N;
+    int lo = 0, hi = N - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cumw[mid] > tau) hi = mid; else lo = mid + 1;
+    }
+    pick[s] = lo;
   }
 #pragma unroll
-  for (int s = 0; s < S; ++s) {
-    const int i = lane + 64 * s;
+  for (int s = 0; s < T4; ++s) {
+    const int i = tid + 64 * kProdWaves * s;
     if (i < N) {
       double xi[D];
       rng_normals<D>(a.seed, stream, (uint32_t)i, xi);
@@ -247,11 +305,15 @@ hipError_t launch_product(int dim, int V, int N, const int32_t* prop_ptr, const 
   ProductArgs a;
   a.V = V; a.N = N; a.prop_ptr = prop_ptr; a.prop_rows = prop_rows; a.prop = prop; a.bel_in = bel_in; a.bel_out = bel_out;
   a.inv_n = 1.0 / N; a.inv_nm1 = N > 1 ? 1.0 / (N - 1) : 1.0; a.c_n = c_n; a.seed = seed; a.stream_offset = stream_offset;
-  switch (dim) {
-    case 2: hipLaunchKernelGGL(k_product<2>, dim3(V), dim3(64), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(k_product<3>, dim3(V), dim3(64), 0, s, a); break;
-    default: return hipErrorInvalidValue;
-  }
+  if (dim != 2 && dim != 3) return hipErrorInvalidValue;
+#define ROME_LAUNCH_PRODUCT(S) \
+  do { if (dim == 2) hipLaunchKernelGGL((k_product<2, S>), dim3(V), dim3(64 * kProdWaves), 0, s, a); \
+       else hipLaunchKernelGGL((k_product<3, S>), dim3(V), dim3(64 * kProdWaves), 0, s, a); } while (0)
+  if (N <= 64) ROME_LAUNCH_PRODUCT(1);
+  else if (N <= 128) ROME_LAUNCH_PRODUCT(2);
+  else if (N <= 256) ROME_LAUNCH_PRODUCT(4);
+  else ROME_LAUNCH_PRODUCT(8);
+#undef ROME_LAUNCH_PRODUCT
   return hipGetLastError();
 }
 
