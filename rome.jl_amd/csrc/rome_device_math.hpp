@@ -199,12 +199,19 @@ __device__ __forceinline__ void rng_entropy_from_words(const EntropyWords& e, in
 // wave64 reductions (all lanes end with the same bits: xor-butterfly of commutative adds)
 // ------------------------------------------------------------------------------------------
 // Row (16-lane) butterflies are DPP moves (quad_perm / row_half_mirror / row_mirror); the four row sums
-// are then combined through v_readlane in a fixed order.  ~4x cheaper than ds_bpermute shuffles.
+// are then folded with row_bcast:15 / row_bcast:31 and read back from lane 63.  ~4x cheaper than ds_bpermute shuffles.
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_masked(double v) {   // rows outside ROW_MASK receive 0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -222,9 +229,20 @@ __device__ __forceinline__ void wave_sum_n(double (&v)[K]) {
   for (int k = 0; k < K; ++k) v[k] += dpp_mov<0x141>(v[k]);  // row_half_mirror
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] += dpp_mov<0x140>(v[k]);  // row_mirror
+#ifdef ROME_REDUCE_READLANE
 #pragma unroll
   for (int k = 0; k < K; ++k)
     v[k] = (readlane_f64(v[k], 0) + readlane_f64(v[k], 16)) + (readlane_f64(v[k], 32) + readlane_f64(v[k], 48));
+#else
+  // every lane of a row now holds its row sum: fold the rows with the GFX9 row broadcasts (lane 15 of rows 0/2 -> rows 1/3,
+  // then lane 31 -> rows 2/3), the total lands in row 3 and is broadcast from lane 63 through an SGPR pair.
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov_masked<0x142, 0xA>(v[k]);  // row_bcast:15 row_mask:0xa
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov_masked<0x143, 0xC>(v[k]);  // row_bcast:31 row_mask:0xc
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = readlane_f64(v[k], 63);
+#endif
 }
 __device__ __forceinline__ double wave_sum(double v) { double a[1] = {v}; wave_sum_n<1>(a); return a[0]; }
 
