@@ -229,11 +229,6 @@ __device__ __forceinline__ void wave_sum_n(double (&v)[K]) {
   for (int k = 0; k < K; ++k) v[k] += dpp_mov<0x141>(v[k]);  // row_half_mirror
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] += dpp_mov<0x140>(v[k]);  // row_mirror
-#ifdef ROME_REDUCE_READLANE
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-    v[k] = (readlane_f64(v[k], 0) + readlane_f64(v[k], 16)) + (readlane_f64(v[k], 32) + readlane_f64(v[k], 48));
-#else
   // every lane of a row now holds its row sum: fold the rows with the GFX9 row broadcasts (lane 15 of rows 0/2 -> rows 1/3,
   // then lane 31 -> rows 2/3), the total lands in row 3 and is broadcast from lane 63 through an SGPR pair.
 #pragma unroll
@@ -242,7 +237,6 @@ __device__ __forceinline__ void wave_sum_n(double (&v)[K]) {
   for (int k = 0; k < K; ++k) v[k] += dpp_mov_masked<0x143, 0xC>(v[k]);  // row_bcast:31 row_mask:0xc
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = readlane_f64(v[k], 63);
-#endif
 }
 __device__ __forceinline__ double wave_sum(double v) { double a[1] = {v}; wave_sum_n<1>(a); return a[0]; }
 

@@ -452,10 +452,8 @@ template <class FP, int SOLVER, int PPL>
 #endif
 // Nelder-Mead on the 2-D/3-D factors is latency-bound (long dependent select/compare chains): asking for 4 waves/SIMD
 // (<= 128 VGPRs) is 5 % faster there; the Newton / closed-form kernels are issue-bound and lose 5-40 % when capped.
-#ifndef ROME_P3_WAVES
-#define ROME_P3_WAVES ROME_MIN_WAVES
-#endif
-__global__ void __launch_bounds__(64 * ROME_WPB, (SOLVER == kSolverNelderMead && FP::DT <= 3) ? 4 : (FP::DT > 3 ? ROME_P3_WAVES : ROME_MIN_WAVES))
+// (the SE(3) kernels need their 256 VGPRs: capped at 3-4 waves/SIMD they spill and run 2.7x slower)
+__global__ void __launch_bounds__(64 * ROME_WPB, (SOLVER == kSolverNelderMead && FP::DT <= 3) ? 4 : ROME_MIN_WAVES)
 k_conv(const ConvArgs a) {
   const int lane = threadIdx.x & 63;
   const int c = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * ROME_WPB + (int)(threadIdx.x >> 6));
@@ -586,9 +584,6 @@ k_conv(const ConvArgs a) {
         }
         st[k] = FP::template solve<SOLVER>(K, prep[k], z[k], fx[k], t[k], a.max_iters, a.tol);
       }
-#ifdef ROME_P3_SCHED_BARRIER
-      if constexpr (FP::DT > 3) __builtin_amdgcn_sched_barrier(0);
-#endif
     }
   }
 
