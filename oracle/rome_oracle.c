@@ -764,6 +764,16 @@ int ro_conv_pose2point2br_mh(const ro_opts* o, int C, const int32_t* factor, int
       if (dt == 3) ob[2 * N + i] = wrap_pi(ob[2 * N + i]);
       if (status) status[(size_t)c * N + i] = 0;
     }
+    /* nullhypo (same rule as the Pose2Pose2 convolution): such particles skip the solve and receive
+     * spread_nh · mean-std(start belief) entropy afterwards */
+    unsigned char* nullh = (unsigned char*)calloc(N, 1);
+    double* nhu0 = (double*)malloc(sizeof(double) * 3 * N);
+    double nh0_spread = 0.0;
+    if (o->nullhypo > 0.0) {
+      if (dt == 3) { double m3[3], s3[3]; ro_belief_spread_se2(N, ob, ob + N, ob + 2 * N, m3, s3); nh0_spread = N > 1 ? o->spread_nh * (s3[0] + s3[1] + s3[2]) / 3.0 : 0.0; }
+      else         { double m2[2], s2[2]; ro_belief_spread_r2(N, ob, ob + N, m2, s2); nh0_spread = N > 1 ? o->spread_nh * (s2[0] + s2[1]) / 2.0 : 0.0; }
+      for (int i = 0; i < N; ++i) nullh[i] = (unsigned char)nullhypo_draw(o, o->stream_offset + (uint64_t)c, (uint32_t)i, dt, nhu0 + 3 * i);
+    }
     int ncyc = (o->solver == RO_SOLVER_CLOSED_FORM && dir == 0) ? 1 : cycles;
     for (int cyc = 0; cyc < ncyc; ++cyc) {
       double spread = 0.0;
@@ -774,6 +784,7 @@ int ro_conv_pose2point2br_mh(const ro_opts* o, int C, const int32_t* factor, int
       for (int i = 0; i < N; ++i) {
         double fx[3] = {0, 0, 0}, t[3] = {0, 0, 0};
         if (dir == 0 && !sel[i]) continue;                       /* other hypothesis: not constrained by this factor */
+        if (nullh[i]) continue;
         for (int k = 0; k < df; ++k) fx[k] = (dir == 1 && !sel[i]) ? ab[k * N + i] : fb[k * N + i];
         for (int k = 0; k < dt; ++k) t[k] = ob[k * N + i];
         if (spread > 0.0) {
@@ -795,6 +806,15 @@ int ro_conv_pose2point2br_mh(const ro_opts* o, int C, const int32_t* factor, int
         if (status && st) status[(size_t)c * N + i] = st;
       }
     }
+    if (nh0_spread > 0.0)
+      for (int i = 0; i < N; ++i) if (nullh[i]) {
+        if (dt == 3) {
+          double t[3] = {ob[i], ob[N + i], ob[2 * N + i]};
+          se2_add_entropy(t, nh0_spread, nhu0 + 3 * i);
+          ob[i] = t[0]; ob[N + i] = t[1]; ob[2 * N + i] = wrap_pi(t[2]);
+        } else { ob[i] += nh0_spread * (nhu0[3 * i] - 0.5); ob[N + i] += nh0_spread * (nhu0[3 * i + 1] - 0.5); }
+      }
+    free(nullh); free(nhu0);
     if (av >= 0 && dir == 0) {
       /* means use the ORIGINAL target belief (start points) and the alternative landmark's belief */
       double mx = 0, my = 0, ax = 0, ay = 0;

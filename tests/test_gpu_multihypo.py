@@ -139,3 +139,29 @@ def test_nullhypo_vs_oracle_and_fraction(kind):
     assert (frac > 0.3).all() and (frac < 0.7).all()
     # the null-hypothesis share stays spread around the START belief (x ≈ 0), not at the factor's solution
     assert (np.abs(out[:, 0][~follows]).mean() < 8.0)
+
+
+@pytest.mark.parametrize("direction", [0, 1])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_nullhypo_bearingrange_vs_oracle(direction, solver):
+    """nullhypo on Pose2Point2BearingRange, both directions: GPU = oracle; the null share keeps its start value (+ entropy)."""
+    rng = np.random.default_rng(11)
+    C_, N = 5, 100
+    mu = np.tile([0.3, 12.0], (C_, 1)); sigma = np.tile([0.03, 0.4], (C_, 1))
+    poses = rng.standard_normal((C_, 3, N)) * np.array([0.3, 0.3, 0.05])[None, :, None]
+    lms = rng.standard_normal((C_, 2, N)) * 0.4 + np.array([40.0, -25.0])[None, :, None]   # start belief far from the solution
+    fixed, target = (poses, lms) if direction == 0 else (lms, poses + np.array([30.0, 10.0, 0.4])[None, :, None])
+    o = R.make_opts(N=N, solver=solver, seed=5, nullhypo=0.4)
+    out = R.conv_pose2point2br(o, direction, mu, sigma, fixed, target)
+    ref = ro.conv_pose2point2br(ro.make_opts(N=N, solver=solver, seed=5, nullhypo=0.4), direction, mu, sigma, fixed, target,
+                                np.arange(C_), np.arange(C_), factor=np.arange(C_))
+    d = out - ref
+    if direction == 1:
+        d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    assert np.abs(d).max() < 1e-8
+    if direction == 0:
+        follows = np.hypot(out[:, 0], out[:, 1]) < 16.0          # landmarks 12 m from poses near the origin
+    else:
+        follows = np.abs(np.hypot(out[:, 0] - 40.0, out[:, 1] + 25.0) - 12.0) < 2.5   # poses on the 12 m ring about the landmark
+    frac = follows.mean(axis=1)
+    assert (frac > 0.4).all() and (frac < 0.8).all(), frac
