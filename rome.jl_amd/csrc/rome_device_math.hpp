@@ -381,6 +381,61 @@ __device__ __forceinline__ void se3_add_entropy(Se3& T, double spread, const dou
 }
 
 // ------------------------------------------------------------------------------------------
+// Unit quaternions (w, x, y, z) -- the rotation state of the SE(3) convolution kernel.  Same group elements as the
+// 3x3 frames above (Exp/Log agree with so3_exp/so3_log to rounding, and are better conditioned at θ -> π), at 4
+// instead of 9 doubles per rotation and 16 instead of 27 multiply-adds per composition.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quat_exp(const double* w, double (&q)[4]) {   // Exp(ω): (cos θ/2, sin(θ/2)/θ · ω)
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double th = fast_sqrt(th2);
+  double s, c;
+  fast_sincos(0.5 * th, &s, &c);
+  const double k = th2 > 1e-16 ? s / th : 0.5 - th2 * (1.0 / 48.0);
+  q[0] = c; q[1] = k * w[0]; q[2] = k * w[1]; q[3] = k * w[2];
+}
+// Rotation angle θ in [0, π] of a unit quaternion with |vector part| = n and |w| = aw (n² + aw² = 1):
+// θ = 2·asin(n) = π − 2·asin(aw), always evaluated on the branch whose argument is <= 1/√2 (well conditioned).
+__device__ __forceinline__ double quat_angle(double n, double aw) {
+  const double a = asin(fmin(n, aw));
+  return n <= aw ? 2.0 * a : kPi - 2.0 * a;
+}
+// Log(q) as a rotation vector with θ in [0, π] (q and −q are the same rotation: the w >= 0 representative is used).
+// Like Manifolds' log!(::Rotations{3}) (so3_log above), rotations with cos θ + 1 <= √eps are returned as θ = π exactly.
+__device__ __forceinline__ void quat_log(const double (&q)[4], double* w) {
+  const double n2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const double n = fast_sqrt(n2);
+  const double aw = fabs(q[0]);
+  double k = n2 > 1e-16 ? quat_angle(n, aw) / n : 2.0 / aw;
+  if (2.0 * aw * aw <= kSqrtEps) k = kPi / n;
+  k = q[0] < 0.0 ? -k : k;
+  w[0] = k * q[1]; w[1] = k * q[2]; w[2] = k * q[3];
+}
+__device__ __forceinline__ void quat_mul(const double (&a)[4], const double (&b)[4], double (&o)[4]) {
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+__device__ __forceinline__ void quat_cmul(const double (&a)[4], const double (&b)[4], double (&o)[4]) {   // conj(a) ⊗ b
+  o[0] = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  o[1] = a[0] * b[1] - a[1] * b[0] - a[2] * b[3] + a[3] * b[2];
+  o[2] = a[0] * b[2] + a[1] * b[3] - a[2] * b[0] - a[3] * b[1];
+  o[3] = a[0] * b[3] - a[1] * b[2] + a[2] * b[1] - a[3] * b[0];
+}
+__device__ __forceinline__ void quat_mulc(const double (&a)[4], const double (&b)[4], double (&o)[4]) {   // a ⊗ conj(b)
+  o[0] = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  o[1] = -a[0] * b[1] + a[1] * b[0] - a[2] * b[3] + a[3] * b[2];
+  o[2] = -a[0] * b[2] + a[1] * b[3] + a[2] * b[0] - a[3] * b[1];
+  o[3] = -a[0] * b[3] - a[1] * b[2] + a[2] * b[1] + a[3] * b[0];
+}
+__device__ __forceinline__ void quat_rot(const double (&q)[4], const double* v, double (&o)[3]) {   // R(q) v
+  const double tx = 2.0 * (q[2] * v[2] - q[3] * v[1]), ty = 2.0 * (q[3] * v[0] - q[1] * v[2]), tz = 2.0 * (q[1] * v[1] - q[2] * v[0]);
+  o[0] = v[0] + q[0] * tx + (q[2] * tz - q[3] * ty);
+  o[1] = v[1] + q[0] * ty + (q[3] * tx - q[1] * tz);
+  o[2] = v[2] + q[0] * tz + (q[1] * ty - q[2] * tx);
+}
+
+// ------------------------------------------------------------------------------------------
 // Nelder-Mead with Optim.jl's defaults (AdaptiveParameters, AffineSimplexer(0.025, 0.5), g_tol test
 // on sqrt(var(f)·n/(n+1)), best-vertex-or-centroid result).  The simplex is kept SORTED in fixed
 // register slots (compile-time indices only -> no scratch); ties are broken by the vertex's storage

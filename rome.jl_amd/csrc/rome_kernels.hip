@@ -99,11 +99,14 @@ struct P2P2 {
   __device__ static __forceinline__ bool needs_cycles(int solver, const Consts& K) {
     return solver != kSolverClosedForm && K.dir != kDirPrior;
   }
+  struct Aux {};
+  __device__ static __forceinline__ Aux init_aux(const double (&)[3]) { return Aux{}; }
+  __device__ static __forceinline__ void finalize(double (&)[3], const Aux&) {}
   template <int PPL>
-  __device__ static __forceinline__ double spread(const double (&t)[PPL][3], const bool (&act)[PPL], double inv, double den) {
+  __device__ static __forceinline__ double spread(const double (&t)[PPL][3], const Aux (&)[PPL], const bool (&act)[PPL], double inv, double den) {
     return spread_se2<PPL>(t, act, inv, den);
   }
-  __device__ static __forceinline__ void add_entropy(double (&t)[3], double spread, const double (&u)[3], double s, double c) {
+  __device__ static __forceinline__ void add_entropy(double (&t)[3], Aux&, double spread, const double (&u)[3], double s, double c) {
     const double ex = spread * (u[0] - 0.5), ey = spread * (u[1] - 0.5), et = spread * (u[2] - 0.5);
     t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] = wrap_pi(t[2] + et);
   }
@@ -135,7 +138,7 @@ struct P2P2 {
 
   template <int SOLVER>
   __device__ static __forceinline__ int solve(const Consts& K, const Prep& P, const double (&z)[3], const double (&fxc)[3],
-                                              double (&t)[3], int max_iters, double tol) {
+                                              double (&t)[3], Aux&, int max_iters, double tol) {
     int st = 0;
     if (K.dir == kDirPrior) {  // PriorPose2 row: the sample exp_ϵ(hat(μ + Lξ)) itself is the proposal
       t[0] = P.a0; t[1] = P.a1; t[2] = wrap_pi(P.a2);
@@ -223,12 +226,15 @@ struct BR {
   __device__ static __forceinline__ bool needs_cycles(int solver, const Consts&) {
     return !(solver == kSolverClosedForm && DIR == 0);
   }
+  struct Aux {};
+  __device__ static __forceinline__ Aux init_aux(const double (&)[DT]) { return Aux{}; }
+  __device__ static __forceinline__ void finalize(double (&)[DT], const Aux&) {}
   template <int PPL>
-  __device__ static __forceinline__ double spread(const double (&t)[PPL][DT], const bool (&act)[PPL], double inv, double den) {
+  __device__ static __forceinline__ double spread(const double (&t)[PPL][DT], const Aux (&)[PPL], const bool (&act)[PPL], double inv, double den) {
     if constexpr (DT == 3) return spread_se2<PPL>(t, act, inv, den);
     else return spread_r2<PPL>(t, act, inv, den);
   }
-  __device__ static __forceinline__ void add_entropy(double (&t)[DT], double spread, const double (&u)[DT], double s, double c) {
+  __device__ static __forceinline__ void add_entropy(double (&t)[DT], Aux&, double spread, const double (&u)[DT], double s, double c) {
     if constexpr (DT == 3) {
       const double ex = spread * (u[0] - 0.5), ey = spread * (u[1] - 0.5), et = spread * (u[2] - 0.5);
       t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] = wrap_pi(t[2] + et);
@@ -242,7 +248,7 @@ struct BR {
   }
   template <int SOLVER>
   __device__ static __forceinline__ int solve(const Consts&, const Prep&, const double (&z)[2], const double (&fx)[DF],
-                                              double (&t)[DT], int max_iters, double tol) {
+                                              double (&t)[DT], Aux&, int max_iters, double tol) {
     int st = 0;
     if constexpr (SOLVER == kSolverClosedForm) {
       if constexpr (DIR == 0) {
@@ -290,17 +296,28 @@ struct BR {
   }
 };
 
-// ---- Pose3Pose3 (belief blocks hold coordinates (t, ω); points are rebuilt per solve)
+// ---- Pose3Pose3.  Belief blocks hold coordinates (t, ω); inside the kernel the rotation of every particle lives as a
+// unit quaternion (Aux) from load to store, so the inflation cycles never go through Exp/Log round trips, and the root
+// (a, qa) of the residual  r = ( p.t + R_p z_t − q.t , Log(R_qᵀ R_p Exp(z_ω)) )  is prepared once per particle:
+//   dir 0 (solve q): qa = q_p ⊗ q_z,        a = p.t + R_p z_t   (the root itself)
+//   dir 1 (solve p): qa = q_q ⊗ conj(q_z),  a = q.t             (root translation = a − R(qa) z_t)
+// The rotation residual is evaluated as Log(conj(q_T) ⊗ qa): the same angle as the reference's Log(R_qᵀ R_p Z) (for
+// dir 1 the vector is that residual rotated by Z, which changes neither Σr² nor the root).
 struct P3P3Cost {
-  double zt[3]; double Z[9]; Se3 F; int dir;
+  double a[3], qa[4], zt[3]; int dir;
   __device__ __forceinline__ double operator()(const double (&x)[6]) const {
-    Se3 T; se3_from_coords(x, T);
-    double r[6];
-    if (dir == 0) residual_pose3pose3(zt, Z, F, T, r); else residual_pose3pose3(zt, Z, T, F, r);
-    double s = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s += r[k] * r[k];
-    return s;
+    double qT[4], e[4];
+    quat_exp(&x[3], qT);
+    quat_cmul(qT, qa, e);
+    const double n = fast_sqrt(e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+    const double th = quat_angle(n, fabs(e[0]));
+    double r0, r1, r2;
+    if (dir == 0) { r0 = a[0] - x[0]; r1 = a[1] - x[1]; r2 = a[2] - x[2]; }
+    else {
+      double v[3]; quat_rot(qT, zt, v);
+      r0 = x[0] + v[0] - a[0]; r1 = x[1] + v[1] - a[1]; r2 = x[2] + v[2] - a[2];
+    }
+    return r0 * r0 + r1 * r1 + r2 * r2 + th * th;
   }
 };
 
@@ -326,25 +343,29 @@ struct P3P3 {
       z[k] = s;
     }
   }
-  __device__ static __forceinline__ void canonical(double (&t)[6]) { Se3 P; se3_from_coords(t, P); se3_to_coords(P, t); }
+  __device__ static __forceinline__ void canonical(double (&)[6]) {}   // finalize() writes the principal rotation vector
   __device__ static __forceinline__ bool needs_cycles(int solver, const Consts& K) {
     return solver != kSolverClosedForm && K.dir != kDirPrior;
   }
+  struct Aux { double q[4]; };
+  __device__ static __forceinline__ Aux init_aux(const double (&t)[6]) { Aux A; quat_exp(&t[3], A.q); return A; }
+  __device__ static __forceinline__ void finalize(double (&t)[6], const Aux& A) { quat_log(A.q, &t[3]); }
 
   // std of the tangent coordinates about particle 0: translation differences and Log(R0ᵀ R_i)
   template <int PPL>
-  __device__ static __forceinline__ double spread(const double (&t)[PPL][6], const bool (&act)[PPL], double inv, double den) {
-    double c0[6], R0[9];
+  __device__ static __forceinline__ double spread(const double (&t)[PPL][6], const Aux (&A)[PPL], const bool (&act)[PPL], double inv, double den) {
+    double c0[3], q0[4];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) c0[k] = readlane_f64(t[0][k], 0);
-    so3_exp(c0 + 3, R0);
+    for (int k = 0; k < 3; ++k) c0[k] = readlane_f64(t[0][k], 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q0[k] = readlane_f64(A[0].q[k], 0);
     double s[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) s[j] = 0.0;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
-      double R[9], U[9], d[6];
-      so3_exp(&t[k][3], R); mat3_tmul(R0, R, U); so3_log(U, d + 3);
+      double e[4], d[6];
+      quat_cmul(q0, A[k].q, e); quat_log(e, d + 3);
       d[0] = t[k][0] - c0[0]; d[1] = t[k][1] - c0[1]; d[2] = t[k][2] - c0[2];
       if (act[k]) {
 #pragma unroll
@@ -357,84 +378,101 @@ struct P3P3 {
     for (int j = 0; j < 6; ++j) acc += fast_sqrt(fmax(0.0, (s[2 * j + 1] - s[2 * j] * s[2 * j] * inv) * den));
     return acc * (1.0 / 6.0);
   }
-  struct Prep {};
-  __device__ static __forceinline__ Prep prepare(const Consts&, const double (&)[6], const double (&)[6]) { return Prep{}; }
+  struct Prep { double a[3], qa[4]; };
+  __device__ static __forceinline__ Prep prepare(const Consts& K, const double (&z)[6], const double (&fxc)[6]) {
+    Prep P;
+    double qz[4];
+    quat_exp(&z[3], qz);
+    if (K.dir == kDirPrior) {  // PriorPose3 row: the sample point exp_ϵ(hat z)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) P.a[k] = z[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) P.qa[k] = qz[k];
+      return P;
+    }
+    double qF[4];
+    quat_exp(&fxc[3], qF);
+    if (K.dir == 0) {
+      double v[3];
+      quat_mul(qF, qz, P.qa); quat_rot(qF, z, v);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) P.a[k] = fxc[k] + v[k];
+    } else {
+      quat_mulc(qF, qz, P.qa);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) P.a[k] = fxc[k];
+    }
+    return P;
+  }
   template <int SOLVER>
   __device__ static __forceinline__ void heading_sincos(const Consts&, const Prep&, int, int, const double (&)[6], double* s, double* c) {
     *s = 0.0; *c = 1.0;
   }
-  __device__ static __forceinline__ void add_entropy(double (&t)[6], double spread, const double (&u)[6], double, double) {
-    Se3 T; se3_from_coords(t, T);
-    se3_add_entropy(T, spread, u);
-    se3_to_coords(T, t);
+  // u0 ∘ exp_ϵ(hat e), e = spread·(u − ½):  t += R e_t,  R ← R Exp(e_ω)
+  __device__ static __forceinline__ void add_entropy(double (&t)[6], Aux& A, double spread, const double (&u)[6], double, double) {
+    double e[6], v[3], qe[4], qn[4];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) e[k] = spread * (u[k] - 0.5);
+    quat_rot(A.q, e, v);
+    t[0] += v[0]; t[1] += v[1]; t[2] += v[2];
+    quat_exp(e + 3, qe); quat_mul(A.q, qe, qn);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A.q[k] = qn[k];
   }
   template <int SOLVER>
-  __device__ static __forceinline__ int solve(const Consts& K, const Prep&, const double (&z)[6], const double (&fxc)[6],
-                                              double (&t)[6], int max_iters, double tol) {
+  __device__ static __forceinline__ int solve(const Consts& K, const Prep& P, const double (&z)[6], const double (&)[6],
+                                              double (&t)[6], Aux& A, int max_iters, double tol) {
     int st = 0;
-    Se3 F, T;
-    if (K.dir == kDirPrior) {  // PriorPose3 row
-      se3_from_coords(z, T); se3_to_coords(T, t);
+    if (K.dir == kDirPrior || (SOLVER == kSolverClosedForm && K.dir == 0)) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t[k] = P.a[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) A.q[k] = P.qa[k];
       return 0;
     }
-    se3_from_coords(fxc, F);
-    double Z[9];
-    so3_exp(&z[3], Z);
-    if constexpr (SOLVER == kSolverClosedForm) {
+    if constexpr (SOLVER == kSolverClosedForm) {   // dir 1
       double v[3];
-      if (K.dir == 0) {
-        mat3_mul(F.R, Z, T.R); mat3_vec(F.R, z, v);
+      quat_rot(P.qa, z, v);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) T.t[k] = F.t[k] + v[k];
-      } else {
-        double Zt[9];
+      for (int k = 0; k < 3; ++k) t[k] = P.a[k] - v[k];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) Zt[i + 3 * j] = Z[j + 3 * i];
-        mat3_mul(F.R, Zt, T.R); mat3_vec(T.R, z, v);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) T.t[k] = F.t[k] - v[k];
-      }
-      se3_to_coords(T, t);
+      for (int k = 0; k < 4; ++k) A.q[k] = P.qa[k];
     } else if constexpr (SOLVER == kSolverNewton) {
-      se3_from_coords(t, T);
+      // Newton on the group: the rotation step  q ← q ⊗ (conj(q) ⊗ qa)  is exact (right-perturbation update with the
+      // residual itself), the translation follows with the updated rotation (block Newton, as for Pose2).
       st = 1;
       for (int it = 0; it < max_iters; ++it) {
-        double r[6];
-        if (K.dir == 0) residual_pose3pose3(z, Z, F, T, r); else residual_pose3pose3(z, Z, T, F, r);
-        double m = 0;
+        double e[4], rt[3];
+        quat_cmul(A.q, P.qa, e);
+        if (K.dir == 0) { rt[0] = P.a[0] - t[0]; rt[1] = P.a[1] - t[1]; rt[2] = P.a[2] - t[2]; }
+        else {
+          double v[3]; quat_rot(A.q, z, v);
+          rt[0] = t[0] + v[0] - P.a[0]; rt[1] = t[1] + v[1] - P.a[1]; rt[2] = t[2] + v[2] - P.a[2];
+        }
+        // |Log e| = 2·atan2(|e_v|, |e_w|): below 2e-10 rad it is 2·e_v to 1e-30; above, the residual exceeds any tolerance
+        const double n2 = e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
+        const double m = fmax(fmax(fabs(rt[0]), fabs(rt[1])), fmax(fabs(rt[2]), 2.0 * fmax(fabs(e[1]), fmax(fabs(e[2]), fabs(e[3])))));
+        if (n2 <= 1e-20 && m <= tol) { st = 0; break; }
+        double qn[4];
+        quat_mul(A.q, e, qn);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) m = fmax(m, fabs(r[k]));
-        if (m <= tol) { st = 0; break; }
-        double E[9], Rn[9];
-        if (K.dir == 0) {
-          so3_exp(&r[3], E); mat3_mul(T.R, E, Rn);
-#pragma unroll
-          for (int k = 0; k < 9; ++k) T.R[k] = Rn[k];
-          T.t[0] += r[0]; T.t[1] += r[1]; T.t[2] += r[2];
-        } else {
-          double d[3], v[3];
-          mat3_vec(Z, &r[3], d); d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2];
-          so3_exp(d, E); mat3_mul(T.R, E, Rn);
-#pragma unroll
-          for (int k = 0; k < 9; ++k) T.R[k] = Rn[k];
-          mat3_vec(T.R, z, v);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) T.t[k] = F.t[k] - v[k];
+        for (int k = 0; k < 4; ++k) A.q[k] = qn[k];
+        if (K.dir == 0) { t[0] += rt[0]; t[1] += rt[1]; t[2] += rt[2]; }
+        else {
+          double v[3]; quat_rot(A.q, z, v);
+          t[0] = P.a[0] - v[0]; t[1] = P.a[1] - v[1]; t[2] = P.a[2] - v[2];
         }
       }
-      se3_to_coords(T, t);
     } else {
       P3P3Cost cost;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) cost.zt[k] = z[k];
+      for (int k = 0; k < 3; ++k) { cost.a[k] = P.a[k]; cost.zt[k] = z[k]; }
 #pragma unroll
-      for (int k = 0; k < 9; ++k) cost.Z[k] = Z[k];
-      cost.F = F; cost.dir = K.dir;
-      // X0c = vee(log(ϵ,u0)) : t is already canonical (Exp/Log) coordinates
+      for (int k = 0; k < 4; ++k) cost.qa[k] = P.qa[k];
+      cost.dir = K.dir;
+      quat_log(A.q, &t[3]);   // X0c = vee(log(ϵ,u0)): Nelder-Mead works on the (t, ω) coordinates
       st = nelder_mead<6>(cost, t, max_iters, tol);
-      se3_from_coords(t, T); se3_to_coords(T, t);
+      quat_exp(&t[3], A.q);
     }
     return st;
   }
@@ -471,6 +509,7 @@ k_conv(const ConvArgs a) {
 
   double fx[PPL][FP::DF], t[PPL][FP::DT], z[PPL][FP::DZ];
   typename FP::Prep prep[PPL];
+  typename FP::Aux aux[PPL];   // state a policy keeps beside the coordinates (Pose3: the rotation as a unit quaternion)
   bool act[PPL];
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
@@ -491,6 +530,7 @@ k_conv(const ConvArgs a) {
     }
     FP::measurement(K, xi, z[k]);
     FP::canonical(t[k]);
+    aux[k] = FP::init_aux(t[k]);
     prep[k] = FP::prepare(K, z[k], fx[k]);
   }
 
@@ -550,7 +590,7 @@ k_conv(const ConvArgs a) {
   double nh0_spread = 0.0;
   const double p_null = a.nullhypo ? a.nullhypo[c] : 0.0;
   if (p_null > 0.0) {  // wave-uniform
-    nh0_spread = a.spread_nh * FP::template spread<PPL>(t, act, a.inv_n, a.inv_nm1);
+    nh0_spread = a.spread_nh * FP::template spread<PPL>(t, aux, act, a.inv_n, a.inv_nm1);
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       const uint32_t ii = (uint32_t)(act[k] ? lane + 64 * k : 0);
@@ -566,7 +606,7 @@ k_conv(const ConvArgs a) {
   int have_call = -1;
   for (int cyc = 0; cyc < ncyc; ++cyc) {
     double spread = 0.0;
-    if (cyc_on && a.inflation > 0.0 && N > 1) spread = a.inflation * FP::template spread<PPL>(t, act, a.inv_n, a.inv_nm1);
+    if (cyc_on && a.inflation > 0.0 && N > 1) spread = a.inflation * FP::template spread<PPL>(t, aux, act, a.inv_n, a.inv_nm1);
     if (spread > 0.0 && have_call != cyc / CPC) {  // wave-uniform
       have_call = cyc / CPC;
 #pragma unroll
@@ -580,9 +620,9 @@ k_conv(const ConvArgs a) {
           rng_entropy_from_words<FP::DT>(ew[k], cyc % CPC, u);
           double hs, hc;
           FP::template heading_sincos<SOLVER>(K, prep[k], st[k], cyc, t[k], &hs, &hc);
-          FP::add_entropy(t[k], spread, u, hs, hc);
+          FP::add_entropy(t[k], aux[k], spread, u, hs, hc);
         }
-        st[k] = FP::template solve<SOLVER>(K, prep[k], z[k], fx[k], t[k], a.max_iters, a.tol);
+        st[k] = FP::template solve<SOLVER>(K, prep[k], z[k], fx[k], t[k], aux[k], a.max_iters, a.tol);
       }
     }
   }
@@ -605,7 +645,7 @@ k_conv(const ConvArgs a) {
         }
         double hs, hc;
         FP::template heading_sincos<SOLVER>(K, prep[k], 1, 0, t[k], &hs, &hc);
-        FP::add_entropy(t[k], nh0_spread, u, hs, hc);
+        FP::add_entropy(t[k], aux[k], nh0_spread, u, hs, hc);
       }
     }
   }
@@ -622,6 +662,7 @@ k_conv(const ConvArgs a) {
   for (int k = 0; k < PPL; ++k) {
     const int i = lane + 64 * k;
     if (act[k]) {
+      FP::finalize(t[k], aux[k]);
 #pragma unroll
       for (int d = 0; d < FP::DT; ++d) ob[d * N + i] = t[k][d];
       if (a.status) a.status[(size_t)c * N + i] = st[k];
