@@ -442,73 +442,62 @@ __device__ __forceinline__ void quat_rot(const double (&q)[4], const double* v, 
 // slot exactly like sortperm's stable order.
 // ------------------------------------------------------------------------------------------
 template <int n>
-struct NmVertex { double f; int slot; double x[n]; };
-
-template <int n>
-__device__ __forceinline__ bool nm_less(const NmVertex<n>& a, const NmVertex<n>& b) {
-  return (a.f < b.f) || (a.f == b.f && a.slot < b.slot);
-}
-template <int n>
-__device__ __forceinline__ void nm_cswap(NmVertex<n>& a, NmVertex<n>& b) {  // ensure a <= b
-  const bool sw = nm_less<n>(b, a);
-  const double fa = sw ? b.f : a.f, fb = sw ? a.f : b.f;
-  const int sa = sw ? b.slot : a.slot, sb = sw ? a.slot : b.slot;
-  a.f = fa; b.f = fb; a.slot = sa; b.slot = sb;
+__device__ __forceinline__ void nm_cswap(double& fa, int& sa, double (&xa)[n], double& fb, int& sb, double (&xb)[n]) {  // ensure a <= b
+  const bool sw = (fb < fa) || (fb == fa && sb < sa);
+  const double f0 = sw ? fb : fa, f1 = sw ? fa : fb;
+  const int s0 = sw ? sb : sa, s1 = sw ? sa : sb;
+  fa = f0; fb = f1; sa = s0; sb = s1;
 #pragma unroll
-  for (int k = 0; k < n; ++k) { const double xa = sw ? b.x[k] : a.x[k], xb = sw ? a.x[k] : b.x[k]; a.x[k] = xa; b.x[k] = xb; }
+  for (int k = 0; k < n; ++k) { const double x0 = sw ? xb[k] : xa[k], x1 = sw ? xa[k] : xb[k]; xa[k] = x0; xb[k] = x1; }
 }
 
 template <int n, class Cost>
 __device__ __forceinline__ int nelder_mead(const Cost& cost, double (&x)[n], int max_iters, double g_tol) {
   constexpr int m = n + 1;
   const double alpha = 1.0, beta = 1.0 + 2.0 / n, gamma = 0.75 - 1.0 / (2.0 * n), delta = 1.0 - 1.0 / n;
-  NmVertex<n> S[m];
+  double F[m], X[m][n];   // plain arrays with compile-time indices only: scalarised into registers
+  int SL[m];
 #pragma unroll
   for (int i = 0; i < m; ++i) {
 #pragma unroll
-    for (int k = 0; k < n; ++k) S[i].x[k] = x[k];
-    if (i > 0) S[i].x[i - 1] = (1.0 + 0.5) * S[i].x[i - 1] + 0.025;
-    S[i].slot = i;
-    S[i].f = cost(S[i].x);
+    for (int k = 0; k < n; ++k) X[i][k] = x[k];
+    if (i > 0) X[i][i - 1] = (1.0 + 0.5) * X[i][i - 1] + 0.025;
+    SL[i] = i;
+    F[i] = cost(X[i]);
   }
   // full sort (insertion network)
 #pragma unroll
   for (int i = 1; i < m; ++i)
 #pragma unroll
-    for (int j = i; j > 0; --j) nm_cswap<n>(S[j - 1], S[j]);
+    for (int j = i; j > 0; --j) nm_cswap<n>(F[j - 1], SL[j - 1], X[j - 1], F[j], SL[j], X[j]);
 
   // Optim's stopping statistic is sqrt(var(f)·n/(n+1)) <= g_tol with the corrected variance; evaluated here as
   // Σ(f-mean)² <= g_tol²·(n+1)  (same decision, no FP64 divide / sqrt in the loop: ≈ 250 SIMD-cycles per iteration)
   const double thr2 = g_tol * g_tol * (double)m;
-  auto objective2 = [&]() {
-    double mean = 0.0;
+  bool converged;
+  {
+    double mean = 0.0, v = 0.0;
 #pragma unroll
-    for (int i = 0; i < m; ++i) mean += S[i].f;
+    for (int i = 0; i < m; ++i) mean += F[i];
     mean *= (1.0 / m);
-    double v = 0.0;
 #pragma unroll
-    for (int i = 0; i < m; ++i) { const double d = S[i].f - mean; v += d * d; }
-    return v;
-  };
-  auto centroid = [&](double (&c)[n]) {  // of all but the highest
-#pragma unroll
-    for (int k = 0; k < n; ++k) {
-      double s = 0.0;
-#pragma unroll
-      for (int i = 0; i < m - 1; ++i) s += S[i].x[k];
-      c[k] = s * (1.0 / n);
-    }
-  };
-
-  bool converged = objective2() <= thr2;
+    for (int i = 0; i < m; ++i) { const double d = F[i] - mean; v += d * d; }
+    converged = v <= thr2;
+  }
   int iter = 0;
   while (!converged && iter < max_iters) {
     ++iter;
     double xc[n], xr[n], xt[n];
-    centroid(xc);
-    const double f_lowest = S[0].f, f_second = S[m - 2].f, f_highest = S[m - 1].f;
 #pragma unroll
-    for (int k = 0; k < n; ++k) xr[k] = xc[k] + alpha * (xc[k] - S[m - 1].x[k]);
+    for (int k = 0; k < n; ++k) {   // centroid of all but the highest
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < m - 1; ++i) s += X[i][k];
+      xc[k] = s * (1.0 / n);
+    }
+    const double f_lowest = F[0], f_second = F[m - 2], f_highest = F[m - 1];
+#pragma unroll
+    for (int k = 0; k < n; ++k) xr[k] = xc[k] + alpha * (xc[k] - X[m - 1][k]);
     const double f_reflect = cost(xr);
     // One second trial point per iteration with a per-lane coefficient (expansion β, outside contraction γ,
     // inside contraction -γ; unused when the reflection is simply accepted): the four Optim branches become
@@ -524,34 +513,46 @@ __device__ __forceinline__ int nelder_mead(const Cost& cost, double (&x)[n], int
     const bool take_reflect = (expand && !take_trial) || accept_reflect;
     const bool shrink = !take_trial && !take_reflect;
     if (!shrink) {
-      S[m - 1].f = take_trial ? f_trial : f_reflect;
+      F[m - 1] = take_trial ? f_trial : f_reflect;
 #pragma unroll
-      for (int k = 0; k < n; ++k) S[m - 1].x[k] = take_trial ? xt[k] : xr[k];
+      for (int k = 0; k < n; ++k) X[m - 1][k] = take_trial ? xt[k] : xr[k];
     }
     if (shrink) {
 #pragma unroll
       for (int i = 1; i < m; ++i) {
 #pragma unroll
-        for (int k = 0; k < n; ++k) S[i].x[k] = S[0].x[k] + delta * (S[i].x[k] - S[0].x[k]);
-        S[i].f = cost(S[i].x);
+        for (int k = 0; k < n; ++k) X[i][k] = X[0][k] + delta * (X[i][k] - X[0][k]);
+        F[i] = cost(X[i]);
       }
 #pragma unroll
       for (int i = 1; i < m; ++i)
 #pragma unroll
-        for (int j = i; j > 0; --j) nm_cswap<n>(S[j - 1], S[j]);
+        for (int j = i; j > 0; --j) nm_cswap<n>(F[j - 1], SL[j - 1], X[j - 1], F[j], SL[j], X[j]);
     } else {
       // only the last vertex changed: bubble it into place
 #pragma unroll
-      for (int j = m - 1; j > 0; --j) nm_cswap<n>(S[j - 1], S[j]);
+      for (int j = m - 1; j > 0; --j) nm_cswap<n>(F[j - 1], SL[j - 1], X[j - 1], F[j], SL[j], X[j]);
     }
-    converged = objective2() <= thr2;
+    double mean = 0.0, v = 0.0;
+#pragma unroll
+    for (int i = 0; i < m; ++i) mean += F[i];
+    mean *= (1.0 / m);
+#pragma unroll
+    for (int i = 0; i < m; ++i) { const double d = F[i] - mean; v += d * d; }
+    converged = v <= thr2;
   }
   double xc[n];
-  centroid(xc);
-  const double fcen = cost(xc);
-  const bool usec = fcen < S[0].f;
 #pragma unroll
-  for (int k = 0; k < n; ++k) x[k] = usec ? xc[k] : S[0].x[k];
+  for (int k = 0; k < n; ++k) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < m - 1; ++i) s += X[i][k];
+    xc[k] = s * (1.0 / n);
+  }
+  const double fcen = cost(xc);
+  const bool usec = fcen < F[0];
+#pragma unroll
+  for (int k = 0; k < n; ++k) x[k] = usec ? xc[k] : X[0][k];
   return converged ? 0 : 1;
 }
 

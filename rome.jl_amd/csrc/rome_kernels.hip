@@ -301,23 +301,21 @@ struct BR {
 // (a, qa) of the residual  r = ( p.t + R_p z_t − q.t , Log(R_qᵀ R_p Exp(z_ω)) )  is prepared once per particle:
 //   dir 0 (solve q): qa = q_p ⊗ q_z,        a = p.t + R_p z_t   (the root itself)
 //   dir 1 (solve p): qa = q_q ⊗ conj(q_z),  a = q.t             (root translation = a − R(qa) z_t)
-// The rotation residual is evaluated as Log(conj(q_T) ⊗ qa): the same angle as the reference's Log(R_qᵀ R_p Z) (for
-// dir 1 the vector is that residual rotated by Z, which changes neither Σr² nor the root).
+// The Newton rotation residual is conj(q_T) ⊗ qa: the same angle as the reference's Log(R_qᵀ R_p Z) (for dir 1 the
+// vector is that residual rotated by Z, which changes neither its norm nor the root).
+// Nelder-Mead mode evaluates Σr² through 3x3 frames, the residual exactly as src/factors/Pose3Pose3.jl:17-29 composes it
+// (measured: 191 ms per helix sweep against 264 ms for a quaternion cost, whose inverse-trig call raises the register
+// pressure of the 32 inlined evaluations; the Newton / closed-form modes never evaluate a Log).
 struct P3P3Cost {
-  double a[3], qa[4], zt[3]; int dir;
+  double zt[3]; double Z[9]; Se3 F; int dir;
   __device__ __forceinline__ double operator()(const double (&x)[6]) const {
-    double qT[4], e[4];
-    quat_exp(&x[3], qT);
-    quat_cmul(qT, qa, e);
-    const double n = fast_sqrt(e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
-    const double th = quat_angle(n, fabs(e[0]));
-    double r0, r1, r2;
-    if (dir == 0) { r0 = a[0] - x[0]; r1 = a[1] - x[1]; r2 = a[2] - x[2]; }
-    else {
-      double v[3]; quat_rot(qT, zt, v);
-      r0 = x[0] + v[0] - a[0]; r1 = x[1] + v[1] - a[1]; r2 = x[2] + v[2] - a[2];
-    }
-    return r0 * r0 + r1 * r1 + r2 * r2 + th * th;
+    Se3 T; se3_from_coords(x, T);
+    double r[6];
+    if (dir == 0) residual_pose3pose3(zt, Z, F, T, r); else residual_pose3pose3(zt, Z, T, F, r);
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += r[k] * r[k];
+    return s;
   }
 };
 
@@ -420,7 +418,7 @@ struct P3P3 {
     for (int k = 0; k < 4; ++k) A.q[k] = qn[k];
   }
   template <int SOLVER>
-  __device__ static __forceinline__ int solve(const Consts& K, const Prep& P, const double (&z)[6], const double (&)[6],
+  __device__ static __forceinline__ int solve(const Consts& K, const Prep& P, const double (&z)[6], const double (&fxc)[6],
                                               double (&t)[6], Aux& A, int max_iters, double tol) {
     int st = 0;
     if (K.dir == kDirPrior || (SOLVER == kSolverClosedForm && K.dir == 0)) {
@@ -466,9 +464,9 @@ struct P3P3 {
     } else {
       P3P3Cost cost;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { cost.a[k] = P.a[k]; cost.zt[k] = z[k]; }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) cost.qa[k] = P.qa[k];
+      for (int k = 0; k < 3; ++k) cost.zt[k] = z[k];
+      so3_exp(&z[3], cost.Z);
+      se3_from_coords(fxc, cost.F);
       cost.dir = K.dir;
       quat_log(A.q, &t[3]);   // X0c = vee(log(ϵ,u0)): Nelder-Mead works on the (t, ω) coordinates
       st = nelder_mead<6>(cost, t, max_iters, tol);
