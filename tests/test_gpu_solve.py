@@ -167,3 +167,27 @@ def test_honeycomb_grow_and_solve_windows():
         assert np.hypot(*(lm[k] - R.getPPE(fg, l))) < 2.5, (l, lm[k], R.getPPE(fg, l))
     for l, k in pi.items():
         assert np.hypot(*(pm[k][:2] - R.getPPE(fg, l)[:2])) < 2.5, (l, pm[k], R.getPPE(fg, l))
+
+
+@pytest.mark.parametrize("bad", ["x2", "x1"])
+def test_stationary_poses_recover_from_bad_initialisation(bad):
+    """test/testBasicPose2Stationary.jl:8-58 (+ the forced-bad-init variant): x0 prior at 0, two zero odometry steps, σ = 0.01;
+    one belief is initialised around (−5, −2, 0.5); after the solve > 95 % of every belief is back in the window
+    |x|,|y| < 1, |θ| < 0.5."""
+    N = 100
+    cov = 1e-4 * np.eye(3)
+    fg = R.initfg(N)
+    fg.addVariable("x0", R.Pose2); fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.zeros(3), cov)))
+    fg.addVariable("x1", R.Pose2); fg.addFactor(["x0", "x1"], R.Pose2Pose2(R.MvNormal(np.zeros(3), cov)))
+    fg.addVariable("x2", R.Pose2); fg.addFactor(["x1", "x2"], R.Pose2Pose2(R.MvNormal(np.zeros(3), cov)))
+    R.dead_reckon_init(fg, seed=3, sigma=(0.01, 0.01, 0.01))
+    rng = np.random.default_rng(8)
+    fg.initVariable(bad, (0.01 * rng.standard_normal((N, 3)) + np.array([-5.0, -2.0, 0.5])).T.copy())
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.solve(R.make_opts(N=N, solver=1, seed=404), n_sweeps=8)
+    b = dg.bel[R.Pose2].cpu().numpy()
+    for v in range(3):
+        assert (np.abs(b[v, 0]) < 1.0).sum() > 0.95 * N and (np.abs(b[v, 1]) < 1.0).sum() > 0.95 * N
+        assert (np.abs(b[v, 2]) < 0.5).sum() > 0.95 * N
+    m, _ = dg.belief_stats(R.Pose2)
+    assert np.abs(m.cpu().numpy()[:3]).max() < 0.1
