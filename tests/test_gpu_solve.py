@@ -191,3 +191,37 @@ def test_stationary_poses_recover_from_bad_initialisation(bad):
         assert (np.abs(b[v, 2]) < 0.5).sum() > 0.95 * N
     m, _ = dg.belief_stats(R.Pose2)
     assert np.abs(m.cpu().numpy()[:3]).max() < 0.1
+
+
+def test_bearing_range_graph_nonparametric_vs_parametric_380():
+    """test/testInflation380.jl:89-150 ("bearing range with inflation, #380"): three poses facing −π, two landmarks sighted with
+    tight bearing/range factors; the non-parametric estimate of x2 must agree with the parametric one to 0.5 m / 0.6 rad."""
+    rng = np.random.default_rng(380)
+    N = 100
+    pr, od, sb, sr = np.array([0.01, 0.01, 0.001]), np.array([0.2, 0.2, 0.2]), 0.008, 0.01
+    fg = R.initfg(N)
+    fg.addVariable("x0", R.Pose2)
+    fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.array([0, 0, -np.pi]) + pr * rng.standard_normal(3), np.diag(pr ** 2))))
+    fg.addVariable("l1", R.Point2); fg.addVariable("l2", R.Point2)
+    br = lambda b, r: R.Pose2Point2BearingRange(R.Normal(b + sb * rng.standard_normal(), sb), R.Normal(r + sr * rng.standard_normal(), sr))
+    fg.addFactor(["x0", "l1"], br(np.pi / 4, np.sqrt(2)))
+    fg.addVariable("x1", R.Pose2)
+    fg.addFactor(["x0", "x1"], R.Pose2Pose2(R.MvNormal(np.array([1.0, 0, 0]) + od * rng.standard_normal(3), np.diag(od ** 2))))
+    fg.addFactor(["x1", "l1"], br(np.pi / 2, 1.0)); fg.addFactor(["x1", "l2"], br(-np.pi / 2, 1.0))
+    fg.addVariable("x2", R.Pose2)
+    fg.addFactor(["x1", "x2"], R.Pose2Pose2(R.MvNormal(np.array([1.0, 0, 0]) + od * rng.standard_normal(3), np.diag(od ** 2))))
+    fg.addFactor(["x2", "l1"], br(3 * np.pi / 4, np.sqrt(2))); fg.addFactor(["x2", "l2"], br(-3 * np.pi / 4, np.sqrt(2)))
+    R.dead_reckon_init(fg, seed=2, sigma=(0.05, 0.05, 0.02))
+    xp = R.solveGraphParametric(fg)
+    assert np.allclose(xp["x2"][:2], [-2, 0], atol=0.4) and np.allclose(xp["l1"], [-1, -1], atol=0.3) and np.allclose(xp["l2"], [-1, 1], atol=0.3)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.solve(R.make_opts(N=N, solver=1, seed=3800), n_sweeps=15)
+    m, _ = dg.belief_stats(R.Pose2)
+    i2 = dg.packed.labels[R.Pose2].index("x2")
+    est = m.cpu().numpy()[i2]
+    assert abs(est[0] - xp["x2"][0]) < 0.5 and abs(est[1] - xp["x2"][1]) < 0.5
+    assert abs(np.arctan2(np.sin(est[2] - xp["x2"][2]), np.cos(est[2] - xp["x2"][2]))) < 0.6
+    ml, _ = dg.belief_stats(R.Point2)
+    ml = ml.cpu().numpy()
+    for l in ("l1", "l2"):
+        assert np.hypot(*(ml[dg.packed.labels[R.Point2].index(l)] - xp[l])) < 0.5
