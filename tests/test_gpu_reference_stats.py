@@ -63,3 +63,38 @@ def test_pose_and_point_convolutions():
     fg.initVariable("l1", lp)
     xp = R.approxConv(fg, f4, "x0", seed=4)
     assert np.isfinite(xp).all()
+
+
+@pytest.mark.parametrize("case", ["yaw", "pitch_from_pi"])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_pose3_hexagon_chain_initialisation(case, solver):
+    """test/testSimpleHexPose3.jl: a PriorPose3 and six Pose3Pose3 legs of 10 m turning π/3 (about z from identity, or about y
+    from a start yawed by π), initialised leg by leg (`initAll!`): the chain closes on itself -- x6 comes back to x0 --
+    and x3 is the opposite corner of the hexagon."""
+    from scipy.spatial.transform import Rotation as Rot
+    N = 100
+    fg = R.initfg(N)
+    fg.addVariable("x0", R.Pose3)
+    yaw0 = 0.0 if case == "yaw" else np.pi
+    f0 = fg.addFactor(["x0"], R.PriorPose3(R.MvNormal([0.0, 0, 0, 0, 0, yaw0], np.diag(np.square([0.1, 0.1, 0.1, 0.01, 0.01, 0.01])))))
+    fg.initVariable("x0", R.approxConv(fg, f0, "x0", seed=1))
+    turn = [0, 0, np.pi / 3] if case == "yaw" else [0, np.pi / 3, 0]
+    for i in range(6):
+        fg.addVariable("x%d" % (i + 1), R.Pose3)
+        fl = fg.addFactor(["x%d" % i, "x%d" % (i + 1)],
+                          R.Pose3Pose3(R.MvNormal([10.0, 0, 0] + turn, np.diag(np.square([0.5, 0.5, 0.5, 0.05, 0.05, 0.05])))))
+        fg.initVariable("x%d" % (i + 1), R.approxConv(fg, fl, "x%d" % (i + 1), solver=solver, seed=10 + i))
+    mean, sd = R.belief_stats(np.stack([fg.getVal("x%d" % i) for i in range(7)]))
+    # exact (noise-free) chain
+    T = [np.eye(4)]; T[0][:3, :3] = Rot.from_rotvec([0, 0, yaw0]).as_matrix()
+    D = np.eye(4); D[:3, :3] = Rot.from_rotvec(turn).as_matrix(); D[:3, 3] = [10, 0, 0]
+    for i in range(6):
+        T.append(T[-1] @ D)
+    assert np.allclose(T[6][:3, 3], 0, atol=1e-9)
+    for i in range(7):
+        assert np.linalg.norm(mean[i, :3] - T[i][:3, 3]) < 0.5 + 4 * np.linalg.norm(sd[i, :3]) / np.sqrt(N), (i, mean[i], T[i][:3, 3])
+        dR = Rot.from_rotvec(mean[i, 3:]).as_matrix().T @ T[i][:3, :3]
+        assert np.linalg.norm(Rot.from_matrix(dR).as_rotvec()) < 0.15, i
+    assert np.linalg.norm(mean[3, :3] - T[3][:3, 3]) < 3.0 and np.linalg.norm(T[3][:3, 3]) > 19.9
+    # uncertainty grows along the chain
+    assert np.linalg.norm(sd[6, :3]) > np.linalg.norm(sd[1, :3]) > np.linalg.norm(sd[0, :3])
