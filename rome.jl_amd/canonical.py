@@ -367,13 +367,29 @@ def _quat_from_R(R):
     return q if q[0] >= 0 else -q
 
 
-def exportG2o(fg, filename="/tmp/test.txt", ignorePriors=True, posePrefix="x"):
+def exportG2o(fg, filename="/tmp/test.txt", ignorePriors=True, posePrefix="x", estimates=None, varIntLabel=None):
     """Write the graph as g2o records: pose variables in label order, each contributing the not-yet-written factors
-    attached to it in creation order; variables are numbered from 0 in order of first appearance
-    (g2oParser.jl:337-396)."""
+    attached to it in creation order; variables are numbered from 0 in order of first appearance, or as `varIntLabel`
+    (label -> int) says.  With `estimates` (label -> coordinates; the reference's `solveKey=` PPEs) VERTEX_SE2 /
+    VERTEX_SE3:QUAT records of the numbered variables come first (g2oParser.jl:298-396, test/testG2oExportSE3.jl)."""
     ids = _VarIds()
+    if varIntLabel:
+        ids.ids.update(varIntLabel)
     done = set()
     lines = []
+    if estimates is not None:
+        if not varIntLabel:
+            raise ValueError("exportG2o: vertex records need varIntLabel (as the reference's exporter does)")
+        for label, i in varIntLabel.items():
+            c = np.asarray(estimates[label], dtype=float)
+            if fg.variables[label] is Pose2:
+                lines.append("VERTEX_SE2 %d %s" % (i, " ".join(_jl(x) for x in c)))
+            else:
+                from .factors import getPoint, Pose3
+                if fg.variables[label] is not Pose3:
+                    raise TypeError("exportG2o does not support %s vertices" % fg.variables[label])
+                q = _quat_from_R(np.asarray(getPoint(Pose3, c))[3:].reshape(3, 3, order="F"))
+                lines.append("VERTEX_SE3:QUAT %d %s" % (i, " ".join(_jl(x) for x in (c[0], c[1], c[2], q[1], q[2], q[3], q[0]))))
     for pose in _pose_labels(fg, posePrefix):
         for flabel, labels, f in fg.factors:
             if pose not in labels or flabel in done:

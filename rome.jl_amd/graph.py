@@ -120,8 +120,28 @@ def parseG2oInstruction(fg, ins):
             if not fg.exists(l):
                 fg.addVariable(l, Pose2)
         fg.addFactor([a, b], Pose2Pose2(MvNormal(mu, cov)))
-    elif ins[0] in ("VERTEX_SE3:QUAT", "EDGE_SE3:QUAT"):
-        raise NotImplementedError("SE3 g2o records are outside the round-1 scope")
+    elif ins[0] == "VERTEX_SE3:QUAT":      # id x y z qx qy qz qw  (g2oParser.jl:76-92)
+        from scipy.spatial.transform import Rotation as Rot
+        lbl = "x" + ins[1]
+        v = [float(x) for x in ins[2:9]]
+        if not fg.exists(lbl):
+            fg.addVariable(lbl, Pose3)
+        fg.vertex_init = getattr(fg, "vertex_init", {})
+        fg.vertex_init[lbl] = np.concatenate([v[0:3], Rot.from_quat(v[3:7]).as_rotvec()])
+    elif ins[0] == "EDGE_SE3:QUAT":        # i j x y z qx qy qz qw + 21 upper-triangle information entries (g2oParser.jl:124-168)
+        from scipy.spatial.transform import Rotation as Rot
+        a, b = "x" + ins[1], "x" + ins[2]
+        v = [float(x) for x in ins[3:31]]
+        mu = np.concatenate([v[0:3], Rot.from_quat(v[3:7]).as_rotvec()])   # coordinates [t; vee(Log(dR))]
+        info = np.zeros((6, 6))
+        info[np.triu_indices(6)] = v[7:28]
+        info = info + np.triu(info, 1).T
+        cov = np.linalg.inv(info)
+        cov = (cov + cov.T) / 2.0
+        for l in (a, b):
+            if not fg.exists(l):
+                fg.addVariable(l, Pose3)
+        fg.addFactor([a, b], Pose3Pose3(MvNormal(mu, cov)))
     return fg
 
 

@@ -160,3 +160,35 @@ def test_point2point2_is_outside_the_device_path():
     fg = R.generateGraph_Boxes2D(4)
     with pytest.raises(TypeError):
         R.PackedGraph(fg)
+
+
+def test_g2o_se3_export_import_round_trip(tmp_path):
+    # test/testG2oExportSE3.jl:7-20 (export of an SE(3) graph with vertex estimates) + the EDGE_SE3:QUAT / VERTEX_SE3:QUAT
+    # import path of src/services/g2oParser.jl:76-168
+    from scipy.spatial.transform import Rotation as Rot
+    fg = R.synth_helix3d(P=40)
+    labels = [l for l in fg.ls()]
+    est = {l: fg.ground_truth[l] for l in labels}
+    path = R.exportG2o(fg, filename=str(tmp_path / "h.g2o"), estimates=est, varIntLabel={l: i for i, l in enumerate(labels)})
+    ins = R.importG2o(path)
+    assert sum(1 for i in ins if i[0] == "VERTEX_SE3:QUAT") == 40
+    n_edges = sum(1 for _, _, f in fg.factors if isinstance(f, R.Pose3Pose3))
+    assert sum(1 for i in ins if i[0] == "EDGE_SE3:QUAT") == n_edges and all(len(i) == 31 for i in ins if i[0] == "EDGE_SE3:QUAT")
+    back = R.initfg()
+    for i in ins:
+        R.parseG2oInstruction(back, i)
+    assert len(back.ls()) == 40
+    a = [(l, f) for _, l, f in fg.factors if isinstance(f, R.Pose3Pose3)]
+    b = [(l, f) for _, l, f in back.factors if isinstance(f, R.Pose3Pose3)]
+    assert sorted(tuple(l) for l, _ in a) == sorted(tuple(l) for l, _ in b)   # written pose by pose, same factor set
+    bd = {tuple(l): f for l, f in b}
+    for la, fa in a:
+        fb = bd[tuple(la)]
+        assert np.allclose(fa.Z.mu[:3], fb.Z.mu[:3], atol=1e-14)
+        dR = Rot.from_rotvec(fa.Z.mu[3:]).as_matrix().T @ Rot.from_rotvec(fb.Z.mu[3:]).as_matrix()
+        assert np.linalg.norm(Rot.from_matrix(dR).as_rotvec()) < 1e-12
+        assert np.allclose(fa.Z.cov, fb.Z.cov, rtol=1e-9, atol=1e-16)
+    for l in labels:
+        assert np.allclose(back.vertex_init[l][:3], est[l][:3], atol=1e-14)
+        dR = Rot.from_rotvec(back.vertex_init[l][3:]).as_matrix().T @ Rot.from_rotvec(est[l][3:]).as_matrix()
+        assert np.linalg.norm(Rot.from_matrix(dR).as_rotvec()) < 1e-12
