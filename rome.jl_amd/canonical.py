@@ -62,6 +62,19 @@ def _predict(factor, prev):
     raise TypeError("no simulated prediction for %s" % type(factor).__name__)
 
 
+def accumulateFactorMeans(fg, flabels):
+    """Compose the measurement means of a prior followed by a chain of relative factors (IIF `accumulateFactorMeans`,
+    pinned by test/testAccumulateFactors.jl:13-33 and test/testParametricSimulated.jl:62-65,149-152)."""
+    flabels = list(flabels)
+    _, _, f0 = fg.getFactor(flabels[0])
+    if not f0.is_prior:
+        raise ValueError("accumulateFactorMeans: the first factor must be a prior")
+    val = np.asarray(f0.Z.mu, dtype=float).copy()
+    for fl in flabels[1:]:
+        val = _predict(fg.getFactor(fl)[2], val)
+    return val
+
+
 def _add_pose_canonical(fg, prev, label, factor, vartype=Pose2, override=None, postpose_cb=None):
     """One new variable + the factor that introduces it (+ its simulated estimate)."""
     if factor.is_prior:

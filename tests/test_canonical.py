@@ -192,3 +192,24 @@ def test_g2o_se3_export_import_round_trip(tmp_path):
         assert np.allclose(back.vertex_init[l][:3], est[l][:3], atol=1e-14)
         dR = Rot.from_rotvec(back.vertex_init[l][3:]).as_matrix().T @ Rot.from_rotvec(est[l][3:]).as_matrix()
         assert np.linalg.norm(Rot.from_matrix(dR).as_rotvec()) < 1e-12
+
+
+def test_accumulate_factor_means():
+    # test/testAccumulateFactors.jl:13-33
+    fg = R.initfg()
+    fg.addVariable("x0", R.Pose2); fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.zeros(3), 0.001 * np.eye(3))))
+    fg.addVariable("x1", R.Pose2); fg.addFactor(["x0", "x1"], R.Pose2Pose2(R.MvNormal([10, 0, 0.0], 0.001 * np.eye(3))))
+    assert np.allclose(R.accumulateFactorMeans(fg, ["x0f1", "x0x1f1"]), [10, 0, 0], atol=1e-3)
+    # test/testParametricSimulated.jl:20-65: heading wraps to ≈ ±π
+    fg = R.initfg()
+    fg.addVariable("x0", R.Pose2); fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.zeros(3), 0.01 * np.eye(3))))
+    fg.addVariable("x1", R.Pose2); fg.addFactor(["x0", "x1"], R.Pose2Pose2(R.MvNormal([0, 0, -np.pi + 0.01], 0.03 * np.eye(3))))
+    v = R.accumulateFactorMeans(fg, ["x0f1", "x0x1f1"])
+    assert np.allclose(v[:2], [0, 0], atol=5e-4) and 0.9 * np.pi < abs(v[2])
+    # test/testParametricSimulated.jl:78-152
+    fg = R.initfg()
+    fg.addVariable("x2", R.Pose2)
+    fg.addFactor(["x2"], R.PriorPose2(R.MvNormal([15.000000000016204, 8.660254037814505, 2.0943951023931953], 0.01 * np.eye(3))))
+    fg.addVariable("x3", R.Pose2); fg.addFactor(["x2", "x3"], R.Pose2Pose2(R.MvNormal([10, 0, np.pi / 3], 0.01 * np.eye(3))))
+    v = R.accumulateFactorMeans(fg, ["x2f1", "x2x3f1"])
+    assert np.allclose(v[:2], [10, 17.32], atol=1e-2) and abs(abs(v[2]) - np.pi) < 1e-2

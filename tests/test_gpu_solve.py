@@ -225,3 +225,15 @@ def test_bearing_range_graph_nonparametric_vs_parametric_380():
     ml = ml.cpu().numpy()
     for l in ("l1", "l2"):
         assert np.hypot(*(ml[dg.packed.labels[R.Point2].index(l)] - xp[l])) < 0.5
+
+
+def test_two_pose_odo_generator_solves():
+    # test/testGraphGenerators.jl:5-14: generateGraph_TwoPoseOdo() solved: x0 stays at the origin (±1)
+    fg = R.generateGraph_TwoPoseOdo(N=100)
+    R.dead_reckon_init(fg, seed=6)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.solve(R.make_opts(N=100, solver=1, seed=12), n_sweeps=6)
+    m, _ = dg.belief_stats(R.Pose2)
+    m = m.cpu().numpy()
+    assert np.allclose(R.getPPE(fg, "x0"), 0, atol=1) and np.allclose(m[0], 0, atol=1)
+    assert np.allclose(m[1], [10, 0, 0], atol=2)
