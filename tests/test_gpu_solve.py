@@ -237,3 +237,38 @@ def test_two_pose_odo_generator_solves():
     m = m.cpu().numpy()
     assert np.allclose(R.getPPE(fg, "x0"), 0, atol=1) and np.allclose(m[0], 0, atol=1)
     assert np.allclose(m[1], [10, 0, 0], atol=2)
+
+
+def test_double_hexagon_two_landmarks_windows():
+    """test/testBeehive2D_DoubleHexInit.jl:7-66: hexagon x0..x6 with landmark l1 (sighted from x0 and x6), an offset leg to x7,
+    a second hexagon x8..x13 with l2 (sighted from x7 and x13); > 80 of 100 particles inside the reference's boxes."""
+    N = 100
+    fg = R.initfg(N)
+    fg.addVariable("x0", R.Pose2)
+    fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.zeros(3), np.diag(np.square([0.1, 0.1, 0.05])))))
+    leg = lambda turn: R.Pose2Pose2(R.MvNormal([10.0, 0.0, turn], np.diag(np.square([0.1, 0.1, 0.1]))))
+    sight = lambda: R.Pose2Point2BearingRange(R.Normal(0, 0.03), R.Normal(20.0, 0.5))
+    fg.addVariable("l1", R.Point2); fg.addFactor(["x0", "l1"], sight())
+    for i in range(6):
+        fg.addVariable("x%d" % (i + 1), R.Pose2); fg.addFactor(["x%d" % i, "x%d" % (i + 1)], leg(np.pi / 3))
+    fg.addFactor(["x6", "l1"], sight())
+    fg.addVariable("x7", R.Pose2); fg.addFactor(["x6", "x7"], leg(-np.pi / 3))
+    fg.addVariable("l2", R.Point2); fg.addFactor(["x7", "l2"], sight())
+    for i in range(7, 13):
+        fg.addVariable("x%d" % (i + 1), R.Pose2); fg.addFactor(["x%d" % i, "x%d" % (i + 1)], leg(np.pi / 3))
+    fg.addFactor(["x13", "l2"], sight())
+    R.dead_reckon_init(fg, seed=14)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.solve(R.make_opts(N=N, solver=1, seed=141), n_sweeps=15)
+    b = dg.bel[R.Pose2].cpu().numpy(); l = dg.bel[R.Point2].cpu().numpy()
+    idx = {lb: k for k, lb in enumerate(dg.packed.labels[R.Pose2])}
+    win = {"x0": ((-3, 3), (-3, 3), (-0.3, 0.3)), "x1": ((7, 13), (-3, 3), (0.7, 1.3)), "x2": ((12, 18), (6, 11), (1.8, 2.4)),
+           "x3": ((7, 13), (15, 20), None), "x4": ((-4, 4), (15, 20), (-2.4, -1.8)), "x5": ((-8, -2), (6, 11), (-1.3, -0.7)),
+           "x6": ((-3, 3), (-3, 3), (-0.3, 0.3))}
+    for lb, w in win.items():
+        p = b[idx[lb]]
+        for d in range(3):
+            if w[d] is not None:
+                assert 80 < ((w[d][0] < p[d]) & (p[d] < w[d][1])).sum(), (lb, d, p[d].mean())
+    l1 = l[dg.packed.labels[R.Point2].index("l1")]
+    assert 80 < ((17 < l1[0]) & (l1[0] < 23)).sum() and 80 < ((-5 < l1[1]) & (l1[1] < 5)).sum()
