@@ -191,6 +191,18 @@ def main():
             torch.cuda.synchronize()
             modes[name] = tb["C"] * reps / (time.perf_counter() - a)
         out["gpu_convolutions_per_s_by_solver"] = modes
+        # the other half of the metric ("solveTree! wall-clock"): one iteration of the device-resident solve loop on the
+        # same graph = all convolutions (one launch) + the proposal product of every variable (one launch); DESIGN.md §11
+        o3 = R.make_opts(N=N, solver=R.SOLVER_NEWTON, seed=0x524F4D45)
+        saved = dg.bel[R.Pose2].clone()
+        dg.conv_step(o3, 0); dg.product_step(o3, 0); torch.cuda.synchronize()
+        a = time.perf_counter()
+        for s in range(50):
+            dg.conv_step(o3, s); dg.product_step(o3, s)
+        torch.cuda.synchronize()
+        out["solve_loop"] = {"ms_per_iteration": (time.perf_counter() - a) * 1e3 / 50,
+                             "what": "conv sweep + proposal product of all %d variables (stand-in for the clique Gibbs of solveTree!, no Bayes tree)" % len(pk.labels[R.Pose2])}
+        dg.bel[R.Pose2].copy_(saved)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R, pk, fg, N, args.cpu_seconds)
