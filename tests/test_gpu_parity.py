@@ -169,10 +169,11 @@ def _br_inputs(C_, N, direction, seed):
     return (mu, sigma, pose, pt, noise) if direction == 0 else (mu, sigma, pt, pose, noise)
 
 
+@pytest.mark.parametrize("N", [50, 100, 256, 400])   # particles-per-lane instantiations 1, 2, 4, 8
 @pytest.mark.parametrize("direction", [0, 1])
 @pytest.mark.parametrize("solver", [0, 1])
-def test_bearingrange_vs_oracle(direction, solver):
-    C_, N = 29, 100
+def test_bearingrange_vs_oracle(direction, solver, N):
+    C_ = 29
     mu, sigma, fixed, target, noise = _br_inputs(C_, N, direction, 40 + direction)
     o = R.make_opts(N=N, solver=solver, seed=99)
     out, st = R.conv_pose2point2br(o, direction, mu, sigma, fixed, target, noise=noise, want_status=True)
@@ -224,7 +225,7 @@ def _so3_dist(a, b):
 
 
 @pytest.mark.parametrize("solver", [0, 1])
-@pytest.mark.parametrize("N", [33, 100])
+@pytest.mark.parametrize("N", [33, 100, 200, 300, 512])   # every particles-per-lane instantiation (1, 2, 4, 8)
 def test_pose3pose3_vs_oracle(solver, N):
     C_ = 19
     mu, cov, fixed, target, dirs, noise = _p3_inputs(C_, N, 200 + N)
@@ -233,7 +234,14 @@ def test_pose3pose3_vs_oracle(solver, N):
     bel = np.concatenate([fixed, target], 0)
     ref, rst = ro.conv_pose3pose3(ro.make_opts(N=N, solver=solver, seed=5), mu, L, bel, np.arange(C_), C_ + np.arange(C_), dirs,
                                   noise=noise, want_status=True)
-    assert _so3_dist(out, ref) < 1e-9
+    # rotation vectors within 1e-2 of |ω| = π are compared at the conditioning of the reference's matrix Log there (the oracle
+    # follows Manifolds' formula; the kernel's quaternion Log is the better conditioned of the two)
+    near = np.linalg.norm(ref[:, 3:], axis=1) > np.pi - 1e-2
+    from scipy.spatial.transform import Rotation as Rot
+    ang = (Rot.from_rotvec(out[:, 3:].transpose(0, 2, 1).reshape(-1, 3)).inv() *
+           Rot.from_rotvec(ref[:, 3:].transpose(0, 2, 1).reshape(-1, 3))).magnitude().reshape(near.shape)
+    assert np.abs(out[:, :3] - ref[:, :3]).max() < 1e-9
+    assert ang[~near].max() < 1e-9 and (not near.any() or ang[near].max() < 1e-6)
     assert (st == 0).all() and (rst == 0).all()
 
 
