@@ -17,6 +17,10 @@ struct rome_ctx {
   static constexpr int kBufs = 11;
   void* dbuf[kBufs] = {nullptr};
   size_t dcap[kBufs] = {0};
+  // pinned host staging of the host-pointer entry points (layout conversion writes straight into DMA-able memory)
+  static constexpr int kHostBufs = 4;   // 0 fixed, 1 target (+ alternative landmark blocks), 2 noise, 3 out
+  void* hbuf[kHostBufs] = {nullptr};
+  size_t hcap[kHostBufs] = {0};
 };
 
 namespace {
@@ -41,6 +45,19 @@ int ensure(rome_ctx* c, int idx, size_t bytes, void** out) {
     c->dcap[idx] = cap;
   }
   *out = c->dbuf[idx];
+  return ROME_OK;
+}
+
+int ensure_host(rome_ctx* c, int idx, size_t bytes, double** out) {
+  if (bytes == 0) bytes = 8;
+  if (c->hcap[idx] < bytes) {
+    if (c->hbuf[idx]) { hipError_t e = hipHostFree(c->hbuf[idx]); if (e != hipSuccess) return hip_fail(c, e); c->hbuf[idx] = nullptr; c->hcap[idx] = 0; }
+    size_t cap = bytes + bytes / 4;
+    hipError_t e = hipHostMalloc(&c->hbuf[idx], cap, hipHostMallocDefault);
+    if (e != hipSuccess) return hip_fail(c, e);
+    c->hcap[idx] = cap;
+  }
+  *out = (double*)c->hbuf[idx];
   return ROME_OK;
 }
 
@@ -99,19 +116,18 @@ int cholesky_one(int d, const double* cov, double* Lp) {
   return ROME_OK;
 }
 
-// host blocks [C][N][d] (AoS) or [C][d][N] (SoA)  ->  SoA staging vector
-void to_soa(const double* src, int C, int N, int d, int layout, std::vector<double>& dst) {
-  dst.resize((size_t)C * N * d);
-  if (layout == ROME_LAYOUT_SOA) { std::memcpy(dst.data(), src, dst.size() * sizeof(double)); return; }
+// host blocks [C][N][d] (AoS) or [C][d][N] (SoA)  ->  SoA staging (pinned)
+void to_soa(const double* src, int C, int N, int d, int layout, double* dst) {
+  if (layout == ROME_LAYOUT_SOA) { std::memcpy(dst, src, (size_t)C * N * d * sizeof(double)); return; }
   for (int c = 0; c < C; ++c) {
-    const double* s = src + (size_t)c * N * d; double* o = dst.data() + (size_t)c * N * d;
+    const double* s = src + (size_t)c * N * d; double* o = dst + (size_t)c * N * d;
     for (int i = 0; i < N; ++i) for (int k = 0; k < d; ++k) o[(size_t)k * N + i] = s[(size_t)i * d + k];
   }
 }
-void from_soa(const std::vector<double>& src, int C, int N, int d, int layout, double* dst) {
-  if (layout == ROME_LAYOUT_SOA) { std::memcpy(dst, src.data(), src.size() * sizeof(double)); return; }
+void from_soa(const double* src, int C, int N, int d, int layout, double* dst) {
+  if (layout == ROME_LAYOUT_SOA) { std::memcpy(dst, src, (size_t)C * N * d * sizeof(double)); return; }
   for (int c = 0; c < C; ++c) {
-    const double* s = src.data() + (size_t)c * N * d; double* o = dst + (size_t)c * N * d;
+    const double* s = src + (size_t)c * N * d; double* o = dst + (size_t)c * N * d;
     for (int i = 0; i < N; ++i) for (int k = 0; k < d; ++k) o[(size_t)i * d + k] = s[(size_t)k * N + i];
   }
 }
@@ -164,37 +180,43 @@ int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const i
   }
   ROME_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  std::vector<double> h_fixed, h_target, h_noise;
   const bool has_fixed = (kind != kPrior2 && kind != kPrior3);
-  if (has_fixed) { to_soa(fixed, C, N, df, o->layout, h_fixed); to_soa(target_inout, C, N, dt, o->layout, h_target); }
-  if (noise) to_soa(noise, C, N, dz, o->layout, h_noise);
+  const bool mh = alt && hypo_w;   // multihypo: the alternative landmark blocks are appended behind the landmark-side array
+  const size_t blk_f = (size_t)C * N * df, blk_t = (size_t)C * N * dt;
+  const size_t n_fixed = has_fixed ? blk_f * ((mh && dir_all == 1) ? 2 : 1) : 0;
+  const size_t n_target = has_fixed ? blk_t * ((mh && dir_all != 1) ? 2 : 1) : 0;
+  const size_t n_noise = noise ? (size_t)C * N * dz : 0;
+  double *h_fixed = nullptr, *h_target = nullptr, *h_noise = nullptr, *h_out = nullptr;
+  int rc;
+  if (has_fixed) {
+    if ((rc = ensure_host(ctx, 0, sizeof(double) * n_fixed, &h_fixed))) return rc;
+    if ((rc = ensure_host(ctx, 1, sizeof(double) * n_target, &h_target))) return rc;
+    to_soa(fixed, C, N, df, o->layout, h_fixed); to_soa(target_inout, C, N, dt, o->layout, h_target);
+  }
+  if (noise) { if ((rc = ensure_host(ctx, 2, sizeof(double) * n_noise, &h_noise))) return rc; to_soa(noise, C, N, dz, o->layout, h_noise); }
+  if ((rc = ensure_host(ctx, 3, sizeof(double) * blk_t, &h_out))) return rc;
   std::vector<int32_t> h_alt;
-  if (alt && hypo_w) {  // multihypo: the alternative landmark blocks are appended behind the landmark-side array
-    std::vector<double> h_a;
-    const int dl = dir_all == 1 ? df : dt;
-    to_soa(alt, C, N, dl, o->layout, h_a);
-    std::vector<double>& side = dir_all == 1 ? h_fixed : h_target;
-    side.insert(side.end(), h_a.begin(), h_a.end());
+  if (mh) {
+    if (dir_all == 1) to_soa(alt, C, N, df, o->layout, h_fixed + blk_f); else to_soa(alt, C, N, dt, o->layout, h_target + blk_t);
     h_alt.resize(C);
     for (int c = 0; c < C; ++c) h_alt[c] = C + c;
   }
 
   void *d_mu, *d_L, *d_fixed = nullptr, *d_target = nullptr, *d_noise = nullptr, *d_out, *d_dir = nullptr, *d_status = nullptr;
-  int rc;
   if ((rc = ensure(ctx, 0, sizeof(double) * C * dz, &d_mu))) return rc;
   if ((rc = ensure(ctx, 1, sizeof(double) * C * nL, &d_L))) return rc;
   if ((rc = ensure(ctx, 2, sizeof(double) * (size_t)C * N * dt, &d_out))) return rc;
   ROME_HIP(ctx, hipMemcpyAsync(d_mu, mu, sizeof(double) * C * dz, hipMemcpyHostToDevice, s));
   ROME_HIP(ctx, hipMemcpyAsync(d_L, Ltab, sizeof(double) * C * nL, hipMemcpyHostToDevice, s));
   if (has_fixed) {
-    if ((rc = ensure(ctx, 3, sizeof(double) * h_fixed.size(), &d_fixed))) return rc;
-    if ((rc = ensure(ctx, 4, sizeof(double) * h_target.size(), &d_target))) return rc;
-    ROME_HIP(ctx, hipMemcpyAsync(d_fixed, h_fixed.data(), sizeof(double) * h_fixed.size(), hipMemcpyHostToDevice, s));
-    ROME_HIP(ctx, hipMemcpyAsync(d_target, h_target.data(), sizeof(double) * h_target.size(), hipMemcpyHostToDevice, s));
+    if ((rc = ensure(ctx, 3, sizeof(double) * n_fixed, &d_fixed))) return rc;
+    if ((rc = ensure(ctx, 4, sizeof(double) * n_target, &d_target))) return rc;
+    ROME_HIP(ctx, hipMemcpyAsync(d_fixed, h_fixed, sizeof(double) * n_fixed, hipMemcpyHostToDevice, s));
+    ROME_HIP(ctx, hipMemcpyAsync(d_target, h_target, sizeof(double) * n_target, hipMemcpyHostToDevice, s));
   }
   if (noise) {
-    if ((rc = ensure(ctx, 5, sizeof(double) * h_noise.size(), &d_noise))) return rc;
-    ROME_HIP(ctx, hipMemcpyAsync(d_noise, h_noise.data(), sizeof(double) * h_noise.size(), hipMemcpyHostToDevice, s));
+    if ((rc = ensure(ctx, 5, sizeof(double) * n_noise, &d_noise))) return rc;
+    ROME_HIP(ctx, hipMemcpyAsync(d_noise, h_noise, sizeof(double) * n_noise, hipMemcpyHostToDevice, s));
   }
   if (dir) {
     if ((rc = ensure(ctx, 6, sizeof(int32_t) * C, &d_dir))) return rc;
@@ -233,8 +255,7 @@ int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const i
     case kPrior3: e = rome::launch_sample_priorpose3(a, s); break;
   }
   ROME_HIP(ctx, e);
-  std::vector<double> h_out((size_t)C * N * dt);   // (with multihypo the target staging holds 2C blocks; the first C are the result)
-  ROME_HIP(ctx, hipMemcpyAsync(h_out.data(), d_out, sizeof(double) * h_out.size(), hipMemcpyDeviceToHost, s));
+  ROME_HIP(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * blk_t, hipMemcpyDeviceToHost, s));
   if (status) ROME_HIP(ctx, hipMemcpyAsync(status, d_status, sizeof(int32_t) * (size_t)C * N, hipMemcpyDeviceToHost, s));
   ROME_HIP(ctx, hipStreamSynchronize(s));
   from_soa(h_out, C, N, dt, o->layout, target_inout);
@@ -328,6 +349,7 @@ void rome_ctx_destroy(rome_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < rome_ctx::kBufs; ++i) if (c->dbuf[i]) (void)hipFree(c->dbuf[i]);
+  for (int i = 0; i < rome_ctx::kHostBufs; ++i) if (c->hbuf[i]) (void)hipHostFree(c->hbuf[i]);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
