@@ -11,6 +11,9 @@
  *                          test/testPartialPose3.jl:390-436  (tests/golden/residual_kats.json)
  *   optimiser/RNG/entropy  PARITY UNPINNED by the reference (no seeds, no iterate checks);
  *                          restated from IIF 0.35 / Optim 1.x / Manifolds 0.10.1 (not vendored).
+ *   convolution statistics pinned statistically on the reference's own solved graph examples/fg-after-solve.tar.gz
+ *                          (tests/golden/manhattan500_reference_solve.npz, tests/test_gpu_reference_solve.py) and on the
+ *                          statistical assertions of test/testBasicPose2Conv.jl, test/TestPoseAndPoint2Constraints.jl.
  */
 #include "rome_oracle.h"
 #include <math.h>
