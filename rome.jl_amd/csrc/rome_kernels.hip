@@ -256,9 +256,9 @@ struct BR {
         t[0] = fx[0] + z[1] * c; t[1] = fx[1] + z[1] * s;
       } else {
         const double dx = fx[0] - t[0], dy = fx[1] - t[1];
-        const double n = sqrt(dx * dx + dy * dy);
+        const double n = fast_sqrt(dx * dx + dy * dy);
         const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
-        t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = atan2(uy, ux) - z[0];
+        t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = fast_atan2(uy, ux) - z[0];
       }
     } else if constexpr (SOLVER == kSolverNewton) {
       st = 1;
@@ -270,7 +270,7 @@ struct BR {
           if (fmax(fabs(r[0]), fabs(r[1])) <= tol) { st = 0; break; }
           const double dx = t[0] - fx[0], dy = t[1] - fx[1];
           const double plx = P.c * dx + P.s * dy, ply = -P.s * dx + P.c * dy;
-          const double n = sqrt(plx * plx + ply * ply), phi = atan2(ply, plx);
+          const double n = fast_sqrt(plx * plx + ply * ply), phi = fast_atan2(ply, plx);
           const double nn = n + r[1];
           double sa, ca; fast_sincos(phi + r[0], &sa, &ca);
           const double qx = nn * ca, qy = nn * sa;
@@ -284,7 +284,7 @@ struct BR {
           const double dx = fx[0] - t[0], dy = fx[1] - t[1];
           const double n = fast_sqrt(dx * dx + dy * dy);
           const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
-          t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = atan2(uy, ux) - z[0];
+          t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = fast_atan2(uy, ux) - z[0];
         }
       }
     } else {
