@@ -142,7 +142,7 @@ class PipelinedSegmentSweep:
         b = self.k & 1
         w = self.works[b]
         if w is not None:
-            w.wait()
+            w.wait()   # stream-level join (the host runs several steps ahead of the GPU, so a host-side query cannot replace it)
         self.plans[b]()
         if self.collective:
             self.works[b] = self.dist.all_gather_into_tensor(self.recv[b].view(-1), self.send[b].view(-1), async_op=True)
