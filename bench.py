@@ -140,7 +140,9 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = float(ev[0].elapsed_time(ev[len(marks)])) / args.steps
+    # N>1: even and odd steps run on two side streams (PipelinedSegmentSweep), which events on the caller's stream do not
+    # bracket: the launch period is then this rank's wall-clock between the barriers
+    kern_ms = 1e3 * (t1 - t0) / args.steps if multi else float(ev[0].elapsed_time(ev[len(marks)])) / args.steps
 
     total_conv = n_conv_step * world * args.steps
     value = total_conv / elapsed
@@ -195,6 +197,20 @@ def main():
             torch.cuda.synchronize()
             modes[name] = tb["C"] * reps / (time.perf_counter() - a)
         out["gpu_convolutions_per_s_by_solver"] = modes
+        # context: independent sweeps issued alternately on two streams overlap one launch's tail with the next one's ramp
+        # (what the N>1 path does to hide the separator join; the headline keeps one launch at a time so that the launch
+        # period is the kernel duration rocprofv3 reports)
+        pl2 = [dg.plan_sweep_pose2pose2(opts, torch.empty_like(prop)) for _ in range(2)]
+        st2 = [torch.cuda.Stream(dev) for _ in range(2)]
+        for st in st2:
+            st.wait_stream(torch.cuda.current_stream(dev))
+        def two_streams(reps):
+            for r in range(reps):
+                with torch.cuda.stream(st2[r & 1]):
+                    pl2[r & 1]()
+        two_streams(10); torch.cuda.synchronize()
+        a = time.perf_counter(); two_streams(200); torch.cuda.synchronize()
+        out["gpu_convolutions_per_s_two_streams"] = tb["C"] * 200 / (time.perf_counter() - a)
         # the other half of the metric ("solveTree! wall-clock"): one iteration of the device-resident solve loop on the
         # same graph = all convolutions (one launch) + the proposal product of every variable (one launch); DESIGN.md §11
         o3 = R.make_opts(N=N, solver=R.SOLVER_NEWTON, seed=0x524F4D45)
