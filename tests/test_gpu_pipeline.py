@@ -1,0 +1,99 @@
+"""The weak-scaling sweep driver (rome_jl_amd.distributed.PipelinedSegmentSweep) on the GPU: kernel-side mirroring of the
+separator rows, ghost blocks in the tail of the belief store, double buffering, and the two-stream RCCL form (world = 1,
+collective forced) against the single-stream copy form and against a step-by-step emulation with plain sweeps."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _segment(R, N, P):
+    fg = R.synth_manhattan(P=P, loops=P // 3, N=N, seed=77)
+    cov = np.diag([1 / 44.6, 1 / 399.0, 1 / 9591.0])
+    fg.addVariable("ghost_prev", R.Pose2); fg.addVariable("ghost_next", R.Pose2)
+    fg.addFactor(["ghost_prev", "x0"], R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.0], cov)))
+    fg.addFactor(["x%d" % (P - 1), "ghost_next"], R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.0], cov)))
+    R.dead_reckon_init(fg, seed=5)
+    return fg
+
+
+def test_pipelined_segment_sweep_forms_agree():
+    import torch
+    import torch.distributed as dist
+    import rome_jl_amd as R
+    from rome_jl_amd.distributed import PipelinedSegmentSweep
+    N, P, S = 100, 400, 7
+    sep = [1, 2 * (P - 2)]     # rows: factor 0 dir 1 -> x0 ; factor P-2 dir 0 -> x_{P-1}
+    opts = R.make_opts(N=N, solver=1, seed=31)
+
+    def run(force_collective):
+        fg = _segment(R, N, P)
+        dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+        pk = dg.packed
+        pipe = PipelinedSegmentSweep(dg, opts, dist if force_collective else None, 1, 0, sep,
+                                     pk.index["ghost_prev"], pk.index["ghost_next"], always_collective=force_collective)
+        assert (pipe.streams is not None) == force_collective
+        outs = []
+        for _ in range(S):
+            pipe.step()
+            pipe.drain(); torch.cuda.synchronize()
+            outs.append(pipe.prop.cpu().numpy().copy())
+        return outs, dg, pk
+
+    plain, dg, pk = run(False)
+    # step-by-step emulation with plain sweeps: step k reads the separators published by step k-2 (initially the
+    # dead-reckoned ghosts); with one rank "previous" and "next" segment are this segment itself
+    fg = _segment(R, N, P)
+    dg2 = R.DeviceGraph(fg); dg2.upload_beliefs(fg)
+    gp, gn = pk.index["ghost_prev"], pk.index["ghost_next"]
+    hist = []
+    for k in range(S):
+        if k >= 2:
+            dg2.bel[R.Pose2][gp].copy_(torch.as_tensor(hist[k - 2][sep[1]]))   # previous segment's last pose
+            dg2.bel[R.Pose2][gn].copy_(torch.as_tensor(hist[k - 2][sep[0]]))   # next segment's first pose
+        out = dg2.sweep_pose2pose2(opts)
+        torch.cuda.synchronize()
+        hist.append(out.cpu().numpy().copy())
+    for k in range(S):
+        assert np.array_equal(plain[k], hist[k]), k
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        forced, _, _ = run(True)
+    finally:
+        dist.destroy_process_group()
+    for k in range(S):
+        assert np.array_equal(plain[k], forced[k]), k
+
+
+def test_pipelined_segment_sweep_overlapped_steps_equal_drained_steps():
+    """Steps issued back to back (sweeps of the two parities overlapping on their streams, collectives in flight) end in the
+    same two proposal tables as steps that are drained one by one."""
+    import torch
+    import torch.distributed as dist
+    import rome_jl_amd as R
+    from rome_jl_amd.distributed import PipelinedSegmentSweep
+    N, P, S = 100, 1200, 24
+    sep = [1, 2 * (P - 2)]
+    opts = R.make_opts(N=N, solver=1, seed=32)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29542")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        res = []
+        for drain_each in (True, False):
+            fg = _segment(R, N, P)
+            dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+            pk = dg.packed
+            pipe = PipelinedSegmentSweep(dg, opts, dist, 1, 0, sep, pk.index["ghost_prev"], pk.index["ghost_next"], always_collective=True)
+            for _ in range(S):
+                pipe.step()
+                if drain_each:
+                    pipe.drain(); torch.cuda.synchronize()
+            pipe.drain(); torch.cuda.synchronize()
+            res.append([p.cpu().numpy().copy() for p in pipe.props])
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
