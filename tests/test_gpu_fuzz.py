@@ -1,0 +1,73 @@
+"""Randomised option sweep: the HIP path against the oracle over random particle counts (every particles-per-lane
+instantiation), inflation-cycle counts, inflation factors, seeds / stream offsets, in-kernel vs pre-sampled noise, layouts
+and nullhypo fractions, for the three relative-factor kernels (closed form and Newton; Nelder-Mead is compared in
+test_gpu_parity.py at its own tolerance)."""
+import numpy as np
+import pytest
+
+import oracle as ro
+from test_gpu_parity import _p2_inputs, _p3_inputs, _br_inputs, wrapdiff
+
+pytestmark = pytest.mark.gpu
+R = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _pkg():
+    global R
+    import rome_jl_amd
+    R = rome_jl_amd
+    R.default_context()
+    yield
+
+
+def _opts(rng, N, solver):
+    kw = dict(N=N, solver=solver, inflate_cycles=int(rng.integers(0, 6)), inflation=float(rng.choice([0.0, 0.5, 5.0, 50.0])),
+              seed=int(rng.integers(1, 2 ** 62)), stream_offset=int(rng.integers(0, 2 ** 40)))
+    if rng.uniform() < 0.3:
+        kw["nullhypo"] = float(rng.uniform(0.05, 0.9))
+    return kw
+
+
+@pytest.mark.parametrize("trial", range(int(__import__("os").environ.get("ROME_FUZZ_TRIALS", "24"))))
+def test_random_configurations(trial):
+    rng = np.random.default_rng(9000 + trial)
+    N = int(rng.choice([1, 2, 3, 31, 64, 65, 100, 127, 128, 129, 200, 256, 257, 333, 512]))
+    C_ = int(rng.integers(1, 12))
+    solver = int(rng.integers(0, 2))
+    kind = ["p2p2", "br0", "br1", "p3p3"][trial % 4]
+    kw = _opts(rng, N, solver)
+    use_noise = rng.uniform() < 0.5
+    if kind == "p2p2":
+        mu, cov, fixed, target, dirs, noise = _p2_inputs(C_, N, 1 + trial)
+        nz = noise if use_noise else None
+        o = R.make_opts(**kw)
+        aos = rng.uniform() < 0.5
+        if aos:
+            o.layout = R.LAYOUT_AOS
+            tr = lambda a: None if a is None else np.ascontiguousarray(a.transpose(0, 2, 1))
+            out = R.conv_pose2pose2(o, mu, cov, tr(fixed), tr(target), dirs=dirs, noise=tr(nz)).transpose(0, 2, 1)
+        else:
+            out = R.conv_pose2pose2(o, mu, cov, fixed, target, dirs=dirs, noise=nz)
+        L = np.array([ro.cholesky_lower(c) for c in cov])
+        ref = ro.conv_pose2pose2(ro.make_opts(**kw), mu, L, np.concatenate([fixed, target], 0), np.arange(C_), C_ + np.arange(C_), dirs, noise=nz)
+        assert np.abs(wrapdiff(out, ref, [2])).max() < 1e-8, (kind, N, kw)
+    elif kind in ("br0", "br1"):
+        d = int(kind[-1])
+        mu, sigma, fixed, target, noise = _br_inputs(C_, N, d, 50 + trial)
+        nz = noise if use_noise else None
+        out = R.conv_pose2point2br(R.make_opts(**kw), d, mu, sigma, fixed, target, noise=nz)
+        ref = ro.conv_pose2point2br(ro.make_opts(**kw), d, mu, sigma, fixed, target, np.arange(C_), np.arange(C_), noise=nz)
+        assert np.abs(wrapdiff(out, ref, [2] if d == 1 else [])).max() < 1e-7, (kind, N, kw)
+    else:
+        from scipy.spatial.transform import Rotation as Rot
+        mu, cov, fixed, target, dirs, noise = _p3_inputs(C_, N, 300 + trial)
+        nz = noise if use_noise else None
+        out = R.conv_pose3pose3(R.make_opts(**kw), mu, cov, fixed, target, dirs=dirs, noise=nz)
+        L = np.array([ro.cholesky_lower(c) for c in cov])
+        ref = ro.conv_pose3pose3(ro.make_opts(**kw), mu, L, np.concatenate([fixed, target], 0), np.arange(C_), C_ + np.arange(C_), dirs, noise=nz)
+        assert np.abs(out[:, :3] - ref[:, :3]).max() < 1e-8, (kind, N, kw)
+        ang = (Rot.from_rotvec(out[:, 3:].transpose(0, 2, 1).reshape(-1, 3)).inv() *
+               Rot.from_rotvec(ref[:, 3:].transpose(0, 2, 1).reshape(-1, 3))).magnitude()
+        near = np.linalg.norm(ref[:, 3:], axis=1).reshape(-1) > np.pi - 1e-2
+        assert ang[~near].max(initial=0.0) < 1e-8 and ang[near].max(initial=0.0) < 2e-4, (kind, N, kw)
