@@ -9,6 +9,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _init_single_rank_rccl(dist, torch, port):
+    """world_size-1 RCCL process group over a local TCP store; an environment that cannot provide one (port taken, no
+    RCCL) skips the RCCL half of these tests instead of failing the suite -- the copy form is still checked."""
+    try:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    except Exception as e:   # noqa: BLE001
+        pytest.skip("cannot create a single-rank RCCL process group here: %r" % (e,))
+
+
 def _segment(R, N, P):
     fg = R.synth_manhattan(P=P, loops=P // 3, N=N, seed=77)
     cov = np.diag([1 / 44.6, 1 / 399.0, 1 / 9591.0])
@@ -59,8 +69,7 @@ def test_pipelined_segment_sweep_forms_agree():
     for k in range(S):
         assert np.array_equal(plain[k], hist[k]), k
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    _init_single_rank_rccl(dist, torch, 29541)
     try:
         forced, _, _ = run(True)
     finally:
@@ -79,8 +88,7 @@ def test_pipelined_segment_sweep_overlapped_steps_equal_drained_steps():
     N, P, S = 100, 1200, 24
     sep = [1, 2 * (P - 2)]
     opts = R.make_opts(N=N, solver=1, seed=32)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29542")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    _init_single_rank_rccl(dist, torch, 29542)
     try:
         res = []
         for drain_each in (True, False):
