@@ -226,9 +226,11 @@ __device__ __forceinline__ void rng_entropy_from_words(const EntropyWords& e, in
 // are then folded with row_bcast:15 / row_bcast:31 and read back from lane 63.  ~4x cheaper than ds_bpermute shuffles.
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
+  // full-wave permutations within rows: every lane receives a value, so the destination needs no prior contents
+  // (mov_dpp = update_dpp with an undefined `old`: saves the two zero-initialising v_mov + s_nop per 64-bit value and step)
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 template <int CTRL, int ROW_MASK>
