@@ -198,7 +198,7 @@ typedef struct rome_conv_dev {
   const double* hypo_w;
   /* optional: IIF `nullhypo=p` per row (addFactor!(fg, [:x3;:x1], odoc3, nullhypo=0.5), test/testPose3Pose3NH.jl:118):
    * with probability nullhypo[c] a particle is not constrained by the factor: it keeps its start value and gets
-   * spread_nh · mean-std entropy.  NULL -> 0 everywhere. */
+   * spread_nh · std entropy (std = root of the Fréchet variance of the target's start belief).  NULL -> 0 everywhere. */
   const double* nullhypo;
 } rome_conv_dev;
 

@@ -531,6 +531,15 @@ static void se2_add_entropy(double t[3], double spread, const double u[3]) {
 
 static inline int get_idx(const int32_t* a, int c) { return a ? a[c] : c; }
 
+/* The scalar spread IIF scales by `inflation` / `spreadNH` (⚠IIF calcStdBasicSpread = Manifolds.std(M, pts)): the square root
+ * of the corrected Fréchet variance Σ_i d(mean, x_i)² / (n-1).  On these product manifolds d² is the sum of the squared
+ * tangent-coordinate differences, so it is the root of the summed per-coordinate variances returned by ro_belief_spread_*. */
+static double frechet_std(const double* sd, int d) {
+  double v = 0.0;
+  for (int k = 0; k < d; ++k) v += sd[k] * sd[k];
+  return sqrt(v);
+}
+
 /* nullhypo draw for particle i of stream st: -> 1 if the factor does NOT apply; u[0..d-1] entropy uniforms
  * (Philox domain 5; block 0: word0 = selector, words 1-3 = u0..u2; block 1: words 0-2 = u3..u5) */
 static int nullhypo_draw(const ro_opts* o, uint64_t st, uint32_t i, int d, double* u) {
@@ -578,7 +587,7 @@ int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int
     if (o->nullhypo > 0.0) {
       double m3[3], s3[3];
       ro_belief_spread_se2(N, ob, ob + N, ob + 2 * N, m3, s3);
-      nh_spread = N > 1 ? o->spread_nh * (s3[0] + s3[1] + s3[2]) / 3.0 : 0.0;
+      nh_spread = N > 1 ? o->spread_nh * frechet_std(s3, 3) : 0.0;
       for (int i = 0; i < N; ++i) nullh[i] = (unsigned char)nullhypo_draw(o, o->stream_offset + (uint64_t)c, (uint32_t)i, 3, nhu + 3 * i);
     }
     if (o->solver == RO_SOLVER_CLOSED_FORM) {
@@ -594,7 +603,7 @@ int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int
         if (o->inflation > 0.0 && N > 1) {
           double mean3[3], std3[3];
           ro_belief_spread_se2(N, ob, ob + N, ob + 2 * N, mean3, std3);
-          spread = o->inflation * (std3[0] + std3[1] + std3[2]) / 3.0;
+          spread = o->inflation * frechet_std(std3, 3);
         }
         for (int i = 0; i < N; ++i) {
           if (nullh[i]) continue;
@@ -768,21 +777,21 @@ int ro_conv_pose2point2br_mh(const ro_opts* o, int C, const int32_t* factor, int
       if (status) status[(size_t)c * N + i] = 0;
     }
     /* nullhypo (same rule as the Pose2Pose2 convolution): such particles skip the solve and receive
-     * spread_nh · mean-std(start belief) entropy afterwards */
+     * spread_nh · std(start belief) entropy afterwards (frechet_std) */
     unsigned char* nullh = (unsigned char*)calloc(N, 1);
     double* nhu0 = (double*)malloc(sizeof(double) * 3 * N);
     double nh0_spread = 0.0;
     if (o->nullhypo > 0.0) {
-      if (dt == 3) { double m3[3], s3[3]; ro_belief_spread_se2(N, ob, ob + N, ob + 2 * N, m3, s3); nh0_spread = N > 1 ? o->spread_nh * (s3[0] + s3[1] + s3[2]) / 3.0 : 0.0; }
-      else         { double m2[2], s2[2]; ro_belief_spread_r2(N, ob, ob + N, m2, s2); nh0_spread = N > 1 ? o->spread_nh * (s2[0] + s2[1]) / 2.0 : 0.0; }
+      if (dt == 3) { double m3[3], s3[3]; ro_belief_spread_se2(N, ob, ob + N, ob + 2 * N, m3, s3); nh0_spread = N > 1 ? o->spread_nh * frechet_std(s3, 3) : 0.0; }
+      else         { double m2[2], s2[2]; ro_belief_spread_r2(N, ob, ob + N, m2, s2); nh0_spread = N > 1 ? o->spread_nh * frechet_std(s2, 2) : 0.0; }
       for (int i = 0; i < N; ++i) nullh[i] = (unsigned char)nullhypo_draw(o, o->stream_offset + (uint64_t)c, (uint32_t)i, dt, nhu0 + 3 * i);
     }
     int ncyc = (o->solver == RO_SOLVER_CLOSED_FORM && dir == 0) ? 1 : cycles;
     for (int cyc = 0; cyc < ncyc; ++cyc) {
       double spread = 0.0;
       if (o->inflation > 0.0 && N > 1 && !(o->solver == RO_SOLVER_CLOSED_FORM && dir == 0)) {
-        if (dt == 3) { double m3[3], s3[3]; ro_belief_spread_se2(N, ob, ob + N, ob + 2 * N, m3, s3); spread = o->inflation * (s3[0] + s3[1] + s3[2]) / 3.0; }
-        else         { double m2[2], s2[2]; ro_belief_spread_r2(N, ob, ob + N, m2, s2); spread = o->inflation * (s2[0] + s2[1]) / 2.0; }
+        if (dt == 3) { double m3[3], s3[3]; ro_belief_spread_se2(N, ob, ob + N, ob + 2 * N, m3, s3); spread = o->inflation * frechet_std(s3, 3); }
+        else         { double m2[2], s2[2]; ro_belief_spread_r2(N, ob, ob + N, m2, s2); spread = o->inflation * frechet_std(s2, 2); }
       }
       for (int i = 0; i < N; ++i) {
         double fx[3] = {0, 0, 0}, t[3] = {0, 0, 0};
@@ -919,7 +928,7 @@ int ro_conv_pose3pose3(const ro_opts* o, int C, const int32_t* factor, const int
     double nh_spread = 0.0;
     if (o->nullhypo > 0.0) {
       double m6[6], s6[6]; ro_belief_spread_se3(N, ob, m6, s6);
-      nh_spread = N > 1 ? o->spread_nh * (s6[0] + s6[1] + s6[2] + s6[3] + s6[4] + s6[5]) / 6.0 : 0.0;
+      nh_spread = N > 1 ? o->spread_nh * frechet_std(s6, 6) : 0.0;
       for (int i = 0; i < N; ++i) nullh[i] = (unsigned char)nullhypo_draw(o, o->stream_offset + (uint64_t)c, (uint32_t)i, 6, nhu + 6 * i);
     }
     int ncyc = o->solver == RO_SOLVER_CLOSED_FORM ? 1 : cycles;
@@ -927,7 +936,7 @@ int ro_conv_pose3pose3(const ro_opts* o, int C, const int32_t* factor, const int
       double spread = 0.0;
       if (o->inflation > 0.0 && N > 1 && o->solver != RO_SOLVER_CLOSED_FORM) {
         double m6[6], s6[6]; ro_belief_spread_se3(N, ob, m6, s6);
-        spread = o->inflation * (s6[0] + s6[1] + s6[2] + s6[3] + s6[4] + s6[5]) / 6.0;
+        spread = o->inflation * frechet_std(s6, 6);
       }
       for (int i = 0; i < N; ++i) {
         double fx[6], t[6], F[12], T[12];

@@ -60,7 +60,7 @@ __device__ __forceinline__ double spread_se2(const double (&t)[PPL][3], const bo
   const double vx = fmax(0.0, (s[1] - s[0] * s[0] * inv) * den);
   const double vy = fmax(0.0, (s[3] - s[2] * s[2] * inv) * den);
   const double vt = fmax(0.0, (s[5] - s[4] * s[4] * inv) * den);
-  return (fast_sqrt(vx) + fast_sqrt(vy) + fast_sqrt(vt)) * (1.0 / 3.0);
+  return fast_sqrt(vx + vy + vt);   // Manifolds.std: root of the corrected Fréchet variance (sum of the coordinate variances)
 }
 template <int PPL>
 __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const bool (&act)[PPL], double inv, double den) {
@@ -74,7 +74,7 @@ __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const boo
   wave_sum_n<4>(s);
   const double vx = fmax(0.0, (s[1] - s[0] * s[0] * inv) * den);
   const double vy = fmax(0.0, (s[3] - s[2] * s[2] * inv) * den);
-  return (fast_sqrt(vx) + fast_sqrt(vy)) * 0.5;
+  return fast_sqrt(vx + vy);
 }
 
 struct P2P2 {
@@ -373,8 +373,8 @@ struct P3P3 {
     wave_sum_n<12>(s);
     double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) acc += fast_sqrt(fmax(0.0, (s[2 * j + 1] - s[2 * j] * s[2 * j] * inv) * den));
-    return acc * (1.0 / 6.0);
+    for (int j = 0; j < 6; ++j) acc += fmax(0.0, (s[2 * j + 1] - s[2 * j] * s[2 * j] * inv) * den);
+    return fast_sqrt(acc);
   }
   struct Prep { double a[3], qa[4]; };
   __device__ static __forceinline__ Prep prepare(const Consts& K, const double (&z)[6], const double (&fxc)[6]) {
@@ -581,7 +581,7 @@ k_conv(const ConvArgs a) {
   }
 
   // ---- nullhypo (IIF addFactor!(…, nullhypo=p), test/testPose3Pose3NH.jl:118): with probability p the factor does
-  //      not apply to a particle; such particles keep their value and receive spreadNH · mean-std entropy instead
+  //      not apply to a particle; such particles keep their value and receive spreadNH · std entropy instead
   bool nullh[PPL];
 #pragma unroll
   for (int k = 0; k < PPL; ++k) nullh[k] = false;

@@ -165,3 +165,42 @@ def test_nullhypo_bearingrange_vs_oracle(direction, solver):
         follows = np.abs(np.hypot(out[:, 0] - 40.0, out[:, 1] + 25.0) - 12.0) < 2.5   # poses on the 12 m ring about the landmark
     frac = follows.mean(axis=1)
     assert (frac > 0.4).all() and (frac < 0.8).all(), frac
+
+
+def test_pose3pose3_nullhypo_against_reference_validation_samples():
+    """test/testPose3Pose3NH.jl:20-145 with the reference's own validation samples (its data files test/X1ptst.csv, X2ptst.csv,
+    copied to tests/golden/): x1 -25-> x2 -25-> x3 chain, then Pose3Pose3([-35,0,...]) over [x3, x1] with nullhypo=0.5.  The
+    proposals on x1 are a mixture of the factor's solution (x ≈ 15) and of x1's own belief plus spreadNH entropy (x ≈ 0);
+    on x3: x ≈ 35 and x ≈ 50.  Mixture fractions, mode locations and the order of magnitude of the null share's
+    translation spread must match the reference samples (their rotation spread predates the scalar-spread entropy of current
+    IncrementalInference and is not compared)."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    X1ref = np.loadtxt(os.path.join(gold, "pose3pose3nh_X1ptst.csv"), delimiter=",")
+    X2ref = np.loadtxt(os.path.join(gold, "pose3pose3nh_X2ptst.csv"), delimiter=",")
+    N = 100
+    cov = np.diag(np.square([1, 1, 1, 0.01, 0.01, 0.01]))
+    fg = R.initfg(N)
+    fg.addVariable("x1", R.Pose3)
+    f1 = fg.addFactor(["x1"], R.PriorPose3(R.MvNormal(np.zeros(6), cov)))
+    fg.initVariable("x1", R.approxConv(fg, f1, "x1", seed=1))
+    fg.addVariable("x2", R.Pose3); f12 = fg.addFactor(["x1", "x2"], R.Pose3Pose3(R.MvNormal([25.0, 0, 0, 0, 0, 0], cov)))
+    fg.initVariable("x2", R.approxConv(fg, f12, "x2", seed=2))
+    fg.addVariable("x3", R.Pose3); f23 = fg.addFactor(["x2", "x3"], R.Pose3Pose3(R.MvNormal([25.0, 0, 0, 0, 0, 0], cov)))
+    fg.initVariable("x3", R.approxConv(fg, f23, "x3", seed=3))
+    m, _ = R.belief_stats(np.stack([fg.getVal("x2"), fg.getVal("x3")]))
+    assert np.allclose(m[0, :3], [25, 0, 0], atol=5.0) and np.allclose(m[1, :3], [50, 0, 0], atol=5.0)      # :101-105
+    f31 = fg.addFactor(["x3", "x1"], R.Pose3Pose3(R.MvNormal([-35.0, 0, 0, 0, 0, 0], cov)))
+    X1 = R.approxConv(fg, f31, "x1", seed=4, nullhypo=0.5)
+    X3 = R.approxConv(fg, f31, "x3", seed=5, nullhypo=0.5)
+    for got, ref, active_x, null_x in ((X1, X1ref, 15.0, 0.0), (X3, X2ref, 35.0, 50.0)):
+        ga, ra = np.abs(got[0] - active_x) < 7, np.abs(ref[0] - active_x) < 7
+        assert abs(ga.mean() - 0.5) < 0.2 and abs(ra.mean() - 0.5) < 0.2
+        assert np.abs(got[:3, ga].mean(axis=1) - ref[:3, ra].mean(axis=1)).max() < 2.5
+        assert np.abs(got[:3, ~ga].mean(axis=1) - ref[:3, ~ra].mean(axis=1)).max() < 2.5
+        assert abs(got[0, ~ga].mean() - null_x) < 2.5
+        ratio = got[:3, ~ga].std(axis=1) / ref[:3, ~ra].std(axis=1)
+        assert (ratio > 1 / 3.0).all() and (ratio < 3.0).all(), ratio
+        # the factor-following share is as tight as the reference's in translation
+        ratio_a = got[:3, ga].std(axis=1) / ref[:3, ra].std(axis=1)
+        assert (ratio_a > 1 / 3.0).all() and (ratio_a < 3.0).all(), ratio_a
