@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--poses", type=int, default=3500)
     ap.add_argument("--loops", type=int, default=1954)
     ap.add_argument("--particles", type=int, default=100)
-    ap.add_argument("--g2o", default=None, help="optional g2o file instead of the synthetic generator")
+    ap.add_argument("--g2o", default=None, help="g2o file (default: tests/golden/manhattan.g2o, the M3500 dataset the reference "
+                                                 "ships as examples/manhattan.g2o; 'synthetic' forces the generator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra per-solver throughput runs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -75,13 +76,19 @@ def main():
     solver = {"closed_form": R.SOLVER_CLOSED_FORM, "newton": R.SOLVER_NEWTON, "nelder_mead": R.SOLVER_NELDER_MEAD}[args.solver]
 
     # ---- workload: this rank's Manhattan-shaped segment (+ ghost separators of the neighbours) ----
-    if args.g2o:
+    default_g2o = os.path.join(ROOT, "tests", "golden", "manhattan.g2o")
+    if args.g2o is None and os.path.exists(default_g2o) and (args.poses, args.loops) == (3500, 1954):
+        args.g2o = default_g2o
+    if args.g2o and args.g2o != "synthetic":
         fg = R.loadG2o(args.g2o, N=N)
-        workload = "g2o:%s" % os.path.basename(args.g2o)
+        workload = "Manhattan-3500 (M3500 pose graph, %s: the data file the reference ships as examples/manhattan.g2o; prior on x0 as " \
+                   "examples/ManhattanDatasetBatch.jl:31)" % os.path.relpath(args.g2o, ROOT) if os.path.abspath(args.g2o) == default_g2o \
+            else "g2o:%s" % os.path.basename(args.g2o)
+        args.poses = sum(1 for t in fg.variables.values() if t is R.Pose2)
     else:
         fg = R.synth_manhattan(P=args.poses, loops=args.loops, seed=0x524F4D45 + rank, N=N)
         workload = "synth_manhattan(P=%d, loops=%d) [g2o-shaped stand-in for examples/manhattan.g2o]" % (args.poses, args.loops)
-    last = "x%d" % (len(fg.variables) - 1)
+    last = "x%d" % (sum(1 for t in fg.variables.values() if t is R.Pose2) - 1)
     if multi:
         # cut edges to the neighbouring segments: ghost variables hold the neighbours' separator beliefs
         cov = np.diag([1 / 44.6, 1 / 399.0, 1 / 9591.0])
@@ -102,8 +109,11 @@ def main():
     if multi:
         from rome_jl_amd.distributed import PipelinedSegmentSweep
         # proposal rows that carry the updated separator estimates (odometry convolutions targeting them)
-        conv_first = 2 * 0 + 1                                   # factor 0 (x0->x1), dir 1 -> target x0
-        conv_last = 2 * (args.poses - 2) + 0 if not args.g2o else 0  # factor P-2 (x_{P-2}->x_{P-1}), dir 0
+        vf, vt = pk.p2p2["var_from"], pk.p2p2["var_to"]
+        f_first = int(np.nonzero((vf == pk.index["x0"]) & (vt == pk.index["x1"]))[0][0])
+        f_last = int(np.nonzero((vf == pk.index["x%d" % (args.poses - 2)]) & (vt == pk.index[last]))[0][0])
+        conv_first = 2 * f_first + 1                             # odometry x0->x1, dir 1 -> target x0
+        conv_last = 2 * f_last + 0                               # odometry x_{P-2}->x_{P-1}, dir 0 -> target x_{P-1}
         pipe = PipelinedSegmentSweep(dg, opts, dist, world, rank, [conv_first, conv_last],
                                      pk.index["ghost_prev"], pk.index["ghost_next"], always_collective=(world == 1))
         sweep = pipe.step
@@ -144,6 +154,8 @@ def main():
     # bracket: the launch period is then this rank's wall-clock between the barriers
     kern_ms = 1e3 * (t1 - t0) / args.steps if multi else float(ev[0].elapsed_time(ev[len(marks)])) / args.steps
 
+    data_kind = "synthetic" if (not args.g2o or args.g2o == "synthetic") else \
+        "Manhattan M3500 dataset (measurements); beliefs synthetic: dead-reckoned means + N(0, sigma) particles"
     total_conv = n_conv_step * world * args.steps
     value = total_conv / elapsed
     alg_bytes = tb["C_rel"] * N * BYTES_PER_PARTICLE_P2P2 + tb["P"] * N * 24
@@ -153,7 +165,7 @@ def main():
         "metric": "factor convolutions/sec (N=100) on Manhattan-3500; solveTree! wall-clock",
         "value": value, "unit": "convolutions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64", "data": data_kind,
         "config": {"workload": workload, "poses_per_gpu": len(pk.labels[R.Pose2]), "pose2pose2_factors_per_gpu": tb["F"],
                    "convolutions_per_step_per_gpu": n_conv_step, "particles": N, "solver": args.solver,
                    "inflate_cycles": int(opts.inflate_cycles), "inflation": float(opts.inflation), "noise": "in-kernel philox",

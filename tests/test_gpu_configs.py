@@ -95,3 +95,39 @@ def test_helix3d_pose3pose3_sweep_vs_oracle_and_roundtrip():
     for v in (0, 17, 4242, P - 1):
         m, s = ro.belief_spread(bel[v])
         assert np.abs(mean[v].cpu().numpy() - m).max() < 1e-9 and np.abs(sd[v].cpu().numpy() - s).max() < 1e-9
+
+
+def test_manhattan_m3500_dataset_parametric_solve_and_sweep():
+    """BASELINE configs[1] on the real data (tests/golden/manhattan.g2o = the reference's examples/manhattan.g2o): the parametric
+    solve converges from dead reckoning to the well-known compact M3500 map, and a non-parametric sweep over all 10 906
+    (factor, direction) convolutions + the prior runs clean around it."""
+    import os
+    import torch
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fg = R.loadG2o(os.path.join(gold, "manhattan.g2o"))
+    R.dead_reckon_init(fg, seed=1)
+    xp = R.solveGraphParametric(fg)
+    X = np.array([xp["x%d" % k] for k in range(3500)])
+    assert np.abs(X[:, :2]).max() < 70.0                      # the optimised M3500 map spans about [-50, 25] x [-60, 15] m
+    # whitened residuals of the solution: chi2 per scalar residual well below 1 (3.6e3 over 16 359 residuals measured; the
+    # reference's residual takes the translation difference in the WORLD frame, SURVEY A.2, so this is not g2o's 146)
+    e = np.array([[int(l[0][1:]), int(l[1][1:])] for _, l, f in fg.factors if isinstance(f, R.Pose2Pose2)])
+    mu = np.array([f.Z.mu for _, _, f in fg.factors if isinstance(f, R.Pose2Pose2)])
+    Wi = np.array([np.linalg.inv(f.Z.cov) for _, _, f in fg.factors if isinstance(f, R.Pose2Pose2)])
+    p, q = X[e[:, 0]], X[e[:, 1]]
+    c, s = np.cos(p[:, 2]), np.sin(p[:, 2])
+    r = np.stack([p[:, 0] + c * mu[:, 0] - s * mu[:, 1] - q[:, 0], p[:, 1] + s * mu[:, 0] + c * mu[:, 1] - q[:, 1],
+                  np.arctan2(np.sin(p[:, 2] + mu[:, 2] - q[:, 2]), np.cos(p[:, 2] + mu[:, 2] - q[:, 2]))], 1)
+    chi2 = np.einsum("fi,fij,fj->", r, Wi, r)
+    assert chi2 < 0.4 * 3 * len(e), chi2
+    dg = R.DeviceGraph(fg); dg.init_from_means(xp)
+    tb = dg.tab["p2p2"]
+    status = torch.zeros((tb["C"], 100), dtype=torch.int32, device="cuda")
+    out = dg.sweep_pose2pose2(R.make_opts(N=100, solver=1, seed=3500), status=status)
+    torch.cuda.synchronize()
+    assert tb["C"] == 10907 and int(status.sum()) == 0 and bool(torch.isfinite(out).all())
+    # every proposal sits at its target's parametric estimate within the factor + belief noise
+    m, sd = R.belief_stats(out.cpu().numpy()[:2000])
+    tgt = X[tb["target"].cpu().numpy()[:2000]]
+    d = m - tgt; d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    assert np.percentile(np.hypot(d[:, 0], d[:, 1]), 99) < 1.0 and np.percentile(np.abs(d[:, 2]), 99) < 0.3

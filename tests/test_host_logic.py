@@ -206,3 +206,24 @@ def test_entropy_rng_definition():
     assert np.allclose(u6 * (1 << 21) - 0.5, np.round(u6 * (1 << 21) - 0.5))
     allu = np.array([ro.rng_entropy(1, 0, i, c, 3) for i in range(400) for c in range(6)])
     assert abs(allu.mean() - 0.5) < 0.02 and abs(allu.std() - 12 ** -0.5) < 0.02
+
+
+def test_real_datasets_load():
+    """The pose-graph datasets the reference ships as examples/manhattan.g2o (M3500) and examples/MIT.g2o, kept as data
+    fixtures under tests/golden/: counts and the record semantics of src/services/g2oParser.jl:98-121."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fg = R.loadG2o(os.path.join(gold, "manhattan.g2o"))
+    assert sum(1 for t in fg.variables.values() if t is R.Pose2) == 3500
+    p2 = [(l, f) for _, l, f in fg.factors if isinstance(f, R.Pose2Pose2)]
+    assert len(p2) == 5453 and sum(1 for _, _, f in fg.factors if isinstance(f, R.PriorPose2)) == 1
+    l, f = p2[0]
+    assert l == ["x0", "x1"] and np.allclose(f.Z.mu, [1.030390, 0.011350, -0.012958])
+    info = np.array([[44.635358, -7.962220, 0.0], [-7.962220, 376.516380, 0.0], [0.0, 0.0, 9745.791650]])
+    assert np.allclose(np.linalg.inv(f.Z.cov), info, rtol=1e-9)
+    assert sum(1 for l, _ in p2 if int(l[1][1:]) - int(l[0][1:]) != 1) == 5453 - 3499
+    pk = R.PackedGraph(fg)
+    assert pk.p2p2["F"] == 5453 and len(pk.labels[R.Pose2]) == 3500
+    mit = R.loadG2o(os.path.join(gold, "MIT.g2o"))
+    assert sum(1 for t in mit.variables.values() if t is R.Pose2) == 808
+    assert sum(1 for _, _, f in mit.factors if isinstance(f, R.Pose2Pose2)) == 827
