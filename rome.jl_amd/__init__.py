@@ -16,7 +16,7 @@ from .api import (linearize, belief_stats, points_to_coords, coords_to_points, c
                   residual_pose3pose3, residual_pose3pose3_pt, residual_priorpose3,
                   conv_pose2pose2, conv_pose2point2br, conv_pose3pose3, sample_priorpose2, sample_priorpose3)
 from .graph import (FactorGraph, initfg, importG2o, parseG2oInstruction, loadG2o, synth_manhattan,
-                    synth_manhattan_edges, synth_pose2_tables, synth_helix3d, synth_mit_br, dead_reckon_init_pose3, generateGraph_Circle, generateGraph_Hexagonal,
+                    synth_manhattan_edges, synth_pose2_tables, synth_helix3d, synth_mit_br, add_synthetic_landmarks, dead_reckon_init_pose3, generateGraph_Circle, generateGraph_Hexagonal,
                     PackedGraph, dead_reckon_init)
 from .canonical import (generateGraph_ZeroPose, buildGraphChain, generateGraph_TwoPoseOdo, calcHelix_T, generateGraph_Helix2D,
                         generateGraph_Helix2DSlew, generateGraph_Helix2DSpiral, generateGraph_Boxes2D, generateGraph_Beehive,

@@ -301,6 +301,34 @@ def synth_helix3d(P=10000, N=100, seed=0x524F4D45, radius=10.0, per_turn=20, pit
     return fg
 
 
+def add_synthetic_landmarks(fg, poses, n_landmarks, rng, sigma_b=0.03, sigma_r=0.5, min_range=3.0):
+    """Point2 landmarks l0.. scattered around the given pose estimates (label -> (x, y, θ)), each sighted by the 2-4 nearest
+    poses at least `min_range` away with Pose2Point2BearingRange(Normal(b, σ_b), Normal(ρ, σ_ρ)) (σ as in
+    src/canonical/GenerateHoneycomb.jl:69; sightings ≥ 6 σ_ρ away so that a sampled range stays positive).
+    Used to put landmarks on pose-only datasets such as the reference's examples/MIT.g2o (BASELINE configs[2]).
+    -> {landmark label: true position}"""
+    if isinstance(rng, (int, np.integer)):
+        rng = np.random.default_rng(int(rng))
+    labels = [l for l in poses if l in fg.variables and fg.variables[l] is Pose2]
+    gt = np.array([poses[l] for l in labels], dtype=float)
+    P = len(labels)
+    lm = gt[rng.choice(P, n_landmarks, replace=False), :2] + rng.uniform(-8, 8, (n_landmarks, 2))
+    truth = {}
+    for j in range(n_landmarks):
+        d = np.hypot(gt[:, 0] - lm[j, 0], gt[:, 1] - lm[j, 1])
+        d[d < min_range] = np.inf
+        near = np.argsort(d)[:rng.integers(2, 5)]
+        fg.addVariable("l%d" % j, Point2)
+        truth["l%d" % j] = lm[j]
+        for k in sorted(near):
+            dx, dy = lm[j] - gt[k, :2]
+            b = np.arctan2(dy, dx) - gt[k, 2] + sigma_b * rng.standard_normal()
+            r = np.hypot(dx, dy) + sigma_r * rng.standard_normal()
+            fg.addFactor([labels[k], "l%d" % j],
+                         Pose2Point2BearingRange(Normal(np.arctan2(np.sin(b), np.cos(b)), sigma_b), Normal(max(r, 0.1), sigma_r)))
+    return truth
+
+
 def synth_mit_br(P=808, n_landmarks=120, N=100, seed=0x524F4D45, step=2.0):
     """BASELINE.json configs[2] stand-in (the shipped MIT.g2o has no landmarks): a P-pose planar
     random walk (steps ≈ 2 m, MIT.g2o odometry statistics σ ≈ (0.75, 0.61, 0.053) scaled down 5x so the walk
@@ -322,19 +350,8 @@ def synth_mit_br(P=808, n_landmarks=120, N=100, seed=0x524F4D45, step=2.0):
     for k in range(1, P):
         fg.addVariable("x%d" % k, Pose2)
         fg.addFactor(["x%d" % (k - 1), "x%d" % k], Pose2Pose2(MvNormal(se2_between(gt[k - 1], gt[k]) + Lc @ rng.standard_normal(3), cov)))
-    lm = gt[rng.choice(P, n_landmarks, replace=False), :2] + rng.uniform(-8, 8, (n_landmarks, 2))
     truth = {"x%d" % k: gt[k] for k in range(P)}
-    for j in range(n_landmarks):
-        d = np.hypot(gt[:, 0] - lm[j, 0], gt[:, 1] - lm[j, 1])
-        d[d < 3.0] = np.inf                      # keep sightings ≥ 6 σ_ρ away: a sampled range must stay positive
-        near = np.argsort(d)[:rng.integers(2, 5)]
-        fg.addVariable("l%d" % j, Point2)
-        truth["l%d" % j] = lm[j]
-        for k in sorted(near):
-            dx, dy = lm[j] - gt[k, :2]
-            b = np.arctan2(dy, dx) - gt[k, 2] + 0.03 * rng.standard_normal()
-            r = np.hypot(dx, dy) + 0.5 * rng.standard_normal()
-            fg.addFactor(["x%d" % k, "l%d" % j], Pose2Point2BearingRange(Normal(np.arctan2(np.sin(b), np.cos(b)), 0.03), Normal(max(r, 0.1), 0.5)))
+    truth.update(add_synthetic_landmarks(fg, truth, n_landmarks, rng))
     fg.ground_truth = truth
     return fg
 

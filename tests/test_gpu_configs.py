@@ -131,3 +131,36 @@ def test_manhattan_m3500_dataset_parametric_solve_and_sweep():
     tgt = X[tb["target"].cpu().numpy()[:2000]]
     d = m - tgt; d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
     assert np.percentile(np.hypot(d[:, 0], d[:, 1]), 99) < 1.0 and np.percentile(np.abs(d[:, 2]), 99) < 0.3
+
+
+def test_mit_dataset_with_landmarks_sweeps_and_solve():
+    """BASELINE configs[2] on the real pose graph (tests/golden/MIT.g2o = the reference's examples/MIT.g2o, 808 poses / 827
+    EDGE_SE2, no landmarks in the file): landmarks are synthesised around the parametric solution and sighted with
+    Pose2Point2BearingRange; both bearing-range directions run over the graph and a few solve iterations keep the landmarks
+    at their true places."""
+    import os
+    import torch
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    N = 100
+    fg = R.loadG2o(os.path.join(gold, "MIT.g2o"), N=N)
+    R.dead_reckon_init(fg, seed=2)
+    xp = R.solveGraphParametric(fg)
+    truth = R.add_synthetic_landmarks(fg, xp, 150, 808)
+    R.dead_reckon_init(fg, seed=2)
+    dg = R.DeviceGraph(fg)
+    dg.upload_beliefs(fg)
+    dg.init_from_means({**xp, **truth})
+    pk = dg.packed
+    assert pk.p2p2["F"] == 827 and len(pk.labels[R.Pose2]) == 808 and len(pk.labels[R.Point2]) == 150 and pk.br["F"] >= 300
+    o = R.make_opts(N=N, solver=1, seed=808)
+    st1 = torch.zeros((pk.br["F"], N), dtype=torch.int32, device="cuda")
+    p1 = dg.sweep_bearingrange(o, 1, status=st1); p0 = dg.sweep_bearingrange(o, 0)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(p1).all()) and bool(torch.isfinite(p0).all()) and float((st1 != 0).float().mean()) < 0.01
+    dg.solve(o, n_sweeps=6)
+    ml, _ = dg.belief_stats(R.Point2)
+    err = np.hypot(*(ml.cpu().numpy() - np.array([truth[l] for l in pk.labels[R.Point2]])).T)
+    assert np.median(err) < 1.0 and np.percentile(err, 95) < 4.0, (np.median(err), np.percentile(err, 95))
+    m2, _ = dg.belief_stats(R.Pose2)
+    X = np.array([xp[l] for l in pk.labels[R.Pose2]])
+    assert np.median(np.hypot(*(m2.cpu().numpy()[:, :2] - X[:, :2]).T)) < 1.0
