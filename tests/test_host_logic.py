@@ -227,3 +227,18 @@ def test_real_datasets_load():
     mit = R.loadG2o(os.path.join(gold, "MIT.g2o"))
     assert sum(1 for t in mit.variables.values() if t is R.Pose2) == 808
     assert sum(1 for _, _, f in mit.factors if isinstance(f, R.Pose2Pose2)) == 827
+
+
+def test_g2o_parser_covariances_match_the_reference_serialisation():
+    """The reference's solved-graph artefact (tests/golden/manhattan500_reference_solve.npz) stores, for 500 Manhattan edges, the
+    MvNormal(μ, Σ) its own parser built from the g2o records (Σ = inv(Λ), src/services/g2oParser.jl:98-121): parsing the same
+    records of the dataset with this package must give the same μ and Σ."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    d = np.load(os.path.join(gold, "manhattan500_reference_solve.npz"))
+    fg = R.loadG2o(os.path.join(gold, "manhattan.g2o"))
+    mine = {(int(l[0][1:]), int(l[1][1:])): f for _, l, f in fg.factors if isinstance(f, R.Pose2Pose2)}
+    for (i, j), mu, cov in zip(d["edges"], d["mu"], d["cov"]):
+        f = mine[(int(i), int(j))]
+        assert np.array_equal(f.Z.mu, mu)
+        assert np.allclose(f.Z.cov, cov, rtol=1e-10, atol=1e-16)
