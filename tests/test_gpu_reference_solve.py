@@ -112,3 +112,18 @@ def test_parametric_solution_explains_the_factors_better_than_the_reference_poin
     dxy = X[:, :2] - d["ppe"][:, 0, :2]
     assert np.sqrt((dxy ** 2).sum(1).mean()) < 3.0
     assert np.abs(wrap(X[:, 2] - d["ppe"][:, 0, 2])).max() < 0.4
+
+
+def test_belief_means_equal_reference_ppe_means():
+    """`rome_belief_stats` on the reference's stored particles against the reference's stored point estimates (`ppe.mean`): x and y to
+    the float32 rounding of the fixture; heading wherever the belief does not straddle ±π (the stored estimate is the
+    arithmetic mean of the wrapped angle coordinates there, the kernel's is the mean on the circle)."""
+    d, ref, _ = _graph()
+    mean, sd = R.belief_stats(ref)
+    ppe_mean = d["ppe"][:, 2]
+    assert np.abs(mean[:, :2] - ppe_mean[:, :2]).max() < 2e-6
+    tight = np.ptp(ref[:, 2, :], axis=1) < 3.0     # heading samples that do not wrap around ±π
+    assert tight.sum() > 300
+    assert np.abs(wrap(mean[tight, 2] - ppe_mean[tight, 2])).max() < 2e-6
+    # "suggested" = (mean x, mean y, max-density heading): translation part again the mean
+    assert np.abs(mean[:, :2] - d["ppe"][:, 0, :2]).max() < 2e-6
