@@ -56,14 +56,32 @@ def test_random_configurations(trial):
         d = int(kind[-1])
         mu, sigma, fixed, target, noise = _br_inputs(C_, N, d, 50 + trial)
         nz = noise if use_noise else None
-        out = R.conv_pose2point2br(R.make_opts(**kw), d, mu, sigma, fixed, target, noise=nz)
+        o = R.make_opts(**kw)
+        if rng.uniform() < 0.5:      # AoS blocks [C][N][dim]
+            o.layout = R.LAYOUT_AOS
+            tr = lambda a: None if a is None else np.ascontiguousarray(a.transpose(0, 2, 1))
+            out = R.conv_pose2point2br(o, d, mu, sigma, tr(fixed), tr(target), noise=tr(nz)).transpose(0, 2, 1)
+        else:
+            out = R.conv_pose2point2br(o, d, mu, sigma, fixed, target, noise=nz)
         ref = ro.conv_pose2point2br(ro.make_opts(**kw), d, mu, sigma, fixed, target, np.arange(C_), np.arange(C_), noise=nz)
         assert np.abs(wrapdiff(out, ref, [2] if d == 1 else [])).max() < 1e-7, (kind, N, kw)
     else:
         from scipy.spatial.transform import Rotation as Rot
         mu, cov, fixed, target, dirs, noise = _p3_inputs(C_, N, 300 + trial)
         nz = noise if use_noise else None
-        out = R.conv_pose3pose3(R.make_opts(**kw), mu, cov, fixed, target, dirs=dirs, noise=nz)
+        o = R.make_opts(**kw)
+        mode = rng.integers(0, 3)
+        tr = lambda a: None if a is None else np.ascontiguousarray(a.transpose(0, 2, 1))
+        if mode == 1:                # AoS coordinates
+            o.layout = R.LAYOUT_AOS
+            out = R.conv_pose3pose3(o, mu, cov, tr(fixed), tr(target), dirs=dirs, noise=tr(nz)).transpose(0, 2, 1)
+        elif mode == 2:              # the reference's native points [t(3), R column-major(9)] per particle
+            o.layout = R.LAYOUT_AOS_POINTS
+            pts = lambda a: R.coords_to_points(6, tr(a).reshape(-1, 6)).reshape(C_, N, 12)
+            res = R.conv_pose3pose3(o, mu, cov, pts(fixed), pts(target), dirs=dirs, noise=tr(nz))
+            out = R.points_to_coords(6, res.reshape(-1, 12)).reshape(C_, N, 6).transpose(0, 2, 1)
+        else:
+            out = R.conv_pose3pose3(o, mu, cov, fixed, target, dirs=dirs, noise=nz)
         L = np.array([ro.cholesky_lower(c) for c in cov])
         ref = ro.conv_pose3pose3(ro.make_opts(**kw), mu, L, np.concatenate([fixed, target], 0), np.arange(C_), C_ + np.arange(C_), dirs, noise=nz)
         assert np.abs(out[:, :3] - ref[:, :3]).max() < 1e-8, (kind, N, kw)
