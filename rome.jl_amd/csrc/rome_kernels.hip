@@ -346,7 +346,16 @@ struct P3P3 {
     return solver != kSolverClosedForm && K.dir != kDirPrior;
   }
   struct Aux { double q[4]; };
-  __device__ static __forceinline__ Aux init_aux(const double (&t)[6]) { Aux A; quat_exp(&t[3], A.q); return A; }
+  // start point u0 -> state.  The reference takes X0c = vee(log(ϵ, u0)) of the start point, and Manifolds' log returns θ = π exactly
+  // for rotations with cos θ + 1 <= √eps: the same snap is applied to the quaternion (w = 0, unit vector part).
+  __device__ static __forceinline__ Aux init_aux(const double (&t)[6]) {
+    Aux A; quat_exp(&t[3], A.q);
+    if (2.0 * A.q[0] * A.q[0] <= kSqrtEps) {
+      const double inv = 1.0 / fast_sqrt(A.q[1] * A.q[1] + A.q[2] * A.q[2] + A.q[3] * A.q[3]);
+      A.q[0] = 0.0; A.q[1] *= inv; A.q[2] *= inv; A.q[3] *= inv;
+    }
+    return A;
+  }
   __device__ static __forceinline__ void finalize(double (&t)[6], const Aux& A) { quat_log(A.q, &t[3]); }
 
   // std of the tangent coordinates about particle 0: translation differences and Log(R0ᵀ R_i)
