@@ -36,10 +36,10 @@ def test_belief_stats_vs_oracle():
             assert np.abs(dm).max() < 1e-10 and np.abs(sd[v] - s).max() < 1e-10, (d, N, v)
 
 
-def test_product_vs_oracle_and_gaussian_product():
+@pytest.mark.parametrize("N", [40, 100, 128, 200, 300, 512])   # every slots-per-lane instantiation of k_product (1, 2, 4, 8)
+def test_product_vs_oracle_and_gaussian_product(N):
     import torch
     rng = np.random.default_rng(3)
-    N = 100
     # 5 Pose2 variables with 0,1,2,3,4 proposals each; Gaussian proposals so the exact product is known
     ptr = np.array([0, 0, 1, 3, 6, 10], dtype=np.int32); rows = np.arange(10, dtype=np.int32)
     sig = rng.uniform(0.3, 1.0, (10, 3)) * [1, 1, 0.2]
