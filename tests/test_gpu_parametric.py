@@ -136,8 +136,9 @@ def test_param_manhattan_recovers_ground_truth():
     """g2o-shaped graph (config 2 shape, smaller): the parametric solve lands on the generator's ground
     truth within the measurement noise, and beats the dead-reckoned initial guess."""
     fg = R.synth_manhattan(P=400, loops=200, seed=3)
-    x0 = R.initParametric(fg)
-    x = R.solveGraphParametric(fg, init=x0)
+    x0 = R.initParametric(fg, refine=False)          # dead reckoning along the odometry
+    x1 = R.initParametric(fg)                        # + the two linear solves (headings, then translations)
+    x = R.solveGraphParametric(fg, init=x1)
     gt = fg.ground_truth
 
     def err(sol):  # RMS position error after removing the gauge (best rigid alignment, 2-D Kabsch)
@@ -146,4 +147,6 @@ def test_param_manhattan_recovers_ground_truth():
         U, _, Vt = np.linalg.svd((A - ca).T @ (B - cb))
         Rm = (U @ np.diag([1, np.sign(np.linalg.det(U @ Vt))]) @ Vt).T
         return np.sqrt(np.mean(np.sum(((A - ca) @ Rm.T + cb - B) ** 2, axis=1)))
-    assert err(x) < 0.5 * err(x0) and err(x) < 0.3, (err(x), err(x0))
+    assert err(x) < 0.5 * err(x0) and err(x) < 0.3 and err(x1) < 1.2 * err(x) + 0.05, (err(x), err(x1), err(x0))
+    xd = R.solveGraphParametric(fg, init=x0)         # the same optimum from the dead-reckoned start
+    assert abs(err(xd) - err(x)) < 0.02
