@@ -234,6 +234,12 @@ def main():
         torch.cuda.synchronize()
         out["solve_loop"] = {"ms_per_iteration": (time.perf_counter() - a) * 1e3 / 50,
                              "what": "conv sweep + proposal product of all %d variables (stand-in for the clique Gibbs of solveTree!, no Bayes tree)" % len(pk.labels[R.Pose2])}
+        # ... and the whole pipeline a user runs on this graph: parametric solve (batched Jacobian kernel + sparse LM on the host)
+        # followed by 10 non-parametric iterations started from it
+        a = time.perf_counter(); xp = R.solveGraphParametric(fg); t_par = time.perf_counter() - a
+        dg.init_from_means(xp); torch.cuda.synchronize()
+        a = time.perf_counter(); dg.solve(o3, n_sweeps=10); torch.cuda.synchronize(); t_np = time.perf_counter() - a
+        out["solve_loop"]["pipeline_seconds"] = {"parametric_solve": t_par, "ten_nonparametric_iterations": t_np}
         dg.bel[R.Pose2].copy_(saved)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
