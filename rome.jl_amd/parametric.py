@@ -156,10 +156,18 @@ class _Problem:
             k = _KIND.get(type(f))
             if k is None:
                 raise TypeError("factor %s is outside the hot path" % type(f).__name__)
-            mu, info = getMeasurementParametric(f)
-            g = groups.setdefault(k, dict(mu=[], W=[], a=[], b=[]))
-            g["mu"].append(mu); g["W"].append(_whitening(info)); g["a"].append(self.index[labels[0]])
+            g = groups.setdefault(k, dict(mu=[], W=[], a=[], b=[], cov=[]))
+            if hasattr(f, "Z"):      # MvNormal factors: μ now, the whitening of the whole group in one batched call below
+                g["mu"].append(f.Z.mu); g["cov"].append(f.Z.cov)
+            else:
+                mu, info = getMeasurementParametric(f)
+                g["mu"].append(mu); g["W"].append(_whitening(info))
+            g["a"].append(self.index[labels[0]])
             g["b"].append(self.index[labels[1]] if len(labels) > 1 else -1)
+        for g in groups.values():
+            if g["cov"]:             # W with WᵀW = Σ⁻¹ for every factor of the group (same as getMeasurementParametric + _whitening)
+                g["W"] = list(np.linalg.cholesky(np.linalg.inv(np.asarray(g["cov"]))).transpose(0, 2, 1))
+            del g["cov"]
         self.groups = {}
         rows, cols = [], []
         m = 0
