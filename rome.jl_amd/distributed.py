@@ -183,3 +183,46 @@ class PipelinedSegmentSweep:
             cur = self.dg.torch.cuda.current_stream(self.store.device)
             for st in self.streams:
                 cur.wait_stream(st)
+
+
+class LinearizeShard:
+    """Row-sharded `rome_linearize` for the parametric solver (`solveGraphParametric(..., shard=LinearizeShard(...))`): rank k
+    evaluates rows shard_range(F, world, k) of every factor kind and an `all_gather` of the padded (r, Ja, Jb) blocks gives every
+    rank the full linearisation, so all ranks take the same Levenberg-Marquardt step.  `kernel` is the per-rank evaluator
+    (default: the HIP entry point through `api.linearize`; the CPU tests inject a stand-in)."""
+
+    def __init__(self, torch, dist, world, rank, device="cpu", kernel=None):
+        self.torch, self.dist, self.world, self.rank, self.device = torch, dist, world, rank, device
+        if kernel is None:
+            from . import api
+            kernel = api.linearize
+        self.kernel = kernel
+
+    def linearize(self, kind, mu, W, xa, xb, ctx=None):
+        torch = self.torch
+        F = len(mu)
+        lo, hi = shard_range(F, self.world, self.rank)
+        if hi > lo:
+            rk, Ja, Jb = self.kernel(kind, mu[lo:hi], W[lo:hi], xa[lo:hi], None if xb is None else xb[lo:hi], ctx=ctx)
+            dr, da = Ja.shape[1], Ja.shape[2]
+            db = 0 if Jb is None else Jb.shape[2]
+        else:   # more ranks than rows: shapes from a one-row probe are not needed, nothing to contribute
+            rk = Ja = Jb = None
+        # block widths are the same on every rank with rows; agree on them (ranks without rows learn them here)
+        dims = torch.tensor([0, 0, 0] if rk is None else [dr, da, db], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(dims, op=self.dist.ReduceOp.MAX)
+        dr, da, db = (int(v) for v in dims.tolist())
+        per = dr * (1 + da + db)
+        q = -(-F // self.world)                                  # rows per rank, padded
+        send = torch.zeros(q * per, dtype=torch.float64, device=self.device)
+        if rk is not None:
+            flat = np.concatenate([rk.reshape(hi - lo, -1), Ja.reshape(hi - lo, -1)] + ([Jb.reshape(hi - lo, -1)] if db else []), axis=1)
+            send[:(hi - lo) * per] = torch.as_tensor(flat.ravel(), device=self.device)
+        recv = torch.empty(self.world * q * per, dtype=torch.float64, device=self.device)
+        self.dist.all_gather_into_tensor(recv, send)
+        out = recv.cpu().numpy().reshape(self.world, q, per)
+        rows = np.concatenate([out[k, :shard_range(F, self.world, k)[1] - shard_range(F, self.world, k)[0]] for k in range(self.world)])
+        r = rows[:, :dr]
+        Ja_ = rows[:, dr:dr + dr * da].reshape(F, dr, da)
+        Jb_ = rows[:, dr + dr * da:].reshape(F, dr, db) if db else None
+        return r, Ja_, Jb_

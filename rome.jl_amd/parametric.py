@@ -238,14 +238,19 @@ class _Problem:
             Y[idx] = (Rot.from_rotvec(X[idx]) * Rot.from_rotvec(d[idx])).as_rotvec()
         return Y
 
-    def linearize(self, X, ctx=None):
-        """-> (r (m,), J scipy.sparse.csr (m, n))"""
+    def linearize(self, X, ctx=None, shard=None):
+        """-> (r (m,), J scipy.sparse.csr (m, n)).  `shard` = rome_jl_amd.distributed.LinearizeShard: every rank evaluates a
+        contiguous slice of the rows of each factor kind on its own GPU and one all-gather per kind rebuilds the full blocks on
+        every rank (factor rows are independent; BASELINE configs[4] "batched Jacobians on 8 GPUs")."""
         import scipy.sparse as sp
         r = np.empty(self.m); vals = []
         for k, g in self.groups.items():
             xa = X[g["ia"]]
             xb = X[g["ib"]] if g["ib"] is not None else None
-            rk, Ja, Jb = api.linearize(k, g["mu"], g["W"], xa, xb, ctx=ctx)
+            if shard is None:
+                rk, Ja, Jb = api.linearize(k, g["mu"], g["W"], xa, xb, ctx=ctx)
+            else:
+                rk, Ja, Jb = shard.linearize(k, g["mu"], g["W"], xa, xb, ctx)
             r[g["rslice"]] = rk.ravel()
             vals.append(Ja.ravel())
             if Jb is not None:
@@ -254,7 +259,7 @@ class _Problem:
         return r, J
 
 
-def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, return_cov=False, verbose=False):
+def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, return_cov=False, verbose=False, shard=None):
     """-> {label: coordinates} (and, if return_cov, {label: marginal covariance block} from (JᵀJ)⁻¹).
     Stops when the relative cost decrease of an accepted step falls below `tol` (small graphs converge
     quadratically; the low-frequency modes of a weakly anchored 3500-pose graph creep at 1e-4/iteration
@@ -264,7 +269,7 @@ def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, retur
     P = _Problem(fg)
     X = P.pack(initParametric(fg) if init is None else init)
     lam = 1e-6
-    r, J = P.linearize(X, ctx)
+    r, J = P.linearize(X, ctx, shard)
     cost = float(r @ r)
     for it in range(max_iters):
         if verbose:
@@ -275,7 +280,7 @@ def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, retur
             d = np.empty(P.n)
             d[P.perm] = P.solve_spd(H + lam * D, -g)
             Xn = P.retract(X, d)
-            rn, Jn = P.linearize(Xn, ctx)
+            rn, Jn = P.linearize(Xn, ctx, shard)
             cn = float(rn @ rn)
             if cn <= cost or lam > 1e12:
                 break
