@@ -288,18 +288,15 @@ def _jl(x):
             mant += ".0"
         return "%se%d" % (mant, int(ex))
     a = abs(x)
-    if a != 0.0 and (a < 1e-4 or a >= 1e6):    # python keeps fixed notation longer than julia does
-        m, e = ("%.17e" % x).split("e")
-        digits = repr(float(m + "e0"))
-        for p in range(1, 18):
+    if a != 0.0 and (a < 1e-4 or a >= 1e6):    # python keeps fixed notation longer than julia does: re-write with an exponent
+        for p in range(0, 17):                 # shortest mantissa that round-trips
             cand = "%.*e" % (p, x)
             if float(cand) == x:
-                m, e = cand.split("e")
-                digits = m.rstrip("0")
-                if digits.endswith("."):
-                    digits += "0"
                 break
-        return "%se%d" % (digits, int(e))
+        m, e = cand.split("e")
+        if "." not in m:
+            m += ".0"
+        return "%se%d" % (m, int(e))
     return r
 
 
