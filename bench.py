@@ -34,8 +34,10 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults: ~0.1 s of untimed sweeps before ~0.1 s of timed ones -- the device needs ≈ 50-100 ms of back-to-back launches to reach
+    # its steady state (with 20 warm-up launches the same kernel reads 50 µs per launch instead of 46 µs)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--solver", default="newton", choices=["closed_form", "newton", "nelder_mead"])
     ap.add_argument("--poses", type=int, default=3500)
     ap.add_argument("--loops", type=int, default=1954)
@@ -200,7 +202,7 @@ def main():
         modes = {}
         for name, sv in (("closed_form", R.SOLVER_CLOSED_FORM), ("newton", R.SOLVER_NEWTON), ("nelder_mead", R.SOLVER_NELDER_MEAD)):
             o2 = R.make_opts(N=N, solver=sv, seed=0x524F4D45)
-            reps = 5 if sv == R.SOLVER_NELDER_MEAD else 100
+            reps = 20 if sv == R.SOLVER_NELDER_MEAD else 1000
             pl = dg.plan_sweep_pose2pose2(o2, prop)
             pl(); torch.cuda.synchronize()
             a = time.perf_counter()
@@ -220,9 +222,9 @@ def main():
             for r in range(reps):
                 with torch.cuda.stream(st2[r & 1]):
                     pl2[r & 1]()
-        two_streams(10); torch.cuda.synchronize()
-        a = time.perf_counter(); two_streams(200); torch.cuda.synchronize()
-        out["gpu_convolutions_per_s_two_streams"] = tb["C"] * 200 / (time.perf_counter() - a)
+        two_streams(200); torch.cuda.synchronize()
+        a = time.perf_counter(); two_streams(2000); torch.cuda.synchronize()
+        out["gpu_convolutions_per_s_two_streams"] = tb["C"] * 2000 / (time.perf_counter() - a)
         # the other half of the metric ("solveTree! wall-clock"): one iteration of the device-resident solve loop on the
         # same graph = all convolutions (one launch) + the proposal product of every variable (one launch); DESIGN.md §11
         o3 = R.make_opts(N=N, solver=R.SOLVER_NEWTON, seed=0x524F4D45)

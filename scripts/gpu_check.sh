@@ -9,8 +9,8 @@ cd $R
 (timeout 400 python bench.py 2>&1 | tail -2) > $O/bench.log
 cd /tmp && export TMPDIR=/tmp
 for s in newton closed_form nelder_mead; do
-  st=100; [ $s = nelder_mead ] && st=10
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$s -o $s -- python $R/bench.py --solver $s --steps $st --warmup 5 --no-cpu-baseline --no-modes > $O/prof_$s.log 2>&1
+  st=2000; wu=2000; [ $s = nelder_mead ] && st=20 && wu=10
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$s -o $s -- python $R/bench.py --solver $s --steps $st --warmup $wu --no-cpu-baseline --no-modes > $O/prof_$s.log 2>&1
 done
 cd $R
 cat $O/pytest.log $O/smoke.log $O/bench.log
