@@ -7,6 +7,10 @@ import rome_jl_amd as R
 
 def timeit(fn, reps):
     fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); one = max(time.perf_counter() - t0, 1e-6)
+    for _ in range(min(5000, int(0.15 / one))):   # steady state: ~0.15 s of back-to-back launches before timing (queued, then drained)
+        fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps): fn()

@@ -14,9 +14,12 @@ for F in (5453, 1 << 16, 1 << 20):
     out = dg.prop[R.Pose2][:tb["C"]]
     for name, sv in (("closed_form", R.SOLVER_CLOSED_FORM), ("newton", R.SOLVER_NEWTON)):
         plan = dg.plan_sweep_pose2pose2(R.make_opts(N=100, solver=sv), out)
-        for _ in range(3): plan()
+        plan(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); plan(); torch.cuda.synchronize(); one = max(time.perf_counter() - t0, 1e-6)
+        for _ in range(min(5000, int(0.15 / one))):   # steady state: ~0.15 s of back-to-back launches before timing
+            plan()
         torch.cuda.synchronize()
-        reps = 20 if F < (1 << 20) else 5
+        reps = 200 if F < (1 << 16) else (50 if F < (1 << 20) else 10)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps): plan()
