@@ -5,7 +5,7 @@
 HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := rome.jl_amd/csrc
-SRC     := $(CSRC)/rome_kernels.hip $(CSRC)/rome_parametric.hip $(CSRC)/rome_product.hip $(CSRC)/rome_capi.hip
+SRC     := $(CSRC)/rome_kernels.hip $(CSRC)/rome_parametric.hip $(CSRC)/rome_product.hip $(CSRC)/rome_kde.hip $(CSRC)/rome_capi.hip
 DEPS    := $(SRC) $(CSRC)/rome_kernels.h $(CSRC)/rome_device_math.hpp include/rome_mi355.h
 LIB     := rome.jl_amd/librome_mi355.so
 

@@ -241,8 +241,22 @@ int rome_linearize_dev(rome_ctx*, int32_t kind, int32_t F, const double* mu, con
  *   AMP.manifoldProduct (unvendored): importance-sampling product of the proposal KDEs, see DESIGN.md §10. */
 int rome_belief_stats_dev(rome_ctx*, int32_t dim, int32_t V, int32_t N, const double* bel, double* mean, double* std);
 int rome_belief_stats(rome_ctx*, int32_t dim, int32_t V, int32_t N, const double* bel, double* mean, double* std); /* host pointers */
+/* rome_kde_bandwidth*: the bandwidth `manikde!` selects for a belief, one per coordinate, by leave-one-out likelihood
+ *   cross-validation of a 1-D Gaussian KDE (golden section on the bracket of KDE.jl's ksize "lcv"; coordinate k is circular
+ *   -- differences wrapped -- when bit k of circular_mask is set: Pose2 = 0b100).  bel [V][dim][N] -> bw [V][dim], dim 1..6,
+ *   2 <= N <= ROME_MAX_PARTICLES.  tol_* <= 0 selects the reference's stopping rules (1e-2 relative for Euclidean
+ *   coordinates, 1e-6 for circular ones).  Reproduces the bandwidths stored in the reference's solved graph
+ *   (examples/fg-after-solve.tar.gz `vecbw`; tests/test_gpu_kde.py). */
+int rome_kde_bandwidth_dev(rome_ctx*, int32_t dim, int32_t V, int32_t N, const double* bel, uint32_t circular_mask,
+                           double tol_euclid, double tol_circular, double* bw);
+int rome_kde_bandwidth(rome_ctx*, int32_t dim, int32_t V, int32_t N, const double* bel, uint32_t circular_mask,
+                       double tol_euclid, double tol_circular, double* bw);                                        /* host pointers */
 int rome_product_dev(rome_ctx*, const rome_opts*, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
                      const double* prop, const double* bel_in, double* bel_out);
+/* same with caller-supplied kernel bandwidths of the proposals, prop_bw [rows][dim] (e.g. rome_kde_bandwidth_dev run on `prop`,
+ * which is what the reference's manikde! attaches to every convolution result); NULL = Silverman's rule in-kernel. */
+int rome_product_bw_dev(rome_ctx*, const rome_opts*, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
+                        const double* prop, const double* prop_bw, const double* bel_in, double* bel_out);
 
 /* thin device-memory helpers for callers without their own HIP runtime binding (e.g. the Julia shim) */
 int rome_dev_alloc(rome_ctx*, uint64_t bytes, void** out);

@@ -231,11 +231,25 @@ def sample_priorpose3(opts, mu, L, factor=None, noise=None, C_=None):
     return out
 
 
-def product(opts, dim, prop_ptr, prop_rows, prop, bel_in):
+def product(opts, dim, prop_ptr, prop_rows, prop, bel_in, prop_bw=None):
     pp, ppp = _i(prop_ptr); pr, ppr = _i(prop_rows); P, pP = _d(prop); B, pB = _d(bel_in)
+    bw, pbw = (None, None) if prop_bw is None else _d(prop_bw)
     V = len(pp) - 1
     out = np.zeros_like(B)
-    rc = lib().ro_product(C.byref(opts), int(dim), V, ppp, ppr, pP, pB, out.ctypes.data_as(C.POINTER(C.c_double)))
+    rc = lib().ro_product_bw(C.byref(opts), int(dim), V, ppp, ppr, pP, pbw, pB, out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    return out
+
+
+def kde_bandwidths(bel, circular_mask, tol_euclid=1e-2, tol_circular=1e-6):
+    """bel (V, dim, N) -> (V, dim) leave-one-out likelihood bandwidths (ro_kde_bandwidths)."""
+    B, pB = _d(bel)
+    V, dim, N = B.shape
+    out = np.zeros((V, dim))
+    lib().ro_kde_bandwidths.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_uint32, C.c_double, C.c_double,
+                                        C.POINTER(C.c_double)]
+    rc = lib().ro_kde_bandwidths(dim, V, N, pB, int(circular_mask), float(tol_euclid), float(tol_circular),
+                                 out.ctypes.data_as(C.POINTER(C.c_double)))
     assert rc == 0
     return out
 

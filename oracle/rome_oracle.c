@@ -1014,6 +1014,83 @@ void ro_set_num_threads(int n) {
 }
 
 /* ======================================================================== */
+/* KDE bandwidth by leave-one-out likelihood cross-validation (⚠AMP manikde! / ⚠KDE.jl kde!(pts) "lcv";   */
+/* SURVEY §8(a) row a11, §8(f) row 1)                                                                    */
+/* ======================================================================== */
+/* The reference wraps every convolution result in `manikde!`, which picks ONE bandwidth per coordinate by
+ * maximising the leave-one-out log-likelihood of a 1-D Gaussian KDE (Euclidean coordinates: KernelDensityEstimate
+ * `ksize(·,"lcv")`, a golden-section search with relative tolerance 1e-2; Circular coordinates: AMP's naive
+ * cross-validation with Optim's GoldenSection, i.e. to ~1e-8).  Both packages are unvendored; the rule below is
+ * PINNED ON REFERENCE OUTPUT: the 361 × 3 bandwidths the reference stored with its solved Manhattan-500 graph
+ * (tests/golden/manhattan500_reference_solve.npz `bandwidth`, next to the particles they were selected for) are
+ * reproduced by it to <= 0.7 % on x, y (the reference's own 1 % stopping rule) and <= 1e-4 on θ -- including the
+ * bimodal beliefs whose likelihood has two local maxima (tests/test_oracle_golden.py).
+ *   D_ij   = x_i - x_j                      (circular: wrapped to [-π, π])
+ *   LL(h)  = Σ_i log max(Σ_{j≠i} exp(-½ D_ij²/h²), 1e-300) - N log((N-1) h √(2π))
+ *   minm   = max(min_{i≠j} |D_ij|, 1e-6);  maxm = max_i y_i - min_i y_i,  y_i = D_i0
+ *   h      = golden-section minimiser of -LL on the bracket (2 minm/(N-1), (minm+maxm)/2, 2 maxm), Numerical-Recipes
+ *            form, stop when |x3-x0| <= tol (|x1|+|x2|) -- the bracket Ihler's KDE toolbox / KDE.jl use.       */
+static double lcv_wrap(double d) { return d - 6.283185307179586476925287 * rint(d * 0.15915494309189533576888); }
+static double lcv_negll(int N, const double* x, int circular, double h) {
+  const double a = -0.5 / (h * h);
+  double ll = 0.0;
+  for (int i = 0; i < N; ++i) {
+    double S = 0.0;
+    for (int j = 0; j < N; ++j) {
+      if (j == i) continue;
+      double d = x[i] - x[j];
+      if (circular) d = lcv_wrap(d);
+      S += exp(a * d * d);
+    }
+    ll += log(fmax(S, 1e-300));
+  }
+  return -(ll - N * log((N - 1) * h * 2.50662827463100050241576528));
+}
+double ro_kde_bandwidth_lcv(int N, const double* x, int circular, double tol, int* n_evals) {
+  if (n_evals) *n_evals = 0;
+  if (N < 2) return 0.0;
+  double minm = INFINITY, ymin = 0.0, ymax = 0.0;
+  for (int i = 0; i < N; ++i) {
+    double y = x[i] - x[0];
+    if (circular) y = lcv_wrap(y);
+    if (y < ymin) ymin = y;
+    if (y > ymax) ymax = y;
+    for (int j = 0; j < N; ++j) {
+      if (j == i) continue;
+      double d = x[i] - x[j];
+      if (circular) d = lcv_wrap(d);
+      if (fabs(d) < minm) minm = fabs(d);
+    }
+  }
+  minm = fmax(minm, 1e-6);
+  const double maxm = fmax(ymax - ymin, minm);
+  const double ax = 2.0 * minm / (N - 1), bx = 0.5 * (minm + maxm), cx = 2.0 * maxm;
+  const double Cg = 0.38196601125010515180, Rg = 0.61803398874989484820;
+  double x0 = ax, x3 = cx, x1, x2;
+  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + Cg * (cx - bx); }
+  else { x2 = bx; x1 = bx - Cg * (bx - ax); }
+  double f1 = lcv_negll(N, x, circular, x1), f2 = lcv_negll(N, x, circular, x2);
+  int ne = 2;
+  while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2)) && ne < 200) {
+    if (f2 < f1) { x0 = x1; x1 = x2; x2 = Rg * x1 + Cg * x3; f1 = f2; f2 = lcv_negll(N, x, circular, x2); }
+    else         { x3 = x2; x2 = x1; x1 = Rg * x2 + Cg * x0; f2 = f1; f1 = lcv_negll(N, x, circular, x1); }
+    ++ne;
+  }
+  if (n_evals) *n_evals = ne;
+  return f1 < f2 ? x1 : x2;
+}
+/* bel [V][dim][N] (SoA blocks) -> bw [V][dim]; coordinate k is circular when bit k of circular_mask is set. */
+int ro_kde_bandwidths(int dim, int V, int N, const double* bel, uint32_t circular_mask, double tol_euclid, double tol_circular, double* bw) {
+  if (dim < 1 || dim > 6 || N < 2) return -1;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int t = 0; t < V * dim; ++t) {
+    const int k = t % dim, circ = (circular_mask >> k) & 1;
+    bw[t] = ro_kde_bandwidth_lcv(N, bel + (size_t)t * N, circ, circ ? tol_circular : tol_euclid, NULL);
+  }
+  return 0;
+}
+
+/* ======================================================================== */
 /* Product of proposals (stand-in for ⚠AMP manifoldProduct)          */
 /* ======================================================================== */
 /* NOT a restatement of ApproxManifoldProducts' multiscale Gibbs product (unvendored, unpinned): a
@@ -1029,8 +1106,9 @@ void ro_set_num_threads(int n) {
  * dim = 2 (Point2) or 3 (Pose2: third coordinate is an angle, differences wrapped).                  */
 static double wrap_diff(double a) { return atan2(sin(a), cos(a)); }
 
-int ro_product(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const int32_t* prop_rows,
-               const double* prop /*[rows][dim][N]*/, const double* bel_in /*[V][dim][N]*/, double* bel_out) {
+int ro_product_bw(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const int32_t* prop_rows,
+                  const double* prop /*[rows][dim][N]*/, const double* prop_bw /*[rows][dim] or NULL: Silverman*/,
+                  const double* bel_in /*[V][dim][N]*/, double* bel_out) {
   const int N = o->n_particles;
   if (dim != 2 && dim != 3) return -1;
   const double cN = pow(4.0 / ((dim + 2.0) * N), 1.0 / (dim + 4.0));
@@ -1049,7 +1127,10 @@ int ro_product(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const 
       if (dim == 3) ro_belief_spread_se2(N, P, P + N, P + 2 * N, mean, sd);
       else ro_belief_spread_r2(N, P, P + N, mean, sd);
       double ln = 0.0;
-      for (int k = 0; k < dim; ++k) { h[l * dim + k] = fmax(cN * sd[k], 1e-6); ln += log(h[l * dim + k]); }
+      for (int k = 0; k < dim; ++k) {
+        h[l * dim + k] = fmax(prop_bw ? prop_bw[(size_t)rows[l] * dim + k] : cN * sd[k], 1e-6);
+        ln += log(h[l * dim + k]);
+      }
       if (ln < best) { best = ln; base = l; }
     }
     const int M = N;
@@ -1104,4 +1185,8 @@ int ro_product(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const 
     free(h); free(logw); free(cum);
   }
   return 0;
+}
+int ro_product(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const int32_t* prop_rows,
+               const double* prop, const double* bel_in, double* bel_out) {
+  return ro_product_bw(o, dim, V, prop_ptr, prop_rows, prop, NULL, bel_in, bel_out);
 }

@@ -109,8 +109,14 @@ int ro_sample_priorpose3(const ro_opts* o, int C, const int32_t* factor,
                          const double* mu, const double* L, const double* noise, double* out /*[C][6][N]*/);
 
 /* product of K proposal beliefs per variable (stand-in for AMP manifoldProduct; see rome_oracle.c) */
+/* leave-one-out likelihood bandwidths (manikde! rule; pinned on the reference's stored bandwidths) */
+double ro_kde_bandwidth_lcv(int N, const double* x, int circular, double tol, int* n_evals);
+int ro_kde_bandwidths(int dim, int V, int N, const double* bel /*[V][dim][N]*/, uint32_t circular_mask, double tol_euclid,
+                      double tol_circular, double* bw /*[V][dim]*/);
 int ro_product(const ro_opts* o, int dim, int V, const int32_t* prop_ptr /*[V+1]*/, const int32_t* prop_rows,
                const double* prop /*[rows][dim][N]*/, const double* bel_in /*[V][dim][N]*/, double* bel_out);
+int ro_product_bw(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
+                  const double* prop_bw /*[rows][dim] or NULL*/, const double* bel_in, double* bel_out);
 
 int ro_num_threads(void);
 void ro_set_num_threads(int n);

@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "librome_mi355.so")
-SOURCES = [os.path.join(HERE, "csrc", f) for f in ("rome_kernels.hip", "rome_parametric.hip", "rome_product.hip", "rome_capi.hip")]
+SOURCES = [os.path.join(HERE, "csrc", f) for f in ("rome_kernels.hip", "rome_parametric.hip", "rome_product.hip", "rome_kde.hip", "rome_capi.hip")]
 DEPS = SOURCES + [os.path.join(HERE, "csrc", f) for f in ("rome_kernels.h", "rome_device_math.hpp")] + \
     [os.path.join(os.path.dirname(HERE), "include", "rome_mi355.h")]
 

@@ -159,6 +159,21 @@ def belief_stats(bel, ctx=None):
     return mean, sd
 
 
+def kde_bandwidth(bel, circular_mask=None, tol_euclid=0.0, tol_circular=0.0, ctx=None):
+    """bel (V, dim, N) host array -> (V, dim) bandwidths as `manikde!` selects them (leave-one-out likelihood
+    cross-validation per coordinate), via rome_kde_bandwidth.  circular_mask: bit k set = coordinate k is an angle
+    (default: 0b100 for dim 3 -- Pose2 --, 0 otherwise); tol_* = 0 selects the reference's stopping rules."""
+    ctx = ctx or default_context()
+    bel = _d(bel)
+    V, d, N = bel.shape
+    if circular_mask is None:
+        circular_mask = 0b100 if d == 3 else 0
+    bw = np.empty((V, d))
+    _lib.check(_lib.load().rome_kde_bandwidth(ctx.handle, d, V, N, _p(bel), int(circular_mask), float(tol_euclid),
+                                              float(tol_circular), _p(bw)), ctx.handle)
+    return bw
+
+
 # ------------------------------------------------------------------ helpers
 def cholesky_lower(cov):
     """n covariances (n,d,d) or one (d,d) -> packed lower factors (n, d(d+1)/2)."""

@@ -596,15 +596,46 @@ int rome_belief_stats(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const doub
   ROME_HIP(c, hipStreamSynchronize(c->stream));
   return ROME_OK;
 }
-int rome_product_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
-                     const double* prop, const double* bel_in, double* bel_out) {
+static int check_kde(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, const double* bw) {
+  if (!c || V < 0 || N < 2 || N > ROME_MAX_PARTICLES || dim < 1 || dim > 6 || (V > 0 && (!bel || !bw))) return ROME_ERR_INVALID_ARG;
+  return ROME_OK;
+}
+int rome_kde_bandwidth_dev(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, uint32_t circular_mask,
+                           double tol_euclid, double tol_circular, double* bw) {
+  int rc = check_kde(c, dim, V, N, bel, bw); if (rc) return rc;
+  ROME_HIP(c, rome::launch_kde_bandwidth(dim, V, N, bel, circular_mask, tol_euclid > 0 ? tol_euclid : 1e-2,
+                                         tol_circular > 0 ? tol_circular : 1e-6, bw, nullptr, c->stream));
+  return ROME_OK;
+}
+int rome_kde_bandwidth(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, uint32_t circular_mask,
+                       double tol_euclid, double tol_circular, double* bw) {
+  int rc = check_kde(c, dim, V, N, bel, bw); if (rc) return rc;
+  if (V == 0) return ROME_OK;
+  ROME_HIP(c, hipSetDevice(c->device));
+  void *d_b, *d_h;
+  const size_t nb = 8ull * V * dim * N, nh = 8ull * V * dim;
+  if ((rc = ensure(c, 0, nb, &d_b))) return rc;
+  if ((rc = ensure(c, 1, nh, &d_h))) return rc;
+  ROME_HIP(c, hipMemcpyAsync(d_b, bel, nb, hipMemcpyHostToDevice, c->stream));
+  ROME_HIP(c, rome::launch_kde_bandwidth(dim, V, N, (const double*)d_b, circular_mask, tol_euclid > 0 ? tol_euclid : 1e-2,
+                                         tol_circular > 0 ? tol_circular : 1e-6, (double*)d_h, nullptr, c->stream));
+  ROME_HIP(c, hipMemcpyAsync(bw, d_h, nh, hipMemcpyDeviceToHost, c->stream));
+  ROME_HIP(c, hipStreamSynchronize(c->stream));
+  return ROME_OK;
+}
+int rome_product_bw_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
+                        const double* prop, const double* prop_bw, const double* bel_in, double* bel_out) {
   int rc = check_opts(o); if (rc) return rc;
   if (!c || V < 0 || (dim != 2 && dim != 3)) return ROME_ERR_INVALID_ARG;
   if (V > 0 && (!prop_ptr || !bel_in || !bel_out)) return ROME_ERR_INVALID_ARG;
   const int N = o->n_particles;
   const double c_n = std::pow(4.0 / ((dim + 2.0) * N), 1.0 / (dim + 4.0));
-  ROME_HIP(c, rome::launch_product(dim, V, N, prop_ptr, prop_rows, prop, bel_in, bel_out, c_n, o->seed, o->stream_offset, c->stream));
+  ROME_HIP(c, rome::launch_product(dim, V, N, prop_ptr, prop_rows, prop, prop_bw, bel_in, bel_out, c_n, o->seed, o->stream_offset, c->stream));
   return ROME_OK;
+}
+int rome_product_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
+                     const double* prop, const double* bel_in, double* bel_out) {
+  return rome_product_bw_dev(c, o, dim, V, prop_ptr, prop_rows, prop, nullptr, bel_in, bel_out);
 }
 
 /* ---- device memory helpers ---- */

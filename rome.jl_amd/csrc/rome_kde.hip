@@ -1,0 +1,133 @@
+// rome_kde.hip -- KDE bandwidths by leave-one-out likelihood cross-validation.
+//
+// The reference wraps every convolution result in `manikde!` (⚠AMP), which selects one bandwidth per coordinate by
+// maximising the leave-one-out log-likelihood of a 1-D Gaussian KDE (Euclidean coordinates: ⚠KDE.jl ksize "lcv",
+// golden section to 1 %; Circular coordinates: naive cross-validation with Optim's GoldenSection).  The rule is the
+// one written down in oracle/rome_oracle.c (ro_kde_bandwidth_lcv), which reproduces the 361 x 3 bandwidths stored
+// with the reference's solved Manhattan-500 graph (tests/golden/manhattan500_reference_solve.npz).
+//
+// Kernel shape: one wave per (belief, coordinate) task, four tasks per 256-thread block.  Lane l owns particles
+// l, l+64, ... (S slots, N <= 64 S); the N kernel points are staged once in the wave's own LDS region and walked with
+// broadcast reads.  One likelihood evaluation is N x S x (difference, square, 20-instruction exp) per lane; the
+// golden-section search (17 evaluations at 1 %, ~33 at 1e-6) runs on wave-uniform scalars, so there is no
+// divergence and no block-level synchronisation.  Compute-bound: 8 N bytes in, 8 bytes out per task.
+#include "rome_device_math.hpp"
+#include "rome_kernels.h"
+
+namespace rome {
+
+constexpr int kKdeWaves = 4;
+
+__device__ __forceinline__ double lcv_wrap(double d) { return d - 6.283185307179586476925287 * rint(d * 0.15915494309189533576888); }
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// -LL(h) of the wave's task; x[s] = own particles (idle slots shadow particle 0), pts = all N particles in LDS
+template <int S, bool CIRC>
+__device__ __forceinline__ double lcv_negll(const double (&x)[S], const bool (&act)[S], const double* __restrict__ pts, int N,
+                                            int lane, double h) {
+  const double a = -0.5 / (h * h);
+  double acc[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) acc[s] = 0.0;
+  for (int j = 0; j < N; ++j) {
+    const double xj = pts[j];   // broadcast read
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      double d = x[s] - xj;
+      if (CIRC) d = lcv_wrap(d);
+      const double e = fast_exp_neg(a * d * d);
+      acc[s] += (lane + 64 * s == j) ? 0.0 : e;
+    }
+  }
+  double ll = 0.0;
+#pragma unroll
+  for (int s = 0; s < S; ++s) if (act[s]) ll += fast_log(fmax(acc[s], 1e-300));
+  ll = wave_sum(ll);
+  return -(ll - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528));
+}
+
+template <int S, bool CIRC>
+__device__ __forceinline__ double lcv_golden(const double (&x)[S], const bool (&act)[S], const double* __restrict__ pts, int N,
+                                             int lane, double tol, int* n_evals) {
+  // bracket: smallest pair distance and extent about particle 0 (oracle: ro_kde_bandwidth_lcv)
+  const double x0v = pts[0];
+  double mn = __builtin_inf(), ylo = 0.0, yhi = 0.0;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    double y = x[s] - x0v;
+    if (CIRC) y = lcv_wrap(y);
+    ylo = fmin(ylo, y); yhi = fmax(yhi, y);   // idle slots hold particle 0: y = 0
+  }
+  for (int j = 0; j < N; ++j) {
+    const double xj = pts[j];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      double d = x[s] - xj;
+      if (CIRC) d = lcv_wrap(d);
+      if (act[s] && lane + 64 * s != j) mn = fmin(mn, fabs(d));
+    }
+  }
+  mn = wave_min(mn); ylo = wave_min(ylo); yhi = -wave_min(-yhi);
+  const double minm = fmax(mn, 1e-6), maxm = fmax(yhi - ylo, minm);
+  const double ax = 2.0 * minm / (double)(N - 1), bx = 0.5 * (minm + maxm), cx = 2.0 * maxm;
+  constexpr double Cg = 0.38196601125010515180, Rg = 0.61803398874989484820;
+  double x0 = ax, x3 = cx, x1, x2;
+  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + Cg * (cx - bx); }
+  else { x2 = bx; x1 = bx - Cg * (bx - ax); }
+  double f1 = lcv_negll<S, CIRC>(x, act, pts, N, lane, x1), f2 = lcv_negll<S, CIRC>(x, act, pts, N, lane, x2);
+  int ne = 2;
+  while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2)) && ne < 200) {
+    if (f2 < f1) { x0 = x1; x1 = x2; x2 = Rg * x1 + Cg * x3; f1 = f2; f2 = lcv_negll<S, CIRC>(x, act, pts, N, lane, x2); }
+    else         { x3 = x2; x2 = x1; x1 = Rg * x2 + Cg * x0; f2 = f1; f1 = lcv_negll<S, CIRC>(x, act, pts, N, lane, x1); }
+    ++ne;
+  }
+  *n_evals = ne;
+  return f1 < f2 ? x1 : x2;
+}
+
+template <int S>
+__global__ void __launch_bounds__(64 * kKdeWaves) k_kde_bandwidth(int T, int dim, int N, const double* __restrict__ bel,
+                                                                  uint32_t circ_mask, double tol_e, double tol_c,
+                                                                  double* __restrict__ bw, int32_t* __restrict__ evals) {
+  __shared__ double pts[kKdeWaves][64 * S];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = blockIdx.x * kKdeWaves + wave;
+  if (t >= T) return;   // wave-uniform; nothing below synchronises across waves
+  const bool circ = (circ_mask >> (t % dim)) & 1u;
+  const double* __restrict__ P = bel + (size_t)t * N;
+  double x[S];
+  bool act[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int i = lane + 64 * s;
+    act[s] = i < N;
+    x[s] = P[act[s] ? i : 0];
+    if (act[s]) pts[wave][i] = x[s];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  int ne = 0;
+  const double h = circ ? lcv_golden<S, true>(x, act, pts[wave], N, lane, tol_c, &ne)
+                        : lcv_golden<S, false>(x, act, pts[wave], N, lane, tol_e, &ne);
+  if (lane == 0) { bw[t] = h; if (evals) evals[t] = ne; }
+}
+
+hipError_t launch_kde_bandwidth(int dim, int V, int N, const double* bel, uint32_t circ_mask, double tol_e, double tol_c,
+                                double* bw, int32_t* evals, hipStream_t s) {
+  const int T = V * dim;
+  if (T <= 0) return hipSuccess;
+  const dim3 grid((T + kKdeWaves - 1) / kKdeWaves), block(64 * kKdeWaves);
+#define ROME_LAUNCH_KDE(SS) hipLaunchKernelGGL((k_kde_bandwidth<SS>), grid, block, 0, s, T, dim, N, bel, circ_mask, tol_e, tol_c, bw, evals)
+  if (N <= 64) ROME_LAUNCH_KDE(1);
+  else if (N <= 128) ROME_LAUNCH_KDE(2);
+  else if (N <= 256) ROME_LAUNCH_KDE(4);
+  else ROME_LAUNCH_KDE(8);
+#undef ROME_LAUNCH_KDE
+  return hipGetLastError();
+}
+
+}  // namespace rome

@@ -93,6 +93,7 @@ struct ProductArgs {
   const int32_t* prop_ptr;   // [V+1]
   const int32_t* prop_rows;  // rows of `prop` targeting each variable
   const double* prop;        // [rows][D][N]
+  const double* prop_bw;     // [rows][D] kernel bandwidths of the proposals (rome_kde_bandwidth_dev), or null: Silverman in-kernel
   const double* bel_in;      // [V][D][N]
   double* bel_out;           // [V][D][N]
   double inv_n, inv_nm1, c_n;  // c_n: Silverman factor (4/((d+2)N))^(1/(d+4)), host-computed
@@ -108,6 +109,22 @@ struct ProductArgs {
 constexpr int kProdWaves = 4;
 constexpr int kProdChunk = 8;   // proposals whose contributions are buffered in LDS at a time
 constexpr int kProdMaxK = 32;   // proposals whose bandwidths are kept in LDS (more: recomputed where needed)
+
+// kernel bandwidths of one proposal: caller-supplied (leave-one-out likelihood rule, rome_kde.hip) or Silverman's rule on
+// the proposal's spread; floored at 1e-6 either way
+template <int D>
+__device__ __forceinline__ void proposal_bandwidth(const ProductArgs& a, int row, const double* __restrict__ P, int N, int lane,
+                                                   double (&h)[D]) {
+  if (a.prop_bw) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) h[k] = fmax(a.prop_bw[(size_t)row * D + k], 1e-6);   // wave-uniform address
+  } else {
+    double x0[D], moff[D], sd[D];
+    block_stats<D>(P, N, a.inv_n, a.inv_nm1, lane, x0, moff, sd);
+#pragma unroll
+    for (int k = 0; k < D; ++k) h[k] = fmax(a.c_n * sd[k], 1e-6);
+  }
+}
 
 template <int D, int S>
 __global__ void __launch_bounds__(64 * kProdWaves) k_product(const ProductArgs a) {
@@ -138,15 +155,14 @@ __global__ void __launch_bounds__(64 * kProdWaves) k_product(const ProductArgs a
   for (int l0 = 0; l0 < K; l0 += kProdMaxK) {
     const int cnt = min(kProdMaxK, K - l0);
     for (int c = wave; c < cnt; c += kProdWaves) {
-      const double* P = a.prop + (size_t)a.prop_rows[r0 + l0 + c] * D * N;
-      double x0[D], moff[D], sd[D];
-      block_stats<D>(P, N, a.inv_n, a.inv_nm1, lane, x0, moff, sd);
+      const int row = a.prop_rows[r0 + l0 + c];
+      double h[D];
+      proposal_bandwidth<D>(a, row, a.prop + (size_t)row * D * N, N, lane, h);
       double ln = 0.0;
 #pragma unroll
       for (int k = 0; k < D; ++k) {
-        const double h = fmax(a.c_n * sd[k], 1e-6);
-        ln += fast_log(h);
-        if (lane == 0) ihbuf[c][k] = 1.0 / h;
+        ln += fast_log(h[k]);
+        if (lane == 0) ihbuf[c][k] = 1.0 / h[k];
       }
       if (lane == 0) lnbuf[c] = ln;
     }
@@ -176,16 +192,17 @@ __global__ void __launch_bounds__(64 * kProdWaves) k_product(const ProductArgs a
     const int cnt = min(kProdChunk, K - 1 - c0);
     for (int c = wave; c < cnt; c += kProdWaves) {
       const int nb = c0 + c, l = nb < base ? nb : nb + 1;   // nb-th non-base proposal
-      const double* __restrict__ P = a.prop + (size_t)a.prop_rows[r0 + l] * D * N;
+      const int row = a.prop_rows[r0 + l];
+      const double* __restrict__ P = a.prop + (size_t)row * D * N;
       double ih[D];
       if (h_cached) {
 #pragma unroll
         for (int k = 0; k < D; ++k) ih[k] = ihbuf[l][k];
       } else {
-        double x0[D], moff[D], sd[D];
-        block_stats<D>(P, N, a.inv_n, a.inv_nm1, lane, x0, moff, sd);
+        double h[D];
+        proposal_bandwidth<D>(a, row, P, N, lane, h);
 #pragma unroll
-        for (int k = 0; k < D; ++k) ih[k] = 1.0 / fmax(a.c_n * sd[k], 1e-6);
+        for (int k = 0; k < D; ++k) ih[k] = 1.0 / h[k];
       }
       double qmin[S], sacc[S];
 #pragma unroll
@@ -299,11 +316,12 @@ hipError_t launch_belief_stats(int dim, int V, int N, const double* bel, double*
 }
 
 hipError_t launch_product(int dim, int V, int N, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
-                          const double* bel_in, double* bel_out, double c_n, uint64_t seed, uint64_t stream_offset, hipStream_t s) {
+                          const double* prop_bw, const double* bel_in, double* bel_out, double c_n, uint64_t seed,
+                          uint64_t stream_offset, hipStream_t s) {
   if (V <= 0) return hipSuccess;
   if (N > kProdMaxN) return hipErrorInvalidValue;
   ProductArgs a;
-  a.V = V; a.N = N; a.prop_ptr = prop_ptr; a.prop_rows = prop_rows; a.prop = prop; a.bel_in = bel_in; a.bel_out = bel_out;
+  a.V = V; a.N = N; a.prop_ptr = prop_ptr; a.prop_rows = prop_rows; a.prop = prop; a.prop_bw = prop_bw; a.bel_in = bel_in; a.bel_out = bel_out;
   a.inv_n = 1.0 / N; a.inv_nm1 = N > 1 ? 1.0 / (N - 1) : 1.0; a.c_n = c_n; a.seed = seed; a.stream_offset = stream_offset;
   if (dim != 2 && dim != 3) return hipErrorInvalidValue;
 #define ROME_LAUNCH_PRODUCT(S) \

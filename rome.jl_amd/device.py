@@ -74,6 +74,7 @@ class DeviceGraph:
         Fb = self.tab["br"]["F"] if "br" in self.tab else 0
         Fb0 = self.tab["br"]["F0"] if "br" in self.tab else 0
         self.n_prop = {Pose2: C2 + Fb, Point2: Fb0}
+        self.prop_bw = {}
         self.prop = {Pose2: torch.zeros((max(C2 + Fb, 1), 3, self.N), dtype=f64, device=self.device),
                      Point2: torch.zeros((max(Fb0, 1), 2, self.N), dtype=f64, device=self.device)}
         self.bel_next = {Pose2: torch.zeros_like(self.bel[Pose2]), Point2: torch.zeros_like(self.bel[Point2])}
@@ -165,8 +166,12 @@ class DeviceGraph:
             self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR1), 1, out=self.prop[Pose2][C2:C2 + Fb])
             self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR0), 0, out=self.prop[Point2][:Fb0])
 
-    def product_step(self, opts, sweep=0):
-        """bel <- product of the proposals targeting each variable (Jacobi update, double-buffered)."""
+    def product_step(self, opts, sweep=0, bandwidth="silverman"):
+        """bel <- product of the proposals targeting each variable (Jacobi update, double-buffered).
+        bandwidth: "silverman" (in-kernel rule on the proposal spread) or "lcv" (leave-one-out likelihood bandwidths of every
+        proposal by rome_kde_bandwidth_dev first -- what the reference's `manikde!` attaches to each convolution result)."""
+        if bandwidth not in ("silverman", "lcv"):
+            raise ValueError("bandwidth must be 'silverman' or 'lcv'")
         self._bind_stream()
         base = sweep << 32
         for vt, dim, off in ((Pose2, 3, self.STREAM_PROD2), (Point2, 2, self.STREAM_PRODL)):
@@ -175,17 +180,26 @@ class DeviceGraph:
                 continue
             o = self._opts_at(opts, base + off)
             c = self.csr[vt]
-            _lib.check(self._lib.rome_product_dev(self.ctx.handle, C.byref(o), dim, V, c["ptr"].data_ptr(), c["rows"].data_ptr(),
-                                                  self.prop[vt].data_ptr(), self.bel[vt].data_ptr(), self.bel_next[vt].data_ptr()),
-                       self.ctx.handle)
+            bw_ptr = None
+            rows = self.prop[vt].shape[0]
+            if bandwidth == "lcv" and rows:
+                if vt not in self.prop_bw:
+                    self.prop_bw[vt] = self.torch.empty((rows, dim), dtype=self.torch.float64, device=self.device)
+                _lib.check(self._lib.rome_kde_bandwidth_dev(self.ctx.handle, dim, rows, self.N, self.prop[vt].data_ptr(),
+                                                            0b100 if vt is Pose2 else 0, 0.0, 0.0, self.prop_bw[vt].data_ptr()),
+                           self.ctx.handle)
+                bw_ptr = self.prop_bw[vt].data_ptr()
+            _lib.check(self._lib.rome_product_bw_dev(self.ctx.handle, C.byref(o), dim, V, c["ptr"].data_ptr(), c["rows"].data_ptr(),
+                                                     self.prop[vt].data_ptr(), bw_ptr, self.bel[vt].data_ptr(),
+                                                     self.bel_next[vt].data_ptr()), self.ctx.handle)
             self.bel[vt], self.bel_next[vt] = self.bel_next[vt], self.bel[vt]
 
-    def solve(self, opts, n_sweeps=10):
+    def solve(self, opts, n_sweeps=10, bandwidth="silverman"):
         """n_sweeps x (convolution sweep, product): whole-graph nonparametric inference stand-in for the
         clique-by-clique Gibbs of `solveTree!` (no Bayes tree)."""
         for s in range(n_sweeps):
             self.conv_step(opts, s)
-            self.product_step(opts, s)
+            self.product_step(opts, s, bandwidth)
 
     def init_from_means(self, means, sigma=None, seed=3):
         """Beliefs = per-variable mean ⊕ N(0, diag σ²) jitter: e.g. means from solveGraphParametric (IIF can
@@ -209,6 +223,16 @@ class DeviceGraph:
         sd = self.torch.empty((V, d), dtype=self.torch.float64, device=self.device)
         _lib.check(self._lib.rome_belief_stats_dev(self.ctx.handle, d, V, N, b.data_ptr(), mean.data_ptr(), sd.data_ptr()), self.ctx.handle)
         return mean, sd
+
+    def kde_bandwidths(self, vartype, tol_euclid=0.0, tol_circular=0.0):
+        """[V, dim] leave-one-out likelihood bandwidths of every belief of one variable type (`manikde!` rule), on device."""
+        self._bind_stream()
+        b = self.bel[vartype]
+        V, d, N = b.shape
+        bw = self.torch.empty((V, d), dtype=self.torch.float64, device=self.device)
+        _lib.check(self._lib.rome_kde_bandwidth_dev(self.ctx.handle, d, V, N, b.data_ptr(), 0b100 if vartype is Pose2 else 0,
+                                                    float(tol_euclid), float(tol_circular), bw.data_ptr()), self.ctx.handle)
+        return bw
 
     def download_beliefs(self, fg):
         for vt in (Pose2, Point2, Pose3):

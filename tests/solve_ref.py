@@ -5,7 +5,7 @@ import numpy as np
 import oracle as ro
 
 
-def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1):
+def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverman"):
     pk = R.PackedGraph(fg)
     bel2 = pk.beliefs(fg, R.Pose2)
     bell = pk.beliefs(fg, R.Point2) if len(pk.labels[R.Point2]) else np.zeros((0, 2, N))
@@ -45,7 +45,8 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1):
                                                alt_var=pk.br["alt"] if mh else None, hypo_w=pk.br["w"] if mh else None)
             propl[:] = ro.conv_pose2point2br(mk(S["BR0"]), 0, pk.br["mu"], pk.br["sigma"], bel2, bell, r0["pose"], r0["point"], factor=r0["factor"],
                                              alt_var=r0["alt"] if mh else None, hypo_w=r0["w"] if mh else None)
-        bel2 = ro.product(mk(S["PROD2"]), 3, ptr2, rows2, prop2, bel2)
+        lcv = bandwidth == "lcv"
+        bel2 = ro.product(mk(S["PROD2"]), 3, ptr2, rows2, prop2, bel2, ro.kde_bandwidths(prop2, 0b100) if lcv else None)
         if Fb:
-            bell = ro.product(mk(S["PRODL"]), 2, ptrl, rowsl, propl, bell)
+            bell = ro.product(mk(S["PRODL"]), 2, ptrl, rowsl, propl, bell, ro.kde_bandwidths(propl, 0) if lcv else None)
     return bel2, bell

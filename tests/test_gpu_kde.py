@@ -1,0 +1,95 @@
+"""KDE bandwidth selection on the device (`rome_kde_bandwidth[_dev]`) -- the bandwidth the
+reference's `manikde!` picks for a belief by leave-one-out likelihood cross-validation.
+
+Pins: (1) the reference's own stored output -- the 361 x 3 bandwidths saved next to the particles of its solved Manhattan-500
+graph (tests/golden/manhattan500_reference_solve.npz, fixture README); (2) the CPU oracle on seeded beliefs of every
+supported size (same golden-section iterates: 1e-9 relative)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as ro
+
+pytestmark = pytest.mark.gpu
+R = None
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manhattan500_reference_solve.npz")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _pkg():
+    global R
+    import rome_jl_amd
+    R = rome_jl_amd
+    R.default_context()
+    yield
+
+
+def test_device_bandwidths_reproduce_the_reference_stored_bandwidths():
+    d = np.load(FIX)
+    bel = np.ascontiguousarray(d["particles"].astype(np.float64).transpose(0, 2, 1))   # [361, 3, 100]
+    h = R.kde_bandwidth(bel)                       # Pose2 default: heading circular, reference stopping rules
+    ratio = h / d["bandwidth"]
+    assert np.abs(ratio[:, :2] - 1).max() < 8e-3, np.abs(ratio[:, :2] - 1).max()    # the reference stops at 1 % itself
+    assert np.abs(ratio[:, 2] - 1).max() < 1e-4, np.abs(ratio[:, 2] - 1).max()
+    # and the oracle agrees with the device far inside those windows
+    ho = ro.kde_bandwidths(bel, 0b100, 1e-2, 1e-6)
+    # (same golden-section iterates; at the 1e-6 stopping rule of the heading the last comparisons are rounding-level ties
+    # -- the likelihood is flat to 1e-12 there -- so the two answers may differ by a final bracket width)
+    rel = np.abs(h / ho - 1)
+    assert rel[:, :2].max() < 1e-9 and rel[:, 2].max() < 3e-6 and np.median(rel) < 1e-12, rel.max(0)
+
+
+@pytest.mark.parametrize("N", [2, 3, 40, 64, 65, 100, 128, 200, 256, 400, 512])
+def test_device_matches_oracle_all_sizes(N):
+    rng = np.random.default_rng(1000 + N)
+    V = 24
+    bel = np.empty((V, 3, N))
+    bel[:, 0] = rng.normal(5.0, 0.3, (V, N))
+    bel[:, 1] = np.where(rng.random((V, N)) < 0.4, rng.normal(-2.0, 0.05, (V, N)), rng.normal(1.0, 0.4, (V, N)))   # bimodal
+    th = rng.normal(np.pi - 0.02, 0.1, (V, N))                                                                    # straddles ±pi
+    bel[:, 2] = np.arctan2(np.sin(th), np.cos(th))
+    for tols in ((0.0, 0.0), (1e-5, 1e-5)):
+        h = R.kde_bandwidth(bel, 0b100, *tols)
+        ho = ro.kde_bandwidths(bel, 0b100, tols[0] or 1e-2, tols[1] or 1e-6)
+        assert np.isfinite(h).all() and (h > 0).all()
+        # same iterates unless a golden-section comparison is a rounding-level tie (then both answers are inside tol)
+        rel = np.abs(h / ho - 1)
+        te, tc = tols[0] or 1e-2, tols[1] or 1e-6
+        assert np.median(rel) < 1e-10
+        # (stopping rules below ~1e-7 would compare likelihoods that differ by rounding noise only, on both sides)
+        assert rel[:, :2].max() < 3 * te and rel[:, 2].max() < 3 * tc, rel.max(0)
+        if te >= 1e-3:
+            assert (rel[:, :2] < 1e-9).mean() >= 0.95
+
+
+def test_point2_and_pose3_layouts_and_device_entry():
+    import torch
+    rng = np.random.default_rng(3)
+    b2 = rng.normal(size=(7, 2, 100)) * np.array([0.5, 2.0])[None, :, None]
+    assert np.abs(R.kde_bandwidth(b2) / ro.kde_bandwidths(b2, 0) - 1).max() < 1e-9
+    b6 = rng.normal(size=(5, 6, 100)) * np.array([1, 2, 3, 0.1, 0.2, 0.3])[None, :, None]
+    assert np.abs(R.kde_bandwidth(b6, 0) / ro.kde_bandwidths(b6, 0) - 1).max() < 1e-9
+    assert np.abs(R.kde_bandwidth(b6, 0b111000) / ro.kde_bandwidths(b6, 0b111000) - 1).max() < 3e-6
+    # device-resident entry on the graph store: every Pose2 belief of a small graph
+    fg = R.generateGraph_Hexagonal(N=100)
+    R.dead_reckon_init(fg, seed=4)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    bw = dg.kde_bandwidths(R.Pose2)
+    torch.cuda.synchronize()
+    ref = ro.kde_bandwidths(dg.bel[R.Pose2].cpu().numpy(), 0b100)
+    rel = np.abs(bw.cpu().numpy() / ref - 1)
+    assert rel[:, :2].max() < 1e-9 and rel[:, 2].max() < 3e-6
+
+
+def test_edge_cases_and_errors():
+    same = np.zeros((1, 1, 50))
+    h = R.kde_bandwidth(same, 0)
+    assert 0 < h[0, 0] < 1e-5 and abs(h[0, 0] / ro.kde_bandwidths(same, 0)[0, 0] - 1) < 1e-9
+    with pytest.raises(Exception):
+        R.kde_bandwidth(np.zeros((1, 1, 1)), 0)            # N < 2
+    with pytest.raises(Exception):
+        R.kde_bandwidth(np.zeros((1, 1, 513)), 0)          # N > ROME_MAX_PARTICLES
+    with pytest.raises(Exception):
+        R.kde_bandwidth(np.zeros((1, 7, 10)), 0)           # dim > 6
+    assert R.kde_bandwidth(np.zeros((0, 3, 10))).shape == (0, 3)

@@ -97,6 +97,40 @@ def test_solve_loop_vs_oracle_hexagonal():
     assert np.mean(np.abs(d) < 1e-8) > 0.95
 
 
+def test_solve_loop_with_lcv_bandwidths_vs_oracle_and_reference_windows():
+    """The same loop with the reference's bandwidth rule (`manikde!`: leave-one-out likelihood per proposal, rome_kde_bandwidth_dev)
+    feeding the product: device = oracle restatement to 1e-3 on the means, and the hexagon posterior still sits in the
+    acceptance boxes of test/testHexagonal2D_CliqByCliq.jl:37-79."""
+    N, S = 100, 6
+    fg = _hex_graph(N)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.solve(R.make_opts(N=N, solver=1, seed=77), n_sweeps=S, bandwidth="lcv")
+    m2, _ = dg.belief_stats(R.Pose2)
+    b2, bl = solve_ref(R, fg, S, N, seed=77, bandwidth="lcv")
+    for v in range(b2.shape[0]):
+        mo, _ = ro.belief_spread(b2[v])
+        dm = m2[v].cpu().numpy() - mo; dm[2] = np.arctan2(np.sin(dm[2]), np.cos(dm[2]))
+        assert np.abs(dm).max() < 1e-3, (v, dm)
+    got2 = dg.bel[R.Pose2].cpu().numpy()
+    d = got2 - b2; d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    assert np.mean(np.abs(d) < 1e-6) > 0.9
+    # differs from the Silverman run (the rule matters), and passes the reference's windows
+    dg2 = R.DeviceGraph(fg); dg2.upload_beliefs(fg)
+    dg2.solve(R.make_opts(N=N, solver=1, seed=77), n_sweeps=S)
+    assert np.abs(dg2.bel[R.Pose2].cpu().numpy() - got2).max() > 1e-3
+    dg.solve(R.make_opts(N=N, solver=1, seed=2026), n_sweeps=8, bandwidth="lcv")
+    b = dg.bel[R.Pose2].cpu().numpy(); l = dg.bel[R.Point2].cpu().numpy()
+    truth = [(0, 0, 0), (10, 0, np.pi / 3), (15, 8.66, 2 * np.pi / 3), (10, 17.32, np.pi), (0, 17.32, -2 * np.pi / 3),
+             (-5, 8.66, -np.pi / 3), (0, 0, 0)]
+    for k, (x, y, th) in enumerate(truth):
+        dth = np.arctan2(np.sin(b[k, 2] - th), np.cos(b[k, 2] - th))
+        inbox = (np.abs(b[k, 0] - x) < 3) & (np.abs(b[k, 1] - y) < 3) & (np.abs(dth) < 0.3)
+        assert inbox.sum() > 35, (k, inbox.sum(), b[k].mean(axis=1))
+    assert ((np.abs(l[0, 0] - 20) < 3) & (np.abs(l[0, 1]) < 3)).sum() > 35
+    with pytest.raises(ValueError):
+        dg.product_step(R.make_opts(N=N), 0, bandwidth="rot")
+
+
 def test_solve_hexagonal_statistical_windows():
     """x0≈(0,0,0), x1≈(10,0,π/3), x2≈(15,8.66,2π/3), x3≈(10,17.32,±π), x4≈(0,17.32,-2π/3),
     x5≈(-5,8.66,-π/3), x6≈(0,0,0), l1≈(20,0); boxes ±3 m / ±0.3 rad hold > 35 of 100 particles."""

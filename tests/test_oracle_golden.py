@@ -95,3 +95,34 @@ def test_priorpose2_residual():
 def test_priorpose3_residual_zero_at_self():
     c = np.array([[1.0, -2.0, 0.5, 0.3, -0.2, 0.9]])
     assert np.linalg.norm(ro.residual_priorpose3(c, c)) < 1e-14
+
+
+def test_kde_bandwidths_reproduce_the_reference_stored_bandwidths():
+    """The reference saved, with every solved belief of its Manhattan-500 graph, the bandwidth `manikde!` selected for it
+    (tests/golden/manhattan500_reference_solve.npz `bandwidth`, fixture README).  The leave-one-out likelihood rule of
+    ro_kde_bandwidths reproduces all 361 x 3 of them: x, y inside the reference's own 1 % golden-section stopping rule,
+    theta (Optim-tolerance search in the reference) to 1e-4 -- including the bimodal beliefs whose likelihood has two local
+    maxima a factor 2-3 apart (a Silverman-type rule is only right in the median: 0.18 ... 0.57 x std here)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manhattan500_reference_solve.npz"))
+    bel = np.ascontiguousarray(d["particles"].astype(np.float64).transpose(0, 2, 1))
+    h = ro.kde_bandwidths(bel, circular_mask=0b100, tol_euclid=1e-2, tol_circular=1e-6)
+    ratio = h / d["bandwidth"]
+    assert np.abs(ratio[:, :2] - 1).max() < 8e-3, np.abs(ratio[:, :2] - 1).max()     # measured 6.2e-3
+    assert np.median(np.abs(ratio[:, :2] - 1)) < 2e-3
+    assert np.abs(ratio[:, 2] - 1).max() < 1e-4, np.abs(ratio[:, 2] - 1).max()       # measured 4.4e-5 (float32 particles in the fixture)
+    # a tighter search moves x, y by less than the reference's own tolerance and keeps every basin
+    h2 = ro.kde_bandwidths(bel, circular_mask=0b100, tol_euclid=1e-6, tol_circular=1e-6)
+    assert np.abs(h2 / h - 1).max() < 8e-3
+
+
+def test_kde_bandwidth_edge_cases():
+    x = np.zeros((1, 1, 50))                                   # all particles identical: finite, tiny
+    assert 0 < ro.kde_bandwidths(x, 0)[0, 0] < 1e-5
+    rng = np.random.default_rng(5)
+    y = rng.normal(size=(1, 1, 400))                           # N(0,1): LCV close to the normal-reference rule
+    assert 0.5 < ro.kde_bandwidths(y, 0, 1e-4)[0, 0] / (1.06 * y.std() * 400 ** -0.2) < 1.6
+    th = np.pi + 0.05 * rng.normal(size=(1, 1, 100))           # a heading belief straddling ±pi
+    thw = np.arctan2(np.sin(th), np.cos(th))
+    hc = ro.kde_bandwidths(thw, 1)[0, 0]
+    assert abs(hc / ro.kde_bandwidths(th - np.pi, 0, 1e-6)[0, 0] - 1) < 1e-5     # same as the unwrapped Euclidean problem
