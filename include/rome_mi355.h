@@ -251,6 +251,12 @@ int rome_kde_bandwidth_dev(rome_ctx*, int32_t dim, int32_t V, int32_t N, const d
                            double tol_euclid, double tol_circular, double* bw);
 int rome_kde_bandwidth(rome_ctx*, int32_t dim, int32_t V, int32_t N, const double* bel, uint32_t circular_mask,
                        double tol_euclid, double tol_circular, double* bw);                                        /* host pointers */
+/* rome_kde_max*: max-density point estimate of a belief, coordinate by coordinate -- IIF's getKDEMax, the `max` entry of a variable's
+ *   PPE (and the heading of `suggested` in the stored graph): the Euclidean marginal KDE with bandwidth bw [V][dim] is evaluated on
+ *   grid_points (<= 0: the reference's 200; max 256) equispaced points over the particle range extended by 10 % on both sides; the first
+ *   maximiser is returned.  out [V][dim].  With the stored bandwidths this reproduces every `ppe.max` of examples/fg-after-solve.tar.gz. */
+int rome_kde_max_dev(rome_ctx*, int32_t dim, int32_t V, int32_t N, const double* bel, const double* bw, int32_t grid_points, double* out);
+int rome_kde_max(rome_ctx*, int32_t dim, int32_t V, int32_t N, const double* bel, const double* bw, int32_t grid_points, double* out); /* host */
 int rome_product_dev(rome_ctx*, const rome_opts*, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
                      const double* prop, const double* bel_in, double* bel_out);
 /* same with caller-supplied kernel bandwidths of the proposals, prop_bw [rows][dim] (e.g. rome_kde_bandwidth_dev run on `prop`,

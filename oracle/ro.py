@@ -254,6 +254,17 @@ def kde_bandwidths(bel, circular_mask, tol_euclid=1e-2, tol_circular=1e-6):
     return out
 
 
+def kde_max(bel, bw, G=200, extend=0.1):
+    """bel (V, dim, N), bw (V, dim) -> (V, dim) max-density coordinates (ro_kde_max)."""
+    B, pB = _d(bel); H, pH = _d(bw)
+    V, dim, N = B.shape
+    out = np.zeros((V, dim))
+    lib().ro_kde_max.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_double,
+                                 C.POINTER(C.c_double)]
+    assert lib().ro_kde_max(dim, V, N, pB, pH, int(G), float(extend), out.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    return out
+
+
 def num_threads():
     return lib().ro_num_threads()
 

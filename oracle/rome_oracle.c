@@ -1090,6 +1090,35 @@ int ro_kde_bandwidths(int dim, int V, int N, const double* bel, uint32_t circula
   return 0;
 }
 
+/* Max-density point estimate of a belief, coordinate by coordinate (⚠IIF getKDEMax, the `max` -- and, for headings, the
+ * `suggested` -- entry of a variable's PPE).  PINNED ON REFERENCE OUTPUT: with the stored bandwidths, the
+ * rule below reproduces the `ppe.max` of all 361 x 3 coordinates saved in the reference's solved Manhattan-500 graph
+ * (tests/golden/manhattan500_reference_solve.npz `ppe[:,1]`), which all lie exactly on this grid:
+ *   r = max_i x_i - min_i x_i;  X_g = (min - extend r) + g (1 + 2 extend) r / (G-1),  g = 0..G-1   (G = 200, extend = 0.1)
+ *   y_g = Σ_j exp(-½ ((X_g - x_j)/h)²)     -- the Euclidean marginal KDE, also for headings (the reference does not wrap here)
+ *   result = X_g at the FIRST g attaining max_g y_g.                                                                   */
+int ro_kde_max(int dim, int V, int N, const double* bel /*[V][dim][N]*/, const double* bw /*[V][dim]*/, int G, double extend,
+               double* out /*[V][dim]*/) {
+  if (dim < 1 || N < 1 || G < 2) return -1;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int t = 0; t < V * dim; ++t) {
+    const double* x = bel + (size_t)t * N;
+    double lo = x[0], hi = x[0];
+    for (int i = 1; i < N; ++i) { if (x[i] < lo) lo = x[i]; if (x[i] > hi) hi = x[i]; }
+    const double r = hi - lo; lo -= extend * r; hi += extend * r;
+    const double step = (hi - lo) / (G - 1), a = -0.5 / (bw[t] * bw[t]);
+    double best = -1.0, xb = lo;
+    for (int g = 0; g < G; ++g) {
+      const double X = g == G - 1 ? hi : lo + g * step;
+      double y = 0.0;
+      for (int j = 0; j < N; ++j) { const double d = X - x[j]; y += exp(a * d * d); }
+      if (y > best) { best = y; xb = X; }
+    }
+    out[t] = xb;
+  }
+  return 0;
+}
+
 /* ======================================================================== */
 /* Product of proposals (stand-in for ⚠AMP manifoldProduct)          */
 /* ======================================================================== */

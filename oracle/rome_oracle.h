@@ -113,6 +113,8 @@ int ro_sample_priorpose3(const ro_opts* o, int C, const int32_t* factor,
 double ro_kde_bandwidth_lcv(int N, const double* x, int circular, double tol, int* n_evals);
 int ro_kde_bandwidths(int dim, int V, int N, const double* bel /*[V][dim][N]*/, uint32_t circular_mask, double tol_euclid,
                       double tol_circular, double* bw /*[V][dim]*/);
+/* per-coordinate max-density point on the reference's 200-point grid (IIF getKDEMax; pinned on the stored ppe.max) */
+int ro_kde_max(int dim, int V, int N, const double* bel, const double* bw, int G, double extend, double* out);
 int ro_product(const ro_opts* o, int dim, int V, const int32_t* prop_ptr /*[V+1]*/, const int32_t* prop_rows,
                const double* prop /*[rows][dim][N]*/, const double* bel_in /*[V][dim][N]*/, double* bel_out);
 int ro_product_bw(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,

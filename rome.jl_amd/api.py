@@ -174,6 +174,31 @@ def kde_bandwidth(bel, circular_mask=None, tol_euclid=0.0, tol_circular=0.0, ctx
     return bw
 
 
+def kde_max(bel, bw=None, grid_points=0, ctx=None):
+    """bel (V, dim, N) host array -> (V, dim) max-density coordinates as IIF's getKDEMax computes them (PPE `max`), via rome_kde_max.
+    bw (V, dim): kernel bandwidths; None selects them with kde_bandwidth (what `manikde!` would have stored)."""
+    ctx = ctx or default_context()
+    bel = _d(bel)
+    V, d, N = bel.shape
+    bw = kde_bandwidth(bel, ctx=ctx) if bw is None else _d(bw, (V, d))
+    out = np.empty((V, d))
+    _lib.check(_lib.load().rome_kde_max(ctx.handle, d, V, N, _p(bel), _p(bw), int(grid_points), _p(out)), ctx.handle)
+    return out
+
+
+def calcPPE(bel, bw=None, ctx=None):
+    """Point estimates of V beliefs as the reference's calcVariablePPE stores them: dict(mean, max, suggested), each (V, dim).
+    `suggested` follows the solved graph the reference ships (examples/fg-after-solve.tar.gz): mean translation, max-density heading for
+    Pose2; the mean otherwise."""
+    bel = _d(bel)
+    mean, _ = belief_stats(bel, ctx)
+    mx = kde_max(bel, bw, ctx=ctx)
+    sug = mean.copy()
+    if bel.shape[1] == 3:
+        sug[:, 2] = mx[:, 2]
+    return {"mean": mean, "max": mx, "suggested": sug}
+
+
 # ------------------------------------------------------------------ helpers
 def cholesky_lower(cov):
     """n covariances (n,d,d) or one (d,d) -> packed lower factors (n, d(d+1)/2)."""

@@ -623,6 +623,32 @@ int rome_kde_bandwidth(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const dou
   ROME_HIP(c, hipStreamSynchronize(c->stream));
   return ROME_OK;
 }
+int rome_kde_max_dev(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, const double* bw, int32_t grid_points,
+                     double* out) {
+  int rc = check_kde(c, dim, V, N, bel, bw); if (rc) return rc;
+  const int G = grid_points > 0 ? grid_points : 200;
+  if (G < 2 || G > 256 || (V > 0 && !out)) return ROME_ERR_INVALID_ARG;
+  ROME_HIP(c, rome::launch_kde_max(dim, V, N, G, 0.1, bel, bw, out, c->stream));
+  return ROME_OK;
+}
+int rome_kde_max(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, const double* bw, int32_t grid_points, double* out) {
+  int rc = check_kde(c, dim, V, N, bel, bw); if (rc) return rc;
+  const int G = grid_points > 0 ? grid_points : 200;
+  if (G < 2 || G > 256 || (V > 0 && !out)) return ROME_ERR_INVALID_ARG;
+  if (V == 0) return ROME_OK;
+  ROME_HIP(c, hipSetDevice(c->device));
+  void *d_b, *d_h, *d_o;
+  const size_t nb = 8ull * V * dim * N, nh = 8ull * V * dim;
+  if ((rc = ensure(c, 0, nb, &d_b))) return rc;
+  if ((rc = ensure(c, 1, nh, &d_h))) return rc;
+  if ((rc = ensure(c, 2, nh, &d_o))) return rc;
+  ROME_HIP(c, hipMemcpyAsync(d_b, bel, nb, hipMemcpyHostToDevice, c->stream));
+  ROME_HIP(c, hipMemcpyAsync(d_h, bw, nh, hipMemcpyHostToDevice, c->stream));
+  ROME_HIP(c, rome::launch_kde_max(dim, V, N, G, 0.1, (const double*)d_b, (const double*)d_h, (double*)d_o, c->stream));
+  ROME_HIP(c, hipMemcpyAsync(out, d_o, nh, hipMemcpyDeviceToHost, c->stream));
+  ROME_HIP(c, hipStreamSynchronize(c->stream));
+  return ROME_OK;
+}
 int rome_product_bw_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
                         const double* prop, const double* prop_bw, const double* bel_in, double* bel_out) {
   int rc = check_opts(o); if (rc) return rc;

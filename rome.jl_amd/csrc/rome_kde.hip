@@ -116,6 +116,58 @@ __global__ void __launch_bounds__(64 * kKdeWaves) k_kde_bandwidth(int T, int dim
   if (lane == 0) { bw[t] = h; if (evals) evals[t] = ne; }
 }
 
+// ---- max-density point of a belief per coordinate (⚠IIF getKDEMax: PPE `max`, `suggested` heading) --------------------------
+// Rule and pin: oracle/rome_oracle.c ro_kde_max (reproduces the 1083 stored ppe.max values of the reference's solved graph).  One wave
+// per (belief, coordinate) task; lane l owns grid points l, l+64, l+128, l+192 (G <= 256); particles staged in the wave's LDS region.
+constexpr int kKdeMaxN = 512;   // = ROME_MAX_PARTICLES (include/rome_mi355.h)
+constexpr int kKdeGridSlots = 4;
+
+__global__ void __launch_bounds__(64 * kKdeWaves) k_kde_max(int T, int N, int G, double extend, const double* __restrict__ bel,
+                                                            const double* __restrict__ bw, double* __restrict__ out) {
+  __shared__ double pts[kKdeWaves][kKdeMaxN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = blockIdx.x * kKdeWaves + wave;
+  if (t >= T) return;
+  const double* __restrict__ P = bel + (size_t)t * N;
+  double lo = __builtin_inf(), nhi = __builtin_inf();
+  for (int i = lane; i < N; i += 64) { const double x = P[i]; pts[wave][i] = x; lo = fmin(lo, x); nhi = fmin(nhi, -x); }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  lo = wave_min(lo);
+  double hi = -wave_min(nhi);
+  const double r = hi - lo; lo -= extend * r; hi += extend * r;
+  const double step = (hi - lo) / (double)(G - 1), h = bw[t], a = -0.5 / (h * h);
+  double X[kKdeGridSlots], y[kKdeGridSlots];
+#pragma unroll
+  for (int s = 0; s < kKdeGridSlots; ++s) {
+    const int g = lane + 64 * s;
+    X[s] = g == G - 1 ? hi : lo + (double)g * step;
+    y[s] = 0.0;
+  }
+  for (int j = 0; j < N; ++j) {
+    const double xj = pts[wave][j];
+#pragma unroll
+    for (int s = 0; s < kKdeGridSlots; ++s) { const double d = X[s] - xj; y[s] += fast_exp_neg(a * d * d); }
+  }
+  // first grid index attaining the maximum: per lane (ascending g), then across lanes (ties -> smaller g)
+  double best = -1.0; int gb = 0;
+#pragma unroll
+  for (int s = 0; s < kKdeGridSlots; ++s) { const int g = lane + 64 * s; if (g < G && y[s] > best) { best = y[s]; gb = g; } }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const double ob = __shfl_xor(best, m, 64); const int og = __shfl_xor(gb, m, 64);
+    if (ob > best || (ob == best && og < gb)) { best = ob; gb = og; }
+  }
+  if (lane == 0) out[t] = gb == G - 1 ? hi : lo + (double)gb * step;
+}
+
+hipError_t launch_kde_max(int dim, int V, int N, int G, double extend, const double* bel, const double* bw, double* out, hipStream_t s) {
+  const int T = V * dim;
+  if (T <= 0) return hipSuccess;
+  if (N < 1 || N > kKdeMaxN || G < 2 || G > 64 * kKdeGridSlots) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_kde_max, dim3((T + kKdeWaves - 1) / kKdeWaves), dim3(64 * kKdeWaves), 0, s, T, N, G, extend, bel, bw, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_kde_bandwidth(int dim, int V, int N, const double* bel, uint32_t circ_mask, double tol_e, double tol_c,
                                 double* bw, int32_t* evals, hipStream_t s) {
   const int T = V * dim;

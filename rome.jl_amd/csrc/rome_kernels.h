@@ -61,6 +61,7 @@ hipError_t launch_linearize(int kind, int F, const double* mu, const double* W, 
 hipError_t launch_belief_stats(int dim, int V, int N, const double* bel, double* mean, double* sdev, hipStream_t s);
 hipError_t launch_kde_bandwidth(int dim, int V, int N, const double* bel, uint32_t circ_mask, double tol_e, double tol_c,
                                 double* bw, int32_t* evals, hipStream_t s);
+hipError_t launch_kde_max(int dim, int V, int N, int G, double extend, const double* bel, const double* bw, double* out, hipStream_t s);
 hipError_t launch_product(int dim, int V, int N, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
                           const double* prop_bw, const double* bel_in, double* bel_out, double c_n, uint64_t seed,
                           uint64_t stream_offset, hipStream_t s);

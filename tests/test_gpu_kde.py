@@ -93,3 +93,46 @@ def test_edge_cases_and_errors():
     with pytest.raises(Exception):
         R.kde_bandwidth(np.zeros((1, 7, 10)), 0)           # dim > 6
     assert R.kde_bandwidth(np.zeros((0, 3, 10))).shape == (0, 3)
+
+
+def test_kde_max_reproduces_the_reference_stored_ppe_max():
+    """IIF getKDEMax on the device: with the bandwidths the reference stored, the per-coordinate max-density point of all 361
+    beliefs equals the stored `ppe.max` (which lies exactly on the 200-point grid over the 10 %-extended particle range); with the
+    device's own bandwidths the same grid point is found for > 98 % of the coordinates, a neighbouring one otherwise.  The stored
+    `suggested` estimate is (mean x, mean y, max-density heading)."""
+    d = np.load(FIX)
+    bel = np.ascontiguousarray(d["particles"].astype(np.float64).transpose(0, 2, 1))
+    ppe_sug, ppe_max = d["ppe"][:, 0], d["ppe"][:, 1]
+    rng = bel.max(2) - bel.min(2)
+    m = R.kde_max(bel, d["bandwidth"])
+    assert np.abs(m - ppe_max).max() < 5e-6, np.abs(m - ppe_max).max()            # float32 particles in the fixture: 8e-7 measured
+    assert np.abs(m - ro.kde_max(bel, d["bandwidth"])).max() < 1e-12
+    own = R.calcPPE(bel)                                                           # bandwidths selected on the device
+    steps = np.abs(own["max"] - ppe_max) / (1.2 * rng / 199)
+    assert (steps < 0.01).mean() > 0.98 and steps.max() < 1.01, ((steps < 0.01).mean(), steps.max())
+    assert np.abs(own["suggested"][:, :2] - ppe_sug[:, :2]).max() < 2e-6
+    hs = np.abs(own["suggested"][:, 2] - ppe_sug[:, 2]) / (1.2 * rng[:, 2] / 199)
+    assert (hs < 0.01).mean() > 0.98 and hs.max() < 1.01
+
+
+@pytest.mark.parametrize("N,G", [(1, 200), (2, 200), (100, 200), (100, 2), (130, 256), (512, 64)])
+def test_kde_max_matches_oracle(N, G):
+    rng = np.random.default_rng(77 + N + G)
+    V = 16
+    bel = rng.normal(size=(V, 3, N)) * np.array([1.0, 0.1, 3.0])[None, :, None] + np.array([5.0, -2.0, 0.0])[None, :, None]
+    bw = rng.uniform(0.05, 0.5, (V, 3)) * np.array([1.0, 0.1, 3.0])
+    if N < 2:
+        with pytest.raises(Exception):
+            R.kde_max(bel, bw, G)
+        return
+    m = R.kde_max(bel, bw, G)
+    mo = ro.kde_max(bel, bw, G)
+    step = 1.2 * (bel.max(2) - bel.min(2)) / (G - 1)
+    same = np.abs(m - mo) < 1e-12 * (1 + np.abs(mo))
+    if N == 2:   # two particles: the density is mirror-symmetric, its two maxima tie exactly; either one is the answer
+        mirror = np.abs(m + mo - bel.max(2) - bel.min(2)) < 1e-9
+        assert (same | mirror).all()
+        return
+    assert same.mean() >= 0.95 and (np.abs(m - mo) <= 1.0001 * step).all()      # libm vs device exp can only flip an exact near-tie
+    with pytest.raises(Exception):
+        R.kde_max(bel, bw, 257)

@@ -126,3 +126,15 @@ def test_kde_bandwidth_edge_cases():
     thw = np.arctan2(np.sin(th), np.cos(th))
     hc = ro.kde_bandwidths(thw, 1)[0, 0]
     assert abs(hc / ro.kde_bandwidths(th - np.pi, 0, 1e-6)[0, 0] - 1) < 1e-5     # same as the unwrapped Euclidean problem
+
+
+def test_kde_max_reproduces_the_reference_stored_ppe_max():
+    """IIF getKDEMax restated (ro_kde_max): with the stored bandwidths, every `ppe.max` coordinate of the reference's solved graph."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manhattan500_reference_solve.npz"))
+    bel = np.ascontiguousarray(d["particles"].astype(np.float64).transpose(0, 2, 1))
+    m = ro.kde_max(bel, d["bandwidth"])
+    assert np.abs(m - d["ppe"][:, 1]).max() < 5e-6
+    lo, r = bel.min(2), bel.max(2) - bel.min(2)
+    idx = (d["ppe"][:, 1] - (lo - 0.1 * r)) / (1.2 * r) * 199          # the stored values sit on the 200-point grid
+    assert np.abs(idx - np.round(idx)).max() < 0.02
