@@ -213,3 +213,70 @@ def test_accumulate_factor_means():
     fg.addVariable("x3", R.Pose2); fg.addFactor(["x2", "x3"], R.Pose2Pose2(R.MvNormal([10, 0, np.pi / 3], 0.01 * np.eye(3))))
     v = R.accumulateFactorMeans(fg, ["x2f1", "x2x3f1"])
     assert np.allclose(v[:2], [10, 17.32], atol=1e-2) and abs(abs(v[2]) - np.pi) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------- saveDFG / loadDFG
+def test_loaddfg_reads_the_reference_test_graph_and_exports_it():
+    """test/testG2oExportSE3.jl:21-31: loadDFG! of test/testdata/g2otest.tar.gz (byte copy in tests/golden), then exportG2o with
+    varIntLabel; the graph is the one the commented recipe of that test builds (:9-15)."""
+    import os
+    import tempfile
+    fg = R.loadDFG(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g2otest.tar.gz"))
+    assert fg.ls() == ["x0", "x1", "x2", "x3"] and all(fg.variables[l] is R.Pose3 for l in fg.ls())
+    assert fg.N == 100 and fg.solverParams["inflateCycles"] == 3 and fg.solverParams["inflation"] == 5.0
+    kinds = sorted((type(f).__name__, tuple(ls)) for _, ls, f in fg.factors)
+    assert kinds == [("Pose3Pose3", ("x0", "x1")), ("Pose3Pose3", ("x1", "x2")), ("Pose3Pose3", ("x2", "x3")), ("PriorPose3", ("x0",))]
+    for _, ls, f in fg.factors:
+        assert np.allclose(f.Z.cov, 0.1 * np.eye(6))
+        assert np.allclose(f.Z.mu, [1, 0, 0, 0, 0, 0] if len(ls) == 2 else np.zeros(6))
+    assert not any(fg.isInitialized(l) for l in fg.ls())          # saved with graphinit=false
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "test.g2o")
+        R.exportG2o(fg, filename=out, varIntLabel={l: i for i, l in enumerate(fg.ls())},
+                    estimates={l: np.zeros(6) for l in fg.ls()})
+        lines = open(out).read().splitlines()
+    assert [l.split()[0] for l in lines] == ["VERTEX_SE3:QUAT"] * 4 + ["EDGE_SE3:QUAT"] * 3
+    e = lines[4].split()
+    assert e[1:3] == ["0", "1"] and [float(x) for x in e[3:10]] == [1, 0, 0, 0, 0, 0, 1] and float(e[10]) == pytest.approx(10.0)
+
+
+def test_savedfg_loaddfg_round_trip_all_factor_types():
+    import os
+    import tempfile
+    fg = R.generateGraph_Hexagonal(N=50)
+    fg.addVariable("l2", R.Point2)
+    fg.addFactor(["x2", "l1", "l2"], R.Pose2Point2BearingRange(R.Normal(0.1, 0.05), R.Normal(12.0, 0.4)), multihypo=[1.0, 0.3, 0.7])
+    fg.addFactor(["l2"], R.PriorPoint2(R.MvNormal([1.0, 2.0], np.array([[0.5, 0.1], [0.1, 0.3]]))))
+    fg.addFactor(["l1", "l2"], R.Point2Point2(R.MvNormal([3.0, -1.0], 0.2 * np.eye(2))))
+    fg.addVariable("p0", R.Pose3); fg.addVariable("p1", R.Pose3)
+    fg.addFactor(["p0"], R.PriorPose3(R.MvNormal(np.zeros(6), 0.01 * np.eye(6))))
+    S = np.diag([0.1, 0.2, 0.3, 0.01, 0.02, 0.03]); S[0, 4] = S[4, 0] = 0.005
+    fg.addFactor(["p0", "p1"], R.Pose3Pose3(R.MvNormal([1, 2, 3, 0.1, 0.2, 0.3], S)))
+    R.dead_reckon_init(fg, seed=2)
+    fg.bws = {"x1": np.array([0.1, 0.2, 0.03])}
+    fg.ppes = {"x1": {"default": {"suggested": np.array([1.0, 2.0, 0.5]), "max": np.array([1.1, 2.1, 0.5]), "mean": np.array([1.0, 2.0, 0.4])}}}
+    with tempfile.TemporaryDirectory() as td:
+        path = R.saveDFG(fg, os.path.join(td, "fg.tar.gz"))
+        g = R.loadDFG(path)
+    assert g.ls() == fg.ls() and g.N == 50
+    assert [(a, b, type(c).__name__) for a, b, c in g.factors] == [(a, b, type(c).__name__) for a, b, c in fg.factors]
+    for (_, _, a), (_, _, b) in zip(fg.factors, g.factors):
+        for fld in ("Z", "bearing", "range"):
+            if hasattr(a, fld):
+                x, y = getattr(a, fld), getattr(b, fld)
+                assert type(x) is type(y)
+                if isinstance(x, R.MvNormal):
+                    assert np.array_equal(x.mu, y.mu) and np.array_equal(x.cov, y.cov)       # column-major cov round trip (asymmetric index check)
+                else:
+                    assert (x.mu, x.sigma) == (y.mu, y.sigma)
+    assert g.multihypo == fg.multihypo
+    for l in fg.ls():
+        assert g.isInitialized(l) == fg.isInitialized(l)
+        if fg.isInitialized(l):
+            assert np.array_equal(g.getVal(l), fg.getVal(l))
+    assert np.array_equal(g.bws["x1"], fg.bws["x1"]) and np.array_equal(g.ppes["x1"]["default"]["max"], [1.1, 2.1, 0.5])
+    with pytest.raises(ValueError):
+        R.unpackFactor("Pose2Pose2Bogus", {"Z": {}})
+    assert isinstance(R.unpackFactor("PackedPose2Pose2", {"Z": R.packBelief(R.MvNormal(np.zeros(3), np.eye(3)))}), R.Pose2Pose2)
+    z = R.unpackBelief({"_type": "IncrementalInference.PackedZeroMeanFullNormal", "cov": [1.0, 0.5, 0.5, 2.0]})
+    assert np.array_equal(z.mu, [0, 0]) and np.array_equal(z.cov, [[1, 0.5], [0.5, 2]])
