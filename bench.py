@@ -236,6 +236,14 @@ def main():
         torch.cuda.synchronize()
         out["solve_loop"] = {"ms_per_iteration": (time.perf_counter() - a) * 1e3 / 50,
                              "what": "conv sweep + proposal product of all %d variables (stand-in for the clique Gibbs of solveTree!, no Bayes tree)" % len(pk.labels[R.Pose2])}
+        # the same iteration with the reference's bandwidth rule: leave-one-out likelihood bandwidths of every proposal (manikde!) first
+        dg.conv_step(o3, 0); dg.product_step(o3, 0, "lcv"); torch.cuda.synchronize()
+        a = time.perf_counter()
+        for s in range(5):
+            dg.conv_step(o3, s); dg.product_step(o3, s, "lcv")
+        torch.cuda.synchronize()
+        out["solve_loop"]["ms_per_iteration_lcv_bandwidths"] = (time.perf_counter() - a) * 1e3 / 5
+        dg.bel[R.Pose2].copy_(saved)
         # ... and the whole pipeline a user runs on this graph: parametric solve (batched Jacobian kernel + sparse LM on the host)
         # followed by 10 non-parametric iterations started from it
         a = time.perf_counter(); xp = R.solveGraphParametric(fg); t_par = time.perf_counter() - a

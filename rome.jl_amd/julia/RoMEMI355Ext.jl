@@ -178,6 +178,26 @@ function linearize(kind::Integer, μ::Matrix{Float64}, W::Array{Float64,3}, xa::
   r, Ja, Jb                                       # Ja[:, :, f] is the TRANSPOSE of factor f's row-major dr x da block
 end
 
+# ---- manikde! bandwidths and getKDEMax on the device (rome_kde_bandwidth / rome_kde_max) -------------------------
+# X: N x d coordinate matrix of ONE belief (column k = coordinate k: exactly the [dim][N] block the C side takes).
+function kde_bandwidths(X::Matrix{Float64}; circular_mask::Integer = size(X, 2) == 3 ? 0b100 : 0)
+  N, d = size(X)
+  bw = Vector{Float64}(undef, d)
+  check(ccall((:rome_kde_bandwidth, LIB), Cint,
+    (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Float64}, UInt32, Float64, Float64, Ptr{Float64}),
+    ctx().h, d, 1, N, X, UInt32(circular_mask), 0.0, 0.0, bw))
+  bw
+end
+
+function kde_max(X::Matrix{Float64}, bw::Vector{Float64} = kde_bandwidths(X))
+  N, d = size(X)
+  m = Vector{Float64}(undef, d)
+  check(ccall((:rome_kde_max, LIB), Cint,
+    (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Float64}),
+    ctx().h, d, 1, N, X, bw, 0, m))
+  m
+end
+
 # ---- residual KATs through the library (mirrors calcFactorResidualTemporary) ---------------------------
 function residual_pose2pose2(z::AbstractMatrix, p::AbstractMatrix, q::AbstractMatrix)   # 3 x n each
   r = similar(z)

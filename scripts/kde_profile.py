@@ -27,3 +27,12 @@ for V, what in ((3500, "beliefs"), (10907, "proposals")):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / 5
         print("%s V=%d tol=%s: %.3f ms per call (%.1f ns per (belief, coordinate))" % (what, V, tols, dt * 1e3, dt * 1e9 / (3 * V)))
+    mx = torch.empty((V, 3), dtype=torch.float64, device="cuda")
+    def callm():
+        _lib.check(lib.rome_kde_max_dev(ctx.handle, 3, V, N, d.data_ptr(), bw.data_ptr(), 0, mx.data_ptr()), ctx.handle)
+    callm(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(5):
+        callm()
+    torch.cuda.synchronize()
+    print("%s V=%d getKDEMax: %.3f ms per call" % (what, V, (time.perf_counter() - t) / 5 * 1e3))
