@@ -15,7 +15,7 @@ from .api import (linearize, belief_stats, kde_bandwidth, kde_max, calcPPE, poin
                   residual_pose2pose2, residual_priorpose2, residual_pose2point2br, residual_pose2point2br_pt,
                   residual_pose3pose3, residual_pose3pose3_pt, residual_priorpose3,
                   conv_pose2pose2, conv_pose2point2br, conv_pose3pose3, sample_priorpose2, sample_priorpose3)
-from .graph import (FactorGraph, initfg, importG2o, parseG2oInstruction, loadG2o, synth_manhattan,
+from .graph import (FactorGraph, initfg, fifoFreeze, isMarginalized, importG2o, parseG2oInstruction, loadG2o, synth_manhattan,
                     synth_manhattan_edges, synth_pose2_tables, synth_helix3d, synth_mit_br, add_synthetic_landmarks, dead_reckon_init_pose3, generateGraph_Circle, generateGraph_Hexagonal,
                     PackedGraph, dead_reckon_init)
 from .canonical import (generateGraph_ZeroPose, buildGraphChain, generateGraph_TwoPoseOdo, calcHelix_T, generateGraph_Helix2D,

@@ -81,15 +81,42 @@ class DeviceGraph:
         tgt2 = [self.tab["p2p2"]["target"].cpu().numpy()] if C2 else []
         if Fb:
             tgt2.append(pk.br["pose"])
+        self._prop_targets = {Pose2: np.concatenate(tgt2) if tgt2 else np.zeros(0, np.int32),
+                              Point2: pk.br["rows0"]["point"] if Fb else np.zeros(0, np.int32)}
+        self.frozen = set()
+        self._build_csr()
+
+    def _build_csr(self):
+        """variable -> proposal rows; frozen (marginalized) variables get no rows, so the product keeps their belief."""
+        pk = self.packed
+        t = lambda a, dt: self.torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=self.device)
+        i32 = self.torch.int32
         self.csr = {}
-        for vt, tg, nv in ((Pose2, np.concatenate(tgt2) if tgt2 else np.zeros(0, np.int32), len(pk.labels[Pose2])),
-                           (Point2, pk.br["rows0"]["point"] if Fb else np.zeros(0, np.int32), len(pk.labels[Point2]))):
-            order = np.argsort(tg, kind="stable").astype(np.int32)
+        for vt in (Pose2, Point2):
+            tg = np.asarray(self._prop_targets[vt], dtype=np.int64)
+            nv = len(pk.labels[vt])
+            live = np.ones(nv + 1, dtype=bool)
+            if self.frozen:
+                for i, l in enumerate(pk.labels[vt]):
+                    if l in self.frozen:
+                        live[i] = False
+            rows = np.nonzero(live[tg])[0] if len(tg) else np.zeros(0, np.int64)
+            order = rows[np.argsort(tg[rows], kind="stable")].astype(np.int32)
             ptr = np.zeros(nv + 1, dtype=np.int32)
-            np.add.at(ptr, np.asarray(tg, dtype=np.int64) + 1, 1)
+            np.add.at(ptr, tg[rows] + 1, 1)
             ptr = np.cumsum(ptr).astype(np.int32)
             self.csr[vt] = dict(ptr=t(ptr, i32), rows=t(order if len(order) else np.zeros(1, np.int32), i32),
                                 ptr_h=ptr, rows_h=order)
+
+    def set_frozen(self, labels):
+        """Fixed-lag operation (IIF `fifoFreeze!` / isMarginalized): the beliefs of `labels` are no longer updated by product_step /
+        solve; they still serve as the fixed side of every convolution they take part in (test/testFixedLagFG.jl:86-121)."""
+        labels = set(labels)
+        known = set(self.packed.labels[Pose2]) | set(self.packed.labels[Point2])
+        if not labels <= known:
+            raise KeyError("set_frozen: unknown variables %s" % sorted(labels - known))
+        self.frozen = labels
+        self._build_csr()
 
     # ---- belief store ----
     def upload_beliefs(self, fg):

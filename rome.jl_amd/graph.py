@@ -88,6 +88,23 @@ def initfg(N=100):
     return FactorGraph(N)
 
 
+def fifoFreeze(fg, qfl=None):
+    """IIF `fifoFreeze!(fg)` with `getSolverParams(fg).qfl` (test/testFixedLagFG.jl:33-35,89): all but the newest `qfl` variables, in the
+    order they were added, become marginalized; returns their labels (and records them in fg.marginalized)."""
+    if qfl is None:
+        qfl = getattr(fg, "qfl", None)
+    if qfl is None or qfl < 0:
+        raise ValueError("fifoFreeze needs the fixed-lag window length qfl")
+    order = fg.ls()
+    frozen = order[:max(len(order) - int(qfl), 0)]
+    fg.marginalized = set(getattr(fg, "marginalized", set())) | set(frozen)
+    return sorted(fg.marginalized, key=order.index)
+
+
+def isMarginalized(fg, label):
+    return label in getattr(fg, "marginalized", set())
+
+
 # ------------------------------------------------------------------------------------------ g2o
 def importG2o(path):
     """Every line split on blanks (src/services/g2oParser.jl:39-49)."""

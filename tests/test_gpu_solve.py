@@ -306,3 +306,45 @@ def test_double_hexagon_two_landmarks_windows():
                 assert 80 < ((w[d][0] < p[d]) & (p[d] < w[d][1])).sum(), (lb, d, p[d].mean())
     l1 = l[dg.packed.labels[R.Point2].index("l1")]
     assert 80 < ((17 < l1[0]) & (l1[0] < 23)).sum() and 80 < ((-5 < l1[1]) & (l1[1] < 5)).sum()
+
+
+def test_fixed_lag_freeze_keeps_old_poses_and_updates_the_window():
+    """test/testFixedLagFG.jl: hexagon + landmark solved, six more poses driven, fifoFreeze! with qfl = 6 -> x5 is marginalized and
+    its particles are EXACTLY unchanged by the next solve, x7 is recalculated (:86-121)."""
+    N = 100
+    fg = R.initfg(N)
+    fg.addVariable("x0", R.Pose2)
+    fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.zeros(3), 0.01 * np.eye(3))))
+    odo = lambda: R.Pose2Pose2(R.MvNormal([10.0, 0, np.pi / 3], np.diag([0.1, 0.1, 0.1]) ** 2))
+    for i in range(6):
+        fg.addVariable("x%d" % (i + 1), R.Pose2)
+        fg.addFactor(["x%d" % i, "x%d" % (i + 1)], odo())
+    fg.addVariable("l1", R.Point2)
+    fg.addFactor(["x0", "l1"], R.Pose2Point2BearingRange(R.Normal(0, 0.1), R.Normal(20.0, 1.0)))
+    R.dead_reckon_init(fg, seed=8)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.solve(R.make_opts(N=N, solver=1, seed=11), n_sweeps=8)
+    dg.download_beliefs(fg)
+    # drive on: loop-closing sighting of l1 from x6, six more poses
+    fg.addFactor(["x6", "l1"], R.Pose2Point2BearingRange(R.Normal(0, 0.1), R.Normal(20.0, 1.0)))
+    for i in range(6, 12):
+        fg.addVariable("x%d" % (i + 1), R.Pose2)
+        fg.addFactor(["x%d" % i, "x%d" % (i + 1)], odo())
+        fg.initVariable("x%d" % (i + 1), R.approxConv(fg, fg.factors[-1][0], "x%d" % (i + 1), seed=100 + i))
+    frozen = R.fifoFreeze(fg, qfl=6)
+    assert "x5" in frozen and "l1" in frozen and "x7" not in frozen and len(frozen) == len(fg.ls()) - 6
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.set_frozen(frozen)
+    before = {l: fg.getVal(l).copy() for l in ("x5", "x7", "l1")}
+    dg.solve(R.make_opts(N=N, solver=1, seed=12), n_sweeps=6)
+    dg.download_beliefs(fg)
+    assert np.array_equal(fg.getVal("x5"), before["x5"]) and np.array_equal(fg.getVal("l1"), before["l1"])     # frozen: bit-identical
+    assert not np.isclose(fg.getVal("x7")[:2], before["x7"][:2]).any()                                        # recalculated
+    # the window is still consistent with the frozen part: x12 sits one hexagon lap further on, i.e. near x6 ≈ (0, 0)
+    m, _ = R.belief_stats(np.stack([fg.getVal("x12")]))
+    assert np.abs(m[0, :2]).max() < 6.0
+    with pytest.raises(KeyError):
+        dg.set_frozen(["nope"])
+    dg.set_frozen([])                                            # thaw: everything moves again
+    dg.solve(R.make_opts(N=N, solver=1, seed=13), n_sweeps=1)
+    assert not np.array_equal(dg.bel[R.Pose2][5].cpu().numpy(), before["x5"])
