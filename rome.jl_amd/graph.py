@@ -63,6 +63,14 @@ class FactorGraph:
             self.multihypo[flabel] = (w[1], w[2])
         return flabel
 
+    def deleteFactor(self, flabel):
+        """DFG `deleteFactor!(fg, label)`"""
+        k = [i for i, f in enumerate(self.factors) if f[0] == flabel]
+        if not k:
+            raise KeyError(flabel)
+        self.factors.pop(k[0])
+        self.multihypo.pop(flabel, None)
+
     def getFactor(self, flabel):
         for f in self.factors:
             if f[0] == flabel:

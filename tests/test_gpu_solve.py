@@ -348,3 +348,27 @@ def test_fixed_lag_freeze_keeps_old_poses_and_updates_the_window():
     dg.set_frozen([])                                            # thaw: everything moves again
     dg.solve(R.make_opts(N=N, solver=1, seed=13), n_sweeps=1)
     assert not np.array_equal(dg.bel[R.Pose2][5].cpu().numpy(), before["x5"])
+
+
+def test_moved_prior_pulls_the_whole_circle_iif913():
+    """test/testTreeInitCommonMsg_IIF913.jl: generateGraph_Circle(4) initialised around the origin, then the prior is replaced by one at
+    (5, 0, 0) -- every initial belief is wrong; after the solve the mean of x4 (one full lap, back at the start) has x > 2, |y| < 1.5."""
+    N = 100
+    fg = R.generateGraph_Circle(4, N=N)
+    R.dead_reckon_init(fg, seed=3)
+    assert abs(fg.getVal("x4")[0].mean()) < 1.0
+    fg.deleteFactor("x0f1")
+    with pytest.raises(KeyError):
+        fg.deleteFactor("x0f1")
+    fg.addFactor(["x0"], R.PriorPose2(R.MvNormal([5.0, 0.0, 0.0], 0.01 * np.eye(3))))
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.solve(R.make_opts(N=N, solver=1, seed=913), n_sweeps=20)
+    m, _ = dg.belief_stats(R.Pose2)
+    m = m.cpu().numpy()
+    x4 = m[fg_index(fg, "x4")]
+    assert 2.0 < x4[0] and -1.5 < x4[1] < 1.5, x4
+    assert abs(m[fg_index(fg, "x0")][0] - 5.0) < 0.5
+
+
+def fg_index(fg, label):
+    return [l for l in fg.ls() if fg.variables[l] is fg.variables[label]].index(label)
