@@ -195,6 +195,15 @@ def main():
             # context for the low HBM fraction: the kernel is VALU-issue bound (SQ counters, separate rocprofv3 pass)
             out["roofline"]["valu_busy_frac_pmc"] = sj["derived"]["valu_busy_fraction"]
             out["roofline"]["valu_instructions_per_wave_pmc"] = sj["derived"]["valu_instructions_per_wave"]
+            # secondary bound: VALU issue.  Busy quad-cycles of the PMC pass (a property of the instruction stream, same
+            # kernel, same table) against the SIMD cycles available in THIS run's measured launch period at the measured 2.45 GHz clock (>= the 2.4 GHz of the guide).
+            if sj.get("SQ_WAVES") == tb["C"] and world == 1:
+                busy_cycles = 4.0 * sj["SQ_ACTIVE_INST_VALU_quadcycles"]
+                clk = max(2.4e9, 1e9 * float(sj["derived"].get("clock_GHz", 2.4)))   # guide: 2.4 GHz max; the PMC pass measured 2.45
+                avail = 256 * 4 * clk * kern_ms * 1e-3
+                out["roofline"]["secondary"] = {"bound": "valu_issue", "achieved": busy_cycles / (kern_ms * 1e-3) / 1e12,
+                                                "peak": 256 * 4 * clk / 1e12, "unit": "T SIMD-cycles/s", "frac": busy_cycles / avail,
+                                                "source": "SQ_ACTIVE_INST_VALU (profiles/sq_counters.json) / (256 CUs x 4 SIMDs x %.2f GHz x kernel time of this run)" % (clk / 1e9)}
         except Exception:
             pass
 
