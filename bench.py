@@ -116,8 +116,16 @@ def main():
         f_last = int(np.nonzero((vf == pk.index["x%d" % (args.poses - 2)]) & (vt == pk.index[last]))[0][0])
         conv_first = 2 * f_first + 1                             # odometry x0->x1, dir 1 -> target x0
         conv_last = 2 * f_last + 0                               # odometry x_{P-2}->x_{P-1}, dir 0 -> target x_{P-1}
+        depth = int(os.environ.get("ROME_PIPE_DEPTH", "2"))
+        # separator exchange through RCCL directly (one communicator per pipeline slot, enqueued on the sweep's own stream);
+        # torch.distributed's collective is the fallback if the direct binding cannot be set up on every rank
+        comms = None
+        if os.environ.get("ROME_BENCH_TORCH_COLLECTIVE") != "1":
+            from rome_jl_amd.rccl import create_comms
+            comms = create_comms(torch, dist, world, rank, dev, depth)
         pipe = PipelinedSegmentSweep(dg, opts, dist, world, rank, [conv_first, conv_last],
-                                     pk.index["ghost_prev"], pk.index["ghost_next"], always_collective=(world == 1))
+                                     pk.index["ghost_prev"], pk.index["ghost_next"], always_collective=(world == 1),
+                                     depth=depth, rccl_comms=comms)
         sweep = pipe.step
 
     def barrier():
@@ -171,7 +179,7 @@ def main():
         "config": {"workload": workload, "poses_per_gpu": len(pk.labels[R.Pose2]), "pose2pose2_factors_per_gpu": tb["F"],
                    "convolutions_per_step_per_gpu": n_conv_step, "particles": N, "solver": args.solver,
                    "inflate_cycles": int(opts.inflate_cycles), "inflation": float(opts.inflation), "noise": "in-kernel philox",
-                   "parallelism": "1 graph segment per GPU, separator all_gather" if multi else "single GPU"},
+                   "parallelism": ("1 graph segment per GPU, separator all_gather (%s, pipeline depth %d)" % ("RCCL direct" if comms else "torch.distributed", depth)) if multi else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "rome::k_conv<P2P2,%s,PPL=2>" % args.solver,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms, "traffic": None},
@@ -268,9 +276,21 @@ def main():
                 out["gpu_convolutions_per_s_by_solver"]["nelder_mead"] / out["cpu_baseline"]["value"]
         out["cpu_baseline"]["gpu_value_over_cpu"] = value / out["cpu_baseline"]["value"]
 
-    if rank == 0:
-        print(json.dumps(out))
+    # the JSON line must be the LAST thing on stdout: RCCL's version banner sits in the C stdio buffer of the ranks that
+    # initialised a communicator and would otherwise be flushed at exit, after the line
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if multi:
+        dist.barrier()
+        torch.cuda.synchronize()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if multi:
+        pipe.close()
         dist.destroy_process_group()
 
 

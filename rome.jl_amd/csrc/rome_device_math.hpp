@@ -264,6 +264,32 @@ __device__ __forceinline__ void wave_sum_n(double (&v)[K]) {
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = readlane_f64(v[k], 63);
 }
+// single-precision variant: the DPP moves fold into v_add_f32_dpp (one instruction per step instead of two moves + an add)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_masked_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int K>
+__device__ __forceinline__ void wave_sum_n_f32(float (&v)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov_f32<0xB1>(v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov_f32<0x4E>(v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov_f32<0x141>(v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov_f32<0x140>(v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov_masked_f32<0x142, 0xA>(v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_mov_masked_f32<0x143, 0xC>(v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[k]), 63));
+}
 __device__ __forceinline__ double wave_sum(double v) { double a[1] = {v}; wave_sum_n<1>(a); return a[0]; }
 
 // ------------------------------------------------------------------------------------------

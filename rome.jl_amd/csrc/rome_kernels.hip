@@ -62,6 +62,27 @@ __device__ __forceinline__ double spread_se2(const double (&t)[PPL][3], const bo
   const double vt = fmax(0.0, (s[5] - s[4] * s[4] * inv) * den);
   return fast_sqrt(vx + vy + vt);   // Manifolds.std: root of the corrected Fréchet variance (sum of the coordinate variances)
 }
+// The same statistic with single-precision moments (differences formed in double, then rounded): used where the spread only
+// scales the jitter of a start point whose root-find result does not depend on it (unique root, closed form / Newton), so the
+// proposals are unchanged to the solver tolerance while the six wave reductions cost a third of the instructions.
+template <int PPL>
+__device__ __forceinline__ double spread_se2_fast(const double (&t)[PPL][3], const bool (&act)[PPL], double inv, double den) {
+  const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0), th0 = readlane_f64(t[0][2], 0);
+  float s[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const float dx = (float)(t[k][0] - x0), dy = (float)(t[k][1] - y0);
+    float dt = (float)(t[k][2] - th0);
+    dt = fmaf(-6.2831853071795865f, rintf(dt * 0.15915494309189535f), dt);
+    if (act[k]) { s[0] += dx; s[1] = fmaf(dx, dx, s[1]); s[2] += dy; s[3] = fmaf(dy, dy, s[3]); s[4] += dt; s[5] = fmaf(dt, dt, s[5]); }
+  }
+  wave_sum_n_f32<6>(s);
+  const float fi = (float)inv, fd = (float)den;
+  const float vx = fmaxf(0.0f, (s[1] - s[0] * s[0] * fi) * fd);
+  const float vy = fmaxf(0.0f, (s[3] - s[2] * s[2] * fi) * fd);
+  const float vt = fmaxf(0.0f, (s[5] - s[4] * s[4] * fi) * fd);
+  return (double)__builtin_sqrtf(vx + vy + vt);
+}
 template <int PPL>
 __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const bool (&act)[PPL], double inv, double den) {
   const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0);
@@ -75,6 +96,20 @@ __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const boo
   const double vx = fmax(0.0, (s[1] - s[0] * s[0] * inv) * den);
   const double vy = fmax(0.0, (s[3] - s[2] * s[2] * inv) * den);
   return fast_sqrt(vx + vy);
+}
+
+template <int PPL>
+__device__ __forceinline__ double spread_r2_fast(const double (&t)[PPL][2], const bool (&act)[PPL], double inv, double den) {
+  const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0);
+  float s[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const float dx = (float)(t[k][0] - x0), dy = (float)(t[k][1] - y0);
+    if (act[k]) { s[0] += dx; s[1] = fmaf(dx, dx, s[1]); s[2] += dy; s[3] = fmaf(dy, dy, s[3]); }
+  }
+  wave_sum_n_f32<4>(s);
+  const float fi = (float)inv, fd = (float)den;
+  return (double)__builtin_sqrtf(fmaxf(0.0f, (s[1] - s[0] * s[0] * fi) * fd) + fmaxf(0.0f, (s[3] - s[2] * s[2] * fi) * fd));
 }
 
 struct P2P2 {
@@ -106,6 +141,13 @@ struct P2P2 {
   __device__ static __forceinline__ double spread(const double (&t)[PPL][3], const Aux (&)[PPL], const bool (&act)[PPL], double inv, double den) {
     return spread_se2<PPL>(t, act, inv, den);
   }
+  // inflation spread of a cycle: the Pose2Pose2 root is unique, so for the closed-form / Newton solvers the start point (hence the
+  // spread's last digits) does not reach the result; Nelder-Mead keeps the double-precision statistic (its result depends on the start)
+  template <int PPL, int SOLVER>
+  __device__ static __forceinline__ double cycle_spread(const double (&t)[PPL][3], const Aux (&A)[PPL], const bool (&act)[PPL], double inv, double den) {
+    if constexpr (SOLVER == kSolverNelderMead) return spread_se2<PPL>(t, act, inv, den);
+    else return spread_se2_fast<PPL>(t, act, inv, den);
+  }
   __device__ static __forceinline__ void add_entropy(double (&t)[3], Aux&, double spread, const double (&u)[3], double s, double c) {
     const double ex = spread * (u[0] - 0.5), ey = spread * (u[1] - 0.5), et = spread * (u[2] - 0.5);
     t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] = wrap_pi(t[2] + et);
@@ -133,7 +175,11 @@ struct P2P2 {
   __device__ static __forceinline__ void heading_sincos(const Consts& K, const Prep& P, int st, int cyc, const double (&t)[3],
                                                         double* s, double* c) {
     if (SOLVER == kSolverNewton && K.dir == 1 && cyc > 0 && st == 0) { *s = P.fs; *c = P.fc; }  // t[2] ≡ θp after a converged solve
-    else fast_sincos(t[2], s, c);
+    else if constexpr (SOLVER == kSolverNelderMead) fast_sincos(t[2], s, c);
+    else {  // unique root: the frame of the jitter only reaches the start point -> hardware single-precision sin/cos (|θ| <= π)
+      const float th = (float)t[2];
+      *s = (double)__sinf(th); *c = (double)__cosf(th);
+    }
   }
 
   template <int SOLVER>
@@ -233,6 +279,11 @@ struct BR {
   __device__ static __forceinline__ double spread(const double (&t)[PPL][DT], const Aux (&)[PPL], const bool (&act)[PPL], double inv, double den) {
     if constexpr (DT == 3) return spread_se2<PPL>(t, act, inv, den);
     else return spread_r2<PPL>(t, act, inv, den);
+  }
+  template <int PPL, int SOLVER>
+  __device__ static __forceinline__ double cycle_spread(const double (&t)[PPL][DT], const Aux (&A)[PPL], const bool (&act)[PPL], double inv, double den) {
+    if constexpr (DIR == 0 && SOLVER != kSolverNelderMead) return spread_r2_fast<PPL>(t, act, inv, den);   // landmark from pose: unique root
+    else return spread<PPL>(t, A, act, inv, den);   // the pose direction has a one-parameter family of roots: the start point matters
   }
   __device__ static __forceinline__ void add_entropy(double (&t)[DT], Aux&, double spread, const double (&u)[DT], double s, double c) {
     if constexpr (DT == 3) {
@@ -384,6 +435,37 @@ struct P3P3 {
 #pragma unroll
     for (int j = 0; j < 6; ++j) acc += fmax(0.0, (s[2 * j + 1] - s[2 * j] * s[2 * j] * inv) * den);
     return fast_sqrt(acc);
+  }
+  // inflation spread of a cycle (see P2P2::cycle_spread): unique root, so closed form / Newton take single-precision moments
+  template <int PPL, int SOLVER>
+  __device__ static __forceinline__ double cycle_spread(const double (&t)[PPL][6], const Aux (&A)[PPL], const bool (&act)[PPL], double inv, double den) {
+    if constexpr (SOLVER == kSolverNelderMead) return spread<PPL>(t, A, act, inv, den);
+    else {
+      double c0[3], q0[4];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) c0[k] = readlane_f64(t[0][k], 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q0[k] = readlane_f64(A[0].q[k], 0);
+      float s[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) s[j] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        double e[4], w[3];
+        quat_cmul(q0, A[k].q, e); quat_log(e, w);
+        const float d[6] = {(float)(t[k][0] - c0[0]), (float)(t[k][1] - c0[1]), (float)(t[k][2] - c0[2]), (float)w[0], (float)w[1], (float)w[2]};
+        if (act[k]) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) { s[2 * j] += d[j]; s[2 * j + 1] = fmaf(d[j], d[j], s[2 * j + 1]); }
+        }
+      }
+      wave_sum_n_f32<12>(s);
+      const float fi = (float)inv, fd = (float)den;
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc += fmaxf(0.0f, (s[2 * j + 1] - s[2 * j] * s[2 * j] * fi) * fd);
+      return (double)__builtin_sqrtf(acc);
+    }
   }
   struct Prep { double a[3], qa[4]; };
   __device__ static __forceinline__ Prep prepare(const Consts& K, const double (&z)[6], const double (&fxc)[6]) {
@@ -613,7 +695,7 @@ k_conv(const ConvArgs a) {
   int have_call = -1;
   for (int cyc = 0; cyc < ncyc; ++cyc) {
     double spread = 0.0;
-    if (cyc_on && a.inflation > 0.0 && N > 1) spread = a.inflation * FP::template spread<PPL>(t, aux, act, a.inv_n, a.inv_nm1);
+    if (cyc_on && a.inflation > 0.0 && N > 1) spread = a.inflation * FP::template cycle_spread<PPL, SOLVER>(t, aux, act, a.inv_n, a.inv_nm1);
     if (spread > 0.0 && have_call != cyc / CPC) {  // wave-uniform
       have_call = cyc / CPC;
 #pragma unroll
@@ -651,7 +733,7 @@ k_conv(const ConvArgs a) {
           for (int d = 3; d < FP::DT; ++d) u[d] = ((double)e1[d - 3] + 0.5) * (1.0 / 4294967296.0);
         }
         double hs, hc;
-        FP::template heading_sincos<SOLVER>(K, prep[k], 1, 0, t[k], &hs, &hc);
+        FP::template heading_sincos<kSolverNelderMead>(K, prep[k], 1, 0, t[k], &hs, &hc);   // this jitter IS the output: full precision
         FP::add_entropy(t[k], aux[k], nh0_spread, u, hs, hc);
       }
     }

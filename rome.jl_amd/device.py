@@ -134,9 +134,10 @@ class DeviceGraph:
     def _launch(self, fn, opts, **kw):
         self._plan(fn, opts, **kw)()
 
-    def _plan(self, fn, opts, **kw):
+    def _plan(self, fn, opts, _ctx=None, **kw):
         """Pre-builds the rome_conv_dev descriptor once; the returned callable only binds the current
-        torch stream and issues the launch (what a captured / replayed step calls)."""
+        torch stream and issues the launch (what a captured / replayed step calls).  `_ctx`: a Context whose stream the
+        caller has fixed (one per pipeline slot) -- the launch then is a single C call with no stream lookup."""
         cd = _lib.ConvDev()
         keep = []
         for k, v in kw.items():
@@ -152,6 +153,16 @@ class DeviceGraph:
         ctx, check, cur = self.ctx, _lib.check, self.torch.cuda.current_stream
         h = ctx.handle
         po, pc = C.byref(o), C.byref(cd)
+
+        if _ctx is not None:
+            hf = _ctx.handle
+
+            def launch_fixed():
+                rc = fn(hf, po, pc)
+                if rc:
+                    check(rc, hf)
+            launch_fixed._keep = (keep, o, cd, _ctx)
+            return launch_fixed
 
         def launch():
             ctx.set_stream(cur(self.device).cuda_stream)

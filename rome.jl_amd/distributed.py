@@ -100,12 +100,13 @@ class PipelinedSegmentSweep:
       (`rome_conv_dev.mirror_*`: no gather kernel);
     * `all_gather_into_tensor` writes straight into ghost blocks that live in the TAIL of the belief store
       (no scatter kernel): the cut factors' `fixed_var`/`target_var` entries simply point there;
-    * send and ghost buffers are double-buffered: sweep k reads the separators gathered after sweep k-2 while
-      collective k-1 is still in flight, so nothing races and the result is deterministic for a fixed schedule.
+    * send and ghost buffers are `depth`-fold buffered (default 2): sweep k reads the separators gathered after sweep k-depth
+      while the collectives k-depth+1 .. k-1 are still in flight, so nothing races and the result is deterministic for a fixed
+      schedule.  A collective's latency (event joins + RCCL launch, tens of µs) is hidden as long as it is shorter than depth-1 sweeps.
     Host work per step: wait (no-op in steady state) + one kernel launch + one async collective.
     """
 
-    def __init__(self, dg, opts, dist, world, rank, sep_rows, ghost_prev, ghost_next, always_collective=False):
+    def __init__(self, dg, opts, dist, world, rank, sep_rows, ghost_prev, ghost_next, always_collective=False, depth=2, rccl_comms=None):
         from .factors import Pose2
         torch = dg.torch
         self.dg, self.dist, self.world, self.rank = dg, dist, world, rank
@@ -115,18 +116,39 @@ class PipelinedSegmentSweep:
         old = dg.bel[Pose2]
         V = old.shape[0]
         per = world * n_sep
-        store = torch.zeros((V + 2 * per, 3, N), dtype=old.dtype, device=old.device)
+        if depth < 2:
+            raise ValueError("PipelinedSegmentSweep needs depth >= 2")
+        self.depth = D = int(depth)
+        store = torch.zeros((V + D * per, 3, N), dtype=old.dtype, device=old.device)
         store[:V].copy_(old)
         dg.bel[Pose2] = store
         self.store, self.V = store, V
-        self.recv = [store[V + b * per: V + (b + 1) * per] for b in range(2)]
-        self.send = [torch.zeros((n_sep, 3, N), dtype=old.dtype, device=old.device) for _ in range(2)]
-        # one proposal table per step parity: consecutive sweeps run on different streams and may overlap
-        self.props = [torch.empty((tb["C"], 3, N), dtype=old.dtype, device=old.device) for _ in range(2)]
+        self.recv = [store[V + b * per: V + (b + 1) * per] for b in range(D)]
+        self.send = [torch.zeros((n_sep, 3, N), dtype=old.dtype, device=old.device) for _ in range(D)]
+        # one proposal table per step slot: consecutive sweeps run on different streams and may overlap
+        self.props = [torch.empty((tb["C"], 3, N), dtype=old.dtype, device=old.device) for _ in range(D)]
         self.prop = self.props[0]
-        self.works = [None, None]
+        self.works = [None] * D
         self.plans = []
-        for b in range(2):
+        # direct RCCL form (rccl.create_comms, one communicator per slot): slot b owns stream b and a rome_ctx bound to it; sweep and
+        # ncclAllGather are enqueued back to back on that stream, so the collective needs no event join and the host work per step is
+        # two C calls.  Otherwise torch.distributed's collective (≈ 30 µs of host time per call) with stream-level joins.
+        self.comms = rccl_comms if (rccl_comms and self.collective and old.is_cuda) else None
+        self.streams = None
+        slot_ctx = [None] * D
+        if self.collective and hasattr(torch, "cuda") and old.is_cuda:
+            cur = torch.cuda.current_stream(old.device)
+            self.streams = [torch.cuda.Stream(old.device) for _ in range(D)]
+            for st in self.streams:
+                st.wait_stream(cur)
+            if self.comms is not None:
+                if len(self.comms) != D:
+                    raise ValueError("need one RCCL communicator per pipeline slot")
+                from . import _lib as _l
+                for b in range(D):
+                    slot_ctx[b] = _l.Context(old.device.index or 0)
+                    slot_ctx[b].set_stream(self.streams[b].cuda_stream)
+        for b in range(D):
             gp = V + b * per + ((rank - 1) % world) * n_sep + 1   # previous segment's LAST pose (slot 1)
             gn = V + b * per + ((rank + 1) % world) * n_sep + 0   # next segment's FIRST pose (slot 0)
             store[gp].copy_(old[ghost_prev]); store[gn].copy_(old[ghost_next])
@@ -137,17 +159,14 @@ class PipelinedSegmentSweep:
             self.plans.append(dg._plan(dg._lib.rome_conv_pose2pose2_dev, opts, n_conv=tb["C"], dir_all=0,
                                        factor=tb["factor"], dir=tb["dir"], fixed_var=fixed, target_var=target,
                                        mu=tb["mu"], L=tb["L"], bel_fixed=store, bel_target=store, out=self.props[b],
-                                       n_mirror=n_sep, mirror_row=tuple(int(r) for r in sep_rows), mirror_out=self.send[b]))
+                                       n_mirror=n_sep, mirror_row=tuple(int(r) for r in sep_rows), mirror_out=self.send[b],
+                                       **({"_ctx": slot_ctx[b]} if slot_ctx[b] is not None else {})))
+        self._ag_args = [(self.send[b].data_ptr(), self.recv[b].data_ptr(), self.send[b].numel(),
+                          self.streams[b].cuda_stream if self.streams is not None else 0) for b in range(D)]
         self.k = 0
-        # Even and odd steps run on two streams.  The join "sweep k+2 waits for collective k" is a wait-for-event packet
-        # at the head of stream k&1 (≈ 8 µs of queue latency on this stack, measured); with one stream it sits between
-        # two sweeps, with two it elapses while the other stream's sweep k+1 keeps the GPU busy.
-        self.streams = None
-        if self.collective and hasattr(torch, "cuda") and old.is_cuda:
-            cur = torch.cuda.current_stream(old.device)
-            self.streams = [torch.cuda.Stream(old.device) for _ in range(2)]
-            for st in self.streams:
-                st.wait_stream(cur)
+        # Steps k, k+1, .. run round-robin on `depth` streams.  In the torch.distributed form the join "sweep k+depth waits for
+        # collective k" is a wait-for-event packet at the head of stream k % depth (≈ 8 µs of queue latency on this stack, measured);
+        # with one stream it would sit between two sweeps, here it elapses while the other streams' sweeps keep the GPU busy.
 
     def _step_on_current_stream(self, b):
         w = self.works[b]
@@ -160,8 +179,11 @@ class PipelinedSegmentSweep:
             self.recv[b].copy_(self.send[b])
 
     def step(self):
-        b = self.k & 1
-        if self.streams is not None:
+        b = self.k % self.depth
+        if self.comms is not None:
+            self.plans[b]()                                  # sweep k on stream b (its rome_ctx is bound to it)
+            self.comms[b].all_gather_f64(*self._ag_args[b])  # ... followed on the same stream by the separator exchange
+        elif self.streams is not None:
             with self.dg.torch.cuda.stream(self.streams[b]):
                 self._step_on_current_stream(b)
         else:
@@ -170,8 +192,8 @@ class PipelinedSegmentSweep:
         self.k += 1
 
     def drain(self):
-        """Wait for the collectives in flight and re-join the two step streams into the caller's stream."""
-        for b in range(2):
+        """Wait for the collectives in flight and re-join the step streams into the caller's stream."""
+        for b in range(self.depth):
             if self.works[b] is not None:
                 if self.streams is not None:
                     with self.dg.torch.cuda.stream(self.streams[b]):
@@ -183,6 +205,14 @@ class PipelinedSegmentSweep:
             cur = self.dg.torch.cuda.current_stream(self.store.device)
             for st in self.streams:
                 cur.wait_stream(st)
+
+    def close(self):
+        if self.comms is not None:
+            self.drain()
+            self.dg.torch.cuda.synchronize()
+            for c in self.comms:
+                c.close()
+            self.comms = None
 
 
 class LinearizeShard:

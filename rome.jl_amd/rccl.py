@@ -1,0 +1,106 @@
+"""Direct RCCL binding for the separator exchange (ctypes on the librccl.so that torch already loaded).
+
+Why: `torch.distributed.all_gather_into_tensor` costs ≈ 30 µs of host time per call (measured, scripts/host_step_cost.py) -- with a
+39 µs sweep kernel the per-step host work of the N > 1 path (stream switch + launch + collective ≈ 47 µs) would bound the step, not the
+GPU.  `ncclAllGather` through ctypes is a ≈ 3 µs call, is enqueued on the SAME stream as the sweep that produced the send buffer (no
+cross-stream event join), and each pipeline slot gets its own communicator so that slots never serialise on one another.
+
+The unique ids are created on rank 0 and distributed with the existing torch.distributed process group (which also remains the
+fallback: `create_comms` returns None on any failure, agreed across ranks, and the caller keeps using torch.distributed)."""
+import ctypes as C
+import os
+
+NCCL_FLOAT64 = 8
+NCCL_UNIQUE_ID_BYTES = 128
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+_lib = None
+
+
+def _load(torch):
+    global _lib
+    if _lib is None:
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        lib = C.CDLL(path if os.path.exists(path) else "librccl.so")
+        lib.ncclGetUniqueId.restype = C.c_int
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+        lib.ncclCommInitRank.restype = C.c_int
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        lib.ncclCommDestroy.restype = C.c_int
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        lib.ncclAllGather.restype = C.c_int
+        lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclGetErrorString.restype = C.c_char_p
+        lib.ncclGetErrorString.argtypes = [C.c_int]
+        _lib = lib
+    return _lib
+
+
+class RcclComm:
+    """One communicator; `all_gather_f64(send_ptr, recv_ptr, count, stream_ptr)` enqueues ncclAllGather on the given HIP stream."""
+
+    def __init__(self, lib, world, rank, uid):
+        self._lib = lib
+        self.comm = C.c_void_p()
+        rc = lib.ncclCommInitRank(C.byref(self.comm), int(world), uid, int(rank))
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank: %s" % lib.ncclGetErrorString(rc).decode())
+        self._ag = lib.ncclAllGather
+
+    def all_gather_f64(self, send_ptr, recv_ptr, count, stream_ptr):
+        rc = self._ag(send_ptr, recv_ptr, count, NCCL_FLOAT64, self.comm, stream_ptr)
+        if rc != 0:
+            raise RuntimeError("ncclAllGather: %s" % self._lib.ncclGetErrorString(rc).decode())
+
+    def close(self):
+        if self.comm:
+            self._lib.ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()
+
+
+def create_comms(torch, dist, world, rank, device, n):
+    """n independent communicators over the ranks of the default process group, or None (on every rank) if any rank failed."""
+    comms, ok = [], 1
+    try:
+        lib = _load(torch)
+        ids = torch.zeros((n, NCCL_UNIQUE_ID_BYTES), dtype=torch.uint8, device=device)
+        if rank == 0:
+            for k in range(n):
+                uid = _UniqueId()
+                rc = lib.ncclGetUniqueId(C.byref(uid))
+                if rc != 0:
+                    raise RuntimeError("ncclGetUniqueId: %s" % lib.ncclGetErrorString(rc).decode())
+                ids[k] = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
+    except Exception:   # noqa: BLE001
+        ok = 0
+        ids = torch.zeros((n, NCCL_UNIQUE_ID_BYTES), dtype=torch.uint8, device=device)
+    if world > 1:
+        # agree BEFORE the (collective, blocking) ncclCommInitRank calls: either every rank enters them or none does
+        pre = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(pre, op=dist.ReduceOp.MIN)
+        ok = int(pre.item())
+        if ok:
+            dist.broadcast(ids, src=0)
+    if ok:
+        try:
+            host = ids.cpu().numpy()
+            for k in range(n):
+                uid = _UniqueId.from_buffer_copy(host[k].tobytes())
+                comms.append(RcclComm(lib, world, rank, uid))
+        except Exception:   # noqa: BLE001
+            ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        for c in comms:
+            try:
+                c.close()
+            except Exception:   # noqa: BLE001
+                pass
+        return None
+    return comms

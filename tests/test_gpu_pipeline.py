@@ -122,3 +122,68 @@ def test_row_sharded_linearisation_on_device_equals_plain_solve():
     finally:
         dist.destroy_process_group()
     assert all(np.array_equal(plain[l], sharded[l]) for l in plain)
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_direct_rccl_form_and_pipeline_depth(depth):
+    """The bench's N>1 form -- one RCCL communicator per pipeline slot driven through ctypes (rome_jl_amd.rccl), sweep and
+    ncclAllGather enqueued on the slot's own stream, no torch.distributed call per step -- against the copy form and against a
+    step-by-step emulation in which step k reads the separators published by step k - depth; free-running steps (sweeps of different
+    slots overlapping) end in the same proposal tables as drained ones."""
+    import torch
+    import torch.distributed as dist
+    import rome_jl_amd as R
+    from rome_jl_amd.distributed import PipelinedSegmentSweep
+    from rome_jl_amd.rccl import create_comms
+    N, P, S = 100, 400, 9
+    sep = [1, 2 * (P - 2)]
+    opts = R.make_opts(N=N, solver=1, seed=33)
+
+    def run(comms, drain_each=True):
+        fg = _segment(R, N, P)
+        dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+        pk = dg.packed
+        pipe = PipelinedSegmentSweep(dg, opts, dist if comms else None, 1, 0, sep, pk.index["ghost_prev"], pk.index["ghost_next"],
+                                     always_collective=bool(comms), depth=depth, rccl_comms=comms)
+        assert (pipe.comms is not None) == bool(comms)
+        outs = []
+        for _ in range(S):
+            pipe.step()
+            if drain_each:
+                pipe.drain(); torch.cuda.synchronize()
+                outs.append(pipe.prop.cpu().numpy().copy())
+        pipe.drain(); torch.cuda.synchronize()
+        final = [p.cpu().numpy().copy() for p in pipe.props]
+        return outs, final, pk
+
+    plain, plain_final, pk = run(None)
+    fg = _segment(R, N, P)
+    dg2 = R.DeviceGraph(fg); dg2.upload_beliefs(fg)
+    gp, gn = pk.index["ghost_prev"], pk.index["ghost_next"]
+    hist = []
+    for k in range(S):
+        if k >= depth:
+            dg2.bel[R.Pose2][gp].copy_(torch.as_tensor(hist[k - depth][sep[1]]))
+            dg2.bel[R.Pose2][gn].copy_(torch.as_tensor(hist[k - depth][sep[0]]))
+        out = dg2.sweep_pose2pose2(opts)
+        torch.cuda.synchronize()
+        hist.append(out.cpu().numpy().copy())
+    for k in range(S):
+        assert np.array_equal(plain[k], hist[k]), k
+
+    _init_single_rank_rccl(dist, torch, 29544 + depth)
+    try:
+        comms = create_comms(torch, dist, 1, 0, torch.device("cuda", 0), depth)
+        if comms is None:
+            pytest.skip("direct RCCL binding unavailable here (bench falls back to torch.distributed)")
+        direct, direct_final, _ = run(comms)
+        comms2 = create_comms(torch, dist, 1, 0, torch.device("cuda", 0), depth)
+        _, free_final, _ = run(comms2, drain_each=False)
+        for c in comms + comms2:
+            c.close()
+    finally:
+        dist.destroy_process_group()
+    for k in range(S):
+        assert np.array_equal(plain[k], direct[k]), k
+    for a, b, c in zip(plain_final, direct_final, free_final):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
