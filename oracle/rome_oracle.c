@@ -346,7 +346,7 @@ static void moments(int N, const double* d, double* mean, double* sd) {
   *mean = m; *sd = sqrt(v / (N > 1 ? (double)(N - 1) : 1.0));
 }
 void ro_belief_spread_se2(int N, const double* x, const double* y, const double* th, double* mean3, double* std3) {
-  double* d = (double*)malloc(sizeof(double) * N);
+  double* d = (double*)calloc((size_t)(N > 0 ? N : 1), sizeof(double));
   double m;
   for (int i = 0; i < N; ++i) d[i] = x[i] - x[0];
   moments(N, d, &m, &std3[0]); mean3[0] = x[0] + m;
@@ -358,7 +358,7 @@ void ro_belief_spread_se2(int N, const double* x, const double* y, const double*
   free(d);
 }
 void ro_belief_spread_r2(int N, const double* x, const double* y, double* mean2, double* std2) {
-  double* d = (double*)malloc(sizeof(double) * N);
+  double* d = (double*)calloc((size_t)(N > 0 ? N : 1), sizeof(double));
   double m;
   for (int i = 0; i < N; ++i) d[i] = x[i] - x[0];
   moments(N, d, &m, &std2[0]); mean2[0] = x[0] + m;
