@@ -81,7 +81,7 @@ __device__ __forceinline__ double spread_se2_fast(const double (&t)[PPL][3], con
   const float vx = fmaxf(0.0f, (s[1] - s[0] * s[0] * fi) * fd);
   const float vy = fmaxf(0.0f, (s[3] - s[2] * s[2] * fi) * fd);
   const float vt = fmaxf(0.0f, (s[5] - s[4] * s[4] * fi) * fd);
-  return (double)__builtin_sqrtf(vx + vy + vt);
+  return (double)fminf(__builtin_sqrtf(vx + vy + vt), 3.0e38f);   // finite even if the single-precision moments overflow
 }
 template <int PPL>
 __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const bool (&act)[PPL], double inv, double den) {
@@ -109,7 +109,7 @@ __device__ __forceinline__ double spread_r2_fast(const double (&t)[PPL][2], cons
   }
   wave_sum_n_f32<4>(s);
   const float fi = (float)inv, fd = (float)den;
-  return (double)__builtin_sqrtf(fmaxf(0.0f, (s[1] - s[0] * s[0] * fi) * fd) + fmaxf(0.0f, (s[3] - s[2] * s[2] * fi) * fd));
+  return (double)fminf(__builtin_sqrtf(fmaxf(0.0f, (s[1] - s[0] * s[0] * fi) * fd) + fmaxf(0.0f, (s[3] - s[2] * s[2] * fi) * fd)), 3.0e38f);
 }
 
 struct P2P2 {
@@ -464,7 +464,7 @@ struct P3P3 {
       float acc = 0.0f;
 #pragma unroll
       for (int j = 0; j < 6; ++j) acc += fmaxf(0.0f, (s[2 * j + 1] - s[2 * j] * s[2 * j] * fi) * fd);
-      return (double)__builtin_sqrtf(acc);
+      return (double)fminf(__builtin_sqrtf(acc), 3.0e38f);
     }
   }
   struct Prep { double a[3], qa[4]; };

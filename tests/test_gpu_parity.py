@@ -391,3 +391,26 @@ def test_native_point_layout_roundtrip_and_convolution():
                              noise=np.ascontiguousarray(n6.transpose(0, 2, 1)))
     got6 = R.getCoordinates(R.Pose3, out6).transpose(0, 2, 1)
     assert _so3_dist(got6, ref6) < 1e-9
+
+
+def test_newton_root_is_independent_of_belief_scale_single_precision_spread():
+    """The inflation spread of the closed-form / Newton solvers is accumulated in single precision (it only scales the jitter of a
+    start point whose root-find has a unique root): beliefs spread over 1e-9 m ... 1e25 m -- beyond float range once squared -- still
+    give the oracle's proposals to the solver tolerance (relative to the coordinate magnitude)."""
+    rng = np.random.default_rng(17)
+    N = 100
+    for scale in (1e-9, 1.0, 1e6, 1e15, 1e25):
+        fixed = np.stack([scale * rng.normal(size=N), scale * rng.normal(size=N), rng.uniform(-3, 3, N)])[None]
+        u0 = np.stack([scale * rng.normal(size=N), scale * rng.normal(size=N), rng.uniform(-3, 3, N)])[None]
+        mu, cov = np.array([[2.0, -1.0, 0.7]]), np.diag([0.01, 0.02, 0.001])[None]
+        for d in (0, 1):
+            o = R.make_opts(N=N, solver=R.SOLVER_NEWTON, seed=5)
+            got = R.conv_pose2pose2(o, mu, cov, fixed, u0.copy(), dirs=[d])
+            oo = ro.make_opts(N=N, solver=ro.SOLVER_NEWTON, seed=5)
+            L = np.array([ro.cholesky_lower(cov[0])])
+            bel = np.concatenate([fixed, u0])
+            ref = ro.conv_pose2pose2(oo, mu, L, bel, [0], [1], [d])
+            err = np.abs(got[0] - ref[0])
+            err[2] = np.abs(np.arctan2(np.sin(got[0, 2] - ref[0, 2]), np.cos(got[0, 2] - ref[0, 2])))
+            assert np.isfinite(got).all()
+            assert (err[:2] <= 1e-9 + 1e-12 * scale * 10).all() and err[2].max() < 1e-9, (scale, d, err.max(1))
