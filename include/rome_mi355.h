@@ -238,7 +238,8 @@ int rome_linearize_dev(rome_ctx*, int32_t kind, int32_t F, const double* mu, con
  *   (examples/ManhattanBatchAnalysis.jl:59-62) and for IIF's inflation spread (calcStdBasicSpread).
  * rome_product_dev: new belief of every variable from the proposals that target it (CSR prop_ptr[V+1] /
  *   prop_rows into prop [rows][dim][N]); variables without proposals keep bel_in.  STAND-IN for
- *   AMP.manifoldProduct (unvendored): importance-sampling product of the proposal KDEs, see DESIGN.md §10. */
+ *   AMP.manifoldProduct (unvendored): importance-sampling product of the proposal KDEs, see DESIGN.md §11.
+ *   dim 2 (Point2), 3 (Pose2) or 6 (Pose3, coordinates [t; rotation vector], N <= 256). */
 int rome_belief_stats_dev(rome_ctx*, int32_t dim, int32_t V, int32_t N, const double* bel, double* mean, double* std);
 int rome_belief_stats(rome_ctx*, int32_t dim, int32_t V, int32_t N, const double* bel, double* mean, double* std); /* host pointers */
 /* rome_kde_bandwidth*: the bandwidth `manikde!` selects for a belief, one per coordinate, by leave-one-out likelihood

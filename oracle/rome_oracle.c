@@ -1132,14 +1132,15 @@ int ro_kde_max(int dim, int V, int N, const double* bel /*[V][dim][N]*/, const d
  *   systematic resampling of N candidates with one uniform u (Philox domain 3), then kernel jitter
  *   x ⊕ (h_prod ⊙ ξ), 1/h_prod,k² = Σ_l 1/h_lk²  (ξ: ro_rng_normals on the variable's stream).
  *   K = 1: the proposal is copied; K = 0: the belief is kept.
- * dim = 2 (Point2) or 3 (Pose2: third coordinate is an angle, differences wrapped).                  */
+ * dim = 2 (Point2), 3 (Pose2: third coordinate is an angle, differences wrapped) or 6 (Pose3: coordinates
+ * [t; rotation vector]; tangent difference (x.t - y.t, Log(R_yᵀ R_x)), jitter R ← R Exp(h_ω ⊙ ξ_ω)).      */
 static double wrap_diff(double a) { return atan2(sin(a), cos(a)); }
 
 int ro_product_bw(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const int32_t* prop_rows,
                   const double* prop /*[rows][dim][N]*/, const double* prop_bw /*[rows][dim] or NULL: Silverman*/,
                   const double* bel_in /*[V][dim][N]*/, double* bel_out) {
   const int N = o->n_particles;
-  if (dim != 2 && dim != 3) return -1;
+  if (dim != 2 && dim != 3 && dim != 6) return -1;
   const double cN = pow(4.0 / ((dim + 2.0) * N), 1.0 / (dim + 4.0));
 #pragma omp parallel for schedule(dynamic, 8)
   for (int v = 0; v < V; ++v) {
@@ -1149,11 +1150,16 @@ int ro_product_bw(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, con
     if (K == 0) { memcpy(ob, bel_in + (size_t)v * dim * N, sizeof(double) * dim * N); continue; }
     if (K == 1) { memcpy(ob, prop + (size_t)rows[0] * dim * N, sizeof(double) * dim * N); continue; }
     double* h = (double*)malloc(sizeof(double) * K * dim);
+    /* dim 6 (Pose3, coordinates [t; rotation vector]): rotation matrices of every proposal point, once */
+    double* Rm = dim == 6 ? (double*)malloc(sizeof(double) * 9 * (size_t)K * N) : NULL;
     int base = 0; double best = INFINITY;
     for (int l = 0; l < K; ++l) {
       const double* P = prop + (size_t)rows[l] * dim * N;
-      double mean[3], sd[3];
-      if (dim == 3) ro_belief_spread_se2(N, P, P + N, P + 2 * N, mean, sd);
+      double mean[6], sd[6];
+      if (dim == 6) {
+        ro_belief_spread_se3(N, P, mean, sd);
+        for (int j = 0; j < N; ++j) { double w[3] = {P[3 * N + j], P[4 * N + j], P[5 * N + j]}; ro_so3_exp(w, Rm + 9 * ((size_t)l * N + j)); }
+      } else if (dim == 3) ro_belief_spread_se2(N, P, P + N, P + 2 * N, mean, sd);
       else ro_belief_spread_r2(N, P, P + N, mean, sd);
       double ln = 0.0;
       for (int k = 0; k < dim; ++k) {
@@ -1167,7 +1173,7 @@ int ro_product_bw(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, con
     double* logw = (double*)malloc(sizeof(double) * M);
     double lwmax = -INFINITY;
     for (int m = 0; m < M; ++m) {
-      double x[3]; for (int k = 0; k < dim; ++k) x[k] = Pb[k * N + m];
+      double x[6]; for (int k = 0; k < dim; ++k) x[k] = Pb[k * N + m];
       double acc = 0.0;
       for (int l = 0; l < K; ++l) {
         if (l == base) continue;
@@ -1176,10 +1182,19 @@ int ro_product_bw(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, con
         double qmin = INFINITY, sacc = 0.0;
         for (int j = 0; j < N; ++j) {
           double q = 0.0;
-          for (int k = 0; k < dim; ++k) {
-            double d = x[k] - P[k * N + j];
-            if (dim == 3 && k == 2) d = wrap_diff(d);
-            d *= 1.0 / h[l * dim + k]; q += d * d;
+          if (dim == 6) {   /* tangent difference of the base point about the kernel point: (x.t - y.t, Log(R_yᵀ R_x)) */
+            double U[9], wv[3];
+            mat3_tmul(Rm + 9 * ((size_t)l * N + j), Rm + 9 * ((size_t)base * N + m), U); ro_so3_log(U, wv);
+            for (int k = 0; k < 3; ++k) {
+              double d = (x[k] - P[k * N + j]) / h[l * dim + k]; q += d * d;
+              double e = wv[k] / h[l * dim + 3 + k]; q += e * e;
+            }
+          } else {
+            for (int k = 0; k < dim; ++k) {
+              double d = x[k] - P[k * N + j];
+              if (dim == 3 && k == 2) d = wrap_diff(d);
+              d *= 1.0 / h[l * dim + k]; q += d * d;
+            }
           }
           const double dq = q - qmin;
           const double e = exp(-0.5 * fabs(dq));
@@ -1194,7 +1209,7 @@ int ro_product_bw(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, con
     double* cum = (double*)malloc(sizeof(double) * M);
     double T = 0.0;
     for (int m = 0; m < M; ++m) { T += exp(logw[m] - lwmax); cum[m] = T; }
-    double hp[3];
+    double hp[6];
     for (int k = 0; k < dim; ++k) { double a = 0.0; for (int l = 0; l < K; ++l) a += 1.0 / (h[l * dim + k] * h[l * dim + k]); hp[k] = 1.0 / sqrt(a); }
     double u;
     { uint32_t key[2] = {(uint32_t)o->seed, (uint32_t)(o->seed >> 32)};
@@ -1206,12 +1221,19 @@ int ro_product_bw(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, con
     for (int i = 0; i < N; ++i) {
       const double tau = (i + u) * T / N;
       while (m < M - 1 && !(cum[m] > tau)) ++m;
-      double xi[3];
+      double xi[6];
       ro_rng_normals(o->seed, o->stream_offset + (uint64_t)v, (uint32_t)i, dim, xi);
-      for (int k = 0; k < dim; ++k) ob[k * N + i] = Pb[k * N + m] + hp[k] * xi[k];
-      if (dim == 3) ob[2 * N + i] = wrap_diff(ob[2 * N + i]);
+      if (dim == 6) {   /* x ⊕ (h_prod ⊙ ξ): translation added, rotation R ← R Exp(h_ω ⊙ ξ_ω) */
+        double e[3] = {hp[3] * xi[3], hp[4] * xi[4], hp[5] * xi[5]}, E[9], Rn[9], wn[3];
+        for (int k = 0; k < 3; ++k) ob[k * N + i] = Pb[k * N + m] + hp[k] * xi[k];
+        ro_so3_exp(e, E); mat3_mul(Rm + 9 * ((size_t)base * N + m), E, Rn); ro_so3_log(Rn, wn);
+        for (int k = 0; k < 3; ++k) ob[(3 + k) * N + i] = wn[k];
+      } else {
+        for (int k = 0; k < dim; ++k) ob[k * N + i] = Pb[k * N + m] + hp[k] * xi[k];
+        if (dim == 3) ob[2 * N + i] = wrap_diff(ob[2 * N + i]);
+      }
     }
-    free(h); free(logw); free(cum);
+    free(h); free(logw); free(cum); free(Rm);
   }
   return 0;
 }

@@ -652,9 +652,10 @@ int rome_kde_max(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* b
 int rome_product_bw_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
                         const double* prop, const double* prop_bw, const double* bel_in, double* bel_out) {
   int rc = check_opts(o); if (rc) return rc;
-  if (!c || V < 0 || (dim != 2 && dim != 3)) return ROME_ERR_INVALID_ARG;
+  if (!c || V < 0 || (dim != 2 && dim != 3 && dim != 6)) return ROME_ERR_INVALID_ARG;
   if (V > 0 && (!prop_ptr || !bel_in || !bel_out)) return ROME_ERR_INVALID_ARG;
   const int N = o->n_particles;
+  if (dim == 6 && N > 256) return ROME_ERR_UNSUPPORTED_N;   /* Pose3 product: points staged in LDS */
   const double c_n = std::pow(4.0 / ((dim + 2.0) * N), 1.0 / (dim + 4.0));
   ROME_HIP(c, rome::launch_product(dim, V, N, prop_ptr, prop_rows, prop, prop_bw, bel_in, bel_out, c_n, o->seed, o->stream_offset, c->stream));
   return ROME_OK;

@@ -303,6 +303,215 @@ __global__ void __launch_bounds__(64 * kProdWaves) k_product(const ProductArgs a
   }
 }
 
+// ---- SE(3) product (Pose3 beliefs; coordinates [t(3); rotation vector(3)]) ------------------------------------------------
+// Same definition as k_product (oracle: ro_product_bw, dim 6) with the tangent difference of SE(3):
+//   d(x, y) = (x.t − y.t, Log(R_yᵀ R_x)),   jitter  t += h_t ⊙ ξ_t,  R ← R Exp(h_ω ⊙ ξ_ω).
+// Rotations are unit quaternions from load to store (one Exp per point when it is loaded or staged, one Log per pair).
+struct Se3Pt { double t[3], q[4]; };
+__device__ __forceinline__ void se3_load(const double* __restrict__ P, int N, int i, Se3Pt& a) {
+  double w[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { a.t[k] = P[k * N + i]; w[k] = P[(3 + k) * N + i]; }
+  quat_exp(w, a.q);
+}
+__device__ __forceinline__ void se3_diff(const Se3Pt& x, const Se3Pt& y, double (&d)[6]) {
+  double e[4];
+  quat_cmul(y.q, x.q, e);
+  quat_log(e, d + 3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = x.t[k] - y.t[k];
+}
+__device__ __forceinline__ void proposal_bandwidth_se3(const ProductArgs& a, int row, const double* __restrict__ P, int N, int lane,
+                                                       double (&h)[6]) {
+  if (a.prop_bw) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) h[k] = fmax(a.prop_bw[(size_t)row * 6 + k], 1e-6);
+    return;
+  }
+  Se3Pt x0; se3_load(P, N, 0, x0);
+  double s[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) s[j] = 0.0;
+  for (int i = lane; i < N; i += 64) {
+    Se3Pt xi; se3_load(P, N, i, xi);
+    double d[6]; se3_diff(xi, x0, d);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { s[2 * k] += d[k]; s[2 * k + 1] += d[k] * d[k]; }
+  }
+  wave_sum_n<12>(s);
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    h[k] = fmax(a.c_n * fast_sqrt(fmax(0.0, (s[2 * k + 1] - s[2 * k] * s[2 * k] * a.inv_n) * a.inv_nm1)), 1e-6);
+}
+
+template <int S>
+__global__ void __launch_bounds__(64 * kProdWaves) k_product_se3(const ProductArgs a) {
+  constexpr int D = 6;
+  constexpr int T4 = (S + kProdWaves - 1) / kProdWaves;
+  __shared__ double pts[kProdWaves][7][64 * S];   // every wave stages (t, q) of the points of its proposal
+  __shared__ double contrib[kProdChunk][64 * S];
+  __shared__ double wts[64 * S];
+  __shared__ double red[kProdWaves];
+  __shared__ double ihbuf[kProdMaxK][D];
+  __shared__ double lnbuf[kProdMaxK];
+  const int v = blockIdx.x;
+  if (v >= a.V) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), N = a.N;
+  const int r0 = a.prop_ptr[v], K = a.prop_ptr[v + 1] - r0;
+  double* ob = a.bel_out + (size_t)v * D * N;
+  if (K <= 1) {
+    const double* src = K == 0 ? a.bel_in + (size_t)v * D * N : a.prop + (size_t)a.prop_rows[r0] * D * N;
+    for (int i = tid; i < D * N; i += 64 * kProdWaves) ob[i] = src[i];
+    return;
+  }
+  int base = 0;
+  double best = __builtin_inf();
+  double hp_acc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) hp_acc[k] = 0.0;
+  for (int l0 = 0; l0 < K; l0 += kProdMaxK) {
+    const int cnt = min(kProdMaxK, K - l0);
+    for (int c = wave; c < cnt; c += kProdWaves) {
+      const int row = a.prop_rows[r0 + l0 + c];
+      double h[D];
+      proposal_bandwidth_se3(a, row, a.prop + (size_t)row * D * N, N, lane, h);
+      double ln = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        ln += fast_log(h[k]);
+        if (lane == 0) ihbuf[c][k] = 1.0 / h[k];
+      }
+      if (lane == 0) lnbuf[c] = ln;
+    }
+    __syncthreads();
+    for (int c = 0; c < cnt; ++c) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) { const double ih = ihbuf[c][k]; hp_acc[k] = fma(ih, ih, hp_acc[k]); }
+      const double ln = lnbuf[c];
+      if (ln < best) { best = ln; base = l0 + c; }
+    }
+    if (l0 + kProdMaxK < K) __syncthreads();
+  }
+  const bool h_cached = K <= kProdMaxK;
+  const double* __restrict__ Pb = a.prop + (size_t)a.prop_rows[r0 + base] * D * N;
+  Se3Pt x[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) { const int i = lane + 64 * s; se3_load(Pb, N, i < N ? i : 0, x[s]); }
+  double lw[T4];
+#pragma unroll
+  for (int s = 0; s < T4; ++s) lw[s] = 0.0;
+  for (int c0 = 0; c0 < K - 1; c0 += kProdChunk) {
+    const int cnt = min(kProdChunk, K - 1 - c0);
+    for (int c = wave; c < cnt; c += kProdWaves) {
+      const int nb = c0 + c, l = nb < base ? nb : nb + 1;
+      const int row = a.prop_rows[r0 + l];
+      const double* __restrict__ P = a.prop + (size_t)row * D * N;
+      double ih[D];
+      if (h_cached) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) ih[k] = ihbuf[l][k];
+      } else {
+        double h[D];
+        proposal_bandwidth_se3(a, row, P, N, lane, h);
+#pragma unroll
+        for (int k = 0; k < D; ++k) ih[k] = 1.0 / h[k];
+      }
+      double qmin[S], sacc[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) { qmin[s] = __builtin_inf(); sacc[s] = 0.0; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int i = lane + 64 * s;
+        if (i < N) {
+          Se3Pt y; se3_load(P, N, i, y);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pts[wave][k][i] = y.t[k];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pts[wave][3 + k][i] = y.q[k];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      for (int j = 0; j < N; ++j) {
+        Se3Pt y;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) y.t[k] = pts[wave][k][j];       // wave-uniform address
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y.q[k] = pts[wave][3 + k][j];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          if (lane + 64 * s < N) {
+            double d[6];
+            se3_diff(x[s], y, d);
+            double q = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const double dt = d[k] * ih[k]; q += dt * dt; const double dw = d[3 + k] * ih[3 + k]; q += dw * dw; }
+            const double dq = q - qmin[s];
+            const double e = fast_exp_neg(-0.5 * fabs(dq));
+            sacc[s] = dq < 0.0 ? fma(sacc[s], e, 1.0) : sacc[s] + e;
+            qmin[s] = fmin(qmin[s], q);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) if (lane + 64 * s < N) contrib[c][lane + 64 * s] = -0.5 * qmin[s] + fast_log(sacc[s]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < T4; ++s) {
+      const int i = tid + 64 * kProdWaves * s;
+      if (i < N) for (int c = 0; c < cnt; ++c) lw[s] += contrib[c][i];
+    }
+    __syncthreads();
+  }
+  double mx = -__builtin_inf();
+#pragma unroll
+  for (int s = 0; s < T4; ++s) if (tid + 64 * kProdWaves * s < N) mx = fmax(mx, lw[s]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+#pragma unroll
+  for (int s = 0; s < T4; ++s) { const int i = tid + 64 * kProdWaves * s; if (i < N) wts[i] = exp(lw[s] - mx); }
+  __syncthreads();
+  if (wave == 0) {
+    double cum = 0.0;
+    for (int m = 0; m < N; ++m) {
+      cum += wts[m];
+      if (lane == (m & 63)) contrib[0][m] = cum;
+    }
+  }
+  __syncthreads();
+  const double* cumw = contrib[0];
+  const double T = cumw[N - 1];
+  const uint64_t stream = a.stream_offset + (uint64_t)v;
+  const u32x4 uw = philox4x32_10(u32x4{0xFFFFFFFFu, (uint32_t)stream, (uint32_t)(stream >> 32), (3u << 16)},
+                                 (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+  const double u = ((double)uw.x + 0.5) * (1.0 / 4294967296.0);
+#pragma unroll
+  for (int s = 0; s < T4; ++s) {
+    const int i = tid + 64 * kProdWaves * s;
+    if (i < N) {
+      const double tau = ((double)i + u) * T / (double)N;
+      int lo = 0, hi = N - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cumw[mid] > tau) hi = mid; else lo = mid + 1;
+      }
+      Se3Pt p; se3_load(Pb, N, lo, p);
+      double xi[D];
+      rng_normals<D>(a.seed, stream, (uint32_t)i, xi);
+      double e[3], qe[4], qn[4], wn[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) e[k] = xi[3 + k] / fast_sqrt(hp_acc[3 + k]);
+      quat_exp(e, qe); quat_mul(p.q, qe, qn); quat_log(qn, wn);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { ob[k * N + i] = p.t[k] + xi[k] / fast_sqrt(hp_acc[k]); ob[(3 + k) * N + i] = wn[k]; }
+    }
+  }
+}
+
 hipError_t launch_belief_stats(int dim, int V, int N, const double* bel, double* mean, double* sdev, hipStream_t s) {
   if (V <= 0) return hipSuccess;
   const double inv_n = 1.0 / N, inv_nm1 = N > 1 ? 1.0 / (N - 1) : 1.0;
@@ -323,6 +532,13 @@ hipError_t launch_product(int dim, int V, int N, const int32_t* prop_ptr, const 
   ProductArgs a;
   a.V = V; a.N = N; a.prop_ptr = prop_ptr; a.prop_rows = prop_rows; a.prop = prop; a.prop_bw = prop_bw; a.bel_in = bel_in; a.bel_out = bel_out;
   a.inv_n = 1.0 / N; a.inv_nm1 = N > 1 ? 1.0 / (N - 1) : 1.0; a.c_n = c_n; a.seed = seed; a.stream_offset = stream_offset;
+  if (dim == 6) {   // Pose3: quaternion state, points staged per wave -- N <= 256
+    if (N <= 64) hipLaunchKernelGGL((k_product_se3<1>), dim3(V), dim3(64 * kProdWaves), 0, s, a);
+    else if (N <= 128) hipLaunchKernelGGL((k_product_se3<2>), dim3(V), dim3(64 * kProdWaves), 0, s, a);
+    else if (N <= 256) hipLaunchKernelGGL((k_product_se3<4>), dim3(V), dim3(64 * kProdWaves), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (dim != 2 && dim != 3) return hipErrorInvalidValue;
 #define ROME_LAUNCH_PRODUCT(S) \
   do { if (dim == 2) hipLaunchKernelGGL((k_product<2, S>), dim3(V), dim3(64 * kProdWaves), 0, s, a); \

@@ -73,16 +73,19 @@ class DeviceGraph:
         C2 = self.tab["p2p2"]["C"] if "p2p2" in self.tab else 0
         Fb = self.tab["br"]["F"] if "br" in self.tab else 0
         Fb0 = self.tab["br"]["F0"] if "br" in self.tab else 0
-        self.n_prop = {Pose2: C2 + Fb, Point2: Fb0}
+        C3 = self.tab["p3p3"]["C"] if "p3p3" in self.tab else 0
+        self.n_prop = {Pose2: C2 + Fb, Point2: Fb0, Pose3: C3}
         self.prop_bw = {}
         self.prop = {Pose2: torch.zeros((max(C2 + Fb, 1), 3, self.N), dtype=f64, device=self.device),
-                     Point2: torch.zeros((max(Fb0, 1), 2, self.N), dtype=f64, device=self.device)}
-        self.bel_next = {Pose2: torch.zeros_like(self.bel[Pose2]), Point2: torch.zeros_like(self.bel[Point2])}
+                     Point2: torch.zeros((max(Fb0, 1), 2, self.N), dtype=f64, device=self.device),
+                     Pose3: torch.zeros((max(C3, 1), 6, self.N), dtype=f64, device=self.device)}
+        self.bel_next = {vt: torch.zeros_like(self.bel[vt]) for vt in (Pose2, Point2, Pose3)}
         tgt2 = [self.tab["p2p2"]["target"].cpu().numpy()] if C2 else []
         if Fb:
             tgt2.append(pk.br["pose"])
         self._prop_targets = {Pose2: np.concatenate(tgt2) if tgt2 else np.zeros(0, np.int32),
-                              Point2: pk.br["rows0"]["point"] if Fb else np.zeros(0, np.int32)}
+                              Point2: pk.br["rows0"]["point"] if Fb else np.zeros(0, np.int32),
+                              Pose3: self.tab["p3p3"]["target"].cpu().numpy() if C3 else np.zeros(0, np.int32)}
         self.frozen = set()
         self._build_csr()
 
@@ -92,7 +95,7 @@ class DeviceGraph:
         t = lambda a, dt: self.torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=self.device)
         i32 = self.torch.int32
         self.csr = {}
-        for vt in (Pose2, Point2):
+        for vt in (Pose2, Point2, Pose3):
             tg = np.asarray(self._prop_targets[vt], dtype=np.int64)
             nv = len(pk.labels[vt])
             live = np.ones(nv + 1, dtype=bool)
@@ -112,7 +115,7 @@ class DeviceGraph:
         """Fixed-lag operation (IIF `fifoFreeze!` / isMarginalized): the beliefs of `labels` are no longer updated by product_step /
         solve; they still serve as the fixed side of every convolution they take part in (test/testFixedLagFG.jl:86-121)."""
         labels = set(labels)
-        known = set(self.packed.labels[Pose2]) | set(self.packed.labels[Point2])
+        known = set(self.packed.labels[Pose2]) | set(self.packed.labels[Point2]) | set(self.packed.labels[Pose3])
         if not labels <= known:
             raise KeyError("set_frozen: unknown variables %s" % sorted(labels - known))
         self.frozen = labels
@@ -185,7 +188,8 @@ class DeviceGraph:
         return self._plan(fn, opts, n_conv=tb["F"], dir_all=0, mu=tb["mu"], L=tb["L"], noise=noise, out=out)
 
     # ---- solve loop pieces ----
-    STREAM_P2P2, STREAM_BR1, STREAM_BR0, STREAM_PROD2, STREAM_PRODL = 0, 1 << 28, 2 << 28, 3 << 28, 4 << 28
+    STREAM_P2P2, STREAM_BR1, STREAM_BR0, STREAM_PROD2, STREAM_PRODL, STREAM_P3P3, STREAM_PROD3 = \
+        0, 1 << 28, 2 << 28, 3 << 28, 4 << 28, 5 << 28, 6 << 28
 
     def _opts_at(self, opts, offset):
         o = _lib.Opts.from_buffer_copy(opts)
@@ -203,6 +207,8 @@ class DeviceGraph:
             Fb, Fb0 = self.tab["br"]["F"], self.tab["br"]["F0"]
             self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR1), 1, out=self.prop[Pose2][C2:C2 + Fb])
             self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR0), 0, out=self.prop[Point2][:Fb0])
+        if "p3p3" in self.tab and self.tab["p3p3"]["C"]:
+            self.sweep_pose3pose3(self._opts_at(opts, base + self.STREAM_P3P3), out=self.prop[Pose3][:self.tab["p3p3"]["C"]])
 
     def product_step(self, opts, sweep=0, bandwidth="silverman"):
         """bel <- product of the proposals targeting each variable (Jacobi update, double-buffered).
@@ -212,7 +218,7 @@ class DeviceGraph:
             raise ValueError("bandwidth must be 'silverman' or 'lcv'")
         self._bind_stream()
         base = sweep << 32
-        for vt, dim, off in ((Pose2, 3, self.STREAM_PROD2), (Point2, 2, self.STREAM_PRODL)):
+        for vt, dim, off in ((Pose2, 3, self.STREAM_PROD2), (Point2, 2, self.STREAM_PRODL), (Pose3, 6, self.STREAM_PROD3)):
             V = self.bel[vt].shape[0]
             if V == 0:
                 continue
@@ -224,7 +230,8 @@ class DeviceGraph:
                 if vt not in self.prop_bw:
                     self.prop_bw[vt] = self.torch.empty((rows, dim), dtype=self.torch.float64, device=self.device)
                 _lib.check(self._lib.rome_kde_bandwidth_dev(self.ctx.handle, dim, rows, self.N, self.prop[vt].data_ptr(),
-                                                            0b100 if vt is Pose2 else 0, 0.0, 0.0, self.prop_bw[vt].data_ptr()),
+                                                            0b100 if vt is Pose2 else (0b111000 if vt is Pose3 else 0), 0.0, 0.0,
+                                                            self.prop_bw[vt].data_ptr()),
                            self.ctx.handle)
                 bw_ptr = self.prop_bw[vt].data_ptr()
             _lib.check(self._lib.rome_product_bw_dev(self.ctx.handle, C.byref(o), dim, V, c["ptr"].data_ptr(), c["rows"].data_ptr(),
@@ -251,6 +258,17 @@ class DeviceGraph:
             m = np.stack([np.asarray(means[l], dtype=float) for l in ls])
             b = m[:, :, None] + sg[None, :, None] * rng.standard_normal((len(ls), vt.dim, self.N))
             self.bel[vt][:len(ls)].copy_(self.torch.as_tensor(b))
+        ls = self.packed.labels[Pose3]
+        if ls:   # Pose3: translation jitter added, rotation jitter composed on the right (R ← R Exp(e))
+            from scipy.spatial.transform import Rotation as Rot
+            sg = np.asarray(sigma[Pose3] if sigma is not None and Pose3 in sigma else [0.05, 0.05, 0.05, 0.01, 0.01, 0.01])
+            m = np.stack([np.asarray(means[l], dtype=float) for l in ls])
+            e = sg[None, :, None] * rng.standard_normal((len(ls), 6, self.N))
+            b = np.empty_like(e)
+            b[:, :3] = m[:, :3, None] + e[:, :3]
+            for k in range(len(ls)):
+                b[k, 3:] = (Rot.from_rotvec(m[k, 3:]) * Rot.from_rotvec(e[k, 3:].T)).as_rotvec().T
+            self.bel[Pose3][:len(ls)].copy_(self.torch.as_tensor(b))
 
     def belief_stats(self, vartype):
         """(mean [V,dim], std [V,dim]) of every belief of one variable type, on device."""
