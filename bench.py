@@ -121,8 +121,12 @@ def main():
         # torch.distributed's collective is the fallback if the direct binding cannot be set up on every rank
         comms = None
         if os.environ.get("ROME_BENCH_TORCH_COLLECTIVE") != "1":
-            from rome_jl_amd.rccl import create_comms
-            comms = create_comms(torch, dist, world, rank, dev, depth)
+            try:
+                from rome_jl_amd.rccl import create_comms
+                comms = create_comms(torch, dist, world, rank, dev, depth)
+            except Exception as e:   # noqa: BLE001  (create_comms agrees on failure across ranks itself; this is the last resort)
+                print("direct RCCL binding unavailable (%r): using torch.distributed collectives" % (e,), file=sys.stderr)
+                comms = None
         pipe = PipelinedSegmentSweep(dg, opts, dist, world, rank, [conv_first, conv_last],
                                      pk.index["ghost_prev"], pk.index["ghost_next"], always_collective=(world == 1),
                                      depth=depth, rccl_comms=comms)
