@@ -241,7 +241,7 @@ class DeviceGraph:
 
     def solve(self, opts, n_sweeps=10, bandwidth="silverman"):
         """n_sweeps x (convolution sweep, product): whole-graph nonparametric inference stand-in for the
-        clique-by-clique Gibbs of `solveTree!` (no Bayes tree; see DESIGN.md §10)."""
+        clique-by-clique Gibbs of `solveTree!` (no Bayes tree; see DESIGN.md §11)."""
         for s in range(n_sweeps):
             self.conv_step(opts, s)
             self.product_step(opts, s, bandwidth)
