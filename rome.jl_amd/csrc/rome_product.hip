@@ -344,8 +344,11 @@ __device__ __forceinline__ void proposal_bandwidth_se3(const ProductArgs& a, int
     h[k] = fmax(a.c_n * fast_sqrt(fmax(0.0, (s[2 * k + 1] - s[2 * k] * s[2 * k] * a.inv_n) * a.inv_nm1)), 1e-6);
 }
 
+#ifndef ROME_PROD3_MINBLK
+#define ROME_PROD3_MINBLK 3   // blocks per CU: 3 waves/SIMD (168 VGPRs, a few spills) measured 1.67 ms vs 2.10 (2) and 2.49 (4) on the 10^4-pose helix
+#endif
 template <int S>
-__global__ void __launch_bounds__(64 * kProdWaves) k_product_se3(const ProductArgs a) {
+__global__ void __launch_bounds__(64 * kProdWaves, ROME_PROD3_MINBLK) k_product_se3(const ProductArgs a) {
   constexpr int D = 6;
   constexpr int T4 = (S + kProdWaves - 1) / kProdWaves;
   __shared__ double pts[kProdWaves][7][64 * S];   // every wave stages (t, q) of the points of its proposal
