@@ -570,6 +570,9 @@ struct P3P3 {
 // ------------------------------------------------------------------------------------------
 // the convolution kernel
 // ------------------------------------------------------------------------------------------
+#ifndef ROME_P3_MINBLK
+#define ROME_P3_MINBLK 3   // Pose3Pose3 closed form / Newton at 3 waves/SIMD: Newton 0.258 -> 0.244 ms on the helix (168 VGPRs, 116 B scratch)
+#endif
 #ifndef ROME_MIN_WAVES
 #define ROME_MIN_WAVES 1
 #endif
@@ -580,7 +583,7 @@ template <class FP, int SOLVER, int PPL>
 // Nelder-Mead on the 2-D/3-D factors is latency-bound (long dependent select/compare chains): asking for 4 waves/SIMD
 // (<= 128 VGPRs) is 5 % faster there; the Newton / closed-form kernels are issue-bound and lose 5-40 % when capped.
 // (the SE(3) kernels need their 256 VGPRs: capped at 3-4 waves/SIMD they spill and run 2.7x slower)
-__global__ void __launch_bounds__(64 * ROME_WPB, (SOLVER == kSolverNelderMead && FP::DT <= 3) ? 4 : ROME_MIN_WAVES)
+__global__ void __launch_bounds__(64 * ROME_WPB, (SOLVER == kSolverNelderMead && FP::DT <= 3) ? 4 : ((SOLVER != kSolverNelderMead && FP::DT == 6) ? ROME_P3_MINBLK : ROME_MIN_WAVES))
 k_conv(const ConvArgs a) {
   const int lane = threadIdx.x & 63;
   const int c = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * ROME_WPB + (int)(threadIdx.x >> 6));
