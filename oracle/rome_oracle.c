@@ -1106,7 +1106,7 @@ int ro_kde_max(int dim, int V, int N, const double* bel /*[V][dim][N]*/, const d
     double lo = x[0], hi = x[0];
     for (int i = 1; i < N; ++i) { if (x[i] < lo) lo = x[i]; if (x[i] > hi) hi = x[i]; }
     const double r = hi - lo; lo -= extend * r; hi += extend * r;
-    const double step = (hi - lo) / (G - 1), a = -0.5 / (bw[t] * bw[t]);
+    const double hb = fmax(bw[t], 1e-150), step = (hi - lo) / (G - 1), a = -0.5 / (hb * hb);
     double best = -1.0, xb = lo;
     for (int g = 0; g < G; ++g) {
       const double X = g == G - 1 ? hi : lo + g * step;

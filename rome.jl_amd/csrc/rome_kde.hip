@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64 * kKdeWaves) k_kde_max(int T, int N, int G,
   lo = wave_min(lo);
   double hi = -wave_min(nhi);
   const double r = hi - lo; lo -= extend * r; hi += extend * r;
-  const double step = (hi - lo) / (double)(G - 1), h = bw[t], a = -0.5 / (h * h);
+  const double step = (hi - lo) / (double)(G - 1), h = fmax(bw[t], 1e-150), a = -0.5 / (h * h);   // a zero bandwidth (unsolved variable) stays finite
   double X[kKdeGridSlots], y[kKdeGridSlots];
 #pragma unroll
   for (int s = 0; s < kKdeGridSlots; ++s) {

@@ -136,3 +136,10 @@ def test_kde_max_matches_oracle(N, G):
     assert same.mean() >= 0.95 and (np.abs(m - mo) <= 1.0001 * step).all()      # libm vs device exp can only flip an exact near-tie
     with pytest.raises(Exception):
         R.kde_max(bel, bw, 257)
+
+
+def test_kde_max_with_zero_bandwidth_is_finite():
+    rng = np.random.default_rng(9)
+    bel = rng.normal(size=(3, 2, 50))
+    m = R.kde_max(bel, np.zeros((3, 2)))
+    assert np.isfinite(m).all() and np.abs(m - ro.kde_max(bel, np.zeros((3, 2)))).max() < 1e-12
