@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra per-solver throughput runs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--settle-launches", type=int, default=4000,
+                    help="untimed launches BEFORE the --warmup steps so that the device reaches its steady clocks whatever W is "
+                         "(the first ~50-100 ms of back-to-back launches run 20-30 %% slower); 0 disables")
     return ap.parse_args()
 
 
@@ -137,6 +140,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # device settle (untimed, not part of the W warm-up steps): the first 50-100 ms of back-to-back launches run at ramping clocks
+    if args.solver != "nelder_mead":
+        for _ in range(max(0, args.settle_launches - args.warmup)):
+            sweep()
     for _ in range(args.warmup):
         sweep()
     barrier()
