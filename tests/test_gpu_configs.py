@@ -184,3 +184,26 @@ def test_helix3d_parametric_gauss_newton():
     # measured: 9.4 m dead-reckoned -> 0.9 m (the remaining error is the drift along the helix axis that odometry noise leaves
     # unobservable: closures only tie adjacent turns together)
     assert e < 1.5 and e < 0.2 * e_init and np.median(ang) < 0.08, (e_init, e, np.median(ang))
+
+
+def test_fixed_lag_example_end_to_end(tmp_path):
+    """examples/manhattan_fixedlag.py (counterpart of examples/ManhattanDatasetFixedLag.jl): incremental parse -> approxConv init ->
+    fifoFreeze -> window solve -> calcPPE / kde_bandwidth -> saveDFG + exportG2o; the archive reloads to the same graph and the
+    estimates stay on the dead-reckoned Manhattan grid."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("manhattan_fixedlag", os.path.join(root, "examples", "manhattan_fixedlag.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    fg, arch, g2o = mod.run(n_instructions=60, qfl=12, stride=15, out_prefix=str(tmp_path / "fl"), verbose=False)
+    assert len(fg.ls()) >= 50 and R.isMarginalized(fg, "x0") and not R.isMarginalized(fg, fg.ls()[-1])
+    g = R.loadDFG(arch)
+    assert g.ls() == fg.ls() and len(g.factors) == len(fg.factors)
+    assert all(np.array_equal(g.getVal(l), fg.getVal(l)) for l in fg.ls())
+    assert np.allclose(g.ppes["x5"]["default"]["suggested"], fg.ppes["x5"]["default"]["suggested"]) and (g.bws["x5"] > 0).all()
+    lines = open(g2o).read().splitlines()
+    assert sum(l.startswith("VERTEX_SE2") for l in lines) == len(fg.ls()) and sum(l.startswith("EDGE_SE2") for l in lines) == 60
+    # unit-step Manhattan world: consecutive pose estimates are ~1 m apart
+    P = np.array([fg.ppes["x%d" % k]["default"]["suggested"][:2] for k in range(len(fg.ls()))])
+    d = np.linalg.norm(np.diff(P, axis=0), axis=1)
+    assert 0.7 < np.median(d) < 1.3 and d.max() < 2.5
