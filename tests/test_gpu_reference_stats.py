@@ -98,3 +98,16 @@ def test_pose3_hexagon_chain_initialisation(case, solver):
     assert np.linalg.norm(mean[3, :3] - T[3][:3, 3]) < 3.0 and np.linalg.norm(T[3][:3, 3]) > 19.9
     # uncertainty grows along the chain
     assert np.linalg.norm(sd[6, :3]) > np.linalg.norm(sd[1, :3]) > np.linalg.norm(sd[0, :3])
+
+
+def test_bearingrange_sampling_windows():
+    """test/testBearingRange2D.jl:12-41: 100 samples of Pose2Point2BearingRange(Normal(0,0.1), Normal(20,1)) have bearing mean within 0.1,
+    std in (0.05, 0.2), range mean within 1.0 of 20, std in (0.5, 1.5).  The in-kernel sampler is observed through the closed-form
+    convolution from the identity pose: landmark = ρ (cos b, sin b)."""
+    N = 100
+    for seed in (1, 2, 3):
+        o = R.make_opts(N=N, solver=R.SOLVER_CLOSED_FORM, seed=seed)
+        out = R.conv_pose2point2br(o, 0, [[0.0, 20.0]], [[0.1, 1.0]], np.zeros((1, 3, N)), np.zeros((1, 2, N)))[0]
+        b, rho = np.arctan2(out[1], out[0]), np.hypot(out[0], out[1])
+        assert abs(b.mean()) < 0.1 and 0.05 < b.std(ddof=1) < 0.2
+        assert abs(rho.mean() - 20.0) < 1.0 and 0.5 < rho.std(ddof=1) < 1.5
