@@ -41,10 +41,28 @@ def _pose_labels(fg, prefix="x"):
 
 
 def getPPE(fg, label, key="simulated"):
-    """`getPPE(fg, label, :simulated).suggested`"""
-    if key != "simulated":
-        raise KeyError("only the :simulated reference estimates are stored on the host graph")
-    return _sim(fg)[label]
+    """`getPPE(fg, label, key).suggested`: the `:simulated` reference estimate of the canonical generators, or -- for any other
+    solveKey -- the point estimate stored by `setPPE` / `loadDFG` (fg.ppes)."""
+    if key == "simulated":
+        return _sim(fg)[label]
+    try:
+        return np.asarray(getattr(fg, "ppes", {})[label][key]["suggested"], dtype=float)
+    except KeyError:
+        raise KeyError("no %s point estimate for %s: call setPPE(fg) after a solve" % (key, label)) from None
+
+
+def setPPE(fg, labels=None, solveKey="default"):
+    """DFG `setPPE!(fg, label, solveKey)` for all (or the given) initialised variables: mean, max and suggested estimates of the
+    current beliefs, computed on the device (rome_belief_stats, rome_kde_bandwidth, rome_kde_max; api.calcPPE) and stored in fg.ppes."""
+    from . import api
+    fg.ppes = getattr(fg, "ppes", None) or {}
+    todo = [l for l in (labels or fg.ls()) if fg.isInitialized(l)]
+    for vt in {fg.variables[l] for l in todo}:
+        ls = [l for l in todo if fg.variables[l] is vt]
+        est = api.calcPPE(np.stack([fg.getVal(l) for l in ls]))
+        for i, l in enumerate(ls):
+            fg.ppes.setdefault(l, {})[solveKey] = {k: est[k][i].copy() for k in est}
+    return fg
 
 
 def _predict(factor, prev):
@@ -387,6 +405,8 @@ def exportG2o(fg, filename="/tmp/test.txt", ignorePriors=True, posePrefix="x", e
         ids.ids.update(varIntLabel)
     done = set()
     lines = []
+    if isinstance(estimates, str):     # a solveKey: the stored point estimates (reference: exportG2o(fg; solveKey=:parametric))
+        estimates = {l: getPPE(fg, l, estimates) for l in (varIntLabel or {})}
     if estimates is not None:
         if not varIntLabel:
             raise ValueError("exportG2o: vertex records need varIntLabel (as the reference's exporter does)")

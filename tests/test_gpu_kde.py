@@ -143,3 +143,23 @@ def test_kde_max_with_zero_bandwidth_is_finite():
     bel = rng.normal(size=(3, 2, 50))
     m = R.kde_max(bel, np.zeros((3, 2)))
     assert np.isfinite(m).all() and np.abs(m - ro.kde_max(bel, np.zeros((3, 2)))).max() < 1e-12
+
+
+def test_setppe_getppe_and_export_by_solvekey(tmp_path):
+    """DFG setPPE! / getPPE on the host mirror (device-computed estimates) and exportG2o(..., estimates=<solveKey>), the call sequence of
+    test/testG2oExportSE3.jl:23-31."""
+    fg = R.generateGraph_Hexagonal(N=100)
+    R.dead_reckon_init(fg, seed=4)
+    with pytest.raises(KeyError):
+        R.getPPE(fg, "x1", "default")
+    R.setPPE(fg)
+    bel = np.stack([fg.getVal("x%d" % k) for k in range(7)])
+    est = R.calcPPE(bel)
+    for k in range(7):
+        assert np.array_equal(R.getPPE(fg, "x%d" % k, "default"), est["suggested"][k])
+        assert set(fg.ppes["x%d" % k]["default"]) == {"mean", "max", "suggested"}
+    assert R.getPPE(fg, "l1", "default").shape == (2,)
+    out = str(tmp_path / "e.g2o")
+    R.exportG2o(fg, filename=out, estimates="default", varIntLabel={"x%d" % k: k for k in range(7)})
+    v = [l.split() for l in open(out).read().splitlines() if l.startswith("VERTEX_SE2")]
+    assert len(v) == 7 and np.allclose([float(x) for x in v[3][2:5]], est["suggested"][3])
