@@ -25,6 +25,7 @@ from .convolution import approxConv, approxConvBelief
 from .serialization import loadDFG, saveDFG, packFactor, unpackFactor, packBelief, unpackBelief
 from .parametric import solveGraphParametric, initParametric
 from .device import DeviceGraph
+from .solve import initAll, solveGraph
 from . import distributed
 
 

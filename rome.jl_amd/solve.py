@@ -1,0 +1,63 @@
+"""Convenience drivers around the hot path (host control flow only; every computation is a device launch).
+
+`initAll` is the counterpart of IIF `initAll!` / `doautoinit!` (graphinit): variables are initialised in graph order by
+convolving a factor whose other variables already have beliefs (priors first).  `solveGraph` strings the pieces a `solveTree!`
+user calls implicitly: initialisation, (optionally) the parametric solve as a starting point, the device-resident non-parametric
+sweeps of DeviceGraph.solve -- a STAND-IN for the Bayes-tree solver --, download and point estimates."""
+import numpy as np
+
+from .convolution import approxConv
+from .factors import _PriorFactor
+
+
+def initAll(fg, seed=1, solver=None):
+    """Initialise every variable that can be reached: priors are sampled, then each uninitialised variable takes the proposal of
+    the FIRST factor (in insertion order) that links it to initialised variables -- IIF multiplies the proposals of all such
+    factors (`predictbelief`); with one odometry chain per variable, the usual case at graph-init time, the two coincide.
+    Returns the labels that are still uninitialised (disconnected from every prior)."""
+    kw = {} if solver is None else {"solver": solver}
+    k = 0
+    changed = True
+    while changed:
+        changed = False
+        for flabel, labels, f in fg.factors:
+            if isinstance(f, _PriorFactor):
+                if not fg.isInitialized(labels[0]):
+                    fg.initVariable(labels[0], approxConv(fg, flabel, labels[0], seed=seed + k, **kw)); k += 1; changed = True
+                continue
+            mh = fg.multihypo.get(flabel)
+            cand = labels[:2] if mh is None else labels[:1]       # multihypo factors only initialise their pose
+            for t in cand:
+                others = [l for l in labels if l != t]
+                if not fg.isInitialized(t) and all(fg.isInitialized(o) for o in (others if mh is None else others[:1])):
+                    if mh is not None and not all(fg.isInitialized(o) for o in others):
+                        continue
+                    fg.initVariable(t, approxConv(fg, flabel, t, seed=seed + k, **kw)); k += 1; changed = True
+    return [l for l in fg.ls() if not fg.isInitialized(l)]
+
+
+def solveGraph(fg, n_sweeps=10, seed=0x524F4D45, init="graph", bandwidth="silverman", frozen=None, opts=None):
+    """initialise -> device sweeps -> download -> setPPE.  init: "graph" (initAll for whatever has no belief yet), "parametric"
+    (beliefs around solveGraphParametric's solution, like IIF's initParametricFrom!) or None (beliefs must exist).
+    Returns the DeviceGraph (beliefs stay resident for further sweeps)."""
+    from .api import make_opts
+    from .canonical import setPPE
+    from .device import DeviceGraph
+    if init not in ("graph", "parametric", None):
+        raise ValueError("init must be 'graph', 'parametric' or None")
+    if init is not None:
+        left = initAll(fg, seed=seed & 0xFFFF)
+        if left:
+            raise ValueError("variables without a path to a prior: %s" % left[:5])
+    dg = DeviceGraph(fg)
+    if init == "parametric":
+        from .parametric import solveGraphParametric
+        dg.init_from_means(solveGraphParametric(fg))
+    else:
+        dg.upload_beliefs(fg)
+    if frozen:
+        dg.set_frozen(frozen)
+    dg.solve(opts if opts is not None else make_opts(N=fg.N, seed=seed), n_sweeps=n_sweeps, bandwidth=bandwidth)
+    dg.download_beliefs(fg)
+    setPPE(fg)
+    return dg

@@ -461,3 +461,27 @@ def test_pose3_solve_loop_on_a_small_helix():
     b2 = dg2.bel[R.Pose3].cpu().numpy()
     s1 = b2[:, :3].std(2).mean()
     assert np.isfinite(b2).all() and 0.02 < s1 < s0, (s0, s1)
+
+
+def test_initall_and_solvegraph_hexagonal():
+    """initAll (graph init by factor convolutions, IIF doautoinit!) + solveGraph (init -> sweeps -> download -> setPPE) on the canonical
+    hexagon: every variable gets a belief from the prior outwards, and the solved point estimates sit in the reference's windows."""
+    fg = R.generateGraph_Hexagonal(N=100)
+    assert not any(fg.isInitialized(l) for l in fg.ls())
+    assert R.initAll(fg, seed=3) == []
+    assert all(fg.isInitialized(l) for l in fg.ls())
+    m1 = fg.getVal("x1").mean(1)
+    assert np.abs(m1[:2] - [10.0, 0.0]).max() < 1.0 and abs(m1[2] - np.pi / 3) < 0.3     # prior ∘ first odometry leg
+    fg2 = R.generateGraph_Hexagonal(N=100)
+    R.solveGraph(fg2, n_sweeps=12, seed=2026)
+    truth = {"x0": (0, 0, 0), "x1": (10, 0, np.pi / 3), "x2": (15, 8.66, 2 * np.pi / 3), "x4": (0, 17.32, -2 * np.pi / 3), "x6": (0, 0, 0)}
+    for l, (x, y, th) in truth.items():
+        p = R.getPPE(fg2, l, "default")
+        assert abs(p[0] - x) < 3 and abs(p[1] - y) < 3 and abs(np.arctan2(np.sin(p[2] - th), np.cos(p[2] - th))) < 0.3, (l, p)
+    pl = R.getPPE(fg2, "l1", "default")
+    assert abs(pl[0] - 20) < 3 and abs(pl[1]) < 3
+    fg3 = R.initfg(50); fg3.addVariable("a", R.Pose2); fg3.addVariable("b", R.Pose2)
+    fg3.addFactor(["a", "b"], R.Pose2Pose2())
+    assert set(R.initAll(fg3)) == {"a", "b"}                      # no prior anywhere
+    with pytest.raises(ValueError):
+        R.solveGraph(fg3)
