@@ -53,6 +53,12 @@ def test_no_cpu_fallback():
         R.DeviceGraph(R.generateGraph_Hexagonal())
     with pytest.raises(R.RomeError):
         R.residual_pose2pose2([[0, 0, 0]], [[0, 0, 0]], [[0, 0, 0]])
+    bel = np.zeros((1, 3, 10)); bel[0, :, 1:] = 1.0
+    for call in (lambda: R.kde_bandwidth(bel), lambda: R.kde_max(bel, np.ones((1, 3))), lambda: R.calcPPE(bel), lambda: R.belief_stats(bel),
+                 lambda: R.initAll(R.generateGraph_Hexagonal()), lambda: R.solveGraph(R.generateGraph_Hexagonal()),
+                 lambda: R.setPPE(R.dead_reckon_init(R.generateGraph_Hexagonal()))):
+        with pytest.raises((R.RomeError, RuntimeError)):
+            call()
     src = "".join(open(os.path.join(ROOT, "rome.jl_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "rome.jl_amd")) if f.endswith(".py"))
     assert "import oracle" not in src and "from oracle" not in src
 
