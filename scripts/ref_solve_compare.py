@@ -62,7 +62,7 @@ for init in ("dead_reckoning", "parametric"):
     for chunk in (10, 40, 150, 800):
         torch.cuda.synchronize(); t = time.perf_counter()
         for s in range(chunk):
-            dg.conv_step(o, tot + s); dg.product_step(o, tot + s)
+            dg.conv_step(o, tot + s); dg.product_step(o, tot + s, os.environ.get("ROME_BW", "silverman"))
         torch.cuda.synchronize(); dt = time.perf_counter() - t
         tot += chunk
         m, sd = dg.belief_stats(R.Pose2)
