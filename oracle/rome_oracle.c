@@ -56,21 +56,39 @@ static inline double u53(uint32_t hi, uint32_t lo) { /* (0,1] */
  * (32-bit uniforms: u1 = (w+1)/2^32 in (0,1], u2 = (w+0.5)/2^32; |n| <= 6.66 sigma).
  * Replaces `rand(MvNormal)` of ⚠IIF sampleTangent / RoME getSample
  * (src/factors/BearingRange2D.jl:17-27); the reference's stream is unseeded -> unpinned. */
-void ro_rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, int d, double* out) {
+static void ro_noise_words(uint64_t seed, uint64_t stream, uint32_t particle, uint32_t b, uint32_t w[4]) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t ctr[4] = {particle, (uint32_t)stream, (uint32_t)(stream >> 32), ((uint32_t)RO_DOMAIN_NOISE << 16) | b};
+  ro_philox4x32_10(ctr, key, w);
+}
+static void ro_box_muller(uint32_t wa, uint32_t wb, double* n0, double* n1) {
+  double u1 = ((double)wa + 1.0) * (1.0 / 4294967296.0);
+  double u2 = ((double)wb + 0.5) * (1.0 / 4294967296.0);
+  double rr = sqrt(-2.0 * log(u1));
+  double a = 2.0 * RO_PI * u2;
+  *n0 = rr * cos(a); *n1 = rr * sin(a);
+}
+/* d == 3: particles p and p ^ 64 share the second Box-Muller pair of the call of particle p & ~64 (cosine branch for bit 6 clear,
+ * sine branch otherwise) instead of each discarding one normal -- same rule as rng_normals<3> in the HIP path. */
+void ro_rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, int d, double* out) {
+  if (d == 3) {
+    uint32_t w[4], wb[4];
+    double c, s;
+    ro_noise_words(seed, stream, particle, 0, w);
+    ro_box_muller(w[0], w[1], &out[0], &out[1]);
+    if (particle & 64u) { ro_noise_words(seed, stream, particle & ~64u, 0, wb); ro_box_muller(wb[2], wb[3], &c, &s); out[2] = s; }
+    else { ro_box_muller(w[2], w[3], &c, &s); out[2] = c; }
+    return;
+  }
   int ncall = (d + 3) / 4;
   for (int b = 0; b < ncall; ++b) {
-    uint32_t ctr[4] = {particle, (uint32_t)stream, (uint32_t)(stream >> 32),
-                       ((uint32_t)RO_DOMAIN_NOISE << 16) | (uint32_t)b};
     uint32_t w[4];
-    ro_philox4x32_10(ctr, key, w);
+    ro_noise_words(seed, stream, particle, (uint32_t)b, w);
     for (int p = 0; p < 2 && 4 * b + 2 * p < d; ++p) {
-      double u1 = ((double)w[2 * p] + 1.0) * (1.0 / 4294967296.0);
-      double u2 = ((double)w[2 * p + 1] + 0.5) * (1.0 / 4294967296.0);
-      double rr = sqrt(-2.0 * log(u1));
-      double a = 2.0 * RO_PI * u2;
-      out[4 * b + 2 * p] = rr * cos(a);
-      if (4 * b + 2 * p + 1 < d) out[4 * b + 2 * p + 1] = rr * sin(a);
+      double n0, n1;
+      ro_box_muller(w[2 * p], w[2 * p + 1], &n0, &n1);
+      out[4 * b + 2 * p] = n0;
+      if (4 * b + 2 * p + 1 < d) out[4 * b + 2 * p + 1] = n1;
     }
   }
 }

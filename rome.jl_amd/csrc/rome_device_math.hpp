@@ -158,29 +158,64 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {  // (0,1]
   return (double)((x >> 11) + 1) * (1.0 / 9007199254740992.0);
 }
 
-// D standard normals for (seed, stream, particle): Box-Muller on Philox words, two pairs per Philox call
-// (32-bit uniforms: u1 = (w+1)/2^32 in (0,1], u2 = (w+0.5)/2^32; |n| <= 6.66 σ).  One call serves Pose2 / Point2.
+// One Box-Muller pair from two Philox words (32-bit uniforms: u1 = (w+1)/2^32 in (0,1], u2 = (w+0.5)/2^32; |n| <= 6.66 σ)
+__device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, double* n0, double* n1) {
+  const double u1 = ((double)wa + 1.0) * (1.0 / 4294967296.0);
+  const double u2 = ((double)wb + 0.5) * (1.0 / 4294967296.0);
+  const double rr = fast_sqrt(-2.0 * fast_log(u1));
+  double s, c;
+  fast_sincos(2.0 * kPi * u2, &s, &c);
+  *n0 = rr * c; *n1 = rr * s;
+}
+__device__ __forceinline__ u32x4 noise_words(uint64_t seed, uint64_t stream, uint32_t particle, uint32_t b) {
+  return philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32), (kDomainNoise << 16) | b},
+                       (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// D standard normals for (seed, stream, particle): Box-Muller on Philox words, two pairs per Philox call.
+// D == 3 (Pose2 measurements and jitters) would discard one normal of its second pair; instead particles p and p ^ 64 -- the two
+// slots of one lane in the convolution kernels -- SHARE that pair: normals 0, 1 come from words (x, y) of the particle's own call,
+// normal 2 from words (z, w) of the call of particle p & ~64, its cosine branch for p & 64 == 0, its sine branch otherwise.  The two
+// branches of a Box-Muller pair are independent N(0,1), the rule depends on the particle id only (not on N or the launch shape), and
+// a lane then evaluates three pairs for its two particles instead of four (rng_normals3_pair).  Oracle: ro_rng_normals.
 template <int D>
 __device__ __forceinline__ void rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, double (&out)[D]) {
-  constexpr int NC = (D + 3) / 4;
+  if constexpr (D == 3) {
+    const u32x4 w = noise_words(seed, stream, particle, 0u);
+    box_muller(w.x, w.y, &out[0], &out[1]);
+    double c, s;
+    if (particle & 64u) {
+      const u32x4 wb = noise_words(seed, stream, particle & ~64u, 0u);
+      box_muller(wb.z, wb.w, &c, &s);
+      out[2] = s;
+    } else {
+      box_muller(w.z, w.w, &c, &s);
+      out[2] = c;
+    }
+  } else {
+    constexpr int NC = (D + 3) / 4;
 #pragma unroll
-  for (int b = 0; b < NC; ++b) {
-    const u32x4 w = philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32), (kDomainNoise << 16) | (uint32_t)b},
-                                  (uint32_t)seed, (uint32_t)(seed >> 32));
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    for (int b = 0; b < NC; ++b) {
+      const u32x4 w = noise_words(seed, stream, particle, (uint32_t)b);
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      if (4 * b + 2 * p < D) {
-        const double u1 = ((double)ww[2 * p] + 1.0) * (1.0 / 4294967296.0);
-        const double u2 = ((double)ww[2 * p + 1] + 0.5) * (1.0 / 4294967296.0);
-        const double rr = fast_sqrt(-2.0 * fast_log(u1));
-        double s, c;
-        fast_sincos(2.0 * kPi * u2, &s, &c);
-        out[4 * b + 2 * p] = rr * c;
-        if (4 * b + 2 * p + 1 < D) out[4 * b + 2 * p + 1] = rr * s;
+      for (int p = 0; p < 2; ++p) {
+        if (4 * b + 2 * p < D) {
+          double n0, n1;
+          box_muller(ww[2 * p], ww[2 * p + 1], &n0, &n1);
+          out[4 * b + 2 * p] = n0;
+          if (4 * b + 2 * p + 1 < D) out[4 * b + 2 * p + 1] = n1;
+        }
       }
     }
   }
+}
+// the D == 3 normals of particles p (bit 6 clear) and p + 64 together: two Philox calls, three Box-Muller pairs
+__device__ __forceinline__ void rng_normals3_pair(uint64_t seed, uint64_t stream, uint32_t p_even, double (&oe)[3], double (&oo)[3]) {
+  const u32x4 we = noise_words(seed, stream, p_even, 0u), wo = noise_words(seed, stream, p_even + 64u, 0u);
+  box_muller(we.x, we.y, &oe[0], &oe[1]);
+  box_muller(wo.x, wo.y, &oo[0], &oo[1]);
+  box_muller(we.z, we.w, &oe[2], &oo[2]);
 }
 
 // Entropy-inflation uniforms (IIF addEntropyOnManifold!: spread·(rand(d) .- 0.5)).  The jitter only

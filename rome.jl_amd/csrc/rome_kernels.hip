@@ -603,6 +603,7 @@ k_conv(const ConvArgs a) {
   typename FP::Prep prep[PPL];
   typename FP::Aux aux[PPL];   // state a policy keeps beside the coordinates (Pose3: the rotation as a unit quaternion)
   bool act[PPL];
+  [[maybe_unused]] double xi_odd[3];   // normals of the odd slot, produced together with the even slot's (shared Box-Muller pair)
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     const int i = lane + 64 * k;
@@ -617,6 +618,10 @@ k_conv(const ConvArgs a) {
       const double* nb = a.noise + (size_t)c * FP::DZ * N;
 #pragma unroll
       for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
+    } else if constexpr (FP::DZ == 3 && PPL >= 2) {
+      // slots k (even) and k+1 of a lane are particles p and p+64: they share the third Box-Muller pair (rng_normals)
+      if ((k & 1) == 0) rng_normals3_pair(a.seed, stream, (uint32_t)i, xi, xi_odd);
+      else { xi[0] = xi_odd[0]; xi[1] = xi_odd[1]; xi[2] = xi_odd[2]; }
     } else {
       rng_normals<FP::DZ>(a.seed, stream, (uint32_t)ii, xi);
     }
