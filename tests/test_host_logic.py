@@ -208,6 +208,15 @@ def test_entropy_rng_definition():
     u = ro.rng_entropy(7, 3, 5, 0, 3); v = ro.rng_entropy(7, 3, 5, 1, 3); w = ro.rng_entropy(7, 3, 5, 3, 3)
     assert ((u > 0) & (u < 1)).all() and not np.allclose(u, v) and not np.allclose(u, w)
     assert np.allclose(u * 16384 - 0.5, np.round(u * 16384 - 0.5))     # 14-bit fields
+    # normals, d = 3: 0, 1 from the particle's own call; 2 = cosine / sine branch of the second Box-Muller pair of the call made for
+    # particle p & ~64 (Philox domain 1): particles p and p ^ 64 share that pair
+    a, b = ro.rng_normals(7, 3, 5, 3), ro.rng_normals(7, 3, 5 + 64, 3)
+    w5 = ro.philox([5, 3, 0, (1 << 16) | 0], [7, 0])
+    rr = np.sqrt(-2 * np.log((w5[2] + 1.0) / 2 ** 32)); ang = 2 * np.pi * (w5[3] + 0.5) / 2 ** 32
+    assert abs(a[2] - rr * np.cos(ang)) < 1e-14 and abs(b[2] - rr * np.sin(ang)) < 1e-14 and not np.allclose(a[:2], b[:2])
+    n3 = np.array([ro.rng_normals(11, 2, i, 3) for i in range(2048)])
+    assert np.abs(n3.mean(0)).max() < 0.08 and np.abs(n3.std(0) - 1).max() < 0.06
+    assert abs(np.corrcoef(n3[:64, 2], n3[64:128, 2])[0, 1]) < 0.35              # the two branches of a shared pair are uncorrelated
     u6 = ro.rng_entropy(7, 3, 5, 2, 6)
     assert np.allclose(u6 * (1 << 21) - 0.5, np.round(u6 * (1 << 21) - 0.5))
     allu = np.array([ro.rng_entropy(1, 0, i, c, 3) for i in range(400) for c in range(6)])
