@@ -644,7 +644,6 @@ k_conv(const ConvArgs a) {
 #pragma unroll
   for (int k = 0; k < PPL; ++k) sel[k] = true;
   double nh_spread = 0.0;
-  uint32_t nh_w1[PPL], nh_w2[PPL];
   if constexpr (FP::kHypoDir >= 0) {
     const int av = a.alt_var ? a.alt_var[c] : -1;
     if (av >= 0) {  // wave-uniform
@@ -656,7 +655,6 @@ k_conv(const ConvArgs a) {
         const u32x4 hw = philox4x32_10(u32x4{(uint32_t)ii, (uint32_t)stream, (uint32_t)(stream >> 32), (4u << 16)},
                                        (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
         const bool primary = ((double)hw.x + 0.5) * (1.0 / 4294967296.0) < w;
-        nh_w1[k] = hw.y; nh_w2[k] = hw.z;
         if constexpr (FP::kHypoDir == 1) {
           if (!primary) {
 #pragma unroll
@@ -750,8 +748,12 @@ k_conv(const ConvArgs a) {
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       if (act[k] && !sel[k]) {  // the other hypothesis holds for this particle: entropy only
-        t[k][0] += nh_spread * (((double)nh_w1[k] + 0.5) * (1.0 / 4294967296.0) - 0.5);
-        t[k][1] += nh_spread * (((double)nh_w2[k] + 0.5) * (1.0 / 4294967296.0) - 0.5);
+        // the words of the hypothesis draw are re-drawn here (same Philox call) instead of staying live across the cycles: kept in
+        // per-slot arrays they were parked in LDS by the compiler
+        const u32x4 hw = philox4x32_10(u32x4{(uint32_t)(lane + 64 * k), (uint32_t)stream, (uint32_t)(stream >> 32), (4u << 16)},
+                                       (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+        t[k][0] += nh_spread * (((double)hw.y + 0.5) * (1.0 / 4294967296.0) - 0.5);
+        t[k][1] += nh_spread * (((double)hw.z + 0.5) * (1.0 / 4294967296.0) - 0.5);
       }
     }
   }
