@@ -207,7 +207,15 @@ def test_oracle_nelder_mead_on_rosenbrock():
 def test_entropy_rng_definition():
     u = ro.rng_entropy(7, 3, 5, 0, 3); v = ro.rng_entropy(7, 3, 5, 1, 3); w = ro.rng_entropy(7, 3, 5, 3, 3)
     assert ((u > 0) & (u < 1)).all() and not np.allclose(u, v) and not np.allclose(u, w)
-    assert np.allclose(u * 16384 - 0.5, np.round(u * 16384 - 0.5))     # 14-bit fields
+    assert np.allclose(u * 128 - 0.5, np.round(u * 128 - 0.5))         # 7-bit fields
+    # particles p and p ^ 64 read the two halves (fields 0..8 / 9..17) of the ONE Philox call made for p & ~64 (domain 2)
+    wds = ro.philox([5, 3, 0, (2 << 16) | 0], [7, 0])
+    big = sum(int(x) << (32 * i) for i, x in enumerate(wds))
+    for part, half in ((5, 0), (5 + 64, 1)):
+        for cyc in range(3):
+            got = ro.rng_entropy(7, 3, part, cyc, 3)
+            want = [(((big >> (7 * (9 * half + 3 * cyc + k))) & 127) + 0.5) / 128 for k in range(3)]
+            assert np.array_equal(got, want)
     # normals, d = 3: 0, 1 from the particle's own call; 2 = cosine / sine branch of the second Box-Muller pair of the call made for
     # particle p & ~64 (Philox domain 1): particles p and p ^ 64 share that pair
     a, b = ro.rng_normals(7, 3, 5, 3), ro.rng_normals(7, 3, 5 + 64, 3)
