@@ -96,22 +96,22 @@ void ro_rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, int d, do
 /* d uniforms in (0,1) for the entropy inflation of cycle `cycle` (⚠IIF addEntropyOnManifold!:
  * spread·(rand(d) .- 0.5); RNG stream unpinned).  Narrow uniforms packed into one Philox call:
  *   d <= 3 : 7-bit fields, 3 cycles per call, two particles (p, p ^ 64) per call (call = cycle/3, field 9*half + (cycle%3)*3 + k)
- *   d == 6 : 21-bit fields, 1 cycle per call  (call = cycle, field index k)
+ *   d == 6 : 10-bit fields, 1 cycle per call, two particles per call (call = cycle, field index 6*half + k)
  * u = (field + 0.5) / 2^bits.  Same definition as the HIP path (rome_device_math.hpp). */
 void ro_rng_entropy(uint64_t seed, uint64_t stream, uint32_t particle, int cycle, int d, double* out) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  const int bits = d <= 3 ? 7 : 21;
+  const int bits = d <= 3 ? 7 : 10;
   const int cpc = d <= 3 ? 3 : 1;
   const int call = cycle / cpc, slot = cycle % cpc;
-  /* d <= 3: particles p and p ^ 64 read the two halves (fields 0..8 / 9..17) of the call made for p & ~64 */
-  const uint32_t owner = d <= 3 ? (particle & ~64u) : particle;
-  const int half = d <= 3 ? (int)((particle >> 6) & 1u) : 0;
+  /* particles p and p ^ 64 read the two halves (d <= 3: fields 0..8 / 9..17; d == 6: fields 0..5 / 6..11) of the call made for p & ~64 */
+  const uint32_t owner = particle & ~64u;
+  const int half = (int)((particle >> 6) & 1u);
   uint32_t ctr[4] = {owner, (uint32_t)stream, (uint32_t)(stream >> 32),
                      ((uint32_t)RO_DOMAIN_ENTROPY << 16) | (uint32_t)call};
   uint32_t w[4];
   ro_philox4x32_10(ctr, key, w);
   for (int k = 0; k < d; ++k) {
-    const int pos = (d <= 3 ? (9 * half + 3 * slot + k) : k) * bits;
+    const int pos = (d <= 3 ? (9 * half + 3 * slot + k) : (6 * half + k)) * bits;
     const int wi = pos >> 5, sh = pos & 31;
     uint64_t two = (uint64_t)w[wi] | ((uint64_t)(wi + 1 < 4 ? w[wi + 1] : 0u) << 32);
     uint32_t f = (uint32_t)((two >> sh) & ((1ull << bits) - 1));

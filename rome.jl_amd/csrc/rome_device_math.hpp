@@ -221,7 +221,7 @@ __device__ __forceinline__ void rng_normals3_pair(uint64_t seed, uint64_t stream
 // Entropy-inflation uniforms (IIF addEntropyOnManifold!: spread·(rand(d) .- 0.5)).  The jitter only
 // seeds the next root-find, so narrow uniforms are drawn and ONE Philox call is shared by several cycles:
 //   D <= 3 : 7-bit fields, 3 cycles per call, two particles (p, p ^ 64) per call   (call index = cycle / 3)
-//   D == 6 : 21-bit fields, 1 cycle  per call   (126 bits)
+//   D == 6 : 10-bit fields, 1 cycle per call, two particles (p, p ^ 64) per call   (120 bits)
 // u = (field + 0.5) / 2^bits  in (0,1).
 typedef u32x4 EntropyWords;  // plain scalars (no array member: keeps the words in VGPRs, not LDS/scratch)
 __device__ __forceinline__ EntropyWords rng_entropy_words(uint64_t seed, uint64_t stream, uint32_t particle, int call) {
@@ -242,10 +242,10 @@ __device__ __forceinline__ uint32_t bitfield128(const EntropyWords& e, int pos, 
 }
 // D <= 3: 7-bit fields, nine per particle (3 cycles x 3 coordinates); particles p and p ^ 64 -- the two slots of a lane -- read the
 // two halves (fields 0..8 / 9..17) of the ONE call made for particle p & ~64, so a lane issues one entropy Philox call per three
-// cycles for its two particles (HALF = (p >> 6) & 1).  D == 6: 21-bit fields of the particle's own call, one cycle per call.
+// cycles for its two particles (HALF = (p >> 6) & 1).  D == 6: 10-bit fields, six per particle and cycle, the same sharing, one cycle per call.
 template <int D, int HALF>
 __device__ __forceinline__ void rng_entropy_from_words(const EntropyWords& e, int slot, double (&out)[D]) {
-  constexpr int BITS = D <= 3 ? 7 : 21;
+  constexpr int BITS = D <= 3 ? 7 : 10;
   // slot = cycle % 3 for D<=3 (0 for D==6); select with constant positions to keep everything in registers
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -255,7 +255,7 @@ __device__ __forceinline__ void rng_entropy_from_words(const EntropyWords& e, in
                      f2 = bitfield128(e, (9 * HALF + 2 * 3 + k) * BITS, BITS);
       f = slot == 0 ? f0 : (slot == 1 ? f1 : f2);
     } else {
-      f = bitfield128(e, k * BITS, BITS);
+      f = bitfield128(e, (6 * HALF + k) * BITS, BITS);
     }
     out[k] = ((double)f + 0.5) * (1.0 / (double)(1u << BITS));
   }

@@ -705,8 +705,8 @@ k_conv(const ConvArgs a) {
     if (spread > 0.0 && have_call != cyc / CPC) {  // wave-uniform
       have_call = cyc / CPC;
 #pragma unroll
-      for (int k = 0; k < PPL; ++k) {   // DT <= 3: slots k (even) and k+1 = particles p, p+64 share the call of p (rng_entropy_from_words)
-        if (FP::DT > 3 || (k & 1) == 0) ew[k] = rng_entropy_words(a.seed, stream, (uint32_t)(lane + 64 * k), have_call);
+      for (int k = 0; k < PPL; ++k) {   // slots k (even) and k+1 = particles p, p+64 share the call of p (rng_entropy_from_words)
+        if ((k & 1) == 0) ew[k] = rng_entropy_words(a.seed, stream, (uint32_t)(lane + 64 * k), have_call);
       }
     }
 #pragma unroll
@@ -715,7 +715,7 @@ k_conv(const ConvArgs a) {
         if (spread > 0.0) {
           double u[FP::DT];
           // k is a compile-time constant after unrolling: static indices only
-          if (FP::DT <= 3 && (k & 1)) rng_entropy_from_words<FP::DT, 1>(ew[k & ~1], cyc % CPC, u);
+          if (k & 1) rng_entropy_from_words<FP::DT, 1>(ew[k & ~1], cyc % CPC, u);
           else rng_entropy_from_words<FP::DT, 0>(ew[k], cyc % CPC, u);
           double hs, hc;
           FP::template heading_sincos<SOLVER>(K, prep[k], st[k], cyc, t[k], &hs, &hc);

@@ -226,7 +226,7 @@ def test_entropy_rng_definition():
     assert np.abs(n3.mean(0)).max() < 0.08 and np.abs(n3.std(0) - 1).max() < 0.06
     assert abs(np.corrcoef(n3[:64, 2], n3[64:128, 2])[0, 1]) < 0.35              # the two branches of a shared pair are uncorrelated
     u6 = ro.rng_entropy(7, 3, 5, 2, 6)
-    assert np.allclose(u6 * (1 << 21) - 0.5, np.round(u6 * (1 << 21) - 0.5))
+    assert np.allclose(u6 * (1 << 10) - 0.5, np.round(u6 * (1 << 10) - 0.5))           # 10-bit fields, two particles per call
     allu = np.array([ro.rng_entropy(1, 0, i, c, 3) for i in range(400) for c in range(6)])
     assert abs(allu.mean() - 0.5) < 0.02 and abs(allu.std() - 12 ** -0.5) < 0.02
 
