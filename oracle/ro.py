@@ -41,8 +41,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+        so = os.environ.get("ROME_ORACLE_SO")   # cpu_bench.py: the -O3 -march=native build made on the timing box
+        if not so:
+            build()
+            so = _SO
+        _lib = C.CDLL(so)
         _lib.ro_sym_rem.restype = C.c_double
         _lib.ro_sym_rem.argtypes = [C.c_double]
         _lib.ro_num_threads.restype = C.c_int
@@ -71,6 +74,12 @@ def rng_normals(seed, stream, particle, d):
     out = np.zeros(d + 1)
     lib().ro_rng_normals(C.c_uint64(seed), C.c_uint64(stream), C.c_uint32(particle), d, out.ctypes.data_as(C.POINTER(C.c_double)))
     return out[:d]
+
+
+def box_muller(wa, wb):
+    a, b = C.c_double(), C.c_double()
+    lib().ro_box_muller(C.c_uint32(wa), C.c_uint32(wb), C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def rng_entropy(seed, stream, particle, cycle, d):

@@ -52,21 +52,53 @@ static inline double u53(uint32_t hi, uint32_t lo) { /* (0,1] */
   return (double)((x >> 11) + 1) * (1.0 / 9007199254740992.0);
 }
 
-/* d standard normals for (seed, stream, particle): Box-Muller on Philox words, two pairs per Philox call
- * (32-bit uniforms: u1 = (w+1)/2^32 in (0,1], u2 = (w+0.5)/2^32; |n| <= 6.66 sigma).
- * Replaces `rand(MvNormal)` of ⚠IIF sampleTangent / RoME getSample
- * (src/factors/BearingRange2D.jl:17-27); the reference's stream is unseeded -> unpinned. */
+/* d standard normals for (seed, stream, particle): Box-Muller on Philox words, two pairs per Philox call.
+ * Replaces `rand(MvNormal)` of ⚠IIF sampleTangent / RoME getSample (src/factors/BearingRange2D.jl:17-27); the
+ * reference's stream is unseeded -> unpinned.  The transform is DEFINED in IEEE single-precision operations (every
+ * multiply-add an explicit fmaf, the file is built with -ffp-contract=off) so that the HIP path evaluates the same
+ * function bit for bit up to its final double-precision square root and products:
+ *   radius   u1 = x·2^-32, x = float(wa) + 1 in [1, 2^32]  (|n| <= 6.66 sigma);  -ln u1 = (32 - e) ln2 - ln m with
+ *            x = m·2^e, m in [1,2), ln m by a degree-7 polynomial in m - 1.5 (|error| <= 2.7e-7);
+ *   angle    a = (π/4)·int32(wb << 2)·2^-31 in [-π/4, π/4) from the low 30 bits of wb, (c, s) = (cos a, sin a) by the
+ *            Cephes single-precision kernels; the direction (c - s, c + s)/√2 is the angle π/4 + a, uniform on the first
+ *            quadrant, and bits 31 / 30 of wb mirror it into the other three;
+ *   normals  n0 = ±√(-ln u1)·(c - s),  n1 = ±√(-ln u1)·(c + s)   (n0² + n1² = -2 ln u1 exactly as in Box-Muller).
+ * The draws carry 24-bit mantissas in a double; their law differs from N(0,1) by < 1e-6 in Kolmogorov distance
+ * (tests/test_host_logic.py::test_normal_generator_law).  FP64 Box-Muller cost the HIP path ~135 VALU instructions per
+ * pair, this form ~50 (profiles/r02_*). */
+static inline float ro_bits_f32(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
+static inline uint32_t ro_f32_bits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
 static void ro_noise_words(uint64_t seed, uint64_t stream, uint32_t particle, uint32_t b, uint32_t w[4]) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
   uint32_t ctr[4] = {particle, (uint32_t)stream, (uint32_t)(stream >> 32), ((uint32_t)RO_DOMAIN_NOISE << 16) | b};
   ro_philox4x32_10(ctr, key, w);
 }
-static void ro_box_muller(uint32_t wa, uint32_t wb, double* n0, double* n1) {
-  double u1 = ((double)wa + 1.0) * (1.0 / 4294967296.0);
-  double u2 = ((double)wb + 0.5) * (1.0 / 4294967296.0);
-  double rr = sqrt(-2.0 * log(u1));
-  double a = 2.0 * RO_PI * u2;
-  *n0 = rr * cos(a); *n1 = rr * sin(a);
+void ro_box_muller(uint32_t wa, uint32_t wb, double* n0, double* n1) {
+  const float x = (float)wa + 1.0f;
+  const uint32_t xb = ro_f32_bits(x);
+  const float ke = (float)(int32_t)(159u - (xb >> 23));                 /* 32 - e */
+  const float t = ro_bits_f32((xb & 0x007FFFFFu) | 0x3F800000u) - 1.5f;
+  float p = 0x1.4fab76p-7f;
+  p = fmaf(p, t, -0x1.1d4ffp-6f);
+  p = fmaf(p, t, 0x1.a972ep-6f);
+  p = fmaf(p, t, -0x1.90d3ap-5f);
+  p = fmaf(p, t, 0x1.94a6a8p-4f);
+  p = fmaf(p, t, -0x1.c72898p-3f);
+  p = fmaf(p, t, 0x1.555544p-1f);
+  p = fmaf(p, t, 0x1.9f324cp-2f);                                       /* ln m */
+  const float h = fmaf(ke, 0x1.62e43p-1f, -p);                          /* -ln u1 (ln2 rounded to single) */
+  const double rr = h > 0.0f ? sqrt((double)h) : 0.0;
+  const float a = (float)(int32_t)(wb << 2) * 0x1.921fb6p-32f;           /* (π/4)·2^-31 */
+  const float z = a * a;
+  float sp = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  sp = fmaf(z, sp, -1.6666654611e-1f);
+  const float sn = fmaf(z * a, sp, a);
+  float cp = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  cp = fmaf(z, cp, 4.166664568298827e-2f);
+  const float cs = fmaf(z * z, cp, fmaf(z, -0.5f, 1.0f));
+  const double d0 = (double)(cs - sn), d1 = (double)(cs + sn);
+  *n0 = (wb & 0x80000000u) ? -(rr * d0) : rr * d0;
+  *n1 = (wb & 0x40000000u) ? -(rr * d1) : rr * d1;
 }
 /* d == 3: particles p and p ^ 64 share the second Box-Muller pair of the call of particle p & ~64 (cosine branch for bit 6 clear,
  * sine branch otherwise) instead of each discarding one normal -- same rule as rng_normals<3> in the HIP path. */
@@ -94,28 +126,20 @@ void ro_rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, int d, do
 }
 
 /* d uniforms in (0,1) for the entropy inflation of cycle `cycle` (⚠IIF addEntropyOnManifold!:
- * spread·(rand(d) .- 0.5); RNG stream unpinned).  Narrow uniforms packed into one Philox call:
- *   d <= 3 : 7-bit fields, 3 cycles per call, two particles (p, p ^ 64) per call (call = cycle/3, field 9*half + (cycle%3)*3 + k)
- *   d == 6 : 10-bit fields, 1 cycle per call, two particles per call (call = cycle, field index 6*half + k)
- * u = (field + 0.5) / 2^bits.  Same definition as the HIP path (rome_device_math.hpp). */
+ * spread·(rand(d) .- 0.5); RNG stream unpinned): one Philox call per particle and cycle (two for d = 6), one 32-bit word
+ * per coordinate, u = (w + 0.5)/2^32.  Counter = (particle, stream, domain 2 | 2·cycle + block).
+ * The HIP path draws exactly these wherever the jitter can reach the proposal (Nelder-Mead, the bearing-range pose
+ * direction with its one-parameter family of roots); for Newton / closed form on the unique-root factors the start point
+ * never reaches the result, so there it jitters with cheaper, narrower uniforms -- a difference the parity tests cannot
+ * and need not see (Newton == closed form to 1e-9, tests/test_gpu_parity.py). */
 void ro_rng_entropy(uint64_t seed, uint64_t stream, uint32_t particle, int cycle, int d, double* out) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  const int bits = d <= 3 ? 7 : 10;
-  const int cpc = d <= 3 ? 3 : 1;
-  const int call = cycle / cpc, slot = cycle % cpc;
-  /* particles p and p ^ 64 read the two halves (d <= 3: fields 0..8 / 9..17; d == 6: fields 0..5 / 6..11) of the call made for p & ~64 */
-  const uint32_t owner = particle & ~64u;
-  const int half = (int)((particle >> 6) & 1u);
-  uint32_t ctr[4] = {owner, (uint32_t)stream, (uint32_t)(stream >> 32),
-                     ((uint32_t)RO_DOMAIN_ENTROPY << 16) | (uint32_t)call};
-  uint32_t w[4];
-  ro_philox4x32_10(ctr, key, w);
-  for (int k = 0; k < d; ++k) {
-    const int pos = (d <= 3 ? (9 * half + 3 * slot + k) : (6 * half + k)) * bits;
-    const int wi = pos >> 5, sh = pos & 31;
-    uint64_t two = (uint64_t)w[wi] | ((uint64_t)(wi + 1 < 4 ? w[wi + 1] : 0u) << 32);
-    uint32_t f = (uint32_t)((two >> sh) & ((1ull << bits) - 1));
-    out[k] = ((double)f + 0.5) / (double)(1u << bits);
+  for (int b = 0; 3 * b < d; ++b) {
+    uint32_t ctr[4] = {particle, (uint32_t)stream, (uint32_t)(stream >> 32),
+                       ((uint32_t)RO_DOMAIN_ENTROPY << 16) | (uint32_t)(2 * cycle + b)};
+    uint32_t w[4];
+    ro_philox4x32_10(ctr, key, w);
+    for (int k = 3 * b; k < d && k < 3 * b + 3; ++k) out[k] = ((double)w[k - 3 * b] + 0.5) * (1.0 / 4294967296.0);
   }
 }
 
@@ -558,7 +582,11 @@ static inline int get_idx(const int32_t* a, int c) { return a ? a[c] : c; }
 static double frechet_std(const double* sd, int d) {
   double v = 0.0;
   for (int k = 0; k < d; ++k) v += sd[k] * sd[k];
-  return sqrt(v);
+  v = sqrt(v);
+  /* ⚠IIF calcStdBasicSpread: "if no std yet, set to 1" (msst = 1e-10 < σ ? σ : 1.0): a belief whose particles coincide
+   * (approxConv / initVariable on an all-zero start) still gets jittered, so the one-parameter root family of the
+   * bearing-range pose direction is spread around the landmark instead of collapsing onto one ray. */
+  return v > 1e-10 ? v : 1.0;
 }
 
 /* nullhypo draw for particle i of stream st: -> 1 if the factor does NOT apply; u[0..d-1] entropy uniforms

@@ -41,6 +41,7 @@ typedef struct {
 
 /* ---- counter-based RNG (shared definition with the HIP path) ---- */
 void ro_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void ro_box_muller(uint32_t wa, uint32_t wb, double* n0, double* n1);
 void ro_rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, int d, double* out);
 void ro_rng_entropy(uint64_t seed, uint64_t stream, uint32_t particle, int cycle, int d, double* out);
 

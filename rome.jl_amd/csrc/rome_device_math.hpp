@@ -158,14 +158,44 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {  // (0,1]
   return (double)((x >> 11) + 1) * (1.0 / 9007199254740992.0);
 }
 
-// One Box-Muller pair from two Philox words (32-bit uniforms: u1 = (w+1)/2^32 in (0,1], u2 = (w+0.5)/2^32; |n| <= 6.66 σ)
+// One Box-Muller pair from two Philox words.  The transform is defined in IEEE single-precision operations (explicit fmaf
+// only, contraction off) -- the same function, bit for bit, as ro_box_muller in oracle/rome_oracle.c up to the final
+// double-precision square root and products:
+//   radius  u1 = x·2^-32, x = float(wa) + 1 in [1, 2^32]: -ln u1 = (32 - e) ln2 - ln m, x = m·2^e, ln m a degree-7 polynomial
+//           in m - 1.5 (|error| <= 2.7e-7; no division, no library log);
+//   angle   a = (π/4)·int32(wb << 2)·2^-31 in [-π/4, π/4): the direction (cos a - sin a, cos a + sin a)/√2 is the angle π/4 + a,
+//           uniform on the first quadrant; bits 31 / 30 of wb mirror it into the other three (no range reduction at all);
+//   n0 = ±√(-ln u1)·(c - s), n1 = ±√(-ln u1)·(c + s).
+// ≈ 50 VALU instructions per pair (the FP64 log / sqrt / sincos form this replaces: ≈ 135); draws carry 24-bit mantissas.
 __device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, double* n0, double* n1) {
-  const double u1 = ((double)wa + 1.0) * (1.0 / 4294967296.0);
-  const double u2 = ((double)wb + 0.5) * (1.0 / 4294967296.0);
-  const double rr = fast_sqrt(-2.0 * fast_log(u1));
-  double s, c;
-  fast_sincos(2.0 * kPi * u2, &s, &c);
-  *n0 = rr * c; *n1 = rr * s;
+#pragma clang fp contract(off)
+  const float x = (float)wa + 1.0f;
+  const uint32_t xb = __float_as_uint(x);
+  const float ke = (float)(int32_t)(159u - (xb >> 23));
+  const float t = __uint_as_float((xb & 0x007FFFFFu) | 0x3F800000u) - 1.5f;
+  float p = 0x1.4fab76p-7f;
+  p = __builtin_fmaf(p, t, -0x1.1d4ffp-6f);
+  p = __builtin_fmaf(p, t, 0x1.a972ep-6f);
+  p = __builtin_fmaf(p, t, -0x1.90d3ap-5f);
+  p = __builtin_fmaf(p, t, 0x1.94a6a8p-4f);
+  p = __builtin_fmaf(p, t, -0x1.c72898p-3f);
+  p = __builtin_fmaf(p, t, 0x1.555544p-1f);
+  p = __builtin_fmaf(p, t, 0x1.9f324cp-2f);
+  const float h = __builtin_fmaf(ke, 0x1.62e43p-1f, -p);
+  const double rr = fast_sqrt((double)h);      // 0 for h <= 0
+  const float a = (float)(int32_t)(wb << 2) * 0x1.921fb6p-32f;
+  const float z = a * a;
+  float sp = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  sp = __builtin_fmaf(z, sp, -1.6666654611e-1f);
+  const float sn = __builtin_fmaf(z * a, sp, a);
+  float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  cp = __builtin_fmaf(z, cp, 4.166664568298827e-2f);
+  const float cs = __builtin_fmaf(z * z, cp, __builtin_fmaf(z, -0.5f, 1.0f));
+  const double d0 = (double)(cs - sn), d1 = (double)(cs + sn);
+  // signs straight into the high words of the doubles (bit 31 of wb -> n0, bit 30 -> n1)
+  const double m0 = rr * d0, m1 = rr * d1;
+  *n0 = __hiloint2double(__double2hiint(m0) ^ (int)(wb & 0x80000000u), __double2loint(m0));
+  *n1 = __hiloint2double(__double2hiint(m1) ^ (int)((wb << 1) & 0x80000000u), __double2loint(m1));
 }
 __device__ __forceinline__ u32x4 noise_words(uint64_t seed, uint64_t stream, uint32_t particle, uint32_t b) {
   return philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32), (kDomainNoise << 16) | b},
@@ -218,8 +248,9 @@ __device__ __forceinline__ void rng_normals3_pair(uint64_t seed, uint64_t stream
   box_muller(we.z, we.w, &oe[2], &oo[2]);
 }
 
-// Entropy-inflation uniforms (IIF addEntropyOnManifold!: spread·(rand(d) .- 0.5)).  The jitter only
-// seeds the next root-find, so narrow uniforms are drawn and ONE Philox call is shared by several cycles:
+// Cheap entropy-inflation uniforms (IIF addEntropyOnManifold!: spread·(rand(d) .- 0.5)) for the kernels whose result does NOT
+// depend on the start point (Newton / closed form on a factor with a unique root; the oracle draws full 32-bit uniforms,
+// rng_entropy_exact below).  Narrow uniforms are drawn and ONE Philox call is shared by several cycles:
 //   D <= 3 : 7-bit fields, 3 cycles per call, two particles (p, p ^ 64) per call   (call index = cycle / 3)
 //   D == 6 : 10-bit fields, 1 cycle per call, two particles (p, p ^ 64) per call   (120 bits)
 // u = (field + 0.5) / 2^bits  in (0,1).
@@ -258,6 +289,20 @@ __device__ __forceinline__ void rng_entropy_from_words(const EntropyWords& e, in
       f = bitfield128(e, (6 * HALF + k) * BITS, BITS);
     }
     out[k] = ((double)f + 0.5) * (1.0 / (double)(1u << BITS));
+  }
+}
+
+// The entropy uniforms as the oracle defines them (ro_rng_entropy): one Philox call per particle and cycle (two for D = 6), one
+// 32-bit word per coordinate.  Used wherever the jitter can reach the proposal: Nelder-Mead, the bearing-range pose direction.
+template <int D>
+__device__ __forceinline__ void rng_entropy_exact(uint64_t seed, uint64_t stream, uint32_t particle, int cycle, double (&out)[D]) {
+#pragma unroll
+  for (int b = 0; 3 * b < D; ++b) {
+    const u32x4 w = philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32), (kDomainEntropy << 16) | (uint32_t)(2 * cycle + b)},
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t ww[3] = {w.x, w.y, w.z};
+#pragma unroll
+    for (int k = 3 * b; k < D && k < 3 * b + 3; ++k) out[k] = ((double)ww[k - 3 * b] + 0.5) * (1.0 / 4294967296.0);
   }
 }
 

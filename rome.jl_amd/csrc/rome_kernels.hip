@@ -115,6 +115,7 @@ __device__ __forceinline__ double spread_r2_fast(const double (&t)[PPL][2], cons
 struct P2P2 {
   static constexpr int DF = 3, DT = 3, DZ = 3, NL = 6;
   static constexpr int kHypoDir = -1;  // no multihypo support
+  static constexpr bool kUniqueRoot = true;   // r(z; p, ·) = 0 has exactly one solution: the start point cannot reach the proposal
   struct Consts { double mu[3]; double L[6]; int dir; };
   __device__ static __forceinline__ Consts load(const ConvArgs& a, int f, int dr) {
     Consts K;
@@ -253,6 +254,7 @@ template <int DIR>
 struct BR {
   static constexpr int DF = DIR == 0 ? 3 : 2, DT = DIR == 0 ? 2 : 3, DZ = 2;
   static constexpr int kHypoDir = DIR;  // multihypo over the landmark slot: DIR 0 target is fractional, DIR 1 fixed is fractional
+  static constexpr bool kUniqueRoot = DIR == 0;   // pose direction: 2 equations / 3 unknowns, a ring of roots around the landmark
   struct Consts { double mu[2]; double sg[2]; };
   __device__ static __forceinline__ Consts load(const ConvArgs& a, int f, int) {
     Consts K; K.mu[0] = a.mu[2 * f]; K.mu[1] = a.mu[2 * f + 1]; K.sg[0] = a.L[2 * f]; K.sg[1] = a.L[2 * f + 1];
@@ -373,6 +375,7 @@ struct P3P3Cost {
 struct P3P3 {
   static constexpr int DF = 6, DT = 6, DZ = 6;
   static constexpr int kHypoDir = -1;
+  static constexpr bool kUniqueRoot = true;
   struct Consts { double mu[6]; const double* L; int dir; };
   __device__ static __forceinline__ Consts load(const ConvArgs& a, int f, int dr) {
     Consts K;
@@ -685,7 +688,8 @@ k_conv(const ConvArgs a) {
   double nh0_spread = 0.0;
   const double p_null = a.nullhypo ? a.nullhypo[c] : 0.0;
   if (p_null > 0.0) {  // wave-uniform
-    nh0_spread = a.spread_nh * FP::template spread<PPL>(t, aux, act, a.inv_n, a.inv_nm1);
+    const double sd0 = FP::template spread<PPL>(t, aux, act, a.inv_n, a.inv_nm1);
+    nh0_spread = N > 1 ? a.spread_nh * (sd0 > 1e-10 ? sd0 : 1.0) : 0.0;   // calcStdBasicSpread fallback, as the inflation spread
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       const uint32_t ii = (uint32_t)(act[k] ? lane + 64 * k : 0);
@@ -696,33 +700,51 @@ k_conv(const ConvArgs a) {
 
   const bool cyc_on = FP::needs_cycles(SOLVER, K);
   const int ncyc = cyc_on ? (a.cycles < 1 ? 1 : a.cycles) : 1;
-  constexpr int CPC = FP::DT <= 3 ? 3 : 1;  // inflation cycles served by one Philox call
-  EntropyWords ew[PPL];
+  // Where the jitter can reach the proposal (Nelder-Mead stops ~1e-4 from the root; the bearing-range pose direction has a
+  // ring of roots) it is drawn exactly as the oracle defines it; elsewhere (unique root, Newton / closed form) cheap narrow uniforms.
+  constexpr bool kExactEntropy = SOLVER == kSolverNelderMead || !FP::kUniqueRoot;
+  // Cycle elision: IIF repeats {inflate, solve} inflateCycles times.  Once every particle of a unique-root factor has converged
+  // (max|r| <= tol) a further cycle re-jitters the start and lands on the same root again (to the solver tolerance, 1e-12):
+  // the remaining cycles are skipped.  Guarded by the parity tests against the oracle, which always runs all cycles.
+  constexpr bool kElide = SOLVER == kSolverNewton && FP::kUniqueRoot;
+  constexpr int CPC = FP::DT <= 3 ? 3 : 1;  // inflation cycles served by one cheap-entropy Philox call
+  [[maybe_unused]] EntropyWords ew[PPL];
   int have_call = -1;
   for (int cyc = 0; cyc < ncyc; ++cyc) {
     double spread = 0.0;
-    if (cyc_on && a.inflation > 0.0 && N > 1) spread = a.inflation * FP::template cycle_spread<PPL, SOLVER>(t, aux, act, a.inv_n, a.inv_nm1);
-    if (spread > 0.0 && have_call != cyc / CPC) {  // wave-uniform
-      have_call = cyc / CPC;
+    if (cyc_on && a.inflation > 0.0 && N > 1) {
+      const double sd = FP::template cycle_spread<PPL, SOLVER>(t, aux, act, a.inv_n, a.inv_nm1);
+      spread = a.inflation * (sd > 1e-10 ? sd : 1.0);   // IIF calcStdBasicSpread: "if no std yet, set to 1"
+    }
+    if constexpr (!kExactEntropy) {
+      if (spread > 0.0 && have_call != cyc / CPC) {  // wave-uniform
+        have_call = cyc / CPC;
 #pragma unroll
-      for (int k = 0; k < PPL; ++k) {   // slots k (even) and k+1 = particles p, p+64 share the call of p (rng_entropy_from_words)
-        if ((k & 1) == 0) ew[k] = rng_entropy_words(a.seed, stream, (uint32_t)(lane + 64 * k), have_call);
+        for (int k = 0; k < PPL; ++k) {   // slots k (even) and k+1 = particles p, p+64 share the call of p (rng_entropy_from_words)
+          if ((k & 1) == 0) ew[k] = rng_entropy_words(a.seed, stream, (uint32_t)(lane + 64 * k), have_call);
+        }
       }
     }
+    int bad = 0;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       if (act[k] && sel[k] && !nullh[k]) {
         if (spread > 0.0) {
           double u[FP::DT];
+          if constexpr (kExactEntropy) rng_entropy_exact<FP::DT>(a.seed, stream, (uint32_t)(lane + 64 * k), cyc, u);
           // k is a compile-time constant after unrolling: static indices only
-          if (k & 1) rng_entropy_from_words<FP::DT, 1>(ew[k & ~1], cyc % CPC, u);
+          else if (k & 1) rng_entropy_from_words<FP::DT, 1>(ew[k & ~1], cyc % CPC, u);
           else rng_entropy_from_words<FP::DT, 0>(ew[k], cyc % CPC, u);
           double hs, hc;
           FP::template heading_sincos<SOLVER>(K, prep[k], st[k], cyc, t[k], &hs, &hc);
           FP::add_entropy(t[k], aux[k], spread, u, hs, hc);
         }
         st[k] = FP::template solve<SOLVER>(K, prep[k], z[k], fx[k], t[k], aux[k], a.max_iters, a.tol);
+        bad |= st[k];
       }
+    }
+    if constexpr (kElide) {
+      if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) break;   // wave-uniform
     }
   }
 

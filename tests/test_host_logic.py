@@ -205,30 +205,67 @@ def test_oracle_nelder_mead_on_rosenbrock():
 
 
 def test_entropy_rng_definition():
-    u = ro.rng_entropy(7, 3, 5, 0, 3); v = ro.rng_entropy(7, 3, 5, 1, 3); w = ro.rng_entropy(7, 3, 5, 3, 3)
+    """Entropy uniforms as the oracle defines them: one Philox call per (particle, cycle) (two for d = 6), domain 2,
+    counter word 3 = (2 << 16) | (2·cycle + block), one 32-bit word per coordinate, u = (w + 0.5) / 2^32."""
+    u = ro.rng_entropy(7, 3, 5, 0, 3); v = ro.rng_entropy(7, 3, 5, 1, 3); w = ro.rng_entropy(7, 3, 5 + 64, 0, 3)
     assert ((u > 0) & (u < 1)).all() and not np.allclose(u, v) and not np.allclose(u, w)
-    assert np.allclose(u * 128 - 0.5, np.round(u * 128 - 0.5))         # 7-bit fields
-    # particles p and p ^ 64 read the two halves (fields 0..8 / 9..17) of the ONE Philox call made for p & ~64 (domain 2)
-    wds = ro.philox([5, 3, 0, (2 << 16) | 0], [7, 0])
-    big = sum(int(x) << (32 * i) for i, x in enumerate(wds))
-    for part, half in ((5, 0), (5 + 64, 1)):
-        for cyc in range(3):
-            got = ro.rng_entropy(7, 3, part, cyc, 3)
-            want = [(((big >> (7 * (9 * half + 3 * cyc + k))) & 127) + 0.5) / 128 for k in range(3)]
-            assert np.array_equal(got, want)
-    # normals, d = 3: 0, 1 from the particle's own call; 2 = cosine / sine branch of the second Box-Muller pair of the call made for
-    # particle p & ~64 (Philox domain 1): particles p and p ^ 64 share that pair
-    a, b = ro.rng_normals(7, 3, 5, 3), ro.rng_normals(7, 3, 5 + 64, 3)
-    w5 = ro.philox([5, 3, 0, (1 << 16) | 0], [7, 0])
-    rr = np.sqrt(-2 * np.log((w5[2] + 1.0) / 2 ** 32)); ang = 2 * np.pi * (w5[3] + 0.5) / 2 ** 32
-    assert abs(a[2] - rr * np.cos(ang)) < 1e-14 and abs(b[2] - rr * np.sin(ang)) < 1e-14 and not np.allclose(a[:2], b[:2])
-    n3 = np.array([ro.rng_normals(11, 2, i, 3) for i in range(2048)])
-    assert np.abs(n3.mean(0)).max() < 0.08 and np.abs(n3.std(0) - 1).max() < 0.06
-    assert abs(np.corrcoef(n3[:64, 2], n3[64:128, 2])[0, 1]) < 0.35              # the two branches of a shared pair are uncorrelated
-    u6 = ro.rng_entropy(7, 3, 5, 2, 6)
-    assert np.allclose(u6 * (1 << 10) - 0.5, np.round(u6 * (1 << 10) - 0.5))           # 10-bit fields, two particles per call
+    for part in (5, 5 + 64):
+        for cyc in range(4):
+            wds = ro.philox([part, 3, 0, (2 << 16) | (2 * cyc)], [7, 0])
+            assert np.array_equal(ro.rng_entropy(7, 3, part, cyc, 3), [(x + 0.5) / 2 ** 32 for x in wds[:3]])
+            assert np.array_equal(ro.rng_entropy(7, 3, part, cyc, 2), [(x + 0.5) / 2 ** 32 for x in wds[:2]])
+            wd2 = ro.philox([part, 3, 0, (2 << 16) | (2 * cyc + 1)], [7, 0])
+            assert np.array_equal(ro.rng_entropy(7, 3, part, cyc, 6), [(x + 0.5) / 2 ** 32 for x in wds[:3] + wd2[:3]])
     allu = np.array([ro.rng_entropy(1, 0, i, c, 3) for i in range(400) for c in range(6)])
     assert abs(allu.mean() - 0.5) < 0.02 and abs(allu.std() - 12 ** -0.5) < 0.02
+
+
+def _bm_exact(wa, wb):
+    """the transform ro_box_muller approximates in single precision, evaluated in double precision"""
+    wa = np.asarray(wa, dtype=np.uint64); wb = np.asarray(wb, dtype=np.uint64)
+    r = np.sqrt(-2 * np.log((wa.astype(np.float64) + 1) / 2 ** 32))
+    a = (np.pi / 4) * ((wb << np.uint64(2)) & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32).astype(np.float64) / 2 ** 31
+    sx = np.where(wb & np.uint64(0x80000000), -1.0, 1.0); sy = np.where(wb & np.uint64(0x40000000), -1.0, 1.0)
+    return sx * r * np.cos(np.pi / 4 + a), sy * r * np.sin(np.pi / 4 + a)
+
+
+def test_normal_generator_definition():
+    # normals, d = 3: 0, 1 from the particle's own call; 2 = first / second output of the second Box-Muller pair of the call made
+    # for particle p & ~64 (Philox domain 1): particles p and p ^ 64 share that pair
+    a, b = ro.rng_normals(7, 3, 5, 3), ro.rng_normals(7, 3, 5 + 64, 3)
+    w5 = ro.philox([5, 3, 0, (1 << 16) | 0], [7, 0]); w69 = ro.philox([5 + 64, 3, 0, (1 << 16) | 0], [7, 0])
+    assert np.array_equal(a[:2], ro.box_muller(w5[0], w5[1])) and np.array_equal(b[:2], ro.box_muller(w69[0], w69[1]))
+    sh = ro.box_muller(w5[2], w5[3])
+    assert a[2] == sh[0] and b[2] == sh[1] and not np.allclose(a[:2], b[:2])
+    e0, e1 = _bm_exact([w5[2]], [w5[3]])
+    assert abs(sh[0] - e0[0]) < 1e-4 and abs(sh[1] - e1[0]) < 1e-4
+    # d = 2 / 6: pairs in call order
+    n6 = ro.rng_normals(7, 3, 5, 6); w5b = ro.philox([5, 3, 0, (1 << 16) | 1], [7, 0])
+    assert np.array_equal(n6, list(ro.box_muller(w5[0], w5[1])) + list(ro.box_muller(w5[2], w5[3])) + list(ro.box_muller(w5b[0], w5b[1])))
+    # edge words: the largest radius (6.66 sigma), the zero radius, the four mirror quadrants
+    big = ro.box_muller(0, 0x20000000)
+    assert abs(np.hypot(*big) - np.sqrt(2 * 32 * np.log(2))) < 1e-5 and ro.box_muller(0xFFFFFFFF, 123) == (0.0, 0.0)
+    sg = [tuple(np.sign(ro.box_muller(12345, q << 30 | 0x1234567))) for q in range(4)]
+    assert sg == [(1, 1), (1, -1), (-1, 1), (-1, -1)]
+    n3 = np.array([ro.rng_normals(11, 2, i, 3) for i in range(2048)])
+    assert np.abs(n3.mean(0)).max() < 0.08 and np.abs(n3.std(0) - 1).max() < 0.06
+    assert abs(np.corrcoef(n3[:64, 2], n3[64:128, 2])[0, 1]) < 0.35              # the two outputs of a shared pair are uncorrelated
+
+
+def test_normal_generator_law():
+    """The single-precision Box-Muller evaluation against the exact transform of the same words (<= 5e-5 absolute, only near
+    the zero radius; <= 5e-6 relative on radii above 0.5) and against N(0,1) (KS on 4e5 draws)."""
+    from scipy import stats
+    rng = np.random.default_rng(5)
+    W = rng.integers(0, 2 ** 32, size=(200000, 2), dtype=np.uint64)
+    out = np.array([ro.box_muller(int(a), int(b)) for a, b in W])
+    e0, e1 = _bm_exact(W[:, 0], W[:, 1])
+    ex = np.stack([e0, e1], 1)
+    assert np.abs(out - ex).max() < 5e-5
+    rad, rex = np.hypot(out[:, 0], out[:, 1]), np.hypot(e0, e1)
+    assert (np.abs(rad - rex) / rex)[rex > 0.5].max() < 5e-6
+    assert stats.kstest(out.ravel(), "norm").pvalue > 1e-3
+    assert abs(np.corrcoef(out.T)[0, 1]) < 0.01 and np.abs(out.mean(0)).max() < 0.01 and np.abs(out.std(0) - 1).max() < 0.01
 
 
 def test_real_datasets_load():
