@@ -241,17 +241,21 @@ __device__ __forceinline__ void rng_normals(uint64_t seed, uint64_t stream, uint
   }
 }
 // the D == 3 normals of particles p (bit 6 clear) and p + 64 together: two Philox calls, three Box-Muller pairs
-__device__ __forceinline__ void rng_normals3_pair(uint64_t seed, uint64_t stream, uint32_t p_even, double (&oe)[3], double (&oo)[3]) {
+// (words z, w of the odd particle's call are not used by the normals: returned as spare bits for the cheap entropy of cycle 0)
+__device__ __forceinline__ void rng_normals3_pair(uint64_t seed, uint64_t stream, uint32_t p_even, double (&oe)[3], double (&oo)[3],
+                                                  uint32_t* spare_e, uint32_t* spare_o) {
   const u32x4 we = noise_words(seed, stream, p_even, 0u), wo = noise_words(seed, stream, p_even + 64u, 0u);
   box_muller(we.x, we.y, &oe[0], &oe[1]);
   box_muller(wo.x, wo.y, &oo[0], &oo[1]);
   box_muller(we.z, we.w, &oe[2], &oo[2]);
+  *spare_e = wo.z; *spare_o = wo.w;
 }
 
 // Cheap entropy-inflation uniforms (IIF addEntropyOnManifold!: spread·(rand(d) .- 0.5)) for the kernels whose result does NOT
 // depend on the start point (Newton / closed form on a factor with a unique root; the oracle draws full 32-bit uniforms,
 // rng_entropy_exact below).  Narrow uniforms are drawn and ONE Philox call is shared by several cycles:
-//   D <= 3 : 7-bit fields, 3 cycles per call, two particles (p, p ^ 64) per call   (call index = cycle / 3)
+//   D <= 3 : 7-bit fields, 3 cycles per call, two particles (p, p ^ 64) per call   (call index = cycle / 3; cycle 0 of a Pose2
+//            measurement comes from two spare words of the noise calls instead)
 //   D == 6 : 10-bit fields, 1 cycle per call, two particles (p, p ^ 64) per call   (120 bits)
 // u = (field + 0.5) / 2^bits  in (0,1).
 typedef u32x4 EntropyWords;  // plain scalars (no array member: keeps the words in VGPRs, not LDS/scratch)
@@ -271,25 +275,33 @@ __device__ __forceinline__ uint32_t bitfield128(const EntropyWords& e, int pos, 
   const uint32_t hi = (sh + bits > 32) ? (word_of(e, wi + 1) << (32 - sh)) : 0u;
   return (lo | hi) & ((1u << bits) - 1u);
 }
-// D <= 3: 7-bit fields, nine per particle (3 cycles x 3 coordinates); particles p and p ^ 64 -- the two slots of a lane -- read the
-// two halves (fields 0..8 / 9..17) of the ONE call made for particle p & ~64, so a lane issues one entropy Philox call per three
-// cycles for its two particles (HALF = (p >> 6) & 1).  D == 6: 10-bit fields, six per particle and cycle, the same sharing, one cycle per call.
+// D <= 3: 7-bit fields, nine per particle (3 cycles x 3 coordinates), field j = 3·slot + k at bit 7j of the particle's 64-bit half
+// of the call: particles p and p ^ 64 -- the two slots of a lane -- read words (x, y) / (z, w) of the ONE call made for particle
+// p & ~64 (HALF = (p >> 6) & 1).  The fields of slot 0 lie in the first word of a half, so two spare 32-bit words of the
+// measurement-noise calls can serve cycle 0 -- with cycle elision the only one that runs -- without any Philox call of its own.
+// D == 6: 10-bit fields, six per particle and cycle at bit 10·(6·HALF + k), the same sharing, one cycle per call.
+// `slot` (= cycle % 3) is wave-uniform: a scalar branch picks the field positions, which are then compile-time constants.
 template <int D, int HALF>
 __device__ __forceinline__ void rng_entropy_from_words(const EntropyWords& e, int slot, double (&out)[D]) {
   constexpr int BITS = D <= 3 ? 7 : 10;
-  // slot = cycle % 3 for D<=3 (0 for D==6); select with constant positions to keep everything in registers
+  uint32_t f[D];
+  if constexpr (D <= 3) {
+    if (slot == 0) {
 #pragma unroll
-  for (int k = 0; k < D; ++k) {
-    uint32_t f;
-    if constexpr (D <= 3) {
-      const uint32_t f0 = bitfield128(e, (9 * HALF + 0 * 3 + k) * BITS, BITS), f1 = bitfield128(e, (9 * HALF + 1 * 3 + k) * BITS, BITS),
-                     f2 = bitfield128(e, (9 * HALF + 2 * 3 + k) * BITS, BITS);
-      f = slot == 0 ? f0 : (slot == 1 ? f1 : f2);
+      for (int k = 0; k < D; ++k) f[k] = bitfield128(e, 64 * HALF + BITS * k, BITS);
+    } else if (slot == 1) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) f[k] = bitfield128(e, 64 * HALF + BITS * (3 + k), BITS);
     } else {
-      f = bitfield128(e, (6 * HALF + k) * BITS, BITS);
+#pragma unroll
+      for (int k = 0; k < D; ++k) f[k] = bitfield128(e, 64 * HALF + BITS * (6 + k), BITS);
     }
-    out[k] = ((double)f + 0.5) * (1.0 / (double)(1u << BITS));
+  } else {
+#pragma unroll
+    for (int k = 0; k < D; ++k) f[k] = bitfield128(e, (6 * HALF + k) * BITS, BITS);
   }
+#pragma unroll
+  for (int k = 0; k < D; ++k) out[k] = ((double)f[k] + 0.5) * (1.0 / (double)(1u << BITS));
 }
 
 // The entropy uniforms as the oracle defines them (ro_rng_entropy): one Philox call per particle and cycle (two for D = 6), one

@@ -67,21 +67,20 @@ __device__ __forceinline__ double spread_se2(const double (&t)[PPL][3], const bo
 // proposals are unchanged to the solver tolerance while the six wave reductions cost a third of the instructions.
 template <int PPL>
 __device__ __forceinline__ double spread_se2_fast(const double (&t)[PPL][3], const bool (&act)[PPL], double inv, double den) {
+  // only the SUM of the coordinate variances is needed: Σ_k var_k = (Σ_i |d_i|² - Σ_k (Σ_i d_ik)² / N) / (N - 1) -> four wave sums
   const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0), th0 = readlane_f64(t[0][2], 0);
-  float s[6] = {0, 0, 0, 0, 0, 0};
+  float s[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     const float dx = (float)(t[k][0] - x0), dy = (float)(t[k][1] - y0);
     float dt = (float)(t[k][2] - th0);
     dt = fmaf(-6.2831853071795865f, rintf(dt * 0.15915494309189535f), dt);
-    if (act[k]) { s[0] += dx; s[1] = fmaf(dx, dx, s[1]); s[2] += dy; s[3] = fmaf(dy, dy, s[3]); s[4] += dt; s[5] = fmaf(dt, dt, s[5]); }
+    if (act[k]) { s[0] += dx; s[1] += dy; s[2] += dt; s[3] = fmaf(dx, dx, fmaf(dy, dy, fmaf(dt, dt, s[3]))); }
   }
-  wave_sum_n_f32<6>(s);
+  wave_sum_n_f32<4>(s);
   const float fi = (float)inv, fd = (float)den;
-  const float vx = fmaxf(0.0f, (s[1] - s[0] * s[0] * fi) * fd);
-  const float vy = fmaxf(0.0f, (s[3] - s[2] * s[2] * fi) * fd);
-  const float vt = fmaxf(0.0f, (s[5] - s[4] * s[4] * fi) * fd);
-  return (double)fminf(__builtin_sqrtf(vx + vy + vt), 3.0e38f);   // finite even if the single-precision moments overflow
+  const float v = fmaxf(0.0f, (s[3] - (s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) * fi) * fd);
+  return (double)fminf(__builtin_sqrtf(v), 3.0e38f);   // finite even if the single-precision moments overflow
 }
 template <int PPL>
 __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const bool (&act)[PPL], double inv, double den) {
@@ -101,15 +100,15 @@ __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const boo
 template <int PPL>
 __device__ __forceinline__ double spread_r2_fast(const double (&t)[PPL][2], const bool (&act)[PPL], double inv, double den) {
   const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0);
-  float s[4] = {0, 0, 0, 0};
+  float s[3] = {0, 0, 0};
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     const float dx = (float)(t[k][0] - x0), dy = (float)(t[k][1] - y0);
-    if (act[k]) { s[0] += dx; s[1] = fmaf(dx, dx, s[1]); s[2] += dy; s[3] = fmaf(dy, dy, s[3]); }
+    if (act[k]) { s[0] += dx; s[1] += dy; s[2] = fmaf(dx, dx, fmaf(dy, dy, s[2])); }
   }
-  wave_sum_n_f32<4>(s);
+  wave_sum_n_f32<3>(s);
   const float fi = (float)inv, fd = (float)den;
-  return (double)fminf(__builtin_sqrtf(fmaxf(0.0f, (s[1] - s[0] * s[0] * fi) * fd) + fmaxf(0.0f, (s[3] - s[2] * s[2] * fi) * fd)), 3.0e38f);
+  return (double)fminf(__builtin_sqrtf(fmaxf(0.0f, (s[2] - (s[0] * s[0] + s[1] * s[1]) * fi) * fd)), 3.0e38f);
 }
 
 struct P2P2 {
@@ -449,9 +448,9 @@ struct P3P3 {
       for (int k = 0; k < 3; ++k) c0[k] = readlane_f64(t[0][k], 0);
 #pragma unroll
       for (int k = 0; k < 4; ++k) q0[k] = readlane_f64(A[0].q[k], 0);
-      float s[12];
+      float s[7];
 #pragma unroll
-      for (int j = 0; j < 12; ++j) s[j] = 0.0f;
+      for (int j = 0; j < 7; ++j) s[j] = 0.0f;
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
         double e[4], w[3];
@@ -459,15 +458,15 @@ struct P3P3 {
         const float d[6] = {(float)(t[k][0] - c0[0]), (float)(t[k][1] - c0[1]), (float)(t[k][2] - c0[2]), (float)w[0], (float)w[1], (float)w[2]};
         if (act[k]) {
 #pragma unroll
-          for (int j = 0; j < 6; ++j) { s[2 * j] += d[j]; s[2 * j + 1] = fmaf(d[j], d[j], s[2 * j + 1]); }
+          for (int j = 0; j < 6; ++j) { s[j] += d[j]; s[6] = fmaf(d[j], d[j], s[6]); }
         }
       }
-      wave_sum_n_f32<12>(s);
+      wave_sum_n_f32<7>(s);   // Σ_k var_k = (Σ|d|² - Σ_k (Σ d_k)² / N) / (N - 1)
       const float fi = (float)inv, fd = (float)den;
-      float acc = 0.0f;
+      float m2 = 0.0f;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) acc += fmaxf(0.0f, (s[2 * j + 1] - s[2 * j] * s[2 * j] * fi) * fd);
-      return (double)fminf(__builtin_sqrtf(acc), 3.0e38f);
+      for (int j = 0; j < 6; ++j) m2 = fmaf(s[j], s[j], m2);
+      return (double)fminf(__builtin_sqrtf(fmaxf(0.0f, (s[6] - m2 * fi) * fd)), 3.0e38f);
     }
   }
   struct Prep { double a[3], qa[4]; };
@@ -579,7 +578,11 @@ struct P3P3 {
 #ifndef ROME_MIN_WAVES
 #define ROME_MIN_WAVES 1
 #endif
-template <class FP, int SOLVER, int PPL>
+// LEAN: the plain sweep -- in-kernel noise, all four table columns present, no multihypo / nullhypo rows.  The same code with
+// those features compiled out: the table row is four scalar loads issued together, nothing stands between the belief loads
+// and the Philox / Box-Muller block (which then runs under the load latency), and the register allocation is not pinned by
+// the feature paths.  launch_ppl picks it whenever the arguments allow.
+template <class FP, int SOLVER, int PPL, bool LEAN>
 #ifndef ROME_WPB
 #define ROME_WPB 4   // wavefronts (= convolutions) per workgroup
 #endif
@@ -592,10 +595,17 @@ k_conv(const ConvArgs a) {
   const int c = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * ROME_WPB + (int)(threadIdx.x >> 6));
   if (c >= a.n_conv) return;
   const int N = a.N;
-  const int f = a.factor ? a.factor[c] : c;
-  const int dr = a.dir ? a.dir[c] : a.dir_all;
-  const int fv = a.fixed_var ? a.fixed_var[c] : c;
-  const int tv = a.target_var ? a.target_var[c] : c;
+  int f, dr, fv, tv;
+  if constexpr (LEAN) {
+    f = a.factor[c]; fv = a.fixed_var[c]; tv = a.target_var[c];
+    if constexpr (FP::kHypoDir < 0) dr = a.dir[c]; else dr = a.dir_all;   // bearing-range: the direction is the kernel's template argument
+  }
+  else {
+    f = a.factor ? a.factor[c] : c;
+    dr = a.dir ? a.dir[c] : a.dir_all;
+    fv = a.fixed_var ? a.fixed_var[c] : c;
+    tv = a.target_var ? a.target_var[c] : c;
+  }
   const typename FP::Consts K = FP::load(a, f, dr);
   const double* __restrict__ fb = a.bel_fixed + (size_t)fv * FP::DF * N;
   const double* __restrict__ tb = a.bel_target + (size_t)tv * FP::DT * N;
@@ -607,6 +617,7 @@ k_conv(const ConvArgs a) {
   typename FP::Aux aux[PPL];   // state a policy keeps beside the coordinates (Pose3: the rotation as a unit quaternion)
   bool act[PPL];
   [[maybe_unused]] double xi_odd[3];   // normals of the odd slot, produced together with the even slot's (shared Box-Muller pair)
+  [[maybe_unused]] EntropyWords ew[PPL];   // cheap-entropy words: slot k (even) serves particles k and k+1
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     const int i = lane + 64 * k;
@@ -617,13 +628,13 @@ k_conv(const ConvArgs a) {
 #pragma unroll
     for (int d = 0; d < FP::DT; ++d) t[k][d] = tb[d * N + ii];
     double xi[FP::DZ];
-    if (a.noise) {
+    if (!LEAN && a.noise) {
       const double* nb = a.noise + (size_t)c * FP::DZ * N;
 #pragma unroll
       for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
     } else if constexpr (FP::DZ == 3 && PPL >= 2) {
       // slots k (even) and k+1 of a lane are particles p and p+64: they share the third Box-Muller pair (rng_normals)
-      if ((k & 1) == 0) rng_normals3_pair(a.seed, stream, (uint32_t)i, xi, xi_odd);
+      if ((k & 1) == 0) { ew[k] = EntropyWords{0u, 0u, 0u, 0u}; rng_normals3_pair(a.seed, stream, (uint32_t)i, xi, xi_odd, &ew[k].x, &ew[k].z); }
       else { xi[0] = xi_odd[0]; xi[1] = xi_odd[1]; xi[2] = xi_odd[2]; }
     } else {
       rng_normals<FP::DZ>(a.seed, stream, (uint32_t)ii, xi);
@@ -647,7 +658,7 @@ k_conv(const ConvArgs a) {
 #pragma unroll
   for (int k = 0; k < PPL; ++k) sel[k] = true;
   double nh_spread = 0.0;
-  if constexpr (FP::kHypoDir >= 0) {
+  if constexpr (FP::kHypoDir >= 0 && !LEAN) {
     const int av = a.alt_var ? a.alt_var[c] : -1;
     if (av >= 0) {  // wave-uniform
       const double w = a.hypo_w[c];
@@ -686,7 +697,7 @@ k_conv(const ConvArgs a) {
 #pragma unroll
   for (int k = 0; k < PPL; ++k) nullh[k] = false;
   double nh0_spread = 0.0;
-  const double p_null = a.nullhypo ? a.nullhypo[c] : 0.0;
+  const double p_null = (!LEAN && a.nullhypo) ? a.nullhypo[c] : 0.0;
   if (p_null > 0.0) {  // wave-uniform
     const double sd0 = FP::template spread<PPL>(t, aux, act, a.inv_n, a.inv_nm1);
     nh0_spread = N > 1 ? a.spread_nh * (sd0 > 1e-10 ? sd0 : 1.0) : 0.0;   // calcStdBasicSpread fallback, as the inflation spread
@@ -708,7 +719,8 @@ k_conv(const ConvArgs a) {
   // the remaining cycles are skipped.  Guarded by the parity tests against the oracle, which always runs all cycles.
   constexpr bool kElide = SOLVER == kSolverNewton && FP::kUniqueRoot;
   constexpr int CPC = FP::DT <= 3 ? 3 : 1;  // inflation cycles served by one cheap-entropy Philox call
-  [[maybe_unused]] EntropyWords ew[PPL];
+  // cycle 0 of a Pose2 measurement with in-kernel noise: two spare words of the noise calls hold its 2 x 3 x 7 entropy bits
+  const bool spare0 = !kExactEntropy && FP::DZ == 3 && PPL >= 2 && (LEAN || a.noise == nullptr);
   int have_call = -1;
   for (int cyc = 0; cyc < ncyc; ++cyc) {
     double spread = 0.0;
@@ -717,7 +729,7 @@ k_conv(const ConvArgs a) {
       spread = a.inflation * (sd > 1e-10 ? sd : 1.0);   // IIF calcStdBasicSpread: "if no std yet, set to 1"
     }
     if constexpr (!kExactEntropy) {
-      if (spread > 0.0 && have_call != cyc / CPC) {  // wave-uniform
+      if (spread > 0.0 && !(spare0 && cyc == 0) && have_call != cyc / CPC) {  // wave-uniform
         have_call = cyc / CPC;
 #pragma unroll
         for (int k = 0; k < PPL; ++k) {   // slots k (even) and k+1 = particles p, p+64 share the call of p (rng_entropy_from_words)
@@ -770,7 +782,7 @@ k_conv(const ConvArgs a) {
       }
     }
   }
-  if constexpr (FP::kHypoDir == 0) {
+  if constexpr (FP::kHypoDir == 0 && !LEAN) {
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       if (act[k] && !sel[k]) {  // the other hypothesis holds for this particle: entropy only
@@ -948,16 +960,22 @@ hipError_t launch_coords_to_points(int n, int dim, const double* c, double* pts,
   if (n > 0) hipLaunchKernelGGL(k_coords_to_points, dim3((n + 255) / 256), dim3(256), 0, s, n, dim, c, pts);
   return hipGetLastError();
 }
-template <class FP, int SOLVER>
-static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
+template <class FP, int SOLVER, bool LEAN>
+static hipError_t launch_ppl_v(const ConvArgs& a, hipStream_t s) {
   const int nb = (a.n_conv + ROME_WPB - 1) / ROME_WPB;
   if (nb == 0) return hipSuccess;
-  if (a.N <= 64)       hipLaunchKernelGGL((k_conv<FP, SOLVER, 1>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
-  else if (a.N <= 128) hipLaunchKernelGGL((k_conv<FP, SOLVER, 2>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
-  else if (a.N <= 256) hipLaunchKernelGGL((k_conv<FP, SOLVER, 4>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
-  else if (a.N <= 512) hipLaunchKernelGGL((k_conv<FP, SOLVER, 8>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  if (a.N <= 64)       hipLaunchKernelGGL((k_conv<FP, SOLVER, 1, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  else if (a.N <= 128) hipLaunchKernelGGL((k_conv<FP, SOLVER, 2, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  else if (a.N <= 256) hipLaunchKernelGGL((k_conv<FP, SOLVER, 4, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  else if (a.N <= 512) hipLaunchKernelGGL((k_conv<FP, SOLVER, 8, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
+}
+template <class FP, int SOLVER>
+static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
+  const bool lean = a.noise == nullptr && a.alt_var == nullptr && a.nullhypo == nullptr &&
+                    a.factor && (a.dir || FP::kHypoDir >= 0) && a.fixed_var && a.target_var;
+  return lean ? launch_ppl_v<FP, SOLVER, true>(a, s) : launch_ppl_v<FP, SOLVER, false>(a, s);
 }
 template <class FP>
 static hipError_t launch_solver(const ConvArgs& a, int solver, hipStream_t s) {
