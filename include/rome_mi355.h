@@ -200,6 +200,11 @@ typedef struct rome_conv_dev {
    * with probability nullhypo[c] a particle is not constrained by the factor: it keeps its start value and gets
    * spread_nh · std entropy (std = root of the Fréchet variance of the target's start belief).  NULL -> 0 everywhere. */
   const double* nullhypo;
+  /* optional: the four table columns interleaved, [C][4] int32 = (factor, dir, fixed_var, target_var) per row.  When given it
+   * REPLACES the column pointers above (which may then be NULL) and, for rows without pre-sampled noise / multihypo /
+   * nullhypo, selects the lean sweep kernel: one 16-byte scalar load per convolution instead of four dependent ones
+   * (Manhattan-3500 Newton sweep 18.0 -> see profiles/).  Bearing-range rows ignore the dir entry. */
+  const int32_t* rows4;
 } rome_conv_dev;
 
 int rome_conv_pose2pose2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);

@@ -36,7 +36,7 @@ class ConvDev(C.Structure):
                 ("mu", C.c_void_p), ("L", C.c_void_p), ("bel_fixed", C.c_void_p), ("bel_target", C.c_void_p),
                 ("noise", C.c_void_p), ("out", C.c_void_p), ("status", C.c_void_p),
                 ("n_mirror", C.c_int32), ("mirror_row", C.c_int32 * 4), ("reserved", C.c_int32), ("mirror_out", C.c_void_p),
-                ("alt_var", C.c_void_p), ("hypo_w", C.c_void_p), ("nullhypo", C.c_void_p)]
+                ("alt_var", C.c_void_p), ("hypo_w", C.c_void_p), ("nullhypo", C.c_void_p), ("rows4", C.c_void_p)]
 
 
 _PD = C.POINTER(C.c_double)

@@ -35,6 +35,15 @@ inline int hip_fail(rome_ctx* c, hipError_t e) {
     if (_e != hipSuccess) return hip_fail((ctx), _e);         \
   } while (0)
 
+// Every entry point that launches or copies binds the thread to the context's device first (a context created for device k
+// must work whatever the caller's current device is); one hipGetDevice when it already is current.
+#define ROME_BIND(ctx)                                                   \
+  do {                                                                   \
+    int _cur = -1;                                                       \
+    if (hipGetDevice(&_cur) != hipSuccess || _cur != (ctx)->device)      \
+      ROME_HIP((ctx), hipSetDevice((ctx)->device));                      \
+  } while (0)
+
 int ensure(rome_ctx* c, int idx, size_t bytes, void** out) {
   if (bytes == 0) bytes = 8;
   if (c->dcap[idx] < bytes) {
@@ -93,7 +102,8 @@ void args_from_dev(rome::ConvArgs& a, const rome_opts* o, const rome_conv_dev* t
   a.factor = t->factor; a.dir = t->dir; a.fixed_var = t->fixed_var; a.target_var = t->target_var;
   a.mu = t->mu; a.L = t->L; a.bel_fixed = t->bel_fixed; a.bel_target = t->bel_target;
   a.noise = t->noise; a.out = t->out; a.status = t->status;
-  a.n_mirror = t->mirror_out ? (t->n_mirror < 0 ? 0 : (t->n_mirror > 4 ? 4 : t->n_mirror)) : 0;
+  a.rows4 = t->rows4;
+  a.n_mirror = t->mirror_out ? (t->n_mirror < 0 ? 0 : t->n_mirror) : 0;   // (> 4 is rejected by dev_common)
   for (int m = 0; m < 4; ++m) a.mirror_row[m] = t->mirror_row[m];
   a.mirror_out = t->mirror_out;
   a.alt_var = t->hypo_w ? t->alt_var : nullptr;
@@ -477,6 +487,8 @@ static int dev_common(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t, b
   if (!c || !t || t->n_conv < 0) return ROME_ERR_INVALID_ARG;
   if (t->n_conv > 0 && (!t->mu || !t->L || !t->out)) return ROME_ERR_INVALID_ARG;
   if (t->n_conv > 0 && need_beliefs && (!t->bel_fixed || !t->bel_target)) return ROME_ERR_INVALID_ARG;
+  if (t->mirror_out && t->n_mirror > 4) return ROME_ERR_INVALID_ARG;   // at most 4 separator rows per launch: never silently dropped
+  ROME_BIND(c);
   return ROME_OK;
 }
 int rome_conv_pose2pose2_dev(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t) {
@@ -537,6 +549,7 @@ int rome_linearize_dev(rome_ctx* c, int32_t kind, int32_t F, const double* mu, c
                        const double* xb, double* r, double* Ja, double* Jb) {
   int dz, dr, da, db;
   if (!c || F < 0 || !lin_dims_host(kind, dz, dr, da, db)) return ROME_ERR_INVALID_ARG;
+  ROME_BIND(c);
   if (F > 0 && (!mu || !W || !xa || !r || !Ja || (db > 0 && (!xb || !Jb)))) return ROME_ERR_INVALID_ARG;
   ROME_HIP(c, rome::launch_linearize(kind, F, mu, W, xa, xb, r, Ja, Jb, c->stream));
   return ROME_OK;
@@ -577,6 +590,7 @@ int rome_linearize(rome_ctx* c, int32_t kind, int32_t F, const double* mu, const
 /* ---- belief statistics / product ---- */
 int rome_belief_stats_dev(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, double* mean, double* sd) {
   if (!c || V < 0 || N < 1 || (dim != 2 && dim != 3 && dim != 6) || (V > 0 && (!bel || !mean || !sd))) return ROME_ERR_INVALID_ARG;
+  ROME_BIND(c);
   ROME_HIP(c, rome::launch_belief_stats(dim, V, N, bel, mean, sd, c->stream));
   return ROME_OK;
 }
@@ -603,6 +617,7 @@ static int check_kde(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const doubl
 int rome_kde_bandwidth_dev(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, uint32_t circular_mask,
                            double tol_euclid, double tol_circular, double* bw) {
   int rc = check_kde(c, dim, V, N, bel, bw); if (rc) return rc;
+  ROME_BIND(c);
   ROME_HIP(c, rome::launch_kde_bandwidth(dim, V, N, bel, circular_mask, tol_euclid > 0 ? tol_euclid : 1e-2,
                                          tol_circular > 0 ? tol_circular : 1e-6, bw, nullptr, c->stream));
   return ROME_OK;
@@ -626,6 +641,7 @@ int rome_kde_bandwidth(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const dou
 int rome_kde_max_dev(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, const double* bw, int32_t grid_points,
                      double* out) {
   int rc = check_kde(c, dim, V, N, bel, bw); if (rc) return rc;
+  ROME_BIND(c);
   const int G = grid_points > 0 ? grid_points : 200;
   if (G < 2 || G > 256 || (V > 0 && !out)) return ROME_ERR_INVALID_ARG;
   ROME_HIP(c, rome::launch_kde_max(dim, V, N, G, 0.1, bel, bw, out, c->stream));
@@ -653,6 +669,7 @@ int rome_product_bw_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t V,
                         const double* prop, const double* prop_bw, const double* bel_in, double* bel_out) {
   int rc = check_opts(o); if (rc) return rc;
   if (!c || V < 0 || (dim != 2 && dim != 3 && dim != 6)) return ROME_ERR_INVALID_ARG;
+  ROME_BIND(c);
   if (V > 0 && (!prop_ptr || !bel_in || !bel_out)) return ROME_ERR_INVALID_ARG;
   const int N = o->n_particles;
   if (dim == 6 && N > 256) return ROME_ERR_UNSUPPORTED_N;   /* Pose3 product: points staged in LDS */
@@ -674,17 +691,20 @@ int rome_dev_alloc(rome_ctx* c, uint64_t bytes, void** out) {
 }
 int rome_dev_free(rome_ctx* c, void* p) {
   if (!c) return ROME_ERR_INVALID_ARG;
+  ROME_BIND(c);
   if (p) ROME_HIP(c, hipFree(p));
   return ROME_OK;
 }
 int rome_dev_upload(rome_ctx* c, void* dst, const void* src, uint64_t bytes) {
   if (!c || (bytes && (!dst || !src))) return ROME_ERR_INVALID_ARG;
+  ROME_BIND(c);
   ROME_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
   ROME_HIP(c, hipStreamSynchronize(c->stream));
   return ROME_OK;
 }
 int rome_dev_download(rome_ctx* c, void* dst, const void* src, uint64_t bytes) {
   if (!c || (bytes && (!dst || !src))) return ROME_ERR_INVALID_ARG;
+  ROME_BIND(c);
   ROME_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   ROME_HIP(c, hipStreamSynchronize(c->stream));
   return ROME_OK;

@@ -16,6 +16,7 @@ struct ConvArgs {
   const int32_t* dir;         // [C] 0: solve 2nd ("to") variable, 1: solve 1st ("from"); nullptr -> dir_all
   const int32_t* fixed_var;   // [C] block of bel_fixed, or nullptr (identity)
   const int32_t* target_var;  // [C] block of bel_target (start points u0), or nullptr (identity)
+  const int32_t* rows4;       // [C][4] (factor, dir, fixed_var, target_var) interleaved, or nullptr; replaces the four columns
   const double* mu;           // [F][dz]
   const double* L;            // [F][dz(dz+1)/2] row-packed lower Cholesky of Σ  (bearing-range: [F][2] sigmas)
   const double* bel_fixed;

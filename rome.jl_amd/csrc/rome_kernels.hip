@@ -13,6 +13,7 @@
 //   * waves of a workgroup never wait for each other (Nelder-Mead trip counts differ per wave).
 // Blocks are 256 threads = 4 convolutions; blockIdx is remapped so that each XCD (own L2) works on
 // a contiguous range of the convolution table (neighbouring factors share variables).
+#include <cstdlib>
 #include "rome_device_math.hpp"
 #include "rome_kernels.h"
 
@@ -153,33 +154,43 @@ struct P2P2 {
     t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] = wrap_pi(t[2] + et);
   }
 
-  // per-particle constants of the root-find, computed once (not once per inflation cycle):
-  //   dir 0: a = q̂ = p ∘ exp_ϵ(z) ; dir 1: a = (q.x, q.y, θq - zθ) ; prior row: a = z
-  //   (fs, fc) = sin/cos of the root heading for dir 1 (θp = θq - zθ is known before solving): the Newton
-  //   iterations and the entropy of the later inflation cycles reuse it instead of re-evaluating sincos.
-  struct Prep { double a0, a1, a2, fs, fc; };
+  // per-particle constants of the root-find, computed once (not once per inflation cycle).  Both directions of the
+  // Pose2Pose2 residual  r(z; p, q) = ( p.t + R(θp) z_t - q.t , wrap(θp + zθ - θq) )  are affine in the unknown once its
+  // heading is fixed, so everything the solvers need from (z, fixed particle) folds into the point a:
+  //   dir 0 (solve q): a = p ∘ exp_ϵ(z) = (p.t + R(θp) z_t, θp + zθ)            r(q) = (a.t - q.t, wrap(aθ - qθ))
+  //   dir 1 (solve p): a = (q.t - R(θq - zθ) z_t, θq - zθ)                       r(p) = (p.t - a.t, wrap(pθ - aθ)) at pθ ≡ aθ
+  //   prior row:       a = z   (the sample is the proposal)
+  // (dir 1: the Jacobian is block-triangular -- r_θ depends on θ only -- so the Newton step solves θ first and takes the
+  // translation step with R at the UPDATED heading θq - zθ: R(θq - zθ) z_t is loop-invariant and is hoisted here.)
+  struct Prep { double a0, a1, a2; };
   __device__ static __forceinline__ Prep prepare(const Consts& K, const double (&z)[3], const double (&fxc)[3]) {
     Prep P;
-    P.fs = 0.0; P.fc = 1.0;
     if (K.dir == 0) {
       double s, c; fast_sincos(fxc[2], &s, &c);
       P.a0 = fxc[0] + c * z[0] - s * z[1]; P.a1 = fxc[1] + s * z[0] + c * z[1]; P.a2 = fxc[2] + z[2];
     } else if (K.dir == 1) {
-      P.a0 = fxc[0]; P.a1 = fxc[1]; P.a2 = fxc[2] - z[2];
-      fast_sincos(P.a2, &P.fs, &P.fc);
+      P.a2 = fxc[2] - z[2];
+      double s, c; fast_sincos(P.a2, &s, &c);
+      P.a0 = fxc[0] - (c * z[0] - s * z[1]); P.a1 = fxc[1] - (s * z[0] + c * z[1]);
     } else { P.a0 = z[0]; P.a1 = z[1]; P.a2 = z[2]; }
     return P;
   }
   // sin/cos of the current target heading for the entropy step (u0 ∘ exp_ϵ(jitter))
   template <int SOLVER>
-  __device__ static __forceinline__ void heading_sincos(const Consts& K, const Prep& P, int st, int cyc, const double (&t)[3],
-                                                        double* s, double* c) {
-    if (SOLVER == kSolverNewton && K.dir == 1 && cyc > 0 && st == 0) { *s = P.fs; *c = P.fc; }  // t[2] ≡ θp after a converged solve
-    else if constexpr (SOLVER == kSolverNelderMead) fast_sincos(t[2], s, c);
+  __device__ static __forceinline__ void heading_sincos(const Consts&, const Prep&, int, int, const double (&t)[3], double* s, double* c) {
+    if constexpr (SOLVER == kSolverNelderMead) fast_sincos(t[2], s, c);
     else {  // unique root: the frame of the jitter only reaches the start point -> hardware single-precision sin/cos (|θ| <= π)
       const float th = (float)t[2];
       *s = (double)__sinf(th); *c = (double)__cosf(th);
     }
+  }
+
+  // one Newton step from t (J = ∓I in the coordinates above); returns true when max|r| <= tol at t (then t is left untouched)
+  __device__ static __forceinline__ bool newton_step(const Prep& P, double (&t)[3], double tol) {
+    const double r0 = P.a0 - t[0], r1 = P.a1 - t[1], r2 = wrap_pi(P.a2 - t[2]);
+    const bool ok = fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol;
+    t[0] = ok ? t[0] : t[0] + r0; t[1] = ok ? t[1] : t[1] + r1; t[2] = ok ? t[2] : t[2] + r2;
+    return ok;
   }
 
   template <int SOLVER>
@@ -190,42 +201,20 @@ struct P2P2 {
       t[0] = P.a0; t[1] = P.a1; t[2] = wrap_pi(P.a2);
       return 0;
     }
-    if (K.dir == 0) {
-      const double qx = P.a0, qy = P.a1, qth = P.a2;
-      if constexpr (SOLVER == kSolverClosedForm) { t[0] = qx; t[1] = qy; t[2] = qth; }
-      else if constexpr (SOLVER == kSolverNewton) {
-        st = 1;
-        for (int it = 0; it < max_iters; ++it) {
-          const double r0 = qx - t[0], r1 = qy - t[1], r2 = wrap_pi(qth - t[2]);
-          if (fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol) { st = 0; break; }
-          t[0] += r0; t[1] += r1; t[2] += r2;   // J = -I
-        }
-      } else {
-        P2P2Cost cost{z[0], z[1], qx, qy, qth, 0};
-        st = nelder_mead<3>(cost, t, max_iters, tol);
-      }
+    if constexpr (SOLVER == kSolverClosedForm) { t[0] = P.a0; t[1] = P.a1; t[2] = P.a2; }
+    else if constexpr (SOLVER == kSolverNewton) {
+      // the residual is affine: the first step lands on the root, the second evaluates max|r| <= tol there.  Two predicated
+      // iterations in straight-line code (both particles of a lane interleave), the general loop only for what is left.
+      bool ok = false;
+      if (max_iters > 0) ok = newton_step(P, t, tol);   // (wave-uniform branches; a converged lane's step leaves t untouched,
+      if (max_iters > 1) ok = newton_step(P, t, tol);   //  so re-evaluating it returns the same verdict)
+      st = ok ? 0 : 1;
+      for (int it = 2; it < max_iters && st; ++it) st = newton_step(P, t, tol) ? 0 : 1;
     } else {
-      const double qx0 = P.a0, qy0 = P.a1, pth = P.a2;  // θp = θq - zθ
-      if constexpr (SOLVER == kSolverClosedForm) {
-        double s, c; fast_sincos(pth, &s, &c);
-        t[0] = qx0 - (c * z[0] - s * z[1]); t[1] = qy0 - (s * z[0] + c * z[1]); t[2] = pth;
-      } else if constexpr (SOLVER == kSolverNewton) {
-        // The Jacobian is block-triangular (r_θ depends on θ only): Newton on θ first, then on the
-        // translation with R(θ) at the UPDATED heading (block Gauss-Seidel/Newton).  sin/cos are only
-        // recomputed when θ moved, so a converging solve costs one sincos instead of three.
-        st = 1;
-        const double s = P.fs, c = P.fc;  // sin/cos(θp): after the θ step below t[2] ≡ θp (mod 2π) up to rounding / tol
-        for (int it = 0; it < max_iters; ++it) {
-          const double r2 = wrap_pi(t[2] - pth);
-          if (fabs(r2) > tol) t[2] -= r2;  // else θ is converged: (r0, r1, r2) below is the residual at the returned point
-          const double r0 = t[0] + c * z[0] - s * z[1] - qx0, r1 = t[1] + s * z[0] + c * z[1] - qy0;
-          if (fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol) { st = 0; break; }
-          t[0] -= r0; t[1] -= r1;
-        }
-      } else {
-        P2P2Cost cost{z[0], z[1], qx0, qy0, pth, 1};
-        st = nelder_mead<3>(cost, t, max_iters, tol);
-      }
+      P2P2Cost cost{z[0], z[1], 0.0, 0.0, 0.0, K.dir};
+      if (K.dir == 0) { cost.a0 = P.a0; cost.a1 = P.a1; cost.a2 = P.a2; }
+      else { cost.a0 = fxc[0]; cost.a1 = fxc[1]; cost.a2 = P.a2; }
+      st = nelder_mead<3>(cost, t, max_iters, tol);
     }
     t[2] = wrap_pi(t[2]);
     return st;
@@ -592,15 +581,18 @@ template <class FP, int SOLVER, int PPL, bool LEAN>
 __global__ void __launch_bounds__(64 * ROME_WPB, (SOLVER == kSolverNelderMead && FP::DT <= 3) ? 4 : ((SOLVER != kSolverNelderMead && FP::DT == 6) ? ROME_P3_MINBLK : ROME_MIN_WAVES))
 k_conv(const ConvArgs a) {
   const int lane = threadIdx.x & 63;
-  const int c = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * ROME_WPB + (int)(threadIdx.x >> 6));
-  if (c >= a.n_conv) return;
+  // no early exit: the (at most ROME_WPB - 1) surplus waves of the last block redo the last row and skip its stores, so that
+  // no kernel-argument load has to wait for the n_conv comparison (all of them are issued together)
+  const int c_raw = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * ROME_WPB + (int)(threadIdx.x >> 6));
+  const bool valid = c_raw < a.n_conv;
+  const int c = valid ? c_raw : a.n_conv - 1;
   const int N = a.N;
   int f, dr, fv, tv;
-  if constexpr (LEAN) {
-    f = a.factor[c]; fv = a.fixed_var[c]; tv = a.target_var[c];
-    if constexpr (FP::kHypoDir < 0) dr = a.dir[c]; else dr = a.dir_all;   // bearing-range: the direction is the kernel's template argument
-  }
-  else {
+  if (LEAN || a.rows4) {   // one 16-byte scalar load for the whole row
+    const int4 row = *reinterpret_cast<const int4*>(a.rows4 + 4 * (size_t)c);
+    f = row.x; fv = row.z; tv = row.w;
+    dr = FP::kHypoDir < 0 ? row.y : a.dir_all;   // bearing-range: the direction is the kernel's template argument
+  } else {
     f = a.factor ? a.factor[c] : c;
     dr = a.dir ? a.dir[c] : a.dir_all;
     fv = a.fixed_var ? a.fixed_var[c] : c;
@@ -618,15 +610,22 @@ k_conv(const ConvArgs a) {
   bool act[PPL];
   [[maybe_unused]] double xi_odd[3];   // normals of the odd slot, produced together with the even slot's (shared Box-Muller pair)
   [[maybe_unused]] EntropyWords ew[PPL];   // cheap-entropy words: slot k (even) serves particles k and k+1
+#ifndef ROME_NOISE_FIRST
+#define ROME_NOISE_FIRST 1
+#endif
+  // measurement samples first (they depend on nothing but the convolution id), then the belief loads: the loaded particles
+  // are then not live across the Philox / Box-Muller block (fewer registers at the kernel's pressure peak)
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     const int i = lane + 64 * k;
     act[k] = i < N;
     const int ii = act[k] ? i : 0;  // idle lanes shadow particle 0 (keeps the math finite, never stored)
+    if constexpr (!ROME_NOISE_FIRST) {
 #pragma unroll
-    for (int d = 0; d < FP::DF; ++d) fx[k][d] = fb[d * N + ii];
+      for (int d = 0; d < FP::DF; ++d) fx[k][d] = fb[d * N + ii];
 #pragma unroll
-    for (int d = 0; d < FP::DT; ++d) t[k][d] = tb[d * N + ii];
+      for (int d = 0; d < FP::DT; ++d) t[k][d] = tb[d * N + ii];
+    }
     double xi[FP::DZ];
     if (!LEAN && a.noise) {
       const double* nb = a.noise + (size_t)c * FP::DZ * N;
@@ -640,6 +639,17 @@ k_conv(const ConvArgs a) {
       rng_normals<FP::DZ>(a.seed, stream, (uint32_t)ii, xi);
     }
     FP::measurement(K, xi, z[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    const int i = lane + 64 * k;
+    const int ii = act[k] ? i : 0;
+    if constexpr (ROME_NOISE_FIRST) {
+#pragma unroll
+      for (int d = 0; d < FP::DF; ++d) fx[k][d] = fb[d * N + ii];
+#pragma unroll
+      for (int d = 0; d < FP::DT; ++d) t[k][d] = tb[d * N + ii];
+    }
     FP::canonical(t[k]);
     aux[k] = FP::init_aux(t[k]);
     prep[k] = FP::prepare(K, z[k], fx[k]);
@@ -798,7 +808,7 @@ k_conv(const ConvArgs a) {
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     const int i = lane + 64 * k;
-    if (act[k]) {
+    if (act[k] && valid) {
       FP::finalize(t[k], aux[k]);
 #pragma unroll
       for (int d = 0; d < FP::DT; ++d) ob[d * N + i] = t[k][d];
@@ -806,7 +816,7 @@ k_conv(const ConvArgs a) {
     }
   }
   for (int m = 0; m < a.n_mirror; ++m) {  // wave-uniform: separator rows are duplicated into the exchange buffer
-    if (a.mirror_row[m] == c) {
+    if (a.mirror_row[m] == c_raw) {
       double* mb = a.mirror_out + (size_t)m * FP::DT * N;
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
@@ -960,21 +970,25 @@ hipError_t launch_coords_to_points(int n, int dim, const double* c, double* pts,
   if (n > 0) hipLaunchKernelGGL(k_coords_to_points, dim3((n + 255) / 256), dim3(256), 0, s, n, dim, c, pts);
   return hipGetLastError();
 }
+static int lds_pad_bytes() {   // experiment knob: unused dynamic LDS per block caps the resident blocks per CU (ROME_LDS_PAD=bytes)
+  static const int v = [] { const char* e = getenv("ROME_LDS_PAD"); return e ? atoi(e) : 0; }();
+  return v;
+}
 template <class FP, int SOLVER, bool LEAN>
 static hipError_t launch_ppl_v(const ConvArgs& a, hipStream_t s) {
   const int nb = (a.n_conv + ROME_WPB - 1) / ROME_WPB;
   if (nb == 0) return hipSuccess;
-  if (a.N <= 64)       hipLaunchKernelGGL((k_conv<FP, SOLVER, 1, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
-  else if (a.N <= 128) hipLaunchKernelGGL((k_conv<FP, SOLVER, 2, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
-  else if (a.N <= 256) hipLaunchKernelGGL((k_conv<FP, SOLVER, 4, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
-  else if (a.N <= 512) hipLaunchKernelGGL((k_conv<FP, SOLVER, 8, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  const int pad = lds_pad_bytes();
+  if (a.N <= 64)       hipLaunchKernelGGL((k_conv<FP, SOLVER, 1, LEAN>), dim3(nb), dim3(64 * ROME_WPB), pad, s, a);
+  else if (a.N <= 128) hipLaunchKernelGGL((k_conv<FP, SOLVER, 2, LEAN>), dim3(nb), dim3(64 * ROME_WPB), pad, s, a);
+  else if (a.N <= 256) hipLaunchKernelGGL((k_conv<FP, SOLVER, 4, LEAN>), dim3(nb), dim3(64 * ROME_WPB), pad, s, a);
+  else if (a.N <= 512) hipLaunchKernelGGL((k_conv<FP, SOLVER, 8, LEAN>), dim3(nb), dim3(64 * ROME_WPB), pad, s, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 template <class FP, int SOLVER>
 static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
-  const bool lean = a.noise == nullptr && a.alt_var == nullptr && a.nullhypo == nullptr &&
-                    a.factor && (a.dir || FP::kHypoDir >= 0) && a.fixed_var && a.target_var;
+  const bool lean = a.rows4 != nullptr && a.noise == nullptr && a.alt_var == nullptr && a.nullhypo == nullptr;
   return lean ? launch_ppl_v<FP, SOLVER, true>(a, s) : launch_ppl_v<FP, SOLVER, false>(a, s);
 }
 template <class FP>

@@ -50,8 +50,10 @@ class DeviceGraph:
             factor = np.concatenate([factor, F + np.arange(P, dtype=np.int32)])
             dr = np.concatenate([dr, np.full(P, 2, dtype=np.int32)])
             fixed = np.concatenate([fixed, ptab["var"]]); target = np.concatenate([target, ptab["var"]])
+            # rows4: the four table columns interleaved (one 16-byte scalar load per convolution; selects the lean kernel)
             self.tab[name] = dict(F=F, P=P, C_rel=2 * F, C=2 * F + P, mu=t(mu, f64), L=t(cholesky_lower(cov), f64),
-                                  factor=t(factor, i32), dir=t(dr, i32), fixed=t(fixed, i32), target=t(target, i32))
+                                  factor=t(factor, i32), dir=t(dr, i32), fixed=t(fixed, i32), target=t(target, i32),
+                                  rows4=t(np.stack([factor, dr, fixed, target], axis=1), i32))
         if pk.br["F"]:
             b = pk.br
             r0 = b["rows0"]
@@ -59,7 +61,9 @@ class DeviceGraph:
             self.tab["br"] = dict(F=b["F"], F0=len(r0["factor"]), mh=mh, mu=t(b["mu"], f64), sigma=t(b["sigma"], f64),
                                   pose=t(b["pose"], i32), point=t(b["point"], i32), alt=t(b["alt"], i32), w=t(b["w"], f64),
                                   factor0=t(r0["factor"], i32), pose0=t(r0["pose"], i32), point0=t(r0["point"], i32),
-                                  alt0=t(r0["alt"], i32), w0=t(r0["w"], f64))
+                                  alt0=t(r0["alt"], i32), w0=t(r0["w"], f64),
+                                  rows4_0=t(np.stack([r0["factor"], np.zeros(len(r0["factor"]), np.int32), r0["pose"], r0["point"]], axis=1), i32),
+                                  rows4_1=t(np.stack([np.arange(b["F"], dtype=np.int32), np.ones(b["F"], np.int32), b["point"], b["pose"]], axis=1), i32))
         for name, tab, d in (("prior2", pk.prior2, 3), ("prior3", pk.prior3, 6)):
             if tab["F"]:
                 self.tab[name] = dict(F=tab["F"], mu=t(tab["mu"], f64), L=t(cholesky_lower(tab["cov"]), f64), var=t(tab["var"], i32))
@@ -178,7 +182,7 @@ class DeviceGraph:
     def plan_sweep_pose2pose2(self, opts, out, noise=None, status=None):
         tb = self.tab["p2p2"]
         return self._plan(self._lib.rome_conv_pose2pose2_dev, opts, n_conv=tb["C"], dir_all=0,
-                          factor=tb["factor"], dir=tb["dir"], fixed_var=tb["fixed"], target_var=tb["target"],
+                          factor=tb["factor"], dir=tb["dir"], fixed_var=tb["fixed"], target_var=tb["target"], rows4=tb["rows4"],
                           mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Pose2],
                           noise=noise, out=out, status=status)
 
@@ -325,7 +329,7 @@ class DeviceGraph:
         o = _lib.Opts.from_buffer_copy(opts); o.stream_offset = opts.stream_offset + lo
         self._launch(self._lib.rome_conv_pose2pose2_dev, o, n_conv=n, dir_all=0,
                      factor=tb["factor"][lo:hi], dir=tb["dir"][lo:hi], fixed_var=tb["fixed"][lo:hi], target_var=tb["target"][lo:hi],
-                     mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Pose2],
+                     rows4=tb["rows4"][lo:hi], mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Pose2],
                      noise=noise, out=out, status=status)
         return out
 
@@ -334,7 +338,7 @@ class DeviceGraph:
         if out is None:
             out = self.torch.empty((tb["C"], 6, self.N), dtype=self.torch.float64, device=self.device)
         self._launch(self._lib.rome_conv_pose3pose3_dev, opts, n_conv=tb["C"], dir_all=0,
-                     factor=tb["factor"], dir=tb["dir"], fixed_var=tb["fixed"], target_var=tb["target"],
+                     factor=tb["factor"], dir=tb["dir"], fixed_var=tb["fixed"], target_var=tb["target"], rows4=tb["rows4"],
                      mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose3], bel_target=self.bel[Pose3],
                      noise=noise, out=out, status=status)
         return out
@@ -348,11 +352,13 @@ class DeviceGraph:
         if out is None:
             out = self.torch.empty((nrow, dt, self.N), dtype=self.torch.float64, device=self.device)
         if direction == 0:
-            kw = dict(factor=tb["factor0"], fixed_var=tb["pose0"], target_var=tb["point0"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Point2])
+            kw = dict(factor=tb["factor0"], fixed_var=tb["pose0"], target_var=tb["point0"], rows4=tb["rows4_0"],
+                      bel_fixed=self.bel[Pose2], bel_target=self.bel[Point2])
             if tb["mh"]:
                 kw.update(alt_var=tb["alt0"], hypo_w=tb["w0"])
         else:
-            kw = dict(factor=None, fixed_var=tb["point"], target_var=tb["pose"], bel_fixed=self.bel[Point2], bel_target=self.bel[Pose2])
+            kw = dict(factor=None, fixed_var=tb["point"], target_var=tb["pose"], rows4=tb["rows4_1"],
+                      bel_fixed=self.bel[Point2], bel_target=self.bel[Pose2])
             if tb["mh"]:
                 kw.update(alt_var=tb["alt"], hypo_w=tb["w"])
         self._launch(self._lib.rome_conv_pose2point2br_dev, opts, n_conv=nrow, dir_all=int(direction), dir=None,

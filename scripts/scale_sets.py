@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import rome_jl_amd as R
 
-for F in (5453, 1 << 16, 1 << 20):
+SIZES = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else (5453, 1 << 16, 1 << 20)
+for F in SIZES:
     pk, bel = R.synth_pose2_tables(F)
     dg = R.DeviceGraph(pk)
     dg.bel[R.Pose2].copy_(torch.as_tensor(bel))

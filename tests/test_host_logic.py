@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(R._lib.Opts) == 72
-    assert ctypes.sizeof(R._lib.ConvDev) == 8 + 11 * 8 + 24 + 8 + 16 + 8
+    assert ctypes.sizeof(R._lib.ConvDev) == 8 + 11 * 8 + 24 + 8 + 16 + 8 + 8   # ... + rows4
     o = R.make_opts(solver=R.SOLVER_NELDER_MEAD)
     assert (o.n_particles, o.max_iters, o.inflate_cycles, o.tol, o.inflation) == (100, 1000, 3, 1e-8, 5.0)
     o = R.make_opts(N=64)
