@@ -46,15 +46,28 @@ def parse():
                                                  "ships as examples/manhattan.g2o; 'synthetic' forces the generator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra per-solver throughput runs")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=40.0)
     ap.add_argument("--settle-launches", type=int, default=4000,
                     help="untimed launches BEFORE the --warmup steps so that the device reaches its steady clocks whatever W is "
                          "(the first ~50-100 ms of back-to-back launches run 20-30 %% slower); 0 disables")
     return ap.parse_args()
 
 
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)   # does not return
     import torch
     import torch.distributed as dist
     import rome_jl_amd as R
@@ -75,7 +88,13 @@ def main():
         if world == 1:
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, "--gpus must match WORLD_SIZE"
+        if dist.get_world_size() != world:
+            raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a number "
+                         "for a different GPU count" % (args.gpus, world))
+    if torch.cuda.device_count() < (args.gpus if "LOCAL_WORLD_SIZE" not in os.environ else int(os.environ["LOCAL_WORLD_SIZE"])):
+        raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) are visible" % (args.gpus, torch.cuda.device_count()))
 
     N = args.particles
     solver = {"closed_form": R.SOLVER_CLOSED_FORM, "newton": R.SOLVER_NEWTON, "nelder_mead": R.SOLVER_NELDER_MEAD}[args.solver]
@@ -184,7 +203,7 @@ def main():
 
     out = {
         "metric": "factor convolutions/sec (N=100) on Manhattan-3500; solveTree! wall-clock",
-        "value": value, "unit": "convolutions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "convolutions/s", "n_gpus": (dist.get_world_size() if multi else 1), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": data_kind,
         "config": {"workload": workload, "poses_per_gpu": len(pk.labels[R.Pose2]), "pose2pose2_factors_per_gpu": tb["F"],
@@ -202,6 +221,7 @@ def main():
                 tj = json.load(f)
             if tj.get("solver") == args.solver and tj.get("n_conv") == tb["C"]:
                 out["roofline"]["traffic"] = tj.get("bytes_per_launch")
+                out["roofline"]["traffic_kind"] = "stored"   # PMC counters need rocprofv3 around the process: not measured in this run
                 out["roofline"]["traffic_source"] = tj.get("source")
         except Exception:
             pass
@@ -282,10 +302,11 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R, pk, fg, N, args.cpu_seconds)
-        if "gpu_convolutions_per_s_by_solver" in out:
-            out["cpu_baseline"]["gpu_nelder_mead_over_cpu_nelder_mead"] = \
-                out["gpu_convolutions_per_s_by_solver"]["nelder_mead"] / out["cpu_baseline"]["value"]
-        out["cpu_baseline"]["gpu_value_over_cpu"] = value / out["cpu_baseline"]["value"]
+        gpu = dict(out.get("gpu_convolutions_per_s_by_solver", {}))
+        gpu[args.solver] = value
+        # every GPU/CPU ratio is same-solver (the CPU side at its best thread count)
+        out["cpu_baseline"]["gpu_over_cpu_same_solver"] = {k: gpu[k] / out["cpu_baseline"]["by_solver"][k]["conv_per_s"]
+                                                           for k in gpu if k in out["cpu_baseline"]["by_solver"]}
 
     # the JSON line must be the LAST thing on stdout: RCCL's version banner sits in the C stdio buffer of the ranks that
     # initialised a communicator and would otherwise be flushed at exit, after the line
@@ -306,29 +327,31 @@ def main():
 
 
 def cpu_baseline(R, pk, fg, N, budget_s):
-    """The oracle (C port of the reference algorithm: Optim-default Nelder-Mead per particle, 3 inflate
-    cycles) on the host cores of this box, OpenMP over convolutions, on a bounded prefix of the SAME
-    convolution table.  Reported baseline only -- never part of the product path."""
-    import oracle as ro
+    """The oracle (C port of the reference algorithm) on the host cores of this box, on a bounded prefix of the SAME
+    convolution table: oracle/cpu_bench.py in fresh processes (OpenMP configured before start, no torch thread pool beside it),
+    built there with -O3 -march=native, >= 5 repetitions, median; Nelder-Mead (the reference's Optim algorithm: `value`),
+    Newton and closed form, at 1 thread and on all cores.  Reported baseline only -- never part of the product path."""
+    import subprocess
+    import tempfile
     factor, dr, fixed, target = R.PackedGraph.conv_table(pk.p2p2)
     L = R.cholesky_lower(pk.p2p2["cov"])
     bel = pk.beliefs(fg, R.Pose2)
-    o = ro.make_opts(N=N, solver=ro.SOLVER_NELDER_MEAD, seed=0x524F4D45)
-    cores = ro.num_threads()
-
-    def run(n):
-        t = time.perf_counter()
-        ro.conv_pose2pose2(o, pk.p2p2["mu"], L, bel, fixed[:n], target[:n], dr[:n], factor=factor[:n])
-        return time.perf_counter() - t
-
-    n0 = min(len(factor), 64 * cores)
-    t0 = run(n0)
-    n = int(min(len(factor), max(n0, n0 * budget_s / max(t0, 1e-3))))
-    reps = max(1, int(budget_s / max(1e-3, t0 * n / n0)))  # repeat the (possibly whole-table) sample up to the budget
-    t = min(run(n) for _ in range(min(reps, 5)))
-    return {"value": n / t, "unit": "convolutions/s", "cores": cores, "kind": "port",
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "table.npz")
+        np.savez(path, mu=pk.p2p2["mu"], L=L, bel=bel, factor=factor, dir=dr, fixed=fixed, target=target)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), path, "--budget", str(budget_s)],
+                           capture_output=True, text=True)
+    if p.returncode != 0:
+        return {"value": None, "unit": "convolutions/s", "kind": "port", "error": p.stderr[-800:]}
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    nm = r["best"]["nelder_mead"]
+    return {"value": nm["conv_per_s"], "unit": "convolutions/s", "cores": nm["threads"], "kind": "port",
             "algorithm": "Optim.jl-default Nelder-Mead per particle (reference algorithm), inflate_cycles=3",
-            "sample": "first %d of %d (factor,direction) convolutions of the same graph, N=%d, %.1f s" % (n, len(factor), N, t)}
+            "sample": "first %d of %d (factor,direction) convolutions of the same graph, N=%d, median of %d runs of %.2f s"
+                      % (nm["sample_convolutions"], len(factor), N, nm["reps"], nm["median_s"]),
+            "flags": r["flags"], "omp": r["omp"], "host": r["host"],
+            "one_thread_conv_per_s": nm["one_thread_conv_per_s"], "parallel_efficiency": nm["parallel_efficiency"],
+            "by_solver": r["best"], "runs": r["runs"]}
 
 
 if __name__ == "__main__":

@@ -399,11 +399,13 @@ struct Se2 { double x, y, c, s; };  // point ((x,y), R=[c -s; s c])
 __device__ __forceinline__ Se2 se2_from_coords(double x, double y, double th) {
   Se2 p; p.x = x; p.y = y; fast_sincos(th, &p.s, &p.c); return p;
 }
-// Manifolds.sym_rem: (x ≈ π ? -π : rem(x, 2π, RoundNearest))
+// Manifolds.sym_rem: (x ≈ π ? -π : rem(x, 2π, RoundNearest)).  The IEEE remainder is evaluated as x − k·2π with k = rint(x/2π) and
+// 2π split in two parts (wrap_pi): exact for |x| < 2π·2^20 up to 2.5e-16·|k|, i.e. the correctly rounded result to an ulp of π for
+// every angle on this path -- instead of ocml's remainder() (a division-free but ~100-instruction exponent loop).
 __device__ __forceinline__ double sym_rem(double x) {
   const double m = fabs(x) > kPi ? fabs(x) : kPi;
-  if (fabs(x - kPi) <= kSqrtEps * m) return -kPi;
-  return remainder(x, 2.0 * kPi);
+  const double r = wrap_pi(x);
+  return fabs(x - kPi) <= kSqrtEps * m ? -kPi : r;
 }
 
 // Pose2Pose2: r = vee(log(q, p ∘ exp_ϵ(X)));  X = ((zx,zy), skew(zθ)) with (cz,sz)=cos/sin(zθ)
@@ -561,6 +563,21 @@ __device__ __forceinline__ void quat_log(const double (&q)[4], double* w) {
   if (2.0 * aw * aw <= kSqrtEps) k = kPi / n;
   k = q[0] < 0.0 ? -k : k;
   w[0] = k * q[1]; w[1] = k * q[2]; w[2] = k * q[3];
+}
+// Single-precision Log for the inflation-spread statistic only (|error| <= 3e-5 rad): asin by a degree-4 polynomial in x² on
+// x <= 1/√2 (the branch selection of quat_angle), one hardware sqrt / rcp; no library call, ~25 instructions.
+__device__ __forceinline__ void quat_log_f32(const double (&q)[4], float (&w)[3]) {
+  const float x = (float)q[1], y = (float)q[2], z = (float)q[3], aw = fabsf((float)q[0]);
+  const float n2 = fmaf(x, x, fmaf(y, y, z * z));
+  const float n = __builtin_sqrtf(n2);
+  const float m = fminf(n, aw), m2 = m * m;
+  float p = 0.09535770863294601f;
+  p = fmaf(p, m2, 0.008225217461585999f); p = fmaf(p, m2, 0.08268097043037415f); p = fmaf(p, m2, 0.16607673466205597f); p = fmaf(p, m2, 1.000010371208191f);
+  const float as = m * p;
+  const float th = n <= aw ? 2.0f * as : 3.14159265358979f - 2.0f * as;
+  float k = n2 > 1e-12f ? th * __builtin_amdgcn_rcpf(n) : 2.0f;
+  k = q[0] < 0.0 ? -k : k;
+  w[0] = k * x; w[1] = k * y; w[2] = k * z;
 }
 __device__ __forceinline__ void quat_mul(const double (&a)[4], const double (&b)[4], double (&o)[4]) {
   o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];

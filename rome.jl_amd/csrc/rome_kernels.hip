@@ -281,53 +281,64 @@ struct BR {
       t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] = wrap_pi(t[2] + et);
     } else { t[0] += spread * (u[0] - 0.5); t[1] += spread * (u[1] - 0.5); }
   }
-  struct Prep {};
-  __device__ static __forceinline__ Prep prepare(const Consts&, const double (&)[2], const double (&)[DF]) { return Prep{}; }
+  // Solver form of the residual (src/factors/BearingRange2D.jl:48-64): pl = R(θp)ᵀ (l − p.t) has norm n = ‖l − p.t‖ and angle
+  // ψ − θp with ψ = atan2(l − p.t) the world bearing, so  r = ( sym_rem(b − (ψ − θp)), ρ − n )  without a sin/cos per evaluation
+  // (same function as residual_bearingrange up to rounding; the residual entry points keep the reference's literal form).
+  //   DIR 0 (landmark): the exact polar Newton step about the pose lands on  l* = p.t + ρ (cos, sin)(θp + b)  whatever the start:
+  //                     l* is prepared once (one sincos), a step is "evaluate r, go to l*".
+  //   DIR 1 (pose):     2 equations / 3 unknowns.  The block step keeps the ray landmark -> pose: move along it to the measured
+  //                     range, then turn to the measured bearing (what the minimum-norm Gauss-Newton step approaches for ρ >> 1).
+  struct Prep { double a0, a1; };
+  __device__ static __forceinline__ Prep prepare(const Consts&, const double (&z)[2], const double (&fx)[DF]) {
+    Prep P; P.a0 = 0.0; P.a1 = 0.0;
+    if constexpr (DIR == 0) {
+      double s, c; fast_sincos(fx[2] + z[0], &s, &c);
+      P.a0 = fx[0] + z[1] * c; P.a1 = fx[1] + z[1] * s;
+    }
+    return P;
+  }
   template <int SOLVER>
   __device__ static __forceinline__ void heading_sincos(const Consts&, const Prep&, int, int, const double (&t)[DT], double* s, double* c) {
     if constexpr (DT == 3) fast_sincos(t[2], s, c); else { *s = 0.0; *c = 1.0; }
   }
+  __device__ static __forceinline__ bool newton_step(const Prep& P, const double (&z)[2], const double (&fx)[DF], double (&t)[DT], double tol) {
+    if constexpr (DIR == 0) {
+      const double dx = t[0] - fx[0], dy = t[1] - fx[1];
+      const double n = fast_sqrt(dx * dx + dy * dy), psi = fast_atan2(dy, dx);
+      const double r0 = sym_rem(z[0] - (psi - fx[2])), r1 = z[1] - n;
+      const bool ok = fmax(fabs(r0), fabs(r1)) <= tol;
+      t[0] = ok ? t[0] : P.a0; t[1] = ok ? t[1] : P.a1;
+      return ok;
+    } else {
+      const double dx = fx[0] - t[0], dy = fx[1] - t[1];
+      const double n2 = dx * dx + dy * dy;
+      const double n = fast_sqrt(n2), psi = fast_atan2(dy, dx);
+      const double r0 = sym_rem(z[0] - (psi - t[2])), r1 = z[1] - n;
+      const bool ok = fmax(fabs(r0), fabs(r1)) <= tol;
+      const double k = n > 0.0 ? z[1] / n : 0.0;                       // pose coincides with the landmark: leave along +x
+      const double nx = n > 0.0 ? fx[0] - k * dx : fx[0] - z[1], ny = fx[1] - k * dy;
+      t[0] = ok ? t[0] : nx; t[1] = ok ? t[1] : ny; t[2] = ok ? t[2] : psi - z[0];
+      return ok;
+    }
+  }
   template <int SOLVER>
-  __device__ static __forceinline__ int solve(const Consts&, const Prep&, const double (&z)[2], const double (&fx)[DF],
+  __device__ static __forceinline__ int solve(const Consts&, const Prep& P, const double (&z)[2], const double (&fx)[DF],
                                               double (&t)[DT], Aux&, int max_iters, double tol) {
     int st = 0;
     if constexpr (SOLVER == kSolverClosedForm) {
-      if constexpr (DIR == 0) {
-        double s, c; fast_sincos(fx[2] + z[0], &s, &c);
-        t[0] = fx[0] + z[1] * c; t[1] = fx[1] + z[1] * s;
-      } else {
+      if constexpr (DIR == 0) { t[0] = P.a0; t[1] = P.a1; }
+      else {
         const double dx = fx[0] - t[0], dy = fx[1] - t[1];
         const double n = fast_sqrt(dx * dx + dy * dy);
         const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
         t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = fast_atan2(uy, ux) - z[0];
       }
     } else if constexpr (SOLVER == kSolverNewton) {
-      st = 1;
-      for (int it = 0; it < max_iters; ++it) {
-        double r[2];
-        if constexpr (DIR == 0) {
-          const Se2 P = se2_from_coords(fx[0], fx[1], fx[2]);
-          residual_bearingrange(z[0], z[1], P, t[0], t[1], r);
-          if (fmax(fabs(r[0]), fabs(r[1])) <= tol) { st = 0; break; }
-          const double dx = t[0] - fx[0], dy = t[1] - fx[1];
-          const double plx = P.c * dx + P.s * dy, ply = -P.s * dx + P.c * dy;
-          const double n = fast_sqrt(plx * plx + ply * ply), phi = fast_atan2(ply, plx);
-          const double nn = n + r[1];
-          double sa, ca; fast_sincos(phi + r[0], &sa, &ca);
-          const double qx = nn * ca, qy = nn * sa;
-          t[0] = fx[0] + P.c * qx - P.s * qy; t[1] = fx[1] + P.s * qx + P.c * qy;
-        } else {
-          const Se2 P = se2_from_coords(t[0], t[1], t[2]);
-          residual_bearingrange(z[0], z[1], P, fx[0], fx[1], r);
-          if (fmax(fabs(r[0]), fabs(r[1])) <= tol) { st = 0; break; }
-          // under-determined (2 eq / 3 unknowns): exact block step that keeps the ray landmark->pose: move along
-          // the ray to the measured range, then rotate to the measured bearing
-          const double dx = fx[0] - t[0], dy = fx[1] - t[1];
-          const double n = fast_sqrt(dx * dx + dy * dy);
-          const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
-          t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = fast_atan2(uy, ux) - z[0];
-        }
-      }
+      bool ok = false;
+      if (max_iters > 0) ok = newton_step(P, z, fx, t, tol);   // lands on a root
+      if (max_iters > 1) ok = newton_step(P, z, fx, t, tol);   // evaluates the residual there (wave-uniform branches)
+      st = ok ? 0 : 1;
+      for (int it = 2; it < max_iters && st; ++it) st = newton_step(P, z, fx, t, tol) ? 0 : 1;
     } else {
       BRCost<DIR> cost{z[0], z[1], {fx[0], fx[1], DF == 3 ? fx[DF - 1] : 0.0}};
       st = nelder_mead<DT>(cost, t, max_iters, tol);
@@ -442,9 +453,10 @@ struct P3P3 {
       for (int j = 0; j < 7; ++j) s[j] = 0.0f;
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
-        double e[4], w[3];
-        quat_cmul(q0, A[k].q, e); quat_log(e, w);
-        const float d[6] = {(float)(t[k][0] - c0[0]), (float)(t[k][1] - c0[1]), (float)(t[k][2] - c0[2]), (float)w[0], (float)w[1], (float)w[2]};
+        double e[4];
+        float w[3];
+        quat_cmul(q0, A[k].q, e); quat_log_f32(e, w);   // single-precision Log (the spread only scales a start-point jitter)
+        const float d[6] = {(float)(t[k][0] - c0[0]), (float)(t[k][1] - c0[1]), (float)(t[k][2] - c0[2]), w[0], w[1], w[2]};
         if (act[k]) {
 #pragma unroll
           for (int j = 0; j < 6; ++j) { s[j] += d[j]; s[6] = fmaf(d[j], d[j], s[6]); }
@@ -458,6 +470,11 @@ struct P3P3 {
       return (double)fminf(__builtin_sqrtf(fmaxf(0.0f, (s[6] - m2 * fi) * fd)), 3.0e38f);
     }
   }
+  // The root (a, qa) of the residual, prepared once per particle for both directions (cf. P2P2::Prep): with the rotation
+  // solved first, the translation residual is affine with R at the root rotation, so R(qa) z_t is loop-invariant:
+  //   dir 0 (solve q): qa = q_p ⊗ q_z,        a = p.t + R_p z_t
+  //   dir 1 (solve p): qa = q_q ⊗ conj(q_z),  a = q.t − R(qa) z_t
+  //   prior row:       qa = Exp(z_ω),          a = z_t
   struct Prep { double a[3], qa[4]; };
   __device__ static __forceinline__ Prep prepare(const Consts& K, const double (&z)[6], const double (&fxc)[6]) {
     Prep P;
@@ -470,17 +487,16 @@ struct P3P3 {
       for (int k = 0; k < 4; ++k) P.qa[k] = qz[k];
       return P;
     }
-    double qF[4];
+    double qF[4], v[3];
     quat_exp(&fxc[3], qF);
     if (K.dir == 0) {
-      double v[3];
       quat_mul(qF, qz, P.qa); quat_rot(qF, z, v);
 #pragma unroll
       for (int k = 0; k < 3; ++k) P.a[k] = fxc[k] + v[k];
     } else {
-      quat_mulc(qF, qz, P.qa);
+      quat_mulc(qF, qz, P.qa); quat_rot(P.qa, z, v);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) P.a[k] = fxc[k];
+      for (int k = 0; k < 3; ++k) P.a[k] = fxc[k] - v[k];
     }
     return P;
   }
@@ -499,51 +515,40 @@ struct P3P3 {
 #pragma unroll
     for (int k = 0; k < 4; ++k) A.q[k] = qn[k];
   }
+  // One Newton step on the group from (t, q): the rotation step q ← q ⊗ (conj(q) ⊗ qa) is exact (right-perturbation update
+  // with the residual itself, no Exp / Log), the translation follows.  Returns true when the residual at (t, q) is within
+  // tol (then the state is left untouched).  |Log e| = 2·atan2(|e_v|, |e_w|): below 2e-10 rad it is 2·e_v to 1e-30.
+  __device__ static __forceinline__ bool newton_step(const Prep& P, double (&t)[6], Aux& A, double tol) {
+    double e[4], qn[4];
+    quat_cmul(A.q, P.qa, e);
+    const double r0 = P.a[0] - t[0], r1 = P.a[1] - t[1], r2 = P.a[2] - t[2];
+    const double n2 = e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
+    const double m = fmax(fmax(fabs(r0), fabs(r1)), fmax(fabs(r2), 2.0 * fmax(fabs(e[1]), fmax(fabs(e[2]), fabs(e[3])))));
+    const bool ok = n2 <= 1e-20 && m <= tol;
+    quat_mul(A.q, e, qn);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A.q[k] = ok ? A.q[k] : qn[k];
+    t[0] = ok ? t[0] : t[0] + r0; t[1] = ok ? t[1] : t[1] + r1; t[2] = ok ? t[2] : t[2] + r2;
+    return ok;
+  }
   template <int SOLVER>
   __device__ static __forceinline__ int solve(const Consts& K, const Prep& P, const double (&z)[6], const double (&fxc)[6],
                                               double (&t)[6], Aux& A, int max_iters, double tol) {
     int st = 0;
-    if (K.dir == kDirPrior || (SOLVER == kSolverClosedForm && K.dir == 0)) {
+    if (K.dir == kDirPrior || SOLVER == kSolverClosedForm) {   // the prepared root itself
 #pragma unroll
       for (int k = 0; k < 3; ++k) t[k] = P.a[k];
 #pragma unroll
       for (int k = 0; k < 4; ++k) A.q[k] = P.qa[k];
       return 0;
     }
-    if constexpr (SOLVER == kSolverClosedForm) {   // dir 1
-      double v[3];
-      quat_rot(P.qa, z, v);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) t[k] = P.a[k] - v[k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) A.q[k] = P.qa[k];
-    } else if constexpr (SOLVER == kSolverNewton) {
-      // Newton on the group: the rotation step  q ← q ⊗ (conj(q) ⊗ qa)  is exact (right-perturbation update with the
-      // residual itself), the translation follows with the updated rotation (block Newton, as for Pose2).
-      st = 1;
-      for (int it = 0; it < max_iters; ++it) {
-        double e[4], rt[3];
-        quat_cmul(A.q, P.qa, e);
-        if (K.dir == 0) { rt[0] = P.a[0] - t[0]; rt[1] = P.a[1] - t[1]; rt[2] = P.a[2] - t[2]; }
-        else {
-          double v[3]; quat_rot(A.q, z, v);
-          rt[0] = t[0] + v[0] - P.a[0]; rt[1] = t[1] + v[1] - P.a[1]; rt[2] = t[2] + v[2] - P.a[2];
-        }
-        // |Log e| = 2·atan2(|e_v|, |e_w|): below 2e-10 rad it is 2·e_v to 1e-30; above, the residual exceeds any tolerance
-        const double n2 = e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
-        const double m = fmax(fmax(fabs(rt[0]), fabs(rt[1])), fmax(fabs(rt[2]), 2.0 * fmax(fabs(e[1]), fmax(fabs(e[2]), fabs(e[3])))));
-        if (n2 <= 1e-20 && m <= tol) { st = 0; break; }
-        double qn[4];
-        quat_mul(A.q, e, qn);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) A.q[k] = qn[k];
-        if (K.dir == 0) { t[0] += rt[0]; t[1] += rt[1]; t[2] += rt[2]; }
-        else {
-          double v[3]; quat_rot(A.q, z, v);
-          t[0] = P.a[0] - v[0]; t[1] = P.a[1] - v[1]; t[2] = P.a[2] - v[2];
-        }
-      }
-    } else {
+    if constexpr (SOLVER == kSolverNewton) {
+      bool ok = false;
+      if (max_iters > 0) ok = newton_step(P, t, A, tol);   // lands on the root
+      if (max_iters > 1) ok = newton_step(P, t, A, tol);   // evaluates the residual there (wave-uniform branches)
+      st = ok ? 0 : 1;
+      for (int it = 2; it < max_iters && st; ++it) st = newton_step(P, t, A, tol) ? 0 : 1;
+    } else if constexpr (SOLVER == kSolverNelderMead) {
       P3P3Cost cost;
 #pragma unroll
       for (int k = 0; k < 3; ++k) cost.zt[k] = z[k];
@@ -562,7 +567,7 @@ struct P3P3 {
 // the convolution kernel
 // ------------------------------------------------------------------------------------------
 #ifndef ROME_P3_MINBLK
-#define ROME_P3_MINBLK 3   // Pose3Pose3 closed form / Newton at 3 waves/SIMD: Newton 0.258 -> 0.244 ms on the helix (168 VGPRs, 116 B scratch)
+#define ROME_P3_MINBLK 1   // (round 1 pinned 3 waves/SIMD here; with the root prepared once the kernel needs far fewer registers)
 #endif
 #ifndef ROME_MIN_WAVES
 #define ROME_MIN_WAVES 1
