@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--particles", type=int, default=100)
     ap.add_argument("--g2o", default=None, help="g2o file (default: tests/golden/manhattan.g2o, the M3500 dataset the reference "
                                                  "ships as examples/manhattan.g2o; 'synthetic' forces the generator)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = one Manhattan-sized segment per GPU + separator all-gather (default); strong = ONE Manhattan graph, "
+                         "convolutions sharded by target ownership + all-gather of the owned beliefs (rome_jl_amd.distributed.TargetShardedSweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra per-solver throughput runs")
     ap.add_argument("--cpu-seconds", type=float, default=40.0)
@@ -113,24 +116,42 @@ def main():
         fg = R.synth_manhattan(P=args.poses, loops=args.loops, seed=0x524F4D45 + rank, N=N)
         workload = "synth_manhattan(P=%d, loops=%d) [g2o-shaped stand-in for examples/manhattan.g2o]" % (args.poses, args.loops)
     last = "x%d" % (sum(1 for t in fg.variables.values() if t is R.Pose2) - 1)
-    if multi:
+    strong = multi and args.scaling == "strong"
+    if multi and not strong:
         # cut edges to the neighbouring segments: ghost variables hold the neighbours' separator beliefs
         cov = np.diag([1 / 44.6, 1 / 399.0, 1 / 9591.0])
         fg.addVariable("ghost_prev", R.Pose2); fg.addVariable("ghost_next", R.Pose2)
         fg.addFactor(["ghost_prev", "x0"], R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.0], cov)))
         fg.addFactor([last, "ghost_next"], R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.0], cov)))
-    R.dead_reckon_init(fg, seed=11 + rank)
+    R.dead_reckon_init(fg, seed=11 + (0 if strong else rank))   # strong scaling: every rank holds the SAME graph and beliefs
     ctx = R.Context(local)
     dg = R.DeviceGraph(fg, device=dev, ctx=ctx)
     dg.upload_beliefs(fg)
     tb = dg.tab["p2p2"]
     n_conv_step = tb["C"]  # convolutions per step on this rank: 2 x F relative + the PriorPose2 row(s), ONE launch
-    opts = R.make_opts(N=N, solver=solver, seed=0x524F4D45, stream_offset=rank * (1 << 32))
+    opts = R.make_opts(N=N, solver=solver, seed=0x524F4D45, stream_offset=0 if strong else rank * (1 << 32))
     prop = torch.empty((tb["C"], 3, N), dtype=torch.float64, device=dev)
     sweep = dg.plan_sweep_pose2pose2(opts, prop)   # pre-built launch descriptor: one hipLaunchKernel per call
 
     pk = dg.packed
-    if multi:
+    pipe = None
+    comms = None
+    depth = 0
+    if strong:
+        from rome_jl_amd.distributed import TargetShardedSweep
+        comm = None
+        if os.environ.get("ROME_BENCH_TORCH_COLLECTIVE") != "1":
+            try:
+                from rome_jl_amd.rccl import create_comms
+                cc = create_comms(torch, dist, world, rank, dev, 1)
+                comm = cc[0] if cc else None
+            except Exception as e:   # noqa: BLE001
+                print("direct RCCL binding unavailable (%r): using torch.distributed collectives" % (e,), file=sys.stderr)
+        pipe = TargetShardedSweep(dg, opts, dist, world, rank, always_collective=(world == 1), rccl_comm=comm)
+        comms = [comm] if comm else None
+        n_conv_step = tb["C"]          # the whole graph per step, over all ranks
+        sweep = pipe.step
+    elif multi:
         from rome_jl_amd.distributed import PipelinedSegmentSweep
         # proposal rows that carry the updated separator estimates (odometry convolutions targeting them)
         vf, vt = pk.p2p2["var_from"], pk.p2p2["var_to"]
@@ -181,7 +202,9 @@ def main():
             ev[j].record(); j += 1
         sweep()
     ev[len(marks)].record()
-    if multi:
+    if strong:
+        pipe.wait()
+    elif multi:
         pipe.drain()
     barrier()
     t1 = time.perf_counter()
@@ -196,20 +219,26 @@ def main():
 
     data_kind = "synthetic" if (not args.g2o or args.g2o == "synthetic") else \
         "Manhattan M3500 dataset (measurements); beliefs synthetic: dead-reckoned means + N(0, sigma) particles"
-    total_conv = n_conv_step * world * args.steps
+    total_conv = n_conv_step * (1 if strong else world) * args.steps
     value = total_conv / elapsed
     alg_bytes = tb["C_rel"] * N * BYTES_PER_PARTICLE_P2P2 + tb["P"] * N * 24
+    if strong:
+        alg_bytes = alg_bytes * pipe.n_rows // max(1, tb["C"])   # this rank's launch covers its own row range
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     out = {
         "metric": "factor convolutions/sec (N=100) on Manhattan-3500; solveTree! wall-clock",
         "value": value, "unit": "convolutions/s", "n_gpus": (dist.get_world_size() if multi else 1), "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f64", "data": data_kind,
         "config": {"workload": workload, "poses_per_gpu": len(pk.labels[R.Pose2]), "pose2pose2_factors_per_gpu": tb["F"],
-                   "convolutions_per_step_per_gpu": n_conv_step, "particles": N, "solver": args.solver,
+                   "convolutions_per_step_per_gpu": (pipe.n_rows if strong else n_conv_step), "particles": N, "solver": args.solver,
                    "inflate_cycles": int(opts.inflate_cycles), "inflation": float(opts.inflation), "noise": "in-kernel philox",
-                   "parallelism": ("1 graph segment per GPU, separator all_gather (%s, pipeline depth %d)" % ("RCCL direct" if comms else "torch.distributed", depth)) if multi else "single GPU"},
+                   "parallelism": ("ONE graph: rows sharded by target ownership (%d of %d on rank 0), all_gather of the owned belief blocks (%s)"
+                                   % (pipe.n_rows, tb["C"], "RCCL direct, in place" if comms else "torch.distributed")) if strong else
+                                  (("1 graph segment per GPU, separator all_gather (%s, pipeline depth %d)" % ("RCCL direct" if comms else "torch.distributed", depth))
+                                   if multi else "single GPU"),
+                   "ranks_seen_by_rccl": (dist.get_world_size() if multi else 1)},
         "roofline": {"bound": "hbm", "kernel": "rome::k_conv<P2P2,%s,PPL=2>" % args.solver,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms, "traffic": None},

@@ -125,6 +125,31 @@ class DeviceGraph:
         self.frozen = labels
         self._build_csr()
 
+    # ---- one uniform view of the convolution tables (what the multi-GPU drivers plan launches from) ----
+    FAMILIES = {"p2p2": ("rome_conv_pose2pose2_dev", Pose2, Pose2, 0), "p3p3": ("rome_conv_pose3pose3_dev", Pose3, Pose3, 0),
+                "br1": ("rome_conv_pose2point2br_dev", Point2, Pose2, 1), "br0": ("rome_conv_pose2point2br_dev", Pose2, Point2, 0)}
+
+    def families(self):
+        """Convolution families present in this graph, in launch order."""
+        out = [f for f in ("p2p2", "p3p3") if f in self.tab and self.tab[f]["C"]]
+        if "br" in self.tab:
+            out += ["br1", "br0"]
+        return out
+
+    def family_table(self, fam):
+        """-> dict(n, fn, vt_fixed, vt_target, dir_all, rows4 [n,4] int32 (factor, dir, fixed, target), mu, L, alt, w)."""
+        name, vf, vt, d = self.FAMILIES[fam]
+        fn = getattr(self._lib, name)
+        if fam in ("p2p2", "p3p3"):
+            tb = self.tab[fam]
+            return dict(n=tb["C"], fn=fn, vt_fixed=vf, vt_target=vt, dir_all=0, rows4=tb["rows4"], mu=tb["mu"], L=tb["L"], alt=None, w=None)
+        tb = self.tab["br"]
+        if fam == "br1":
+            return dict(n=tb["F"], fn=fn, vt_fixed=vf, vt_target=vt, dir_all=1, rows4=tb["rows4_1"], mu=tb["mu"], L=tb["sigma"],
+                        alt=tb["alt"] if tb["mh"] else None, w=tb["w"] if tb["mh"] else None)
+        return dict(n=tb["F0"], fn=fn, vt_fixed=vf, vt_target=vt, dir_all=0, rows4=tb["rows4_0"], mu=tb["mu"], L=tb["sigma"],
+                    alt=tb["alt0"] if tb["mh"] else None, w=tb["w0"] if tb["mh"] else None)
+
     # ---- belief store ----
     def upload_beliefs(self, fg):
         for vt in (Pose2, Point2, Pose3):

@@ -93,52 +93,91 @@ def chain_segment_exchange(torch, dist, world, rank, N, device, publish_rows, gh
                              always_collective=always_collective)
 
 
-class PipelinedSegmentSweep:
-    """Weak-scaling sweep driver with the separator exchange fully off the critical path.
+class SeparatorPipeline:
+    """Weak-scaling sweep driver for a rank-local graph segment of ANY mix of factor families (Pose2Pose2, Pose3Pose3,
+    bearing-range in both directions), with the separator exchange fully off the critical path.
 
-    * the sweep kernel itself mirrors this rank's separator proposals into the RCCL send buffer
-      (`rome_conv_dev.mirror_*`: no gather kernel);
-    * `all_gather_into_tensor` writes straight into ghost blocks that live in the TAIL of the belief store
-      (no scatter kernel): the cut factors' `fixed_var`/`target_var` entries simply point there;
-    * send and ghost buffers are `depth`-fold buffered (default 2): sweep k reads the separators gathered after sweep k-depth
-      while the collectives k-depth+1 .. k-1 are still in flight, so nothing races and the result is deterministic for a fixed
-      schedule.  A collective's latency (event joins + RCCL launch, tens of µs) is hidden as long as it is shorter than depth-1 sweeps.
-    Host work per step: wait (no-op in steady state) + one kernel launch + one async collective.
+    Every rank holds its own segment as a DeviceGraph in which the remote separator variables appear as *ghost* variables.
+    `publish`: [(family, conv_row)] -- proposal rows of this rank whose block is the message for the neighbours (the sweep
+    kernel itself mirrors them into the RCCL send buffer, `rome_conv_dev.mirror_*`: no gather kernel; at most 4 per family);
+    the k-th published block of a variable type is that type's *slot* k.  Every rank must publish the same number of blocks
+    per variable type (one fixed-size all-gather per step carries all types).
+    `ghosts`: [(vartype, local_ghost_index, source_rank, source_slot)].
+
+    Memory: one arena of doubles owned by the pipeline (dg.bel is left untouched): the belief stores of the variable types,
+    then `depth` receive buffers.  All region offsets are multiples of 6N doubles (= lcm of the block sizes 2N, 3N, 6N), so a
+    block of the receive buffer IS block number g of the type's store for an integer g: the all-gather lands straight in ghost
+    blocks (no scatter kernel) and the cut factors' table entries simply point there.
+    Send and receive buffers are `depth`-fold buffered (default 2): sweep k reads the separators gathered after sweep k-depth
+    while the collectives k-depth+1 .. k-1 are still in flight, so nothing races and the result is deterministic for a fixed
+    schedule.  Host work per step: one launch per family + one async collective.
     """
 
-    def __init__(self, dg, opts, dist, world, rank, sep_rows, ghost_prev, ghost_next, always_collective=False, depth=2, rccl_comms=None):
-        from .factors import Pose2
+    def __init__(self, dg, opts, dist, world, rank, publish, ghosts, always_collective=False, depth=2, rccl_comms=None):
         torch = dg.torch
         self.dg, self.dist, self.world, self.rank = dg, dist, world, rank
         self.collective = world > 1 or always_collective
-        tb = dg.tab["p2p2"]
-        N, n_sep = dg.N, len(sep_rows)
-        old = dg.bel[Pose2]
-        V = old.shape[0]
-        per = world * n_sep
         if depth < 2:
-            raise ValueError("PipelinedSegmentSweep needs depth >= 2")
+            raise ValueError("SeparatorPipeline needs depth >= 2")
         self.depth = D = int(depth)
-        store = torch.zeros((V + D * per, 3, N), dtype=old.dtype, device=old.device)
-        store[:V].copy_(old)
-        dg.bel[Pose2] = store
-        self.store, self.V = store, V
-        self.recv = [store[V + b * per: V + (b + 1) * per] for b in range(D)]
-        self.send = [torch.zeros((n_sep, 3, N), dtype=old.dtype, device=old.device) for _ in range(D)]
-        # one proposal table per step slot: consecutive sweeps run on different streams and may overlap
-        self.props = [torch.empty((tb["C"], 3, N), dtype=old.dtype, device=old.device) for _ in range(D)]
+        N = dg.N
+        fams = dg.families()
+        ftab = {f: dg.family_table(f) for f in fams}
+        vts = []
+        for f in fams:
+            for vt in (ftab[f]["vt_fixed"], ftab[f]["vt_target"]):
+                if vt not in vts:
+                    vts.append(vt)
+        dim = {vt: int(vt.dim) for vt in vts}
+        U = 6 * N
+        pad = lambda n: -(-n // U) * U
+        any_bel = dg.bel[vts[0]]
+        dev, dt = any_bel.device, any_bel.dtype
+        # published slots per variable type; per family a contiguous slot range (one mirror_out pointer per launch)
+        pub_by_f = {f: [int(r) for ff, r in publish if ff == f] for f in fams}
+        for ff, _ in publish:
+            if ff not in fams:
+                raise ValueError("publish: family %r is not in this graph" % (ff,))
+        if any(len(v) > 4 for v in pub_by_f.values()):
+            raise ValueError("at most 4 published rows per family (rome_conv_dev.mirror_row)")
+        slot0, npub = {}, {vt: 0 for vt in vts}
+        for f in fams:
+            vt = ftab[f]["vt_target"]
+            slot0[f] = npub[vt]
+            npub[vt] += len(pub_by_f[f])
+        sec_off, off = {}, 0
+        for vt in vts:
+            sec_off[vt] = off
+            off += pad(npub[vt] * dim[vt] * N)
+        self.payload = payload = max(off, U)
+        store_off, off = {}, 0
+        for vt in vts:
+            store_off[vt] = off
+            off += pad(dg.bel[vt].shape[0] * dim[vt] * N)
+        recv_off = [off + b * world * payload for b in range(D)]
+        self.arena = torch.zeros(off + D * world * payload, dtype=dt, device=dev)
+        self.V = {vt: dg.bel[vt].shape[0] for vt in vts}
+        self.store = {}
+        for vt in vts:
+            nblk = (self.arena.numel() - store_off[vt]) // (dim[vt] * N)
+            self.store[vt] = self.arena[store_off[vt]: store_off[vt] + nblk * dim[vt] * N].view(nblk, dim[vt], N)
+            self.store[vt][:self.V[vt]].copy_(dg.bel[vt])
+        self.recv = [self.arena[recv_off[b]: recv_off[b] + world * payload] for b in range(D)]
+        self.send = [torch.zeros(payload, dtype=dt, device=dev) for _ in range(D)]
+        self.out = [{f: torch.empty((ftab[f]["n"], dim[ftab[f]["vt_target"]], N), dtype=dt, device=dev) for f in fams} for _ in range(D)]
+        self.families = fams
+        self.props = [o.get("p2p2") for o in self.out]   # (the Pose2Pose2 tables, what the chain-of-segments bench reads)
         self.prop = self.props[0]
         self.works = [None] * D
-        self.plans = []
-        # direct RCCL form (rccl.create_comms, one communicator per slot): slot b owns stream b and a rome_ctx bound to it; sweep and
-        # ncclAllGather are enqueued back to back on that stream, so the collective needs no event join and the host work per step is
-        # two C calls.  Otherwise torch.distributed's collective (≈ 30 µs of host time per call) with stream-level joins.
-        self.comms = rccl_comms if (rccl_comms and self.collective and old.is_cuda) else None
+        # direct RCCL form (rccl.create_comms, one communicator per slot): slot b owns stream b and a rome_ctx bound to it; sweeps
+        # and ncclAllGather are enqueued back to back on that stream, so the collective needs no event join and the host work per
+        # step is a few C calls.  Otherwise torch.distributed's collective (≈ 30 µs of host time per call) with stream-level joins.
+        self.comms = rccl_comms if (rccl_comms and self.collective and any_bel.is_cuda) else None
         self.streams = None
         slot_ctx = [None] * D
-        if self.collective and hasattr(torch, "cuda") and old.is_cuda:
-            cur = torch.cuda.current_stream(old.device)
-            self.streams = [torch.cuda.Stream(old.device) for _ in range(D)]
+        if self.collective and hasattr(torch, "cuda") and any_bel.is_cuda:
+            cur = torch.cuda.current_stream(dev)
+            self.streams = [torch.cuda.Stream(dev) for _ in range(D)]
             for st in self.streams:
                 st.wait_stream(cur)
             if self.comms is not None:
@@ -146,21 +185,49 @@ class PipelinedSegmentSweep:
                     raise ValueError("need one RCCL communicator per pipeline slot")
                 from . import _lib as _l
                 for b in range(D):
-                    slot_ctx[b] = _l.Context(old.device.index or 0)
+                    slot_ctx[b] = _l.Context(dev.index or 0)
                     slot_ctx[b].set_stream(self.streams[b].cuda_stream)
+
+        def ghost_block(vt, b, src_rank, src_slot):
+            o = recv_off[b] + (src_rank % world) * payload + sec_off[vt] + src_slot * dim[vt] * N - store_off[vt]
+            assert o % (dim[vt] * N) == 0
+            return o // (dim[vt] * N)
+
+        self.plans = []
         for b in range(D):
-            gp = V + b * per + ((rank - 1) % world) * n_sep + 1   # previous segment's LAST pose (slot 1)
-            gn = V + b * per + ((rank + 1) % world) * n_sep + 0   # next segment's FIRST pose (slot 0)
-            store[gp].copy_(old[ghost_prev]); store[gn].copy_(old[ghost_next])
-            fixed = tb["fixed"].clone(); target = tb["target"].clone()
-            for arr in (fixed, target):
-                arr[arr == ghost_prev] = gp
-                arr[arr == ghost_next] = gn
-            self.plans.append(dg._plan(dg._lib.rome_conv_pose2pose2_dev, opts, n_conv=tb["C"], dir_all=0,
-                                       factor=tb["factor"], dir=tb["dir"], fixed_var=fixed, target_var=target,
-                                       mu=tb["mu"], L=tb["L"], bel_fixed=store, bel_target=store, out=self.props[b],
-                                       n_mirror=n_sep, mirror_row=tuple(int(r) for r in sep_rows), mirror_out=self.send[b],
-                                       **({"_ctx": slot_ctx[b]} if slot_ctx[b] is not None else {})))
+            remap = {vt: {} for vt in vts}
+            for vt, gi, src, slot in ghosts:
+                if slot >= npub[vt]:
+                    raise ValueError("ghost refers to slot %d of %s but only %d are published" % (slot, vt.__name__, npub[vt]))
+                g = ghost_block(vt, b, src, slot)
+                remap[vt][int(gi)] = g
+                self.store[vt][g].copy_(dg.bel[vt][int(gi)])   # until the first message arrives: the local initial belief
+            plans_b = []
+            for f in fams:
+                tb = ftab[f]
+                rows = tb["rows4"].clone()
+                for col, vt in ((2, tb["vt_fixed"]), (3, tb["vt_target"])):
+                    for gi, g in remap[vt].items():
+                        rows[:, col][tb["rows4"][:, col] == gi] = g
+                alt = tb["alt"]
+                if alt is not None:
+                    vl = tb["vt_fixed"] if f == "br1" else tb["vt_target"]   # the landmark slot
+                    alt = alt.clone()
+                    for gi, g in remap[vl].items():
+                        alt[tb["alt"] == gi] = g
+                vt_t = tb["vt_target"]
+                kw = dict(n_conv=tb["n"], dir_all=tb["dir_all"], rows4=rows, mu=tb["mu"], L=tb["L"],
+                          bel_fixed=self.store[tb["vt_fixed"]], bel_target=self.store[vt_t], out=self.out[b][f])
+                if alt is not None:
+                    kw.update(alt_var=alt, hypo_w=tb["w"])
+                if pub_by_f[f]:
+                    lo = sec_off[vt_t] + slot0[f] * dim[vt_t] * N
+                    kw.update(n_mirror=len(pub_by_f[f]), mirror_row=tuple(pub_by_f[f]),
+                              mirror_out=self.send[b][lo: lo + len(pub_by_f[f]) * dim[vt_t] * N])
+                if slot_ctx[b] is not None:
+                    kw["_ctx"] = slot_ctx[b]
+                plans_b.append(dg._plan(tb["fn"], opts, **kw))
+            self.plans.append(plans_b)
         self._ag_args = [(self.send[b].data_ptr(), self.recv[b].data_ptr(), self.send[b].numel(),
                           self.streams[b].cuda_stream if self.streams is not None else 0) for b in range(D)]
         self.k = 0
@@ -172,16 +239,18 @@ class PipelinedSegmentSweep:
         w = self.works[b]
         if w is not None:
             w.wait()   # stream-level join (the host runs several steps ahead of the GPU: a host-side query cannot replace it)
-        self.plans[b]()
+        for pl in self.plans[b]:
+            pl()
         if self.collective:
-            self.works[b] = self.dist.all_gather_into_tensor(self.recv[b].view(-1), self.send[b].view(-1), async_op=True)
+            self.works[b] = self.dist.all_gather_into_tensor(self.recv[b], self.send[b], async_op=True)
         else:
-            self.recv[b].copy_(self.send[b])
+            self.recv[b][:self.payload].copy_(self.send[b])
 
     def step(self):
         b = self.k % self.depth
         if self.comms is not None:
-            self.plans[b]()                                  # sweep k on stream b (its rome_ctx is bound to it)
+            for pl in self.plans[b]:
+                pl()                                         # sweeps of step k on stream b (their rome_ctx is bound to it)
             self.comms[b].all_gather_f64(*self._ag_args[b])  # ... followed on the same stream by the separator exchange
         elif self.streams is not None:
             with self.dg.torch.cuda.stream(self.streams[b]):
@@ -202,7 +271,7 @@ class PipelinedSegmentSweep:
                     self.works[b].wait()
                 self.works[b] = None
         if self.streams is not None:
-            cur = self.dg.torch.cuda.current_stream(self.store.device)
+            cur = self.dg.torch.cuda.current_stream(self.arena.device)
             for st in self.streams:
                 cur.wait_stream(st)
 
@@ -213,6 +282,89 @@ class PipelinedSegmentSweep:
             for c in self.comms:
                 c.close()
             self.comms = None
+
+
+class PipelinedSegmentSweep(SeparatorPipeline):
+    """The chain-of-segments layout of bench.py's weak scaling: a ring of Manhattan-shaped segments, every rank publishes the
+    proposals of its first and last pose (`sep_rows`: Pose2Pose2 table rows, slots 0 / 1); ghost_prev <- previous rank's slot 1,
+    ghost_next <- next rank's slot 0."""
+
+    def __init__(self, dg, opts, dist, world, rank, sep_rows, ghost_prev, ghost_next, always_collective=False, depth=2, rccl_comms=None):
+        from .factors import Pose2
+        super().__init__(dg, opts, dist, world, rank, [("p2p2", int(r)) for r in sep_rows],
+                         [(Pose2, ghost_prev, rank - 1, 1), (Pose2, ghost_next, rank + 1, 0)],
+                         always_collective=always_collective, depth=depth, rccl_comms=rccl_comms)
+
+
+class TargetShardedSweep:
+    """STRONG scaling of one graph: every rank keeps the whole belief store and the whole convolution table of a
+    family, sorted by target variable; rank r owns variables [r·q, (r+1)·q) (q = ceil(V / world)) and sweeps exactly the rows that
+    target them -- a contiguous row range of the sorted table, whatever the world size, so the Philox stream of a row (its
+    position in the sorted table) and hence every proposal is partition-independent.  After the sweep (and, in a solve loop, the
+    product of the owned variables, which finds its proposals contiguous) one all-gather of the owned belief blocks
+    (V/world x dim x N doubles per rank; Manhattan: 8.4 MB in total) restores the replicated store."""
+
+    def __init__(self, dg, opts, dist, world, rank, family="p2p2", always_collective=False, rccl_comm=None):
+        torch = dg.torch
+        self.dg, self.dist, self.world, self.rank = dg, dist, world, rank
+        self.collective = world > 1 or always_collective
+        tb = dg.family_table(family)
+        self.family, vt = family, tb["vt_target"]
+        if tb["vt_fixed"] is not vt:
+            raise ValueError("TargetShardedSweep shards a single-variable-type family (p2p2 / p3p3)")
+        N, d = dg.N, int(vt.dim)
+        V = dg.bel[vt].shape[0]
+        self.q = q = -(-V // world)
+        rows_h = tb["rows4"].cpu().numpy()
+        order = np.argsort(rows_h[:, 3], kind="stable")
+        sorted_rows = rows_h[order]
+        ptr = np.zeros(world * q + 1, dtype=np.int64)
+        np.add.at(ptr, sorted_rows[:, 3].astype(np.int64) + 1, 1)
+        self.ptr = ptr = np.cumsum(ptr)
+        self.order = order                                    # sorted row j = original row order[j]
+        self.row_lo, self.row_hi = int(ptr[rank * q]), int(ptr[min((rank + 1) * q, world * q)])
+        any_bel = dg.bel[vt]
+        self.store = torch.zeros((world * q, d, N), dtype=any_bel.dtype, device=any_bel.device)
+        self.store[:V].copy_(any_bel)
+        self.rows4 = torch.as_tensor(np.ascontiguousarray(sorted_rows), dtype=torch.int32, device=any_bel.device)
+        self.prop = torch.zeros((tb["n"], d, N), dtype=any_bel.dtype, device=any_bel.device)   # sorted-table order
+        o = type(opts).from_buffer_copy(opts) if hasattr(type(opts), "from_buffer_copy") else opts
+        if hasattr(o, "stream_offset"):
+            o.stream_offset = opts.stream_offset + self.row_lo
+        n = self.row_hi - self.row_lo
+        self.n_rows = n
+        self.plan = dg._plan(tb["fn"], o, n_conv=n, dir_all=tb["dir_all"], rows4=self.rows4[self.row_lo:self.row_hi], mu=tb["mu"], L=tb["L"],
+                             bel_fixed=self.store, bel_target=self.store, out=self.prop[self.row_lo:self.row_hi]) if n else (lambda: None)
+        self.mine = self.store[rank * q:(rank + 1) * q]
+        self.comm = rccl_comm if (rccl_comm is not None and self.collective and any_bel.is_cuda) else None
+        self.work = None
+
+    def step(self):
+        """sweep of the owned rows, then the all-gather of the owned belief blocks (asynchronous; `wait()` completes it)."""
+        self.wait()
+        self.plan()
+        self.exchange()
+
+    def exchange(self):
+        if not self.collective:
+            return
+        if self.comm is not None:   # in place: the send block is this rank's slice of the receive buffer
+            st = self.dg.torch.cuda.current_stream(self.store.device).cuda_stream
+            self.comm.all_gather_f64(self.mine.data_ptr(), self.store.data_ptr(), self.mine.numel(), st)
+        else:
+            self.work = self.dist.all_gather_into_tensor(self.store.view(-1), self.mine.reshape(-1).clone(), async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+    def close(self):
+        self.wait()
+        if self.comm is not None:
+            self.dg.torch.cuda.synchronize()
+            self.comm.close()
+            self.comm = None
 
 
 class LinearizeShard:

@@ -6,14 +6,16 @@
 tag=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$tag; T=/tmp/prof_$tag; mkdir -p $O $T
 cd /tmp && export TMPDIR=/tmp
+if [ -z "$SKIP_TRACES" ]; then
 # 1. kernel traces (same command as the bench line: defaults = 4000 settle+warm-up launches, 2000 timed)
 for s in newton closed_form nelder_mead; do
   st=2000; wu=2000; [ $s = nelder_mead ] && st=20 && wu=10
   timeout 400 rocprofv3 --kernel-trace --stats -d $T/trace_$s -o $s -- python $R/bench.py --solver $s --steps $st --warmup $wu --no-cpu-baseline --no-modes > $T/trace_$s.log 2>&1
   db=$(find $T/trace_$s -name "*_results.db" | head -1)
   python3 $R/scripts/rocpd_summary.py $db $O/${tag}_kernel_trace_$s.md > /dev/null
-  tail -1 $T/trace_$s.log > $O/${tag}_bench_under_trace_$s.json
+  grep '^{' $T/trace_$s.log | tail -1 > $O/${tag}_bench_under_trace_$s.json
 done
+fi
 # 2. HBM traffic
 [ -x $R/scripts/ubench/copy8 ] || hipcc --offload-arch=gfx950 -O3 -o $R/scripts/ubench/copy8 $R/scripts/ubench/copy8.hip
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -32,17 +34,17 @@ import sqlite3, glob, json
 T, O, tag = "$T", "$O", "$tag"
 def counters(pattern, like):
     out = {}
-    for d in sorted(glob.glob(pattern)):
+    for d in sorted(glob.glob(pattern, recursive=True)):
         db = sqlite3.connect(d)
         for name, cn, n, avg in db.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"):
             if like in name: out[cn] = (avg, n, name)
         for name, avg in db.execute("select name, avg(duration) from kernels group by name"):
             if like in name: out.setdefault("_dur", []).append(avg)
     return out
-cal = {c: counters("%s/cal_%s/*/*_results.db" % (T, c), "copy")[c][0] for c in ("FETCH_SIZE", "WRITE_SIZE")}
+cal = {c: counters("%s/cal_%s/**/*_results.db" % (T, c), "copy")[c][0] for c in ("FETCH_SIZE", "WRITE_SIZE")}
 fetch_scale = 2.0 if cal["FETCH_SIZE"] < 0.75 * 2097152 else 1.0   # copy8 reads 2 GiB: gfx950 FETCH_SIZE reports half of it
 for s in ("newton", "closed_form"):
-    f = counters("%s/%s_FETCH_SIZE/*/*_results.db" % (T, s), "k_conv"); w = counters("%s/%s_WRITE_SIZE/*/*_results.db" % (T, s), "k_conv")
+    f = counters("%s/%s_FETCH_SIZE/**/*_results.db" % (T, s), "k_conv"); w = counters("%s/%s_WRITE_SIZE/**/*_results.db" % (T, s), "k_conv")
     rd = f["FETCH_SIZE"][0] * 1024 * fetch_scale; wr = w["WRITE_SIZE"][0] * 1024
     json.dump({"source": "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), bench.py --solver %s --steps 20; "
                          "FETCH_SIZE x%.0f per the gfx950 correction, calibrated in the same run on scripts/ubench/copy8 (2 GiB read reported %.4g KB, 2 GiB written reported %.4g KB)"
@@ -50,7 +52,7 @@ for s in ("newton", "closed_form"):
                "solver": s, "n_conv": 10907, "kernel": f["FETCH_SIZE"][2], "fetch_size_kb_raw": f["FETCH_SIZE"][0], "write_size_kb_raw": w["WRITE_SIZE"][0],
                "launches_averaged": f["FETCH_SIZE"][1], "bytes_per_launch": int(rd + wr), "read_bytes_per_launch": int(rd), "write_bytes_per_launch": int(wr),
                "algorithmic_bytes_per_launch": 78525600}, open("%s/hbm_traffic_%s.json" % (O, s), "w"), indent=1)
-    a = counters("%s/sqa_%s/*/*_results.db" % (T, s), "k_conv"); b = counters("%s/sqb_%s/*/*_results.db" % (T, s), "k_conv")
+    a = counters("%s/sqa_%s/**/*_results.db" % (T, s), "k_conv"); b = counters("%s/sqb_%s/**/*_results.db" % (T, s), "k_conv")
     dur = sum(a["_dur"]) / len(a["_dur"])
     waves = a["SQ_WAVES"][0]
     json.dump({"source": "scripts/profile_round.sh: rocprofv3 --pmc SQ_* --kernel-trace, bench.py --solver %s --steps 10 after the settle launches (averages over %d steady-state launches, Manhattan M3500), per launch of %s"

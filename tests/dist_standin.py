@@ -1,0 +1,66 @@
+"""CPU stand-in for DeviceGraph (TEST INFRASTRUCTURE): just enough of its interface for the multi-GPU drivers of
+rome_jl_amd.distributed -- families(), family_table(), bel, _plan() -- on torch CPU tensors, with the ORACLE doing the compute
+of a launch, so that the drivers' buffering / ghost addressing / collectives run for real over gloo."""
+import numpy as np
+import torch
+
+
+class OracleDG:
+    def __init__(self, R, fg, seed=5):
+        import oracle as ro
+        self.torch, self.N, self.R, self.ro, self.seed = torch, fg.N, R, ro, seed
+        pk = R.PackedGraph(fg)
+        self.packed = pk
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.int32)))
+        self.bel = {vt: torch.as_tensor(pk.beliefs(fg, vt)) if len(pk.labels[vt]) else torch.zeros((0, vt.dim, fg.N), dtype=torch.float64)
+                    for vt in (R.Pose2, R.Point2, R.Pose3)}
+        self.tabs = {}
+        if pk.p2p2["F"] or pk.prior2["F"]:
+            factor, dr, fixed, target = R.PackedGraph.conv_table(pk.p2p2)
+            F, P = pk.p2p2["F"], pk.prior2["F"]
+            mu = np.concatenate([pk.p2p2["mu"].reshape(F, 3), pk.prior2["mu"].reshape(P, 3)])
+            cov = np.concatenate([pk.p2p2["cov"].reshape(F, 3, 3), pk.prior2["cov"].reshape(P, 3, 3)])
+            rows = np.stack([np.concatenate([factor, F + np.arange(P)]), np.concatenate([dr, np.full(P, 2)]),
+                             np.concatenate([fixed, pk.prior2["var"]]), np.concatenate([target, pk.prior2["var"]])], axis=1)
+            self.tabs["p2p2"] = dict(n=2 * F + P, fn="p2p2", vt_fixed=R.Pose2, vt_target=R.Pose2, dir_all=0, rows4=i32(rows),
+                                     mu=mu, L=np.array([ro.cholesky_lower(c) for c in cov]), alt=None, w=None)
+        if pk.br["F"]:
+            b = pk.br; r0 = b["rows0"]; Fb = b["F"]
+            self.tabs["br1"] = dict(n=Fb, fn="br1", vt_fixed=R.Point2, vt_target=R.Pose2, dir_all=1, mu=b["mu"], L=b["sigma"], alt=None, w=None,
+                                    rows4=i32(np.stack([np.arange(Fb), np.ones(Fb), b["point"], b["pose"]], axis=1)))
+            self.tabs["br0"] = dict(n=len(r0["factor"]), fn="br0", vt_fixed=R.Pose2, vt_target=R.Point2, dir_all=0, mu=b["mu"], L=b["sigma"],
+                                    alt=None, w=None, rows4=i32(np.stack([r0["factor"], np.zeros(len(r0["factor"])), r0["pose"], r0["point"]], axis=1)))
+
+    def families(self):
+        return [f for f in ("p2p2", "br1", "br0") if f in self.tabs]
+
+    def family_table(self, fam):
+        return self.tabs[fam]
+
+    def _plan(self, fn, opts, **kw):
+        ro, N = self.ro, self.N
+        rows = kw["rows4"].numpy()
+        out, mu, L = kw["out"], kw["mu"], kw["L"]
+        bf, bt = kw["bel_fixed"], kw["bel_target"]
+        mirror_rows, mirror_out = kw.get("mirror_row", ()), kw.get("mirror_out")
+        base = int(opts.stream_offset) if opts is not None else 0
+        seed = self.seed
+
+        def launch():
+            n = len(rows)
+            res = np.zeros(tuple(out.shape))
+            for k in range(n):   # one oracle call per row: Philox stream = base + row position, like the kernel
+                o = ro.make_opts(N=N, solver=ro.SOLVER_NEWTON, seed=seed, stream_offset=base + k)
+                f, d, fv, tv = (int(x) for x in rows[k])
+                if fn == "p2p2":
+                    if d == 2:
+                        res[k] = ro.sample_priorpose2(o, mu[f], L[f])[0]
+                    else:
+                        res[k] = ro.conv_pose2pose2(o, mu, L, bf.numpy(), [fv], [tv], [d], factor=[f])[0]
+                else:
+                    res[k] = ro.conv_pose2point2br(o, 1 if fn == "br1" else 0, mu, L, bf.numpy(), bt.numpy(), [fv], [tv], factor=[f])[0]
+            out.copy_(torch.as_tensor(res))
+            for m, r in enumerate(mirror_rows):
+                blk = out[r].reshape(-1)
+                mirror_out[m * blk.numel():(m + 1) * blk.numel()].copy_(blk)
+        return launch

@@ -107,45 +107,13 @@ def _segment_problem(R, rank, N):
     return fg
 
 
-class _OracleDG:
-    """Just enough of DeviceGraph for PipelinedSegmentSweep, on CPU tensors, compute through the oracle."""
-
-    def __init__(self, R, fg, stream_base):
-        import oracle as ro
-        self.torch, self.N, self.R, self.ro = torch, fg.N, R, ro
-        pk = R.PackedGraph(fg)
-        self.packed = pk
-        factor, dr, fixed, target = R.PackedGraph.conv_table(pk.p2p2)
-        F, P = pk.p2p2["F"], pk.prior2["F"]
-        self.mu = np.concatenate([pk.p2p2["mu"], pk.prior2["mu"]]); cov = np.concatenate([pk.p2p2["cov"], pk.prior2["cov"]])
-        self.L = np.array([ro.cholesky_lower(c) for c in cov])
-        i32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.int32))
-        self.tab = {"p2p2": dict(F=F, P=P, C=2 * F + P, C_rel=2 * F, factor=i32(np.concatenate([factor, F + np.arange(P)])),
-                                 dir=i32(np.concatenate([dr, np.full(P, 2)])), fixed=i32(np.concatenate([fixed, pk.prior2["var"]])),
-                                 target=i32(np.concatenate([target, pk.prior2["var"]])), mu=None, L=None)}
-        self.bel = {R.Pose2: torch.as_tensor(pk.beliefs(fg, R.Pose2))}
-        self._lib = type("L", (), {"rome_conv_pose2pose2_dev": None})()
-        self.stream_base = stream_base
-
-    def _plan(self, fn, opts, **kw):
-        ro, N = self.ro, self.N
-        fixed, target, store, out = kw["fixed_var"].numpy(), kw["target_var"].numpy(), kw["bel_fixed"], kw["out"]
-        factor, dr = kw["factor"].numpy(), kw["dir"].numpy()
-        mirror_rows, mirror_out = kw["mirror_row"], kw["mirror_out"]
-        rel = dr != 2
-
-        def launch():
-            o = ro.make_opts(N=N, solver=ro.SOLVER_NEWTON, seed=5, stream_offset=self.stream_base)
-            res = np.zeros((len(dr), 3, N))
-            res[rel] = ro.conv_pose2pose2(o, self.mu, self.L, store.numpy(), fixed[rel], target[rel], dr[rel], factor=factor[rel])
-            # conv_pose2pose2 numbers its Philox streams by position in the call: re-run the prior rows on their own ids
-            for k in np.nonzero(~rel)[0]:
-                ok = ro.make_opts(N=N, seed=5, stream_offset=self.stream_base + int(k))
-                res[k] = ro.sample_priorpose2(ok, self.mu[factor[k]], self.L[factor[k]])[0]
-            out.copy_(torch.as_tensor(res))
-            for m, r in enumerate(mirror_rows):
-                mirror_out[m].copy_(out[r])
-        return launch
+def _OracleDG(R, fg, stream_base):
+    """CPU stand-in for DeviceGraph (tests/dist_standin.py): the launch plan runs the ORACLE on torch CPU tensors."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_standin import OracleDG
+    dg = OracleDG(R, fg, seed=5)
+    dg.stream_base = stream_base
+    return dg
 
 
 def _pipe_worker(rank, world, port, ret):
@@ -160,7 +128,9 @@ def _pipe_worker(rank, world, port, ret):
         dg = _OracleDG(R, fg, stream_base=rank << 32)
         pk = dg.packed
         sep_rows = [1, 2 * (40 - 2)]       # x0 <- (x0->x1, dir 1) ; x39 <- (x38->x39, dir 0)
-        pipe = PipelinedSegmentSweep(dg, None, dist, world, rank, sep_rows, pk.index["ghost_prev"], pk.index["ghost_next"])
+        import oracle as ro
+        pipe = PipelinedSegmentSweep(dg, ro.make_opts(N=N, stream_offset=rank << 32), dist, world, rank, sep_rows,
+                                     pk.index["ghost_prev"], pk.index["ghost_next"])
         hist = []
         for k in range(5):
             pipe.step()
@@ -196,16 +166,172 @@ def test_pipelined_segment_sweep_two_ranks_matches_single_process_emulation():
                 store[pk.index["ghost_next"]] = torch.as_tensor(props[(r + 1) % world][k - 2][sep_rows[0]])
             else:
                 store[pk.index["ghost_prev"]], store[pk.index["ghost_next"]] = init_ghost[r]
-            tb = d.tab["p2p2"]
-            out = torch.zeros((tb["C"], 3, N), dtype=torch.float64)
-            d._plan(None, None, fixed_var=tb["fixed"], target_var=tb["target"], factor=tb["factor"], dir=tb["dir"],
-                    bel_fixed=store, out=out, mirror_row=(), mirror_out=None)()
+            tb = d.family_table("p2p2")
+            out = torch.zeros((tb["n"], 3, N), dtype=torch.float64)
+            import oracle as ro
+            d._plan("p2p2", ro.make_opts(N=N, stream_offset=r << 32), rows4=tb["rows4"], mu=tb["mu"], L=tb["L"],
+                    bel_fixed=store, bel_target=store, out=out)()
             props[r].append(out.numpy())
     for r in range(world):
         for k in range(5):
             assert np.array_equal(ret[r][k], props[r][k]), (r, k)
     # the cut factors really see the neighbour: sweep 2 differs from what the initial ghosts would give
     assert not np.array_equal(ret[0][2], ret[0][0])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SeparatorPipeline on a bearing-range graph (BASELINE configs[3]/[4] shape: poses + landmarks, both bearing-range directions and
+# the odometry family in one step, ONE all-gather carrying a Pose2 and a Point2 separator), 2 ranks over gloo against a
+# single-process emulation of the same schedule.
+def _br_segment(R, rank, N):
+    rng = np.random.default_rng(40 + rank)
+    fg = R.initfg(N)
+    P = 12
+    fg.addVariable("x0", R.Pose2)
+    fg.addFactor(["x0"], R.PriorPose2(R.MvNormal([10.0 * rank, 0.0, 0.0], np.diag([0.01, 0.01, 0.0025]))))
+    cov = np.diag(np.square([0.15, 0.12, 0.0106]))
+    for k in range(1, P):
+        fg.addVariable("x%d" % k, R.Pose2)
+        fg.addFactor(["x%d" % (k - 1), "x%d" % k], R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.1 * (k % 3 - 1)], cov)))
+    for j in range(3):
+        fg.addVariable("l%d" % j, R.Point2)
+    # ghosts: the neighbour's last pose and a landmark that the neighbour also sights
+    fg.addVariable("ghost_pose", R.Pose2); fg.addVariable("ghost_lm", R.Point2)
+    fg.addFactor(["ghost_pose", "x0"], R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.0], cov)))
+    sight = [("x1", "l0"), ("x2", "l0"), ("x4", "l1"), ("x6", "l1"), ("x9", "l2"), ("x10", "l2"), ("x11", "ghost_lm"), ("x3", "ghost_lm")]
+    for xp, lm in sight:
+        fg.addFactor([xp, lm], R.Pose2Point2BearingRange(R.Normal(float(rng.uniform(-1, 1)), 0.03), R.Normal(float(rng.uniform(3, 8)), 0.5)))
+    R.dead_reckon_init(fg, seed=3 + rank)
+    for j, l in enumerate(["l0", "l1", "l2", "ghost_lm"]):
+        fg.initVariable(l, np.array([[2.0 + 3 * j], [4.0]]) + rng.standard_normal((2, N)))
+    return fg
+
+
+def _br_layout(pk, d):
+    """published rows: Pose2 slot 0 = proposal of x11 from its odometry (p2p2 row), Point2 slot 0 = proposal of l2 from x10 (br0 row)"""
+    f_last = int(np.nonzero((pk.p2p2["var_from"] == pk.index["x10"]) & (pk.p2p2["var_to"] == pk.index["x11"]))[0][0])
+    r0 = d.family_table("br0")["rows4"].numpy()
+    row_l2 = int(np.nonzero((r0[:, 2] == pk.index["x10"]) & (r0[:, 3] == pk.index["l2"]))[0][0])
+    return 2 * f_last, row_l2
+
+
+def _br_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import rome_jl_amd as R
+        import oracle as ro
+        from rome_jl_amd.distributed import SeparatorPipeline
+        N = 16
+        fg = _br_segment(R, rank, N)
+        dg = _OracleDG(R, fg, 0)
+        pk = dg.packed
+        row_pose, row_lm = _br_layout(pk, dg)
+        pipe = SeparatorPipeline(dg, ro.make_opts(N=N, stream_offset=rank << 32), dist, world, rank,
+                                 publish=[("p2p2", row_pose), ("br0", row_lm)],
+                                 ghosts=[(R.Pose2, pk.index["ghost_pose"], rank - 1, 0), (R.Point2, pk.index["ghost_lm"], rank - 1, 0)])
+        hist = []
+        for k in range(4):
+            pipe.step()
+            hist.append({f: pipe.out[k % 2][f].clone().numpy() for f in pipe.families})
+        pipe.drain()
+        ret[rank] = (hist, bool(np.array_equal(dg.bel[R.Pose2].numpy(), pk.beliefs(fg, R.Pose2))))   # dg.bel untouched
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_separator_pipeline_bearing_range_two_ranks_matches_emulation():
+    world = 2
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_br_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import rome_jl_amd as R
+    import oracle as ro
+    N = 16
+    dgs = [_OracleDG(R, _br_segment(R, r, N), 0) for r in range(world)]
+    lay = [_br_layout(d.packed, d) for d in dgs]
+    hist = [[] for _ in range(world)]
+    for k in range(4):
+        for r, d in enumerate(dgs):
+            pk = d.packed
+            bel = {vt: d.bel[vt].clone() for vt in (R.Pose2, R.Point2)}
+            if k >= 2:   # step k reads what the previous rank published in step k-2
+                src = (r - 1) % world
+                bel[R.Pose2][pk.index["ghost_pose"]] = torch.as_tensor(hist[src][k - 2]["p2p2"][lay[src][0]])
+                bel[R.Point2][pk.index["ghost_lm"]] = torch.as_tensor(hist[src][k - 2]["br0"][lay[src][1]])
+            outs = {}
+            for f in d.families():
+                tb = d.family_table(f)
+                out = torch.zeros((tb["n"], tb["vt_target"].dim, N), dtype=torch.float64)
+                d._plan(tb["fn"], ro.make_opts(N=N, stream_offset=r << 32), rows4=tb["rows4"], mu=tb["mu"], L=tb["L"],
+                        bel_fixed=bel[tb["vt_fixed"]], bel_target=bel[tb["vt_target"]], out=out)()
+                outs[f] = out.numpy()
+            hist[r].append(outs)
+    for r in range(world):
+        got, untouched = ret[r]
+        assert untouched
+        for k in range(4):
+            for f in ("p2p2", "br1", "br0"):
+                assert np.array_equal(got[k][f], hist[r][k][f]), (r, k, f)
+    # the ghost landmark really arrives: the pose proposals of the ghost sighting change once the message is in
+    assert not np.array_equal(ret[0][0][2]["br1"], ret[0][0][0]["br1"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# TargetShardedSweep: strong scaling of ONE graph.  2 and 3 ranks sweep disjoint row ranges of the target-sorted table and
+# all-gather the owned belief blocks; the assembled proposal table equals the unsharded sweep of the same sorted table.
+def _strong_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import rome_jl_amd as R
+        import oracle as ro
+        from rome_jl_amd.distributed import TargetShardedSweep
+        N = 16
+        fg = R.synth_manhattan(P=50, loops=20, seed=9, N=N)
+        R.dead_reckon_init(fg, seed=2)
+        dg = _OracleDG(R, fg, 0)
+        sh = TargetShardedSweep(dg, ro.make_opts(N=N, stream_offset=7), dist, world, rank)
+        V = dg.bel[R.Pose2].shape[0]
+        sh.step(); sh.wait()
+        t = sh.prop.clone()
+        dist.all_reduce(t)                               # disjoint row ranges -> the sum assembles the table
+        same_store = bool(np.array_equal(sh.store[:V].numpy(), dg.bel[R.Pose2].numpy()))   # the all-gather of unchanged blocks is a no-op
+        sh.mine.mul_(0.0).add_(float(rank + 1))          # pretend a product updated the owned beliefs ...
+        sh.exchange(); sh.wait()                         # ... and publish them
+        owners_ok = all(bool((sh.store[r * sh.q:min((r + 1) * sh.q, V)] == float(r + 1)).all()) for r in range(world))
+        ret[rank] = (t.numpy(), sh.order.copy(), (sh.row_lo, sh.row_hi), owners_ok and same_store)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_target_sharded_sweep_assembles_the_unsharded_table(world):
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_strong_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import rome_jl_amd as R
+    import oracle as ro
+    N = 16
+    fg = R.synth_manhattan(P=50, loops=20, seed=9, N=N)
+    R.dead_reckon_init(fg, seed=2)
+    dg = _OracleDG(R, fg, 0)
+    tb = dg.family_table("p2p2")
+    rows = tb["rows4"].numpy()
+    order = np.argsort(rows[:, 3], kind="stable")
+    out = torch.zeros((tb["n"], 3, N), dtype=torch.float64)
+    dg._plan("p2p2", ro.make_opts(N=N, stream_offset=7), rows4=torch.as_tensor(rows[order]), mu=tb["mu"], L=tb["L"],
+             bel_fixed=dg.bel[R.Pose2], bel_target=dg.bel[R.Pose2], out=out)()
+    spans = sorted(ret[r][2] for r in range(world))
+    assert spans[0][0] == 0 and spans[-1][1] == tb["n"] and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    for r in range(world):
+        table, order_r, _, owners_ok = ret[r]
+        assert owners_ok and np.array_equal(order_r, order)
+        assert np.array_equal(table, out.numpy())        # sweep inputs are the initial beliefs: same table as the unsharded sweep
 
 
 # ------------------------------------------------------------------ row-sharded linearisation of the parametric solver
