@@ -57,7 +57,13 @@ class FactorGraph:
                 raise TypeError("addFactor: %s expects %s for %s" % (type(factor).__name__, t, l))
         if len(labels_chk) != len(factor.variable_types):
             raise ValueError("addFactor: wrong number of variables")
-        flabel = "".join(labels) + "f%d" % (1 + sum(1 for f in self.factors if f[1] == labels))
+        # DFG numbers the factors of one variable list f1, f2, ...; after deleteFactor a plain count would hand out a label that is
+        # still in use: take the smallest free suffix instead
+        used = {f[0] for f in self.factors}
+        k = 1
+        while "".join(labels) + "f%d" % k in used:
+            k += 1
+        flabel = "".join(labels) + "f%d" % k
         self.factors.append((flabel, labels, factor))
         if extra is not None:
             self.multihypo[flabel] = (w[1], w[2])
@@ -176,10 +182,13 @@ def loadG2o(path, N=100, prior_sigma=(0.1, 0.1, 0.05), max_edges=None):
     fg = initfg(N)
     fg.addVariable("x0", Pose2)
     fg.addFactor(["x0"], PriorPose2(MvNormal(np.zeros(3), np.diag(np.square(prior_sigma)))))
-    for k, ins in enumerate(importG2o(path)):
-        if max_edges is not None and k >= max_edges:
+    n_edges = 0
+    for ins in importG2o(path):
+        is_edge = ins[0].startswith("EDGE")
+        if max_edges is not None and is_edge and n_edges >= max_edges:
             break
         parseG2oInstruction(fg, ins)
+        n_edges += int(is_edge)     # max_edges counts EDGE_* records only (VERTEX_* lines are not edges)
     return fg
 
 

@@ -285,6 +285,8 @@ def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, retur
             if cn <= cost or lam > 1e12:
                 break
             lam *= 10.0
+        if cn > cost:   # damping exhausted without a descent step: keep the last accepted iterate (never commit an uphill one)
+            break
         done = (cost - cn) <= tol * max(1.0, cost) or np.abs(d).max() < 1e-8
         X, r, J, cost = Xn, rn, Jn, cn
         lam = max(lam / 10.0, 1e-12)

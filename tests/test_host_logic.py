@@ -302,3 +302,25 @@ def test_g2o_parser_covariances_match_the_reference_serialisation():
         f = mine[(int(i), int(j))]
         assert np.array_equal(f.Z.mu, mu)
         assert np.allclose(f.Z.cov, cov, rtol=1e-10, atol=1e-16)
+
+
+def test_factor_labels_stay_unique_after_delete():
+    """DFG-style labels <vars>f<k>: deleting a factor must not let a later addFactor reuse a label that is still in the graph."""
+    fg = R.initfg(8)
+    fg.addVariable("x0", R.Pose2); fg.addVariable("x1", R.Pose2)
+    z = R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.0], np.eye(3) * 0.01))
+    a = fg.addFactor(["x0", "x1"], z); b = fg.addFactor(["x0", "x1"], z)
+    assert (a, b) == ("x0x1f1", "x0x1f2")
+    fg.deleteFactor(a)
+    c = fg.addFactor(["x0", "x1"], z)
+    assert c == "x0x1f1" and len({f[0] for f in fg.factors}) == 2     # the free suffix, not a duplicate of f2
+    d = fg.addFactor(["x0", "x1"], z)
+    assert d == "x0x1f3"
+
+
+def test_loadg2o_max_edges_counts_edges_only(tmp_path):
+    p = tmp_path / "g.g2o"
+    p.write_text("VERTEX_SE2 0 0 0 0\nVERTEX_SE2 1 1 0 0\nVERTEX_SE2 2 2 0 0\n"
+                 "EDGE_SE2 0 1 1 0 0 10 0 0 10 0 10\nEDGE_SE2 1 2 1 0 0 10 0 0 10 0 10\nEDGE_SE2 0 2 2 0 0 10 0 0 10 0 10\n")
+    fg = R.loadG2o(str(p), N=4, max_edges=2)
+    assert sum(1 for _, _, f in fg.factors if isinstance(f, R.Pose2Pose2)) == 2
