@@ -111,12 +111,154 @@ __device__ __forceinline__ double lcv_golden(const double (&x)[S], const bool (&
   return f1 < f2 ? x1 : x2;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Fast path, N <= 128 (two particles per lane): the same golden-section search -- bracket arithmetic in double, identical iterates --
+// with the likelihood evaluated in single precision on the hardware exponential:
+//   * row sums: particle i adds exp2(a2 d_ij²) over the N-1 others, j = i+1 .. i+N-1 read from a DOUBLED copy of the particles in
+//     LDS (p32d[j] = p32d[j+N]: no index wrap, lane-consecutive addresses, constant offsets; the j = i term never occurs, so an
+//     isolated particle's tiny sum is not cancelled against a self term).  Per term: f32 subtract, two multiplies, v_exp_f32,
+//     accumulate (8-term single-precision partials folded into double sums); no exchange of symmetric terms, no fences.
+//     The particles are staged as single-precision offsets from particle 0 (a fixed 6e-8·range perturbation of the data, the same
+//     for every h);
+//   * Euclidean stopping rules (>= 1e-2): a golden-section step only COMPARES two likelihoods; when they differ by less than
+//     kTieEps (30x the single-precision noise of a likelihood) both are re-evaluated in double precision (lcv_negll), so every
+//     decision is the double-precision one and the iterates are the oracle's;
+//   * finer stopping rules (the 1e-6 of circular coordinates): the golden section stops at a 1e-2 bracket and the search finishes
+//     on the DERIVATIVE, g(h) = Σ_i T_i/S_i − N h² = 0 with T_i = Σ_j w_ij d_ij² (accumulated in the same pass), by secant steps.
+//     The zero of g is conditioned like 1e-7/curvature in single precision, whereas comparing likelihood VALUES 1e-6 apart needs
+//     double precision: the 33 double-precision evaluations of a heading become ~15 + 3 single-precision ones, and a near-tie
+//     decision of the golden section cannot hurt (the secant may leave the last bracket by its width).
+// Measured (scripts/kde_profile.py, profiles/r02_kde_bandwidth.txt).
+constexpr double kTieEps = 3e-5;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool CIRC>
+__device__ __forceinline__ void lcv_eval32(const f32x2 xi, const bool act0, const bool act1, const float* __restrict__ b0,
+                                           const float* __restrict__ b1, int N, double h, double* negll, double* g) {
+  // b0 / b1: p32d + (own index of slot 0 / 1): the other particles are b[1] .. b[N-1]
+  const float a2 = (float)(-0.72134752044448170368 / (h * h));   // -½ log2(e) / h²
+  double S0 = 0.0, S1 = 0.0;
+  f32x2 T = {0.0f, 0.0f};
+  auto term = [&](float x0, float x1, f32x2& ps) {
+    f32x2 xj = {x0, x1};
+    f32x2 d = xi - xj;
+    if (CIRC) {
+      d.x = fmaf(-6.2831853071795865f, rintf(d.x * 0.15915494309189535f), d.x);
+      d.y = fmaf(-6.2831853071795865f, rintf(d.y * 0.15915494309189535f), d.y);
+    }
+    const f32x2 d2 = d * d;
+    f32x2 w = d2 * a2;
+    w.x = __builtin_amdgcn_exp2f(w.x); w.y = __builtin_amdgcn_exp2f(w.y);
+    ps += w;
+    T = __builtin_elementwise_fma(w, d2, T);
+  };
+  const int M = N - 1, M8 = M & ~7;
+  int k = 1;
+  for (; k <= M8; k += 8) {
+    f32x2 ps = {0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) term(b0[k + u], b1[k + u], ps);
+    S0 += (double)ps.x; S1 += (double)ps.y;
+  }
+  {
+    f32x2 ps = {0.0f, 0.0f};
+    for (; k <= M; ++k) term(b0[k], b1[k], ps);
+    S0 += (double)ps.x; S1 += (double)ps.y;
+  }
+  double ll = 0.0, gg = 0.0;
+  if (act0) { const double s = fmax(S0, 1e-300); ll += fast_log(s); gg += (double)T.x / s; }
+  if (act1) { const double s = fmax(S1, 1e-300); ll += fast_log(s); gg += (double)T.y / s; }
+  double v[2] = {ll, gg};
+  wave_sum_n<2>(v);
+  *negll = -(v[0] - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528));
+  *g = v[1] - (double)N * h * h;
+}
+
+template <bool CIRC>
+__device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bool (&act)[2], const double* __restrict__ pts,
+                                                  float* __restrict__ p32d, double* __restrict__ wbuf, int N, int lane, double tol, int* n_evals) {
+  // bracket: smallest pair distance and extent about particle 0 (oracle: ro_kde_bandwidth_lcv) -- in double, as the slow path
+  const double x0v = pts[0];
+  double mn = __builtin_inf(), ylo = 0.0, yhi = 0.0;
+  f32x2 xi;
+  {
+    double y0 = x[0] - x0v, y1 = x[1] - x0v;
+    if (CIRC) { y0 = lcv_wrap(y0); y1 = lcv_wrap(y1); }
+    ylo = fmin(fmin(ylo, y0), y1); yhi = fmax(fmax(yhi, y0), y1);   // idle slots hold particle 0: y = 0
+    xi.x = (float)y0; xi.y = (float)y1;
+    if (act[0]) { p32d[lane] = xi.x; p32d[lane + N] = xi.x; }
+    if (act[1]) { p32d[lane + 64] = xi.y; p32d[lane + 64 + N] = xi.y; }
+  }
+  for (int j = 0; j < N; ++j) {
+    const double xj = pts[j];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      double d = x[s] - xj;
+      if (CIRC) d = lcv_wrap(d);
+      if (act[s] && lane + 64 * s != j) mn = fmin(mn, fabs(d));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  const float* b0 = p32d + (act[0] ? lane : 0);
+  const float* b1 = p32d + (act[1] ? lane + 64 : 0);
+  mn = wave_min(mn); ylo = wave_min(ylo); yhi = -wave_min(-yhi);
+  const double minm = fmax(mn, 1e-6), maxm = fmax(yhi - ylo, minm);
+  const double ax = 2.0 * minm / (double)(N - 1), bx = 0.5 * (minm + maxm), cx = 2.0 * maxm;
+  constexpr double Cg = 0.38196601125010515180, Rg = 0.61803398874989484820;
+  double x0 = ax, x3 = cx, x1, x2;
+  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + Cg * (cx - bx); }
+  else { x2 = bx; x1 = bx - Cg * (bx - ax); }
+  double f1, f2, g1, g2;
+  lcv_eval32<CIRC>(xi, act[0], act[1], b0, b1, N, x1, &f1, &g1);
+  lcv_eval32<CIRC>(xi, act[0], act[1], b0, b1, N, x2, &f2, &g2);
+  int ne = 2;
+  const bool finish = tol < 1e-2;          // finer than the golden section is run in single precision: finish on the derivative
+  const double tol_gs = finish ? 1e-2 : tol;
+  while (fabs(x3 - x0) > tol_gs * (fabs(x1) + fabs(x2)) && ne < 200) {
+    bool lower2 = f2 < f1;
+    if (!finish && fabs(f2 - f1) < kTieEps) {   // wave-uniform: decide in double precision
+      const double e1 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x1), e2 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x2);
+      lower2 = e2 < e1;
+    }
+    if (lower2) { x0 = x1; x1 = x2; x2 = Rg * x1 + Cg * x3; f1 = f2; g1 = g2; lcv_eval32<CIRC>(xi, act[0], act[1], b0, b1, N, x2, &f2, &g2); }
+    else        { x3 = x2; x2 = x1; x1 = Rg * x2 + Cg * x0; f2 = f1; g2 = g1; lcv_eval32<CIRC>(xi, act[0], act[1], b0, b1, N, x1, &f1, &g1); }
+    ++ne;
+  }
+  double best = f1 < f2 ? x1 : x2;
+  if (!finish && fabs(f2 - f1) < kTieEps) {
+    const double e1 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x1), e2 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x2);
+    best = e1 < e2 ? x1 : x2;
+  }
+  if (finish) {
+    // secant steps on g from the two interior points; the iterate may leave the last bracket by its width (a near-tie decision
+    // of the single-precision golden section), never further (flat or noisy g: keep the golden-section answer)
+    const double wdt = x3 - x0, lo = fmax(x0 - wdt, 0.5 * x0), hi = x3 + wdt;
+    double ha = x1, ga = g1, hb = x2, gb = g2;
+    for (int it = 0; it < 5; ++it) {
+      const double den = gb - ga;
+      if (!(fabs(den) > 0.0)) break;
+      const double hc = hb - gb * (hb - ha) / den;
+      if (!(hc > lo && hc < hi)) break;
+      double fc, gc;
+      lcv_eval32<CIRC>(xi, act[0], act[1], b0, b1, N, hc, &fc, &gc);
+      ++ne;
+      const bool done = fabs(hc - hb) <= tol * fabs(hc);
+      ha = hb; ga = gb; hb = hc; gb = gc;
+      best = hc;
+      if (done) break;
+    }
+  }
+  *n_evals = ne;
+  return best;
+}
+
 template <int S>
 __global__ void __launch_bounds__(64 * kKdeWaves) k_kde_bandwidth(int T, int dim, int N, const double* __restrict__ bel,
                                                                   uint32_t circ_mask, double tol_e, double tol_c,
                                                                   double* __restrict__ bw, int32_t* __restrict__ evals) {
   __shared__ double pts[kKdeWaves][64 * S];
   __shared__ double wex[kKdeWaves][64 * S];   // per-wave exchange row of the symmetric likelihood evaluation
+  __shared__ float p32buf[kKdeWaves][S == 2 ? 256 : 1];   // fast path: particles as single-precision offsets from particle 0, twice
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = blockIdx.x * kKdeWaves + wave;
   if (t >= T) return;   // wave-uniform; nothing below synchronises across waves
@@ -133,8 +275,15 @@ __global__ void __launch_bounds__(64 * kKdeWaves) k_kde_bandwidth(int T, int dim
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   int ne = 0;
-  const double h = circ ? lcv_golden<S, true>(x, act, pts[wave], wex[wave], N, lane, tol_c, &ne)
-                        : lcv_golden<S, false>(x, act, pts[wave], wex[wave], N, lane, tol_e, &ne);
+  double h;
+  if constexpr (S == 2) {
+    float* p32 = reinterpret_cast<float*>(p32buf[wave]);
+    h = circ ? lcv_golden_fast<true>(x, act, pts[wave], p32, wex[wave], N, lane, tol_c, &ne)
+             : lcv_golden_fast<false>(x, act, pts[wave], p32, wex[wave], N, lane, tol_e, &ne);
+  } else {
+    h = circ ? lcv_golden<S, true>(x, act, pts[wave], wex[wave], N, lane, tol_c, &ne)
+             : lcv_golden<S, false>(x, act, pts[wave], wex[wave], N, lane, tol_e, &ne);
+  }
   if (lane == 0) { bw[t] = h; if (evals) evals[t] = ne; }
 }
 

@@ -56,7 +56,10 @@ def test_device_matches_oracle_all_sizes(N):
         # same iterates unless a golden-section comparison is a rounding-level tie (then both answers are inside tol)
         rel = np.abs(h / ho - 1)
         te, tc = tols[0] or 1e-2, tols[1] or 1e-6
-        assert np.median(rel) < 1e-10
+        # Euclidean rules >= 1e-2 run the oracle's golden-section iterates; finer rules (and every circular default) stop the
+        # golden section at 1e-2 and finish on the derivative of the likelihood: same optimum within the tolerance, not the same iterates
+        if te >= 1e-2:
+            assert np.median(rel[:, :2]) < 1e-10
         # (stopping rules below ~1e-7 would compare likelihoods that differ by rounding noise only, on both sides)
         assert rel[:, :2].max() < 3 * te and rel[:, 2].max() < 3 * tc, rel.max(0)
         if te >= 1e-3:
