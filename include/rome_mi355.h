@@ -269,6 +269,18 @@ int rome_product_dev(rome_ctx*, const rome_opts*, int32_t dim, int32_t V, const 
  * which is what the reference's manikde! attaches to every convolution result); NULL = Silverman's rule in-kernel. */
 int rome_product_bw_dev(rome_ctx*, const rome_opts*, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
                         const double* prop, const double* prop_bw, const double* bel_in, double* bel_out);
+/* rome_product_gibbs_dev: the reference's own product -- ⚠AMP `manifoldProduct(ff, manifold; Niter)` -> ⚠KDE.jl `prodAppxMSGibbsS`:
+ *   multiscale Gibbs sampling from the product of the proposal KDEs (Ihler, Sudderth, Freeman, Willsky, NIPS 2003), restated from
+ *   the paper (neither package is vendored: statistical pins only; oracle/rome_oracle.c ro_product_msgibbs is the step-by-step
+ *   definition the kernel is compared with).  Same CSR layout as rome_product_dev; prop_bw [rows][dim] = the bandwidth manikde!
+ *   attached to every proposal (rome_kde_bandwidth_dev) is REQUIRED; coordinate k is circular when bit k of circular_mask is set
+ *   (Pose2: 0b100); gibbs_iters = AMP's Niter (1); max_proposals >= max_v (prop_ptr[v+1] - prop_ptr[v]) sizes the LDS of a block
+ *   (the CSR is built on the host, so the caller knows it); n_prop_rows = rows of prop / prop_bw (a ball tree is built for each, in a
+ *   context-owned workspace of 6.8 kB per row).  dim 2 (Point2) or 3 (Pose2), N <= 128.  Variables without proposals keep bel_in, with
+ *   one proposal take it unchanged (as AMP does). */
+int rome_product_gibbs_dev(rome_ctx*, const rome_opts*, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
+                           const double* prop, const double* prop_bw, int32_t n_prop_rows, const double* bel_in, double* bel_out,
+                           uint32_t circular_mask, int32_t gibbs_iters, int32_t max_proposals);
 
 /* thin device-memory helpers for callers without their own HIP runtime binding (e.g. the Julia shim) */
 int rome_dev_alloc(rome_ctx*, uint64_t bytes, void** out);

@@ -250,6 +250,19 @@ def product(opts, dim, prop_ptr, prop_rows, prop, bel_in, prop_bw=None):
     return out
 
 
+def product_msgibbs(opts, dim, prop_ptr, prop_rows, prop, prop_bw, bel_in, circular_mask=0, gibbs_iters=1):
+    """⚠AMP manifoldProduct restated (multiscale Gibbs product of the proposal KDEs); prop_bw (rows, dim) required."""
+    pp, ppp = _i(prop_ptr); pr, ppr = _i(prop_rows); P, pP = _d(prop); B, pB = _d(bel_in); bw, pbw = _d(prop_bw)
+    V = len(pp) - 1
+    out = np.zeros_like(B)
+    fn = lib().ro_product_msgibbs
+    fn.argtypes = [C.POINTER(Opts), C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                   C.POINTER(C.c_double), C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+    rc = fn(C.byref(opts), int(dim), V, ppp, ppr, pP, pbw, pB, int(circular_mask), int(gibbs_iters), out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    return out
+
+
 def kde_bandwidths(bel, circular_mask, tol_euclid=1e-2, tol_circular=1e-6):
     """bel (V, dim, N) -> (V, dim) leave-one-out likelihood bandwidths (ro_kde_bandwidths)."""
     B, pB = _d(bel)

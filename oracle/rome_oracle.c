@@ -1290,3 +1290,264 @@ int ro_product(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const 
                const double* prop, const double* bel_in, double* bel_out) {
   return ro_product_bw(o, dim, V, prop_ptr, prop_rows, prop, NULL, bel_in, bel_out);
 }
+
+/* ======================================================================== */
+/* manifoldProduct: multiscale Gibbs sampling from a product of kernel density estimates                                       */
+/* ======================================================================== */
+/* ⚠AMP `manifoldProduct(ff, manifold; Niter=1)` -> ⚠KDE.jl `prodAppxMSGibbsS` (port of A. Ihler's kde toolbox): the algorithm of
+ * Ihler, Sudderth, Freeman, Willsky, "Efficient multiscale sampling from products of Gaussian mixtures", NIPS 2003, restated
+ * from the paper and the published implementation (neither package is vendored with RoME).
+ * PARITY UNPINNED by the reference (random; no seeds): pinned statistically only -- the hexagon windows of
+ * test/testHexagonal2D_CliqByCliq.jl:37-79 and the reference's solved graph examples/fg-after-solve.tar.gz (tests/).
+ *
+ * Every input density j (a proposal: N points, one bandwidth per coordinate) is summarised by a binary ball tree:
+ *   level l has 2^l nodes, node z covers the sorted positions [floor(z N / 2^l), floor((z+1) N / 2^l)); levels 0 .. L,
+ *   L = ceil(log2 N), so level L holds the single points.  Top-down, every node with >= 2 points is sorted along the coordinate
+ *   of largest extent (max - min over its points; first such coordinate), which sends the lower half to its left child --
+ *   Ihler's kd-tree build with index-range halving.  Node statistics, bottom-up (Chan's pairwise update, in double):
+ *       n = n_l + n_r,  mean = (n_l m_l + n_r m_r)/n,  M2 = M2_l + M2_r + n_l n_r/n (m_l - m_r)²,  var = M2/n + h²
+ *   i.e. the node is the moment-matched Gaussian of the kernels below it (weight n/N).  Coordinates are offsets from the
+ *   density's point 0 (circular coordinates: wrapped offsets), kept in SINGLE precision like the device's tree (mean, var, 1/var
+ *   and c = log(n/N) - ½ Σ log var are rounded to float once); all evaluations below are in double on those values.
+ * One output sample (Philox stream = variable, counter = sample index), labels sel[j] = root:
+ *   for l = 1 .. L:
+ *     (a) x ~ product of the Gaussians of the currently selected nodes (level l-1)           [samplePoint]
+ *     (b) every tree moves to level l                                                          [levelDown]
+ *     (c) for every j: sel[j] ~ p(z) ∝ w_z N(x; m_z, var_z) over ALL nodes of level l          [sampleIndices]
+ *     (d) gibbs_iters sweeps, for every j: with (M, C) the product Gaussian of the other selected nodes,
+ *         sel[j] ~ p(z) ∝ w_z N(m_z; M, var_z + C) over all nodes of level l                   [sampleIndex: the Gibbs step]
+ *   output = a draw from the product of the selected level-L kernels (the particles themselves, full precision).
+ * Categorical draws are one-pass reservoir selections (running maximum of log p, rescaled total, accept candidate z with
+ * probability a_z / T) driven by a xorshift32 stream seeded from one Philox word per draw -- the same arithmetic on both sides.
+ * K = 0: the belief is kept; K = 1: the proposal is the product (AMP returns it unchanged). */
+typedef struct { float key; int id; } msg_key;
+static int msg_cmp(const void* a, const void* b) {
+  const msg_key* p = (const msg_key*)a; const msg_key* q = (const msg_key*)b;
+  if (p->key < q->key) return -1;
+  if (p->key > q->key) return 1;
+  return p->id - q->id;
+}
+typedef struct {
+  int L, N, D;
+  float* mean;   /* [nodes of levels 0..L-1][D]  (node (l, z) at index (1<<l) - 1 + z) */
+  float* var; float* ivar; float* cz; int* cnt;
+  float* ys;     /* [N][D] offsets of the points in final (sorted) order */
+  int* perm;     /* sorted position -> particle index */
+  float lvar[6], livar[6], lcz;   /* level-L kernels */
+  double ref[6], h[6];
+} msg_tree;
+static inline void msg_range(int N, int l, int z, int* a, int* b) { *a = (int)(((long long)z * N) >> l); *b = (int)(((long long)(z + 1) * N) >> l); }
+static void msg_build(msg_tree* T, int N, int D, const double* P /*[D][N]*/, const double* h, uint32_t circ) {
+  int L = 0; while ((1 << L) < N) ++L;
+  T->L = L; T->N = N; T->D = D;
+  const int nn = (1 << L) - 1 > 0 ? (1 << L) - 1 : 1;
+  T->mean = (float*)calloc((size_t)nn * D, sizeof(float)); T->var = (float*)calloc((size_t)nn * D, sizeof(float));
+  T->ivar = (float*)calloc((size_t)nn * D, sizeof(float)); T->cz = (float*)calloc(nn, sizeof(float)); T->cnt = (int*)calloc(nn, sizeof(int));
+  T->ys = (float*)malloc(sizeof(float) * N * D); T->perm = (int*)malloc(sizeof(int) * N);
+  float* y = (float*)malloc(sizeof(float) * N * D);
+  for (int d = 0; d < D; ++d) {
+    T->ref[d] = P[d * N]; T->h[d] = fmax(h[d], 1e-6);
+    for (int i = 0; i < N; ++i) {
+      double o = P[d * N + i] - P[d * N];
+      if ((circ >> d) & 1u) o = lcv_wrap(o);
+      y[i * D + d] = (float)o + 0.0f;   /* -0 -> +0: one order for equal offsets */
+    }
+  }
+  for (int i = 0; i < N; ++i) T->perm[i] = i;
+  msg_key* kk = (msg_key*)malloc(sizeof(msg_key) * N);
+  for (int l = 0; l < L; ++l)
+    for (int z = 0; z < (1 << l); ++z) {
+      int a, b; msg_range(N, l, z, &a, &b);
+      if (b - a < 2) continue;
+      int best = 0; float ext = -1.0f;
+      for (int d = 0; d < D; ++d) {
+        float mn = INFINITY, mx = -INFINITY;
+        for (int p = a; p < b; ++p) { const float v = y[T->perm[p] * D + d]; if (v < mn) mn = v; if (v > mx) mx = v; }
+        if (mx - mn > ext) { ext = mx - mn; best = d; }
+      }
+      for (int p = a; p < b; ++p) { kk[p - a].key = y[T->perm[p] * D + best]; kk[p - a].id = T->perm[p]; }
+      qsort(kk, (size_t)(b - a), sizeof(msg_key), msg_cmp);
+      for (int p = a; p < b; ++p) T->perm[p] = kk[p - a].id;
+    }
+  free(kk);
+  for (int p = 0; p < N; ++p) for (int d = 0; d < D; ++d) T->ys[p * D + d] = y[T->perm[p] * D + d];
+  free(y);
+  /* bottom-up statistics: (n, mean, M2) per node and coordinate, level L = single points */
+  const int tot = (1 << (L + 1)) - 1;
+  double* m = (double*)calloc((size_t)tot * D, sizeof(double)); double* M2 = (double*)calloc((size_t)tot * D, sizeof(double));
+  int* n = (int*)calloc(tot, sizeof(int));
+  for (int z = 0; z < (1 << L); ++z) {
+    int a, b; msg_range(N, L, z, &a, &b);
+    const int id = (1 << L) - 1 + z;
+    n[id] = b - a;
+    if (b > a) for (int d = 0; d < D; ++d) m[id * D + d] = (double)T->ys[a * D + d];
+  }
+  for (int l = L - 1; l >= 0; --l)
+    for (int z = 0; z < (1 << l); ++z) {
+      const int id = (1 << l) - 1 + z, cl = (1 << (l + 1)) - 1 + 2 * z, cr = cl + 1;
+      const int nl = n[cl], nr = n[cr];
+      n[id] = nl + nr;
+      for (int d = 0; d < D; ++d) {
+        if (nl + nr == 0) continue;
+        if (nr == 0) { m[id * D + d] = m[cl * D + d]; M2[id * D + d] = M2[cl * D + d]; continue; }
+        if (nl == 0) { m[id * D + d] = m[cr * D + d]; M2[id * D + d] = M2[cr * D + d]; continue; }
+        const double dl = m[cl * D + d] - m[cr * D + d], nt = (double)(nl + nr);
+        m[id * D + d] = ((double)nl * m[cl * D + d] + (double)nr * m[cr * D + d]) / nt;
+        M2[id * D + d] = M2[cl * D + d] + M2[cr * D + d] + (double)nl * (double)nr / nt * dl * dl;
+      }
+      T->cnt[id] = n[id];
+      if (n[id] > 0) {
+        double lg = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double v = M2[id * D + d] / (double)n[id] + T->h[d] * T->h[d];
+          T->mean[id * D + d] = (float)m[id * D + d]; T->var[id * D + d] = (float)v; T->ivar[id * D + d] = (float)(1.0 / v);
+          lg += log(v);
+        }
+        T->cz[id] = (float)(log((double)n[id] / (double)N) - 0.5 * lg);
+      }
+    }
+  double lg = 0.0;
+  for (int d = 0; d < D; ++d) { const double v = T->h[d] * T->h[d]; T->lvar[d] = (float)v; T->livar[d] = (float)(1.0 / v); lg += log(v); }
+  T->lcz = (float)(log(1.0 / (double)N) - 0.5 * lg);
+  free(m); free(M2); free(n);
+}
+static void msg_free(msg_tree* T) { free(T->mean); free(T->var); free(T->ivar); free(T->cz); free(T->cnt); free(T->ys); free(T->perm); }
+/* statistics of node z of level l (l == L: the single points) as doubles of the stored floats; returns the count */
+static int msg_node(const msg_tree* T, int l, int z, double* mean, double* var, double* ivar, double* cz) {
+  if (l < T->L) {
+    const int id = (1 << l) - 1 + z;
+    for (int d = 0; d < T->D; ++d) { mean[d] = (double)T->mean[id * T->D + d]; var[d] = (double)T->var[id * T->D + d]; ivar[d] = (double)T->ivar[id * T->D + d]; }
+    *cz = (double)T->cz[id];
+    return T->cnt[id];
+  }
+  int a, b; msg_range(T->N, l, z, &a, &b);
+  if (b <= a) return 0;
+  for (int d = 0; d < T->D; ++d) { mean[d] = (double)T->ys[a * T->D + d]; var[d] = (double)T->lvar[d]; ivar[d] = (double)T->livar[d]; }
+  *cz = (double)T->lcz;
+  return 1;
+}
+static inline uint32_t msg_xorshift(uint32_t r) { r ^= r << 13; r ^= r >> 17; r ^= r << 5; return r; }
+typedef struct { double M, T; uint32_t r; int sel; } msg_res;
+static inline void msg_res_init(msg_res* R, uint32_t seed_word) { R->M = -INFINITY; R->T = 0.0; R->r = seed_word | 1u; R->sel = 0; }
+static inline void msg_res_add(msg_res* R, int z, double logp) {
+  const double Mn = logp > R->M ? logp : R->M;
+  const double a = exp(logp - Mn);
+  R->T = R->T * exp(R->M - Mn) + a;     /* exp(-inf) = 0 on the first candidate */
+  R->M = Mn;
+  R->r = msg_xorshift(R->r);
+  if ((double)(R->r >> 8) * (1.0 / 16777216.0) * R->T < a) R->sel = z;
+}
+int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const int32_t* prop_rows,
+                       const double* prop /*[rows][dim][N]*/, const double* prop_bw /*[rows][dim]*/, const double* bel_in,
+                       uint32_t circular_mask, int gibbs_iters, double* bel_out) {
+  const int N = o->n_particles, D = dim;
+  if ((dim != 2 && dim != 3) || N < 1 || !prop_bw) return -1;
+  if (gibbs_iters < 1) gibbs_iters = 1;
+  const uint32_t key[2] = {(uint32_t)o->seed, (uint32_t)(o->seed >> 32)};
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int v = 0; v < V; ++v) {
+    const int K = prop_ptr[v + 1] - prop_ptr[v];
+    const int32_t* rows = prop_rows + prop_ptr[v];
+    double* ob = bel_out + (size_t)v * D * N;
+    if (K == 0) { memcpy(ob, bel_in + (size_t)v * D * N, sizeof(double) * D * N); continue; }
+    if (K == 1) { memcpy(ob, prop + (size_t)rows[0] * D * N, sizeof(double) * D * N); continue; }
+    msg_tree* T = (msg_tree*)malloc(sizeof(msg_tree) * K);
+    for (int j = 0; j < K; ++j) msg_build(&T[j], N, D, prop + (size_t)rows[j] * D * N, prop_bw + (size_t)rows[j] * D, circular_mask);
+    const int L = T[0].L;
+    int* sel = (int*)malloc(sizeof(int) * K);
+    const uint64_t st = o->stream_offset + (uint64_t)v;
+    for (int s = 0; s < N; ++s) {
+      uint32_t qu = 0, qn = 0, wu[4], wn[4]; double npair[2];
+      #define MSG_UNIFORM_WORD(out) do { if ((qu & 3u) == 0) { uint32_t c_[4] = {(uint32_t)s, (uint32_t)st, (uint32_t)(st >> 32), (6u << 16) | (qu >> 2)}; \
+                                           ro_philox4x32_10(c_, key, wu); } (out) = wu[qu & 3u]; ++qu; } while (0)
+      #define MSG_NORMAL(out) do { if ((qn & 3u) == 0) { uint32_t c_[4] = {(uint32_t)s, (uint32_t)st, (uint32_t)(st >> 32), (7u << 16) | (qn >> 2)}; \
+                                     ro_philox4x32_10(c_, key, wn); } \
+                                   if ((qn & 1u) == 0) ro_box_muller(wn[qn & 2u], wn[(qn & 2u) + 1], &npair[0], &npair[1]); (out) = npair[qn & 1u]; ++qn; } while (0)
+      for (int j = 0; j < K; ++j) sel[j] = 0;
+      double x[6];
+      for (int l = 1; l <= L + 1; ++l) {
+        /* (a) product of the selected nodes of level l-1; leaving out nothing.  Circular coordinates: deviations from density 0's mean */
+        for (int d = 0; d < D; ++d) {
+          double prec = 0.0, num = 0.0, mu0 = 0.0;
+          for (int j = 0; j < K; ++j) {
+            double mean[6], var[6], ivar[6], cz;
+            msg_node(&T[j], l - 1, sel[j], mean, var, ivar, &cz);
+            double mabs, iv;
+            if (l - 1 == L) {   /* the selected kernel itself: the particle at full precision, its bandwidth in double */
+              mabs = prop[(size_t)rows[j] * D * N + (size_t)d * N + T[j].perm[(int)(((long long)sel[j] * N) >> L)]];
+              iv = 1.0 / (T[j].h[d] * T[j].h[d]);
+            }
+            else { mabs = T[j].ref[d] + mean[d]; iv = ivar[d]; }
+            if (j == 0) mu0 = mabs;
+            double dev = mabs - mu0;
+            if ((circular_mask >> d) & 1u) dev = lcv_wrap(dev);
+            prec += iv; num += iv * dev;
+          }
+          double xi; MSG_NORMAL(xi);
+          x[d] = mu0 + num / prec + xi / sqrt(prec);
+        }
+        if (l == L + 1) break;   /* that was the output draw from the selected kernels */
+        /* (c) labels of level l given the point */
+        for (int j = 0; j < K; ++j) {
+          uint32_t w; MSG_UNIFORM_WORD(w);
+          msg_res R; msg_res_init(&R, w);
+          for (int z = 0; z < (1 << l); ++z) {
+            double mean[6], var[6], ivar[6], cz;
+            if (msg_node(&T[j], l, z, mean, var, ivar, &cz) == 0) continue;
+            double q = 0.0;
+            for (int d = 0; d < D; ++d) {
+              double e = x[d] - T[j].ref[d];
+              if ((circular_mask >> d) & 1u) e = lcv_wrap(e);
+              e -= mean[d];
+              if ((circular_mask >> d) & 1u) e = lcv_wrap(e);
+              q += e * e * ivar[d];
+            }
+            msg_res_add(&R, z, cz - 0.5 * q);
+          }
+          sel[j] = R.sel;
+        }
+        /* (d) Gibbs sweeps over the labels */
+        for (int it = 0; it < gibbs_iters; ++it)
+          for (int j = 0; j < K; ++j) {
+            double Mx[6], Cx[6];
+            for (int d = 0; d < D; ++d) {
+              double prec = 0.0, num = 0.0, mu0 = 0.0; int first = 1;
+              for (int i = 0; i < K; ++i) {
+                if (i == j) continue;
+                double mean[6], var[6], ivar[6], cz;
+                msg_node(&T[i], l, sel[i], mean, var, ivar, &cz);
+                const double mabs = T[i].ref[d] + mean[d];
+                if (first) { mu0 = mabs; first = 0; }
+                double dev = mabs - mu0;
+                if ((circular_mask >> d) & 1u) dev = lcv_wrap(dev);
+                prec += ivar[d]; num += ivar[d] * dev;
+              }
+              Mx[d] = mu0 + num / prec; Cx[d] = 1.0 / prec;
+            }
+            uint32_t w; MSG_UNIFORM_WORD(w);
+            msg_res R; msg_res_init(&R, w);
+            for (int z = 0; z < (1 << l); ++z) {
+              double mean[6], var[6], ivar[6], cz;
+              const int cnt = msg_node(&T[j], l, z, mean, var, ivar, &cz);
+              if (cnt == 0) continue;
+              double q = 0.0;
+              for (int d = 0; d < D; ++d) {
+                double e = T[j].ref[d] + mean[d] - Mx[d];
+                if ((circular_mask >> d) & 1u) e = lcv_wrap(e);
+                const double vv = var[d] + Cx[d];
+                q += e * e / vv + log(vv);
+              }
+              msg_res_add(&R, z, log((double)cnt / (double)N) - 0.5 * q);
+            }
+            sel[j] = R.sel;
+          }
+      }
+      for (int d = 0; d < D; ++d) ob[(size_t)d * N + s] = ((circular_mask >> d) & 1u) ? lcv_wrap(x[d]) : x[d];
+      #undef MSG_UNIFORM_WORD
+      #undef MSG_NORMAL
+    }
+    for (int j = 0; j < K; ++j) msg_free(&T[j]);
+    free(T); free(sel);
+  }
+  return 0;
+}

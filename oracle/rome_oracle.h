@@ -118,6 +118,10 @@ int ro_kde_bandwidths(int dim, int V, int N, const double* bel /*[V][dim][N]*/, 
 int ro_kde_max(int dim, int V, int N, const double* bel, const double* bw, int G, double extend, double* out);
 int ro_product(const ro_opts* o, int dim, int V, const int32_t* prop_ptr /*[V+1]*/, const int32_t* prop_rows,
                const double* prop /*[rows][dim][N]*/, const double* bel_in /*[V][dim][N]*/, double* bel_out);
+/* ⚠AMP manifoldProduct restated: multiscale Gibbs sampling from the product of the proposal KDEs (see rome_oracle.c);
+ * dim 2 (Point2) / 3 (Pose2, circular_mask 0b100); prop_bw [rows][dim] = the bandwidths manikde! attached to every proposal. */
+int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
+                       const double* prop_bw, const double* bel_in, uint32_t circular_mask, int gibbs_iters, double* bel_out);
 int ro_product_bw(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
                   const double* prop_bw /*[rows][dim] or NULL*/, const double* bel_in, double* bel_out);
 

@@ -11,7 +11,7 @@ from ._lib import (Context, Opts, RomeError, SOLVER_CLOSED_FORM, SOLVER_NEWTON, 
 from .factors import (MvNormal, Normal, Uniform, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
                       Pose3Pose3, PriorPose3, PriorPoint2, Point2Point2, getMeasurementParametric, getPoint, getCoordinates, pack_factor,
                       unpack_factor)
-from .api import (linearize, belief_stats, kde_bandwidth, kde_max, calcPPE, points_to_coords, coords_to_points, calcFactorResidualTemporary, make_opts, cholesky_lower, default_context,
+from .api import (linearize, belief_stats, kde_bandwidth, kde_max, manifoldProduct, calcPPE, points_to_coords, coords_to_points, calcFactorResidualTemporary, make_opts, cholesky_lower, default_context,
                   residual_pose2pose2, residual_priorpose2, residual_pose2point2br, residual_pose2point2br_pt,
                   residual_pose3pose3, residual_pose3pose3_pt, residual_priorpose3,
                   conv_pose2pose2, conv_pose2point2br, conv_pose3pose3, sample_priorpose2, sample_priorpose3)

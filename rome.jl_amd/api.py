@@ -174,6 +174,30 @@ def kde_bandwidth(bel, circular_mask=None, tol_euclid=0.0, tol_circular=0.0, ctx
     return bw
 
 
+def manifoldProduct(proposals, circular_mask=None, bandwidths=None, Niter=1, opts=None, ctx=None):
+    """⚠AMP `manifoldProduct(ff, manifold; Niter=1)`: N samples from the product of K kernel density estimates by multiscale Gibbs
+    sampling (rome_product_gibbs_dev).  proposals (K, dim, N) host array (dim 2: Point2, 3: Pose2); bandwidths (K, dim) or None =
+    the `manikde!` rule (kde_bandwidth).  -> (dim, N).  K = 1 returns the density's own points, as AMP does."""
+    import torch
+    ctx = ctx or default_context()
+    P = _d(proposals)
+    K, d, N = P.shape
+    if circular_mask is None:
+        circular_mask = 0b100 if d == 3 else 0
+    bw = kde_bandwidth(P, circular_mask, ctx=ctx) if bandwidths is None else _d(bandwidths, (K, d))
+    o = opts if opts is not None else make_opts(N=N)
+    dev = torch.device("cuda", ctx.device if hasattr(ctx, "device") else 0)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    tp, tb = t(P, torch.float64), t(bw, torch.float64)
+    ptr, rows = t([0, K], torch.int32), t(np.arange(K), torch.int32)
+    bin_, out = torch.zeros((1, d, N), dtype=torch.float64, device=dev), torch.empty((1, d, N), dtype=torch.float64, device=dev)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(_lib.load().rome_product_gibbs_dev(ctx.handle, C.byref(o), d, 1, ptr.data_ptr(), rows.data_ptr(), tp.data_ptr(), tb.data_ptr(), K,
+                                                  bin_.data_ptr(), out.data_ptr(), int(circular_mask), int(Niter), max(1, K)), ctx.handle)
+    torch.cuda.synchronize(dev)
+    return out[0].cpu().numpy()
+
+
 def kde_max(bel, bw=None, grid_points=0, ctx=None):
     """bel (V, dim, N) host array -> (V, dim) max-density coordinates as IIF's getKDEMax computes them (PPE `max`), via rome_kde_max.
     bw (V, dim): kernel bandwidths; None selects them with kde_bandwidth (what `manikde!` would have stored)."""

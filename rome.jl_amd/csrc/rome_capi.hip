@@ -682,6 +682,22 @@ int rome_product_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t V, co
   return rome_product_bw_dev(c, o, dim, V, prop_ptr, prop_rows, prop, nullptr, bel_in, bel_out);
 }
 
+int rome_product_gibbs_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
+                           const double* prop, const double* prop_bw, int32_t n_prop_rows, const double* bel_in, double* bel_out,
+                           uint32_t circular_mask, int32_t gibbs_iters, int32_t max_proposals) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || V < 0 || n_prop_rows < 0 || (dim != 2 && dim != 3) || max_proposals < 1) return ROME_ERR_INVALID_ARG;
+  if (V > 0 && (!prop_ptr || !prop_rows || !bel_in || !bel_out)) return ROME_ERR_INVALID_ARG;
+  if (n_prop_rows > 0 && (!prop || !prop_bw)) return ROME_ERR_INVALID_ARG;
+  if (o->n_particles > 128) return ROME_ERR_UNSUPPORTED_N;   /* lane = output sample, two wavefronts per variable */
+  ROME_BIND(c);
+  void* trees = nullptr;   /* one ball tree per proposal row, context-owned workspace (grown on demand, kept) */
+  rc = ensure(c, 10, rome::gibbs_workspace_bytes(dim, n_prop_rows), &trees); if (rc) return rc;
+  ROME_HIP(c, rome::launch_product_gibbs(dim, V, o->n_particles, n_prop_rows, prop_ptr, prop_rows, prop, prop_bw, bel_in, bel_out, trees,
+                                         circular_mask, gibbs_iters, max_proposals, o->seed, o->stream_offset, c->stream));
+  return ROME_OK;
+}
+
 /* ---- device memory helpers ---- */
 int rome_dev_alloc(rome_ctx* c, uint64_t bytes, void** out) {
   if (!c || !out) return ROME_ERR_INVALID_ARG;

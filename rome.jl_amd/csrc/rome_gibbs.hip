@@ -1,0 +1,507 @@
+// rome_gibbs.hip -- manifoldProduct: multiscale Gibbs sampling from a product of kernel density estimates.
+//
+// What the reference does with the proposals of a variable (⚠AMP `manifoldProduct(ff, manifold; Niter=1)` -> ⚠KDE.jl
+// `prodAppxMSGibbsS`, a port of A. Ihler's kde toolbox): Ihler, Sudderth, Freeman, Willsky, "Efficient multiscale sampling from
+// products of Gaussian mixtures", NIPS 2003.  Restated from the paper / published implementation (neither package is vendored
+// with RoME); the definition, step by step, is ro_product_msgibbs in oracle/rome_oracle.c and
+// the two are compared sample by sample (tests/test_gpu_gibbs.py).  Random and unseeded upstream: pinned statistically only.
+//
+// Mapping on gfx950: two kernels.
+//   build   k_gibbs_trees: one wavefront per proposal (four per block) writes the proposal's ball tree (6.8 kB for Pose2) to a
+//           workspace in HBM -- every proposal feeds exactly one product.  A tree is built top-down by sorting:
+//           at level l every node re-sorts its index range along its widest coordinate -- ONE 128-key bitonic sort of the whole
+//           wavefront per level with the key (node, coordinate, id): sorting by node first keeps every point inside its node's
+//           range, so the nodes of a level are sorted simultaneously (segment extents by LDS integer min/max atomics).
+//           Node statistics bottom-up by Chan's pairwise update with the children fetched by lane shuffles (same arithmetic
+//           order as the oracle), stored in single precision as offsets from the proposal's point 0.
+//   sample  k_product_gibbs: one 128-thread block per variable, lane = output sample (N <= 128).  Every categorical draw walks the
+//           candidates of a level with WAVE-UNIFORM node statistics -- scalar loads of the tree through the scalar cache / L2, no LDS
+//           copy of the trees (with them in LDS a hub variable with 11 proposals pinned 81 kB and the whole launch ran at one
+//           block per CU: 10.3 ms per Manhattan sweep; from HBM/L2: see profiles/) -- against the lane's own point / product
+//           Gaussian: no divergence; one-pass reservoir selection (running max of log p, rescaled total) driven by a xorshift32
+//           stream seeded from one Philox word.  LDS: 128 label bytes per proposal.
+#include "rome_device_math.hpp"
+#include "rome_kernels.h"
+
+namespace rome {
+
+constexpr int kGibbsThreads = 128;
+constexpr int kGibbsMaxN = 128;
+constexpr int kGibbsNodes = 127;   // internal nodes of levels 0 .. 6
+
+struct GibbsArgs {
+  int V, N, L, max_k, iters;
+  uint32_t circ;
+  const int32_t* prop_ptr; const int32_t* prop_rows;
+  const double* prop; const double* prop_bw; const double* bel_in; double* bel_out;
+  void* trees;            // workspace: one GibbsTree<D> per proposal row
+  int n_rows;
+  uint64_t seed, stream_offset;
+};
+
+template <int D>
+struct alignas(8) GibbsTree {
+  double ref[D], h[D];
+  float mean[kGibbsNodes][D], var[kGibbsNodes][D], ivar[kGibbsNodes][D], cz[kGibbsNodes];
+  float ys[kGibbsMaxN][D];
+  float lvar[D], livar[D], lcz;
+  int row;
+  uint8_t perm[kGibbsMaxN];
+};
+
+__device__ __forceinline__ double gwrap(double d) { return d - 6.283185307179586476925287 * rint(d * 0.15915494309189533576888); }
+__device__ __forceinline__ uint32_t fkey(float f) {   // order-preserving map float -> uint32
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ void node_range(int N, int l, int z, int* a, int* b) {
+  *a = (int)(((long long)z * N) >> l); *b = (int)(((long long)(z + 1) * N) >> l);
+}
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+  const int lo = __shfl(__double2loint(v), src, 64), hi = __shfl(__double2hiint(v), src, 64);
+  return __hiloint2double(hi, lo);
+}
+
+// one wavefront builds tree `T` of proposal `P` ([D][N] doubles, bandwidths h); scr: 2 x 128 x D ints of per-wave scratch
+template <int D>
+__device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restrict__ P, const double* __restrict__ hb, int row,
+                            int N, int L, uint32_t circ, int lane, float* __restrict__ ybuf /*[128][D]*/, int* __restrict__ ext /*[128][2D]*/) {
+  // ---- offsets from point 0, single precision; positions p = lane, lane + 64
+  float y[2][D];
+  int id[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int i = lane + 64 * s;
+    id[s] = i;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      double o = (i < N ? P[d * N + i] : P[d * N]) - P[d * N];
+      if ((circ >> d) & 1u) o = gwrap(o);
+      y[s][d] = (float)o + 0.0f;   // (-0 -> +0: one order for equal offsets)
+      if (i < N) ybuf[i * D + d] = y[s][d];
+    }
+  }
+  if (lane < D) { T->ref[lane] = P[lane * N]; T->h[lane] = fmax(hb[lane], 1e-6); }
+  if (lane == 0) T->row = row;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  // ---- top-down: per level one bitonic sort of (node, key along the node's widest coordinate, id)
+  for (int l = 0; l < L; ++l) {
+    const int nn = 1 << l;
+    for (int q = lane; q < nn * 2 * D; q += 64) ext[q] = (q & 1) ? (int)0x80000000 : 0x7FFFFFFF;   // (min, max) per node and coordinate
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    int z[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int p = lane + 64 * s;
+      z[s] = p < N ? (int)((((long long)(p + 1) << l) - 1) / N) : nn;   // node of position p (padding positions sort last)
+      if (p < N) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const int k = (int)(fkey(y[s][d]) ^ 0x80000000u);    // signed order
+          atomicMin(&ext[(z[s] * D + d) * 2], k); atomicMax(&ext[(z[s] * D + d) * 2 + 1], k);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    uint64_t key[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int p = lane + 64 * s;
+      if (p < N) {
+        int best = 0; float be = -1.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const uint32_t kmn = (uint32_t)ext[(z[s] * D + d) * 2] ^ 0x80000000u, kmx = (uint32_t)ext[(z[s] * D + d) * 2 + 1] ^ 0x80000000u;
+          const float mn = __uint_as_float((kmn & 0x80000000u) ? (kmn & 0x7FFFFFFFu) : ~kmn), mx = __uint_as_float((kmx & 0x80000000u) ? (kmx & 0x7FFFFFFFu) : ~kmx);
+          const float e = mx - mn;
+          if (e > be) { be = e; best = d; }
+        }
+        float kv = y[s][0];
+#pragma unroll
+        for (int d = 1; d < D; ++d) kv = best == d ? y[s][d] : kv;
+        key[s] = ((uint64_t)z[s] << 40) | ((uint64_t)fkey(kv) << 8) | (uint64_t)id[s];
+      } else key[s] = ~0ull;
+    }
+    // bitonic sort of the 128 keys (position p = lane + 64 s), ascending
+    for (int k2 = 2; k2 <= 128; k2 <<= 1) {
+      for (int j2 = k2 >> 1; j2 >= 1; j2 >>= 1) {
+        if (j2 == 64) {   // partner = other slot of the same lane (only in the last stage: ascending everywhere)
+          const uint64_t a = key[0] < key[1] ? key[0] : key[1], b = key[0] < key[1] ? key[1] : key[0];
+          key[0] = a; key[1] = b;
+        } else {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int p = lane + 64 * s;
+            const uint32_t plo = __shfl_xor((uint32_t)key[s], j2, 64), phi = __shfl_xor((uint32_t)(key[s] >> 32), j2, 64);
+            const uint64_t other = ((uint64_t)phi << 32) | plo;
+            const bool up = (p & k2) == 0;              // ascending block
+            const bool lower = (p & j2) == 0;           // this position keeps the smaller key of the pair when ascending
+            const bool keep_min = up == lower;
+            key[s] = keep_min ? (key[s] < other ? key[s] : other) : (key[s] < other ? other : key[s]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int p = lane + 64 * s;
+      id[s] = p < N ? (int)(key[s] & 0xFFu) : 0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) y[s][d] = ybuf[id[s] * D + d];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int p = lane + 64 * s;
+    if (p < N) {
+      T->perm[p] = (uint8_t)id[s];
+#pragma unroll
+      for (int d = 0; d < D; ++d) T->ys[p][d] = y[s][d];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  // ---- bottom-up statistics (n, mean, M2): level L slots z = lane + 64 s hold single points
+  double h2[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) { const double h = fmax(hb[d], 1e-6); h2[d] = h * h; }
+  int n[2];
+  double m[2][D], M2[2][D];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int zz = lane + 64 * s;
+    int a = 0, b = 0;
+    if (zz < (1 << L)) node_range(N, L, zz, &a, &b);
+    n[s] = b - a;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { m[s][d] = n[s] > 0 ? (double)T->ys[a][d] : 0.0; M2[s][d] = 0.0; }
+  }
+  for (int l = L - 1; l >= 0; --l) {
+#pragma clang fp contract(off)
+    // node zz = lane of level l (at most 64 nodes: slot 0) <- children 2 zz, 2 zz + 1 of level l + 1; child c lives in slot c >> 6,
+    // lane c & 63 (both children in the same slot).  Same arithmetic, in the same order, as msg_build in the oracle.
+    const int zz = lane;
+    const int c0 = (2 * zz) & 127, sl = c0 >> 6, la = c0 & 63, lb = (la + 1) & 63;
+    const int nl0 = __shfl(n[0], la, 64), nl1 = __shfl(n[1], la, 64), nr0 = __shfl(n[0], lb, 64), nr1 = __shfl(n[1], lb, 64);
+    const int nl = sl ? nl1 : nl0, nr = sl ? nr1 : nr0;
+    const bool livep = zz < (1 << l);
+    double pm[D], pM[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const double ml0 = shfl_f64(m[0][d], la), ml1 = shfl_f64(m[1][d], la), mr0 = shfl_f64(m[0][d], lb), mr1 = shfl_f64(m[1][d], lb);
+      const double Ml0 = shfl_f64(M2[0][d], la), Ml1 = shfl_f64(M2[1][d], la), Mr0 = shfl_f64(M2[0][d], lb), Mr1 = shfl_f64(M2[1][d], lb);
+      const double ml = sl ? ml1 : ml0, mr = sl ? mr1 : mr0, Ml = sl ? Ml1 : Ml0, Mr = sl ? Mr1 : Mr0;
+      double mm = 0.0, MM = 0.0;
+      if (nl + nr > 0) {
+        if (nr == 0) { mm = ml; MM = Ml; }
+        else if (nl == 0) { mm = mr; MM = Mr; }
+        else {
+          const double dl = ml - mr, nt = (double)(nl + nr);
+          mm = ((double)nl * ml + (double)nr * mr) / nt;
+          MM = Ml + Mr + (double)nl * (double)nr / nt * dl * dl;
+        }
+      }
+      pm[d] = mm; pM[d] = MM;
+    }
+    n[0] = livep ? nl + nr : 0; n[1] = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { m[0][d] = pm[d]; M2[0][d] = pM[d]; }
+    if (livep && n[0] > 0) {
+      const int idn = (1 << l) - 1 + zz;
+      double lg = 0.0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const double v = M2[0][d] / (double)n[0] + h2[d];
+        T->mean[idn][d] = (float)m[0][d]; T->var[idn][d] = (float)v; T->ivar[idn][d] = (float)(1.0 / v);
+        lg += log(v);
+      }
+      T->cz[idn] = (float)(log((double)n[0] / (double)N) - 0.5 * lg);
+    }
+  }
+  if (lane == 0) {
+    double lg = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { T->lvar[d] = (float)h2[d]; T->livar[d] = (float)(1.0 / h2[d]); lg += log(h2[d]); }
+    T->lcz = (float)(log(1.0 / (double)N) - 0.5 * lg);
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) k_gibbs_trees(const GibbsArgs a) {
+  __shared__ float ybuf[4][kGibbsMaxN * D];
+  __shared__ int ext[4][64 * 2 * D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+  if (row >= a.n_rows) return;   // wave-uniform; waves never synchronise with each other
+  GibbsTree<D>* T = reinterpret_cast<GibbsTree<D>*>(a.trees) + row;
+  gibbs_build<D>(T, a.prop + (size_t)row * D * a.N, a.prop_bw + (size_t)row * D, row, a.N, a.L, a.circ, lane, ybuf[wave], ext[wave]);
+}
+
+// one-pass categorical draw: running maximum M of log p, total T of exp(log p - M), candidate z replaces the selection with
+// probability a_z / T (xorshift32 uniform).  The rescaling exponential is only evaluated when some lane's maximum moves.
+struct Reservoir {
+  double M, T; uint32_t r; int sel;
+  __device__ __forceinline__ void init(uint32_t w) { M = -__builtin_inf(); T = 0.0; r = w | 1u; sel = 0; }
+  __device__ __forceinline__ void add(int z, double logp) {
+    const bool moved = logp > M;
+    const double Mn = moved ? logp : M;
+    if (__builtin_amdgcn_ballot_w64(moved) != 0) T *= fast_exp_neg(M - Mn);   // exp(-inf) = 0 on the first candidate; 1 where M stays
+    const double a = fast_exp_neg(logp - Mn);
+    T += a;
+    M = Mn;
+    r ^= r << 13; r ^= r >> 17; r ^= r << 5;
+    if ((double)(r >> 8) * (1.0 / 16777216.0) * T < a) sel = z;
+  }
+};
+// 1 / v for v > 0: single-precision reciprocal seed + two Newton steps in double (relative error ~1e-16; a division costs 3x)
+__device__ __forceinline__ double fast_rcp_pos(double v) {
+  double r = (double)__builtin_amdgcn_rcpf((float)v);
+  r = r * fma(-v, r, 2.0);
+  r = r * fma(-v, r, 2.0);
+  return r;
+}
+
+// LDS image of ONE level of one tree: what the candidate loops of that level read (wave-uniform -> LDS broadcasts)
+template <int D>
+struct GibbsLevel {
+  union {
+    struct { float mean[64][D], var[64][D], ivar[64][D], cz[64]; } in;   // levels 0 .. L-1 (at most 64 nodes)
+    float ys[kGibbsMaxN][D];                                             // level L: the sorted single points
+  };
+};
+template <int D>
+struct GibbsConst { double ref[D], h[D]; float lvar[D], livar[D], lcz; int row; };
+
+template <int D>
+__global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int v = blockIdx.x;
+  if (v >= a.V) return;
+  const int tid = threadIdx.x;
+  const int N = a.N, L = a.L;
+  const int k0 = a.prop_ptr[v], K = a.prop_ptr[v + 1] - k0;
+  double* ob = a.bel_out + (size_t)v * D * N;
+  if (K <= 1) {   // K = 0: the belief is kept; K = 1: the proposal is the product
+    const double* src = K == 0 ? a.bel_in + (size_t)v * D * N : a.prop + (size_t)a.prop_rows[k0] * D * N;
+    for (int q = tid; q < D * N; q += kGibbsThreads) ob[q] = src[q];
+    return;
+  }
+  __shared__ double logn[kGibbsMaxN + 1];   // log(c / N): the weight of a node with c points
+  for (int c = tid; c <= kGibbsMaxN; c += kGibbsThreads) logn[c] = c > 0 ? log((double)c / (double)N) : 0.0;
+  // dynamic LDS: [max_k] level images | [max_k] constants | [max_k][128] labels
+  GibbsLevel<D>* lev = reinterpret_cast<GibbsLevel<D>*>(smem);
+  GibbsConst<D>* cst = reinterpret_cast<GibbsConst<D>*>(smem + sizeof(GibbsLevel<D>) * a.max_k);
+  uint8_t* selbuf = smem + (sizeof(GibbsLevel<D>) + sizeof(GibbsConst<D>)) * a.max_k;
+  const GibbsTree<D>* __restrict__ W = reinterpret_cast<const GibbsTree<D>*>(a.trees);
+  for (int j = tid; j < K; j += kGibbsThreads) {
+    const int row = a.prop_rows[k0 + j];
+    const GibbsTree<D>& T = W[row];
+    GibbsConst<D>& c = cst[j];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { c.ref[d] = T.ref[d]; c.h[d] = T.h[d]; c.lvar[d] = T.lvar[d]; c.livar[d] = T.livar[d]; }
+    c.lcz = T.lcz; c.row = row;
+  }
+  __syncthreads();
+  // cooperative copy of level l of every tree into LDS (coalesced: the level's nodes are contiguous in each array of the tree)
+  auto stage = [&](int l) {
+    __syncthreads();   // everyone is done with the previous level's image
+    for (int j = 0; j < K; ++j) {
+      const GibbsTree<D>& T = W[cst[j].row];
+      GibbsLevel<D>& G = lev[j];
+      if (l < L) {
+        const int n = 1 << l, o = n - 1;
+        for (int q = tid; q < n * D; q += kGibbsThreads) {
+          (&G.in.mean[0][0])[q] = (&T.mean[o][0])[q]; (&G.in.var[0][0])[q] = (&T.var[o][0])[q]; (&G.in.ivar[0][0])[q] = (&T.ivar[o][0])[q];
+        }
+        for (int q = tid; q < n; q += kGibbsThreads) G.in.cz[q] = T.cz[o + q];
+      } else {
+        for (int q = tid; q < N * D; q += kGibbsThreads) (&G.ys[0][0])[q] = (&T.ys[0][0])[q];
+      }
+    }
+    __syncthreads();
+  };
+  // ---- sampling: lane = output sample
+  const int s = tid;
+  const bool live = s < N;
+  const uint64_t st = a.stream_offset + (uint64_t)v;
+  uint32_t qu = 0, qn = 0;
+  u32x4 wu = {0, 0, 0, 0}, wn = {0, 0, 0, 0};
+  double npair0 = 0.0, npair1 = 0.0;
+  auto uniform_word = [&]() -> uint32_t {
+    if ((qu & 3u) == 0) wu = philox4x32_10(u32x4{(uint32_t)s, (uint32_t)st, (uint32_t)(st >> 32), (6u << 16) | (qu >> 2)}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    const uint32_t k = qu & 3u; ++qu;
+    return k == 0 ? wu.x : (k == 1 ? wu.y : (k == 2 ? wu.z : wu.w));
+  };
+  auto normal = [&]() -> double {
+    if ((qn & 3u) == 0) wn = philox4x32_10(u32x4{(uint32_t)s, (uint32_t)st, (uint32_t)(st >> 32), (7u << 16) | (qn >> 2)}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    if ((qn & 1u) == 0) { if (qn & 2u) box_muller(wn.z, wn.w, &npair0, &npair1); else box_muller(wn.x, wn.y, &npair0, &npair1); }
+    const double r = (qn & 1u) ? npair1 : npair0; ++qn;
+    return r;
+  };
+  for (int j = 0; j < K; ++j) selbuf[j * 128 + tid] = 0;
+  stage(0);
+  double x[D];
+  for (int l = 1; l <= L + 1; ++l) {
+    // (a) a point from the product of the selected nodes of level l - 1 (its image is the one in LDS)
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      double prec = 0.0, num = 0.0, mu0 = 0.0;
+      for (int j = 0; j < K; ++j) {
+        const GibbsConst<D>& c = cst[j];
+        const int sz = selbuf[j * 128 + tid];
+        double mabs, iv;
+        if (l - 1 == L) {   // the selected kernel itself: the particle at full precision, its bandwidth in double
+          const int pos = (int)(((long long)sz * N) >> L);
+          mabs = a.prop[(size_t)c.row * D * N + (size_t)d * N + W[c.row].perm[pos]];
+          iv = 1.0 / (c.h[d] * c.h[d]);
+        } else { mabs = c.ref[d] + (double)lev[j].in.mean[sz][d]; iv = (double)lev[j].in.ivar[sz][d]; }
+        if (j == 0) mu0 = mabs;
+        double dev = mabs - mu0;
+        if ((a.circ >> d) & 1u) dev = gwrap(dev);
+        prec += iv; num += iv * dev;
+      }
+      const double xi = normal();
+      x[d] = mu0 + num / prec + xi / fast_sqrt(prec);
+    }
+    if (l == L + 1) break;
+    stage(l);
+    const int nz = 1 << l;
+    // (c) labels of level l given the point
+    for (int j = 0; j < K; ++j) {
+      const GibbsConst<D>& c = cst[j];
+      const GibbsLevel<D>& G = lev[j];
+      Reservoir R; R.init(uniform_word());
+      double e0[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) { e0[d] = x[d] - c.ref[d]; if ((a.circ >> d) & 1u) e0[d] = gwrap(e0[d]); }
+      if (l < L) {
+        for (int z = 0; z < nz; ++z) {   // wave-uniform candidate: node statistics are LDS broadcasts
+          int ra, rb; node_range(N, l, z, &ra, &rb);
+          if (rb <= ra) continue;
+          double q = 0.0;
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            double e = e0[d] - (double)G.in.mean[z][d];
+            if ((a.circ >> d) & 1u) e = gwrap(e);
+            q += e * e * (double)G.in.ivar[z][d];
+          }
+          R.add(z, (double)G.in.cz[z] - 0.5 * q);
+        }
+      } else {
+        double iv[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) iv[d] = (double)c.livar[d];
+        const double lcz = (double)c.lcz;
+        for (int z = 0; z < nz; ++z) {
+          int ra, rb; node_range(N, l, z, &ra, &rb);
+          if (rb <= ra) continue;
+          double q = 0.0;
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            double e = e0[d] - (double)G.ys[ra][d];
+            if ((a.circ >> d) & 1u) e = gwrap(e);
+            q += e * e * iv[d];
+          }
+          R.add(z, lcz - 0.5 * q);
+        }
+      }
+      selbuf[j * 128 + tid] = (uint8_t)R.sel;
+    }
+    // (d) Gibbs sweeps over the labels
+    for (int it = 0; it < a.iters; ++it)
+      for (int j = 0; j < K; ++j) {
+        double Mx[D], Cx[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          double prec = 0.0, num = 0.0, mu0 = 0.0; bool first = true;
+          for (int i = 0; i < K; ++i) {
+            if (i == j) continue;
+            const int sz = selbuf[i * 128 + tid];
+            double mean, iv;
+            if (l < L) { mean = (double)lev[i].in.mean[sz][d]; iv = (double)lev[i].in.ivar[sz][d]; }
+            else { const int pos = (int)(((long long)sz * N) >> L); mean = (double)lev[i].ys[pos][d]; iv = (double)cst[i].livar[d]; }
+            const double mabs = cst[i].ref[d] + mean;
+            if (first) { mu0 = mabs; first = false; }
+            double dev = mabs - mu0;
+            if ((a.circ >> d) & 1u) dev = gwrap(dev);
+            prec += iv; num += iv * dev;
+          }
+          Mx[d] = mu0 + num / prec; Cx[d] = 1.0 / prec;
+        }
+        const GibbsConst<D>& c = cst[j];
+        const GibbsLevel<D>& G = lev[j];
+        Reservoir R; R.init(uniform_word());
+        double e0[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) e0[d] = c.ref[d] - Mx[d];
+        if (l < L) {
+          for (int z = 0; z < nz; ++z) {
+            int ra, rb; node_range(N, l, z, &ra, &rb);
+            if (rb <= ra) continue;
+            double q = 0.0, pv = 1.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              double e = e0[d] + (double)G.in.mean[z][d];
+              if ((a.circ >> d) & 1u) e = gwrap(e);
+              const double vv = (double)G.in.var[z][d] + Cx[d];
+              q += e * e * fast_rcp_pos(vv);
+              pv *= vv;                       // Σ_d log(var_d + C_d) = log Π_d (var_d + C_d): one logarithm per candidate
+            }
+            R.add(z, logn[rb - ra] - 0.5 * (q + fast_log(pv)));
+          }
+        } else {   // single points: every candidate has the variance h² + C and the weight 1/N: constants of the draw drop out
+          double ivv[D];
+#pragma unroll
+          for (int d = 0; d < D; ++d) ivv[d] = fast_rcp_pos((double)c.lvar[d] + Cx[d]);
+          for (int z = 0; z < nz; ++z) {
+            int ra, rb; node_range(N, l, z, &ra, &rb);
+            if (rb <= ra) continue;
+            double q = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              double e = e0[d] + (double)G.ys[ra][d];
+              if ((a.circ >> d) & 1u) e = gwrap(e);
+              q += e * e * ivv[d];
+            }
+            R.add(z, -0.5 * q);
+          }
+        }
+        selbuf[j * 128 + tid] = (uint8_t)R.sel;
+      }
+  }
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) ob[(size_t)d * N + s] = ((a.circ >> d) & 1u) ? gwrap(x[d]) : x[d];
+  }
+}
+
+size_t gibbs_workspace_bytes(int dim, int n_rows) { return (dim == 2 ? sizeof(GibbsTree<2>) : sizeof(GibbsTree<3>)) * (size_t)(n_rows > 0 ? n_rows : 1); }
+
+hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
+                                const double* prop_bw, const double* bel_in, double* bel_out, void* trees, uint32_t circ, int iters, int max_k,
+                                uint64_t seed, uint64_t stream_offset, hipStream_t s) {
+  if (V <= 0) return hipSuccess;
+  if (N < 1 || N > kGibbsMaxN || (dim != 2 && dim != 3) || max_k < 1 || n_rows < 0) return hipErrorInvalidValue;
+  GibbsArgs a;
+  a.V = V; a.N = N; a.L = 0; while ((1 << a.L) < N) ++a.L;
+  a.max_k = max_k; a.iters = iters < 1 ? 1 : iters; a.circ = circ;
+  a.prop_ptr = prop_ptr; a.prop_rows = prop_rows; a.prop = prop; a.prop_bw = prop_bw; a.bel_in = bel_in; a.bel_out = bel_out;
+  a.trees = trees; a.n_rows = n_rows;
+  a.seed = seed; a.stream_offset = stream_offset;
+  const size_t per = dim == 2 ? sizeof(GibbsLevel<2>) + sizeof(GibbsConst<2>) : sizeof(GibbsLevel<3>) + sizeof(GibbsConst<3>);
+  const size_t bytes = (per + 128) * (size_t)max_k;
+  if (bytes > 150 * 1024) return hipErrorInvalidValue;
+  if (bytes > 48 * 1024) {
+    hipError_t e = dim == 2 ? hipFuncSetAttribute((const void*)k_product_gibbs<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
+                            : hipFuncSetAttribute((const void*)k_product_gibbs<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+  }
+  if (n_rows > 0) {
+    if (dim == 2) hipLaunchKernelGGL((k_gibbs_trees<2>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gibbs_trees<3>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
+  }
+  if (dim == 2) hipLaunchKernelGGL((k_product_gibbs<2>), dim3(V), dim3(kGibbsThreads), bytes, s, a);
+  else hipLaunchKernelGGL((k_product_gibbs<3>), dim3(V), dim3(kGibbsThreads), bytes, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace rome

@@ -239,12 +239,19 @@ class DeviceGraph:
         if "p3p3" in self.tab and self.tab["p3p3"]["C"]:
             self.sweep_pose3pose3(self._opts_at(opts, base + self.STREAM_P3P3), out=self.prop[Pose3][:self.tab["p3p3"]["C"]])
 
-    def product_step(self, opts, sweep=0, bandwidth="silverman"):
-        """bel <- product of the proposals targeting each variable (Jacobi update, double-buffered).
-        bandwidth: "silverman" (in-kernel rule on the proposal spread) or "lcv" (leave-one-out likelihood bandwidths of every
-        proposal by rome_kde_bandwidth_dev first -- what the reference's `manikde!` attaches to each convolution result)."""
+    def product_step(self, opts, sweep=0, bandwidth="silverman", product="importance", gibbs_iters=1):
+        """bel <- product of the proposals targeting each variable (Jacobi update: computed into bel_next, copied back in place
+        so that launch plans holding the belief pointers stay valid).
+        product:   "gibbs" = the reference's algorithm, ⚠AMP manifoldProduct / KDE.jl multiscale Gibbs sampling
+                   (rome_product_gibbs_dev; Point2 / Pose2, N <= 128; always on the `manikde!` bandwidths of the proposals);
+                   "importance" = the round-1 importance-sampling stand-in (rome_product_bw_dev; also Pose3).
+        bandwidth: "silverman" (in-kernel rule on the proposal spread; importance product only) or "lcv" (leave-one-out
+                   likelihood bandwidths of every proposal by rome_kde_bandwidth_dev first -- what the reference's `manikde!`
+                   attaches to each convolution result)."""
         if bandwidth not in ("silverman", "lcv"):
             raise ValueError("bandwidth must be 'silverman' or 'lcv'")
+        if product not in ("importance", "gibbs"):
+            raise ValueError("product must be 'importance' or 'gibbs'")
         self._bind_stream()
         base = sweep << 32
         for vt, dim, off in ((Pose2, 3, self.STREAM_PROD2), (Point2, 2, self.STREAM_PRODL), (Pose3, 6, self.STREAM_PROD3)):
@@ -254,26 +261,33 @@ class DeviceGraph:
             o = self._opts_at(opts, base + off)
             c = self.csr[vt]
             bw_ptr = None
-            rows = self.prop[vt].shape[0]
-            if bandwidth == "lcv" and rows:
+            rows = self.n_prop[vt]
+            gibbs = product == "gibbs" and dim in (2, 3)
+            circ = 0b100 if vt is Pose2 else (0b111000 if vt is Pose3 else 0)
+            if (bandwidth == "lcv" or gibbs) and rows:
                 if vt not in self.prop_bw:
-                    self.prop_bw[vt] = self.torch.empty((rows, dim), dtype=self.torch.float64, device=self.device)
-                _lib.check(self._lib.rome_kde_bandwidth_dev(self.ctx.handle, dim, rows, self.N, self.prop[vt].data_ptr(),
-                                                            0b100 if vt is Pose2 else (0b111000 if vt is Pose3 else 0), 0.0, 0.0,
+                    self.prop_bw[vt] = self.torch.empty((self.prop[vt].shape[0], dim), dtype=self.torch.float64, device=self.device)
+                _lib.check(self._lib.rome_kde_bandwidth_dev(self.ctx.handle, dim, rows, self.N, self.prop[vt].data_ptr(), circ, 0.0, 0.0,
                                                             self.prop_bw[vt].data_ptr()),
                            self.ctx.handle)
                 bw_ptr = self.prop_bw[vt].data_ptr()
-            _lib.check(self._lib.rome_product_bw_dev(self.ctx.handle, C.byref(o), dim, V, c["ptr"].data_ptr(), c["rows"].data_ptr(),
-                                                     self.prop[vt].data_ptr(), bw_ptr, self.bel[vt].data_ptr(),
-                                                     self.bel_next[vt].data_ptr()), self.ctx.handle)
-            self.bel[vt], self.bel_next[vt] = self.bel_next[vt], self.bel[vt]
+            if gibbs and rows:
+                max_k = max(1, int(np.diff(c["ptr_h"]).max())) if len(c["ptr_h"]) > 1 else 1
+                _lib.check(self._lib.rome_product_gibbs_dev(self.ctx.handle, C.byref(o), dim, V, c["ptr"].data_ptr(), c["rows"].data_ptr(),
+                                                            self.prop[vt].data_ptr(), bw_ptr, rows, self.bel[vt].data_ptr(),
+                                                            self.bel_next[vt].data_ptr(), circ, int(gibbs_iters), max_k), self.ctx.handle)
+            else:
+                _lib.check(self._lib.rome_product_bw_dev(self.ctx.handle, C.byref(o), dim, V, c["ptr"].data_ptr(), c["rows"].data_ptr(),
+                                                         self.prop[vt].data_ptr(), bw_ptr, self.bel[vt].data_ptr(),
+                                                         self.bel_next[vt].data_ptr()), self.ctx.handle)
+            self.bel[vt].copy_(self.bel_next[vt])
 
-    def solve(self, opts, n_sweeps=10, bandwidth="silverman"):
-        """n_sweeps x (convolution sweep, product): whole-graph nonparametric inference stand-in for the
+    def solve(self, opts, n_sweeps=10, bandwidth="silverman", product="importance", gibbs_iters=1):
+        """n_sweeps x (convolution sweep, product): whole-graph nonparametric inference, a Jacobi schedule in place of the
         clique-by-clique Gibbs of `solveTree!` (no Bayes tree)."""
         for s in range(n_sweeps):
             self.conv_step(opts, s)
-            self.product_step(opts, s, bandwidth)
+            self.product_step(opts, s, bandwidth, product, gibbs_iters)
 
     def init_from_means(self, means, sigma=None, seed=3):
         """Beliefs = per-variable mean ⊕ N(0, diag σ²) jitter: e.g. means from solveGraphParametric (IIF can

@@ -26,3 +26,11 @@ print("conv sweep      %.3f ms" % timeit(lambda: dg.conv_step(o, 0)))
 print("product         %.3f ms" % timeit(lambda: dg.product_step(o, 0)))
 print("conv + product  %.3f ms" % timeit(lambda: (dg.conv_step(o, 0), dg.product_step(o, 0))))
 t = time.perf_counter(); dg.solve(o, 50); torch.cuda.synchronize(); print("solve(50) wall  %.3f ms/sweep" % ((time.perf_counter() - t) * 20))
+saved = dg.bel[R.Pose2].clone()
+dg.conv_step(o, 0)
+print("manikde! bandwidths + importance product  %.3f ms" % timeit(lambda: dg.product_step(o, 0, "lcv"), 10))
+dg.bel[R.Pose2].copy_(saved); dg.conv_step(o, 0)
+print("manikde! bandwidths + Gibbs product (manifoldProduct, Niter=1)  %.3f ms" % timeit(lambda: dg.product_step(o, 0, "lcv", "gibbs"), 10))
+dg.bel[R.Pose2].copy_(saved)
+K = np.diff(dg.csr[R.Pose2]["ptr_h"])
+print("proposals per variable: max %d, mean %.2f, histogram %s" % (K.max(), K.mean(), np.bincount(K).tolist()))

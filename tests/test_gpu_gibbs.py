@@ -1,0 +1,116 @@
+"""manifoldProduct on the device (rome_product_gibbs_dev): the multiscale Gibbs product of kernel density estimates that the
+reference runs through ⚠AMP / ⚠KDE.jl (Ihler et al., NIPS 2003), against its step-by-step restatement in the oracle
+(ro_product_msgibbs) sample by sample, and against what a product of Gaussians must give.  Unseeded upstream: statistical pins only
+(the reference-side windows are exercised through DeviceGraph.solve in tests/test_gpu_solve.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _pkg():
+    global R, torch
+    import torch as _t
+    import rome_jl_amd
+    R, torch = rome_jl_amd, _t
+    R.default_context()
+    yield
+
+
+def _device_product(dim, N, ptr, rows, prop, bw, bel_in, circ, iters=1, seed=11, stream_offset=5):
+    from rome_jl_amd import _lib
+    ctx = R.default_context()
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    tp, tb, ti = t(prop, torch.float64), t(bw, torch.float64), t(bel_in, torch.float64)
+    tptr, trows = t(ptr, torch.int32), t(rows, torch.int32)
+    out = torch.empty_like(ti)
+    o = R.make_opts(N=N, seed=seed, stream_offset=stream_offset)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(_lib.load().rome_product_gibbs_dev(ctx.handle, C.byref(o), dim, len(ptr) - 1, tptr.data_ptr(), trows.data_ptr(), tp.data_ptr(),
+                                                  tb.data_ptr(), len(prop), ti.data_ptr(), out.data_ptr(), circ, iters, int(max(1, np.diff(ptr).max()))),
+               ctx.handle)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _problem(dim, N, Ks, rng, circ):
+    props = []
+    ptr = [0]
+    for K in Ks:
+        centre = rng.normal(0, 3, dim)
+        for _ in range(K):
+            mu = centre + rng.normal(0, 0.3, dim)
+            sd = rng.uniform(0.05, 0.8, dim)
+            P = mu[:, None] + sd[:, None] * rng.standard_normal((dim, N))
+            if rng.random() < 0.3:   # a bimodal proposal
+                P[0, rng.random(N) < 0.4] += 2.5
+            if circ:
+                P[dim - 1] = np.arctan2(np.sin(P[dim - 1] + 3.0), np.cos(P[dim - 1] + 3.0))   # headings straddling ±π
+            props.append(P)
+        ptr.append(ptr[-1] + K)
+    prop = np.stack(props)
+    rows = rng.permutation(len(props)).astype(np.int32)          # proposals scattered over the table
+    prop = prop[np.argsort(rows)]                                # row rows[k] holds the k-th proposal of the CSR order
+    return np.array(ptr, dtype=np.int32), rows, prop
+
+
+@pytest.mark.parametrize("dim,N,iters", [(3, 100, 1), (3, 100, 2), (2, 100, 1), (3, 64, 1), (3, 37, 1), (3, 128, 1), (2, 5, 1), (3, 2, 1)])
+def test_device_equals_oracle_sample_by_sample(dim, N, iters):
+    rng = np.random.default_rng(100 * dim + N + iters)
+    circ = 0b100 if dim == 3 else 0
+    Ks = [2, 3, 0, 1, 5, 11, 2, 4, 7, 3]
+    ptr, rows, prop = _problem(dim, N, Ks, rng, bool(circ))
+    bw = ro.kde_bandwidths(prop, circ) if N > 2 else np.full((len(prop), dim), 0.3)
+    bel_in = rng.standard_normal((len(Ks), dim, N))
+    got = _device_product(dim, N, ptr, rows, prop, bw, bel_in, circ, iters)
+    o = ro.make_opts(N=N, seed=11, stream_offset=5)
+    ref = ro.product_msgibbs(o, dim, ptr, rows, prop, bw, bel_in, circ, iters)
+    assert np.isfinite(got).all()
+    d = got - ref
+    if circ:
+        d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    same = np.abs(d).max(axis=1) < 1e-9                       # (variable, sample)
+    # a categorical draw can differ only when a uniform lands within rounding of a cumulative boundary
+    assert same.mean() > 0.995, same.mean()
+    assert np.array_equal(got[2], bel_in[2])                   # K = 0: the belief is kept
+    assert np.array_equal(got[3], prop[rows[ptr[3]]])          # K = 1: the proposal itself (AMP returns it unchanged)
+
+
+def test_product_of_gaussian_densities_has_the_gaussian_product_moments():
+    rng = np.random.default_rng(7)
+    N, V = 100, 300
+    m1, s1 = np.array([0.0, 0.0, 0.1]), np.array([1.0, 0.5, 0.1])
+    m2, s2 = np.array([1.0, 0.5, 0.3]), np.array([0.5, 1.0, 0.2])
+    prop = np.empty((2 * V, 3, N))
+    prop[0::2] = m1[None, :, None] + s1[None, :, None] * rng.standard_normal((V, 3, N))
+    prop[1::2] = m2[None, :, None] + s2[None, :, None] * rng.standard_normal((V, 3, N))
+    bw = R.kde_bandwidth(prop)
+    ptr = np.arange(0, 2 * V + 1, 2, dtype=np.int32); rows = np.arange(2 * V, dtype=np.int32)
+    out = _device_product(3, N, ptr, rows, prop, bw, np.zeros((V, 3, N)), 0b100)
+    # KDE smoothing widens each factor to s² + h²; the product of the smoothed Gaussians is the target
+    h1, h2 = bw[0::2].mean(0), bw[1::2].mean(0)
+    v1, v2 = s1 ** 2 + h1 ** 2, s2 ** 2 + h2 ** 2
+    P = 1 / v1 + 1 / v2
+    mean, sd = (m1 / v1 + m2 / v2) / P, 1 / np.sqrt(P)
+    assert np.abs(out.mean((0, 2)) - mean).max() < 0.03, (out.mean((0, 2)), mean)
+    pooled = np.sqrt(((out - out.mean(2, keepdims=True)) ** 2).mean((0, 2)) * N / (N - 1))
+    assert np.abs(pooled / sd - 1).max() < 0.08, (pooled, sd)
+
+
+def test_manifold_product_wrapper_and_multimodal_selection():
+    """Two bimodal densities that agree on ONE mode only: the product keeps that mode (what an importance product on one
+    density's points also does, but here from the Gibbs labels), and `manifoldProduct` of a single density returns its points."""
+    rng = np.random.default_rng(3)
+    N = 100
+    a = np.concatenate([rng.normal(-3, 0.2, N // 2), rng.normal(2, 0.2, N - N // 2)])
+    b = np.concatenate([rng.normal(2.1, 0.2, N // 2), rng.normal(6, 0.2, N - N // 2)])
+    P = np.stack([np.stack([a, rng.normal(0, 0.2, N)]), np.stack([b, rng.normal(0, 0.2, N)])])
+    x = R.manifoldProduct(P)
+    assert x.shape == (2, N) and (np.abs(x[0] - 2.05) < 1.0).mean() > 0.97
+    assert np.array_equal(R.manifoldProduct(P[:1]), P[0])
