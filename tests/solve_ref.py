@@ -5,7 +5,7 @@ import numpy as np
 import oracle as ro
 
 
-def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverman"):
+def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverman", product="importance"):
     pk = R.PackedGraph(fg)
     bel2 = pk.beliefs(fg, R.Pose2)
     bell = pk.beliefs(fg, R.Point2) if len(pk.labels[R.Point2]) else np.zeros((0, 2, N))
@@ -46,6 +46,11 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
             propl[:] = ro.conv_pose2point2br(mk(S["BR0"]), 0, pk.br["mu"], pk.br["sigma"], bel2, bell, r0["pose"], r0["point"], factor=r0["factor"],
                                              alt_var=r0["alt"] if mh else None, hypo_w=r0["w"] if mh else None)
         lcv = bandwidth == "lcv"
+        if product == "gibbs":   # the reference's product: multiscale Gibbs sampling on the manikde! bandwidths of the proposals
+            bel2 = ro.product_msgibbs(mk(S["PROD2"]), 3, ptr2, rows2, prop2, ro.kde_bandwidths(prop2, 0b100), bel2, 0b100, 1)
+            if Fb:
+                bell = ro.product_msgibbs(mk(S["PRODL"]), 2, ptrl, rowsl, propl, ro.kde_bandwidths(propl, 0), bell, 0, 1)
+            continue
         bel2 = ro.product(mk(S["PROD2"]), 3, ptr2, rows2, prop2, bel2, ro.kde_bandwidths(prop2, 0b100) if lcv else None)
         if Fb:
             bell = ro.product(mk(S["PRODL"]), 2, ptrl, rowsl, propl, bell, ro.kde_bandwidths(propl, 0) if lcv else None)

@@ -114,3 +114,71 @@ def test_manifold_product_wrapper_and_multimodal_selection():
     x = R.manifoldProduct(P)
     assert x.shape == (2, N) and (np.abs(x[0] - 2.05) < 1.0).mean() > 0.97
     assert np.array_equal(R.manifoldProduct(P[:1]), P[0])
+
+
+def test_solve_loop_with_the_reference_product_hexagonal():
+    """DeviceGraph.solve(product="gibbs") -- convolutions, `manikde!` bandwidths, multiscale Gibbs product, all on the device --
+    against the oracle's restatement of the same loop (pose means within north_star's 1e-3; nearly all particles identical),
+    and against the reference's own acceptance windows for this graph (test/testHexagonal2D_CliqByCliq.jl:37-79)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from solve_ref import solve_ref
+    N, S = 100, 4
+    fg = R.generateGraph_Hexagonal(N=N)
+    R.dead_reckon_init(fg, seed=5)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.solve(R.make_opts(N=N, solver=1, seed=77), n_sweeps=S, product="gibbs")
+    b2, bl = solve_ref(R, fg, S, N, seed=77, product="gibbs")
+    got2 = dg.bel[R.Pose2].cpu().numpy()
+    d = got2 - b2; d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    m2, _ = dg.belief_stats(R.Pose2)
+    for v in range(b2.shape[0]):
+        mo, _ = ro.belief_spread(b2[v])
+        dm = m2[v].cpu().numpy() - mo; dm[2] = np.arctan2(np.sin(dm[2]), np.cos(dm[2]))
+        assert np.abs(dm).max() < 1e-3, (v, dm)
+    assert np.mean(np.abs(d) < 1e-6) > 0.9
+    dg.solve(R.make_opts(N=N, solver=1, seed=2026), n_sweeps=8, product="gibbs")
+    b = dg.bel[R.Pose2].cpu().numpy(); l = dg.bel[R.Point2].cpu().numpy()
+    truth = [(0, 0, 0), (10, 0, np.pi / 3), (15, 8.66, 2 * np.pi / 3), (10, 17.32, np.pi), (0, 17.32, -2 * np.pi / 3),
+             (-5, 8.66, -np.pi / 3), (0, 0, 0)]
+    for k, (x, y, th) in enumerate(truth):
+        dth = np.arctan2(np.sin(b[k, 2] - th), np.cos(b[k, 2] - th))
+        inbox = (np.abs(b[k, 0] - x) < 3) & (np.abs(b[k, 1] - y) < 3) & (np.abs(dth) < 0.3)
+        assert inbox.sum() > 35, (k, inbox.sum(), b[k].mean(axis=1))
+    assert ((np.abs(l[0, 0] - 20) < 3) & (np.abs(l[0, 1]) < 3)).sum() > 35
+
+
+def test_reference_solved_graph_product_consistency():
+    """The reference's own solved Manhattan-500 graph (examples/fg-after-solve.tar.gz): for every variable, convolve the
+    reference's posteriors of its neighbours through the factors (device), take the multiscale Gibbs product of the proposals
+    (device) and compare with the reference's posterior of that variable -- the fixed point its solveTree! had reached.  The
+    product must sit on the reference posterior (normalised mean offset) and have a comparable width; the round-1 importance
+    product is held to the same windows, so the two products can be compared on reference data."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manhattan500_reference_solve.npz"))
+    bel = np.ascontiguousarray(fx["particles"].astype(np.float64).transpose(0, 2, 1))     # [361, 3, 100]
+    N = bel.shape[2]
+    fg = R.initfg(N)
+    labels = ["x%d" % k for k in range(bel.shape[0])]
+    for l in labels:
+        fg.addVariable(l, R.Pose2)
+    idx = {l: k for k, l in enumerate(labels)}
+    for (a, b), mu, cov in zip(fx["edges"], fx["mu"], fx["cov"]):
+        fg.addFactor([labels[int(a)], labels[int(b)]], R.Pose2Pose2(R.MvNormal(mu, cov)))
+    fg.addFactor([labels[0]], R.PriorPose2(R.MvNormal(fx["prior_mu"], fx["prior_cov"])))
+    for k, l in enumerate(labels):
+        fg.initVariable(l, bel[k])
+    res = {}
+    for product in ("gibbs", "importance"):
+        dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+        o = R.make_opts(N=N, solver=1, seed=5)
+        dg.conv_step(o, 0); dg.product_step(o, 0, "lcv", product)
+        new = dg.bel[R.Pose2].cpu().numpy()
+        sd_ref = bel[:, :2].std(axis=2)
+        off = np.abs(new[:, :2].mean(axis=2) - bel[:, :2].mean(axis=2)) / np.maximum(sd_ref, 1e-3)
+        ratio = new[:, :2].std(axis=2) / np.maximum(sd_ref, 1e-3)
+        res[product] = (np.median(off), np.percentile(off, 95), np.median(ratio))
+    g = res["gibbs"]
+    print("reference-solve consistency (median offset/sd, 95 %% offset/sd, median sd ratio):", res)
+    assert g[0] < 1.0 and g[1] < 4.0, res            # the product of the neighbours' messages sits on the reference posterior
+    assert 0.4 < g[2] < 1.6, res                      # ... with a comparable width
