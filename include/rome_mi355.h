@@ -167,6 +167,31 @@ int rome_sample_priorpose3(rome_ctx*, const rome_opts*, int32_t C, const double*
                            const double* noise /*C*N*6 or NULL*/, double* out /*C*N*6*/);
 
 /* ---------------------------------------------------------------------------------------------
+ * Clique-level batch from HOST beliefs: every (factor, direction) convolution of a clique -- or of one variable, what IIF
+ * `proposalbeliefs!(dfg, destlbl, factors, ...)` computes factor by factor (each an `approxConvBelief`; the call
+ * behind `solveTree!`, examples/ManhattanDatasetBatch.jl:43) -- in ONE call: the beliefs are passed once per VARIABLE, the row
+ * tables index them, one kernel launch per factor family, one synchronisation.  A per-factor call moves 3 belief blocks and pays
+ * ~45 µs of latency per convolution; this entry moves every belief once (PCIe-inclusive rate: DESIGN.md §6).
+ *   bel_*      [n][dim][N] blocks per variable type (layout per opts->layout: SoA, AoS [n][N][dim], or the reference's point
+ *              containers for Pose2 / Pose3), n_* variables of the type in the clique
+ *   *_rows4    [rows][4] = (factor, dir, fixed_var, target_var): indices into the family's factor table and the belief arrays
+ *              (Pose2Pose2 / Pose3Pose3: dir 0 solves the 2nd variable, 1 the 1st, ROME_DIR_PRIOR = prior row with
+ *              fixed_var = target_var; bearing-range: br1 rows solve the pose from the landmark, br0 the landmark from the pose)
+ *   *_mu/_cov  factor tables ([F][dz], [F][dz*dz] row-major covariances; bearing-range: [F][2] sigmas, < 0 = Uniform half-width)
+ *   out_*      [rows][dt][N] proposals in the same layout as the beliefs
+ * Philox stream of row r of a family = opts->stream_offset + family offset (0, 1<<28, 2<<28, 5<<28 for p2p2, br1, br0, p3p3: the
+ * same as the device-resident graph sweeps) + r, so a clique call reproduces the per-factor calls made with those streams.  */
+typedef struct rome_clique_host {
+  int32_t n_pose2, n_point2, n_pose3, reserved0;
+  const double* bel_pose2; const double* bel_point2; const double* bel_pose3;
+  int32_t n_p2p2, f_p2p2; const int32_t* p2p2_rows4; const double* p2p2_mu; const double* p2p2_cov; double* out_p2p2;
+  int32_t n_br1, n_br0; int32_t f_br, reserved1; const int32_t* br1_rows4; const int32_t* br0_rows4;
+  const double* br_mu; const double* br_sigma; double* out_br1; double* out_br0;
+  int32_t n_p3p3, f_p3p3; const int32_t* p3p3_rows4; const double* p3p3_mu; const double* p3p3_cov; double* out_p3p3;
+} rome_clique_host;
+int rome_clique_proposals(rome_ctx*, const rome_opts*, const rome_clique_host*);
+
+/* ---------------------------------------------------------------------------------------------
  * Graph-indexed DEVICE-pointer variant: beliefs stay resident in HBM (SoA blocks [var][dim][N]),
  * one launch sweeps a whole table of (factor, direction) convolutions.  This is what a clique /
  * whole-graph sweep of `solveTree!` (examples/ManhattanDatasetBatch.jl:43) issues.

@@ -1,0 +1,143 @@
+"""Clique-level batching behind the factor-plugin surface (IIF `proposalbeliefs!` / `predictbelief`).
+
+What `solveTree!` (examples/ManhattanDatasetBatch.jl:43) asks of the convolution path is never ONE convolution: a Gibbs step on a
+clique variable calls `proposalbeliefs!(dfg, destlbl, factors, ...)`, i.e. `approxConvBelief` for EVERY factor of the variable, and
+a clique sweep does that for every frontal variable.  `proposalbeliefs` below hands the whole batch to the library in one call
+(`rome_clique_proposals`): every belief crosses PCIe once, one kernel launch per factor family, one synchronisation -- instead of
+three belief blocks and ~45 µs of latency per convolution.  The per-factor path (`approxConv`) and this one draw the same Philox
+streams when asked to (stream = family offset + row), so they agree bit for bit (tests/test_gpu_clique.py).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, api
+from .factors import (Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange, Pose3Pose3, PriorPose3)
+
+FAMILY_STREAM = {"p2p2": 0, "br1": 1 << 28, "br0": 2 << 28, "p3p3": 5 << 28}   # = DeviceGraph.STREAM_* / rome_clique_proposals
+
+
+class CliqueHost(C.Structure):
+    _fields_ = [("n_pose2", C.c_int32), ("n_point2", C.c_int32), ("n_pose3", C.c_int32), ("reserved0", C.c_int32),
+                ("bel_pose2", C.c_void_p), ("bel_point2", C.c_void_p), ("bel_pose3", C.c_void_p),
+                ("n_p2p2", C.c_int32), ("f_p2p2", C.c_int32), ("p2p2_rows4", C.c_void_p), ("p2p2_mu", C.c_void_p), ("p2p2_cov", C.c_void_p),
+                ("out_p2p2", C.c_void_p),
+                ("n_br1", C.c_int32), ("n_br0", C.c_int32), ("f_br", C.c_int32), ("reserved1", C.c_int32),
+                ("br1_rows4", C.c_void_p), ("br0_rows4", C.c_void_p), ("br_mu", C.c_void_p), ("br_sigma", C.c_void_p),
+                ("out_br1", C.c_void_p), ("out_br0", C.c_void_p),
+                ("n_p3p3", C.c_int32), ("f_p3p3", C.c_int32), ("p3p3_rows4", C.c_void_p), ("p3p3_mu", C.c_void_p), ("p3p3_cov", C.c_void_p),
+                ("out_p3p3", C.c_void_p)]
+
+
+class CliqueBatch:
+    """The (factor, target) pairs of a clique as row tables over the clique's own variables.
+
+    pairs: iterable of (factor_label, target_label).  Row r of a family is the r-th pair of that family in the order given;
+    `rows[(flabel, target)] = (family, r)`."""
+
+    def __init__(self, fg, pairs):
+        self.fg, self.N = fg, fg.N
+        self.vars = {Pose2: [], Point2: [], Pose3: []}
+        self.vidx = {}
+        self.rows = {}
+        tabs = {k: dict(rows4=[], fidx={}, mu=[], spread=[]) for k in ("p2p2", "br", "p3p3")}
+        self.fam_rows = {"p2p2": [], "br1": [], "br0": [], "p3p3": []}
+
+        def var(l):
+            if l not in self.vidx:
+                t = fg.variables[l]
+                self.vidx[l] = len(self.vars[t]); self.vars[t].append(l)
+            return self.vidx[l]
+
+        def fac(kind, flabel, mu, spread):
+            tb = tabs[kind]
+            if flabel not in tb["fidx"]:
+                tb["fidx"][flabel] = len(tb["mu"]); tb["mu"].append(np.asarray(mu, float)); tb["spread"].append(np.asarray(spread, float))
+            return tb["fidx"][flabel]
+
+        for flabel, target in pairs:
+            _, labels, f = fg.getFactor(flabel)
+            if target not in labels:
+                raise KeyError("%s is not connected to factor %s" % (target, flabel))
+            if fg.multihypo.get(flabel) is not None:
+                raise NotImplementedError("multihypo factors go through approxConv (per-factor path)")
+            if isinstance(f, (Pose2Pose2, Pose3Pose3)):
+                fam = "p2p2" if isinstance(f, Pose2Pose2) else "p3p3"
+                d = 0 if labels[1] == target else 1
+                other = labels[0] if d == 0 else labels[1]
+                row = (fac(fam, flabel, f.Z.mu, f.Z.cov), d, var(other), var(target))
+            elif isinstance(f, (PriorPose2, PriorPose3)):
+                fam = "p2p2" if isinstance(f, PriorPose2) else "p3p3"
+                row = (fac(fam, flabel, f.Z.mu, f.Z.cov), 2, var(target), var(target))
+            elif isinstance(f, Pose2Point2BearingRange):
+                d = 0 if labels[1] == target else 1
+                fam = "br0" if d == 0 else "br1"
+                other = labels[0] if d == 0 else labels[1]
+                row = (fac("br", flabel, [f.bearing.mu, f.range.mu], [f.bearing.sigma, f.range.sigma]), d, var(other), var(target))
+            else:
+                raise TypeError("factor type %s is outside the hot path" % type(f).__name__)
+            self.rows[(flabel, target)] = (fam, len(self.fam_rows[fam]))
+            self.fam_rows[fam].append(row)
+        self.tabs = tabs
+
+    def beliefs(self, vt):
+        """(n, dim, N) belief blocks of the clique's variables of one type; uninitialised variables start at zero
+        (approxConv's convention: the start point of a root-find with a unique root does not matter)."""
+        ls = self.vars[vt]
+        out = np.zeros((len(ls), vt.dim, self.N))
+        for k, l in enumerate(ls):
+            if self.fg.isInitialized(l):
+                out[k] = self.fg.getVal(l)
+        return out
+
+    def run(self, opts, ctx=None):
+        """-> {family: (rows, dt, N) proposals} through rome_clique_proposals (ONE call)."""
+        ctx = ctx or api.default_context()
+        q = CliqueHost()
+        keep = []
+
+        def ptr(a, dt=np.float64):
+            a = np.ascontiguousarray(a, dtype=dt); keep.append(a)
+            return a.ctypes.data_as(C.c_void_p) if a.size else None
+
+        bel = {vt: self.beliefs(vt) for vt in (Pose2, Point2, Pose3)}
+        q.n_pose2, q.n_point2, q.n_pose3 = (len(self.vars[t]) for t in (Pose2, Point2, Pose3))
+        q.bel_pose2, q.bel_point2, q.bel_pose3 = ptr(bel[Pose2]), ptr(bel[Point2]), ptr(bel[Pose3])
+        out = {}
+        for fam, dt in (("p2p2", 3), ("br1", 3), ("br0", 2), ("p3p3", 6)):
+            out[fam] = np.zeros((len(self.fam_rows[fam]), dt, self.N))
+        t = self.tabs
+        q.n_p2p2, q.f_p2p2 = len(self.fam_rows["p2p2"]), len(t["p2p2"]["mu"])
+        q.p2p2_rows4 = ptr(np.array(self.fam_rows["p2p2"], dtype=np.int32).reshape(-1, 4), np.int32)
+        q.p2p2_mu, q.p2p2_cov = ptr(np.array(t["p2p2"]["mu"]).reshape(-1, 3)), ptr(np.array(t["p2p2"]["spread"]).reshape(-1, 9))
+        q.n_br1, q.n_br0, q.f_br = len(self.fam_rows["br1"]), len(self.fam_rows["br0"]), len(t["br"]["mu"])
+        q.br1_rows4 = ptr(np.array(self.fam_rows["br1"], dtype=np.int32).reshape(-1, 4), np.int32)
+        q.br0_rows4 = ptr(np.array(self.fam_rows["br0"], dtype=np.int32).reshape(-1, 4), np.int32)
+        q.br_mu, q.br_sigma = ptr(np.array(t["br"]["mu"]).reshape(-1, 2)), ptr(np.array(t["br"]["spread"]).reshape(-1, 2))
+        q.n_p3p3, q.f_p3p3 = len(self.fam_rows["p3p3"]), len(t["p3p3"]["mu"])
+        q.p3p3_rows4 = ptr(np.array(self.fam_rows["p3p3"], dtype=np.int32).reshape(-1, 4), np.int32)
+        q.p3p3_mu, q.p3p3_cov = ptr(np.array(t["p3p3"]["mu"]).reshape(-1, 6)), ptr(np.array(t["p3p3"]["spread"]).reshape(-1, 36))
+        q.out_p2p2, q.out_br1, q.out_br0, q.out_p3p3 = (out[f].ctypes.data_as(C.c_void_p) if out[f].size else None
+                                                       for f in ("p2p2", "br1", "br0", "p3p3"))
+        o = _lib.Opts.from_buffer_copy(opts)
+        o.layout = _lib.LAYOUT_SOA
+        _lib.check(_lib.load().rome_clique_proposals(ctx.handle, C.byref(o), C.byref(q)), ctx.handle)
+        return out
+
+
+def proposalbeliefs(fg, destlabels, factor_labels=None, solver=_lib.SOLVER_NEWTON, seed=None, ctx=None, **optkw):
+    """IIF `proposalbeliefs!` for one or several destination variables in ONE library call: the proposal of every factor of
+    every destination (or of `factor_labels` only) -> {(factor_label, dest_label): (dim, N) proposal points}.
+    Row r of a factor family draws Philox stream `stream_offset + FAMILY_STREAM[family] + r` (rows in destination, then factor
+    order), which is what `approxConv(fg, flabel, dest, stream_offset=...)` draws when given that stream."""
+    if isinstance(destlabels, str):
+        destlabels = [destlabels]
+    pairs = []
+    for dest in destlabels:
+        for flabel, labels, _ in fg.factors:
+            if dest in labels and (factor_labels is None or flabel in factor_labels):
+                pairs.append((flabel, dest))
+    batch = CliqueBatch(fg, pairs)
+    opts = api.make_opts(N=fg.N, solver=solver, seed=seed, **optkw)
+    out = batch.run(opts, ctx)
+    return {pair: out[fam][r] for pair, (fam, r) in batch.rows.items()}, batch

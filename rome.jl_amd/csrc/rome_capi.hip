@@ -523,6 +523,126 @@ int rome_sample_priorpose3_dev(rome_ctx* c, const rome_opts* o, const rome_conv_
   return ROME_OK;
 }
 
+/* ---- clique-level batch from host beliefs ---- */
+namespace {
+// one belief array of the clique: [n][dim][N] (SoA), [n][N][dim] (AoS) or native points -> SoA coordinates on the device
+int stage_beliefs(rome_ctx* c, const rome_opts* o, int n, int dim, const double* host, std::vector<double>& tmp, void** dev, size_t* used,
+                  unsigned char* arena, size_t cap) {
+  const int N = o->n_particles;
+  const size_t cnt = (size_t)n * dim * N;
+  *dev = arena + *used;
+  if (n == 0) return ROME_OK;
+  if (*used + cnt * sizeof(double) > cap) return ROME_ERR_ALLOC;
+  const double* src = host;
+  if (o->layout == ROME_LAYOUT_AOS_POINTS && dim != 2) {
+    tmp.resize(cnt);   // points -> AoS coordinates (device conversion kernels), then the transpose below
+    int rc = convert_rows(c, dim, (size_t)n * N, host, tmp.data(), true); if (rc) return rc;
+    std::vector<double> soa(cnt);
+    to_soa(tmp.data(), n, N, dim, ROME_LAYOUT_AOS, soa.data());
+    tmp.swap(soa); src = tmp.data();
+  } else if (o->layout != ROME_LAYOUT_SOA) {
+    tmp.resize(cnt); to_soa(host, n, N, dim, ROME_LAYOUT_AOS, tmp.data()); src = tmp.data();
+  }
+  ROME_HIP(c, hipMemcpyAsync(*dev, src, cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (src != host) ROME_HIP(c, hipStreamSynchronize(c->stream));   // tmp is reused by the caller
+  *used += (cnt * sizeof(double) + 255) & ~(size_t)255;
+  return ROME_OK;
+}
+}  // namespace
+
+int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_host* q) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || !q) return ROME_ERR_INVALID_ARG;
+  const int N = o->n_particles;
+  struct Fam { int n; const int32_t* rows4; int F; const double* mu; const double* spread; int dz, nL, dfx, dt; double* out; int vf, vt; int dir_all; uint64_t off; int kind; };
+  // variable types: 0 Pose2, 1 Point2, 2 Pose3
+  Fam fam[4] = {
+    {q->n_p2p2, q->p2p2_rows4, q->f_p2p2, q->p2p2_mu, q->p2p2_cov, 3, 6, 3, 3, q->out_p2p2, 0, 0, 0, 0ull, 0},
+    {q->n_br1, q->br1_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 2, 3, q->out_br1, 1, 0, 1, 1ull << 28, 1},
+    {q->n_br0, q->br0_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 3, 2, q->out_br0, 0, 1, 0, 2ull << 28, 1},
+    {q->n_p3p3, q->p3p3_rows4, q->f_p3p3, q->p3p3_mu, q->p3p3_cov, 6, 21, 6, 6, q->out_p3p3, 2, 2, 0, 5ull << 28, 2}};
+  const int nv[3] = {q->n_pose2, q->n_point2, q->n_pose3};
+  const int vdim[3] = {3, 2, 6};
+  const double* vhost[3] = {q->bel_pose2, q->bel_point2, q->bel_pose3};
+  size_t need = 0;
+  for (int t = 0; t < 3; ++t) { if (nv[t] < 0 || (nv[t] > 0 && !vhost[t])) return ROME_ERR_INVALID_ARG; need += (((size_t)nv[t] * vdim[t] * N * 8) + 255) & ~(size_t)255; }
+  for (const Fam& f : fam) {
+    if (f.n < 0 || f.F < 0 || (f.n > 0 && (!f.rows4 || !f.mu || !f.spread || !f.out || f.F == 0))) return ROME_ERR_INVALID_ARG;
+    for (int r = 0; r < f.n; ++r) {   // table entries must address the clique's own arrays
+      const int32_t* e = f.rows4 + 4 * (size_t)r;
+      if (e[0] < 0 || e[0] >= f.F || e[2] < 0 || e[2] >= nv[f.vf] || e[3] < 0 || e[3] >= nv[f.vt] || e[1] < 0 || e[1] > 2) return ROME_ERR_INVALID_ARG;
+    }
+    need += (((size_t)f.n * f.dt * N * 8) + 255) & ~(size_t)255;             // proposals
+    need += (((size_t)f.n * 16) + 255) & ~(size_t)255;                       // rows4
+    need += (((size_t)f.F * (f.dz + f.nL) * 8) + 511) & ~(size_t)255;        // mu + L
+  }
+  ROME_BIND(c);
+  void* arena_v = nullptr;
+  if ((rc = ensure(c, 9, need + 4096, &arena_v))) return rc;
+  unsigned char* arena = (unsigned char*)arena_v;
+  size_t used = 0;
+  const size_t cap = need + 4096;
+  std::vector<double> tmp;
+  void* dbel[3];
+  for (int t = 0; t < 3; ++t) if ((rc = stage_beliefs(c, o, nv[t], vdim[t], vhost[t], tmp, &dbel[t], &used, arena, cap))) return rc;
+  hipStream_t s = c->stream;
+  std::vector<std::vector<double>> Ls(4);
+  double* dout[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int k = 0; k < 4; ++k) {
+    const Fam& f = fam[k];
+    if (f.n == 0) continue;
+    const double* Lsrc = f.spread;
+    if (f.kind != 1) {   // MvNormal factors: packed lower Cholesky of every covariance
+      Ls[k].resize((size_t)f.F * f.nL);
+      if ((rc = rome_cholesky_lower(f.dz, f.F, f.spread, Ls[k].data()))) return rc;
+      Lsrc = Ls[k].data();
+    }
+    auto put = [&](const void* src, size_t bytes, void** dst) -> int {
+      *dst = arena + used;
+      ROME_HIP(c, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
+      used += (bytes + 255) & ~(size_t)255;
+      return ROME_OK;
+    };
+    void *d_rows, *d_mu, *d_L;
+    if ((rc = put(f.rows4, (size_t)f.n * 16, &d_rows))) return rc;
+    if ((rc = put(f.mu, (size_t)f.F * f.dz * 8, &d_mu))) return rc;
+    if ((rc = put(Lsrc, (size_t)f.F * f.nL * 8, &d_L))) return rc;
+    dout[k] = (double*)(arena + used);
+    used += (((size_t)f.n * f.dt * N * 8) + 255) & ~(size_t)255;
+    rome::ConvArgs a;
+    rome_opts of = *o; of.stream_offset = o->stream_offset + f.off;   // family offsets of the device graph (DeviceGraph.STREAM_*)
+    fill_args(a, &of);
+    a.n_conv = f.n; a.dir_all = f.dir_all; a.rows4 = (const int32_t*)d_rows;
+    a.mu = (const double*)d_mu; a.L = (const double*)d_L;
+    a.bel_fixed = (const double*)dbel[f.vf]; a.bel_target = (const double*)dbel[f.vt]; a.out = dout[k];
+    hipError_t e = f.kind == 0 ? rome::launch_conv_pose2pose2(a, o->solver, s) : (f.kind == 1 ? rome::launch_conv_bearingrange(a, o->solver, s)
+                                                                                            : rome::launch_conv_pose3pose3(a, o->solver, s));
+    ROME_HIP(c, e);
+  }
+  // proposals back to the host in the caller's layout
+  std::vector<std::vector<double>> hout(4);
+  for (int k = 0; k < 4; ++k) {
+    const Fam& f = fam[k];
+    if (f.n == 0) continue;
+    const size_t cnt = (size_t)f.n * f.dt * N;
+    if (o->layout == ROME_LAYOUT_SOA) ROME_HIP(c, hipMemcpyAsync(f.out, dout[k], cnt * 8, hipMemcpyDeviceToHost, s));
+    else { hout[k].resize(cnt); ROME_HIP(c, hipMemcpyAsync(hout[k].data(), dout[k], cnt * 8, hipMemcpyDeviceToHost, s)); }
+  }
+  ROME_HIP(c, hipStreamSynchronize(s));
+  if (o->layout != ROME_LAYOUT_SOA)
+    for (int k = 0; k < 4; ++k) {
+      const Fam& f = fam[k];
+      if (f.n == 0) continue;
+      if (o->layout == ROME_LAYOUT_AOS || f.dt == 2) from_soa(hout[k].data(), f.n, N, f.dt, ROME_LAYOUT_AOS, f.out);
+      else {
+        std::vector<double> aos(hout[k].size());
+        from_soa(hout[k].data(), f.n, N, f.dt, ROME_LAYOUT_AOS, aos.data());
+        if ((rc = convert_rows(c, f.dt, (size_t)f.n * N, aos.data(), f.out, false))) return rc;
+      }
+    }
+  return ROME_OK;
+}
+
 /* ---- native point containers <-> coordinates ---- */
 int rome_points_to_coords(rome_ctx* c, int32_t dim, int32_t n, const double* pts, double* coords) {
   if (!c || n < 0 || (dim != 2 && dim != 3 && dim != 6) || (n > 0 && (!pts || !coords))) return ROME_ERR_INVALID_ARG;
