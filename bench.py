@@ -374,13 +374,25 @@ def cpu_baseline(R, pk, fg, N, budget_s):
         return {"value": None, "unit": "convolutions/s", "kind": "port", "error": p.stderr[-800:]}
     r = json.loads(p.stdout.strip().splitlines()[-1])
     nm = r["best"]["nelder_mead"]
+    # the reference itself: bench/ref_conv.jl times IIF's approxConvBelief iff a Julia with RoME/IIF exists here
+    import shutil
+    julia = shutil.which("julia")
+    if julia:
+        try:
+            jp = subprocess.run([julia, os.path.join(ROOT, "bench", "ref_conv.jl")], capture_output=True, text=True, timeout=900,
+                                env=dict(os.environ, JULIA_NUM_THREADS=str(nm["threads"])))
+            jref = json.loads(jp.stdout.strip().splitlines()[-1]) if jp.returncode == 0 else {"error": jp.stderr[-400:]}
+        except Exception as e:   # noqa: BLE001
+            jref = {"error": repr(e)}
+    else:
+        jref = "julia reference not runnable on this box (no julia on PATH; bench/ref_conv.jl is the provided script)"
     return {"value": nm["conv_per_s"], "unit": "convolutions/s", "cores": nm["threads"], "kind": "port",
             "algorithm": "Optim.jl-default Nelder-Mead per particle (reference algorithm), inflate_cycles=3",
             "sample": "first %d of %d (factor,direction) convolutions of the same graph, N=%d, median of %d runs of %.2f s"
                       % (nm["sample_convolutions"], len(factor), N, nm["reps"], nm["median_s"]),
             "flags": r["flags"], "omp": r["omp"], "host": r["host"],
             "one_thread_conv_per_s": nm["one_thread_conv_per_s"], "parallel_efficiency": nm["parallel_efficiency"],
-            "by_solver": r["best"], "runs": r["runs"]}
+            "by_solver": r["best"], "runs": r["runs"], "julia_reference": jref}
 
 
 if __name__ == "__main__":
