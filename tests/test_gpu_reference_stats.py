@@ -111,3 +111,28 @@ def test_bearingrange_sampling_windows():
         b, rho = np.arctan2(out[1], out[0]), np.hypot(out[0], out[1])
         assert abs(b.mean()) < 0.1 and 0.05 < b.std(ddof=1) < 0.2
         assert abs(rho.mean() - 20.0) < 1.0 and 0.5 < rho.std(ddof=1) < 1.5
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+def test_pose_from_landmark_from_a_degenerate_start_spreads_around_the_ring(solver):
+    """IIF calcStdBasicSpread: "if no std yet, set to 1" -- approxConv / initVariable start an uninitialised target from identical
+    points.  For the bearing-range POSE direction (2 equations, 3 unknowns: a ring of roots around the landmark) the jitter of that
+    start decides where on the ring a particle lands: without the fallback every particle would sit on the one ray through the
+    common start point.  The jitter here is the full-width (32-bit) uniform of the oracle, not the cheap one of the unique-root
+    kernels; device == oracle, the ring is covered over a wide arc, and the result is independent of N's slot packing."""
+    import oracle as ro
+    N = 100
+    lm = np.array([[10.0], [0.0]]) + 0.05 * np.random.default_rng(1).standard_normal((2, N))
+    o = R.make_opts(N=N, solver=solver, seed=12)
+    out = R.conv_pose2point2br(o, 1, [[0.3, 10.0]], [[0.03, 0.5]], lm[None], np.zeros((1, 3, N)))[0]
+    ref = ro.conv_pose2point2br(ro.make_opts(N=N, solver=solver, seed=12), 1, [[0.3, 10.0]], [[0.03, 0.5]], lm[None], np.zeros((1, 3, N)), [0], [0])[0]
+    d = out - ref; d[2] = np.arctan2(np.sin(d[2]), np.cos(d[2]))
+    assert np.median(np.abs(d)) < 1e-8 and (np.abs(d).max(axis=0) < 1e-5).mean() > 0.95
+    ang = np.arctan2(out[1] - lm[1], out[0] - lm[0])           # where on the ring around the landmark
+    rng_ = np.hypot(out[0] - lm[0], out[1] - lm[1])
+    assert np.abs(rng_ - 10.0).max() < 2.5                     # on the ring (sigma_rho = 0.5)
+    spread = np.sqrt(-2 * np.log(np.hypot(np.cos(ang).mean(), np.sin(ang).mean())))   # circular std
+    assert spread > 0.35, spread                               # a wide arc, not one ray (collapsed: < 0.01)
+    # the measured bearing holds at every root of the ring
+    b = np.arctan2(lm[1] - out[1], lm[0] - out[0]) - out[2]
+    assert np.abs(np.arctan2(np.sin(b - 0.3), np.cos(b - 0.3))).max() < 0.2
