@@ -174,6 +174,30 @@ __device__ __forceinline__ void lcv_eval32(const f32x2 xi, const bool act0, cons
   *g = v[1] - (double)N * h * h;
 }
 
+// g(h) = Σ_i T_i/S_i − N h² in double precision (row sums over the double-precision particles in LDS, j = i skipped): ONE such
+// evaluation polishes the single-precision secant result -- for a flat likelihood the single-precision zero of g is only good to
+// ~1e-4, the slope is not the problem
+template <bool CIRC>
+__device__ __forceinline__ double lcv_g64(const double (&x)[2], const bool (&act)[2], const double* __restrict__ pts, int N, int lane, double h) {
+  const double a = -0.5 / (h * h);
+  double S[2] = {0.0, 0.0}, T[2] = {0.0, 0.0};
+  for (int j = 0; j < N; ++j) {
+    const double xj = pts[j];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      double d = x[s] - xj;
+      if (CIRC) d = lcv_wrap(d);
+      const double d2 = d * d;
+      const double w = (lane + 64 * s == j) ? 0.0 : fast_exp_neg(a * d2);
+      S[s] += w; T[s] = fma(w, d2, T[s]);
+    }
+  }
+  double gg = 0.0;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) if (act[s]) gg += T[s] / fmax(S[s], 1e-300);
+  return wave_sum(gg) - (double)N * h * h;
+}
+
 template <bool CIRC>
 __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bool (&act)[2], const double* __restrict__ pts,
                                                   float* __restrict__ p32d, double* __restrict__ wbuf, int N, int lane, double tol, int* n_evals) {
@@ -246,6 +270,12 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
       ha = hb; ga = gb; hb = hc; gb = gc;
       best = hc;
       if (done) break;
+    }
+    if (best == hb && fabs(gb - ga) > 0.0 && hb != ha) {   // one Newton step with the double-precision value of g and the secant slope
+      const double g64 = lcv_g64<CIRC>(x, act, pts, N, lane, hb);
+      const double hn = hb - g64 * (hb - ha) / (gb - ga);
+      ++ne;
+      if (hn > lo && hn < hi && fabs(hn - hb) < 1e-2 * hb) best = hn;
     }
   }
   *n_evals = ne;
