@@ -312,7 +312,7 @@ def main():
             dg.conv_step(o3, s); dg.product_step(o3, s)
         torch.cuda.synchronize()
         out["solve_loop"] = {"ms_per_iteration": (time.perf_counter() - a) * 1e3 / 50,
-                             "what": "conv sweep + proposal product of all %d variables (stand-in for the clique Gibbs of solveTree!, no Bayes tree)" % len(pk.labels[R.Pose2])}
+                             "what": "conv sweep + importance-sampling product (round-1 stand-in, in-kernel Silverman bandwidths) of all %d variables" % len(pk.labels[R.Pose2])}
         # the same iteration with the reference's bandwidth rule: leave-one-out likelihood bandwidths of every proposal (manikde!) first
         dg.conv_step(o3, 0); dg.product_step(o3, 0, "lcv"); torch.cuda.synchronize()
         a = time.perf_counter()
@@ -320,6 +320,15 @@ def main():
             dg.conv_step(o3, s); dg.product_step(o3, s, "lcv")
         torch.cuda.synchronize()
         out["solve_loop"]["ms_per_iteration_lcv_bandwidths"] = (time.perf_counter() - a) * 1e3 / 5
+        dg.bel[R.Pose2].copy_(saved)
+        # ... and with the reference's own product as well: manikde! bandwidths + multiscale Gibbs product (AMP manifoldProduct)
+        dg.conv_step(o3, 0); dg.product_step(o3, 0, "lcv", "gibbs"); torch.cuda.synchronize()
+        a = time.perf_counter()
+        for s in range(5):
+            dg.conv_step(o3, s); dg.product_step(o3, s, "lcv", "gibbs")
+        torch.cuda.synchronize()
+        out["solve_loop"]["ms_per_iteration_reference_product"] = (time.perf_counter() - a) * 1e3 / 5
+        out["solve_loop"]["what_reference_product"] = "conv sweep + manikde! bandwidths of all proposals + multiscale Gibbs product (manifoldProduct restated) of all variables; whole-graph Jacobi schedule, no Bayes tree"
         dg.bel[R.Pose2].copy_(saved)
         # ... and the whole pipeline a user runs on this graph: parametric solve (batched Jacobian kernel + sparse LM on the host)
         # followed by 10 non-parametric iterations started from it
