@@ -191,7 +191,9 @@ def main():
     # launch plan binds the rome_ctx to) inside the timed region.  An event is a barrier packet in the queue (≈ 5 µs of
     # dispatch gap each on this stack), so they are recorded every `stride` launches, not around every launch:
     # consecutive events bracket `stride` back-to-back launches of the dominant kernel [+ the separator exchange when N>1].
-    stride = max(1, args.steps // 20)
+    # (short runs -- the driver's --steps 20 -- bracket the whole timed region with two events only: 21 events around 20 launches would
+    #  add their own dispatch gaps to the period they measure)
+    stride = max(1, args.steps // 20) if args.steps >= 200 else args.steps
     marks = list(range(0, args.steps, stride))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(marks) + 1)]
     barrier()

@@ -572,6 +572,9 @@ struct P3P3 {
 #ifndef ROME_MIN_WAVES
 #define ROME_MIN_WAVES 1
 #endif
+#ifndef ROME_NM_MINWAVES
+#define ROME_NM_MINWAVES 4
+#endif
 // LEAN: the plain sweep -- in-kernel noise, all four table columns present, no multihypo / nullhypo rows.  The same code with
 // those features compiled out: the table row is four scalar loads issued together, nothing stands between the belief loads
 // and the Philox / Box-Muller block (which then runs under the load latency), and the register allocation is not pinned by
@@ -583,7 +586,7 @@ template <class FP, int SOLVER, int PPL, bool LEAN>
 // Nelder-Mead on the 2-D/3-D factors is latency-bound (long dependent select/compare chains): asking for 4 waves/SIMD
 // (<= 128 VGPRs) is 5 % faster there; the Newton / closed-form kernels are issue-bound and lose 5-40 % when capped.
 // (the SE(3) kernels need their 256 VGPRs: capped at 3-4 waves/SIMD they spill and run 2.7x slower)
-__global__ void __launch_bounds__(64 * ROME_WPB, (SOLVER == kSolverNelderMead && FP::DT <= 3) ? 4 : ((SOLVER != kSolverNelderMead && FP::DT == 6) ? ROME_P3_MINBLK : ROME_MIN_WAVES))
+__global__ void __launch_bounds__(64 * ROME_WPB, (SOLVER == kSolverNelderMead && FP::DT <= 3) ? ROME_NM_MINWAVES : ((SOLVER != kSolverNelderMead && FP::DT == 6) ? ROME_P3_MINBLK : ROME_MIN_WAVES))
 k_conv(const ConvArgs a) {
   const int lane = threadIdx.x & 63;
   // no early exit: the (at most ROME_WPB - 1) surplus waves of the last block redo the last row and skip its stores, so that
