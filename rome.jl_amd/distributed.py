@@ -345,6 +345,50 @@ class TargetShardedSweep:
         self.plan()
         self.exchange()
 
+    def solve_step(self, opts, sweep=0, gibbs_iters=1):
+        """One strong-scaled SOLVE iteration with the reference's operations: sweep of the owned rows, `manikde!` bandwidths of
+        those proposals, multiscale Gibbs product (manifoldProduct) of the owned variables -- whose proposals are a contiguous
+        row range of the target-sorted table -- then the all-gather of the owned beliefs.  Everything but the final exchange is
+        rank-local; bandwidths and product (5.7 of the 5.9 ms of a Manhattan iteration) shard perfectly."""
+        import ctypes as C
+        from . import _lib
+        dg, torch = self.dg, self.dg.torch
+        self.wait()
+        if not hasattr(self, "_solve"):
+            dev = self.store.device
+            n, d = self.prop.shape[0], self.store.shape[1]
+            self._solve = dict(bw=torch.zeros((max(n, 1), d), dtype=self.store.dtype, device=dev),
+                               ptr=torch.as_tensor(self.ptr.astype(np.int32), device=dev),
+                               rows=torch.arange(max(n, 1), dtype=torch.int32, device=dev),
+                               out=torch.zeros_like(self.mine),
+                               max_k=int(max(1, np.diff(self.ptr).max())))
+        S = self._solve
+        d, N = self.store.shape[1], self.store.shape[2]
+        circ = 0b100 if d == 3 else 0
+        lib, h = dg._lib, dg.ctx.handle
+        dg._bind_stream()
+        o = type(opts).from_buffer_copy(opts)
+        o.stream_offset = opts.stream_offset + (sweep << 32) + self.row_lo
+        lo_v, q = self.rank * self.q, self.q
+        if self.n_rows:
+            # the sweep of the owned rows with this iteration's Philox streams
+            self._sweep_plan(o)()
+            _lib.check(lib.rome_kde_bandwidth_dev(h, d, self.n_rows, N, self.prop[self.row_lo:self.row_hi].data_ptr(), circ, 0.0, 0.0,
+                                                  S["bw"][self.row_lo:self.row_hi].data_ptr()), h)
+        op = type(opts).from_buffer_copy(opts)
+        op.stream_offset = opts.stream_offset + (sweep << 32) + dg.STREAM_PROD2 + lo_v      # product stream = global variable id
+        # CSR of the owned variables: ptr entries are absolute rows of the sorted table; only rows [row_lo, row_hi) are read
+        _lib.check(lib.rome_product_gibbs_dev(h, C.byref(op), d, q, S["ptr"][lo_v:lo_v + q + 1].data_ptr(), S["rows"].data_ptr(),
+                                              self.prop.data_ptr(), S["bw"].data_ptr(), self.prop.shape[0], self.mine.data_ptr(),
+                                              S["out"].data_ptr(), circ, int(gibbs_iters), S["max_k"]), h)
+        self.mine.copy_(S["out"])
+        self.exchange()
+
+    def _sweep_plan(self, o):
+        tb = self.dg.family_table(self.family)
+        return self.dg._plan(tb["fn"], o, n_conv=self.n_rows, dir_all=tb["dir_all"], rows4=self.rows4[self.row_lo:self.row_hi], mu=tb["mu"], L=tb["L"],
+                             bel_fixed=self.store, bel_target=self.store, out=self.prop[self.row_lo:self.row_hi])
+
     def exchange(self):
         if not self.collective:
             return
