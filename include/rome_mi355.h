@@ -63,6 +63,7 @@ enum {
 enum { ROME_SOLVER_CLOSED_FORM = 0, ROME_SOLVER_NEWTON = 1, ROME_SOLVER_NELDER_MEAD = 2 };
 enum { ROME_LAYOUT_SOA = 0, ROME_LAYOUT_AOS = 1, ROME_LAYOUT_AOS_POINTS = 2 };
 enum { ROME_DIR_TO = 0, ROME_DIR_FROM = 1, ROME_DIR_PRIOR = 2 };
+enum { ROME_NOISE_STANDARD_NORMALS = 0, ROME_NOISE_MEASUREMENTS = 1 };
 
 /* Mirrors the IIF SolverParams fields that reach this path (N, inflateCycles, inflation). */
 typedef struct rome_opts {
@@ -75,7 +76,12 @@ typedef struct rome_opts {
   uint64_t seed;          /* Philox4x32-10 key                                                         */
   uint64_t stream_offset; /* Philox stream of convolution c = stream_offset + c  (global conv id when sharded) */
   int32_t layout;         /* host-pointer entry points only: ROME_LAYOUT_*                             */
-  int32_t reserved;
+  int32_t presampled;     /* meaning of the `noise` argument / field when it is given:
+                           *   ROME_NOISE_STANDARD_NORMALS (0): ξ ~ N(0, I), the library forms z = μ + Lξ (bearing-range: μ + σ ξ);
+                           *   ROME_NOISE_MEASUREMENTS (1): the rows ARE the measurement samples z (tangent coordinates of the
+                           *   factor's `getSample`): any `SamplableBelief` -- Rayleigh, mixtures, AliasingScalarSampler, a KDE --
+                           *   sampled by the caller (`Pose2Point2BearingRange{B,R}` is generic in B and R,
+                           *   src/factors/BearingRange2D.jl:10-27); mu / cov / sigma are then unused                       */
   double  spread_nh;      /* IIF spreadNH (default 3.0): entropy scale for particles of the other hypothesis (multihypo) */
   double  nullhypo;       /* host-pointer entry points only: IIF nullhypo= probability applied to every row of the call */
 } rome_opts;
@@ -88,6 +94,8 @@ int  rome_last_hip_error(const rome_ctx* ctx); /* raw hipError_t of the last fai
 const char* rome_last_hip_error_string(const rome_ctx* ctx);
 
 void rome_opts_default(rome_opts* o, int32_t solver);
+/* (SURVEY §8(b) sketched `device = -1 -> CPU oracle`: deliberately NOT provided -- the library has no CPU path of any kind; without a
+ * HIP device rome_ctx_create returns ROME_ERR_NO_DEVICE) */
 int  rome_ctx_create(rome_ctx** out, int device);
 void rome_ctx_destroy(rome_ctx* ctx);
 int  rome_ctx_set_stream(rome_ctx* ctx, void* hip_stream); /* launch on a caller-owned hipStream_t; NULL = HIP's default (null) stream */

@@ -12,6 +12,7 @@ SO = os.environ.get("ROME_MI355_LIB") or os.path.join(HERE, "librome_mi355.so") 
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED_N, ERR_ALLOC = -1, -2, -3, -4, -5, -6
 SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD = 0, 1, 2
+NOISE_STANDARD_NORMALS, NOISE_MEASUREMENTS = 0, 1
 LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS = 0, 1, 2
 MAX_PARTICLES = 512
 FACTOR_PRIORPOSE2, FACTOR_POSE2POSE2, FACTOR_POSE2POINT2BR, FACTOR_PRIORPOINT2, FACTOR_POSE3POSE3, FACTOR_PRIORPOSE3 = range(6)
@@ -27,7 +28,7 @@ class Opts(C.Structure):
     _fields_ = [("n_particles", C.c_int32), ("solver", C.c_int32), ("max_iters", C.c_int32),
                 ("inflate_cycles", C.c_int32), ("tol", C.c_double), ("inflation", C.c_double),
                 ("seed", C.c_uint64), ("stream_offset", C.c_uint64), ("layout", C.c_int32),
-                ("reserved", C.c_int32), ("spread_nh", C.c_double), ("nullhypo", C.c_double)]
+                ("presampled", C.c_int32), ("spread_nh", C.c_double), ("nullhypo", C.c_double)]
 
 
 class ConvDev(C.Structure):

@@ -237,10 +237,12 @@ def cholesky_lower(cov):
 
 
 def make_opts(N=100, solver=_lib.SOLVER_NEWTON, max_iters=None, inflate_cycles=None, tol=None, inflation=None,
-              seed=None, stream_offset=None, layout=None, spread_nh=None, nullhypo=None):
+              seed=None, stream_offset=None, layout=None, spread_nh=None, nullhypo=None, presampled=None):
+    """presampled=1 (NOISE_MEASUREMENTS): the `noise` argument of the conv_* calls holds the measurement samples themselves
+    (any SamplableBelief sampled by the caller) instead of standard normals."""
     return _lib.default_opts(solver, n_particles=N, max_iters=max_iters, inflate_cycles=inflate_cycles, tol=tol,
                              inflation=inflation, seed=seed, stream_offset=stream_offset, layout=layout,
-                             spread_nh=spread_nh, nullhypo=nullhypo)
+                             spread_nh=spread_nh, nullhypo=nullhypo, presampled=presampled)
 
 
 def _blocks(a, C_, N, d, layout, points_ok=True):

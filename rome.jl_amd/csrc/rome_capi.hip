@@ -79,6 +79,7 @@ int check_opts(const rome_opts* o) {
   if (!(o->tol >= 0.0) || !(o->inflation >= 0.0) || !(o->spread_nh >= 0.0)) return ROME_ERR_INVALID_ARG;
   if (!(o->nullhypo >= 0.0 && o->nullhypo <= 1.0)) return ROME_ERR_INVALID_ARG;
   if (o->layout != ROME_LAYOUT_SOA && o->layout != ROME_LAYOUT_AOS && o->layout != ROME_LAYOUT_AOS_POINTS) return ROME_ERR_INVALID_ARG;
+  if (o->presampled != ROME_NOISE_STANDARD_NORMALS && o->presampled != ROME_NOISE_MEASUREMENTS) return ROME_ERR_INVALID_ARG;
   return ROME_OK;
 }
 
@@ -94,6 +95,7 @@ void fill_args(rome::ConvArgs& a, const rome_opts* o) {
   a.seed = o->seed;
   a.stream_offset = o->stream_offset;
   a.spread_nh = o->spread_nh;
+  a.noise_is_meas = o->presampled == ROME_NOISE_MEASUREMENTS;
 }
 
 void args_from_dev(rome::ConvArgs& a, const rome_opts* o, const rome_conv_dev* t) {

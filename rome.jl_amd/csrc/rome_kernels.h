@@ -21,7 +21,8 @@ struct ConvArgs {
   const double* L;            // [F][dz(dz+1)/2] row-packed lower Cholesky of Σ  (bearing-range: [F][2] sigmas)
   const double* bel_fixed;
   const double* bel_target;
-  const double* noise;        // [C][dz][N] standard normals, or nullptr -> in-kernel Philox
+  const double* noise;        // [C][dz][N] standard normals (or, noise_is_meas: the measurement samples themselves), or nullptr -> in-kernel Philox
+  int noise_is_meas;
   double* out;                // [C][dt][N]
   int32_t* status;            // [C][N] or nullptr
   const int32_t* alt_var;     // [C] bearing-range multihypo: the other landmark candidate (-1: single hypothesis), or nullptr

@@ -646,7 +646,10 @@ k_conv(const ConvArgs a) {
     } else {
       rng_normals<FP::DZ>(a.seed, stream, (uint32_t)ii, xi);
     }
-    FP::measurement(K, xi, z[k]);
+    if (!LEAN && a.noise && a.noise_is_meas) {   // the caller sampled the measurement model itself (any SamplableBelief)
+#pragma unroll
+      for (int d = 0; d < FP::DZ; ++d) z[k][d] = xi[d];
+    } else FP::measurement(K, xi, z[k]);
   }
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {

@@ -26,7 +26,7 @@ struct RomeOpts
   seed::UInt64
   stream_offset::UInt64
   layout::Int32          # 0 SoA [block][dim][N], 1 AoS [block][N][dim], 2 AoS of the reference's point containers
-  reserved::Int32
+  presampled::Int32      # 0: `noise` rows are standard normals; 1: they are the measurement samples themselves (any SamplableBelief)
   spread_nh::Float64     # IIF spreadNH
   nullhypo::Float64      # IIF nullhypo= of the factor(s) in the call
 end

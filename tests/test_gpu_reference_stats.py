@@ -136,3 +136,33 @@ def test_pose_from_landmark_from_a_degenerate_start_spreads_around_the_ring(solv
     # the measured bearing holds at every root of the ring
     b = np.arctan2(lm[1] - out[1], lm[0] - out[0]) - out[2]
     assert np.abs(np.arctan2(np.sin(b - 0.3), np.cos(b - 0.3))).max() < 0.2
+
+
+def test_generic_measurement_beliefs_through_presampled_measurements():
+    """`Pose2Point2BearingRange{B<:SamplableBelief, R<:SamplableBelief}` (src/factors/BearingRange2D.jl:10-27) is generic in its
+    bearing and range beliefs; `getSample` just draws from them.  Any such belief is served by handing the library the N measurement
+    samples themselves (opts.presampled = ROME_NOISE_MEASUREMENTS): here a Rayleigh range and a two-component mixture bearing.
+    Closed form = the exact landmark of every sampled measurement; Newton and Nelder-Mead agree with it; Pose2Pose2 likewise with a
+    heavy-tailed (Student-t) odometry sample."""
+    rng = np.random.default_rng(8)
+    N, C_ = 100, 3
+    b = np.where(rng.random((C_, N)) < 0.5, rng.normal(-0.4, 0.02, (C_, N)), rng.normal(0.6, 0.05, (C_, N)))   # mixture bearing
+    rho = rng.rayleigh(8.0, (C_, N)) + 2.0                                                                        # Rayleigh range
+    z = np.stack([b, rho], axis=1)                                                                                # (C, 2, N)
+    pose = rng.normal(0, 1, (C_, 3, N)); pose[:, 2] *= 0.3
+    want = np.stack([pose[:, 0] + rho * np.cos(pose[:, 2] + b), pose[:, 1] + rho * np.sin(pose[:, 2] + b)], axis=1)
+    for solver, tol in ((0, 1e-10), (1, 1e-9), (2, 2e-2)):
+        o = R.make_opts(N=N, solver=solver, seed=3, presampled=1)
+        got = R.conv_pose2point2br(o, 0, np.zeros((C_, 2)), np.ones((C_, 2)), pose, np.zeros((C_, 2, N)), noise=z)
+        err = np.abs(got - want)
+        assert np.median(err) < tol and (err.max() < tol or solver == 2), (solver, err.max())
+    # Pose2Pose2 with Student-t odometry samples: dir 0 root = p ∘ exp(z)
+    zt = np.stack([10 + 0.1 * rng.standard_t(3, (C_, N)), 0.1 * rng.standard_t(3, (C_, N)), np.pi / 3 + 0.02 * rng.standard_t(3, (C_, N))], axis=1)
+    o = R.make_opts(N=N, solver=1, seed=3, presampled=1)
+    got = R.conv_pose2pose2(o, np.zeros((C_, 3)), np.tile(np.eye(3), (C_, 1, 1)), pose, np.zeros((C_, 3, N)), dirs=[0] * C_, noise=zt)
+    c, s = np.cos(pose[:, 2]), np.sin(pose[:, 2])
+    want = np.stack([pose[:, 0] + c * zt[:, 0] - s * zt[:, 1], pose[:, 1] + s * zt[:, 0] + c * zt[:, 1], pose[:, 2] + zt[:, 2]], axis=1)
+    d = got - want; d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    assert np.abs(d).max() < 1e-9
+    with pytest.raises(Exception):
+        R.conv_pose2pose2(R.make_opts(N=N, presampled=7), np.zeros((1, 3)), np.eye(3)[None], pose[:1], np.zeros((1, 3, N)), dirs=[0])
