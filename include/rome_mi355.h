@@ -51,7 +51,9 @@ enum {
   ROME_ERR_ALLOC = -6
 };
 
-#define ROME_MAX_PARTICLES 512
+#define ROME_MAX_PARTICLES 4096   /* convolutions / prior sampling: N <= 512 lives in registers, larger N is walked in chunks of 128;
+                                    the KDE and importance-product entries take N <= 512, the Gibbs product N <= 128 */
+#define ROME_MAX_PARTICLES_REGISTER 512
 
 /* Solvers for the per-particle root-find (replaces Optim.optimize(cost, X0c, NelderMead()) in IIF
  * `_solveLambdaNumeric`, called for every particle of every convolution):

@@ -733,7 +733,7 @@ int rome_belief_stats(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const doub
   return ROME_OK;
 }
 static int check_kde(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, const double* bw) {
-  if (!c || V < 0 || N < 2 || N > ROME_MAX_PARTICLES || dim < 1 || dim > 6 || (V > 0 && (!bel || !bw))) return ROME_ERR_INVALID_ARG;
+  if (!c || V < 0 || N < 2 || N > ROME_MAX_PARTICLES_REGISTER || dim < 1 || dim > 6 || (V > 0 && (!bel || !bw))) return ROME_ERR_INVALID_ARG;
   return ROME_OK;
 }
 int rome_kde_bandwidth_dev(rome_ctx* c, int32_t dim, int32_t V, int32_t N, const double* bel, uint32_t circular_mask,

@@ -138,6 +138,12 @@ struct P2P2 {
   struct Aux {};
   __device__ static __forceinline__ Aux init_aux(const double (&)[3]) { return Aux{}; }
   __device__ static __forceinline__ void finalize(double (&)[3], const Aux&) {}
+  // tangent coordinates of a point about the belief's particle 0 (the spread statistic, chunk by chunk: k_conv_big)
+  struct Ref { double c[3]; };
+  __device__ static __forceinline__ Ref make_ref(const double (&t0)[3], const Aux&) { return Ref{{t0[0], t0[1], t0[2]}}; }
+  __device__ static __forceinline__ void tangent(const Ref& r, const double (&t)[3], const Aux&, double (&d)[3]) {
+    d[0] = t[0] - r.c[0]; d[1] = t[1] - r.c[1]; d[2] = wrap_pi(t[2] - r.c[2]);
+  }
   template <int PPL>
   __device__ static __forceinline__ double spread(const double (&t)[PPL][3], const Aux (&)[PPL], const bool (&act)[PPL], double inv, double den) {
     return spread_se2<PPL>(t, act, inv, den);
@@ -265,6 +271,17 @@ struct BR {
   struct Aux {};
   __device__ static __forceinline__ Aux init_aux(const double (&)[DT]) { return Aux{}; }
   __device__ static __forceinline__ void finalize(double (&)[DT], const Aux&) {}
+  struct Ref { double c[DT]; };
+  __device__ static __forceinline__ Ref make_ref(const double (&t0)[DT], const Aux&) {
+    Ref r;
+#pragma unroll
+    for (int k = 0; k < DT; ++k) r.c[k] = t0[k];
+    return r;
+  }
+  __device__ static __forceinline__ void tangent(const Ref& r, const double (&t)[DT], const Aux&, double (&d)[DT]) {
+    d[0] = t[0] - r.c[0]; d[1] = t[1] - r.c[1];
+    if constexpr (DT == 3) d[2] = wrap_pi(t[2] - r.c[2]);
+  }
   template <int PPL>
   __device__ static __forceinline__ double spread(const double (&t)[PPL][DT], const Aux (&)[PPL], const bool (&act)[PPL], double inv, double den) {
     if constexpr (DT == 3) return spread_se2<PPL>(t, act, inv, den);
@@ -410,6 +427,15 @@ struct P3P3 {
     return A;
   }
   __device__ static __forceinline__ void finalize(double (&t)[6], const Aux& A) { quat_log(A.q, &t[3]); }
+  struct Ref { double c[3]; double q[4]; };
+  __device__ static __forceinline__ Ref make_ref(const double (&t0)[6], const Aux& A0) {
+    return Ref{{t0[0], t0[1], t0[2]}, {A0.q[0], A0.q[1], A0.q[2], A0.q[3]}};
+  }
+  __device__ static __forceinline__ void tangent(const Ref& r, const double (&t)[6], const Aux& A, double (&d)[6]) {
+    double e[4];
+    quat_cmul(r.q, A.q, e); quat_log(e, d + 3);
+    d[0] = t[0] - r.c[0]; d[1] = t[1] - r.c[1]; d[2] = t[2] - r.c[2];
+  }
 
   // std of the tangent coordinates about particle 0: translation differences and Log(R0ᵀ R_i)
   template <int PPL>
@@ -841,6 +867,128 @@ k_conv(const ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// N > 512: the same convolution with the particles walked in chunks of 128 instead of living in registers for the whole
+// kernel.  Cycle by cycle: (1) the spread of ALL N current points (the start points u0 in cycle 0, the previous cycle's
+// solutions afterwards -- they are re-read from the proposal block itself), (2) chunk by chunk: load, re-draw the measurement
+// samples (counter-based: the same every time), jitter with the oracle's full-width uniforms, solve, store.  Cycle elision as in
+// k_conv.  One wavefront per convolution; multihypo / nullhypo rows are not served here (the launcher refuses them).
+// ------------------------------------------------------------------------------------------
+template <class FP, int SOLVER>
+__global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
+  constexpr int PPL = 2;
+  const int lane = threadIdx.x & 63;
+  const int c_raw = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * ROME_WPB + (int)(threadIdx.x >> 6));
+  const bool valid = c_raw < a.n_conv;
+  const int c = valid ? c_raw : a.n_conv - 1;
+  const int N = a.N;
+  int f, dr, fv, tv;
+  if (a.rows4) {
+    const int4 row = *reinterpret_cast<const int4*>(a.rows4 + 4 * (size_t)c);
+    f = row.x; fv = row.z; tv = row.w; dr = FP::kHypoDir < 0 ? row.y : a.dir_all;
+  } else {
+    f = a.factor ? a.factor[c] : c; dr = a.dir ? a.dir[c] : a.dir_all;
+    fv = a.fixed_var ? a.fixed_var[c] : c; tv = a.target_var ? a.target_var[c] : c;
+  }
+  const typename FP::Consts K = FP::load(a, f, dr);
+  const double* __restrict__ fb = a.bel_fixed + (size_t)fv * FP::DF * N;
+  const double* tb = a.bel_target + (size_t)tv * FP::DT * N;
+  double* ob = a.out + (size_t)c * FP::DT * N;
+  const uint64_t stream = a.stream_offset + (uint64_t)c;
+  const bool cyc_on = FP::needs_cycles(SOLVER, K);
+  const int ncyc = cyc_on ? (a.cycles < 1 ? 1 : a.cycles) : 1;
+  constexpr bool kElide = SOLVER == kSolverNewton && FP::kUniqueRoot;
+  if (!valid) return;   // (nothing below synchronises across waves; surplus waves of the last block have no row)
+  for (int cyc = 0; cyc < ncyc; ++cyc) {
+    const double* cur = cyc == 0 ? tb : ob;
+    double spread = 0.0;
+    if (cyc_on && a.inflation > 0.0 && N > 1) {
+      double t0[FP::DT];
+#pragma unroll
+      for (int d = 0; d < FP::DT; ++d) t0[d] = cur[d * N];
+      FP::canonical(t0);
+      const typename FP::Aux a0 = FP::init_aux(t0);
+      const typename FP::Ref ref = FP::make_ref(t0, a0);
+      double sm[2 * FP::DT];
+#pragma unroll
+      for (int j = 0; j < 2 * FP::DT; ++j) sm[j] = 0.0;
+      for (int i = lane; i < N; i += 64) {
+        double t[FP::DT], dd[FP::DT];
+#pragma unroll
+        for (int d = 0; d < FP::DT; ++d) t[d] = cur[d * N + i];
+        FP::canonical(t);
+        const typename FP::Aux ax = FP::init_aux(t);
+        FP::tangent(ref, t, ax, dd);
+#pragma unroll
+        for (int d = 0; d < FP::DT; ++d) { sm[2 * d] += dd[d]; sm[2 * d + 1] += dd[d] * dd[d]; }
+      }
+      wave_sum_n<2 * FP::DT>(sm);
+      double var = 0.0;
+#pragma unroll
+      for (int d = 0; d < FP::DT; ++d) var += fmax(0.0, (sm[2 * d + 1] - sm[2 * d] * sm[2 * d] * a.inv_n) * a.inv_nm1);
+      const double sd = fast_sqrt(var);
+      spread = a.inflation * (sd > 1e-10 ? sd : 1.0);
+    }
+    int bad = 0;
+    for (int base = 0; base < N; base += 64 * PPL) {
+      double fx[PPL][FP::DF], t[PPL][FP::DT], z[PPL][FP::DZ];
+      typename FP::Aux aux[PPL];
+      bool act[PPL];
+      [[maybe_unused]] double xi_odd[3];
+      [[maybe_unused]] uint32_t sp0, sp1;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const int i = base + lane + 64 * k;
+        act[k] = i < N;
+        const int ii = act[k] ? i : 0;
+#pragma unroll
+        for (int d = 0; d < FP::DF; ++d) fx[k][d] = fb[d * N + ii];
+#pragma unroll
+        for (int d = 0; d < FP::DT; ++d) t[k][d] = cur[d * N + ii];
+        double xi[FP::DZ];
+        if (a.noise) {
+          const double* nb = a.noise + (size_t)c * FP::DZ * N;
+#pragma unroll
+          for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
+        } else if constexpr (FP::DZ == 3) {   // particles p, p + 64 of a 128-chunk share the third Box-Muller pair (rng_normals)
+          if ((k & 1) == 0) rng_normals3_pair(a.seed, stream, (uint32_t)i, xi, xi_odd, &sp0, &sp1);
+          else { xi[0] = xi_odd[0]; xi[1] = xi_odd[1]; xi[2] = xi_odd[2]; }
+        } else rng_normals<FP::DZ>(a.seed, stream, (uint32_t)ii, xi);
+        if (a.noise && a.noise_is_meas) {
+#pragma unroll
+          for (int d = 0; d < FP::DZ; ++d) z[k][d] = xi[d];
+        } else FP::measurement(K, xi, z[k]);
+        FP::canonical(t[k]);
+        aux[k] = FP::init_aux(t[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const int i = base + lane + 64 * k;
+        if (act[k]) {
+          const typename FP::Prep prep = FP::prepare(K, z[k], fx[k]);
+          if (spread > 0.0) {
+            double u[FP::DT], hs, hc;
+            rng_entropy_exact<FP::DT>(a.seed, stream, (uint32_t)i, cyc, u);
+            FP::template heading_sincos<kSolverNelderMead>(K, prep, 1, cyc, t[k], &hs, &hc);
+            FP::add_entropy(t[k], aux[k], spread, u, hs, hc);
+          }
+          const int st = FP::template solve<SOLVER>(K, prep, z[k], fx[k], t[k], aux[k], a.max_iters, a.tol);
+          bad |= st;
+          FP::finalize(t[k], aux[k]);
+#pragma unroll
+          for (int d = 0; d < FP::DT; ++d) ob[d * N + i] = t[k][d];
+          if (a.status) a.status[(size_t)c * N + i] = st;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next cycle's spread pass reads what other lanes of this wave just wrote
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if constexpr (kElide) {
+      if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) break;
+    }
+  }
+}
+
 // ---- prior sampling: out = coords(exp_ϵ(hat(μ + Lξ))) ; one wave per prior
 template <int D, int PPL>
 __global__ void __launch_bounds__(256) k_sample_prior(const ConvArgs a) {
@@ -854,7 +1002,7 @@ __global__ void __launch_bounds__(256) k_sample_prior(const ConvArgs a) {
   const double* L = a.L + (size_t)NL * f;
   double* ob = a.out + (size_t)c * D * N;
   const uint64_t stream = a.stream_offset + (uint64_t)c;
-#pragma unroll
+#pragma unroll(PPL <= 8 ? PPL : 1)
   for (int k = 0; k < PPL; ++k) {
     const int i = lane + 64 * k;
     if (i < N) {
@@ -994,7 +1142,10 @@ static hipError_t launch_ppl_v(const ConvArgs& a, hipStream_t s) {
   else if (a.N <= 128) hipLaunchKernelGGL((k_conv<FP, SOLVER, 2, LEAN>), dim3(nb), dim3(64 * ROME_WPB), pad, s, a);
   else if (a.N <= 256) hipLaunchKernelGGL((k_conv<FP, SOLVER, 4, LEAN>), dim3(nb), dim3(64 * ROME_WPB), pad, s, a);
   else if (a.N <= 512) hipLaunchKernelGGL((k_conv<FP, SOLVER, 8, LEAN>), dim3(nb), dim3(64 * ROME_WPB), pad, s, a);
-  else return hipErrorInvalidValue;
+  else {   // particles walked in chunks (k_conv_big); rows with multihypo / nullhypo / mirrors stay on the register-resident kernels
+    if (a.alt_var || a.nullhypo || a.n_mirror > 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_conv_big<FP, SOLVER>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  }
   return hipGetLastError();
 }
 template <class FP, int SOLVER>
@@ -1025,6 +1176,7 @@ static hipError_t launch_prior(const ConvArgs& a, hipStream_t s) {
   else if (a.N <= 128) hipLaunchKernelGGL((k_sample_prior<D, 2>), dim3(nb), dim3(256), 0, s, a);
   else if (a.N <= 256) hipLaunchKernelGGL((k_sample_prior<D, 4>), dim3(nb), dim3(256), 0, s, a);
   else if (a.N <= 512) hipLaunchKernelGGL((k_sample_prior<D, 8>), dim3(nb), dim3(256), 0, s, a);
+  else if (a.N <= 4096) hipLaunchKernelGGL((k_sample_prior<D, 64>), dim3(nb), dim3(256), 0, s, a);   // (a runtime-bounded loop over 64 slots)
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
