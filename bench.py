@@ -93,6 +93,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != world:
             raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world))
+    if multi:
+        # a collective that never completes (a rank died, an interconnect problem) must not hang the box: give up loudly
+        import threading
+        limit = float(os.environ.get("ROME_BENCH_WATCHDOG_S", "600"))
+
+        def _bail():
+            print("bench.py: rank %d: multi-GPU run did not finish within %.0f s -- aborting" % (rank, limit), file=sys.stderr, flush=True)
+            os._exit(124)
+        wd = threading.Timer(limit, _bail); wd.daemon = True; wd.start()
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a number "
                          "for a different GPU count" % (args.gpus, world))
