@@ -3,7 +3,8 @@
 `initAll` is the counterpart of IIF `initAll!` / `doautoinit!` (graphinit): variables are initialised in graph order by
 convolving a factor whose other variables already have beliefs (priors first).  `solveGraph` strings the pieces a `solveTree!`
 user calls implicitly: initialisation, (optionally) the parametric solve as a starting point, the device-resident non-parametric
-sweeps of DeviceGraph.solve -- a STAND-IN for the Bayes-tree solver --, download and point estimates."""
+sweeps of DeviceGraph.solve -- the per-variable operations of the reference (convolutions, manikde! bandwidths, manifoldProduct)
+on a whole-graph Jacobi schedule instead of the Bayes tree --, download and point estimates."""
 import numpy as np
 
 from .convolution import approxConv
@@ -36,10 +37,11 @@ def initAll(fg, seed=1, solver=None):
     return [l for l in fg.ls() if not fg.isInitialized(l)]
 
 
-def solveGraph(fg, n_sweeps=10, seed=0x524F4D45, init="graph", bandwidth="silverman", frozen=None, opts=None):
+def solveGraph(fg, n_sweeps=10, seed=0x524F4D45, init="graph", bandwidth="silverman", frozen=None, opts=None, product="importance"):
     """initialise -> device sweeps -> download -> setPPE.  init: "graph" (initAll for whatever has no belief yet), "parametric"
     (beliefs around solveGraphParametric's solution, like IIF's initParametricFrom!) or None (beliefs must exist).
-    Returns the DeviceGraph (beliefs stay resident for further sweeps)."""
+    product: "gibbs" = the reference's `manifoldProduct` (multiscale Gibbs product on `manikde!` bandwidths) per variable,
+    "importance" = the round-1 stand-in.  Returns the DeviceGraph (beliefs stay resident for further sweeps)."""
     from .api import make_opts
     from .canonical import setPPE
     from .device import DeviceGraph
@@ -57,7 +59,7 @@ def solveGraph(fg, n_sweeps=10, seed=0x524F4D45, init="graph", bandwidth="silver
         dg.upload_beliefs(fg)
     if frozen:
         dg.set_frozen(frozen)
-    dg.solve(opts if opts is not None else make_opts(N=fg.N, seed=seed), n_sweeps=n_sweeps, bandwidth=bandwidth)
+    dg.solve(opts if opts is not None else make_opts(N=fg.N, seed=seed), n_sweeps=n_sweeps, bandwidth=bandwidth, product=product)
     dg.download_beliefs(fg)
     setPPE(fg)
     return dg

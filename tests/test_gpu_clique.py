@@ -135,3 +135,23 @@ def test_clique_layouts_and_errors():
     q.p2p2_rows4 = rows.ctypes.data_as(C.c_void_p); q.p2p2_mu = mu.ctypes.data_as(C.c_void_p); q.p2p2_cov = cov.ctypes.data_as(C.c_void_p)
     q.out_p2p2 = out.ctypes.data_as(C.c_void_p)
     assert _lib.load().rome_clique_proposals(ctx.handle, C.byref(R.make_opts(N=64)), C.byref(q)) == _lib.ERR_INVALID_ARG
+
+
+def test_predictbelief_multiplies_all_proposals_of_a_variable():
+    """IIF predictbelief = proposalbeliefs + manifoldProduct, two library calls: x3 of the hexagon has two odometry neighbours,
+    the predicted belief is tighter than either proposal and sits between / on them; solveGraph runs with the reference's product."""
+    fg = _hexagon()
+    props, _ = R.proposalbeliefs(fg, "x3", seed=4)
+    assert len(props) == 2
+    pb = R.predictbelief(fg, "x3", seed=4)
+    assert pb.shape == (3, fg.N) and np.isfinite(pb).all()
+    sd = np.array([p[:2].std(axis=1) for p in props.values()])
+    assert (pb[:2].std(axis=1) < sd.max(axis=0)).all()                       # the product is tighter than the wider proposal
+    m = np.array([p[:2].mean(axis=1) for p in props.values()])
+    assert np.linalg.norm(pb[:2].mean(axis=1) - m.mean(axis=0)) < 2.0
+    one = R.predictbelief(fg, "x0", factor_labels=[fg.factors[0][0]], seed=4)   # the prior alone: its samples
+    assert one.shape == (3, fg.N)
+    fg2 = R.generateGraph_Hexagonal(N=100)
+    dg = R.solveGraph(fg2, n_sweeps=6, product="gibbs")
+    x6 = fg2.getVal("x6")
+    assert np.hypot(x6[0].mean(), x6[1].mean()) < 3.0                          # the loop closes on the origin
