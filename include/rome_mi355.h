@@ -311,8 +311,10 @@ int rome_product_bw_dev(rome_ctx*, const rome_opts*, int32_t dim, int32_t V, con
  *   attached to every proposal (rome_kde_bandwidth_dev) is REQUIRED; coordinate k is circular when bit k of circular_mask is set
  *   (Pose2: 0b100); gibbs_iters = AMP's Niter (1); max_proposals >= max_v (prop_ptr[v+1] - prop_ptr[v]) sizes the LDS of a block
  *   (the CSR is built on the host, so the caller knows it); n_prop_rows = rows of prop / prop_bw (a ball tree is built for each, in a
- *   context-owned workspace of 6.8 kB per row).  dim 2 (Point2) or 3 (Pose2), N <= 128.  Variables without proposals keep bel_in, with
- *   one proposal take it unchanged (as AMP does). */
+ *   context-owned workspace of 6.8 kB per row for Pose2).  dim 2 (Point2), 3 (Pose2) or 6 (Pose3: coordinates [t; rotation vector];
+ *   the rotation coordinates of a proposal live in the chart at the rotation of its point 0 -- Log(R_0ᵀ R_i) -- where the tree and
+ *   every candidate evaluation are Euclidean; only the product Gaussians of selected nodes change charts, by Exp / Log; pass
+ *   circular_mask = 0), N <= 128.  Variables without proposals keep bel_in, with one proposal take it unchanged (as AMP does). */
 int rome_product_gibbs_dev(rome_ctx*, const rome_opts*, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
                            const double* prop, const double* prop_bw, int32_t n_prop_rows, const double* bel_in, double* bel_out,
                            uint32_t circular_mask, int32_t gibbs_iters, int32_t max_proposals);

@@ -1335,6 +1335,7 @@ typedef struct {
   int* perm;     /* sorted position -> particle index */
   float lvar[6], livar[6], lcz;   /* level-L kernels */
   double ref[6], h[6];
+  double R0[9];                   /* dim 6 (Pose3): rotation of point 0 -- coordinates 3..5 are Log(R0ᵀ R_i), the chart at R0 */
 } msg_tree;
 static inline void msg_range(int N, int l, int z, int* a, int* b) { *a = (int)(((long long)z * N) >> l); *b = (int)(((long long)(z + 1) * N) >> l); }
 static void msg_build(msg_tree* T, int N, int D, const double* P /*[D][N]*/, const double* h, uint32_t circ) {
@@ -1347,10 +1348,20 @@ static void msg_build(msg_tree* T, int N, int D, const double* P /*[D][N]*/, con
   float* y = (float*)malloc(sizeof(float) * N * D);
   for (int d = 0; d < D; ++d) {
     T->ref[d] = P[d * N]; T->h[d] = fmax(h[d], 1e-6);
+    if (D == 6 && d >= 3) continue;
     for (int i = 0; i < N; ++i) {
       double o = P[d * N + i] - P[d * N];
       if ((circ >> d) & 1u) o = lcv_wrap(o);
       y[i * D + d] = (float)o + 0.0f;   /* -0 -> +0: one order for equal offsets */
+    }
+  }
+  if (D == 6) {   /* Pose3: rotation coordinates in the chart at the rotation of point 0 */
+    double w0[3] = {P[3 * N], P[4 * N], P[5 * N]};
+    ro_so3_exp(w0, T->R0);
+    for (int i = 0; i < N; ++i) {
+      double w[3] = {P[3 * N + i], P[4 * N + i], P[5 * N + i]}, Ri[9], U[9], lg[3];
+      ro_so3_exp(w, Ri); mat3_tmul(T->R0, Ri, U); ro_so3_log(U, lg);
+      for (int k = 0; k < 3; ++k) y[i * D + 3 + k] = (float)lg[k] + 0.0f;
     }
   }
   for (int i = 0; i < N; ++i) T->perm[i] = i;
@@ -1441,7 +1452,7 @@ int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr
                        const double* prop /*[rows][dim][N]*/, const double* prop_bw /*[rows][dim]*/, const double* bel_in,
                        uint32_t circular_mask, int gibbs_iters, double* bel_out) {
   const int N = o->n_particles, D = dim;
-  if ((dim != 2 && dim != 3) || N < 1 || !prop_bw) return -1;
+  if ((dim != 2 && dim != 3 && dim != 6) || N < 1 || !prop_bw) return -1;
   if (gibbs_iters < 1) gibbs_iters = 1;
   const uint32_t key[2] = {(uint32_t)o->seed, (uint32_t)(o->seed >> 32)};
 #pragma omp parallel for schedule(dynamic, 4)
@@ -1465,9 +1476,12 @@ int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr
                                    if ((qn & 1u) == 0) ro_box_muller(wn[qn & 2u], wn[(qn & 2u) + 1], &npair[0], &npair[1]); (out) = npair[qn & 1u]; ++qn; } while (0)
       for (int j = 0; j < K; ++j) sel[j] = 0;
       double x[6];
+      double xR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   /* dim 6: rotation of the current point */
+      const int DE = D == 6 ? 3 : D;                /* coordinates handled one by one (Euclidean / circular) */
       for (int l = 1; l <= L + 1; ++l) {
-        /* (a) product of the selected nodes of level l-1; leaving out nothing.  Circular coordinates: deviations from density 0's mean */
-        for (int d = 0; d < D; ++d) {
+        /* (a) a point from the product of the selected nodes of level l-1.  Deviations are taken from density 0's node
+         * (circular coordinates: wrapped; rotations: Log(Q_0ᵀ Q_j) with Q_j = R0_j Exp(mean_ω) the node's absolute rotation) */
+        for (int d = 0; d < DE; ++d) {
           double prec = 0.0, num = 0.0, mu0 = 0.0;
           for (int j = 0; j < K; ++j) {
             double mean[6], var[6], ivar[6], cz;
@@ -1486,19 +1500,44 @@ int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr
           double xi; MSG_NORMAL(xi);
           x[d] = mu0 + num / prec + xi / sqrt(prec);
         }
+        if (D == 6) {
+          double B[9], prec[3] = {0, 0, 0}, num[3] = {0, 0, 0};
+          for (int j = 0; j < K; ++j) {
+            double mean[6], var[6], ivar[6], cz, Q[9], iv[3];
+            msg_node(&T[j], l - 1, sel[j], mean, var, ivar, &cz);
+            if (l - 1 == L) {
+              const int pi = T[j].perm[(int)(((long long)sel[j] * N) >> L)];
+              double w[3] = {prop[(size_t)rows[j] * D * N + 3 * (size_t)N + pi], prop[(size_t)rows[j] * D * N + 4 * (size_t)N + pi],
+                             prop[(size_t)rows[j] * D * N + 5 * (size_t)N + pi]};
+              ro_so3_exp(w, Q);
+              for (int k = 0; k < 3; ++k) iv[k] = 1.0 / (T[j].h[3 + k] * T[j].h[3 + k]);
+            } else {
+              double E[9]; ro_so3_exp(mean + 3, E); mat3_mul(T[j].R0, E, Q);
+              for (int k = 0; k < 3; ++k) iv[k] = ivar[3 + k];
+            }
+            double dev[3] = {0, 0, 0};
+            if (j == 0) memcpy(B, Q, sizeof(B));
+            else { double U[9]; mat3_tmul(B, Q, U); ro_so3_log(U, dev); }
+            for (int k = 0; k < 3; ++k) { prec[k] += iv[k]; num[k] += iv[k] * dev[k]; }
+          }
+          double e[3], E[9];
+          for (int k = 0; k < 3; ++k) { double xi; MSG_NORMAL(xi); e[k] = num[k] / prec[k] + xi / sqrt(prec[k]); }
+          ro_so3_exp(e, E); mat3_mul(B, E, xR);
+        }
         if (l == L + 1) break;   /* that was the output draw from the selected kernels */
-        /* (c) labels of level l given the point */
+        /* (c) labels of level l given the point (the point in the density's own chart: Euclidean there) */
         for (int j = 0; j < K; ++j) {
           uint32_t w; MSG_UNIFORM_WORD(w);
           msg_res R; msg_res_init(&R, w);
+          double e0[6];
+          for (int d = 0; d < DE; ++d) { e0[d] = x[d] - T[j].ref[d]; if ((circular_mask >> d) & 1u) e0[d] = lcv_wrap(e0[d]); }
+          if (D == 6) { double U[9]; mat3_tmul(T[j].R0, xR, U); ro_so3_log(U, e0 + 3); }
           for (int z = 0; z < (1 << l); ++z) {
             double mean[6], var[6], ivar[6], cz;
             if (msg_node(&T[j], l, z, mean, var, ivar, &cz) == 0) continue;
             double q = 0.0;
             for (int d = 0; d < D; ++d) {
-              double e = x[d] - T[j].ref[d];
-              if ((circular_mask >> d) & 1u) e = lcv_wrap(e);
-              e -= mean[d];
+              double e = e0[d] - mean[d];
               if ((circular_mask >> d) & 1u) e = lcv_wrap(e);
               q += e * e * ivar[d];
             }
@@ -1509,8 +1548,8 @@ int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr
         /* (d) Gibbs sweeps over the labels */
         for (int it = 0; it < gibbs_iters; ++it)
           for (int j = 0; j < K; ++j) {
-            double Mx[6], Cx[6];
-            for (int d = 0; d < D; ++d) {
+            double Mx[6], Cx[6];   /* product Gaussian of the other selected nodes, mean in density j's chart */
+            for (int d = 0; d < DE; ++d) {
               double prec = 0.0, num = 0.0, mu0 = 0.0; int first = 1;
               for (int i = 0; i < K; ++i) {
                 if (i == j) continue;
@@ -1522,7 +1561,23 @@ int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr
                 if ((circular_mask >> d) & 1u) dev = lcv_wrap(dev);
                 prec += ivar[d]; num += ivar[d] * dev;
               }
-              Mx[d] = mu0 + num / prec; Cx[d] = 1.0 / prec;
+              Mx[d] = mu0 + num / prec - T[j].ref[d]; Cx[d] = 1.0 / prec;
+              if ((circular_mask >> d) & 1u) Mx[d] = lcv_wrap(Mx[d]);
+            }
+            if (D == 6) {
+              double B[9], prec[3] = {0, 0, 0}, num[3] = {0, 0, 0}; int first = 1;
+              for (int i = 0; i < K; ++i) {
+                if (i == j) continue;
+                double mean[6], var[6], ivar[6], cz, E[9], Q[9], dev[3] = {0, 0, 0};
+                msg_node(&T[i], l, sel[i], mean, var, ivar, &cz);
+                ro_so3_exp(mean + 3, E); mat3_mul(T[i].R0, E, Q);
+                if (first) { memcpy(B, Q, sizeof(B)); first = 0; }
+                else { double U[9]; mat3_tmul(B, Q, U); ro_so3_log(U, dev); }
+                for (int k = 0; k < 3; ++k) { prec[k] += ivar[3 + k]; num[k] += ivar[3 + k] * dev[k]; }
+              }
+              double e[3], E[9], QM[9], U[9];
+              for (int k = 0; k < 3; ++k) { e[k] = num[k] / prec[k]; Cx[3 + k] = 1.0 / prec[k]; }
+              ro_so3_exp(e, E); mat3_mul(B, E, QM); mat3_tmul(T[j].R0, QM, U); ro_so3_log(U, Mx + 3);
             }
             uint32_t w; MSG_UNIFORM_WORD(w);
             msg_res R; msg_res_init(&R, w);
@@ -1532,7 +1587,7 @@ int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr
               if (cnt == 0) continue;
               double q = 0.0;
               for (int d = 0; d < D; ++d) {
-                double e = T[j].ref[d] + mean[d] - Mx[d];
+                double e = mean[d] - Mx[d];
                 if ((circular_mask >> d) & 1u) e = lcv_wrap(e);
                 const double vv = var[d] + Cx[d];
                 q += e * e / vv + log(vv);
@@ -1542,6 +1597,7 @@ int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr
             sel[j] = R.sel;
           }
       }
+      if (D == 6) ro_so3_log(xR, x + 3);
       for (int d = 0; d < D; ++d) ob[(size_t)d * N + s] = ((circular_mask >> d) & 1u) ? lcv_wrap(x[d]) : x[d];
       #undef MSG_UNIFORM_WORD
       #undef MSG_NORMAL

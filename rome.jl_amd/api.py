@@ -176,15 +176,18 @@ def kde_bandwidth(bel, circular_mask=None, tol_euclid=0.0, tol_circular=0.0, ctx
 
 def manifoldProduct(proposals, circular_mask=None, bandwidths=None, Niter=1, opts=None, ctx=None):
     """⚠AMP `manifoldProduct(ff, manifold; Niter=1)`: N samples from the product of K kernel density estimates by multiscale Gibbs
-    sampling (rome_product_gibbs_dev).  proposals (K, dim, N) host array (dim 2: Point2, 3: Pose2); bandwidths (K, dim) or None =
-    the `manikde!` rule (kde_bandwidth).  -> (dim, N).  K = 1 returns the density's own points, as AMP does."""
+    sampling (rome_product_gibbs_dev).  proposals (K, dim, N) host array (dim 2: Point2, 3: Pose2, 6: Pose3 coordinates (t, ω));
+    bandwidths (K, dim) or None = the `manikde!` rule (kde_bandwidth; Pose3: rotation-vector coordinates as circular).
+    -> (dim, N).  K = 1 returns the density's own points, as AMP does."""
     import torch
     ctx = ctx or default_context()
     P = _d(proposals)
     K, d, N = P.shape
     if circular_mask is None:
         circular_mask = 0b100 if d == 3 else 0
-    bw = kde_bandwidth(P, circular_mask, ctx=ctx) if bandwidths is None else _d(bandwidths, (K, d))
+    bw = kde_bandwidth(P, 0b111000 if d == 6 else circular_mask, ctx=ctx) if bandwidths is None else _d(bandwidths, (K, d))
+    if d == 6:
+        circular_mask = 0     # rotations live in the chart of each density: no wrapped coordinate
     o = opts if opts is not None else make_opts(N=N)
     dev = torch.device("cuda", ctx.device if hasattr(ctx, "device") else 0)
     t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)

@@ -147,7 +147,7 @@ def predictbelief(fg, destlabel, factor_labels=None, solver=_lib.SOLVER_NEWTON, 
     """IIF `predictbelief(dfg, destlbl, factors; N)`: the proposals of every usable factor of `destlabel` (one library call,
     `proposalbeliefs`) multiplied by `manifoldProduct` (multiscale Gibbs product on the `manikde!` bandwidths, one more call) ->
     (dim, N) points of the predicted belief.  A factor is usable when its other variable has a belief (priors always are).
-    Multihypo factors and Pose3 destinations (no SE(3) Gibbs product yet) go through `approxConv` / the single-proposal case."""
+    Multihypo factors go through `approxConv`."""
     usable = []
     for flabel, labels, f in fg.factors:
         if destlabel not in labels or (factor_labels is not None and flabel not in factor_labels):
@@ -160,6 +160,6 @@ def predictbelief(fg, destlabel, factor_labels=None, solver=_lib.SOLVER_NEWTON, 
         raise ValueError("predictbelief: no factor of %s has initialised neighbours" % destlabel)
     props, _ = proposalbeliefs(fg, destlabel, factor_labels=usable, solver=solver, seed=seed, ctx=ctx, **optkw)
     P = np.stack([props[(fl, destlabel)] for fl in usable])
-    if len(usable) == 1 or fg.variables[destlabel] is Pose3:
+    if len(usable) == 1:
         return P[0]
     return api.manifoldProduct(P, Niter=Niter, opts=api.make_opts(N=fg.N, seed=seed, **{k: v for k, v in optkw.items() if k == "stream_offset"}), ctx=ctx)

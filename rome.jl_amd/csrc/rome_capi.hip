@@ -808,7 +808,7 @@ int rome_product_gibbs_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t
                            const double* prop, const double* prop_bw, int32_t n_prop_rows, const double* bel_in, double* bel_out,
                            uint32_t circular_mask, int32_t gibbs_iters, int32_t max_proposals) {
   int rc = check_opts(o); if (rc) return rc;
-  if (!c || V < 0 || n_prop_rows < 0 || (dim != 2 && dim != 3) || max_proposals < 1) return ROME_ERR_INVALID_ARG;
+  if (!c || V < 0 || n_prop_rows < 0 || (dim != 2 && dim != 3 && dim != 6) || max_proposals < 1) return ROME_ERR_INVALID_ARG;
   if (V > 0 && (!prop_ptr || !prop_rows || !bel_in || !bel_out)) return ROME_ERR_INVALID_ARG;
   if (n_prop_rows > 0 && (!prop || !prop_bw)) return ROME_ERR_INVALID_ARG;
   if (o->n_particles > 128) return ROME_ERR_UNSUPPORTED_N;   /* lane = output sample, two wavefronts per variable */

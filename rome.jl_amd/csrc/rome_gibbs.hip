@@ -42,6 +42,7 @@ struct GibbsArgs {
 template <int D>
 struct alignas(8) GibbsTree {
   double ref[D], h[D];
+  double q0[4];   // D = 6 (Pose3): unit quaternion of point 0 -- coordinates 3..5 are Log(q0* ⊗ q_i), the chart at that rotation
   float mean[kGibbsNodes][D], var[kGibbsNodes][D], ivar[kGibbsNodes][D], cz[kGibbsNodes];
   float ys[kGibbsMaxN][D];
   float lvar[D], livar[D], lcz;
@@ -73,13 +74,23 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
   for (int s = 0; s < 2; ++s) {
     const int i = lane + 64 * s;
     id[s] = i;
+    const int ii = i < N ? i : 0;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      double o = (i < N ? P[d * N + i] : P[d * N]) - P[d * N];
+    for (int d = 0; d < (D == 6 ? 3 : D); ++d) {
+      double o = P[d * N + ii] - P[d * N];
       if ((circ >> d) & 1u) o = gwrap(o);
       y[s][d] = (float)o + 0.0f;   // (-0 -> +0: one order for equal offsets)
-      if (i < N) ybuf[i * D + d] = y[s][d];
     }
+    if constexpr (D == 6) {   // Pose3: rotation coordinates in the chart at the rotation of point 0
+      const double w0[3] = {P[3 * N], P[4 * N], P[5 * N]}, wi[3] = {P[3 * N + ii], P[4 * N + ii], P[5 * N + ii]};
+      double qa[4], qb[4], e[4], lg[3];
+      quat_exp(w0, qa); quat_exp(wi, qb); quat_cmul(qa, qb, e); quat_log(e, lg);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) y[s][3 + k] = (float)lg[k] + 0.0f;
+      if (lane == 0 && s == 0) { T->q0[0] = qa[0]; T->q0[1] = qa[1]; T->q0[2] = qa[2]; T->q0[3] = qa[3]; }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) if (i < N) ybuf[i * D + d] = y[s][d];
   }
   if (lane < D) { T->ref[lane] = P[lane * N]; T->h[lane] = fmax(hb[lane], 1e-6); }
   if (lane == 0) T->row = row;
@@ -269,7 +280,7 @@ struct GibbsLevel {
   };
 };
 template <int D>
-struct GibbsConst { double ref[D], h[D]; float lvar[D], livar[D], lcz; int row; };
+struct GibbsConst { double ref[D], h[D], q0[4]; float lvar[D], livar[D], lcz; int row; };
 
 template <int D>
 __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs a) {
@@ -298,6 +309,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
     GibbsConst<D>& c = cst[j];
 #pragma unroll
     for (int d = 0; d < D; ++d) { c.ref[d] = T.ref[d]; c.h[d] = T.h[d]; c.lvar[d] = T.lvar[d]; c.livar[d] = T.livar[d]; }
+    if constexpr (D == 6) { c.q0[0] = T.q0[0]; c.q0[1] = T.q0[1]; c.q0[2] = T.q0[2]; c.q0[3] = T.q0[3]; }
     c.lcz = T.lcz; c.row = row;
   }
   __syncthreads();
@@ -340,10 +352,13 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
   for (int j = 0; j < K; ++j) selbuf[j * 128 + tid] = 0;
   stage(0);
   double x[D];
+  [[maybe_unused]] double xq[4] = {1.0, 0.0, 0.0, 0.0};   // D = 6: rotation of the current point
+  constexpr int DE = D == 6 ? 3 : D;                      // coordinates handled one by one (Euclidean / circular)
   for (int l = 1; l <= L + 1; ++l) {
-    // (a) a point from the product of the selected nodes of level l - 1 (its image is the one in LDS)
+    // (a) a point from the product of the selected nodes of level l - 1 (its image is the one in LDS).  Deviations are taken
+    //     from density 0's node; rotations: Log(Q_0* ⊗ Q_j) with Q_j = q0_j ⊗ Exp(mean_ω) the node's absolute rotation
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DE; ++d) {
       double prec = 0.0, num = 0.0, mu0 = 0.0;
       for (int j = 0; j < K; ++j) {
         const GibbsConst<D>& c = cst[j];
@@ -362,17 +377,48 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
       const double xi = normal();
       x[d] = mu0 + num / prec + xi / fast_sqrt(prec);
     }
+    if constexpr (D == 6) {
+      double B[4] = {1.0, 0.0, 0.0, 0.0}, prec[3] = {0.0, 0.0, 0.0}, num[3] = {0.0, 0.0, 0.0};
+      for (int j = 0; j < K; ++j) {
+        const GibbsConst<D>& c = cst[j];
+        const int sz = selbuf[j * 128 + tid];
+        double Q[4], iv[3];
+        if (l - 1 == L) {
+          const int pi = W[c.row].perm[(int)(((long long)sz * N) >> L)];
+          const double* pp = a.prop + (size_t)c.row * D * N + pi;
+          const double w[3] = {pp[3 * (size_t)N], pp[4 * (size_t)N], pp[5 * (size_t)N]};
+          quat_exp(w, Q);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) iv[k] = 1.0 / (c.h[3 + k] * c.h[3 + k]);
+        } else {
+          const double m[3] = {(double)lev[j].in.mean[sz][3], (double)lev[j].in.mean[sz][4], (double)lev[j].in.mean[sz][5]};
+          double E[4]; quat_exp(m, E); quat_mul(c.q0, E, Q);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) iv[k] = (double)lev[j].in.ivar[sz][3 + k];
+        }
+        double dev[3] = {0.0, 0.0, 0.0};
+        if (j == 0) { B[0] = Q[0]; B[1] = Q[1]; B[2] = Q[2]; B[3] = Q[3]; }
+        else { double e[4]; quat_cmul(B, Q, e); quat_log(e, dev); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { prec[k] += iv[k]; num[k] += iv[k] * dev[k]; }
+      }
+      double e[3], E[4];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const double xi = normal(); e[k] = num[k] / prec[k] + xi / fast_sqrt(prec[k]); }
+      quat_exp(e, E); quat_mul(B, E, xq);
+    }
     if (l == L + 1) break;
     stage(l);
     const int nz = 1 << l;
-    // (c) labels of level l given the point
+    // (c) labels of level l given the point, which is expressed ONCE in the density's own chart: Euclidean there
     for (int j = 0; j < K; ++j) {
       const GibbsConst<D>& c = cst[j];
       const GibbsLevel<D>& G = lev[j];
       Reservoir R; R.init(uniform_word());
       double e0[D];
 #pragma unroll
-      for (int d = 0; d < D; ++d) { e0[d] = x[d] - c.ref[d]; if ((a.circ >> d) & 1u) e0[d] = gwrap(e0[d]); }
+      for (int d = 0; d < DE; ++d) { e0[d] = x[d] - c.ref[d]; if ((a.circ >> d) & 1u) e0[d] = gwrap(e0[d]); }
+      if constexpr (D == 6) { double e[4]; quat_cmul(c.q0, xq, e); quat_log(e, e0 + 3); }
       if (l < L) {
         for (int z = 0; z < nz; ++z) {   // wave-uniform candidate: node statistics are LDS broadcasts
           int ra, rb; node_range(N, l, z, &ra, &rb);
@@ -409,9 +455,10 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
     // (d) Gibbs sweeps over the labels
     for (int it = 0; it < a.iters; ++it)
       for (int j = 0; j < K; ++j) {
-        double Mx[D], Cx[D];
+        const GibbsConst<D>& c = cst[j];
+        double Mx[D], Cx[D];   // product Gaussian of the other selected nodes, its mean in density j's chart
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
+        for (int d = 0; d < DE; ++d) {
           double prec = 0.0, num = 0.0, mu0 = 0.0; bool first = true;
           for (int i = 0; i < K; ++i) {
             if (i == j) continue;
@@ -425,14 +472,37 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
             if ((a.circ >> d) & 1u) dev = gwrap(dev);
             prec += iv; num += iv * dev;
           }
-          Mx[d] = mu0 + num / prec; Cx[d] = 1.0 / prec;
+          Mx[d] = mu0 + num / prec - c.ref[d]; Cx[d] = 1.0 / prec;
+          if ((a.circ >> d) & 1u) Mx[d] = gwrap(Mx[d]);
         }
-        const GibbsConst<D>& c = cst[j];
+        if constexpr (D == 6) {
+          double B[4] = {1.0, 0.0, 0.0, 0.0}, prec[3] = {0.0, 0.0, 0.0}, num[3] = {0.0, 0.0, 0.0}; bool first = true;
+          for (int i = 0; i < K; ++i) {
+            if (i == j) continue;
+            const int sz = selbuf[i * 128 + tid];
+            double m[3], iv[3];
+            if (l < L) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) { m[k] = (double)lev[i].in.mean[sz][3 + k]; iv[k] = (double)lev[i].in.ivar[sz][3 + k]; }
+            } else {
+              const int pos = (int)(((long long)sz * N) >> L);
+#pragma unroll
+              for (int k = 0; k < 3; ++k) { m[k] = (double)lev[i].ys[pos][3 + k]; iv[k] = (double)cst[i].livar[3 + k]; }
+            }
+            double E[4], Q[4], dev[3] = {0.0, 0.0, 0.0};
+            quat_exp(m, E); quat_mul(cst[i].q0, E, Q);
+            if (first) { B[0] = Q[0]; B[1] = Q[1]; B[2] = Q[2]; B[3] = Q[3]; first = false; }
+            else { double e[4]; quat_cmul(B, Q, e); quat_log(e, dev); }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { prec[k] += iv[k]; num[k] += iv[k] * dev[k]; }
+          }
+          double e[3], E[4], QM[4], r[4];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { e[k] = num[k] / prec[k]; Cx[3 + k] = 1.0 / prec[k]; }
+          quat_exp(e, E); quat_mul(B, E, QM); quat_cmul(c.q0, QM, r); quat_log(r, Mx + 3);
+        }
         const GibbsLevel<D>& G = lev[j];
         Reservoir R; R.init(uniform_word());
-        double e0[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) e0[d] = c.ref[d] - Mx[d];
         if (l < L) {
           for (int z = 0; z < nz; ++z) {
             int ra, rb; node_range(N, l, z, &ra, &rb);
@@ -440,7 +510,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
             double q = 0.0, pv = 1.0;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-              double e = e0[d] + (double)G.in.mean[z][d];
+              double e = (double)G.in.mean[z][d] - Mx[d];
               if ((a.circ >> d) & 1u) e = gwrap(e);
               const double vv = (double)G.in.var[z][d] + Cx[d];
               q += e * e * fast_rcp_pos(vv);
@@ -458,7 +528,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
             double q = 0.0;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-              double e = e0[d] + (double)G.ys[ra][d];
+              double e = (double)G.ys[ra][d] - Mx[d];
               if ((a.circ >> d) & 1u) e = gwrap(e);
               q += e * e * ivv[d];
             }
@@ -468,39 +538,45 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
         selbuf[j * 128 + tid] = (uint8_t)R.sel;
       }
   }
+  if constexpr (D == 6) quat_log(xq, x + 3);
   if (live) {
 #pragma unroll
     for (int d = 0; d < D; ++d) ob[(size_t)d * N + s] = ((a.circ >> d) & 1u) ? gwrap(x[d]) : x[d];
   }
 }
 
-size_t gibbs_workspace_bytes(int dim, int n_rows) { return (dim == 2 ? sizeof(GibbsTree<2>) : sizeof(GibbsTree<3>)) * (size_t)(n_rows > 0 ? n_rows : 1); }
+size_t gibbs_workspace_bytes(int dim, int n_rows) {
+  return (dim == 2 ? sizeof(GibbsTree<2>) : (dim == 3 ? sizeof(GibbsTree<3>) : sizeof(GibbsTree<6>))) * (size_t)(n_rows > 0 ? n_rows : 1);
+}
 
 hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
                                 const double* prop_bw, const double* bel_in, double* bel_out, void* trees, uint32_t circ, int iters, int max_k,
                                 uint64_t seed, uint64_t stream_offset, hipStream_t s) {
   if (V <= 0) return hipSuccess;
-  if (N < 1 || N > kGibbsMaxN || (dim != 2 && dim != 3) || max_k < 1 || n_rows < 0) return hipErrorInvalidValue;
+  if (N < 1 || N > kGibbsMaxN || (dim != 2 && dim != 3 && dim != 6) || max_k < 1 || n_rows < 0) return hipErrorInvalidValue;
   GibbsArgs a;
   a.V = V; a.N = N; a.L = 0; while ((1 << a.L) < N) ++a.L;
   a.max_k = max_k; a.iters = iters < 1 ? 1 : iters; a.circ = circ;
   a.prop_ptr = prop_ptr; a.prop_rows = prop_rows; a.prop = prop; a.prop_bw = prop_bw; a.bel_in = bel_in; a.bel_out = bel_out;
   a.trees = trees; a.n_rows = n_rows;
   a.seed = seed; a.stream_offset = stream_offset;
-  const size_t per = dim == 2 ? sizeof(GibbsLevel<2>) + sizeof(GibbsConst<2>) : sizeof(GibbsLevel<3>) + sizeof(GibbsConst<3>);
+  const size_t per = dim == 2 ? sizeof(GibbsLevel<2>) + sizeof(GibbsConst<2>)
+                              : (dim == 3 ? sizeof(GibbsLevel<3>) + sizeof(GibbsConst<3>) : sizeof(GibbsLevel<6>) + sizeof(GibbsConst<6>));
   const size_t bytes = (per + 128) * (size_t)max_k;
   if (bytes > 150 * 1024) return hipErrorInvalidValue;
+  const void* fn = dim == 2 ? (const void*)k_product_gibbs<2> : (dim == 3 ? (const void*)k_product_gibbs<3> : (const void*)k_product_gibbs<6>);
   if (bytes > 48 * 1024) {
-    hipError_t e = dim == 2 ? hipFuncSetAttribute((const void*)k_product_gibbs<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
-                            : hipFuncSetAttribute((const void*)k_product_gibbs<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
   }
   if (n_rows > 0) {
     if (dim == 2) hipLaunchKernelGGL((k_gibbs_trees<2>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gibbs_trees<3>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
+    else if (dim == 3) hipLaunchKernelGGL((k_gibbs_trees<3>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gibbs_trees<6>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
   }
   if (dim == 2) hipLaunchKernelGGL((k_product_gibbs<2>), dim3(V), dim3(kGibbsThreads), bytes, s, a);
-  else hipLaunchKernelGGL((k_product_gibbs<3>), dim3(V), dim3(kGibbsThreads), bytes, s, a);
+  else if (dim == 3) hipLaunchKernelGGL((k_product_gibbs<3>), dim3(V), dim3(kGibbsThreads), bytes, s, a);
+  else hipLaunchKernelGGL((k_product_gibbs<6>), dim3(V), dim3(kGibbsThreads), bytes, s, a);
   return hipGetLastError();
 }
 

@@ -243,8 +243,8 @@ class DeviceGraph:
         """bel <- product of the proposals targeting each variable (Jacobi update: computed into bel_next, copied back in place
         so that launch plans holding the belief pointers stay valid).
         product:   "gibbs" = the reference's algorithm, ⚠AMP manifoldProduct / KDE.jl multiscale Gibbs sampling
-                   (rome_product_gibbs_dev; Point2 / Pose2, N <= 128; always on the `manikde!` bandwidths of the proposals);
-                   "importance" = the round-1 importance-sampling stand-in (rome_product_bw_dev; also Pose3).
+                   (rome_product_gibbs_dev; Point2 / Pose2 / Pose3, N <= 128; always on the `manikde!` bandwidths of the proposals);
+                   "importance" = the round-1 importance-sampling stand-in (rome_product_bw_dev).
         bandwidth: "silverman" (in-kernel rule on the proposal spread; importance product only) or "lcv" (leave-one-out
                    likelihood bandwidths of every proposal by rome_kde_bandwidth_dev first -- what the reference's `manikde!`
                    attaches to each convolution result)."""
@@ -262,8 +262,8 @@ class DeviceGraph:
             c = self.csr[vt]
             bw_ptr = None
             rows = self.n_prop[vt]
-            gibbs = product == "gibbs" and dim in (2, 3)
-            circ = 0b100 if vt is Pose2 else (0b111000 if vt is Pose3 else 0)
+            gibbs = product == "gibbs"
+            circ = 0b100 if vt is Pose2 else (0b111000 if vt is Pose3 else 0)   # bandwidth rule: which coordinates are angles
             if (bandwidth == "lcv" or gibbs) and rows:
                 if vt not in self.prop_bw:
                     self.prop_bw[vt] = self.torch.empty((self.prop[vt].shape[0], dim), dtype=self.torch.float64, device=self.device)
@@ -275,7 +275,8 @@ class DeviceGraph:
                 max_k = max(1, int(np.diff(c["ptr_h"]).max())) if len(c["ptr_h"]) > 1 else 1
                 _lib.check(self._lib.rome_product_gibbs_dev(self.ctx.handle, C.byref(o), dim, V, c["ptr"].data_ptr(), c["rows"].data_ptr(),
                                                             self.prop[vt].data_ptr(), bw_ptr, rows, self.bel[vt].data_ptr(),
-                                                            self.bel_next[vt].data_ptr(), circ, int(gibbs_iters), max_k), self.ctx.handle)
+                                                            self.bel_next[vt].data_ptr(), 0b100 if vt is Pose2 else 0, int(gibbs_iters), max_k),
+                           self.ctx.handle)   # (Pose3: rotations are handled in the chart of each proposal, no wrapped coordinate)
             else:
                 _lib.check(self._lib.rome_product_bw_dev(self.ctx.handle, C.byref(o), dim, V, c["ptr"].data_ptr(), c["rows"].data_ptr(),
                                                          self.prop[vt].data_ptr(), bw_ptr, self.bel[vt].data_ptr(),

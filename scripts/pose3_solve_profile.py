@@ -18,3 +18,9 @@ for name, fn in (("conv_step", lambda s: dg.conv_step(o, s)), ("product_step", l
         fn(s)
     torch.cuda.synchronize()
     print("Pose3 helix (%d poses, %d convolutions): %-12s %.3f ms" % (len(dg.packed.labels[R.Pose3]), dg.tab["p3p3"]["C"], name, (time.perf_counter() - t) / 20 * 1e3))
+dg.conv_step(o, 0); dg.product_step(o, 0, "lcv", "gibbs"); torch.cuda.synchronize()
+t = time.perf_counter()
+for s in range(5):
+    dg.conv_step(o, s); dg.product_step(o, s, "lcv", "gibbs")
+torch.cuda.synchronize()
+print("Pose3 helix: iteration with manikde! bandwidths + Gibbs product on SE(3)  %.3f ms" % ((time.perf_counter() - t) / 5 * 1e3))

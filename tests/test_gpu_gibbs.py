@@ -182,3 +182,46 @@ def test_reference_solved_graph_product_consistency():
     print("reference-solve consistency (median offset/sd, 95 %% offset/sd, median sd ratio):", res)
     assert g[0] < 1.0 and g[1] < 4.0, res            # the product of the neighbours' messages sits on the reference posterior
     assert 0.4 < g[2] < 1.6, res                      # ... with a comparable width
+
+
+def test_pose3_product_device_equals_oracle_and_gaussian_moments():
+    """SE(3): the rotation coordinates of every proposal live in the chart at the rotation of its point 0; trees and candidate
+    evaluations are Euclidean there, the product Gaussians of selected nodes change charts by Exp / Log.  Device (quaternions) ==
+    oracle (rotation matrices) sample by sample; the product of two Gaussian densities on SE(3) has the Gaussian-product moments."""
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(2)
+    N, V = 100, 60
+
+    def make(mu, sd):
+        t = np.asarray(mu[:3])[:, None] + np.asarray(sd[:3])[:, None] * rng.standard_normal((3, N))
+        w = (Rot.from_rotvec(mu[3:]) * Rot.from_rotvec((np.asarray(sd[3:])[:, None] * rng.standard_normal((3, N))).T)).as_rotvec().T
+        return np.concatenate([t, w])
+    m1, s1 = np.array([0, 0, 0, 0.2, 2.9, -0.1]), np.array([1.0, 0.5, 0.2, 0.05, 0.1, 0.02])
+    m2, s2 = np.array([1.0, 0.5, 0.1, 0.25, 2.95, -0.05]), np.array([0.5, 1.0, 0.3, 0.1, 0.05, 0.04])
+    Ks = [2] * (V - 3) + [3, 1, 0]
+    props = []
+    for K in Ks:
+        for k in range(K):
+            props.append(make(m1, s1) if k % 2 == 0 else make(m2, s2))
+    prop = np.stack(props)
+    ptr = np.concatenate([[0], np.cumsum(Ks)]).astype(np.int32); rows = np.arange(len(prop), dtype=np.int32)
+    bw = R.kde_bandwidth(prop, 0b111000)
+    bel_in = rng.standard_normal((V, 6, N))
+    got = _device_product(6, N, ptr, rows, prop, bw, bel_in, 0)
+    ref = ro.product_msgibbs(ro.make_opts(N=N, seed=11, stream_offset=5), 6, ptr, rows, prop, bw, bel_in, 0, 1)
+    assert np.isfinite(got).all()
+    dR = (Rot.from_rotvec(got.transpose(0, 2, 1).reshape(-1, 6)[:, 3:]).inv() * Rot.from_rotvec(ref.transpose(0, 2, 1).reshape(-1, 6)[:, 3:])).magnitude()
+    same = (np.abs(got[:, :3] - ref[:, :3]).max(axis=1).reshape(-1) < 1e-9) & (dR < 1e-9)
+    assert same.mean() > 0.995, same.mean()
+    assert np.array_equal(got[V - 1], bel_in[V - 1]) and np.array_equal(got[V - 2], prop[ptr[V - 2]])
+    two = got[:V - 3]
+    h = bw[:2]
+    v1, v2 = s1 ** 2 + h[0] ** 2, s2 ** 2 + h[1] ** 2
+    P = 1 / v1 + 1 / v2
+    assert np.abs(two[:, :3].mean((0, 2)) - ((m1 / v1 + m2 / v2) / P)[:3]).max() < 0.05
+    R1 = Rot.from_rotvec(m1[3:])
+    dev = (R1.inv() * Rot.from_rotvec(two.transpose(0, 2, 1).reshape(-1, 6)[:, 3:])).as_rotvec()
+    exp_dev = ((R1.inv() * Rot.from_rotvec(m2[3:])).as_rotvec() / v2[3:]) / P[3:]
+    assert np.abs(dev.mean(0) - exp_dev).max() < 0.01 and np.abs(dev.std(0) * np.sqrt(P[3:]) - 1).max() < 0.12
+    x = R.manifoldProduct(prop[:2])
+    assert x.shape == (6, N) and np.isfinite(x).all()

@@ -461,6 +461,17 @@ def test_pose3_solve_loop_on_a_small_helix():
     b2 = dg2.bel[R.Pose3].cpu().numpy()
     s1 = b2[:, :3].std(2).mean()
     assert np.isfinite(b2).all() and 0.02 < s1 < s0, (s0, s1)
+    # the same with the reference's product (manikde! bandwidths + multiscale Gibbs product on SE(3)): holds the MAP estimate too
+    dg3 = R.DeviceGraph(fg)
+    dg3.init_from_means(xp)
+    dg3.solve(R.make_opts(N=N, solver=1, seed=5), n_sweeps=6, product="gibbs")
+    b3 = dg3.bel[R.Pose3].cpu().numpy()
+    e3 = np.linalg.norm(b3[:, :3].mean(2) - mp[:, :3], axis=1)
+    assert np.isfinite(b3).all() and np.median(e3) < 0.15 and e3.max() < 0.6, (np.median(e3), e3.max())
+    for v in (0, 10, P - 1):
+        mw, _ = _so3_mean_std(b3[v, 3:])
+        assert np.linalg.norm((Rot.from_rotvec(mp[v, 3:]).inv() * Rot.from_rotvec(mw)).as_rotvec()) < 0.05
+        assert (b3[v, :3].std(1) > 1e-3).all() and (b3[v, :3].std(1) < 0.5).all()
 
 
 def test_initall_and_solvegraph_hexagonal():
