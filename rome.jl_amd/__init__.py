@@ -7,7 +7,7 @@ host-side mirror of the reference interface; it contains no compute and no CPU f
 """
 from . import _lib
 from ._lib import (Context, Opts, RomeError, SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD,
-                   LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS, MAX_PARTICLES)
+                   LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS, MAX_PARTICLES, MAX_PARTICLES_REGISTER)
 from .factors import (MvNormal, Normal, Uniform, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
                       Pose3Pose3, PriorPose3, PriorPoint2, Point2Point2, getMeasurementParametric, getPoint, getCoordinates, pack_factor,
                       unpack_factor)

@@ -14,7 +14,8 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED_N, ERR_
 SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD = 0, 1, 2
 NOISE_STANDARD_NORMALS, NOISE_MEASUREMENTS = 0, 1
 LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS = 0, 1, 2
-MAX_PARTICLES = 512
+MAX_PARTICLES = 4096            # ROME_MAX_PARTICLES (the register-resident kernels: MAX_PARTICLES_REGISTER)
+MAX_PARTICLES_REGISTER = 512
 FACTOR_PRIORPOSE2, FACTOR_POSE2POSE2, FACTOR_POSE2POINT2BR, FACTOR_PRIORPOINT2, FACTOR_POSE3POSE3, FACTOR_PRIORPOSE3 = range(6)
 
 
