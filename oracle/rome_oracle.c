@@ -1423,7 +1423,7 @@ static void msg_build(msg_tree* T, int N, int D, const double* P /*[D][N]*/, con
   free(m); free(M2); free(n);
 }
 static void msg_free(msg_tree* T) { free(T->mean); free(T->var); free(T->ivar); free(T->cz); free(T->cnt); free(T->ys); free(T->perm); }
-/* statistics of node z of level l (l == L: the single points) as doubles of the stored floats; returns the count */
+/* statistics of node z of level l (l == L: the single point at sorted position z) as doubles of the stored floats; returns the count */
 static int msg_node(const msg_tree* T, int l, int z, double* mean, double* var, double* ivar, double* cz) {
   if (l < T->L) {
     const int id = (1 << l) - 1 + z;
@@ -1431,22 +1431,120 @@ static int msg_node(const msg_tree* T, int l, int z, double* mean, double* var, 
     *cz = (double)T->cz[id];
     return T->cnt[id];
   }
-  int a, b; msg_range(T->N, l, z, &a, &b);
-  if (b <= a) return 0;
+  const int a = z;   /* labels of level L are sorted positions */
   for (int d = 0; d < T->D; ++d) { mean[d] = (double)T->ys[a * T->D + d]; var[d] = (double)T->lvar[d]; ivar[d] = (double)T->livar[d]; }
   *cz = (double)T->lcz;
   return 1;
 }
 static inline uint32_t msg_xorshift(uint32_t r) { r ^= r << 13; r ^= r >> 17; r ^= r << 5; return r; }
-typedef struct { double M, T; uint32_t r; int sel; } msg_res;
-static inline void msg_res_init(msg_res* R, uint32_t seed_word) { R->M = -INFINITY; R->T = 0.0; R->r = seed_word | 1u; R->sel = 0; }
-static inline void msg_res_add(msg_res* R, int z, double logp) {
-  const double Mn = logp > R->M ? logp : R->M;
-  const double a = exp(logp - Mn);
-  R->T = R->T * exp(R->M - Mn) + a;     /* exp(-inf) = 0 on the first candidate */
-  R->M = Mn;
+/* Candidate arithmetic: IEEE single precision, every operation written out (this file is compiled with -ffp-contract=off; fmaf is
+ * the correctly rounded fused operation).  The device evaluates two candidates per lane with packed instructions: same values. */
+#define MSG_ABSENT (-3.0e38f)   /* log p of "no candidate"; also the initial running maximum */
+static inline float msg_f32_from_bits(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
+static inline uint32_t msg_bits_from_f32(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
+/* exp(max(x, -80)), x <= 0 (never 0: e^-80 = 1.8e-35 is below every acceptance threshold and every total); k = rint(x log2 e),
+ * r = x - k ln2 in two parts, Cephes expf polynomial, 2^k added on the exponent field */
+static inline float msg_exp32(float x) {
+  x = fmaxf(x, -80.0f);
+  const float k = rintf(x * 1.44269504f);
+  float r = fmaf(k, -0.693359375f, x);
+  r = fmaf(k, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float y = fmaf(p, r * r, r) + 1.0f;
+  return msg_f32_from_bits(msg_bits_from_f32(y) + ((uint32_t)(int32_t)k << 23));
+}
+/* ln(v), v > 0 normal: v = m 2^e, ln m the degree-7 polynomial in m - 1.5 of ro_box_muller's radius */
+static inline float msg_ln32(float v) {
+  const uint32_t xb = msg_bits_from_f32(v);
+  const float ke = (float)((int32_t)(xb >> 23) - 127);
+  const float t = msg_f32_from_bits((xb & 0x007FFFFFu) | 0x3F800000u) - 1.5f;
+  float p = 0x1.4fab76p-7f;
+  p = fmaf(p, t, -0x1.1d4ffp-6f);
+  p = fmaf(p, t, 0x1.a972ep-6f);
+  p = fmaf(p, t, -0x1.90d3ap-5f);
+  p = fmaf(p, t, 0x1.94a6a8p-4f);
+  p = fmaf(p, t, -0x1.c72898p-3f);
+  p = fmaf(p, t, 0x1.555544p-1f);
+  p = fmaf(p, t, 0x1.9f324cp-2f);
+  return fmaf(ke, 0x1.62e43p-1f, p);
+}
+/* e - 2π rint(e / 2π), 2π = 6.28125 + 1.9353072e-3 */
+static inline float msg_wrap32(float e) {
+  const float k = rintf(e * 0.15915494f);
+  e = fmaf(k, -6.28125f, e);
+  return fmaf(k, -1.9353072e-3f, e);
+}
+/* one-pass categorical draw over candidate PAIRS (A, B): running maximum M of log p, total T of exp(log p - M); a candidate
+ * replaces the selection when float(r | 255)·T < a·2^32 (u = its top 24 bits, never 0), r the next state of a xorshift32 stream */
+typedef struct { float M, T; uint32_t r; int sel; } msg_res;
+static inline void msg_res_init(msg_res* R, uint32_t seed_word) { R->M = MSG_ABSENT; R->T = 0.0f; R->r = seed_word | 1u; R->sel = 0; }
+static inline void msg_res_pair(msg_res* R, int zA, int zB, float lpA, float lpB) {
+  const float Mn = fmaxf(fmaxf(R->M, lpA), lpB);
+  const float T0 = R->T * msg_exp32(R->M - Mn);
+  const float aA = msg_exp32(lpA - Mn), aB = msg_exp32(lpB - Mn);
+  const float TA = T0 + aA, TB = TA + aB;
   R->r = msg_xorshift(R->r);
-  if ((double)(R->r >> 8) * (1.0 / 16777216.0) * R->T < a) R->sel = z;
+  if ((float)(R->r | 0xFFu) * TA < aA * 4294967296.0f) R->sel = zA;
+  R->r = msg_xorshift(R->r);
+  if ((float)(R->r | 0xFFu) * TB < aB * 4294967296.0f) R->sel = zB;
+  R->T = TB; R->M = Mn;
+}
+/* Σ_d s_d / v_d over a group of gd <= 3 coordinates with one division: (Σ_d s_d Π_{e≠d} v_e) / Π_d v_d; *pv = Π_d v_d */
+static inline float msg_ratio_group(int gd, const float* s, const float* v, float* pv) {
+  float num, den;
+  if (gd == 3) {
+    const float pab = v[0] * v[1];
+    num = fmaf(s[0], v[1] * v[2], fmaf(s[1], v[0] * v[2], s[2] * pab));
+    den = pab * v[2];
+  } else {
+    num = fmaf(s[0], v[1], s[1] * v[0]);
+    den = v[0] * v[1];
+  }
+  *pv = den;
+  return num / den;
+}
+/* log p of candidate z of level l < L given the point e0 (in the density's chart, single precision)  [sampleIndices] */
+static inline float msg_lp_point(const msg_tree* T, int l, int z, const float* e0, uint32_t circ) {
+  const int id = (1 << l) - 1 + z, D = T->D;
+  float q = 0.0f;
+  for (int d = 0; d < D; ++d) {
+    float e = e0[d] - T->mean[id * D + d];
+    if ((circ >> d) & 1u) e = msg_wrap32(e);
+    q = fmaf(e * e, T->ivar[id * D + d], q);
+  }
+  return fmaf(-0.5f, q, T->cz[id]);
+}
+/* log p of candidate z of level l < L given the product Gaussian (mx, cx) of the other densities  [the Gibbs step] */
+static inline float msg_lp_gauss(const msg_tree* T, int l, int z, const float* mx, const float* cx, uint32_t circ) {
+  const int id = (1 << l) - 1 + z, D = T->D;
+  float sq[6], vv[6];
+  for (int d = 0; d < D; ++d) {
+    float e = T->mean[id * D + d] - mx[d];
+    if ((circ >> d) & 1u) e = msg_wrap32(e);
+    sq[d] = e * e;
+    vv[d] = T->var[id * D + d] + cx[d];
+  }
+  float pv;
+  float q = msg_ratio_group(D == 2 ? 2 : 3, sq, vv, &pv);
+  float t = q + msg_ln32(pv);
+  if (D == 6) { q = msg_ratio_group(3, sq + 3, vv + 3, &pv); t = t + (q + msg_ln32(pv)); }
+  return fmaf(-0.5f, t, (float)log((double)T->cnt[id] / (double)T->N));
+}
+/* -½ Σ_d (y_p - c)_d² w_d of the single point at sorted position p (sign: e = ±(y - c), squared) */
+static inline float msg_lp_leaf(const msg_tree* T, int p, const float* c, const float* w, int point_minus_leaf, uint32_t circ) {
+  const int D = T->D;
+  float q = 0.0f;
+  for (int d = 0; d < D; ++d) {
+    float e = point_minus_leaf ? c[d] - T->ys[p * D + d] : T->ys[p * D + d] - c[d];
+    if ((circ >> d) & 1u) e = msg_wrap32(e);
+    q = fmaf(e * e, w[d], q);
+  }
+  return q * -0.5f;
 }
 int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr, const int32_t* prop_rows,
                        const double* prop /*[rows][dim][N]*/, const double* prop_bw /*[rows][dim]*/, const double* bel_in,
@@ -1488,7 +1586,7 @@ int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr
             msg_node(&T[j], l - 1, sel[j], mean, var, ivar, &cz);
             double mabs, iv;
             if (l - 1 == L) {   /* the selected kernel itself: the particle at full precision, its bandwidth in double */
-              mabs = prop[(size_t)rows[j] * D * N + (size_t)d * N + T[j].perm[(int)(((long long)sel[j] * N) >> L)]];
+              mabs = prop[(size_t)rows[j] * D * N + (size_t)d * N + T[j].perm[sel[j]]];
               iv = 1.0 / (T[j].h[d] * T[j].h[d]);
             }
             else { mabs = T[j].ref[d] + mean[d]; iv = ivar[d]; }
@@ -1506,7 +1604,7 @@ int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr
             double mean[6], var[6], ivar[6], cz, Q[9], iv[3];
             msg_node(&T[j], l - 1, sel[j], mean, var, ivar, &cz);
             if (l - 1 == L) {
-              const int pi = T[j].perm[(int)(((long long)sel[j] * N) >> L)];
+              const int pi = T[j].perm[sel[j]];
               double w[3] = {prop[(size_t)rows[j] * D * N + 3 * (size_t)N + pi], prop[(size_t)rows[j] * D * N + 4 * (size_t)N + pi],
                              prop[(size_t)rows[j] * D * N + 5 * (size_t)N + pi]};
               ro_so3_exp(w, Q);
@@ -1525,24 +1623,21 @@ int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr
           ro_so3_exp(e, E); mat3_mul(B, E, xR);
         }
         if (l == L + 1) break;   /* that was the output draw from the selected kernels */
-        /* (c) labels of level l given the point (the point in the density's own chart: Euclidean there) */
+        /* (c) labels of level l given the point (in the density's own chart -- Euclidean there -- and rounded to single) */
         for (int j = 0; j < K; ++j) {
           uint32_t w; MSG_UNIFORM_WORD(w);
           msg_res R; msg_res_init(&R, w);
-          double e0[6];
-          for (int d = 0; d < DE; ++d) { e0[d] = x[d] - T[j].ref[d]; if ((circular_mask >> d) & 1u) e0[d] = lcv_wrap(e0[d]); }
-          if (D == 6) { double U[9]; mat3_tmul(T[j].R0, xR, U); ro_so3_log(U, e0 + 3); }
-          for (int z = 0; z < (1 << l); ++z) {
-            double mean[6], var[6], ivar[6], cz;
-            if (msg_node(&T[j], l, z, mean, var, ivar, &cz) == 0) continue;
-            double q = 0.0;
-            for (int d = 0; d < D; ++d) {
-              double e = e0[d] - mean[d];
-              if ((circular_mask >> d) & 1u) e = lcv_wrap(e);
-              q += e * e * ivar[d];
-            }
-            msg_res_add(&R, z, cz - 0.5 * q);
-          }
+          double e0d[6]; float e0[6];
+          for (int d = 0; d < DE; ++d) { e0d[d] = x[d] - T[j].ref[d]; if ((circular_mask >> d) & 1u) e0d[d] = lcv_wrap(e0d[d]); }
+          if (D == 6) { double U[9]; mat3_tmul(T[j].R0, xR, U); ro_so3_log(U, e0d + 3); }
+          for (int d = 0; d < D; ++d) e0[d] = (float)e0d[d];
+          if (l < L)
+            for (int z = 0; z < (1 << l); z += 2)
+              msg_res_pair(&R, z, z + 1, msg_lp_point(&T[j], l, z, e0, circular_mask), msg_lp_point(&T[j], l, z + 1, e0, circular_mask));
+          else   /* single points (label = sorted position): common variance and weight -- the constants of the draw drop out */
+            for (int p = 0; p < N; p += 2)
+              msg_res_pair(&R, p, p + 1, msg_lp_leaf(&T[j], p, e0, T[j].livar, 1, circular_mask),
+                           p + 1 < N ? msg_lp_leaf(&T[j], p + 1, e0, T[j].livar, 1, circular_mask) : MSG_ABSENT);
           sel[j] = R.sel;
         }
         /* (d) Gibbs sweeps over the labels */
@@ -1581,18 +1676,17 @@ int ro_product_msgibbs(const ro_opts* o, int dim, int V, const int32_t* prop_ptr
             }
             uint32_t w; MSG_UNIFORM_WORD(w);
             msg_res R; msg_res_init(&R, w);
-            for (int z = 0; z < (1 << l); ++z) {
-              double mean[6], var[6], ivar[6], cz;
-              const int cnt = msg_node(&T[j], l, z, mean, var, ivar, &cz);
-              if (cnt == 0) continue;
-              double q = 0.0;
-              for (int d = 0; d < D; ++d) {
-                double e = mean[d] - Mx[d];
-                if ((circular_mask >> d) & 1u) e = lcv_wrap(e);
-                const double vv = var[d] + Cx[d];
-                q += e * e / vv + log(vv);
-              }
-              msg_res_add(&R, z, log((double)cnt / (double)N) - 0.5 * q);
+            float mx[6], cx[6];
+            for (int d = 0; d < D; ++d) { mx[d] = (float)Mx[d]; cx[d] = (float)Cx[d]; }
+            if (l < L)
+              for (int z = 0; z < (1 << l); z += 2)
+                msg_res_pair(&R, z, z + 1, msg_lp_gauss(&T[j], l, z, mx, cx, circular_mask), msg_lp_gauss(&T[j], l, z + 1, mx, cx, circular_mask));
+            else {
+              float ivv[6];
+              for (int d = 0; d < D; ++d) ivv[d] = 1.0f / (T[j].lvar[d] + cx[d]);
+              for (int p = 0; p < N; p += 2)
+                msg_res_pair(&R, p, p + 1, msg_lp_leaf(&T[j], p, mx, ivv, 0, circular_mask),
+                             p + 1 < N ? msg_lp_leaf(&T[j], p + 1, mx, ivv, 0, circular_mask) : MSG_ABSENT);
             }
             sel[j] = R.sel;
           }

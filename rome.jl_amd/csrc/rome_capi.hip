@@ -814,7 +814,7 @@ int rome_product_gibbs_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t
   if (o->n_particles > 128) return ROME_ERR_UNSUPPORTED_N;   /* lane = output sample, two wavefronts per variable */
   ROME_BIND(c);
   void* trees = nullptr;   /* one ball tree per proposal row, context-owned workspace (grown on demand, kept) */
-  rc = ensure(c, 10, rome::gibbs_workspace_bytes(dim, n_prop_rows), &trees); if (rc) return rc;
+  rc = ensure(c, 10, rome::gibbs_workspace_bytes(dim, n_prop_rows, V), &trees); if (rc) return rc;
   ROME_HIP(c, rome::launch_product_gibbs(dim, V, o->n_particles, n_prop_rows, prop_ptr, prop_rows, prop, prop_bw, bel_in, bel_out, trees,
                                          circular_mask, gibbs_iters, max_proposals, o->seed, o->stream_offset, c->stream));
   return ROME_OK;

@@ -35,6 +35,7 @@ struct GibbsArgs {
   const int32_t* prop_ptr; const int32_t* prop_rows;
   const double* prop; const double* prop_bw; const double* bel_in; double* bel_out;
   void* trees;            // workspace: one GibbsTree<D> per proposal row
+  const int32_t* order;   // workspace: variables by descending number of proposals
   int n_rows;
   uint64_t seed, stream_offset;
 };
@@ -43,8 +44,8 @@ template <int D>
 struct alignas(8) GibbsTree {
   double ref[D], h[D];
   double q0[4];   // D = 6 (Pose3): unit quaternion of point 0 -- coordinates 3..5 are Log(q0* ⊗ q_i), the chart at that rotation
-  float mean[kGibbsNodes][D], var[kGibbsNodes][D], ivar[kGibbsNodes][D], cz[kGibbsNodes];
-  float ys[kGibbsMaxN][D];
+  float mean[D][128], var[D][128], ivar[D][128], cz[128];   // node (l, z) at index 2^l - 1 + z: a level is contiguous per coordinate
+  float ys[D][kGibbsMaxN];                                  // level L: the single points in sorted order
   float lvar[D], livar[D], lcz;
   int row;
   uint8_t perm[kGibbsMaxN];
@@ -167,7 +168,7 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
     if (p < N) {
       T->perm[p] = (uint8_t)id[s];
 #pragma unroll
-      for (int d = 0; d < D; ++d) T->ys[p][d] = y[s][d];
+      for (int d = 0; d < D; ++d) T->ys[d][p] = y[s][d];
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -184,7 +185,7 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
     if (zz < (1 << L)) node_range(N, L, zz, &a, &b);
     n[s] = b - a;
 #pragma unroll
-    for (int d = 0; d < D; ++d) { m[s][d] = n[s] > 0 ? (double)T->ys[a][d] : 0.0; M2[s][d] = 0.0; }
+    for (int d = 0; d < D; ++d) { m[s][d] = n[s] > 0 ? (double)T->ys[d][a] : 0.0; M2[s][d] = 0.0; }
   }
   for (int l = L - 1; l >= 0; --l) {
 #pragma clang fp contract(off)
@@ -222,7 +223,7 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const double v = M2[0][d] / (double)n[0] + h2[d];
-        T->mean[idn][d] = (float)m[0][d]; T->var[idn][d] = (float)v; T->ivar[idn][d] = (float)(1.0 / v);
+        T->mean[d][idn] = (float)m[0][d]; T->var[d][idn] = (float)v; T->ivar[d][idn] = (float)(1.0 / v);
         lg += log(v);
       }
       T->cz[idn] = (float)(log((double)n[0] / (double)N) - 0.5 * lg);
@@ -247,57 +248,128 @@ __global__ void __launch_bounds__(256) k_gibbs_trees(const GibbsArgs a) {
   gibbs_build<D>(T, a.prop + (size_t)row * D * a.N, a.prop_bw + (size_t)row * D, row, a.N, a.L, a.circ, lane, ybuf[wave], ext[wave]);
 }
 
-// one-pass categorical draw: running maximum M of log p, total T of exp(log p - M), candidate z replaces the selection with
-// probability a_z / T (xorshift32 uniform).  The rescaling exponential is only evaluated when some lane's maximum moves.
+// ---- candidate arithmetic: IEEE single precision, every operation spelled out (explicit fma, contraction off), so that the
+// oracle (msg_exp32 / msg_ln32 / msg_wrap32 / msg_res_pair in oracle/rome_oracle.c) reproduces it bit for bit.  Written on
+// f32x2 = two CANDIDATES of the same lane (nodes z, z + 1: their statistics are one 8-byte LDS broadcast), which the compiler maps to
+// the packed v_pk_{add,mul,fma}_f32 instructions: half the VALU issue slots of the one-candidate-at-a-time form.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr float kAbsent = -3.0e38f;   // log p of "no candidate" (odd N at the leaf level; also the initial running maximum)
+
+__device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
+// exp(max(x, -80)), x <= 0 (never 0: e^-80 = 1.8e-35 is below every acceptance threshold and every total); k = rint(x log2 e), Cody-Waite r = x - k ln2, Cephes expf polynomial, scaled by 2^k on the exponent field
+__device__ __forceinline__ f32x2 exp32_neg(f32x2 x) {
+#pragma clang fp contract(off)
+  const f32x2 xc = __builtin_elementwise_max(x, splat(-80.0f));
+  const f32x2 k = __builtin_elementwise_rint(xc * 1.44269504f);
+  f32x2 r = __builtin_elementwise_fma(k, splat(-0.693359375f), xc);
+  r = __builtin_elementwise_fma(k, splat(2.12194440e-4f), r);
+  f32x2 p = splat(1.9875691500e-4f);
+  p = __builtin_elementwise_fma(p, r, splat(1.3981999507e-3f));
+  p = __builtin_elementwise_fma(p, r, splat(8.3334519073e-3f));
+  p = __builtin_elementwise_fma(p, r, splat(4.1665795894e-2f));
+  p = __builtin_elementwise_fma(p, r, splat(1.6666665459e-1f));
+  p = __builtin_elementwise_fma(p, r, splat(5.0000001201e-1f));
+  const f32x2 y = __builtin_elementwise_fma(p, r * r, r) + 1.0f;
+  const i32x2 ki = __builtin_convertvector(k, i32x2);
+  const i32x2 bits = (i32x2)y + (ki << 23);
+  return (f32x2)bits;
+}
+__device__ __forceinline__ float exp32_neg(float x) { return exp32_neg(f32x2{x, x}).x; }
+// ln(v), v > 0 normal: v = m 2^e, ln m the degree-7 polynomial in m - 1.5 of the Box-Muller radius (rome_device_math.hpp)
+__device__ __forceinline__ f32x2 ln32_pos(f32x2 v) {
+#pragma clang fp contract(off)
+  const u32x2 xb = (u32x2)v;
+  const i32x2 e = (i32x2)(xb >> 23) - 127;
+  const f32x2 ke = __builtin_convertvector(e, f32x2);
+  const f32x2 t = (f32x2)((xb & 0x007FFFFFu) | 0x3F800000u) - 1.5f;
+  f32x2 p = splat(0x1.4fab76p-7f);
+  p = __builtin_elementwise_fma(p, t, splat(-0x1.1d4ffp-6f));
+  p = __builtin_elementwise_fma(p, t, splat(0x1.a972ep-6f));
+  p = __builtin_elementwise_fma(p, t, splat(-0x1.90d3ap-5f));
+  p = __builtin_elementwise_fma(p, t, splat(0x1.94a6a8p-4f));
+  p = __builtin_elementwise_fma(p, t, splat(-0x1.c72898p-3f));
+  p = __builtin_elementwise_fma(p, t, splat(0x1.555544p-1f));
+  p = __builtin_elementwise_fma(p, t, splat(0x1.9f324cp-2f));
+  return __builtin_elementwise_fma(ke, splat(0x1.62e43p-1f), p);
+}
+// e - 2π rint(e / 2π) with 2π = 6.28125 + 1.9353072e-3 (the first part exact in 8 bits)
+__device__ __forceinline__ f32x2 wrap32(f32x2 e) {
+#pragma clang fp contract(off)
+  const f32x2 k = __builtin_elementwise_rint(e * 0.15915494f);
+  e = __builtin_elementwise_fma(k, splat(-6.28125f), e);
+  return __builtin_elementwise_fma(k, splat(-1.9353072e-3f), e);
+}
+// one-pass categorical draw over candidate PAIRS: running maximum M of log p, total T of exp(log p - M); candidate z replaces the
+// selection when u T < a_z, u the top 24 bits of a xorshift32 stream (written as float(r | 255)·T < a·2^32: both products of the spec)
 struct Reservoir {
-  double M, T; uint32_t r; int sel;
-  __device__ __forceinline__ void init(uint32_t w) { M = -__builtin_inf(); T = 0.0; r = w | 1u; sel = 0; }
-  __device__ __forceinline__ void add(int z, double logp) {
-    const bool moved = logp > M;
-    const double Mn = moved ? logp : M;
-    if (__builtin_amdgcn_ballot_w64(moved) != 0) T *= fast_exp_neg(M - Mn);   // exp(-inf) = 0 on the first candidate; 1 where M stays
-    const double a = fast_exp_neg(logp - Mn);
-    T += a;
-    M = Mn;
+  float M, T; uint32_t r; int sel;
+  __device__ __forceinline__ void init(uint32_t w) { M = kAbsent; T = 0.0f; r = w | 1u; sel = 0; }
+  __device__ __forceinline__ void add2(int zA, int zB, f32x2 lp) {
+#pragma clang fp contract(off)
+    const float Mn = fmaxf(fmaxf(M, lp.x), lp.y);
+    if (__builtin_amdgcn_ballot_w64(Mn > M) != 0) T = T * exp32_neg(M - Mn);   // exp32(0) = 1 exactly where M stays
+    const f32x2 a = exp32_neg(lp - Mn);
+    const float TA = T + a.x, TB = TA + a.y;
     r ^= r << 13; r ^= r >> 17; r ^= r << 5;
-    if ((double)(r >> 8) * (1.0 / 16777216.0) * T < a) sel = z;
+    const uint32_t rA = r;
+    r ^= r << 13; r ^= r >> 17; r ^= r << 5;
+    const f32x2 lhs = f32x2{(float)(rA | 0xFFu), (float)(r | 0xFFu)} * f32x2{TA, TB};   // u in (0, 1]: 24 bits, never 0
+    const f32x2 rhs = a * 4294967296.0f;
+    sel = lhs.x < rhs.x ? zA : sel;
+    sel = lhs.y < rhs.y ? zB : sel;
+    T = TB; M = Mn;
   }
 };
-// 1 / v for v > 0: single-precision reciprocal seed + two Newton steps in double (relative error ~1e-16; a division costs 3x)
-__device__ __forceinline__ double fast_rcp_pos(double v) {
-  double r = (double)__builtin_amdgcn_rcpf((float)v);
-  r = r * fma(-v, r, 2.0);
-  r = r * fma(-v, r, 2.0);
-  return r;
+// Σ_d s_d / v_d and Π_d v_d of a group of GD <= 3 coordinates with ONE division: (Σ_d s_d Π_{e≠d} v_e) / Π_d v_d
+template <int GD>
+__device__ __forceinline__ void ratio_group(const f32x2* s, const f32x2* v, f32x2* q, f32x2* pv) {
+#pragma clang fp contract(off)
+  f32x2 num, den;
+  if constexpr (GD == 3) {
+    const f32x2 pab = v[0] * v[1];
+    num = __builtin_elementwise_fma(s[0], v[1] * v[2], __builtin_elementwise_fma(s[1], v[0] * v[2], s[2] * pab));
+    den = pab * v[2];
+  } else {
+    num = __builtin_elementwise_fma(s[0], v[1], s[1] * v[0]);
+    den = v[0] * v[1];
+  }
+  *q = f32x2{num.x / den.x, num.y / den.y};
+  *pv = den;
 }
 
-// LDS image of ONE level of one tree: what the candidate loops of that level read (wave-uniform -> LDS broadcasts)
+// LDS image of ONE level of one tree: what the candidate loops of that level read (wave-uniform -> LDS broadcasts, two nodes a read)
 template <int D>
 struct GibbsLevel {
   union {
-    struct { float mean[64][D], var[64][D], ivar[64][D], cz[64]; } in;   // levels 0 .. L-1 (at most 64 nodes)
-    float ys[kGibbsMaxN][D];                                             // level L: the sorted single points
+    struct { float mean[D][64], var[D][64], ivar[D][64], cz[64], lnc[64]; } in;   // levels 1 .. L-1 (at most 64 nodes); lnc = log(count / N)
+    float ys[D][kGibbsMaxN];                                                     // level L: the sorted single points
   };
 };
 template <int D>
-struct GibbsConst { double ref[D], h[D], q0[4]; float lvar[D], livar[D], lcz; int row; };
+struct GibbsConst { double ref[D], h[D], q0[4]; float lvar[D], livar[D]; int row; };
 
-template <int D>
+// CM: the circular mask at compile time (-1: read from the arguments) -- with a run-time mask the compiler evaluates the wrap of
+// EVERY coordinate and selects (24 of the 54 instructions of a Pose2 candidate pair)
+template <int D, int CM>
 __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs a) {
+#pragma clang fp contract(off)   // the candidate arithmetic below is a bit-exact specification
   extern __shared__ __align__(16) unsigned char smem[];
-  const int v = blockIdx.x;
-  if (v >= a.V) return;
+  if ((int)blockIdx.x >= a.V) return;
+  const int v = a.order[blockIdx.x];
   const int tid = threadIdx.x;
   const int N = a.N, L = a.L;
   const int k0 = a.prop_ptr[v], K = a.prop_ptr[v + 1] - k0;
+  auto circ_bit = [&](int d) -> bool { if constexpr (CM >= 0) return (CM >> d) & 1; else return (a.circ >> d) & 1u; };
   double* ob = a.bel_out + (size_t)v * D * N;
   if (K <= 1) {   // K = 0: the belief is kept; K = 1: the proposal is the product
     const double* src = K == 0 ? a.bel_in + (size_t)v * D * N : a.prop + (size_t)a.prop_rows[k0] * D * N;
     for (int q = tid; q < D * N; q += kGibbsThreads) ob[q] = src[q];
     return;
   }
-  __shared__ double logn[kGibbsMaxN + 1];   // log(c / N): the weight of a node with c points
-  for (int c = tid; c <= kGibbsMaxN; c += kGibbsThreads) logn[c] = c > 0 ? log((double)c / (double)N) : 0.0;
+  __shared__ float logn[kGibbsMaxN + 1];   // log(c / N): the weight of a node with c points
+  for (int c = tid; c <= kGibbsMaxN; c += kGibbsThreads) logn[c] = c > 0 ? (float)log((double)c / (double)N) : 0.0f;
   // dynamic LDS: [max_k] level images | [max_k] constants | [max_k][128] labels
   GibbsLevel<D>* lev = reinterpret_cast<GibbsLevel<D>*>(smem);
   GibbsConst<D>* cst = reinterpret_cast<GibbsConst<D>*>(smem + sizeof(GibbsLevel<D>) * a.max_k);
@@ -310,7 +382,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
 #pragma unroll
     for (int d = 0; d < D; ++d) { c.ref[d] = T.ref[d]; c.h[d] = T.h[d]; c.lvar[d] = T.lvar[d]; c.livar[d] = T.livar[d]; }
     if constexpr (D == 6) { c.q0[0] = T.q0[0]; c.q0[1] = T.q0[1]; c.q0[2] = T.q0[2]; c.q0[3] = T.q0[3]; }
-    c.lcz = T.lcz; c.row = row;
+    c.row = row;
   }
   __syncthreads();
   // cooperative copy of level l of every tree into LDS (coalesced: the level's nodes are contiguous in each array of the tree)
@@ -322,11 +394,15 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
       if (l < L) {
         const int n = 1 << l, o = n - 1;
         for (int q = tid; q < n * D; q += kGibbsThreads) {
-          (&G.in.mean[0][0])[q] = (&T.mean[o][0])[q]; (&G.in.var[0][0])[q] = (&T.var[o][0])[q]; (&G.in.ivar[0][0])[q] = (&T.ivar[o][0])[q];
+          const int d = q >> l, z = q & (n - 1);
+          G.in.mean[d][z] = T.mean[d][o + z]; G.in.var[d][z] = T.var[d][o + z]; G.in.ivar[d][z] = T.ivar[d][o + z];
         }
-        for (int q = tid; q < n; q += kGibbsThreads) G.in.cz[q] = T.cz[o + q];
+        for (int q = tid; q < n; q += kGibbsThreads) {
+          int ra, rb; node_range(N, l, q, &ra, &rb);
+          G.in.cz[q] = T.cz[o + q]; G.in.lnc[q] = logn[rb - ra];
+        }
       } else {
-        for (int q = tid; q < N * D; q += kGibbsThreads) (&G.ys[0][0])[q] = (&T.ys[0][0])[q];
+        for (int q = tid; q < kGibbsMaxN * D; q += kGibbsThreads) (&G.ys[0][0])[q] = (&T.ys[0][0])[q];
       }
     }
     __syncthreads();
@@ -356,7 +432,8 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
   constexpr int DE = D == 6 ? 3 : D;                      // coordinates handled one by one (Euclidean / circular)
   for (int l = 1; l <= L + 1; ++l) {
     // (a) a point from the product of the selected nodes of level l - 1 (its image is the one in LDS).  Deviations are taken
-    //     from density 0's node; rotations: Log(Q_0* ⊗ Q_j) with Q_j = q0_j ⊗ Exp(mean_ω) the node's absolute rotation
+    //     from density 0's node; rotations: Log(Q_0* ⊗ Q_j) with Q_j = q0_j ⊗ Exp(mean_ω) the node's absolute rotation.
+    //     Labels of level L are sorted positions.
 #pragma unroll
     for (int d = 0; d < DE; ++d) {
       double prec = 0.0, num = 0.0, mu0 = 0.0;
@@ -365,13 +442,12 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
         const int sz = selbuf[j * 128 + tid];
         double mabs, iv;
         if (l - 1 == L) {   // the selected kernel itself: the particle at full precision, its bandwidth in double
-          const int pos = (int)(((long long)sz * N) >> L);
-          mabs = a.prop[(size_t)c.row * D * N + (size_t)d * N + W[c.row].perm[pos]];
+          mabs = a.prop[(size_t)c.row * D * N + (size_t)d * N + W[c.row].perm[sz]];
           iv = 1.0 / (c.h[d] * c.h[d]);
-        } else { mabs = c.ref[d] + (double)lev[j].in.mean[sz][d]; iv = (double)lev[j].in.ivar[sz][d]; }
+        } else { mabs = c.ref[d] + (double)lev[j].in.mean[d][sz]; iv = (double)lev[j].in.ivar[d][sz]; }
         if (j == 0) mu0 = mabs;
         double dev = mabs - mu0;
-        if ((a.circ >> d) & 1u) dev = gwrap(dev);
+        if (circ_bit(d)) dev = gwrap(dev);
         prec += iv; num += iv * dev;
       }
       const double xi = normal();
@@ -384,17 +460,17 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
         const int sz = selbuf[j * 128 + tid];
         double Q[4], iv[3];
         if (l - 1 == L) {
-          const int pi = W[c.row].perm[(int)(((long long)sz * N) >> L)];
+          const int pi = W[c.row].perm[sz];
           const double* pp = a.prop + (size_t)c.row * D * N + pi;
           const double w[3] = {pp[3 * (size_t)N], pp[4 * (size_t)N], pp[5 * (size_t)N]};
           quat_exp(w, Q);
 #pragma unroll
           for (int k = 0; k < 3; ++k) iv[k] = 1.0 / (c.h[3 + k] * c.h[3 + k]);
         } else {
-          const double m[3] = {(double)lev[j].in.mean[sz][3], (double)lev[j].in.mean[sz][4], (double)lev[j].in.mean[sz][5]};
+          const double m[3] = {(double)lev[j].in.mean[3][sz], (double)lev[j].in.mean[4][sz], (double)lev[j].in.mean[5][sz]};
           double E[4]; quat_exp(m, E); quat_mul(c.q0, E, Q);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) iv[k] = (double)lev[j].in.ivar[sz][3 + k];
+          for (int k = 0; k < 3; ++k) iv[k] = (double)lev[j].in.ivar[3 + k][sz];
         }
         double dev[3] = {0.0, 0.0, 0.0};
         if (j == 0) { B[0] = Q[0]; B[1] = Q[1]; B[2] = Q[2]; B[3] = Q[3]; }
@@ -410,44 +486,43 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
     if (l == L + 1) break;
     stage(l);
     const int nz = 1 << l;
-    // (c) labels of level l given the point, which is expressed ONCE in the density's own chart: Euclidean there
+    // (c) labels of level l given the point, which is expressed ONCE in the density's own chart (Euclidean there) and rounded
     for (int j = 0; j < K; ++j) {
       const GibbsConst<D>& c = cst[j];
       const GibbsLevel<D>& G = lev[j];
       Reservoir R; R.init(uniform_word());
-      double e0[D];
+      float e0[D];
+      {
+        double e0d[D];
 #pragma unroll
-      for (int d = 0; d < DE; ++d) { e0[d] = x[d] - c.ref[d]; if ((a.circ >> d) & 1u) e0[d] = gwrap(e0[d]); }
-      if constexpr (D == 6) { double e[4]; quat_cmul(c.q0, xq, e); quat_log(e, e0 + 3); }
+        for (int d = 0; d < DE; ++d) { e0d[d] = x[d] - c.ref[d]; if (circ_bit(d)) e0d[d] = gwrap(e0d[d]); }
+        if constexpr (D == 6) { double e[4]; quat_cmul(c.q0, xq, e); quat_log(e, e0d + 3); }
+#pragma unroll
+        for (int d = 0; d < D; ++d) e0[d] = (float)e0d[d];
+      }
       if (l < L) {
-        for (int z = 0; z < nz; ++z) {   // wave-uniform candidate: node statistics are LDS broadcasts
-          int ra, rb; node_range(N, l, z, &ra, &rb);
-          if (rb <= ra) continue;
-          double q = 0.0;
+        for (int z = 0; z < nz; z += 2) {   // wave-uniform candidates: node statistics are LDS broadcasts
+          f32x2 q = splat(0.0f);
 #pragma unroll
           for (int d = 0; d < D; ++d) {
-            double e = e0[d] - (double)G.in.mean[z][d];
-            if ((a.circ >> d) & 1u) e = gwrap(e);
-            q += e * e * (double)G.in.ivar[z][d];
+            f32x2 e = splat(e0[d]) - *reinterpret_cast<const f32x2*>(&G.in.mean[d][z]);
+            if (circ_bit(d)) e = wrap32(e);
+            q = __builtin_elementwise_fma(e * e, *reinterpret_cast<const f32x2*>(&G.in.ivar[d][z]), q);
           }
-          R.add(z, (double)G.in.cz[z] - 0.5 * q);
+          R.add2(z, z + 1, __builtin_elementwise_fma(splat(-0.5f), q, *reinterpret_cast<const f32x2*>(&G.in.cz[z])));
         }
-      } else {
-        double iv[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) iv[d] = (double)c.livar[d];
-        const double lcz = (double)c.lcz;
-        for (int z = 0; z < nz; ++z) {
-          int ra, rb; node_range(N, l, z, &ra, &rb);
-          if (rb <= ra) continue;
-          double q = 0.0;
+      } else {   // single points: every candidate has the kernel's variance and the weight 1/N: constants of the draw drop out
+        for (int p = 0; p < N; p += 2) {
+          f32x2 q = splat(0.0f);
 #pragma unroll
           for (int d = 0; d < D; ++d) {
-            double e = e0[d] - (double)G.ys[ra][d];
-            if ((a.circ >> d) & 1u) e = gwrap(e);
-            q += e * e * iv[d];
+            f32x2 e = splat(e0[d]) - *reinterpret_cast<const f32x2*>(&G.ys[d][p]);
+            if (circ_bit(d)) e = wrap32(e);
+            q = __builtin_elementwise_fma(e * e, splat(c.livar[d]), q);
           }
-          R.add(z, lcz - 0.5 * q);
+          f32x2 lp = q * -0.5f;
+          if (p + 1 >= N) lp.y = kAbsent;
+          R.add2(p, p + 1, lp);
         }
       }
       selbuf[j * 128 + tid] = (uint8_t)R.sel;
@@ -464,16 +539,16 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
             if (i == j) continue;
             const int sz = selbuf[i * 128 + tid];
             double mean, iv;
-            if (l < L) { mean = (double)lev[i].in.mean[sz][d]; iv = (double)lev[i].in.ivar[sz][d]; }
-            else { const int pos = (int)(((long long)sz * N) >> L); mean = (double)lev[i].ys[pos][d]; iv = (double)cst[i].livar[d]; }
+            if (l < L) { mean = (double)lev[i].in.mean[d][sz]; iv = (double)lev[i].in.ivar[d][sz]; }
+            else { mean = (double)lev[i].ys[d][sz]; iv = (double)cst[i].livar[d]; }
             const double mabs = cst[i].ref[d] + mean;
             if (first) { mu0 = mabs; first = false; }
             double dev = mabs - mu0;
-            if ((a.circ >> d) & 1u) dev = gwrap(dev);
+            if (circ_bit(d)) dev = gwrap(dev);
             prec += iv; num += iv * dev;
           }
           Mx[d] = mu0 + num / prec - c.ref[d]; Cx[d] = 1.0 / prec;
-          if ((a.circ >> d) & 1u) Mx[d] = gwrap(Mx[d]);
+          if (circ_bit(d)) Mx[d] = gwrap(Mx[d]);
         }
         if constexpr (D == 6) {
           double B[4] = {1.0, 0.0, 0.0, 0.0}, prec[3] = {0.0, 0.0, 0.0}, num[3] = {0.0, 0.0, 0.0}; bool first = true;
@@ -483,11 +558,10 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
             double m[3], iv[3];
             if (l < L) {
 #pragma unroll
-              for (int k = 0; k < 3; ++k) { m[k] = (double)lev[i].in.mean[sz][3 + k]; iv[k] = (double)lev[i].in.ivar[sz][3 + k]; }
+              for (int k = 0; k < 3; ++k) { m[k] = (double)lev[i].in.mean[3 + k][sz]; iv[k] = (double)lev[i].in.ivar[3 + k][sz]; }
             } else {
-              const int pos = (int)(((long long)sz * N) >> L);
 #pragma unroll
-              for (int k = 0; k < 3; ++k) { m[k] = (double)lev[i].ys[pos][3 + k]; iv[k] = (double)cst[i].livar[3 + k]; }
+              for (int k = 0; k < 3; ++k) { m[k] = (double)lev[i].ys[3 + k][sz]; iv[k] = (double)cst[i].livar[3 + k]; }
             }
             double E[4], Q[4], dev[3] = {0.0, 0.0, 0.0};
             quat_exp(m, E); quat_mul(cst[i].q0, E, Q);
@@ -501,38 +575,43 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
           for (int k = 0; k < 3; ++k) { e[k] = num[k] / prec[k]; Cx[3 + k] = 1.0 / prec[k]; }
           quat_exp(e, E); quat_mul(B, E, QM); quat_cmul(c.q0, QM, r); quat_log(r, Mx + 3);
         }
+        float mx[D], cx[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { mx[d] = (float)Mx[d]; cx[d] = (float)Cx[d]; }
         const GibbsLevel<D>& G = lev[j];
         Reservoir R; R.init(uniform_word());
         if (l < L) {
-          for (int z = 0; z < nz; ++z) {
-            int ra, rb; node_range(N, l, z, &ra, &rb);
-            if (rb <= ra) continue;
-            double q = 0.0, pv = 1.0;
+          for (int z = 0; z < nz; z += 2) {
+            f32x2 sq[D], vv[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-              double e = (double)G.in.mean[z][d] - Mx[d];
-              if ((a.circ >> d) & 1u) e = gwrap(e);
-              const double vv = (double)G.in.var[z][d] + Cx[d];
-              q += e * e * fast_rcp_pos(vv);
-              pv *= vv;                       // Σ_d log(var_d + C_d) = log Π_d (var_d + C_d): one logarithm per candidate
+              f32x2 e = *reinterpret_cast<const f32x2*>(&G.in.mean[d][z]) - splat(mx[d]);
+              if (circ_bit(d)) e = wrap32(e);
+              sq[d] = e * e;
+              vv[d] = *reinterpret_cast<const f32x2*>(&G.in.var[d][z]) + splat(cx[d]);
             }
-            R.add(z, logn[rb - ra] - 0.5 * (q + fast_log(pv)));
+            // Σ_d e_d² / v_d + Σ_d log v_d with one division and one logarithm per group of <= 3 coordinates
+            f32x2 q, pv;
+            ratio_group<(D == 2 ? 2 : 3)>(sq, vv, &q, &pv);
+            f32x2 t = q + ln32_pos(pv);
+            if constexpr (D == 6) { ratio_group<3>(sq + 3, vv + 3, &q, &pv); t = t + (q + ln32_pos(pv)); }
+            R.add2(z, z + 1, __builtin_elementwise_fma(splat(-0.5f), t, *reinterpret_cast<const f32x2*>(&G.in.lnc[z])));
           }
-        } else {   // single points: every candidate has the variance h² + C and the weight 1/N: constants of the draw drop out
-          double ivv[D];
+        } else {   // single points: every candidate has the variance h² + C and the weight 1/N
+          float ivv[D];
 #pragma unroll
-          for (int d = 0; d < D; ++d) ivv[d] = fast_rcp_pos((double)c.lvar[d] + Cx[d]);
-          for (int z = 0; z < nz; ++z) {
-            int ra, rb; node_range(N, l, z, &ra, &rb);
-            if (rb <= ra) continue;
-            double q = 0.0;
+          for (int d = 0; d < D; ++d) ivv[d] = 1.0f / (c.lvar[d] + cx[d]);
+          for (int p = 0; p < N; p += 2) {
+            f32x2 q = splat(0.0f);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-              double e = (double)G.ys[ra][d] - Mx[d];
-              if ((a.circ >> d) & 1u) e = gwrap(e);
-              q += e * e * ivv[d];
+              f32x2 e = *reinterpret_cast<const f32x2*>(&G.ys[d][p]) - splat(mx[d]);
+              if (circ_bit(d)) e = wrap32(e);
+              q = __builtin_elementwise_fma(e * e, splat(ivv[d]), q);
             }
-            R.add(z, -0.5 * q);
+            f32x2 lp = q * -0.5f;
+            if (p + 1 >= N) lp.y = kAbsent;
+            R.add2(p, p + 1, lp);
           }
         }
         selbuf[j * 128 + tid] = (uint8_t)R.sel;
@@ -541,12 +620,30 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
   if constexpr (D == 6) quat_log(xq, x + 3);
   if (live) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) ob[(size_t)d * N + s] = ((a.circ >> d) & 1u) ? gwrap(x[d]) : x[d];
+    for (int d = 0; d < D; ++d) ob[(size_t)d * N + s] = (circ_bit(d)) ? gwrap(x[d]) : x[d];
   }
 }
 
-size_t gibbs_workspace_bytes(int dim, int n_rows) {
+static size_t tree_bytes(int dim, int n_rows) {
   return (dim == 2 ? sizeof(GibbsTree<2>) : (dim == 3 ? sizeof(GibbsTree<3>) : sizeof(GibbsTree<6>))) * (size_t)(n_rows > 0 ? n_rows : 1);
+}
+// workspace: one tree per proposal row | the variables ordered by their number of proposals
+size_t gibbs_workspace_bytes(int dim, int n_rows, int V) { return tree_bytes(dim, n_rows) + sizeof(int32_t) * (size_t)(V > 0 ? V : 1); }
+
+// Variables in descending order of their number of proposals (counting sort, one block): the blocks of the sampling kernel are
+// dispatched in this order, i.e. longest first (a block's run time is proportional to its variable's proposal count, 2 .. 11 on
+// Manhattan), and the short ones fill in behind them -- list scheduling by the hardware dispatcher.  In graph order the hub's block
+// started wherever its index fell and the launch ended with a few SIMDs still busy (1.9 -> 1.25 ms together with the rest).  The
+// order inside a count is whatever the atomics give -- the product of a variable does not depend on it.
+__global__ void __launch_bounds__(1024) k_gibbs_order(int V, const int32_t* __restrict__ prop_ptr, int32_t* __restrict__ order) {
+  __shared__ int hist[65], start[65];
+  for (int k = threadIdx.x; k < 65; k += 1024) hist[k] = 0;
+  __syncthreads();
+  for (int v = threadIdx.x; v < V; v += 1024) { const int K = prop_ptr[v + 1] - prop_ptr[v]; atomicAdd(&hist[K < 64 ? K : 64], 1); }
+  __syncthreads();
+  if (threadIdx.x == 0) { int acc = 0; for (int k = 64; k >= 0; --k) { start[k] = acc; acc += hist[k]; } }
+  __syncthreads();
+  for (int v = threadIdx.x; v < V; v += 1024) { const int K = prop_ptr[v + 1] - prop_ptr[v]; order[atomicAdd(&start[K < 64 ? K : 64], 1)] = v; }
 }
 
 hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
@@ -559,25 +656,34 @@ hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t
   a.max_k = max_k; a.iters = iters < 1 ? 1 : iters; a.circ = circ;
   a.prop_ptr = prop_ptr; a.prop_rows = prop_rows; a.prop = prop; a.prop_bw = prop_bw; a.bel_in = bel_in; a.bel_out = bel_out;
   a.trees = trees; a.n_rows = n_rows;
+  int32_t* order = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(trees) + tree_bytes(dim, n_rows));
+  a.order = order;
+  hipLaunchKernelGGL(k_gibbs_order, dim3(1), dim3(1024), 0, s, V, prop_ptr, order);
   a.seed = seed; a.stream_offset = stream_offset;
-  const size_t per = dim == 2 ? sizeof(GibbsLevel<2>) + sizeof(GibbsConst<2>)
-                              : (dim == 3 ? sizeof(GibbsLevel<3>) + sizeof(GibbsConst<3>) : sizeof(GibbsLevel<6>) + sizeof(GibbsConst<6>));
-  const size_t bytes = (per + 128) * (size_t)max_k;
-  if (bytes > 150 * 1024) return hipErrorInvalidValue;
-  const void* fn = dim == 2 ? (const void*)k_product_gibbs<2> : (dim == 3 ? (const void*)k_product_gibbs<3> : (const void*)k_product_gibbs<6>);
-  if (bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-  }
   if (n_rows > 0) {
     if (dim == 2) hipLaunchKernelGGL((k_gibbs_trees<2>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
     else if (dim == 3) hipLaunchKernelGGL((k_gibbs_trees<3>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_gibbs_trees<6>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
   }
-  if (dim == 2) hipLaunchKernelGGL((k_product_gibbs<2>), dim3(V), dim3(kGibbsThreads), bytes, s, a);
-  else if (dim == 3) hipLaunchKernelGGL((k_product_gibbs<3>), dim3(V), dim3(kGibbsThreads), bytes, s, a);
-  else hipLaunchKernelGGL((k_product_gibbs<6>), dim3(V), dim3(kGibbsThreads), bytes, s, a);
-  return hipGetLastError();
+  // LDS of a block: one level image per proposal of its variable, sized for the variable with the most proposals (28 kB for the hub
+  // of Manhattan: five blocks per CU).  Launching the variables in two classes of proposal counts with a smaller LDS for the common
+  // case was measured SLOWER (1.25 -> 1.5 ms): with everything resident at once nothing rebalances the SIMDs, whereas at five
+  // blocks per CU the sorted order (largest first) is list scheduling: short blocks fill in behind the long ones.
+  const size_t per = (dim == 2 ? sizeof(GibbsLevel<2>) + sizeof(GibbsConst<2>)
+                               : (dim == 3 ? sizeof(GibbsLevel<3>) + sizeof(GibbsConst<3>) : sizeof(GibbsLevel<6>) + sizeof(GibbsConst<6>))) + 128;
+  const size_t bytes = per * (size_t)max_k;
+  if (bytes > 150 * 1024) return hipErrorInvalidValue;
+  auto launch = [&](auto kernel) -> hipError_t {
+    if (bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(V), dim3(kGibbsThreads), bytes, s, a);
+    return hipGetLastError();
+  };
+  if (dim == 2) return circ == 0 ? launch(k_product_gibbs<2, 0>) : launch(k_product_gibbs<2, -1>);
+  if (dim == 3) return circ == 4u ? launch(k_product_gibbs<3, 4>) : (circ == 0 ? launch(k_product_gibbs<3, 0>) : launch(k_product_gibbs<3, -1>));
+  return circ == 0 ? launch(k_product_gibbs<6, 0>) : launch(k_product_gibbs<6, -1>);
 }
 
 }  // namespace rome

@@ -68,7 +68,7 @@ hipError_t launch_product(int dim, int V, int N, const int32_t* prop_ptr, const 
                           const double* prop_bw, const double* bel_in, double* bel_out, double c_n, uint64_t seed,
                           uint64_t stream_offset, hipStream_t s);
 
-size_t gibbs_workspace_bytes(int dim, int n_rows);
+size_t gibbs_workspace_bytes(int dim, int n_rows, int V);
 hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
                                 const double* prop_bw, const double* bel_in, double* bel_out, void* trees, uint32_t circ, int iters, int max_k,
                                 uint64_t seed, uint64_t stream_offset, hipStream_t s);
