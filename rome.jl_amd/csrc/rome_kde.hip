@@ -114,10 +114,13 @@ __device__ __forceinline__ double lcv_golden(const double (&x)[S], const bool (&
 // ------------------------------------------------------------------------------------------------------------------------------
 // Fast path, N <= 128 (two particles per lane): the same golden-section search -- bracket arithmetic in double, identical iterates --
 // with the likelihood evaluated in single precision on the hardware exponential:
-//   * row sums: particle i adds exp2(a2 d_ij²) over the N-1 others, j = i+1 .. i+N-1 read from a DOUBLED copy of the particles in
-//     LDS (p32d[j] = p32d[j+N]: no index wrap, lane-consecutive addresses, constant offsets; the j = i term never occurs, so an
-//     isolated particle's tiny sum is not cancelled against a self term).  Per term: f32 subtract, two multiplies, v_exp_f32,
-//     accumulate (8-term single-precision partials folded into double sums); no exchange of symmetric terms, no fences.
+//   * row sums: particle i adds exp2(a2 d_ij²) over the N-1 others, j = i+1 .. i+N-1 (mod N), read from an array of partner PAIRS
+//     in LDS, q[m] = (y[m mod N], y[(m+64) mod N]): the partners of a lane's two particles at ring distance k are the one 8-byte
+//     word q[lane + k] -- no index wrap, lane-consecutive addresses, constant offsets; the j = i term never occurs, so an isolated
+//     particle's tiny sum is not cancelled against a self term.  Per term: f32 subtract, two multiplies, v_exp_f32, accumulate
+//     (8-term single-precision partials folded into double sums); no exchange of symmetric terms, no fences.  Issue cost on
+//     gfx950 (scripts/ubench/ubench32: plain f32 VALU 2.5 cycles per wave, packed f32 5.0 -- the same rate per element --
+//     v_exp_f32 8.25): 40 cycles per term of two pairs, 16.5 of them the two exponentials;
 //     The particles are staged as single-precision offsets from particle 0 (a fixed 6e-8·range perturbation of the data, the same
 //     for every h);
 //   * Euclidean stopping rules (>= 1e-2): a golden-section step only COMPARES two likelihoods; when they differ by less than
@@ -132,15 +135,16 @@ __device__ __forceinline__ double lcv_golden(const double (&x)[S], const bool (&
 constexpr double kTieEps = 3e-5;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool CIRC>
-__device__ __forceinline__ void lcv_eval32(const f32x2 xi, const bool act0, const bool act1, const float* __restrict__ b0,
-                                           const float* __restrict__ b1, int N, double h, double* negll, double* g) {
-  // b0 / b1: p32d + (own index of slot 0 / 1): the other particles are b[1] .. b[N-1]
+template <bool CIRC, bool WITH_T>
+__device__ __forceinline__ void lcv_eval32(const f32x2 xi, const bool act0, const bool act1, const f32x2* __restrict__ q, int N, double h,
+                                           double* negll, double* g) {
+  // q: the wave's pair array + lane: q[k] = (particle lane + k, particle lane + 64 + k), indices modulo N -- the partners of the
+  // lane's two particles at ring distance k = 1 .. N-1, ONE 8-byte read per term.  WITH_T: also T_i = Σ_j w_ij d_ij² (the
+  // derivative g; only the finish of the fine stopping rules reads it: 5 of the 45 issue cycles of a term)
   const float a2 = (float)(-0.72134752044448170368 / (h * h));   // -½ log2(e) / h²
   double S0 = 0.0, S1 = 0.0;
   f32x2 T = {0.0f, 0.0f};
-  auto term = [&](float x0, float x1, f32x2& ps) {
-    f32x2 xj = {x0, x1};
+  auto term = [&](const f32x2 xj, f32x2& ps) {
     f32x2 d = xi - xj;
     if (CIRC) {
       d.x = fmaf(-6.2831853071795865f, rintf(d.x * 0.15915494309189535f), d.x);
@@ -150,28 +154,30 @@ __device__ __forceinline__ void lcv_eval32(const f32x2 xi, const bool act0, cons
     f32x2 w = d2 * a2;
     w.x = __builtin_amdgcn_exp2f(w.x); w.y = __builtin_amdgcn_exp2f(w.y);
     ps += w;
-    T = __builtin_elementwise_fma(w, d2, T);
+    if (WITH_T) T = __builtin_elementwise_fma(w, d2, T);
   };
   const int M = N - 1, M8 = M & ~7;
   int k = 1;
   for (; k <= M8; k += 8) {
     f32x2 ps = {0.0f, 0.0f};
 #pragma unroll
-    for (int u = 0; u < 8; ++u) term(b0[k + u], b1[k + u], ps);
+    for (int u = 0; u < 8; ++u) term(q[k + u], ps);
     S0 += (double)ps.x; S1 += (double)ps.y;
   }
   {
     f32x2 ps = {0.0f, 0.0f};
-    for (; k <= M; ++k) term(b0[k], b1[k], ps);
+    for (; k <= M; ++k) term(q[k], ps);
     S0 += (double)ps.x; S1 += (double)ps.y;
   }
   double ll = 0.0, gg = 0.0;
-  if (act0) { const double s = fmax(S0, 1e-300); ll += fast_log(s); gg += (double)T.x / s; }
-  if (act1) { const double s = fmax(S1, 1e-300); ll += fast_log(s); gg += (double)T.y / s; }
-  double v[2] = {ll, gg};
-  wave_sum_n<2>(v);
-  *negll = -(v[0] - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528));
-  *g = v[1] - (double)N * h * h;
+  if (act0) { const double s = fmax(S0, 1e-300); ll += fast_log(s); if (WITH_T) gg += (double)T.x / s; }
+  if (act1) { const double s = fmax(S1, 1e-300); ll += fast_log(s); if (WITH_T) gg += (double)T.y / s; }
+  if (WITH_T) {
+    double v[2] = {ll, gg};
+    wave_sum_n<2>(v);
+    ll = v[0]; *g = v[1] - (double)N * h * h;
+  } else { ll = wave_sum(ll); *g = 0.0; }
+  *negll = -(ll - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528));
 }
 
 // g(h) = Σ_i T_i/S_i − N h² in double precision (row sums over the double-precision particles in LDS, j = i skipped): ONE such
@@ -210,8 +216,8 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
     if (CIRC) { y0 = lcv_wrap(y0); y1 = lcv_wrap(y1); }
     ylo = fmin(fmin(ylo, y0), y1); yhi = fmax(fmax(yhi, y0), y1);   // idle slots hold particle 0: y = 0
     xi.x = (float)y0; xi.y = (float)y1;
-    if (act[0]) { p32d[lane] = xi.x; p32d[lane + N] = xi.x; }
-    if (act[1]) { p32d[lane + 64] = xi.y; p32d[lane + 64 + N] = xi.y; }
+    p32d[384 + lane] = xi.x;                       // (64 < N: every lane has a first particle)
+    if (act[1]) p32d[384 + lane + 64] = xi.y;
   }
   for (int j = 0; j < N; ++j) {
     const double xj = pts[j];
@@ -223,8 +229,11 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-  const float* b0 = p32d + (act[0] ? lane : 0);
-  const float* b1 = p32d + (act[1] ? lane + 64 : 0);
+  f32x2* qa = reinterpret_cast<f32x2*>(p32d);     // pair array: qa[m] = (y[m mod N], y[(m + 64) mod N]), m < 192
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { const int m = lane + 64 * r; qa[m] = f32x2{p32d[384 + m % N], p32d[384 + (m + 64) % N]}; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  const f32x2* q = qa + lane;
   mn = wave_min(mn); ylo = wave_min(ylo); yhi = -wave_min(-yhi);
   const double minm = fmax(mn, 1e-6), maxm = fmax(yhi - ylo, minm);
   const double ax = 2.0 * minm / (double)(N - 1), bx = 0.5 * (minm + maxm), cx = 2.0 * maxm;
@@ -233,10 +242,13 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
   if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + Cg * (cx - bx); }
   else { x2 = bx; x1 = bx - Cg * (bx - ax); }
   double f1, f2, g1, g2;
-  lcv_eval32<CIRC>(xi, act[0], act[1], b0, b1, N, x1, &f1, &g1);
-  lcv_eval32<CIRC>(xi, act[0], act[1], b0, b1, N, x2, &f2, &g2);
-  int ne = 2;
   const bool finish = tol < 1e-2;          // finer than the golden section is run in single precision: finish on the derivative
+  auto eval = [&](double hh, double* f, double* gd) {
+    if (finish) lcv_eval32<CIRC, true>(xi, act[0], act[1], q, N, hh, f, gd); else lcv_eval32<CIRC, false>(xi, act[0], act[1], q, N, hh, f, gd);
+  };
+  eval(x1, &f1, &g1);
+  eval(x2, &f2, &g2);
+  int ne = 2;
   const double tol_gs = finish ? 1e-2 : tol;
   while (fabs(x3 - x0) > tol_gs * (fabs(x1) + fabs(x2)) && ne < 200) {
     bool lower2 = f2 < f1;
@@ -244,8 +256,8 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
       const double e1 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x1), e2 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x2);
       lower2 = e2 < e1;
     }
-    if (lower2) { x0 = x1; x1 = x2; x2 = Rg * x1 + Cg * x3; f1 = f2; g1 = g2; lcv_eval32<CIRC>(xi, act[0], act[1], b0, b1, N, x2, &f2, &g2); }
-    else        { x3 = x2; x2 = x1; x1 = Rg * x2 + Cg * x0; f2 = f1; g2 = g1; lcv_eval32<CIRC>(xi, act[0], act[1], b0, b1, N, x1, &f1, &g1); }
+    if (lower2) { x0 = x1; x1 = x2; x2 = Rg * x1 + Cg * x3; f1 = f2; g1 = g2; eval(x2, &f2, &g2); }
+    else        { x3 = x2; x2 = x1; x1 = Rg * x2 + Cg * x0; f2 = f1; g2 = g1; eval(x1, &f1, &g1); }
     ++ne;
   }
   double best = f1 < f2 ? x1 : x2;
@@ -264,7 +276,7 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
       const double hc = hb - gb * (hb - ha) / den;
       if (!(hc > lo && hc < hi)) break;
       double fc, gc;
-      lcv_eval32<CIRC>(xi, act[0], act[1], b0, b1, N, hc, &fc, &gc);
+      eval(hc, &fc, &gc);
       ++ne;
       const bool done = fabs(hc - hb) <= tol * fabs(hc);
       ha = hb; ga = gb; hb = hc; gb = gc;
@@ -288,7 +300,7 @@ __global__ void __launch_bounds__(64 * kKdeWaves) k_kde_bandwidth(int T, int dim
                                                                   double* __restrict__ bw, int32_t* __restrict__ evals) {
   __shared__ double pts[kKdeWaves][64 * S];
   __shared__ double wex[kKdeWaves][64 * S];   // per-wave exchange row of the symmetric likelihood evaluation
-  __shared__ float p32buf[kKdeWaves][S == 2 ? 256 : 1];   // fast path: particles as single-precision offsets from particle 0, twice
+  __shared__ __align__(8) float p32buf[kKdeWaves][S == 2 ? 512 : 2];   // fast path: 192 partner pairs (single-precision offsets from particle 0) | the 128 offsets
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = blockIdx.x * kKdeWaves + wave;
   if (t >= T) return;   // wave-uniform; nothing below synchronises across waves
