@@ -26,10 +26,13 @@ class OracleDG:
                                      mu=mu, L=np.array([ro.cholesky_lower(c) for c in cov]), alt=None, w=None)
         if pk.br["F"]:
             b = pk.br; r0 = b["rows0"]; Fb = b["F"]
-            self.tabs["br1"] = dict(n=Fb, fn="br1", vt_fixed=R.Point2, vt_target=R.Pose2, dir_all=1, mu=b["mu"], L=b["sigma"], alt=None, w=None,
+            mh = bool((b["alt"] >= 0).any())   # multihypo: alternative landmark per row (-1: none), P(primary) per row
+            self.tabs["br1"] = dict(n=Fb, fn="br1", vt_fixed=R.Point2, vt_target=R.Pose2, dir_all=1, mu=b["mu"], L=b["sigma"],
+                                    alt=i32(b["alt"]) if mh else None, w=np.asarray(b["w"], dtype=np.float64) if mh else None,
                                     rows4=i32(np.stack([np.arange(Fb), np.ones(Fb), b["point"], b["pose"]], axis=1)))
             self.tabs["br0"] = dict(n=len(r0["factor"]), fn="br0", vt_fixed=R.Pose2, vt_target=R.Point2, dir_all=0, mu=b["mu"], L=b["sigma"],
-                                    alt=None, w=None, rows4=i32(np.stack([r0["factor"], np.zeros(len(r0["factor"])), r0["pose"], r0["point"]], axis=1)))
+                                    alt=i32(r0["alt"]) if mh else None, w=np.asarray(r0["w"], dtype=np.float64) if mh else None,
+                                    rows4=i32(np.stack([r0["factor"], np.zeros(len(r0["factor"])), r0["pose"], r0["point"]], axis=1)))
 
     def families(self):
         return [f for f in ("p2p2", "br1", "br0") if f in self.tabs]
@@ -43,6 +46,8 @@ class OracleDG:
         out, mu, L = kw["out"], kw["mu"], kw["L"]
         bf, bt = kw["bel_fixed"], kw["bel_target"]
         mirror_rows, mirror_out = kw.get("mirror_row", ()), kw.get("mirror_out")
+        alt = kw["alt_var"].numpy() if kw.get("alt_var") is not None else None
+        hw = np.asarray(kw["hypo_w"], dtype=np.float64) if kw.get("hypo_w") is not None else None
         base = int(opts.stream_offset) if opts is not None else 0
         seed = self.seed
 
@@ -58,7 +63,8 @@ class OracleDG:
                     else:
                         res[k] = ro.conv_pose2pose2(o, mu, L, bf.numpy(), [fv], [tv], [d], factor=[f])[0]
                 else:
-                    res[k] = ro.conv_pose2point2br(o, 1 if fn == "br1" else 0, mu, L, bf.numpy(), bt.numpy(), [fv], [tv], factor=[f])[0]
+                    mhkw = {} if alt is None else dict(alt_var=[int(alt[k])], hypo_w=[float(hw[k])])
+                    res[k] = ro.conv_pose2point2br(o, 1 if fn == "br1" else 0, mu, L, bf.numpy(), bt.numpy(), [fv], [tv], factor=[f], **mhkw)[0]
             out.copy_(torch.as_tensor(res))
             for m, r in enumerate(mirror_rows):
                 blk = out[r].reshape(-1)

@@ -201,6 +201,9 @@ def _br_segment(R, rank, N):
     sight = [("x1", "l0"), ("x2", "l0"), ("x4", "l1"), ("x6", "l1"), ("x9", "l2"), ("x10", "l2"), ("x11", "ghost_lm"), ("x3", "ghost_lm")]
     for xp, lm in sight:
         fg.addFactor([xp, lm], R.Pose2Point2BearingRange(R.Normal(float(rng.uniform(-1, 1)), 0.03), R.Normal(float(rng.uniform(3, 8)), 0.5)))
+    # a data-association ambiguity whose alternative is the GHOST landmark (IIF multihypo, test/testMultimodalRangeBearing.jl:53): the
+    # alternative column of both bearing-range tables must follow the ghost into the receive buffers
+    fg.addFactor(["x7", "l1", "ghost_lm"], R.Pose2Point2BearingRange(R.Normal(0.3, 0.03), R.Normal(5.0, 0.5)), multihypo=[1.0, 0.6, 0.4])
     R.dead_reckon_init(fg, seed=3 + rank)
     for j, l in enumerate(["l0", "l1", "l2", "ghost_lm"]):
         fg.initVariable(l, np.array([[2.0 + 3 * j], [4.0]]) + rng.standard_normal((2, N)))
@@ -265,8 +268,9 @@ def test_separator_pipeline_bearing_range_two_ranks_matches_emulation():
             for f in d.families():
                 tb = d.family_table(f)
                 out = torch.zeros((tb["n"], tb["vt_target"].dim, N), dtype=torch.float64)
+                mh = {} if tb["alt"] is None else dict(alt_var=tb["alt"], hypo_w=tb["w"])
                 d._plan(tb["fn"], ro.make_opts(N=N, stream_offset=r << 32), rows4=tb["rows4"], mu=tb["mu"], L=tb["L"],
-                        bel_fixed=bel[tb["vt_fixed"]], bel_target=bel[tb["vt_target"]], out=out)()
+                        bel_fixed=bel[tb["vt_fixed"]], bel_target=bel[tb["vt_target"]], out=out, **mh)()
                 outs[f] = out.numpy()
             hist[r].append(outs)
     for r in range(world):
