@@ -82,6 +82,45 @@ def test_device_equals_oracle_sample_by_sample(dim, N, iters):
     assert np.array_equal(got[3], prop[rows[ptr[3]]])          # K = 1: the proposal itself (AMP returns it unchanged)
 
 
+@pytest.mark.parametrize("dim,N,circ", [(3, 99, 0b011), (3, 33, 0), (2, 101, 0b10), (2, 1, 0), (3, 1, 0b100), (3, 3, 0b100)])
+def test_unusual_masks_odd_counts_and_single_particles(dim, N, circ):
+    """The kernels are instantiated for the circular masks of the variable types (none; Pose2's heading) and once per dimension for
+    any other mask read at run time; odd N leaves the last candidate pair of the leaf level half empty; N = 1 has no tree levels."""
+    rng = np.random.default_rng(1000 * dim + 10 * N + circ)
+    Ks = [2, 3, 1, 0, 6, 2]
+    ptr, rows, prop = _problem(dim, N, Ks, rng, False)
+    for d in range(dim):
+        if (circ >> d) & 1:
+            prop[:, d] = np.arctan2(np.sin(prop[:, d] + 3.0), np.cos(prop[:, d] + 3.0))
+    bw = rng.uniform(0.05, 0.4, (len(prop), dim))
+    bel_in = rng.standard_normal((len(Ks), dim, N))
+    got = _device_product(dim, N, ptr, rows, prop, bw, bel_in, circ, 1)
+    ref = ro.product_msgibbs(ro.make_opts(N=N, seed=11, stream_offset=5), dim, ptr, rows, prop, bw, bel_in, circ, 1)
+    assert np.isfinite(got).all()
+    d = got - ref
+    for k in range(dim):
+        if (circ >> k) & 1:
+            d[:, k] = np.arctan2(np.sin(d[:, k]), np.cos(d[:, k]))
+    assert (np.abs(d).max(axis=1) < 1e-9).mean() > 0.99
+
+
+def test_proposals_far_apart_stay_finite_and_equal_the_oracle():
+    """Proposals hundreds of bandwidths apart: every candidate weight of a draw underflows against the running maximum (the
+    clamped exponential); the draw must still follow the oracle and stay finite -- the product sits between the proposals."""
+    rng = np.random.default_rng(5)
+    N, V = 100, 40
+    prop = np.empty((2 * V, 3, N))
+    prop[0::2] = np.array([0.0, 0.0, 0.0])[None, :, None] + 0.05 * rng.standard_normal((V, 3, N))
+    prop[1::2] = np.array([40.0, -25.0, 1.0])[None, :, None] + 0.05 * rng.standard_normal((V, 3, N))
+    bw = np.full((2 * V, 3), 0.03)
+    ptr = np.arange(0, 2 * V + 1, 2, dtype=np.int32); rows = np.arange(2 * V, dtype=np.int32)
+    got = _device_product(3, N, ptr, rows, prop, bw, np.zeros((V, 3, N)), 0b100)
+    ref = ro.product_msgibbs(ro.make_opts(N=N, seed=11, stream_offset=5), 3, ptr, rows, prop, bw, np.zeros((V, 3, N)), 0b100, 1)
+    assert np.isfinite(got).all()
+    assert (np.abs(got - ref).max(axis=1) < 1e-9).mean() > 0.99
+    assert np.abs(got[:, 0].mean() - 20.0) < 1.0 and np.abs(got[:, 1].mean() + 12.5) < 1.0
+
+
 def test_product_of_gaussian_densities_has_the_gaussian_product_moments():
     rng = np.random.default_rng(7)
     N, V = 100, 300
