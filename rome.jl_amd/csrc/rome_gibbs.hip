@@ -6,20 +6,21 @@
 // with RoME); the definition, step by step, is ro_product_msgibbs in oracle/rome_oracle.c and
 // the two are compared sample by sample (tests/test_gpu_gibbs.py).  Random and unseeded upstream: pinned statistically only.
 //
-// Mapping on gfx950: two kernels.
-//   build   k_gibbs_trees: one wavefront per proposal (four per block) writes the proposal's ball tree (6.8 kB for Pose2) to a
+// Mapping on gfx950: three kernels.
+//   build   k_gibbs_trees: one wavefront per proposal (four per block) writes the proposal's ball tree (6.9 kB for Pose2) to a
 //           workspace in HBM -- every proposal feeds exactly one product.  A tree is built top-down by sorting:
 //           at level l every node re-sorts its index range along its widest coordinate -- ONE 128-key bitonic sort of the whole
 //           wavefront per level with the key (node, coordinate, id): sorting by node first keeps every point inside its node's
 //           range, so the nodes of a level are sorted simultaneously (segment extents by LDS integer min/max atomics).
 //           Node statistics bottom-up by Chan's pairwise update with the children fetched by lane shuffles (same arithmetic
-//           order as the oracle), stored in single precision as offsets from the proposal's point 0.
-//   sample  k_product_gibbs: one 128-thread block per variable, lane = output sample (N <= 128).  Every categorical draw walks the
-//           candidates of a level with WAVE-UNIFORM node statistics -- scalar loads of the tree through the scalar cache / L2, no LDS
-//           copy of the trees (with them in LDS a hub variable with 11 proposals pinned 81 kB and the whole launch ran at one
-//           block per CU: 10.3 ms per Manhattan sweep; from HBM/L2: see profiles/) -- against the lane's own point / product
-//           Gaussian: no divergence; one-pass reservoir selection (running max of log p, rescaled total) driven by a xorshift32
-//           stream seeded from one Philox word.  LDS: 128 label bytes per proposal.
+//           order as the oracle), stored in single precision as offsets from the proposal's point 0, [coordinate][node].
+//   order   k_gibbs_order: the variables by descending number of proposals (one block, counting sort) -- the dispatch order of
+//   sample  k_product_gibbs: one 128-thread block per variable, lane = output sample (N <= 128).  The current level of every tree
+//           of the variable is staged in LDS (2.8 kB per tree; the whole trees would pin 81 kB for a hub variable with 11
+//           proposals); every categorical draw walks the candidates of a level two at a time with WAVE-UNIFORM node statistics
+//           (8-byte LDS broadcasts) against the lane's own point / product Gaussian: no divergence; one-pass reservoir selection
+//           (running max of log p, rescaled total) driven by a xorshift32 stream seeded from one Philox word.  The candidate
+//           arithmetic is an exact single-precision specification shared with the oracle (below).
 #include "rome_device_math.hpp"
 #include "rome_kernels.h"
 
