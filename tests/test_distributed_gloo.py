@@ -116,7 +116,7 @@ def _OracleDG(R, fg, stream_base):
     return dg
 
 
-def _pipe_worker(rank, world, port, ret):
+def _pipe_worker(rank, world, port, ret, depth=2, steps=5):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -130,9 +130,9 @@ def _pipe_worker(rank, world, port, ret):
         sep_rows = [1, 2 * (40 - 2)]       # x0 <- (x0->x1, dir 1) ; x39 <- (x38->x39, dir 0)
         import oracle as ro
         pipe = PipelinedSegmentSweep(dg, ro.make_opts(N=N, stream_offset=rank << 32), dist, world, rank, sep_rows,
-                                     pk.index["ghost_prev"], pk.index["ghost_next"])
+                                     pk.index["ghost_prev"], pk.index["ghost_next"], depth=depth)
         hist = []
-        for k in range(5):
+        for k in range(steps):
             pipe.step()
             hist.append(pipe.prop.clone())
         pipe.drain()
@@ -142,11 +142,12 @@ def _pipe_worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(600)
-def test_pipelined_segment_sweep_two_ranks_matches_single_process_emulation():
-    world = 2
+@pytest.mark.parametrize("world,depth,steps", [(2, 2, 5), (3, 4, 9)])
+def test_pipelined_segment_sweep_two_ranks_matches_single_process_emulation(world, depth, steps):
     mgr = mp.Manager(); ret = mgr.dict()
-    mp.spawn(_pipe_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
-    # single-process emulation of the same schedule: sweep k of rank r reads the separators its neighbours produced in sweep k-2
+    mp.spawn(_pipe_worker, args=(world, _free_port(), ret, depth, steps), nprocs=world, join=True)
+    # single-process emulation of the same schedule: sweep k of rank r reads the separators its neighbours produced in sweep k-depth
+    # (bench.py runs four slots on more than two ranks)
     sys.path.insert(0, ROOT)
     import rome_jl_amd as R
     N = 16
@@ -157,13 +158,13 @@ def test_pipelined_segment_sweep_two_ranks_matches_single_process_emulation():
     sep_rows = [1, 2 * (40 - 2)]
     init_ghost = [(d.bel[R.Pose2][d.packed.index["ghost_prev"]].clone(), d.bel[R.Pose2][d.packed.index["ghost_next"]].clone()) for d in dgs]
     props = [[] for _ in range(world)]
-    for k in range(5):
+    for k in range(steps):
         for r, d in enumerate(dgs):
             pk = d.packed
             store = d.bel[R.Pose2].clone()
-            if k >= 2:
-                store[pk.index["ghost_prev"]] = torch.as_tensor(props[(r - 1) % world][k - 2][sep_rows[1]])
-                store[pk.index["ghost_next"]] = torch.as_tensor(props[(r + 1) % world][k - 2][sep_rows[0]])
+            if k >= depth:
+                store[pk.index["ghost_prev"]] = torch.as_tensor(props[(r - 1) % world][k - depth][sep_rows[1]])
+                store[pk.index["ghost_next"]] = torch.as_tensor(props[(r + 1) % world][k - depth][sep_rows[0]])
             else:
                 store[pk.index["ghost_prev"]], store[pk.index["ghost_next"]] = init_ghost[r]
             tb = d.family_table("p2p2")
@@ -173,10 +174,10 @@ def test_pipelined_segment_sweep_two_ranks_matches_single_process_emulation():
                     bel_fixed=store, bel_target=store, out=out)()
             props[r].append(out.numpy())
     for r in range(world):
-        for k in range(5):
+        for k in range(steps):
             assert np.array_equal(ret[r][k], props[r][k]), (r, k)
-    # the cut factors really see the neighbour: sweep 2 differs from what the initial ghosts would give
-    assert not np.array_equal(ret[0][2], ret[0][0])
+    # the cut factors really see the neighbour: sweep `depth` differs from what the initial ghosts would give
+    assert not np.array_equal(ret[0][depth], ret[0][0])
 
 
 # ---------------------------------------------------------------------------------------------------------
