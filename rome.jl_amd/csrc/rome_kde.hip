@@ -112,81 +112,34 @@ __device__ __forceinline__ double lcv_golden(const double (&x)[S], const bool (&
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Fast path, N <= 128 (two particles per lane): the same golden-section search -- bracket arithmetic in double, identical iterates --
-// with the likelihood evaluated in single precision on the hardware exponential:
-//   * row sums: particle i adds exp2(a2 d_ij²) over the N-1 others, j = i+1 .. i+N-1 (mod N), read from an array of partner PAIRS
-//     in LDS, q[m] = (y[m mod N], y[(m+64) mod N]): the partners of a lane's two particles at ring distance k are the one 8-byte
-//     word q[lane + k] -- no index wrap, lane-consecutive addresses, constant offsets; the j = i term never occurs, so an isolated
-//     particle's tiny sum is not cancelled against a self term.  Per term: f32 subtract, two multiplies, v_exp_f32, accumulate
-//     (8-term single-precision partials folded into double sums); no exchange of symmetric terms, no fences.  Issue cost on
-//     gfx950 (scripts/ubench/ubench32: plain f32 VALU 2.5 cycles per wave, packed f32 5.0 -- the same rate per element --
-//     v_exp_f32 8.25): 40 cycles per term of two pairs, 16.5 of them the two exponentials;
-//     The particles are staged as single-precision offsets from particle 0 (a fixed 6e-8·range perturbation of the data, the same
-//     for every h);
+// Fast path, 64 < N <= 128 (k_kde_bandwidth_fast): the same golden-section search -- bracket arithmetic in double, identical
+// iterates -- with the likelihood evaluated in single precision on the hardware exponential:
+//   * row sums by the blocked symmetric scheme below (lcv_eval_blk): every unordered pair of particles is evaluated once.  The
+//     particles are staged as single-precision offsets from particle 0 (a fixed 6e-8·range perturbation of the data, the same for
+//     every h).  Issue costs on gfx950 (scripts/ubench/ubench32, profiles/r02_ubench_f32_issue.txt): plain f32 VALU 2.5 cycles per
+//     wave64, packed f32 5.0 (the same rate per element), v_exp_f32 8.25, f64 fma 5.8;
 //   * Euclidean stopping rules (>= 1e-2): a golden-section step only COMPARES two likelihoods; when they differ by less than
 //     kTieEps (30x the single-precision noise of a likelihood) both are re-evaluated in double precision (lcv_negll), so every
 //     decision is the double-precision one and the iterates are the oracle's;
 //   * finer stopping rules (the 1e-6 of circular coordinates): the golden section stops at a 1e-2 bracket and the search finishes
-//     on the DERIVATIVE, g(h) = Σ_i T_i/S_i − N h² = 0 with T_i = Σ_j w_ij d_ij² (accumulated in the same pass), by secant steps.
-//     The zero of g is conditioned like 1e-7/curvature in single precision, whereas comparing likelihood VALUES 1e-6 apart needs
-//     double precision: the 33 double-precision evaluations of a heading become ~15 + 3 single-precision ones, and a near-tie
-//     decision of the golden section cannot hurt (the secant may leave the last bracket by its width).
-// Measured (scripts/kde_profile.py, profiles/r02_kde_bandwidth.txt).
+//     on the DERIVATIVE, g(h) = Σ_i T_i/S_i − N h² = 0 with T_i = Σ_j w_ij d_ij² (accumulated in the same pass): secant steps in
+//     single precision down to 1e-4, then ONE Newton step with g and g' evaluated in double precision (lcv_g64).  Comparing
+//     likelihood VALUES 1e-6 apart needs double precision throughout: the 33 double-precision evaluations of a heading become
+//     ~17 + 2 single-precision ones + 1, and a near-tie decision of the golden section cannot hurt (the secant may leave the last
+//     bracket by its width).
+// History of the evaluation (proposals of a Manhattan sweep, profiles/r02_kde_bandwidth.txt): double precision with symmetric LDS
+// exchange 6.6 ms; single-precision ring over ordered pairs 2.2 -> 1.8 ms; blocked symmetric 1.55 ms.
 constexpr double kTieEps = 3e-5;
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool CIRC, bool WITH_T>
-__device__ __forceinline__ void lcv_eval32(const f32x2 xi, const bool act0, const bool act1, const f32x2* __restrict__ q, int N, double h,
-                                           double* negll, double* g) {
-  // q: the wave's pair array + lane: q[k] = (particle lane + k, particle lane + 64 + k), indices modulo N -- the partners of the
-  // lane's two particles at ring distance k = 1 .. N-1, ONE 8-byte read per term.  WITH_T: also T_i = Σ_j w_ij d_ij² (the
-  // derivative g; only the finish of the fine stopping rules reads it: 5 of the 45 issue cycles of a term)
-  const float a2 = (float)(-0.72134752044448170368 / (h * h));   // -½ log2(e) / h²
-  double S0 = 0.0, S1 = 0.0;
-  f32x2 T = {0.0f, 0.0f};
-  auto term = [&](const f32x2 xj, f32x2& ps) {
-    f32x2 d = xi - xj;
-    if (CIRC) {
-      d.x = fmaf(-6.2831853071795865f, rintf(d.x * 0.15915494309189535f), d.x);
-      d.y = fmaf(-6.2831853071795865f, rintf(d.y * 0.15915494309189535f), d.y);
-    }
-    const f32x2 d2 = d * d;
-    f32x2 w = d2 * a2;
-    w.x = __builtin_amdgcn_exp2f(w.x); w.y = __builtin_amdgcn_exp2f(w.y);
-    ps += w;
-    if (WITH_T) T = __builtin_elementwise_fma(w, d2, T);
-  };
-  const int M = N - 1, M8 = M & ~7;
-  int k = 1;
-  for (; k <= M8; k += 8) {
-    f32x2 ps = {0.0f, 0.0f};
-#pragma unroll
-    for (int u = 0; u < 8; ++u) term(q[k + u], ps);
-    S0 += (double)ps.x; S1 += (double)ps.y;
-  }
-  {
-    f32x2 ps = {0.0f, 0.0f};
-    for (; k <= M; ++k) term(q[k], ps);
-    S0 += (double)ps.x; S1 += (double)ps.y;
-  }
-  double ll = 0.0, gg = 0.0;
-  if (act0) { const double s = fmax(S0, 1e-300); ll += fast_log(s); if (WITH_T) gg += (double)T.x / s; }
-  if (act1) { const double s = fmax(S1, 1e-300); ll += fast_log(s); if (WITH_T) gg += (double)T.y / s; }
-  if (WITH_T) {
-    double v[2] = {ll, gg};
-    wave_sum_n<2>(v);
-    ll = v[0]; *g = v[1] - (double)N * h * h;
-  } else { ll = wave_sum(ll); *g = 0.0; }
-  *negll = -(ll - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528));
-}
-
-// g(h) = Σ_i T_i/S_i − N h² in double precision (row sums over the double-precision particles in LDS, j = i skipped): ONE such
-// evaluation polishes the single-precision secant result -- for a flat likelihood the single-precision zero of g is only good to
-// ~1e-4, the slope is not the problem
+// g(h) = Σ_i T_i/S_i − N h² AND its derivative in double precision (row sums over the double-precision particles in LDS, j = i
+// skipped): ONE such evaluation polishes the single-precision secant result by a true Newton step -- for a flat likelihood the
+// single-precision zero of g is only good to ~1e-4, and so is a slope taken from single-precision differences.  With
+// S_i = Σ_j w_ij, T_i = Σ_j w_ij d², Q_i = Σ_j w_ij d⁴ and ∂w/∂h = w d²/h³:  g'(h) = Σ_i (Q_i S_i − T_i²)/(h³ S_i²) − 2 N h.
 template <bool CIRC>
-__device__ __forceinline__ double lcv_g64(const double (&x)[2], const bool (&act)[2], const double* __restrict__ pts, int N, int lane, double h) {
+__device__ __forceinline__ void lcv_g64(const double (&x)[2], const bool (&act)[2], const double* __restrict__ pts, int N, int lane, double h,
+                                        double* g, double* dg) {
   const double a = -0.5 / (h * h);
-  double S[2] = {0.0, 0.0}, T[2] = {0.0, 0.0};
+  double S[2] = {0.0, 0.0}, T[2] = {0.0, 0.0}, Q[2] = {0.0, 0.0};
   for (int j = 0; j < N; ++j) {
     const double xj = pts[j];
 #pragma unroll
@@ -195,29 +148,149 @@ __device__ __forceinline__ double lcv_g64(const double (&x)[2], const bool (&act
       if (CIRC) d = lcv_wrap(d);
       const double d2 = d * d;
       const double w = (lane + 64 * s == j) ? 0.0 : fast_exp_neg(a * d2);
-      S[s] += w; T[s] = fma(w, d2, T[s]);
+      const double wd = w * d2;
+      S[s] += w; T[s] += wd; Q[s] = fma(wd, d2, Q[s]);
     }
   }
-  double gg = 0.0;
+  double v[2] = {0.0, 0.0};
 #pragma unroll
-  for (int s = 0; s < 2; ++s) if (act[s]) gg += T[s] / fmax(S[s], 1e-300);
-  return wave_sum(gg) - (double)N * h * h;
+  for (int s = 0; s < 2; ++s) if (act[s]) {
+    const double sv = fmax(S[s], 1e-300), ts = T[s] / sv;
+    v[0] += ts; v[1] += Q[s] / sv - ts * ts;
+  }
+  wave_sum_n<2>(v);
+  *g = v[0] - (double)N * h * h;
+  *dg = v[1] / (h * h * h) - 2.0 * (double)N * h;
 }
 
-template <bool CIRC>
+// ---- blocked SYMMETRIC evaluation of the row sums (fast path, 64 < N <= 128) -----------------------------------------------------
+// The N particles are cut into nb <= 10 blocks of B (10 for N <= 100, else 13; the tail padded with far-away points of weight 0) and
+// every lane owns ONE unordered pair of blocks (a <= b): nb(nb+1)/2 <= 55 lanes busy.  A lane evaluates its B x B weights once and
+// accumulates them both ways -- B row partials for block a, B column partials for block b -- in registers, with the 2B particle
+// values in registers too: per UNORDERED pair 3 VALU + v_exp_f32 + 2 accumulates = 21 issue cycles (the ring scheme before it: 20
+// per ORDERED pair).  Partials go to an nb x nb matrix of cells in LDS, cell (p, q) = the partial sums of the rows of block p
+// against block q; row i then sums the nb cells of its block row (B-term single-precision partials, single-precision sums of
+// <= 10 of them, converted once).  The derivative sums T_i go through the same cells after the row sums have been read.
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  return __hiloint2double(__shfl_xor(__double2hiint(v), m, 64), __shfl_xor(__double2loint(v), m, 64));
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <int B>
+__host__ __device__ constexpr int kdeCells(int N) { const int nb = (N + B - 1) / B; return nb * nb * B; }   // floats per wave
+template <int B>
+struct BlkPlan { int nb, a, b; bool ok, diag; };
+template <int B>
+__device__ __forceinline__ BlkPlan<B> blk_plan(int N, int lane) {
+  BlkPlan<B> p;
+  p.nb = (N + B - 1) / B;
+  p.ok = lane < p.nb * (p.nb + 1) / 2;
+  int a = 0, rem = p.ok ? lane : 0;   // idle lanes recompute pair 0 and store nothing
+  while (rem >= p.nb - a) { rem -= p.nb - a; ++a; }
+  p.a = a; p.b = a + rem; p.diag = rem == 0;
+  return p;
+}
+
+template <bool CIRC, bool WITH_T, int B>
+__device__ __forceinline__ void lcv_eval_blk(const BlkPlan<B>& pl, const float* __restrict__ xs, float* __restrict__ M, int N, int lane,
+                                             double h, double* negll, double* g) {
+  const float hf = (float)h;
+  const float a2 = -0.72134752f / (hf * hf);   // -½ log2(e) / h²
+  const int nb = pl.nb;
+  float xi[B], xj[B], r[B], c[B];
+  [[maybe_unused]] float tr[B], tc[B];
+#pragma unroll
+  for (int u = 0; u < B; ++u) {
+    xi[u] = xs[pl.a * B + u]; xj[u] = xs[pl.b * B + u]; r[u] = 0.0f; c[u] = 0.0f;
+    if (WITH_T) { tr[u] = 0.0f; tc[u] = 0.0f; }
+  }
+#pragma unroll
+  for (int ii = 0; ii < B; ++ii) {
+#pragma unroll
+    for (int jj = 0; jj < B; ++jj) {
+      float d = xi[ii] - xj[jj];
+      if (CIRC) d = fmaf(-6.2831853071795865f, rintf(d * 0.15915494309189535f), d);
+      const float d2 = d * d;
+      float w = __builtin_amdgcn_exp2f(d2 * a2);
+      if (ii == jj) w = pl.diag ? 0.0f : w;      // a block against itself: every ordered pair once, the particle itself never
+      r[ii] += w; c[jj] += w;
+      if (WITH_T) { const float tw = w * d2; tr[ii] += tw; tc[jj] += tw; }
+    }
+    // one row of B pairs in flight: left alone, the compiler evaluates all B² weights first and accumulates afterwards (> 400 VGPRs).
+    // The empty asm statements pin the row and column sums after this row and make the next row's particle depend on them.
+    asm volatile("" : "+v"(r[ii]));
+    if (WITH_T) asm volatile("" : "+v"(tr[ii]));
+    if (ii + 1 < B) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) { asm volatile("" : "+v"(c[u])); if (WITH_T) asm volatile("" : "+v"(tc[u])); }
+      asm volatile("" : "+v"(xi[ii + 1]));
+    }
+  }
+  float* cr = M + (pl.a * nb + pl.b) * B;
+  float* cc = M + (pl.b * nb + pl.a) * B;
+  const int i0 = lane, i1 = lane + 64;
+  const bool act0 = i0 < N, act1 = i1 < N;
+  const int b0 = i0 / B, b1 = (act1 ? i1 : 0) / B;
+  const float* row0 = M + b0 * nb * B + (i0 - b0 * B);
+  const float* row1 = M + b1 * nb * B + ((act1 ? i1 : 0) - b1 * B);
+  auto exchange = [&](const float (&pr)[B], const float (&pc)[B], double* o0, double* o1) {
+    if (pl.ok) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) cr[u] = pr[u];
+      if (!pl.diag) {
+#pragma unroll
+        for (int u = 0; u < B; ++u) cc[u] = pc[u];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (WITH_T) {   // the derivative finish resolves 1e-6: the <= 10 partials of a row are folded in double (as the ring scheme did)
+      double s0 = 0.0, s1 = 0.0;
+      for (int k = 0; k < nb; ++k) { s0 += (double)row0[k * B]; s1 += (double)row1[k * B]; }
+      *o0 = s0; *o1 = s1;
+    } else {
+      float s0 = 0.0f, s1 = 0.0f;
+      for (int k = 0; k < nb; ++k) { s0 += row0[k * B]; s1 += row1[k * B]; }
+      *o0 = (double)s0; *o1 = (double)s1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // the cells are rewritten next
+  };
+  double S0, S1, T0 = 0.0, T1 = 0.0;
+  exchange(r, c, &S0, &S1);
+  if (WITH_T) exchange(tr, tc, &T0, &T1);
+  // Σ_i log S_i = log Π_i S_i: mantissas multiplied (64 lanes x 2 factors in [1, 2)² < 2^256: inside the double range), exponents
+  // added, ONE logarithm per evaluation instead of two per lane
+  const double s0 = act0 ? fmax(S0, 1e-300) : 1.0, s1 = act1 ? fmax(S1, 1e-300) : 1.0;
+  double mant = __builtin_amdgcn_frexp_mant(s0) * __builtin_amdgcn_frexp_mant(s1);   // in [0.25, 1)
+  int expo = __builtin_amdgcn_frexp_exp(s0) + __builtin_amdgcn_frexp_exp(s1);
+  double gg = 0.0;
+  if (WITH_T) gg = (act0 ? T0 / s0 : 0.0) + (act1 ? T1 / s1 : 0.0);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    mant *= shfl_xor_f64(mant, off);
+    expo += __shfl_xor(expo, off, 64);
+    if (off == 8) { expo += __builtin_amdgcn_frexp_exp(mant); mant = __builtin_amdgcn_frexp_mant(mant); }   // 2^-16 .. 1 -> renormalise half way
+  }
+  const double ll = uniform_f64(fast_log(mant) + (double)expo * 0.693147180559945309417);
+  if (WITH_T) *g = uniform_f64(wave_sum(gg) - (double)N * h * h); else *g = 0.0;
+  // (wave-uniform by construction; saying so lets the search state live in scalar registers across the unrolled block body)
+  *negll = uniform_f64(-(ll - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528)));
+}
+
+template <bool CIRC, int B>
 __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bool (&act)[2], const double* __restrict__ pts,
-                                                  float* __restrict__ p32d, double* __restrict__ wbuf, int N, int lane, double tol, int* n_evals) {
+                                                  float* __restrict__ xs, float* __restrict__ M, double* __restrict__ wbuf, int N, int lane,
+                                                  double tol, int* n_evals) {
   // bracket: smallest pair distance and extent about particle 0 (oracle: ro_kde_bandwidth_lcv) -- in double, as the slow path
   const double x0v = pts[0];
   double mn = __builtin_inf(), ylo = 0.0, yhi = 0.0;
-  f32x2 xi;
   {
     double y0 = x[0] - x0v, y1 = x[1] - x0v;
     if (CIRC) { y0 = lcv_wrap(y0); y1 = lcv_wrap(y1); }
     ylo = fmin(fmin(ylo, y0), y1); yhi = fmax(fmax(yhi, y0), y1);   // idle slots hold particle 0: y = 0
-    xi.x = (float)y0; xi.y = (float)y1;
-    p32d[384 + lane] = xi.x;                       // (64 < N: every lane has a first particle)
-    if (act[1]) p32d[384 + lane + 64] = xi.y;
+    xs[lane] = (float)y0;                          // (64 < N: every lane has a first particle)
+    xs[lane + 64] = act[1] ? (float)y1 : 1.0e18f;  // padding: far away, weight exp2(-huge) = 0 against everything
+    if (lane < 8) xs[128 + lane] = 1.0e18f;
   }
   for (int j = 0; j < N; ++j) {
     const double xj = pts[j];
@@ -229,67 +302,79 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-  f32x2* qa = reinterpret_cast<f32x2*>(p32d);     // pair array: qa[m] = (y[m mod N], y[(m + 64) mod N]), m < 192
-#pragma unroll
-  for (int r = 0; r < 3; ++r) { const int m = lane + 64 * r; qa[m] = f32x2{p32d[384 + m % N], p32d[384 + (m + 64) % N]}; }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-  const f32x2* q = qa + lane;
-  mn = wave_min(mn); ylo = wave_min(ylo); yhi = -wave_min(-yhi);
+  const BlkPlan<B> pl = blk_plan<B>(N, lane);
+  mn = uniform_f64(wave_min(mn)); ylo = uniform_f64(wave_min(ylo)); yhi = uniform_f64(-wave_min(-yhi));
+  // the search state is wave-uniform: every update goes through readfirstlane (U) so that it lives in scalar registers across the
+  // unrolled block body instead of being spilled around it
+#define U(v) uniform_f64(v)
   const double minm = fmax(mn, 1e-6), maxm = fmax(yhi - ylo, minm);
-  const double ax = 2.0 * minm / (double)(N - 1), bx = 0.5 * (minm + maxm), cx = 2.0 * maxm;
+  const double ax = U(2.0 * minm / (double)(N - 1)), bx = U(0.5 * (minm + maxm)), cx = U(2.0 * maxm);
   constexpr double Cg = 0.38196601125010515180, Rg = 0.61803398874989484820;
   double x0 = ax, x3 = cx, x1, x2;
-  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + Cg * (cx - bx); }
-  else { x2 = bx; x1 = bx - Cg * (bx - ax); }
-  double f1, f2, g1, g2;
+  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = U(bx + Cg * (cx - bx)); }
+  else { x2 = bx; x1 = U(bx - Cg * (bx - ax)); }
   const bool finish = tol < 1e-2;          // finer than the golden section is run in single precision: finish on the derivative
-  auto eval = [&](double hh, double* f, double* gd) {
-    if (finish) lcv_eval32<CIRC, true>(xi, act[0], act[1], q, N, hh, f, gd); else lcv_eval32<CIRC, false>(xi, act[0], act[1], q, N, hh, f, gd);
-  };
-  eval(x1, &f1, &g1);
-  eval(x2, &f2, &g2);
-  int ne = 2;
   const double tol_gs = finish ? 1e-2 : tol;
-  while (fabs(x3 - x0) > tol_gs * (fabs(x1) + fabs(x2)) && ne < 200) {
-    bool lower2 = f2 < f1;
-    if (!finish && fabs(f2 - f1) < kTieEps) {   // wave-uniform: decide in double precision
-      const double e1 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x1), e2 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x2);
-      lower2 = e2 < e1;
-    }
-    if (lower2) { x0 = x1; x1 = x2; x2 = Rg * x1 + Cg * x3; f1 = f2; g1 = g2; eval(x2, &f2, &g2); }
-    else        { x3 = x2; x2 = x1; x1 = Rg * x2 + Cg * x0; f2 = f1; g2 = g1; eval(x1, &f1, &g1); }
+  // ONE evaluation site (the unrolled B x B body is a few kB of code per instantiation): a small state machine asks for the next h.
+  //   phase 0 / 1: the two interior points; 2: golden section (`upper`: the request replaces x2, else x1); 3: secant on g
+  double f1 = 0.0, f2 = 0.0, g1 = 0.0, g2 = 0.0, best = x1;
+  double ha = 0.0, ga = 0.0, hb = 0.0, gb = 0.0, lo = 0.0, hi = 0.0;
+  int ne = 0, phase = 0, it = 0;
+  bool upper = false;
+  double hq = x1;
+  for (;;) {
+    double fv, gv;
+    if (finish) lcv_eval_blk<CIRC, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
+    else lcv_eval_blk<CIRC, false, B>(pl, xs, M, N, lane, hq, &fv, &gv);
     ++ne;
-  }
-  double best = f1 < f2 ? x1 : x2;
-  if (!finish && fabs(f2 - f1) < kTieEps) {
-    const double e1 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x1), e2 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x2);
-    best = e1 < e2 ? x1 : x2;
-  }
-  if (finish) {
-    // secant steps on g from the two interior points; the iterate may leave the last bracket by its width (a near-tie decision
-    // of the single-precision golden section), never further (flat or noisy g: keep the golden-section answer)
-    const double wdt = x3 - x0, lo = fmax(x0 - wdt, 0.5 * x0), hi = x3 + wdt;
-    double ha = x1, ga = g1, hb = x2, gb = g2;
-    for (int it = 0; it < 5; ++it) {
-      const double den = gb - ga;
-      if (!(fabs(den) > 0.0)) break;
-      const double hc = hb - gb * (hb - ha) / den;
-      if (!(hc > lo && hc < hi)) break;
-      double fc, gc;
-      eval(hc, &fc, &gc);
-      ++ne;
-      const bool done = fabs(hc - hb) <= tol * fabs(hc);
-      ha = hb; ga = gb; hb = hc; gb = gc;
-      best = hc;
-      if (done) break;
+    if (phase == 0) { f1 = fv; g1 = gv; hq = x2; phase = 1; continue; }
+    if (phase == 1) { f2 = fv; g2 = gv; phase = 2; }
+    else if (phase == 2) { if (upper) { f2 = fv; g2 = gv; } else { f1 = fv; g1 = gv; } }
+    if (phase == 2) {
+      if (fabs(x3 - x0) > tol_gs * (fabs(x1) + fabs(x2)) && ne < 200) {
+        bool lower2 = f2 < f1;
+        if (!finish && fabs(f2 - f1) < kTieEps) {   // wave-uniform: decide in double precision
+          const double e1 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x1), e2 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x2);
+          lower2 = e2 < e1;
+        }
+        if (lower2) { x0 = x1; x1 = x2; x2 = U(Rg * x1 + Cg * x3); f1 = f2; g1 = g2; hq = x2; upper = true; }
+        else        { x3 = x2; x2 = x1; x1 = U(Rg * x2 + Cg * x0); f2 = f1; g2 = g1; hq = x1; upper = false; }
+        continue;
+      }
+      best = f1 < f2 ? x1 : x2;
+      if (!finish) {
+        if (fabs(f2 - f1) < kTieEps) {
+          const double e1 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x1), e2 = lcv_negll<2, CIRC>(x, act, pts, wbuf, N, lane, x2);
+          best = e1 < e2 ? x1 : x2;
+        }
+        break;
+      }
+      // secant steps on g from the two interior points; the iterate may leave the last bracket by its width (a near-tie decision
+      // of the single-precision golden section), never further (flat or noisy g: keep the golden-section answer)
+      const double wdt = x3 - x0;
+      lo = U(fmax(x0 - wdt, 0.5 * x0)); hi = U(x3 + wdt);
+      ha = x1; ga = g1; hb = x2; gb = g2;
+      phase = 3;
+    } else {   // phase 3: the evaluation at hq is in (fv, gv)
+      const bool done = fabs(hq - hb) <= fmax(tol, 1e-4) * fabs(hq);   // (the double-precision Newton step below squares what is left)
+      ha = hb; ga = gb; hb = hq; gb = gv;
+      best = hq;
+      if (done || ++it >= 5) break;
     }
-    if (best == hb && fabs(gb - ga) > 0.0 && hb != ha) {   // one Newton step with the double-precision value of g and the secant slope
-      const double g64 = lcv_g64<CIRC>(x, act, pts, N, lane, hb);
-      const double hn = hb - g64 * (hb - ha) / (gb - ga);
-      ++ne;
-      if (hn > lo && hn < hi && fabs(hn - hb) < 1e-2 * hb) best = hn;
-    }
+    const double den = gb - ga;
+    if (!(fabs(den) > 0.0)) break;
+    const double hc = U(hb - gb * (hb - ha) / den);
+    if (!(hc > lo && hc < hi)) break;
+    hq = hc;
   }
+  if (finish && best == hb) {   // one Newton step in double precision (value and derivative of g)
+    double g64, dg64;
+    lcv_g64<CIRC>(x, act, pts, N, lane, hb, &g64, &dg64);
+    const double hn = hb - g64 / dg64;
+    ++ne;
+    if (dg64 < 0.0 && hn > lo && hn < hi && fabs(hn - hb) < 1e-2 * hb) best = hn;
+  }
+#undef U
   *n_evals = ne;
   return best;
 }
@@ -300,7 +385,6 @@ __global__ void __launch_bounds__(64 * kKdeWaves) k_kde_bandwidth(int T, int dim
                                                                   double* __restrict__ bw, int32_t* __restrict__ evals) {
   __shared__ double pts[kKdeWaves][64 * S];
   __shared__ double wex[kKdeWaves][64 * S];   // per-wave exchange row of the symmetric likelihood evaluation
-  __shared__ __align__(8) float p32buf[kKdeWaves][S == 2 ? 512 : 2];   // fast path: 192 partner pairs (single-precision offsets from particle 0) | the 128 offsets
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = blockIdx.x * kKdeWaves + wave;
   if (t >= T) return;   // wave-uniform; nothing below synchronises across waves
@@ -317,15 +401,41 @@ __global__ void __launch_bounds__(64 * kKdeWaves) k_kde_bandwidth(int T, int dim
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   int ne = 0;
-  double h;
-  if constexpr (S == 2) {
-    float* p32 = reinterpret_cast<float*>(p32buf[wave]);
-    h = circ ? lcv_golden_fast<true>(x, act, pts[wave], p32, wex[wave], N, lane, tol_c, &ne)
-             : lcv_golden_fast<false>(x, act, pts[wave], p32, wex[wave], N, lane, tol_e, &ne);
-  } else {
-    h = circ ? lcv_golden<S, true>(x, act, pts[wave], wex[wave], N, lane, tol_c, &ne)
-             : lcv_golden<S, false>(x, act, pts[wave], wex[wave], N, lane, tol_e, &ne);
+  const double h = circ ? lcv_golden<S, true>(x, act, pts[wave], wex[wave], N, lane, tol_c, &ne)
+                        : lcv_golden<S, false>(x, act, pts[wave], wex[wave], N, lane, tol_e, &ne);
+  if (lane == 0) { bw[t] = h; if (evals) evals[t] = ne; }
+}
+
+// the fast path as its own kernel per block size (register allocation is per kernel: the B = 13 bodies must not set the occupancy of
+// the N = 100 case); four waves per SIMD (128 VGPRs: measured faster than three without the ~70 spills, which sit in the rare
+// double-precision paths) -- left alone the scheduler spreads the unrolled block bodies over > 400 VGPRs
+template <int B>
+__global__ void __launch_bounds__(64 * kKdeWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_kde_bandwidth_fast(int T, int dim, int N, const double* __restrict__ bel, uint32_t circ_mask, double tol_e, double tol_c,
+                     double* __restrict__ bw, int32_t* __restrict__ evals) {
+  __shared__ double pts[kKdeWaves][128];
+  __shared__ double wex[kKdeWaves][128];   // exchange row of the double-precision evaluations (tie decisions)
+  __shared__ float xsbuf[kKdeWaves][136];  // the particles as single-precision offsets from particle 0 (+ padding)
+  extern __shared__ float cellbuf[];       // per wave nb x nb cells of B partial sums (sized by the launcher)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = blockIdx.x * kKdeWaves + wave;
+  if (t >= T) return;   // wave-uniform; nothing below synchronises across waves
+  const bool circ = (circ_mask >> (t % dim)) & 1u;
+  const double* __restrict__ P = bel + (size_t)t * N;
+  double x[2];
+  bool act[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int i = lane + 64 * s;
+    act[s] = i < N;
+    x[s] = P[act[s] ? i : 0];
+    if (act[s]) pts[wave][i] = x[s];
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  int ne = 0;
+  float* M = cellbuf + wave * kdeCells<B>(N);
+  const double h = circ ? lcv_golden_fast<true, B>(x, act, pts[wave], xsbuf[wave], M, wex[wave], N, lane, tol_c, &ne)
+                        : lcv_golden_fast<false, B>(x, act, pts[wave], xsbuf[wave], M, wex[wave], N, lane, tol_e, &ne);
   if (lane == 0) { bw[t] = h; if (evals) evals[t] = ne; }
 }
 
@@ -388,7 +498,12 @@ hipError_t launch_kde_bandwidth(int dim, int V, int N, const double* bel, uint32
   const dim3 grid((T + kKdeWaves - 1) / kKdeWaves), block(64 * kKdeWaves);
 #define ROME_LAUNCH_KDE(SS) hipLaunchKernelGGL((k_kde_bandwidth<SS>), grid, block, 0, s, T, dim, N, bel, circ_mask, tol_e, tol_c, bw, evals)
   if (N <= 64) ROME_LAUNCH_KDE(1);
-  else if (N <= 128) ROME_LAUNCH_KDE(2);
+  else if (N <= 100)
+    hipLaunchKernelGGL((k_kde_bandwidth_fast<10>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<10>(N), s, T, dim, N, bel, circ_mask,
+                       tol_e, tol_c, bw, evals);
+  else if (N <= 128)
+    hipLaunchKernelGGL((k_kde_bandwidth_fast<13>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<13>(N), s, T, dim, N, bel, circ_mask,
+                       tol_e, tol_c, bw, evals);
   else if (N <= 256) ROME_LAUNCH_KDE(4);
   else ROME_LAUNCH_KDE(8);
 #undef ROME_LAUNCH_KDE
