@@ -104,6 +104,21 @@ def test_unusual_masks_odd_counts_and_single_particles(dim, N, circ):
     assert (np.abs(d).max(axis=1) < 1e-9).mean() > 0.99
 
 
+def test_many_proposals_per_variable_dynamic_lds_beyond_48k():
+    """A variable with 24 proposals: the LDS of its block (one level image per proposal) passes 48 kB -- the launch raises the
+    kernel's dynamic-LDS limit -- and the counting sort of the dispatch order sees a count far from the others."""
+    rng = np.random.default_rng(77)
+    N, Ks = 100, [24, 2, 3]
+    ptr, rows, prop = _problem(3, N, Ks, rng, True)
+    bw = rng.uniform(0.1, 0.4, (len(prop), 3))
+    bel_in = np.zeros((len(Ks), 3, N))
+    got = _device_product(3, N, ptr, rows, prop, bw, bel_in, 0b100, 1)
+    ref = ro.product_msgibbs(ro.make_opts(N=N, seed=11, stream_offset=5), 3, ptr, rows, prop, bw, bel_in, 0b100, 1)
+    d = got - ref
+    d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    assert np.isfinite(got).all() and (np.abs(d).max(axis=1) < 1e-9).mean() > 0.99
+
+
 def test_proposals_far_apart_stay_finite_and_equal_the_oracle():
     """Proposals hundreds of bandwidths apart: every candidate weight of a draw underflows against the running maximum (the
     clamped exponential); the draw must still follow the oracle and stay finite -- the product sits between the proposals."""
