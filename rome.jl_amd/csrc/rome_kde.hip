@@ -11,6 +11,7 @@
 // reads.  One likelihood evaluation is ⌊N/2⌋ x S x (difference, square, 20-instruction exp) per lane -- every kernel weight
 // is evaluated once and exchanged through LDS (lcv_negll); the golden-section search (17 evaluations at 1 %, ~33 at 1e-6) runs on wave-uniform scalars, so there is no
 // divergence and no block-level synchronisation.  Compute-bound: 8 N bytes in, 8 bytes out per task.
+#include <type_traits>
 #include "rome_device_math.hpp"
 #include "rome_kernels.h"
 
@@ -171,8 +172,35 @@ __device__ __forceinline__ void lcv_g64(const double (&x)[2], const bool (&act)[
 // per ORDERED pair).  Partials go to an nb x nb matrix of cells in LDS, cell (p, q) = the partial sums of the rows of block p
 // against block q; row i then sums the nb cells of its block row (B-term single-precision partials, single-precision sums of
 // <= 10 of them, converted once).  The derivative sums T_i go through the same cells after the row sums have been read.
-__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
-  return __hiloint2double(__shfl_xor(__double2hiint(v), m, 64), __shfl_xor(__double2loint(v), m, 64));
+// 1 / v for a positive normal double: single-precision seed + two Newton steps (relative error ~1e-16; an IEEE division costs 5x)
+__device__ __forceinline__ double rcp_pos_f64(double v) {
+  const int e = __builtin_amdgcn_frexp_exp(v);                 // the seed is taken on the mantissa: v may be outside the float range
+  const double m = __builtin_amdgcn_frexp_mant(v);
+  double r = (double)__builtin_amdgcn_rcpf((float)m);
+  r = r * fma(-m, r, 2.0);
+  r = r * fma(-m, r, 2.0);
+  return __builtin_ldexp(r, -e);
+}
+// Π over the wavefront of values given as (mantissa in [0.25, 1), exponent): the DPP pattern of wave_sum_n with multiplies; the
+// mantissa product of a 16-lane row (>= 2^-32) is renormalised before the rows are folded.  Result in every lane.
+__device__ __forceinline__ void wave_prod_frexp(double* mant, int* expo) {
+  double m = *mant; int e = *expo;
+  m *= dpp_mov<0xB1>(m);  e += __builtin_amdgcn_mov_dpp(e, 0xB1, 0xF, 0xF, true);
+  m *= dpp_mov<0x4E>(m);  e += __builtin_amdgcn_mov_dpp(e, 0x4E, 0xF, 0xF, true);
+  m *= dpp_mov<0x141>(m); e += __builtin_amdgcn_mov_dpp(e, 0x141, 0xF, 0xF, true);
+  m *= dpp_mov<0x140>(m); e += __builtin_amdgcn_mov_dpp(e, 0x140, 0xF, 0xF, true);
+  e += __builtin_amdgcn_frexp_exp(m); m = __builtin_amdgcn_frexp_mant(m);
+  auto bcast = [&](auto ctrl_tag, auto mask_tag) {
+    constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(m), CTRL, MASK, 0xF, false);            // rows outside the mask: 1.0
+    const int hi = __builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(m), CTRL, MASK, 0xF, false);
+    m *= __hiloint2double(hi, lo);
+    e += __builtin_amdgcn_update_dpp(0, e, CTRL, MASK, 0xF, false);
+  };
+  bcast(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});   // row_bcast:15 -> rows 1, 3
+  bcast(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});   // row_bcast:31 -> rows 2, 3
+  *mant = readlane_f64(m, 63);
+  *expo = __builtin_amdgcn_readlane(e, 63);
 }
 __device__ __forceinline__ double uniform_f64(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -258,19 +286,14 @@ __device__ __forceinline__ void lcv_eval_blk(const BlkPlan<B>& pl, const float* 
   double S0, S1, T0 = 0.0, T1 = 0.0;
   exchange(r, c, &S0, &S1);
   if (WITH_T) exchange(tr, tc, &T0, &T1);
-  // Σ_i log S_i = log Π_i S_i: mantissas multiplied (64 lanes x 2 factors in [1, 2)² < 2^256: inside the double range), exponents
-  // added, ONE logarithm per evaluation instead of two per lane
+  // Σ_i log S_i = log Π_i S_i: mantissas multiplied, exponents added (wave_prod_frexp), ONE logarithm per evaluation instead of
+  // two per lane
   const double s0 = act0 ? fmax(S0, 1e-300) : 1.0, s1 = act1 ? fmax(S1, 1e-300) : 1.0;
   double mant = __builtin_amdgcn_frexp_mant(s0) * __builtin_amdgcn_frexp_mant(s1);   // in [0.25, 1)
   int expo = __builtin_amdgcn_frexp_exp(s0) + __builtin_amdgcn_frexp_exp(s1);
   double gg = 0.0;
-  if (WITH_T) gg = (act0 ? T0 / s0 : 0.0) + (act1 ? T1 / s1 : 0.0);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    mant *= shfl_xor_f64(mant, off);
-    expo += __shfl_xor(expo, off, 64);
-    if (off == 8) { expo += __builtin_amdgcn_frexp_exp(mant); mant = __builtin_amdgcn_frexp_mant(mant); }   // 2^-16 .. 1 -> renormalise half way
-  }
+  if (WITH_T) gg = (act0 ? T0 * rcp_pos_f64(s0) : 0.0) + (act1 ? T1 * rcp_pos_f64(s1) : 0.0);
+  wave_prod_frexp(&mant, &expo);
   const double ll = uniform_f64(fast_log(mant) + (double)expo * 0.693147180559945309417);
   if (WITH_T) *g = uniform_f64(wave_sum(gg) - (double)N * h * h); else *g = 0.0;
   // (wave-uniform by construction; saying so lets the search state live in scalar registers across the unrolled block body)
