@@ -153,6 +153,16 @@ int rome_conv_pose2pose2(rome_ctx*, const rome_opts*, int32_t C, const int32_t* 
  * mu = (mean bearing, mean range), sigma = (σ_b, σ_ρ) of the two Normal() fields
  * (src/factors/BearingRange2D.jl:10-13); getSample :17-27.  A negative sigma encodes a Uniform belief on
  * [mu - |sigma|, mu + |sigma|] (test/TestPoseAndPoint2Constraints.jl:95 uses Uniform(-pi,pi) bearings).                                      */
+/* Pose2Pose2 with IIF `multihypo=[1, w, 1-w]` over the SECOND pose of the factor (addFactor!(fg, [:a; :b1; :b2], Pose2Pose2(z),
+ * multihypo=[1; w; 1-w]): IIF accepts the keyword on any factor; the reference's own uses are on bearing-range factors,
+ * test/testMultimodalRangeBearing.jl:53 -- the same rule is applied here).  One direction per call.  dir 1 (solve a): `fixed` holds
+ * the particles of b1, `alt` those of b2, per particle the fixed pose is drawn from (b1 with probability hypo_w[c], else b2).
+ * dir 0 (solve b1 from a): `alt` = b2; particles drawn for b2 are not constrained by the factor, they keep their value and receive
+ * spreadNH * |mean_xy(b1) - mean_xy(b2)| * (U - 1/2) entropy on every coordinate. */
+int rome_conv_pose2pose2_mh(rome_ctx*, const rome_opts*, int32_t C, int32_t dir,
+                            const double* mu /*C*3*/, const double* cov /*C*9*/,
+                            const double* fixed /*C*N*3*/, const double* alt /*C*N*3*/, const double* hypo_w /*C*/,
+                            const double* noise /*C*N*3 or NULL*/, double* target_inout /*C*N*3*/, int32_t* status);
 int rome_conv_pose2point2br(rome_ctx*, const rome_opts*, int32_t C, int32_t dir,
                             const double* mu /*C*2*/, const double* sigma /*C*2*/,
                             const double* fixed, const double* noise /*C*N*2 or NULL*/,

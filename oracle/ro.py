@@ -180,14 +180,18 @@ def nelder_mead(f, x0, max_iters=1000, g_tol=1e-8):
     return x, rc, ne.value
 
 
-def conv_pose2pose2(opts, mu, L, bel, fixed_var, target_var, dirs, factor=None, noise=None, want_status=False):
+def conv_pose2pose2(opts, mu, L, bel, fixed_var, target_var, dirs, factor=None, noise=None, want_status=False,
+                    alt_var=None, hypo_w=None, spread_nh=3.0):
     mu, pmu = _d(mu); L, pL = _d(L); bel, pb = _d(bel)
     fv, pfv = _i(fixed_var); tv, ptv = _i(target_var); dr, pdr = _i(dirs); fa, pfa = _i(factor)
     Cn = len(fv); N = opts.n_particles
     nz, pn = (None, None) if noise is None else _d(noise)
     out = np.zeros((Cn, 3, N)); st = np.zeros((Cn, N), dtype=np.int32)
-    rc = lib().ro_conv_pose2pose2(C.byref(opts), Cn, pfa, pdr, pfv, ptv, pmu, pL, pb, pn,
-                                  out.ctypes.data_as(C.POINTER(C.c_double)), st.ctypes.data_as(C.POINTER(C.c_int32)))
+    av, pav = _i(alt_var)
+    hw, phw = (None, None) if hypo_w is None else _d(hypo_w)
+    rc = lib().ro_conv_pose2pose2_mh(C.byref(opts), Cn, pfa, pdr, pfv, ptv, pmu, pL, pb, pn,
+                                     out.ctypes.data_as(C.POINTER(C.c_double)), st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     pav, phw, C.c_double(spread_nh))
     assert rc == 0
     return (out, st) if want_status else out
 

@@ -605,10 +605,16 @@ static int nullhypo_draw(const ro_opts* o, uint64_t st, uint32_t i, int d, doubl
   return isnull;
 }
 
-int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int32_t* dir,
-                       const int32_t* fixed_var, const int32_t* target_var,
-                       const double* mu, const double* L, const double* bel, const double* noise,
-                       double* out, int32_t* status) {
+/* With multihypo over the SECOND pose of the factor (IIF `addFactor!(fg, [:a; :b1; :b2], Pose2Pose2(...), multihypo=[1; w; 1-w])`;
+ * the reference's own uses of multihypo are all on bearing-range factors, same rule as ro_conv_pose2point2br_mh): alt_var[c] >= 0
+ * names the other candidate's belief, hypo_w[c] the probability of the row's own.  Row direction 1 (solve the first pose): per
+ * particle the fixed pose is drawn from (own, alt).  Row direction 0 (solve this candidate): particles drawn for the other
+ * candidate are not constrained by the factor -- they keep their value and receive entropy
+ * spread_nh · ‖mean_xy(this) − mean_xy(alt)‖ · (U − ½) on every coordinate. */
+int ro_conv_pose2pose2_mh(const ro_opts* o, int C, const int32_t* factor, const int32_t* dir,
+                          const int32_t* fixed_var, const int32_t* target_var,
+                          const double* mu, const double* L, const double* bel, const double* noise,
+                          double* out, int32_t* status, const int32_t* alt_var, const double* hypo_w, double spread_nh) {
   const int N = o->n_particles;
   if (N <= 0 || C < 0) return -1;
   int cycles = o->inflate_cycles < 1 ? 1 : o->inflate_cycles;
@@ -630,6 +636,22 @@ int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int
       ob[i] = tb[i]; ob[N + i] = tb[N + i]; ob[2 * N + i] = wrap_pi(tb[2 * N + i]); /* X0c = vee(log(ϵ,u0)) */
       if (status) status[(size_t)c * N + i] = 0;
     }
+    const int av = (alt_var && hypo_w && dr != 2) ? alt_var[c] : -1;
+    const int hd = dr == 1 ? 1 : 0;                       /* which side of the factor is fractional */
+    const double* ab = av >= 0 ? bel + (size_t)av * 3 * N : NULL;
+    unsigned char* sel = (unsigned char*)malloc(N);
+    double* mhu = (double*)malloc(sizeof(double) * 3 * N);
+    for (int i = 0; i < N; ++i) {
+      sel[i] = 1;
+      if (av >= 0) {
+        uint32_t key[2] = {(uint32_t)o->seed, (uint32_t)(o->seed >> 32)};
+        uint64_t stq = o->stream_offset + (uint64_t)c;
+        uint32_t ctr[4] = {(uint32_t)i, (uint32_t)stq, (uint32_t)(stq >> 32), (4u << 16)}, w4[4];
+        ro_philox4x32_10(ctr, key, w4);
+        sel[i] = (((double)w4[0] + 0.5) * (1.0 / 4294967296.0)) < hypo_w[c];
+        for (int k = 0; k < 3; ++k) mhu[3 * i + k] = ((double)w4[1 + k] + 0.5) * (1.0 / 4294967296.0);
+      }
+    }
     unsigned char* nullh = (unsigned char*)calloc(N, 1);
     double* nhu = (double*)malloc(sizeof(double) * 3 * N);
     double nh_spread = 0.0;
@@ -641,8 +663,9 @@ int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int
     }
     if (o->solver == RO_SOLVER_CLOSED_FORM) {
       for (int i = 0; i < N; ++i) {
-        if (nullh[i]) continue;
-        double fx[3] = {fb[i], fb[N + i], fb[2 * N + i]}, t[3];
+        if (nullh[i] || (hd == 0 && !sel[i])) continue;
+        const double* fs = (hd == 1 && !sel[i]) ? ab : fb;
+        double fx[3] = {fs[i], fs[N + i], fs[2 * N + i]}, t[3];
         p2p2_closed(zs + 3 * i, fx, dr, t);
         ob[i] = t[0]; ob[N + i] = t[1]; ob[2 * N + i] = wrap_pi(t[2]);
       }
@@ -655,8 +678,9 @@ int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int
           spread = o->inflation * frechet_std(std3, 3);
         }
         for (int i = 0; i < N; ++i) {
-          if (nullh[i]) continue;
-          double fx[3] = {fb[i], fb[N + i], fb[2 * N + i]};
+          if (nullh[i] || (hd == 0 && !sel[i])) continue;
+          const double* fs = (hd == 1 && !sel[i]) ? ab : fb;
+          double fx[3] = {fs[i], fs[N + i], fs[2 * N + i]};
           double t[3] = {ob[i], ob[N + i], ob[2 * N + i]};
           if (spread > 0.0) {
             double u[3];
@@ -682,9 +706,25 @@ int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int
         se2_add_entropy(t, nh_spread, nhu + 3 * i);
         ob[i] = t[0]; ob[N + i] = t[1]; ob[2 * N + i] = wrap_pi(t[2]);
       }
-    free(zs); free(nullh); free(nhu);
+    if (av >= 0 && hd == 0) {   /* means of the ORIGINAL target belief (start points) and of the other candidate's belief */
+      double mx = 0, my = 0, ax = 0, ay = 0;
+      for (int i = 0; i < N; ++i) { mx += tb[i]; my += tb[N + i]; ax += ab[i]; ay += ab[N + i]; }
+      const double dxm = (mx - ax) / N, dym = (my - ay) / N;
+      const double nh = spread_nh * sqrt(dxm * dxm + dym * dym);
+      for (int i = 0; i < N; ++i) if (!sel[i]) {
+        ob[i] += nh * (mhu[3 * i] - 0.5); ob[N + i] += nh * (mhu[3 * i + 1] - 0.5);
+        ob[2 * N + i] = wrap_pi(ob[2 * N + i] + nh * (mhu[3 * i + 2] - 0.5));
+      }
+    }
+    free(zs); free(nullh); free(nhu); free(sel); free(mhu);
   }
   return 0;
+}
+int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int32_t* dir,
+                       const int32_t* fixed_var, const int32_t* target_var,
+                       const double* mu, const double* L, const double* bel, const double* noise,
+                       double* out, int32_t* status) {
+  return ro_conv_pose2pose2_mh(o, C, factor, dir, fixed_var, target_var, mu, L, bel, noise, out, status, NULL, NULL, 0.0);
 }
 
 /* ---- PriorPose2: N samples exp_ϵ(hat(μ + Lξ)) (⚠IIF samplePoint; src/factors/PriorPose2.jl:13-17) ---- */

@@ -88,6 +88,11 @@ int ro_conv_pose2pose2(const ro_opts* o, int C, const int32_t* factor, const int
                        const int32_t* fixed_var, const int32_t* target_var,
                        const double* mu /*[F][3]*/, const double* L /*[F][6]*/,
                        const double* bel /*[V][3][N]*/, const double* noise, double* out, int32_t* status);
+int ro_conv_pose2pose2_mh(const ro_opts* o, int C, const int32_t* factor, const int32_t* dir,
+                       const int32_t* fixed_var, const int32_t* target_var,
+                       const double* mu /*[F][3]*/, const double* L /*[F][6]*/,
+                       const double* bel /*[V][3][N]*/, const double* noise, double* out, int32_t* status,
+                          const int32_t* alt_var, const double* hypo_w, double spread_nh);
 int ro_conv_pose2point2br(const ro_opts* o, int C, const int32_t* factor, int dir,
                           const int32_t* fixed_var, const int32_t* target_var,
                           const double* mu /*[F][2] (bearing,range)*/, const double* sigma /*[F][2]*/,

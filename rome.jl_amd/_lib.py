@@ -73,6 +73,7 @@ SIGNATURES = {
     "rome_conv_pose2pose2": (C.c_int, [_CTX, _PO, C.c_int32, _PI, _PD, _PD, _PD, _PD, _PD, _PI]),
     "rome_conv_pose2point2br": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PI]),
     "rome_conv_pose2point2br_mh": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PI]),
+    "rome_conv_pose2pose2_mh": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PI]),
     "rome_conv_pose3pose3": (C.c_int, [_CTX, _PO, C.c_int32, _PI, _PD, _PD, _PD, _PD, _PD, _PI]),
     "rome_sample_priorpose2": (C.c_int, [_CTX, _PO, C.c_int32, _PD, _PD, _PD, _PD]),
     "rome_sample_priorpose3": (C.c_int, [_CTX, _PO, C.c_int32, _PD, _PD, _PD, _PD]),

@@ -272,15 +272,25 @@ def coords_to_points(dim, coords, ctx=None):
 
 
 # ------------------------------------------------------------------ host-pointer convolutions
-def conv_pose2pose2(opts, mu, cov, fixed, target, dirs=None, noise=None, want_status=False, ctx=None):
+def conv_pose2pose2(opts, mu, cov, fixed, target, dirs=None, noise=None, want_status=False, ctx=None, alt=None, hypo_w=None):
+    """alt / hypo_w: multihypo over two candidates for the factor's second pose (blocks of the other candidate, P(primary));
+    `dirs` must then be one direction (0 or 1) for the whole call."""
     ctx = ctx or default_context()
     mu = np.atleast_2d(_d(mu)); C_ = mu.shape[0]; N = opts.n_particles
     cov = _d(cov, (C_, 3, 3))
     fixed = _blocks(fixed, C_, N, 3, opts.layout)
     out = _blocks(target, C_, N, 3, opts.layout).copy()
     noise = None if noise is None else _blocks(noise, C_, N, 3, opts.layout, points_ok=False)
-    dirs = None if dirs is None else np.ascontiguousarray(dirs, dtype=np.int32)
     st = np.zeros((C_, N), dtype=np.int32) if want_status else None
+    if alt is not None:
+        d = np.unique(np.asarray(0 if dirs is None else dirs, dtype=np.int32))
+        if d.size != 1 or int(d[0]) not in (0, 1):
+            raise ValueError("conv_pose2pose2 with multihypo: one direction (0 or 1) per call")
+        alt = _blocks(alt, C_, N, 3, opts.layout); hypo_w = _d(hypo_w, (C_,))
+        _lib.check(_lib.load().rome_conv_pose2pose2_mh(ctx.handle, C.byref(opts), C_, int(d[0]), _p(mu), _p(cov), _p(fixed), _p(alt),
+                                                      _p(hypo_w), _p(noise), _p(out), _pi(st)), ctx.handle)
+        return (out, st) if want_status else out
+    dirs = None if dirs is None else np.ascontiguousarray(dirs, dtype=np.int32)
     _lib.check(_lib.load().rome_conv_pose2pose2(ctx.handle, C.byref(opts), C_, _pi(dirs), _p(mu), _p(cov), _p(fixed),
                                                _p(noise), _p(out), _pi(st)), ctx.handle)
     return (out, st) if want_status else out

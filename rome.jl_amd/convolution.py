@@ -18,6 +18,14 @@ def approxConv(fg, flabel, target, solver=_lib.SOLVER_NEWTON, seed=None, ctx=Non
     if isinstance(f, PriorPose3):
         return api.sample_priorpose3(opts, [f.Z.mu], [f.Z.cov], ctx=ctx)[0]
     mh = fg.multihypo.get(flabel)
+    if mh is not None and isinstance(f, Pose2Pose2):   # Pose2Pose2 over [a, b1, b2]
+        a, b1, b2 = labels
+        opts.layout = _lib.LAYOUT_SOA
+        z3 = lambda l: fg.getVal(l)[None] if fg.isInitialized(l) else np.zeros((1, 3, fg.N))
+        if target == a:
+            return api.conv_pose2pose2(opts, [f.Z.mu], [f.Z.cov], z3(b1), z3(a), dirs=[1], alt=z3(b2), hypo_w=[mh[0]], ctx=ctx)[0]
+        prim, alt, w = (b1, b2, mh[0]) if target == b1 else (b2, b1, mh[1])
+        return api.conv_pose2pose2(opts, [f.Z.mu], [f.Z.cov], fg.getVal(a)[None], z3(prim), dirs=[0], alt=z3(alt), hypo_w=[w], ctx=ctx)[0]
     if mh is not None:   # Pose2Point2BearingRange over [pose, l1, l2]
         pose, l1, l2 = labels
         opts.layout = _lib.LAYOUT_SOA

@@ -439,6 +439,17 @@ int rome_conv_pose2pose2(rome_ctx* c, const rome_opts* o, int32_t C, const int32
   if ((rc = rome_cholesky_lower(3, C, cov, L.data()))) return rc;
   return host_conv(c, o, kP2P2, C, dir, 0, 3, 3, 3, mu, L.data(), 6, fixed, noise, target_inout, status);
 }
+int rome_conv_pose2pose2_mh(rome_ctx* c, const rome_opts* o, int32_t C, int32_t dir, const double* mu, const double* cov,
+                            const double* fixed, const double* alt, const double* hypo_w, const double* noise,
+                            double* target_inout, int32_t* status) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || C < 0 || (dir != 0 && dir != 1) || (C > 0 && (!mu || !cov || !fixed || !alt || !hypo_w || !target_inout))) return ROME_ERR_INVALID_ARG;
+  if (C == 0) return ROME_OK;
+  for (int i = 0; i < C; ++i) if (!(hypo_w[i] >= 0.0 && hypo_w[i] <= 1.0)) return ROME_ERR_INVALID_ARG;
+  std::vector<double> L((size_t)C * 6);
+  if ((rc = rome_cholesky_lower(3, C, cov, L.data()))) return rc;
+  return host_conv(c, o, kP2P2, C, nullptr, dir, 3, 3, 3, mu, L.data(), 6, fixed, noise, target_inout, status, alt, hypo_w);
+}
 int rome_conv_pose2point2br(rome_ctx* c, const rome_opts* o, int32_t C, int32_t dir, const double* mu, const double* sigma,
                             const double* fixed, const double* noise, double* target_inout, int32_t* status) {
   int rc = check_opts(o); if (rc) return rc;

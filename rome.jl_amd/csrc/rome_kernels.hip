@@ -114,7 +114,8 @@ __device__ __forceinline__ double spread_r2_fast(const double (&t)[PPL][2], cons
 
 struct P2P2 {
   static constexpr int DF = 3, DT = 3, DZ = 3, NL = 6;
-  static constexpr int kHypoDir = -1;  // no multihypo support
+  static constexpr int kHypoDir = 2;   // multihypo over the SECOND pose of the factor: the fractional side follows the row's direction
+                                       // (dir 0: the target is one of the candidates; dir 1: the fixed pose is drawn per particle)
   static constexpr bool kUniqueRoot = true;   // r(z; p, ·) = 0 has exactly one solution: the start point cannot reach the proposal
   struct Consts { double mu[3]; double L[6]; int dir; };
   __device__ static __forceinline__ Consts load(const ConvArgs& a, int f, int dr) {
@@ -625,7 +626,7 @@ k_conv(const ConvArgs a) {
   if (LEAN || a.rows4) {   // one 16-byte scalar load for the whole row
     const int4 row = *reinterpret_cast<const int4*>(a.rows4 + 4 * (size_t)c);
     f = row.x; fv = row.z; tv = row.w;
-    dr = FP::kHypoDir < 0 ? row.y : a.dir_all;   // bearing-range: the direction is the kernel's template argument
+    dr = (FP::kHypoDir < 0 || FP::kHypoDir == 2) ? row.y : a.dir_all;   // bearing-range: the direction is the kernel's template argument
   } else {
     f = a.factor ? a.factor[c] : c;
     dr = a.dir ? a.dir[c] : a.dir_all;
@@ -696,27 +697,30 @@ k_conv(const ConvArgs a) {
 #pragma unroll
   for (int k = 0; k < PPL; ++k) st[k] = 0;
 
-  // ---- multihypo (IIF `multihypo=[1, w, 1-w]` on the landmark slot of a bearing-range factor; ⚠IIF
-  //      computeAcrossHypothesis!): per particle a categorical draw decides which landmark the sighting belongs to.
-  //      DIR 1 (solve the pose): the fixed landmark particle comes from the drawn hypothesis.
-  //      DIR 0 (solve this landmark): particles of the other hypothesis are not constrained by the factor: they keep
+  // ---- multihypo (IIF `multihypo=[1, w, 1-w]` on the second variable of a factor -- the landmark slot of a bearing-range
+  //      factor, the second pose of a Pose2Pose2; ⚠IIF computeAcrossHypothesis!): per particle a categorical draw decides which
+  //      candidate the measurement belongs to.
+  //      side 1 (solve the first variable): the fixed particle comes from the drawn candidate.
+  //      side 0 (solve this candidate): particles of the other hypothesis are not constrained by the factor: they keep
   //      their value and only receive entropy  spreadNH · ‖mean(this) - mean(other)‖ · (U-½)  (applied after the cycles).
   bool sel[PPL];
 #pragma unroll
   for (int k = 0; k < PPL; ++k) sel[k] = true;
   double nh_spread = 0.0;
+  [[maybe_unused]] int hd = FP::kHypoDir;   // which side of the factor is fractional (Pose2Pose2: by the row's direction)
   if constexpr (FP::kHypoDir >= 0 && !LEAN) {
-    const int av = a.alt_var ? a.alt_var[c] : -1;
+    if constexpr (FP::kHypoDir == 2) hd = dr == 1 ? 1 : 0;
+    const int av = (a.alt_var && dr != 2) ? a.alt_var[c] : -1;
     if (av >= 0) {  // wave-uniform
       const double w = a.hypo_w[c];
-      const double* __restrict__ ab = (FP::kHypoDir == 1 ? a.bel_fixed : a.bel_target) + (size_t)av * (FP::kHypoDir == 1 ? FP::DF : FP::DT) * N;
+      const double* __restrict__ ab = (hd == 1 ? a.bel_fixed + (size_t)av * FP::DF * N : a.bel_target + (size_t)av * FP::DT * N);
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
         const int i = lane + 64 * k, ii = act[k] ? i : 0;
         const u32x4 hw = philox4x32_10(u32x4{(uint32_t)ii, (uint32_t)stream, (uint32_t)(stream >> 32), (4u << 16)},
                                        (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
         const bool primary = ((double)hw.x + 0.5) * (1.0 / 4294967296.0) < w;
-        if constexpr (FP::kHypoDir == 1) {
+        if (hd == 1) {
           if (!primary) {
 #pragma unroll
             for (int d = 0; d < FP::DF; ++d) fx[k][d] = ab[d * N + ii];
@@ -724,7 +728,7 @@ k_conv(const ConvArgs a) {
           }
         } else sel[k] = primary;
       }
-      if constexpr (FP::kHypoDir == 0) {
+      if (hd == 0) {
         double sm[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < PPL; ++k) if (act[k]) {
@@ -829,7 +833,7 @@ k_conv(const ConvArgs a) {
       }
     }
   }
-  if constexpr (FP::kHypoDir == 0 && !LEAN) {
+  if constexpr ((FP::kHypoDir == 0 || FP::kHypoDir == 2) && !LEAN) {
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       if (act[k] && !sel[k]) {  // the other hypothesis holds for this particle: entropy only
@@ -839,6 +843,7 @@ k_conv(const ConvArgs a) {
                                        (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
         t[k][0] += nh_spread * (((double)hw.y + 0.5) * (1.0 / 4294967296.0) - 0.5);
         t[k][1] += nh_spread * (((double)hw.z + 0.5) * (1.0 / 4294967296.0) - 0.5);
+        if constexpr (FP::DT == 3) t[k][2] += nh_spread * (((double)hw.w + 0.5) * (1.0 / 4294967296.0) - 0.5);   // a pose: the heading too
       }
     }
   }
@@ -885,7 +890,7 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
   int f, dr, fv, tv;
   if (a.rows4) {
     const int4 row = *reinterpret_cast<const int4*>(a.rows4 + 4 * (size_t)c);
-    f = row.x; fv = row.z; tv = row.w; dr = FP::kHypoDir < 0 ? row.y : a.dir_all;
+    f = row.x; fv = row.z; tv = row.w; dr = (FP::kHypoDir < 0 || FP::kHypoDir == 2) ? row.y : a.dir_all;
   } else {
     f = a.factor ? a.factor[c] : c; dr = a.dir ? a.dir[c] : a.dir_all;
     fv = a.fixed_var ? a.fixed_var[c] : c; tv = a.target_var ? a.target_var[c] : c;

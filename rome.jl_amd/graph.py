@@ -36,17 +36,20 @@ class FactorGraph:
         return list(self.variables)
 
     def addFactor(self, labels, factor, multihypo=None):
-        """multihypo=[1.0, w1, w2] (IIF kwarg, test/testMultimodalRangeBearing.jl:53): a Pose2Point2BearingRange
-        whose landmark is l1 with probability w1 or l2 with probability w2 -- labels = [pose, l1, l2]."""
+        """multihypo=[1.0, w1, w2] (IIF kwarg, test/testMultimodalRangeBearing.jl:53): the SECOND variable of a two-variable factor is
+        labels[1] with probability w1 or labels[2] with probability w2 -- a Pose2Point2BearingRange over [pose, l1, l2] (every use in
+        the reference) or a Pose2Pose2 over [a, b1, b2] (per-factor convolutions only: approxConv; the whole-graph tables do not
+        carry Pose2Pose2 hypotheses)."""
         labels = list(labels)
         if multihypo is not None:
-            if not isinstance(factor, Pose2Point2BearingRange) or len(labels) != 3 or len(multihypo) != 3:
-                raise ValueError("multihypo is supported for Pose2Point2BearingRange over [pose, l1, l2]")
+            if not isinstance(factor, (Pose2Point2BearingRange, Pose2Pose2)) or len(labels) != 3 or len(multihypo) != 3:
+                raise ValueError("multihypo is supported for Pose2Point2BearingRange over [pose, l1, l2] and Pose2Pose2 over [a, b1, b2]")
             w = [float(x) for x in multihypo]
             if w[0] != 1.0 or abs(w[1] + w[2] - 1.0) > 1e-12 or min(w[1:]) < 0:
                 raise ValueError("multihypo must be [1.0, w1, w2] with w1 + w2 = 1")
-            if self.variables.get(labels[2]) is not Point2:
-                raise TypeError("multihypo: %s must be a Point2 variable" % labels[2])
+            second = factor.variable_types[1]
+            if self.variables.get(labels[2]) is not second:
+                raise TypeError("multihypo: %s must be a %s variable" % (labels[2], second.__name__ if hasattr(second, "__name__") else second))
             extra, labels_chk = labels[2], labels[:2]
         else:
             extra, labels_chk = None, labels
@@ -424,7 +427,10 @@ class PackedGraph:
         p2, br, p3, pr2, pr3, prpt = [], [], [], [], [], []
         for flabel, labels, f in fg.factors:
             ids = [self.index[l] for l in labels]
-            if isinstance(f, Pose2Pose2): p2.append((ids, f, flabel))
+            if isinstance(f, Pose2Pose2):
+                if fg.multihypo.get(flabel) is not None:
+                    raise NotImplementedError("%s: Pose2Pose2 multihypo is served by approxConv (per-factor path), not by the graph tables" % flabel)
+                p2.append((ids, f, flabel))
             elif isinstance(f, Pose2Point2BearingRange): br.append((ids, f, flabel, fg.multihypo.get(flabel)))
             elif isinstance(f, Pose3Pose3): p3.append((ids, f, flabel))
             elif isinstance(f, PriorPose2): pr2.append((ids, f, flabel))

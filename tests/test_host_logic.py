@@ -324,3 +324,22 @@ def test_loadg2o_max_edges_counts_edges_only(tmp_path):
                  "EDGE_SE2 0 1 1 0 0 10 0 0 10 0 10\nEDGE_SE2 1 2 1 0 0 10 0 0 10 0 10\nEDGE_SE2 0 2 2 0 0 10 0 0 10 0 10\n")
     fg = R.loadG2o(str(p), N=4, max_edges=2)
     assert sum(1 for _, _, f in fg.factors if isinstance(f, R.Pose2Pose2)) == 2
+
+
+def test_multihypo_is_accepted_on_pose2pose2_and_refused_by_the_graph_tables():
+    """IIF's `multihypo=` keyword on a relative pose factor: labels [a, b1, b2]; served by approxConv only (per-factor path)."""
+    fg = R.initfg(10)
+    for l in ("a", "b1", "b2"):
+        fg.addVariable(l, R.Pose2)
+    fg.addVariable("l0", R.Point2)
+    f = R.Pose2Pose2(R.MvNormal([1.0, 0.0, 0.0], np.diag([0.01, 0.01, 0.0025])))
+    fl = fg.addFactor(["a", "b1", "b2"], f, multihypo=[1.0, 0.6, 0.4])
+    assert fg.multihypo[fl] == (0.6, 0.4) and fg.getFactor(fl)[1] == ["a", "b1", "b2"]
+    with pytest.raises(TypeError):
+        fg.addFactor(["a", "b1", "l0"], f, multihypo=[1.0, 0.5, 0.5])       # the alternative must be a Pose2 too
+    with pytest.raises(ValueError):
+        fg.addFactor(["a", "b1", "b2"], f, multihypo=[1.0, 0.6, 0.6])
+    with pytest.raises(NotImplementedError):
+        R.PackedGraph(fg)
+    fg.deleteFactor(fl)
+    assert fl not in fg.multihypo and R.PackedGraph(fg).p2p2["F"] == 0
