@@ -157,6 +157,53 @@ def test_product_of_gaussian_densities_has_the_gaussian_product_moments():
     assert np.abs(pooled / sd - 1).max() < 0.08, (pooled, sd)
 
 
+def _exact_product_samples(P, H, n, rng):
+    """n exact draws from the product of two kernel density estimates (Euclidean coordinates): the product of two mixtures of N
+    Gaussians is a mixture of N² Gaussians with closed-form weights, means and variances.  P: (2, D, N), H: (2, D)."""
+    D, N = P.shape[1], P.shape[2]
+    logw = np.zeros((N, N))
+    for d in range(D):
+        logw += -0.5 * (P[0, d][:, None] - P[1, d][None, :]) ** 2 / (H[0, d] ** 2 + H[1, d] ** 2)
+    w = np.exp(logw - logw.max()).ravel(); w /= w.sum()
+    idx = rng.choice(N * N, size=n, p=w); i, j = idx // N, idx % N
+    out = np.empty((D, n))
+    for d in range(D):
+        p1, p2 = 1 / H[0, d] ** 2, 1 / H[1, d] ** 2
+        out[d] = (P[0, d][i] * p1 + P[1, d][j] * p2) / (p1 + p2) + rng.standard_normal(n) / np.sqrt(p1 + p2)
+    return out
+
+
+def test_against_exact_sampling_of_the_product_mixture():
+    """A pin that does not go through the oracle: 30 000 draws of the device's multiscale Gibbs product against 30 000 EXACT draws
+    of the same product density (two-sample Kolmogorov-Smirnov per coordinate).  Overlapping unimodal proposals: one Gibbs sweep
+    (the reference's Niter = 1) already matches.  Proposals with two modes each: the relative weight of the surviving modes needs a
+    few sweeps -- with one sweep the labels inherited from the coarse levels are still felt (a property of the published algorithm,
+    which the reference shares at its default); with three the sampler matches the exact product."""
+    from scipy import stats
+    rng = np.random.default_rng(1)
+    N, V = 100, 300
+    ptr = np.arange(0, 2 * V + 1, 2, dtype=np.int32); rows = np.arange(2 * V, dtype=np.int32)
+
+    def device_draws(P, H, iters):
+        got = _device_product(2, N, ptr, rows, np.tile(P, (V, 1, 1)), np.tile(H, (V, 1)), np.zeros((V, 2, N)), 0, iters)
+        return got.transpose(1, 0, 2).reshape(2, -1)          # every variable has the same two proposals and its own Philox stream
+
+    A = np.stack([rng.normal(0, 1, N), rng.normal(0, 0.5, N)]); B = np.stack([rng.normal(0.8, 0.7, N), rng.normal(-0.3, 0.8, N)])
+    P = np.stack([A, B]); H = R.kde_bandwidth(P, 0)
+    ex = _exact_product_samples(P, H, V * N, rng)
+    g = device_draws(P, H, 1)
+    assert max(stats.ks_2samp(g[d], ex[d]).statistic for d in range(2)) < 0.025
+    A = np.stack([np.concatenate([rng.normal(-2, 0.3, N // 2), rng.normal(2, 0.3, N - N // 2)]), rng.normal(0, 0.5, N)])
+    B = np.stack([np.concatenate([rng.normal(2.2, 0.3, N // 3), rng.normal(-1.7, 0.3, N - N // 3)]), rng.normal(0.2, 0.5, N)])
+    P = np.stack([A, B]); H = R.kde_bandwidth(P, 0)
+    ex = _exact_product_samples(P, H, V * N, rng)
+    g3 = device_draws(P, H, 3)
+    assert max(stats.ks_2samp(g3[d], ex[d]).statistic for d in range(2)) < 0.025
+    assert abs((g3[0] > 0).mean() - (ex[0] > 0).mean()) < 0.02
+    g1 = device_draws(P, H, 1)                                  # one sweep: both modes are there, widths right, weights not yet mixed
+    assert 0.2 < (g1[0] > 0).mean() < 0.8 and stats.ks_2samp(g1[1], ex[1]).statistic < 0.04
+
+
 def test_manifold_product_wrapper_and_multimodal_selection():
     """Two bimodal densities that agree on ONE mode only: the product keeps that mode (what an importance product on one
     density's points also does, but here from the Gibbs labels), and `manifoldProduct` of a single density returns its points."""
