@@ -31,7 +31,7 @@ constexpr int kGibbsMaxN = 128;
 constexpr int kGibbsNodes = 127;   // internal nodes of levels 0 .. 6
 
 struct GibbsArgs {
-  int V, N, L, max_k, iters;
+  int V, N, L, max_k, k_lds, iters;   // k_lds: level images resident in LDS per block (variables with more proposals stream them)
   uint32_t circ;
   const int32_t* prop_ptr; const int32_t* prop_rows;
   const double* prop; const double* prop_bw; const double* bel_in; double* bel_out;
@@ -371,10 +371,15 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
   }
   __shared__ float logn[kGibbsMaxN + 1];   // log(c / N): the weight of a node with c points
   for (int c = tid; c <= kGibbsMaxN; c += kGibbsThreads) logn[c] = c > 0 ? (float)log((double)c / (double)N) : 0.0f;
-  // dynamic LDS: [max_k] level images | [max_k] constants | [max_k][128] labels
+  // dynamic LDS: [k_lds] level images | [max_k] constants | [max_k][128] labels.  A variable with at most k_lds proposals keeps the
+  // current level of all its trees resident; one with more STREAMS them: the image of the tree being scanned is staged into slot 0
+  // before every categorical draw, and the statistics of selected nodes come from the trees in HBM / L2 (a handful of gathers per
+  // draw).  Sizing every block for the hub variable of a pose graph (11 proposals: 28 kB) left 2.5 waves per SIMD; 12 kB give six
+  // and the same work runs 24 % faster (profiles/r02_gibbs_occupancy.txt).
   GibbsLevel<D>* lev = reinterpret_cast<GibbsLevel<D>*>(smem);
-  GibbsConst<D>* cst = reinterpret_cast<GibbsConst<D>*>(smem + sizeof(GibbsLevel<D>) * a.max_k);
-  uint8_t* selbuf = smem + (sizeof(GibbsLevel<D>) + sizeof(GibbsConst<D>)) * a.max_k;
+  GibbsConst<D>* cst = reinterpret_cast<GibbsConst<D>*>(smem + sizeof(GibbsLevel<D>) * a.k_lds);
+  uint8_t* selbuf = smem + sizeof(GibbsLevel<D>) * a.k_lds + sizeof(GibbsConst<D>) * a.max_k;
+  const bool resident = K <= a.k_lds;
   const GibbsTree<D>* __restrict__ W = reinterpret_cast<const GibbsTree<D>*>(a.trees);
   for (int j = tid; j < K; j += kGibbsThreads) {
     const int row = a.prop_rows[k0 + j];
@@ -386,27 +391,46 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
     c.row = row;
   }
   __syncthreads();
-  // cooperative copy of level l of every tree into LDS (coalesced: the level's nodes are contiguous in each array of the tree)
-  auto stage = [&](int l) {
-    __syncthreads();   // everyone is done with the previous level's image
-    for (int j = 0; j < K; ++j) {
-      const GibbsTree<D>& T = W[cst[j].row];
-      GibbsLevel<D>& G = lev[j];
-      if (l < L) {
-        const int n = 1 << l, o = n - 1;
-        for (int q = tid; q < n * D; q += kGibbsThreads) {
-          const int d = q >> l, z = q & (n - 1);
-          G.in.mean[d][z] = T.mean[d][o + z]; G.in.var[d][z] = T.var[d][o + z]; G.in.ivar[d][z] = T.ivar[d][o + z];
-        }
-        for (int q = tid; q < n; q += kGibbsThreads) {
-          int ra, rb; node_range(N, l, q, &ra, &rb);
-          G.in.cz[q] = T.cz[o + q]; G.in.lnc[q] = logn[rb - ra];
-        }
-      } else {
-        for (int q = tid; q < kGibbsMaxN * D; q += kGibbsThreads) (&G.ys[0][0])[q] = (&T.ys[0][0])[q];
+  // cooperative copy of level l of tree j into image slot `slot` (coalesced: the level's nodes are contiguous in each array of the tree)
+  auto copy_level = [&](int l, int j, int slot) {
+    const GibbsTree<D>& T = W[cst[j].row];
+    GibbsLevel<D>& G = lev[slot];
+    if (l < L) {
+      const int n = 1 << l, o = n - 1;
+      for (int q = tid; q < n * D; q += kGibbsThreads) {
+        const int d = q >> l, z = q & (n - 1);
+        G.in.mean[d][z] = T.mean[d][o + z]; G.in.var[d][z] = T.var[d][o + z]; G.in.ivar[d][z] = T.ivar[d][o + z];
       }
+      for (int q = tid; q < n; q += kGibbsThreads) {
+        int ra, rb; node_range(N, l, q, &ra, &rb);
+        G.in.cz[q] = T.cz[o + q]; G.in.lnc[q] = logn[rb - ra];
+      }
+    } else {
+      for (int q = tid; q < kGibbsMaxN * D; q += kGibbsThreads) (&G.ys[0][0])[q] = (&T.ys[0][0])[q];
     }
+  };
+  auto stage = [&](int l) {   // resident variables: level l of every tree
+    if (!resident) return;
+    __syncthreads();   // everyone is done with the previous level's image
+    for (int j = 0; j < K; ++j) copy_level(l, j, j);
     __syncthreads();
+  };
+  auto image = [&](int l, int j) -> const GibbsLevel<D>& {   // the image the candidate loops of (level l, tree j) read
+    if (resident) return lev[j];
+    __syncthreads();
+    copy_level(l, j, 0);
+    __syncthreads();
+    return lev[0];
+  };
+  // statistics of node sz of level l of tree i (a selected node: lane-divergent index): LDS image, or the tree itself when streaming
+  auto node_mean = [&](int l, int i, int d, int sz) -> float {
+    if (resident) return l < L ? lev[i].in.mean[d][sz] : lev[i].ys[d][sz];
+    const GibbsTree<D>& T = W[cst[i].row];
+    return l < L ? T.mean[d][(1 << l) - 1 + sz] : T.ys[d][sz];
+  };
+  auto node_ivar = [&](int l, int i, int d, int sz) -> float {
+    if (l == L) return cst[i].livar[d];
+    return resident ? lev[i].in.ivar[d][sz] : W[cst[i].row].ivar[d][(1 << l) - 1 + sz];
   };
   // ---- sampling: lane = output sample
   const int s = tid;
@@ -445,7 +469,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
         if (l - 1 == L) {   // the selected kernel itself: the particle at full precision, its bandwidth in double
           mabs = a.prop[(size_t)c.row * D * N + (size_t)d * N + W[c.row].perm[sz]];
           iv = 1.0 / (c.h[d] * c.h[d]);
-        } else { mabs = c.ref[d] + (double)lev[j].in.mean[d][sz]; iv = (double)lev[j].in.ivar[d][sz]; }
+        } else { mabs = c.ref[d] + (double)node_mean(l - 1, j, d, sz); iv = (double)node_ivar(l - 1, j, d, sz); }
         if (j == 0) mu0 = mabs;
         double dev = mabs - mu0;
         if (circ_bit(d)) dev = gwrap(dev);
@@ -468,10 +492,10 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
 #pragma unroll
           for (int k = 0; k < 3; ++k) iv[k] = 1.0 / (c.h[3 + k] * c.h[3 + k]);
         } else {
-          const double m[3] = {(double)lev[j].in.mean[3][sz], (double)lev[j].in.mean[4][sz], (double)lev[j].in.mean[5][sz]};
+          const double m[3] = {(double)node_mean(l - 1, j, 3, sz), (double)node_mean(l - 1, j, 4, sz), (double)node_mean(l - 1, j, 5, sz)};
           double E[4]; quat_exp(m, E); quat_mul(c.q0, E, Q);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) iv[k] = (double)lev[j].in.ivar[3 + k][sz];
+          for (int k = 0; k < 3; ++k) iv[k] = (double)node_ivar(l - 1, j, 3 + k, sz);
         }
         double dev[3] = {0.0, 0.0, 0.0};
         if (j == 0) { B[0] = Q[0]; B[1] = Q[1]; B[2] = Q[2]; B[3] = Q[3]; }
@@ -490,7 +514,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
     // (c) labels of level l given the point, which is expressed ONCE in the density's own chart (Euclidean there) and rounded
     for (int j = 0; j < K; ++j) {
       const GibbsConst<D>& c = cst[j];
-      const GibbsLevel<D>& G = lev[j];
+      const GibbsLevel<D>& G = image(l, j);
       Reservoir R; R.init(uniform_word());
       float e0[D];
       {
@@ -540,8 +564,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
             if (i == j) continue;
             const int sz = selbuf[i * 128 + tid];
             double mean, iv;
-            if (l < L) { mean = (double)lev[i].in.mean[d][sz]; iv = (double)lev[i].in.ivar[d][sz]; }
-            else { mean = (double)lev[i].ys[d][sz]; iv = (double)cst[i].livar[d]; }
+            mean = (double)node_mean(l, i, d, sz); iv = (double)node_ivar(l, i, d, sz);
             const double mabs = cst[i].ref[d] + mean;
             if (first) { mu0 = mabs; first = false; }
             double dev = mabs - mu0;
@@ -557,13 +580,8 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
             if (i == j) continue;
             const int sz = selbuf[i * 128 + tid];
             double m[3], iv[3];
-            if (l < L) {
 #pragma unroll
-              for (int k = 0; k < 3; ++k) { m[k] = (double)lev[i].in.mean[3 + k][sz]; iv[k] = (double)lev[i].in.ivar[3 + k][sz]; }
-            } else {
-#pragma unroll
-              for (int k = 0; k < 3; ++k) { m[k] = (double)lev[i].ys[3 + k][sz]; iv[k] = (double)cst[i].livar[3 + k]; }
-            }
+            for (int k = 0; k < 3; ++k) { m[k] = (double)node_mean(l, i, 3 + k, sz); iv[k] = (double)node_ivar(l, i, 3 + k, sz); }
             double E[4], Q[4], dev[3] = {0.0, 0.0, 0.0};
             quat_exp(m, E); quat_mul(cst[i].q0, E, Q);
             if (first) { B[0] = Q[0]; B[1] = Q[1]; B[2] = Q[2]; B[3] = Q[3]; first = false; }
@@ -579,7 +597,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
         float mx[D], cx[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) { mx[d] = (float)Mx[d]; cx[d] = (float)Cx[d]; }
-        const GibbsLevel<D>& G = lev[j];
+        const GibbsLevel<D>& G = image(l, j);
         Reservoir R; R.init(uniform_word());
         if (l < L) {
           for (int z = 0; z < nz; z += 2) {
@@ -666,13 +684,13 @@ hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t
     else if (dim == 3) hipLaunchKernelGGL((k_gibbs_trees<3>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_gibbs_trees<6>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
   }
-  // LDS of a block: one level image per proposal of its variable, sized for the variable with the most proposals (28 kB for the hub
-  // of Manhattan: five blocks per CU).  Launching the variables in two classes of proposal counts with a smaller LDS for the common
-  // case was measured SLOWER (1.25 -> 1.5 ms): with everything resident at once nothing rebalances the SIMDs, whereas at five
-  // blocks per CU the sorted order (largest first) is list scheduling: short blocks fill in behind the long ones.
-  const size_t per = (dim == 2 ? sizeof(GibbsLevel<2>) + sizeof(GibbsConst<2>)
-                               : (dim == 3 ? sizeof(GibbsLevel<3>) + sizeof(GibbsConst<3>) : sizeof(GibbsLevel<6>) + sizeof(GibbsConst<6>))) + 128;
-  const size_t bytes = per * (size_t)max_k;
+  // LDS of a block: kGibbsResident level images (variables with more proposals stream theirs through slot 0) + constants and labels
+  // for the variable with the most proposals
+  constexpr int kGibbsResident = 4;
+  a.k_lds = max_k < kGibbsResident ? max_k : kGibbsResident;
+  const size_t img = dim == 2 ? sizeof(GibbsLevel<2>) : (dim == 3 ? sizeof(GibbsLevel<3>) : sizeof(GibbsLevel<6>));
+  const size_t per = (dim == 2 ? sizeof(GibbsConst<2>) : (dim == 3 ? sizeof(GibbsConst<3>) : sizeof(GibbsConst<6>))) + 128;
+  const size_t bytes = img * (size_t)a.k_lds + per * (size_t)max_k;
   if (bytes > 150 * 1024) return hipErrorInvalidValue;
   auto launch = [&](auto kernel) -> hipError_t {
     if (bytes > 48 * 1024) {
