@@ -315,17 +315,25 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
     xs[lane + 64] = act[1] ? (float)y1 : 1.0e18f;  // padding: far away, weight exp2(-huge) = 0 against everything
     if (lane < 8) xs[128 + lane] = 1.0e18f;
   }
-  for (int j = 0; j < N; ++j) {
-    const double xj = pts[j];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      double d = x[s] - xj;
-      if (CIRC) d = lcv_wrap(d);
-      if (act[s] && lane + 64 * s != j) mn = fmin(mn, fabs(d));
-    }
-  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   const BlkPlan<B> pl = blk_plan<B>(N, lane);
+  {   // smallest pair distance, in double on the particles themselves: the lane's block pair, every unordered pair once
+    double pi[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) pi[u] = pts[min(pl.a * B + u, N - 1)];
+#pragma unroll 1
+    for (int jj = 0; jj < B; ++jj) {
+      const int j = pl.b * B + jj;
+      const double pj = pts[min(j, N - 1)];
+#pragma unroll
+      for (int ii = 0; ii < B; ++ii) {
+        double d = pi[ii] - pj;
+        if (CIRC) d = lcv_wrap(d);
+        const bool use = pl.ok && j < N && pl.a * B + ii < N && !(pl.diag && ii == jj);
+        mn = fmin(mn, use ? fabs(d) : __builtin_inf());
+      }
+    }
+  }
   mn = uniform_f64(wave_min(mn)); ylo = uniform_f64(wave_min(ylo)); yhi = uniform_f64(-wave_min(-yhi));
   // the search state is wave-uniform: every update goes through readfirstlane (U) so that it lives in scalar registers across the
   // unrolled block body instead of being spilled around it
