@@ -50,10 +50,23 @@ class DeviceGraph:
             factor = np.concatenate([factor, F + np.arange(P, dtype=np.int32)])
             dr = np.concatenate([dr, np.full(P, 2, dtype=np.int32)])
             fixed = np.concatenate([fixed, ptab["var"]]); target = np.concatenate([target, ptab["var"]])
+            # multihypo factors (Pose2Pose2 over two candidates of the second pose): alternative / probability per row, and one
+            # more row per such factor -- the proposal of the second candidate -- BEHIND the prior rows (rows 2f+dir and 2F+p keep
+            # their meaning).  A table with hypotheses runs on the general kernel, one without on the lean one.
+            hyp = PackedGraph.conv_hypotheses(tab) if "alt" in tab else None
+            E = 0
+            alt = w = None
+            if hyp is not None:
+                alt2, w2, ex = hyp
+                E = len(ex["factor"])
+                alt = np.concatenate([alt2, np.full(P, -1, np.int32), ex["alt"]]); w = np.concatenate([w2, np.ones(P), ex["w"]])
+                factor = np.concatenate([factor, ex["factor"]]); dr = np.concatenate([dr, ex["dir"]])
+                fixed = np.concatenate([fixed, ex["fixed"]]); target = np.concatenate([target, ex["target"]])
             # rows4: the four table columns interleaved (one 16-byte scalar load per convolution; selects the lean kernel)
-            self.tab[name] = dict(F=F, P=P, C_rel=2 * F, C=2 * F + P, mu=t(mu, f64), L=t(cholesky_lower(cov), f64),
+            self.tab[name] = dict(F=F, P=P, E=E, C_rel=2 * F, C=2 * F + P + E, mu=t(mu, f64), L=t(cholesky_lower(cov), f64),
                                   factor=t(factor, i32), dir=t(dr, i32), fixed=t(fixed, i32), target=t(target, i32),
-                                  rows4=t(np.stack([factor, dr, fixed, target], axis=1), i32))
+                                  rows4=t(np.stack([factor, dr, fixed, target], axis=1), i32), mh=hyp is not None,
+                                  alt=t(alt, i32) if alt is not None else None, w=t(w, f64) if w is not None else None)
         if pk.br["F"]:
             b = pk.br
             r0 = b["rows0"]
@@ -142,7 +155,8 @@ class DeviceGraph:
         fn = getattr(self._lib, name)
         if fam in ("p2p2", "p3p3"):
             tb = self.tab[fam]
-            return dict(n=tb["C"], fn=fn, vt_fixed=vf, vt_target=vt, dir_all=0, rows4=tb["rows4"], mu=tb["mu"], L=tb["L"], alt=None, w=None)
+            return dict(n=tb["C"], fn=fn, vt_fixed=vf, vt_target=vt, dir_all=0, rows4=tb["rows4"], mu=tb["mu"], L=tb["L"],
+                        alt=tb["alt"] if tb["mh"] else None, w=tb["w"] if tb["mh"] else None)
         tb = self.tab["br"]
         if fam == "br1":
             return dict(n=tb["F"], fn=fn, vt_fixed=vf, vt_target=vt, dir_all=1, rows4=tb["rows4_1"], mu=tb["mu"], L=tb["sigma"],
@@ -206,10 +220,11 @@ class DeviceGraph:
 
     def plan_sweep_pose2pose2(self, opts, out, noise=None, status=None):
         tb = self.tab["p2p2"]
+        mh = dict(alt_var=tb["alt"], hypo_w=tb["w"]) if tb["mh"] else {}
         return self._plan(self._lib.rome_conv_pose2pose2_dev, opts, n_conv=tb["C"], dir_all=0,
                           factor=tb["factor"], dir=tb["dir"], fixed_var=tb["fixed"], target_var=tb["target"], rows4=tb["rows4"],
                           mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Pose2],
-                          noise=noise, out=out, status=status)
+                          noise=noise, out=out, status=status, **mh)
 
     def plan_sample_priors(self, opts, out, kind="prior2", noise=None):
         tb = self.tab[kind]
@@ -359,18 +374,19 @@ class DeviceGraph:
 
     # ---- sweeps ----
     def sweep_pose2pose2(self, opts, out=None, noise=None, status=None, conv_slice=None):
-        """All (factor, direction) Pose2Pose2 convolutions (row 2f+dir) followed by the PriorPose2 rows
-        -> proposals [2F+P, 3, N], one launch."""
+        """All (factor, direction) Pose2Pose2 convolutions (row 2f+dir) followed by the PriorPose2 rows (and one row per multihypo
+        factor for its second candidate) -> proposals [2F+P+E, 3, N], one launch."""
         tb = self.tab["p2p2"]
         lo, hi = (0, tb["C"]) if conv_slice is None else conv_slice
         n = hi - lo
         if out is None:
             out = self.torch.empty((n, 3, self.N), dtype=self.torch.float64, device=self.device)
         o = _lib.Opts.from_buffer_copy(opts); o.stream_offset = opts.stream_offset + lo
+        mh = dict(alt_var=tb["alt"][lo:hi], hypo_w=tb["w"][lo:hi]) if tb["mh"] else {}
         self._launch(self._lib.rome_conv_pose2pose2_dev, o, n_conv=n, dir_all=0,
                      factor=tb["factor"][lo:hi], dir=tb["dir"][lo:hi], fixed_var=tb["fixed"][lo:hi], target_var=tb["target"][lo:hi],
                      rows4=tb["rows4"][lo:hi], mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Pose2],
-                     noise=noise, out=out, status=status)
+                     noise=noise, out=out, status=status, **mh)
         return out
 
     def sweep_pose3pose3(self, opts, out=None, noise=None, status=None):

@@ -333,8 +333,13 @@ class TargetShardedSweep:
             o.stream_offset = opts.stream_offset + self.row_lo
         n = self.row_hi - self.row_lo
         self.n_rows = n
+        mh = {}
+        if tb["alt"] is not None:   # multihypo rows travel with their rows through the sort
+            idx = torch.as_tensor(order, device=tb["alt"].device)
+            self.alt, self.w = tb["alt"][idx].contiguous(), torch.as_tensor(tb["w"])[idx.to(torch.as_tensor(tb["w"]).device)].contiguous()
+            mh = dict(alt_var=self.alt[self.row_lo:self.row_hi], hypo_w=self.w[self.row_lo:self.row_hi])
         self.plan = dg._plan(tb["fn"], o, n_conv=n, dir_all=tb["dir_all"], rows4=self.rows4[self.row_lo:self.row_hi], mu=tb["mu"], L=tb["L"],
-                             bel_fixed=self.store, bel_target=self.store, out=self.prop[self.row_lo:self.row_hi]) if n else (lambda: None)
+                             bel_fixed=self.store, bel_target=self.store, out=self.prop[self.row_lo:self.row_hi], **mh) if n else (lambda: None)
         self.mine = self.store[rank * q:(rank + 1) * q]
         self.comm = rccl_comm if (rccl_comm is not None and self.collective and any_bel.is_cuda) else None
         self.work = None

@@ -38,8 +38,7 @@ class FactorGraph:
     def addFactor(self, labels, factor, multihypo=None):
         """multihypo=[1.0, w1, w2] (IIF kwarg, test/testMultimodalRangeBearing.jl:53): the SECOND variable of a two-variable factor is
         labels[1] with probability w1 or labels[2] with probability w2 -- a Pose2Point2BearingRange over [pose, l1, l2] (every use in
-        the reference) or a Pose2Pose2 over [a, b1, b2] (per-factor convolutions only: approxConv; the whole-graph tables do not
-        carry Pose2Pose2 hypotheses)."""
+        the reference) or a Pose2Pose2 over [a, b1, b2] (IIF accepts the keyword on any factor)."""
         labels = list(labels)
         if multihypo is not None:
             if not isinstance(factor, (Pose2Point2BearingRange, Pose2Pose2)) or len(labels) != 3 or len(multihypo) != 3:
@@ -427,12 +426,9 @@ class PackedGraph:
         p2, br, p3, pr2, pr3, prpt = [], [], [], [], [], []
         for flabel, labels, f in fg.factors:
             ids = [self.index[l] for l in labels]
-            if isinstance(f, Pose2Pose2):
-                if fg.multihypo.get(flabel) is not None:
-                    raise NotImplementedError("%s: Pose2Pose2 multihypo is served by approxConv (per-factor path), not by the graph tables" % flabel)
-                p2.append((ids, f, flabel))
+            if isinstance(f, Pose2Pose2): p2.append((ids, f, flabel, fg.multihypo.get(flabel)))
             elif isinstance(f, Pose2Point2BearingRange): br.append((ids, f, flabel, fg.multihypo.get(flabel)))
-            elif isinstance(f, Pose3Pose3): p3.append((ids, f, flabel))
+            elif isinstance(f, Pose3Pose3): p3.append((ids, f, flabel, None))
             elif isinstance(f, PriorPose2): pr2.append((ids, f, flabel))
             elif isinstance(f, PriorPose3): pr3.append((ids, f, flabel))
             elif isinstance(f, PriorPoint2): prpt.append((ids, f, flabel))
@@ -442,9 +438,12 @@ class PackedGraph:
             F = len(items)
             mu = np.zeros((F, d)); cov = np.zeros((F, d, d))
             vfrom = np.zeros(F, dtype=np.int32); vto = np.zeros(F, dtype=np.int32)
-            for k, (ids, f, _) in enumerate(items):
-                mu[k] = f.Z.mu; cov[k] = f.Z.cov; vfrom[k], vto[k] = ids
-            return dict(F=F, mu=mu, cov=cov, var_from=vfrom, var_to=vto, labels=[it[2] for it in items])
+            alt = np.full(F, -1, dtype=np.int32); w = np.ones(F); w2 = np.zeros(F)
+            for k, (ids, f, _, mh) in enumerate(items):
+                mu[k] = f.Z.mu; cov[k] = f.Z.cov; vfrom[k], vto[k] = ids[:2]
+                if mh is not None:   # multihypo over the second pose: var_to with probability w, else alt
+                    alt[k] = ids[2]; w[k], w2[k] = mh
+            return dict(F=F, mu=mu, cov=cov, var_from=vfrom, var_to=vto, alt=alt, w=w, w2=w2, labels=[it[2] for it in items])
 
         self.p2p2 = rel_tables(p2, 3)
         self.p3p3 = rel_tables(p3, 6)
@@ -512,6 +511,20 @@ class PackedGraph:
         fixed[1::2] = tab["var_to"]; target[1::2] = tab["var_from"]
         return factor, d, fixed, target
 
+    @staticmethod
+    def conv_hypotheses(tab):
+        """multihypo columns of a relative-pose table, or None when no factor carries hypotheses:
+        (alt, w) for the 2F interleaved rows of conv_table -- both rows of a multihypo factor name the other candidate and the
+        probability of their own -- and `extra`: one more row per such factor, (f, dir 0, fixed = from, target = the second candidate)
+        with alt = the first candidate and w = its own probability (the second candidate receives a proposal too)."""
+        mh = np.nonzero(tab["alt"] >= 0)[0].astype(np.int32)
+        if mh.size == 0:
+            return None
+        alt = np.repeat(tab["alt"], 2).astype(np.int32); w = np.repeat(tab["w"], 2).astype(np.float64)
+        extra = dict(factor=mh, dir=np.zeros(mh.size, np.int32), fixed=tab["var_from"][mh], target=tab["alt"][mh],
+                     alt=tab["var_to"][mh], w=tab["w2"][mh].astype(np.float64))
+        return alt, w, extra
+
     def beliefs(self, fg, vartype):
         """(V, dim, N) SoA blocks from fg.vals (all variables of the type must be initialised)."""
         ls = self.labels[vartype]
@@ -565,7 +578,7 @@ def dead_reckon_init(fg, seed=1, sigma=(0.1, 0.1, 0.05)):
         progress = False
         rest = []
         for labels, f in pending:
-            a, b = labels
+            a, b = labels[:2]   # (a multihypo factor dead-reckons through its first candidate)
             if a in mean and b not in mean:
                 mean[b] = se2_compose(mean[a], f.Z.mu); progress = True
             elif b in mean and a not in mean:

@@ -16,7 +16,13 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
     L = np.array([ro.cholesky_lower(c) for c in cov])
     factor = np.concatenate([factor, F + np.arange(P)]); dr = np.concatenate([dr, np.full(P, 2)])
     fixed = np.concatenate([fixed, pk.prior2["var"]]); target = np.concatenate([target, pk.prior2["var"]])
-    C2 = 2 * F + P
+    hyp = R.PackedGraph.conv_hypotheses(pk.p2p2)   # multihypo Pose2Pose2 factors: alternative / probability per row + extra rows
+    E = 0
+    if hyp is not None:
+        alt2, w2, ex = hyp
+        E = len(ex["factor"])
+        target = np.concatenate([target, ex["target"]])
+    C2 = 2 * F + P + E
     Fb = pk.br["F"]
     tg2 = np.concatenate([target, pk.br["pose"]]) if Fb else target
     r0 = pk.br["rows0"]; Fb0 = len(r0["factor"])
@@ -32,9 +38,12 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
     for s in range(n_sweeps):
         base = s << 32
         mk = lambda off: ro.make_opts(N=N, solver=solver, seed=seed, stream_offset=base + off)
-        rel = dr != 2
         prop2 = np.zeros((C2 + Fb, 3, N))
-        prop2[:C2][rel] = ro.conv_pose2pose2(mk(S["P2P2"]), mu, L, bel2, fixed[rel], target[rel], dr[rel], factor=factor[rel])
+        mhkw = {} if hyp is None else dict(alt_var=alt2, hypo_w=w2)
+        prop2[:2 * F] = ro.conv_pose2pose2(mk(S["P2P2"]), mu, L, bel2, fixed[:2 * F], target[:2 * F], dr[:2 * F], factor=factor[:2 * F], **mhkw)
+        if E:   # the proposals of the second candidates: rows behind the priors, Philox stream = row index
+            prop2[2 * F + P:C2] = ro.conv_pose2pose2(mk(S["P2P2"] + 2 * F + P), mu, L, bel2, ex["fixed"], ex["target"], ex["dir"],
+                                                     factor=ex["factor"], alt_var=ex["alt"], hypo_w=ex["w"])
         # prior rows: stream id = row index
         for k in range(P):
             o = ro.make_opts(N=N, seed=seed, stream_offset=base + S["P2P2"] + 2 * F + k)

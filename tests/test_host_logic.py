@@ -326,8 +326,8 @@ def test_loadg2o_max_edges_counts_edges_only(tmp_path):
     assert sum(1 for _, _, f in fg.factors if isinstance(f, R.Pose2Pose2)) == 2
 
 
-def test_multihypo_is_accepted_on_pose2pose2_and_refused_by_the_graph_tables():
-    """IIF's `multihypo=` keyword on a relative pose factor: labels [a, b1, b2]; served by approxConv only (per-factor path)."""
+def test_multihypo_is_accepted_on_pose2pose2_and_carried_by_the_graph_tables():
+    """IIF's `multihypo=` keyword on a relative pose factor: labels [a, b1, b2]."""
     fg = R.initfg(10)
     for l in ("a", "b1", "b2"):
         fg.addVariable(l, R.Pose2)
@@ -339,7 +339,9 @@ def test_multihypo_is_accepted_on_pose2pose2_and_refused_by_the_graph_tables():
         fg.addFactor(["a", "b1", "l0"], f, multihypo=[1.0, 0.5, 0.5])       # the alternative must be a Pose2 too
     with pytest.raises(ValueError):
         fg.addFactor(["a", "b1", "b2"], f, multihypo=[1.0, 0.6, 0.6])
-    with pytest.raises(NotImplementedError):
-        R.PackedGraph(fg)
+    pk = R.PackedGraph(fg)                                                     # the tables carry the hypotheses
+    alt, w, ex = R.PackedGraph.conv_hypotheses(pk.p2p2)
+    assert list(alt) == [pk.index["b2"]] * 2 and list(w) == [0.6, 0.6]
+    assert list(ex["target"]) == [pk.index["b2"]] and list(ex["alt"]) == [pk.index["b1"]] and list(ex["w"]) == [0.4] and list(ex["dir"]) == [0]
     fg.deleteFactor(fl)
-    assert fl not in fg.multihypo and R.PackedGraph(fg).p2p2["F"] == 0
+    assert fl not in fg.multihypo and R.PackedGraph(fg).p2p2["F"] == 0 and R.PackedGraph.conv_hypotheses(R.PackedGraph(fg).p2p2) is None
