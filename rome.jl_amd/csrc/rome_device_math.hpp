@@ -22,27 +22,26 @@ constexpr double kSqrtEps = 1.4901161193847656e-8;  // Julia isapprox default rt
 // ------------------------------------------------------------------------------------------
 // elementary functions tuned for this path
 // ------------------------------------------------------------------------------------------
-// sin/cos with a two-term Cody-Waite reduction by π/2 (FMA) and the fdlibm kernel polynomials.
-// Abs error ≈ 2e-16 for |x| <= 1e5 (checked against libm on 5e6 points) and ≈ |x|·1e-21 beyond; every
-// angle on this path is a pose heading, a rotation-vector norm or 2πu, i.e. O(1..100).  No library
-// fallback on purpose: the Payne-Hanek path of ocml's sincos costs ~60 VGPRs at every call site.
+// sin/cos by table and short polynomials: x = n·π/128 + r, |r| <= π/256 (two-term Cody-Waite reduction with FMA), sin/cos of
+// n·π/128 from a 256-entry table of correctly rounded doubles (4 kB, one 16-byte load through the vector cache), sin r / cos r to
+// r⁵ / r⁶ (truncation < 1e-17), combined by the angle-addition formulas.  16 double-precision instructions instead of the 31 + 6
+// selects of the π/2 reduction with the fdlibm kernel polynomials it replaces (a double-precision instruction issues in 5.8
+// cycles per wave on gfx950: 1.5 of the headline kernel's 16.7 µs were sincos).  Abs error <= 3e-16 for |x| <= 1e5 (checked against
+// libm on 5e6 points, tests/test_gpu_parity.py); every angle on this path is a pose heading, a rotation-vector norm or 2πu.
+__device__ static const double kSinCosTable[512] = {
+#include "rome_sincos_table.inc"
+};
 __device__ __forceinline__ void fast_sincos(double x, double* sn, double* cs) {
-  const double n = rint(x * 0.63661977236758134308);  // 2/π
-  double r = fma(-n, 1.5707963267948966, x);
-  r = fma(-n, 6.123233995736766e-17, r);
-  const int q = (int)n;
+  const double n = rint(x * 40.74366543152521);                 // 128/π
+  double r = fma(-n, 0x1.921fb54442d18p-6, x);                   // π/128, high and low parts
+  r = fma(-n, 0x1.1a62633145c07p-60, r);
+  const int k = (int)n & 255;
+  const double2 t = *reinterpret_cast<const double2*>(&kSinCosTable[2 * k]);   // (sin, cos) of n·π/128
   const double z = r * r;
-  const double ps = r + r * z * fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                                                              2.75573137070700676789e-06), -1.98412698298579493134e-04),
-                                           8.33333333332248946124e-03), -1.66666666666666324348e-01);
-  const double pc = fma(z * z, fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                                                              -2.75573143513906633035e-07), 2.48015872894767294178e-05),
-                                           -1.38888888888741095749e-03), 4.16666666666666019037e-02),
-                        fma(-0.5, z, 1.0));
-  const double s0 = (q & 1) ? pc : ps;
-  const double c0 = (q & 1) ? ps : pc;
-  *sn = (q & 2) ? -s0 : s0;
-  *cs = ((q + 1) & 2) ? -c0 : c0;
+  const double sr = fma(r * z, fma(z, 8.33333333333333333e-03, -1.66666666666666667e-01), r);
+  const double cr = fma(z, fma(z, fma(z, -1.38888888888888889e-03, 4.16666666666666667e-02), -0.5), 1.0);
+  *sn = fma(t.x, cr, t.y * sr);
+  *cs = fma(t.y, cr, -(t.x * sr));
 }
 
 // θ -> [-π, π]: same value as atan2(sin θ, cos θ) up to an ulp (and the ±π tie), without transcendentals.
