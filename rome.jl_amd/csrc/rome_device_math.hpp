@@ -26,8 +26,8 @@ constexpr double kSqrtEps = 1.4901161193847656e-8;  // Julia isapprox default rt
 // n·π/128 from a 256-entry table of correctly rounded doubles (4 kB, one 16-byte load through the vector cache), sin r / cos r to
 // r⁵ / r⁶ (truncation < 1e-17), combined by the angle-addition formulas.  16 double-precision instructions instead of the 31 + 6
 // selects of the π/2 reduction with the fdlibm kernel polynomials it replaces (a double-precision instruction issues in 5.8
-// cycles per wave on gfx950: 1.5 of the headline kernel's 16.7 µs were sincos).  Abs error <= 3e-16 for |x| <= 1e5 (checked against
-// libm on 5e6 points, tests/test_gpu_parity.py); every angle on this path is a pose heading, a rotation-vector norm or 2πu.
+// cycles per wave on gfx950: 1.5 of the headline kernel's 16.7 µs were sincos).  Abs error <= 5e-16 for |x| <= 1e5 (against numpy,
+// tests/test_gpu_device_math.py); every angle on this path is a pose heading, a rotation-vector norm or 2πu.
 __device__ static const double kSinCosTable[512] = {
 #include "rome_sincos_table.inc"
 };

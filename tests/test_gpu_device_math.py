@@ -22,6 +22,7 @@ def test_device_math_against_numpy(tmp_path):
     n = 200000
     x = rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 2.5, n)
     y = rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 2.5, n)
+    x[8:2008] = rng.uniform(-1e5, 1e5, 2000)                                         # sin/cos: headings far from the principal range
     x[:8] = [0.0, np.pi, -np.pi, 1e-300, 3.0 * np.pi, -0.0, 745.0, 1.0]
     y[:8] = [0.0, 0.0, 1e-300, 1.0, -2.0, 5.0, 1e-12, 1.0]
     np.concatenate([x, y]).tofile(str(tmp_path / "in.bin"))
