@@ -87,7 +87,7 @@ void ro_box_muller(uint32_t wa, uint32_t wb, double* n0, double* n1) {
   p = fmaf(p, t, 0x1.555544p-1f);
   p = fmaf(p, t, 0x1.9f324cp-2f);                                       /* ln m */
   const float h = fmaf(ke, 0x1.62e43p-1f, -p);                          /* -ln u1 (ln2 rounded to single) */
-  const double rr = h > 0.0f ? sqrt((double)h) : 0.0;
+  const float rr = h > 0.0f ? sqrtf(h) : 0.0f;                             /* IEEE single-precision square root */
   const float a = (float)(int32_t)(wb << 2) * 0x1.921fb6p-32f;           /* (π/4)·2^-31 */
   const float z = a * a;
   float sp = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
@@ -96,9 +96,9 @@ void ro_box_muller(uint32_t wa, uint32_t wb, double* n0, double* n1) {
   float cp = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
   cp = fmaf(z, cp, 4.166664568298827e-2f);
   const float cs = fmaf(z * z, cp, fmaf(z, -0.5f, 1.0f));
-  const double d0 = (double)(cs - sn), d1 = (double)(cs + sn);
-  *n0 = (wb & 0x80000000u) ? -(rr * d0) : rr * d0;
-  *n1 = (wb & 0x40000000u) ? -(rr * d1) : rr * d1;
+  const float m0 = rr * (cs - sn), m1 = rr * (cs + sn);                  /* single-precision products: the draws are floats */
+  *n0 = (double)((wb & 0x80000000u) ? -m0 : m0);
+  *n1 = (double)((wb & 0x40000000u) ? -m1 : m1);
 }
 /* d == 3: particles p and p ^ 64 share the second Box-Muller pair of the call of particle p & ~64 (cosine branch for bit 6 clear,
  * sine branch otherwise) instead of each discarding one normal -- same rule as rng_normals<3> in the HIP path. */

@@ -158,14 +158,14 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {  // (0,1]
 }
 
 // One Box-Muller pair from two Philox words.  The transform is defined in IEEE single-precision operations (explicit fmaf
-// only, contraction off) -- the same function, bit for bit, as ro_box_muller in oracle/rome_oracle.c up to the final
-// double-precision square root and products:
+// only, contraction off) -- the same function, bit for bit, as ro_box_muller in oracle/rome_oracle.c:
 //   radius  u1 = x·2^-32, x = float(wa) + 1 in [1, 2^32]: -ln u1 = (32 - e) ln2 - ln m, x = m·2^e, ln m a degree-7 polynomial
 //           in m - 1.5 (|error| <= 2.7e-7; no division, no library log);
 //   angle   a = (π/4)·int32(wb << 2)·2^-31 in [-π/4, π/4): the direction (cos a - sin a, cos a + sin a)/√2 is the angle π/4 + a,
 //           uniform on the first quadrant; bits 31 / 30 of wb mirror it into the other three (no range reduction at all);
 //   n0 = ±√(-ln u1)·(c - s), n1 = ±√(-ln u1)·(c + s).
-// ≈ 50 VALU instructions per pair (the FP64 log / sqrt / sincos form this replaces: ≈ 135); draws carry 24-bit mantissas.
+// ≈ 50 VALU instructions per pair, none in double precision but the final conversions (the FP64 log / sqrt / sincos form it
+// replaces: ≈ 135); draws carry 24-bit mantissas.
 __device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, double* n0, double* n1) {
 #pragma clang fp contract(off)
   const float x = (float)wa + 1.0f;
@@ -181,7 +181,7 @@ __device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, double* n0,
   p = __builtin_fmaf(p, t, 0x1.555544p-1f);
   p = __builtin_fmaf(p, t, 0x1.9f324cp-2f);
   const float h = __builtin_fmaf(ke, 0x1.62e43p-1f, -p);
-  const double rr = fast_sqrt((double)h);      // 0 for h <= 0
+  const float rr = h > 0.0f ? __builtin_sqrtf(h) : 0.0f;   // IEEE single-precision square root (correctly rounded expansion)
   const float a = (float)(int32_t)(wb << 2) * 0x1.921fb6p-32f;
   const float z = a * a;
   float sp = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
@@ -190,11 +190,10 @@ __device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, double* n0,
   float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
   cp = __builtin_fmaf(z, cp, 4.166664568298827e-2f);
   const float cs = __builtin_fmaf(z * z, cp, __builtin_fmaf(z, -0.5f, 1.0f));
-  const double d0 = (double)(cs - sn), d1 = (double)(cs + sn);
-  // signs straight into the high words of the doubles (bit 31 of wb -> n0, bit 30 -> n1)
-  const double m0 = rr * d0, m1 = rr * d1;
-  *n0 = __hiloint2double(__double2hiint(m0) ^ (int)(wb & 0x80000000u), __double2loint(m0));
-  *n1 = __hiloint2double(__double2hiint(m1) ^ (int)((wb << 1) & 0x80000000u), __double2loint(m1));
+  // single-precision products, signs by bit 31 of wb -> n0 and bit 30 -> n1, converted once: the draws are floats
+  const float m0 = rr * (cs - sn), m1 = rr * (cs + sn);
+  *n0 = (double)__uint_as_float(__float_as_uint(m0) ^ (wb & 0x80000000u));
+  *n1 = (double)__uint_as_float(__float_as_uint(m1) ^ ((wb << 1) & 0x80000000u));
 }
 __device__ __forceinline__ u32x4 noise_words(uint64_t seed, uint64_t stream, uint32_t particle, uint32_t b) {
   return philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32), (kDomainNoise << 16) | b},
