@@ -113,7 +113,7 @@ __device__ __forceinline__ double lcv_golden(const double (&x)[S], const bool (&
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Fast path, 64 < N <= 128 (k_kde_bandwidth_fast): the same golden-section search -- bracket arithmetic in double, identical
+// Fast path, 8 <= N <= 128 (k_kde_bandwidth_fast): the same golden-section search -- bracket arithmetic in double, identical
 // iterates -- with the likelihood evaluated in single precision on the hardware exponential:
 //   * row sums by the blocked symmetric scheme below (lcv_eval_blk): every unordered pair of particles is evaluated once.  The
 //     particles are staged as single-precision offsets from particle 0 (a fixed 6e-8·range perturbation of the data, the same for
@@ -164,8 +164,9 @@ __device__ __forceinline__ void lcv_g64(const double (&x)[2], const bool (&act)[
   *dg = v[1] / (h * h * h) - 2.0 * (double)N * h;
 }
 
-// ---- blocked SYMMETRIC evaluation of the row sums (fast path, 64 < N <= 128) -----------------------------------------------------
-// The N particles are cut into nb <= 10 blocks of B (10 for N <= 100, else 13; the tail padded with far-away points of weight 0) and
+// ---- blocked SYMMETRIC evaluation of the row sums (fast path, 8 <= N <= 128) -----------------------------------------------------
+// The N particles are cut into nb <= 10 blocks of B (7 for N <= 70, 10 for N <= 100, else 13; the tail padded with far-away points of
+// weight 0) and
 // every lane owns ONE unordered pair of blocks (a <= b): nb(nb+1)/2 <= 55 lanes busy.  A lane evaluates its B x B weights once and
 // accumulates them both ways -- B row partials for block a, B column partials for block b -- in registers, with the 2B particle
 // values in registers too: per UNORDERED pair 3 VALU + v_exp_f32 + 2 accumulates = 21 issue cycles (the ring scheme before it: 20
@@ -311,7 +312,7 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
     double y0 = x[0] - x0v, y1 = x[1] - x0v;
     if (CIRC) { y0 = lcv_wrap(y0); y1 = lcv_wrap(y1); }
     ylo = fmin(fmin(ylo, y0), y1); yhi = fmax(fmax(yhi, y0), y1);   // idle slots hold particle 0: y = 0
-    xs[lane] = (float)y0;                          // (64 < N: every lane has a first particle)
+    xs[lane] = act[0] ? (float)y0 : 1.0e18f;
     xs[lane + 64] = act[1] ? (float)y1 : 1.0e18f;  // padding: far away, weight exp2(-huge) = 0 against everything
     if (lane < 8) xs[128 + lane] = 1.0e18f;
   }
@@ -528,7 +529,10 @@ hipError_t launch_kde_bandwidth(int dim, int V, int N, const double* bel, uint32
   if (T <= 0) return hipSuccess;
   const dim3 grid((T + kKdeWaves - 1) / kKdeWaves), block(64 * kKdeWaves);
 #define ROME_LAUNCH_KDE(SS) hipLaunchKernelGGL((k_kde_bandwidth<SS>), grid, block, 0, s, T, dim, N, bel, circ_mask, tol_e, tol_c, bw, evals)
-  if (N <= 64) ROME_LAUNCH_KDE(1);
+  if (N < 8) ROME_LAUNCH_KDE(1);
+  else if (N <= 70)
+    hipLaunchKernelGGL((k_kde_bandwidth_fast<7>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<7>(N), s, T, dim, N, bel, circ_mask,
+                       tol_e, tol_c, bw, evals);
   else if (N <= 100)
     hipLaunchKernelGGL((k_kde_bandwidth_fast<10>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<10>(N), s, T, dim, N, bel, circ_mask,
                        tol_e, tol_c, bw, evals);
