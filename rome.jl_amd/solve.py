@@ -37,11 +37,13 @@ def initAll(fg, seed=1, solver=None):
     return [l for l in fg.ls() if not fg.isInitialized(l)]
 
 
-def solveGraph(fg, n_sweeps=10, seed=0x524F4D45, init="graph", bandwidth="silverman", frozen=None, opts=None, product="importance"):
+def solveGraph(fg, n_sweeps=10, seed=0x524F4D45, init="graph", bandwidth="silverman", frozen=None, opts=None, product="importance",
+               gibbs_iters=1):
     """initialise -> device sweeps -> download -> setPPE.  init: "graph" (initAll for whatever has no belief yet), "parametric"
     (beliefs around solveGraphParametric's solution, like IIF's initParametricFrom!) or None (beliefs must exist).
     product: "gibbs" = the reference's `manifoldProduct` (multiscale Gibbs product on `manikde!` bandwidths) per variable,
-    "importance" = the round-1 stand-in.  Returns the DeviceGraph (beliefs stay resident for further sweeps)."""
+    "importance" = the round-1 stand-in; gibbs_iters = AMP's `Niter` (1 at the reference's default; the relative weight of the modes of
+    a multimodal product needs ~3, tests/test_gpu_gibbs.py).  Returns the DeviceGraph (beliefs stay resident for further sweeps)."""
     from .api import make_opts
     from .canonical import setPPE
     from .device import DeviceGraph
@@ -59,7 +61,8 @@ def solveGraph(fg, n_sweeps=10, seed=0x524F4D45, init="graph", bandwidth="silver
         dg.upload_beliefs(fg)
     if frozen:
         dg.set_frozen(frozen)
-    dg.solve(opts if opts is not None else make_opts(N=fg.N, seed=seed), n_sweeps=n_sweeps, bandwidth=bandwidth, product=product)
+    dg.solve(opts if opts is not None else make_opts(N=fg.N, seed=seed), n_sweeps=n_sweeps, bandwidth=bandwidth, product=product,
+             gibbs_iters=gibbs_iters)
     dg.download_beliefs(fg)
     setPPE(fg)
     return dg
