@@ -65,6 +65,21 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// value of lane (l ^ j), j a power of two < 64 (a constant once the sort is unrolled): DPP moves inside a 16-lane row (quad permutes
+// for 1 and 2; for 4 and 8 a left and a right row shift, each kept by the banks it is valid for), ds_bpermute across rows.
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int j) {
+  const int x = (int)v;
+  switch (j) {
+    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
+    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
+    case 4: { const int a = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);
+              return (uint32_t)__builtin_amdgcn_update_dpp(a, x, 0x114, 0xF, 0xA, false); }
+    case 8: { const int a = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xF, 0x3, false);
+              return (uint32_t)__builtin_amdgcn_update_dpp(a, x, 0x118, 0xF, 0xC, false); }
+    default: return (uint32_t)__shfl_xor(x, j, 64);
+  }
+}
+
 // one wavefront builds tree `T` of proposal `P` ([D][N] doubles, bandwidths h); scr: 2 x 128 x D ints of per-wave scratch
 template <int D>
 __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restrict__ P, const double* __restrict__ hb, int row,
@@ -136,7 +151,9 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
       } else key[s] = ~0ull;
     }
     // bitonic sort of the 128 keys (position p = lane + 64 s), ascending
+#pragma unroll
     for (int k2 = 2; k2 <= 128; k2 <<= 1) {
+#pragma unroll
       for (int j2 = k2 >> 1; j2 >= 1; j2 >>= 1) {
         if (j2 == 64) {   // partner = other slot of the same lane (only in the last stage: ascending everywhere)
           const uint64_t a = key[0] < key[1] ? key[0] : key[1], b = key[0] < key[1] ? key[1] : key[0];
@@ -145,7 +162,7 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             const int p = lane + 64 * s;
-            const uint32_t plo = __shfl_xor((uint32_t)key[s], j2, 64), phi = __shfl_xor((uint32_t)(key[s] >> 32), j2, 64);
+            const uint32_t plo = lane_xor((uint32_t)key[s], j2), phi = lane_xor((uint32_t)(key[s] >> 32), j2);
             const uint64_t other = ((uint64_t)phi << 32) | plo;
             const bool up = (p & k2) == 0;              // ascending block
             const bool lower = (p & j2) == 0;           // this position keeps the smaller key of the pair when ascending
