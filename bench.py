@@ -169,7 +169,7 @@ def main():
         conv_first = 2 * f_first + 1                             # odometry x0->x1, dir 1 -> target x0
         conv_last = 2 * f_last + 0                               # odometry x_{P-2}->x_{P-1}, dir 0 -> target x_{P-1}
         # pipeline depth = steps in flight (a ghost belief is `depth` steps old): the step period is max(sweep, (sweep + exchange) /
-        # depth).  One rank, exchange forced: 13.5 µs per step for every depth 2..6 (profiles/r02_bench_n1_forced_exchange.json); a
+        # depth).  One rank, exchange forced: 12.6–13.7 µs per step for every depth 2..6 (profiles/r02_bench_n1_forced_exchange.json); a
         # ring all-gather over more than two GPUs costs several sweeps of latency, so four slots there
         depth = int(os.environ.get("ROME_PIPE_DEPTH", "4" if world > 2 else "2"))
         # separator exchange through RCCL directly (one communicator per pipeline slot, enqueued on the sweep's own stream);
