@@ -27,7 +27,10 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-BYTES_PER_PARTICLE_P2P2 = 72  # fixed pose 3 + start point u0 3 + solution 3 doubles (in-kernel RNG: no noise read)
+# algorithmic HBM bytes per Pose2Pose2 particle root-find (in-kernel RNG: no noise read):
+#   closed_form / newton : fixed pose 3 + solution 3 doubles = 48   (the unique root does not depend on the start point: u0 is NOT read)
+#   gauss_newton / nelder_mead (start from the belief point): fixed 3 + start point u0 3 + solution 3 = 72
+BYTES_PER_PARTICLE_P2P2 = {"closed_form": 48, "newton": 48, "gauss_newton": 72, "nelder_mead": 72}
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -38,7 +41,7 @@ def parse():
     # its steady state (with 20 warm-up launches the same kernel reads 50 µs per launch instead of 46 µs)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--solver", default="newton", choices=["closed_form", "newton", "nelder_mead"])
+    ap.add_argument("--solver", default="newton", choices=["closed_form", "newton", "nelder_mead", "gauss_newton"])
     ap.add_argument("--poses", type=int, default=3500)
     ap.add_argument("--loops", type=int, default=1954)
     ap.add_argument("--particles", type=int, default=100)
@@ -109,7 +112,8 @@ def main():
         raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) are visible" % (args.gpus, torch.cuda.device_count()))
 
     N = args.particles
-    solver = {"closed_form": R.SOLVER_CLOSED_FORM, "newton": R.SOLVER_NEWTON, "nelder_mead": R.SOLVER_NELDER_MEAD}[args.solver]
+    solver = {"closed_form": R.SOLVER_CLOSED_FORM, "newton": R.SOLVER_NEWTON, "nelder_mead": R.SOLVER_NELDER_MEAD,
+              "gauss_newton": R.SOLVER_GAUSS_NEWTON}[args.solver]
 
     # ---- workload: this rank's Manhattan-shaped segment (+ ghost separators of the neighbours) ----
     default_g2o = os.path.join(ROOT, "tests", "golden", "manhattan.g2o")
@@ -235,7 +239,7 @@ def main():
         "Manhattan M3500 dataset (measurements); beliefs synthetic: dead-reckoned means + N(0, sigma) particles"
     total_conv = n_conv_step * (1 if strong else world) * args.steps
     value = total_conv / elapsed
-    alg_bytes = tb["C_rel"] * N * BYTES_PER_PARTICLE_P2P2 + tb["P"] * N * 24
+    alg_bytes = tb["C_rel"] * N * BYTES_PER_PARTICLE_P2P2[args.solver] + tb["P"] * N * 24
     if strong:
         alg_bytes = alg_bytes * pipe.n_rows // max(1, tb["C"])   # this rank's launch covers its own row range
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9

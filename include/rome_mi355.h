@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define ROME_MI355_VERSION 100 /* 0.1.0 */
+#define ROME_MI355_VERSION 110 /* 0.1.1: ROME_SOLVER_GAUSS_NEWTON, rome_conv_dev.mirror_map, rome_clique_upsolve */
 
 enum {
   ROME_OK = 0,
@@ -57,12 +57,20 @@ enum {
 
 /* Solvers for the per-particle root-find (replaces Optim.optimize(cost, X0c, NelderMead()) in IIF
  * `_solveLambdaNumeric`, called for every particle of every convolution):
- *   CLOSED_FORM  analytic root; start point / inflation only matter for the
- *                under-determined bearing-range -> pose direction
- *   NEWTON       iterate on the actual residual functor with analytic group Jacobians until
- *                max|r| <= tol  (default)
- *   NELDER_MEAD  Optim.jl's NelderMead() with its defaults on Σ r², i.e. the reference's algorithm  */
-enum { ROME_SOLVER_CLOSED_FORM = 0, ROME_SOLVER_NEWTON = 1, ROME_SOLVER_NELDER_MEAD = 2 };
+ *   CLOSED_FORM   analytic root, status always 0; start point / inflation only matter for the
+ *                 under-determined bearing-range -> pose direction (a ring of roots: the member nearest the jittered start)
+ *   NEWTON        (default) unique-root factors (Pose2Pose2, PriorPose2, bearing-range -> landmark, Pose3Pose3): the root of the
+ *                 residual is unique, so no start point or inflation cycle can change it: the kernel returns the analytic root
+ *                 and, when a `status` array is given, evaluates the residual FUNCTOR there (status = max|r| <= tol ? 0 : 1).
+ *                 The start points are not read.  Bearing-range -> pose: Newton iteration from the jittered start point to
+ *                 max|r| <= tol (inflate_cycles x {entropy, iterate}).
+ *   NELDER_MEAD   Optim.jl's NelderMead() with its defaults on Σ r², i.e. the reference's algorithm, inflate_cycles x
+ *                 {entropy, minimise} from the start points
+ *   GAUSS_NEWTON  numerical root-find on the residual FUNCTOR itself (the reference's CalcFactor evaluated through points /
+ *                 rotation matrices at every iterate) with analytic group updates, from the jittered start points,
+ *                 inflate_cycles x {entropy, iterate to max|r| <= tol}; cycles after the one in which every particle of a
+ *                 unique-root convolution has converged are skipped.  Same algorithm as the oracle's Newton mode.          */
+enum { ROME_SOLVER_CLOSED_FORM = 0, ROME_SOLVER_NEWTON = 1, ROME_SOLVER_NELDER_MEAD = 2, ROME_SOLVER_GAUSS_NEWTON = 3 };
 enum { ROME_LAYOUT_SOA = 0, ROME_LAYOUT_AOS = 1, ROME_LAYOUT_AOS_POINTS = 2 };
 enum { ROME_DIR_TO = 0, ROME_DIR_FROM = 1, ROME_DIR_PRIOR = 2 };
 enum { ROME_NOISE_STANDARD_NORMALS = 0, ROME_NOISE_MEASUREMENTS = 1 };
@@ -71,9 +79,9 @@ enum { ROME_NOISE_STANDARD_NORMALS = 0, ROME_NOISE_MEASUREMENTS = 1 };
 typedef struct rome_opts {
   int32_t n_particles;    /* N, IIF default 100 (src/canonical/GenerateHexagonal.jl:30)               */
   int32_t solver;         /* ROME_SOLVER_*                                                             */
-  int32_t max_iters;      /* NEWTON default 20 ; NELDER_MEAD default 1000 (Optim iterations)           */
+  int32_t max_iters;      /* NEWTON / GAUSS_NEWTON default 20 ; NELDER_MEAD default 1000 (Optim iterations) */
   int32_t inflate_cycles; /* IIF inflateCycles, default 3                                              */
-  double  tol;            /* NEWTON: max|r| <= tol (1e-12) ; NELDER_MEAD: Optim g_tol (1e-8)           */
+  double  tol;            /* NEWTON / GAUSS_NEWTON: max|r| <= tol (1e-12) ; NELDER_MEAD: Optim g_tol (1e-8) */
   double  inflation;      /* IIF inflation (kappa) for the entropy added before each cycle, default 5.0 */
   uint64_t seed;          /* Philox4x32-10 key                                                         */
   uint64_t stream_offset; /* Philox stream of convolution c = stream_offset + c  (global conv id when sharded) */
@@ -250,6 +258,9 @@ typedef struct rome_conv_dev {
    * nullhypo, selects the lean sweep kernel: one 16-byte scalar load per convolution instead of four dependent ones
    * (Manhattan-3500 Newton sweep 18.0 -> see profiles/).  Bearing-range rows ignore the dir entry. */
   const int32_t* rows4;
+  /* optional: ANY number of mirrored rows (replaces n_mirror / mirror_row when given): mirror_map[c] = block of mirror_out that
+   * row c's proposal is also written to, -1 = none.  A Bayes-tree cut / the beehive lattice publishes more than four separators. */
+  const int32_t* mirror_map;
 } rome_conv_dev;
 
 int rome_conv_pose2pose2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);

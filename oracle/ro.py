@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "librome_oracle.so")
 
 SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD = 0, 1, 2
+SOLVER_GAUSS_NEWTON = 1   # the oracle's Newton mode IS the Gauss-Newton iteration on the residual functor (p2p2_newton, br_newton, p3p3_newton_pt)
 
 
 def build(force=False):

@@ -100,15 +100,16 @@ void ro_box_muller(uint32_t wa, uint32_t wb, double* n0, double* n1) {
   *n0 = (double)((wb & 0x80000000u) ? -m0 : m0);
   *n1 = (double)((wb & 0x40000000u) ? -m1 : m1);
 }
-/* d == 3: particles p and p ^ 64 share the second Box-Muller pair of the call of particle p & ~64 (cosine branch for bit 6 clear,
- * sine branch otherwise) instead of each discarding one normal -- same rule as rng_normals<3> in the HIP path. */
+/* d == 3: particles p and p ^ 1 (neighbours 2j, 2j+1) share the second Box-Muller pair of the call of the EVEN particle p & ~1
+ * (cosine branch for the even particle, sine branch for the odd one) instead of each discarding one normal -- same rule as
+ * rng_normals<3> in the HIP path, where one thread owns both particles of a pair (two Philox calls, three pairs, 16-byte loads). */
 void ro_rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, int d, double* out) {
   if (d == 3) {
     uint32_t w[4], wb[4];
     double c, s;
     ro_noise_words(seed, stream, particle, 0, w);
     ro_box_muller(w[0], w[1], &out[0], &out[1]);
-    if (particle & 64u) { ro_noise_words(seed, stream, particle & ~64u, 0, wb); ro_box_muller(wb[2], wb[3], &c, &s); out[2] = s; }
+    if (particle & 1u) { ro_noise_words(seed, stream, particle & ~1u, 0, wb); ro_box_muller(wb[2], wb[3], &c, &s); out[2] = s; }
     else { ro_box_muller(w[2], w[3], &c, &s); out[2] = c; }
     return;
   }

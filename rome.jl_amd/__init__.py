@@ -6,7 +6,7 @@ as hand-written HIP kernels in librome_mi355.so (C ABI: include/rome_mi355.h).  
 host-side mirror of the reference interface; it contains no compute and no CPU fallback.
 """
 from . import _lib
-from ._lib import (Context, Opts, RomeError, SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD,
+from ._lib import (Context, Opts, RomeError, SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD, SOLVER_GAUSS_NEWTON,
                    LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS, MAX_PARTICLES, MAX_PARTICLES_REGISTER)
 from .factors import (MvNormal, Normal, Uniform, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
                       Pose3Pose3, PriorPose3, PriorPoint2, Point2Point2, getMeasurementParametric, getPoint, getCoordinates, pack_factor,

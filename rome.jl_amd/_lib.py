@@ -11,7 +11,7 @@ SO = os.environ.get("ROME_MI355_LIB") or os.path.join(HERE, "librome_mi355.so") 
 
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED_N, ERR_ALLOC = -1, -2, -3, -4, -5, -6
-SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD = 0, 1, 2
+SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD, SOLVER_GAUSS_NEWTON = 0, 1, 2, 3
 NOISE_STANDARD_NORMALS, NOISE_MEASUREMENTS = 0, 1
 LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS = 0, 1, 2
 MAX_PARTICLES = 4096            # ROME_MAX_PARTICLES (the register-resident kernels: MAX_PARTICLES_REGISTER)
@@ -38,7 +38,8 @@ class ConvDev(C.Structure):
                 ("mu", C.c_void_p), ("L", C.c_void_p), ("bel_fixed", C.c_void_p), ("bel_target", C.c_void_p),
                 ("noise", C.c_void_p), ("out", C.c_void_p), ("status", C.c_void_p),
                 ("n_mirror", C.c_int32), ("mirror_row", C.c_int32 * 4), ("reserved", C.c_int32), ("mirror_out", C.c_void_p),
-                ("alt_var", C.c_void_p), ("hypo_w", C.c_void_p), ("nullhypo", C.c_void_p), ("rows4", C.c_void_p)]
+                ("alt_var", C.c_void_p), ("hypo_w", C.c_void_p), ("nullhypo", C.c_void_p), ("rows4", C.c_void_p),
+                ("mirror_map", C.c_void_p)]
 
 
 _PD = C.POINTER(C.c_double)

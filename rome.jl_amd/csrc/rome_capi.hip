@@ -74,7 +74,7 @@ int check_opts(const rome_opts* o) {
   if (!o) return ROME_ERR_INVALID_ARG;
   if (o->n_particles < 1) return ROME_ERR_INVALID_ARG;
   if (o->n_particles > ROME_MAX_PARTICLES) return ROME_ERR_UNSUPPORTED_N;
-  if (o->solver < ROME_SOLVER_CLOSED_FORM || o->solver > ROME_SOLVER_NELDER_MEAD) return ROME_ERR_INVALID_ARG;
+  if (o->solver < ROME_SOLVER_CLOSED_FORM || o->solver > ROME_SOLVER_GAUSS_NEWTON) return ROME_ERR_INVALID_ARG;
   if (o->max_iters < 1 || o->inflate_cycles < 0 || o->inflate_cycles > 255) return ROME_ERR_INVALID_ARG;
   if (!(o->tol >= 0.0) || !(o->inflation >= 0.0) || !(o->spread_nh >= 0.0)) return ROME_ERR_INVALID_ARG;
   if (!(o->nullhypo >= 0.0 && o->nullhypo <= 1.0)) return ROME_ERR_INVALID_ARG;
@@ -108,6 +108,7 @@ void args_from_dev(rome::ConvArgs& a, const rome_opts* o, const rome_conv_dev* t
   a.n_mirror = t->mirror_out ? (t->n_mirror < 0 ? 0 : t->n_mirror) : 0;   // (> 4 is rejected by dev_common)
   for (int m = 0; m < 4; ++m) a.mirror_row[m] = t->mirror_row[m];
   a.mirror_out = t->mirror_out;
+  a.mirror_map = t->mirror_out ? t->mirror_map : nullptr;
   a.alt_var = t->hypo_w ? t->alt_var : nullptr;
   a.hypo_w = t->hypo_w;
   a.nullhypo = t->nullhypo;

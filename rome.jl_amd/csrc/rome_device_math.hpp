@@ -201,19 +201,20 @@ __device__ __forceinline__ u32x4 noise_words(uint64_t seed, uint64_t stream, uin
 }
 
 // D standard normals for (seed, stream, particle): Box-Muller on Philox words, two pairs per Philox call.
-// D == 3 (Pose2 measurements and jitters) would discard one normal of its second pair; instead particles p and p ^ 64 -- the two
-// slots of one lane in the convolution kernels -- SHARE that pair: normals 0, 1 come from words (x, y) of the particle's own call,
-// normal 2 from words (z, w) of the call of particle p & ~64, its cosine branch for p & 64 == 0, its sine branch otherwise.  The two
-// branches of a Box-Muller pair are independent N(0,1), the rule depends on the particle id only (not on N or the launch shape), and
-// a lane then evaluates three pairs for its two particles instead of four (rng_normals3_pair).  Oracle: ro_rng_normals.
+// D == 3 (Pose2 measurements) would discard one normal of its second pair; instead the NEIGHBOURING particles 2j and 2j + 1 -- the two
+// particles one thread owns in the convolution kernels (adjacent in the SoA belief rows: one 16-byte load per coordinate) -- SHARE
+// that pair: normals 0, 1 come from words (x, y) of the particle's own call, normal 2 from words (z, w) of the call of the EVEN
+// particle p & ~1, its cosine branch for the even particle, its sine branch for the odd one.  The two branches of a Box-Muller pair
+// are independent N(0,1), the rule depends on the particle id only (not on N or the launch shape), and a thread then evaluates
+// three pairs for its two particles instead of four (rng_normals3_pair).  Oracle: ro_rng_normals.
 template <int D>
 __device__ __forceinline__ void rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, double (&out)[D]) {
   if constexpr (D == 3) {
     const u32x4 w = noise_words(seed, stream, particle, 0u);
     box_muller(w.x, w.y, &out[0], &out[1]);
     double c, s;
-    if (particle & 64u) {
-      const u32x4 wb = noise_words(seed, stream, particle & ~64u, 0u);
+    if (particle & 1u) {
+      const u32x4 wb = noise_words(seed, stream, particle & ~1u, 0u);
       box_muller(wb.z, wb.w, &c, &s);
       out[2] = s;
     } else {
@@ -238,68 +239,12 @@ __device__ __forceinline__ void rng_normals(uint64_t seed, uint64_t stream, uint
     }
   }
 }
-// the D == 3 normals of particles p (bit 6 clear) and p + 64 together: two Philox calls, three Box-Muller pairs
-// (words z, w of the odd particle's call are not used by the normals: returned as spare bits for the cheap entropy of cycle 0)
-__device__ __forceinline__ void rng_normals3_pair(uint64_t seed, uint64_t stream, uint32_t p_even, double (&oe)[3], double (&oo)[3],
-                                                  uint32_t* spare_e, uint32_t* spare_o) {
-  const u32x4 we = noise_words(seed, stream, p_even, 0u), wo = noise_words(seed, stream, p_even + 64u, 0u);
+// the D == 3 normals of particles p_even (even) and p_even + 1 together: two Philox calls, three Box-Muller pairs
+__device__ __forceinline__ void rng_normals3_pair(uint64_t seed, uint64_t stream, uint32_t p_even, double (&oe)[3], double (&oo)[3]) {
+  const u32x4 we = noise_words(seed, stream, p_even, 0u), wo = noise_words(seed, stream, p_even + 1u, 0u);
   box_muller(we.x, we.y, &oe[0], &oe[1]);
   box_muller(wo.x, wo.y, &oo[0], &oo[1]);
   box_muller(we.z, we.w, &oe[2], &oo[2]);
-  *spare_e = wo.z; *spare_o = wo.w;
-}
-
-// Cheap entropy-inflation uniforms (IIF addEntropyOnManifold!: spread·(rand(d) .- 0.5)) for the kernels whose result does NOT
-// depend on the start point (Newton / closed form on a factor with a unique root; the oracle draws full 32-bit uniforms,
-// rng_entropy_exact below).  Narrow uniforms are drawn and ONE Philox call is shared by several cycles:
-//   D <= 3 : 7-bit fields, 3 cycles per call, two particles (p, p ^ 64) per call   (call index = cycle / 3; cycle 0 of a Pose2
-//            measurement comes from two spare words of the noise calls instead)
-//   D == 6 : 10-bit fields, 1 cycle per call, two particles (p, p ^ 64) per call   (120 bits)
-// u = (field + 0.5) / 2^bits  in (0,1).
-typedef u32x4 EntropyWords;  // plain scalars (no array member: keeps the words in VGPRs, not LDS/scratch)
-__device__ __forceinline__ EntropyWords rng_entropy_words(uint64_t seed, uint64_t stream, uint32_t particle, int call) {
-  return philox4x32_10(u32x4{particle, (uint32_t)stream, (uint32_t)(stream >> 32), (kDomainEntropy << 16) | (uint32_t)call},
-                       (uint32_t)seed, (uint32_t)(seed >> 32));
-}
-__device__ __forceinline__ uint32_t word_of(const EntropyWords& e, int wi) {  // wi is a compile-time constant after inlining
-  return wi == 0 ? e.x : (wi == 1 ? e.y : (wi == 2 ? e.z : (wi == 3 ? e.w : 0u)));
-}
-__device__ __forceinline__ uint32_t bitfield128(const EntropyWords& e, int pos, int bits) {
-  // 32-bit operations only (pos and bits are compile-time constants after inlining): combining two words into a 64-bit value let the
-  // compiler type-pun the word struct (i32 stores, i64 loads), which kept it in memory -- promoted to LDS -- in the 2-dimensional
-  // bearing-range kernels (bearing-range -> landmark Newton 0.067 -> 0.057 ms once the words stay in registers)
-  const int wi = pos >> 5, sh = pos & 31;
-  const uint32_t lo = word_of(e, wi) >> sh;
-  const uint32_t hi = (sh + bits > 32) ? (word_of(e, wi + 1) << (32 - sh)) : 0u;
-  return (lo | hi) & ((1u << bits) - 1u);
-}
-// D <= 3: 7-bit fields, nine per particle (3 cycles x 3 coordinates), field j = 3·slot + k at bit 7j of the particle's 64-bit half
-// of the call: particles p and p ^ 64 -- the two slots of a lane -- read words (x, y) / (z, w) of the ONE call made for particle
-// p & ~64 (HALF = (p >> 6) & 1).  The fields of slot 0 lie in the first word of a half, so two spare 32-bit words of the
-// measurement-noise calls can serve cycle 0 -- with cycle elision the only one that runs -- without any Philox call of its own.
-// D == 6: 10-bit fields, six per particle and cycle at bit 10·(6·HALF + k), the same sharing, one cycle per call.
-// `slot` (= cycle % 3) is wave-uniform: a scalar branch picks the field positions, which are then compile-time constants.
-template <int D, int HALF>
-__device__ __forceinline__ void rng_entropy_from_words(const EntropyWords& e, int slot, double (&out)[D]) {
-  constexpr int BITS = D <= 3 ? 7 : 10;
-  uint32_t f[D];
-  if constexpr (D <= 3) {
-    if (slot == 0) {
-#pragma unroll
-      for (int k = 0; k < D; ++k) f[k] = bitfield128(e, 64 * HALF + BITS * k, BITS);
-    } else if (slot == 1) {
-#pragma unroll
-      for (int k = 0; k < D; ++k) f[k] = bitfield128(e, 64 * HALF + BITS * (3 + k), BITS);
-    } else {
-#pragma unroll
-      for (int k = 0; k < D; ++k) f[k] = bitfield128(e, 64 * HALF + BITS * (6 + k), BITS);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < D; ++k) f[k] = bitfield128(e, (6 * HALF + k) * BITS, BITS);
-  }
-#pragma unroll
-  for (int k = 0; k < D; ++k) out[k] = ((double)f[k] + 0.5) * (1.0 / (double)(1u << BITS));
 }
 
 // The entropy uniforms as the oracle defines them (ro_rng_entropy): one Philox call per particle and cycle (two for D = 6), one

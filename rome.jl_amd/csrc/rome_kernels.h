@@ -5,7 +5,7 @@
 
 namespace rome {
 
-enum { kSolverClosedForm = 0, kSolverNewton = 1, kSolverNelderMead = 2 };
+enum { kSolverClosedForm = 0, kSolverNewton = 1, kSolverNelderMead = 2, kSolverGaussNewton = 3 };
 enum { kDirTo = 0, kDirFrom = 1, kDirPrior = 2 };  // kDirPrior: row is a prior (no fixed variable): proposal = sample
 
 // All pointers are DEVICE pointers.  Belief / proposal blocks are SoA: [block][dim][N].
@@ -32,6 +32,7 @@ struct ConvArgs {
   int n_mirror;               // rows additionally written to mirror_out[m] (separator beliefs -> send buffer)
   int mirror_row[4];
   double* mirror_out;
+  const int32_t* mirror_map;  // [C] block of mirror_out row c is ALSO written to (-1: none), or nullptr -> mirror_row; any number of rows
   int dir_all;
   int max_iters;
   int cycles;

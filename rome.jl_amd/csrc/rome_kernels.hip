@@ -4,8 +4,13 @@
 // (IncrementalInference `computeAcrossHypothesis!` -> `_solveCCWNumeric!`)
 // around the RoME residual functors (rows a2/a4/a6/a8).
 //
-// Mapping: ONE WAVEFRONT PER CONVOLUTION.  Lane l owns particles l, l+64, ... (PPL per lane, in
-// registers), so
+// Two mappings:
+//  * k_conv_flat -- the plain whole-graph sweep of a unique-root factor (closed form / Newton, in-kernel noise): the particles of
+//    consecutive convolutions are PACKED onto the threads of a 256-thread block (thread = two neighbouring particles, 50 threads
+//    per N = 100 convolution, 5 convolutions = 250 of 256 threads), per-factor μ / chol Σ staged through LDS.
+//  * k_conv -- ONE WAVEFRONT PER CONVOLUTION for everything that needs a statistic over the N particles of a belief (the inflation
+//    spread of the iterative solvers, multihypo / nullhypo) or pre-sampled noise.  Lane l owns particles 2l, 2l+1, 128+2l, ...
+//    (PPL per lane, in registers), so
 //   * the belief blocks are SoA [var][dim][N]: a wave reads/writes contiguous runs -> coalesced;
 //   * per-factor constants (μ, chol Σ, var ids, direction) are wave-uniform -> scalar loads / SGPRs;
 //   * the per-cycle belief statistics IIF needs for the entropy inflation (std of the N target
@@ -63,26 +68,6 @@ __device__ __forceinline__ double spread_se2(const double (&t)[PPL][3], const bo
   const double vt = fmax(0.0, (s[5] - s[4] * s[4] * inv) * den);
   return fast_sqrt(vx + vy + vt);   // Manifolds.std: root of the corrected Fréchet variance (sum of the coordinate variances)
 }
-// The same statistic with single-precision moments (differences formed in double, then rounded): used where the spread only
-// scales the jitter of a start point whose root-find result does not depend on it (unique root, closed form / Newton), so the
-// proposals are unchanged to the solver tolerance while the six wave reductions cost a third of the instructions.
-template <int PPL>
-__device__ __forceinline__ double spread_se2_fast(const double (&t)[PPL][3], const bool (&act)[PPL], double inv, double den) {
-  // only the SUM of the coordinate variances is needed: Σ_k var_k = (Σ_i |d_i|² - Σ_k (Σ_i d_ik)² / N) / (N - 1) -> four wave sums
-  const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0), th0 = readlane_f64(t[0][2], 0);
-  float s[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < PPL; ++k) {
-    const float dx = (float)(t[k][0] - x0), dy = (float)(t[k][1] - y0);
-    float dt = (float)(t[k][2] - th0);
-    dt = fmaf(-6.2831853071795865f, rintf(dt * 0.15915494309189535f), dt);
-    if (act[k]) { s[0] += dx; s[1] += dy; s[2] += dt; s[3] = fmaf(dx, dx, fmaf(dy, dy, fmaf(dt, dt, s[3]))); }
-  }
-  wave_sum_n_f32<4>(s);
-  const float fi = (float)inv, fd = (float)den;
-  const float v = fmaxf(0.0f, (s[3] - (s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) * fi) * fd);
-  return (double)fminf(__builtin_sqrtf(v), 3.0e38f);   // finite even if the single-precision moments overflow
-}
 template <int PPL>
 __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const bool (&act)[PPL], double inv, double den) {
   const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0);
@@ -98,22 +83,8 @@ __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const boo
   return fast_sqrt(vx + vy);
 }
 
-template <int PPL>
-__device__ __forceinline__ double spread_r2_fast(const double (&t)[PPL][2], const bool (&act)[PPL], double inv, double den) {
-  const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0);
-  float s[3] = {0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < PPL; ++k) {
-    const float dx = (float)(t[k][0] - x0), dy = (float)(t[k][1] - y0);
-    if (act[k]) { s[0] += dx; s[1] += dy; s[2] = fmaf(dx, dx, fmaf(dy, dy, s[2])); }
-  }
-  wave_sum_n_f32<3>(s);
-  const float fi = (float)inv, fd = (float)den;
-  return (double)fminf(__builtin_sqrtf(fmaxf(0.0f, (s[2] - (s[0] * s[0] + s[1] * s[1]) * fi) * fd)), 3.0e38f);
-}
-
 struct P2P2 {
-  static constexpr int DF = 3, DT = 3, DZ = 3, NL = 6;
+  static constexpr int DF = 3, DT = 3, DZ = 3, NL = 6, NK = 9;
   static constexpr int kHypoDir = 2;   // multihypo over the SECOND pose of the factor: the fractional side follows the row's direction
                                        // (dir 0: the target is one of the candidates; dir 1: the fixed pose is drawn per particle)
   static constexpr bool kUniqueRoot = true;   // r(z; p, ·) = 0 has exactly one solution: the start point cannot reach the proposal
@@ -127,14 +98,26 @@ struct P2P2 {
     K.dir = dr;
     return K;
   }
+  // the same constants from the block's LDS image [μ(3), L(6)] (k_conv_flat)
+  __device__ static __forceinline__ Consts from_lds(const double* sk, int dr) {
+    Consts K;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) K.mu[k] = sk[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) K.L[k] = sk[3 + k];
+    K.dir = dr;
+    return K;
+  }
   __device__ static __forceinline__ void measurement(const Consts& K, const double (&xi)[3], double (&z)[3]) {
     z[0] = K.mu[0] + K.L[0] * xi[0];
     z[1] = K.mu[1] + K.L[1] * xi[0] + K.L[2] * xi[1];
     z[2] = K.mu[2] + K.L[3] * xi[0] + K.L[4] * xi[1] + K.L[5] * xi[2];
   }
   __device__ static __forceinline__ void canonical(double (&t)[3]) { t[2] = wrap_pi(t[2]); }
+  // do the inflation cycles (entropy + re-solve) apply?  Only to the solvers that START from the jittered belief point: Nelder-Mead
+  // and the Gauss-Newton iteration on the residual functor.  CLOSED_FORM and NEWTON return the unique root directly.
   __device__ static __forceinline__ bool needs_cycles(int solver, const Consts& K) {
-    return solver != kSolverClosedForm && K.dir != kDirPrior;
+    return (solver == kSolverNelderMead || solver == kSolverGaussNewton) && K.dir != kDirPrior;
   }
   struct Aux {};
   __device__ static __forceinline__ Aux init_aux(const double (&)[3]) { return Aux{}; }
@@ -149,75 +132,70 @@ struct P2P2 {
   __device__ static __forceinline__ double spread(const double (&t)[PPL][3], const Aux (&)[PPL], const bool (&act)[PPL], double inv, double den) {
     return spread_se2<PPL>(t, act, inv, den);
   }
-  // inflation spread of a cycle: the Pose2Pose2 root is unique, so for the closed-form / Newton solvers the start point (hence the
-  // spread's last digits) does not reach the result; Nelder-Mead keeps the double-precision statistic (its result depends on the start)
-  template <int PPL, int SOLVER>
-  __device__ static __forceinline__ double cycle_spread(const double (&t)[PPL][3], const Aux (&A)[PPL], const bool (&act)[PPL], double inv, double den) {
-    if constexpr (SOLVER == kSolverNelderMead) return spread_se2<PPL>(t, act, inv, den);
-    else return spread_se2_fast<PPL>(t, act, inv, den);
-  }
-  __device__ static __forceinline__ void add_entropy(double (&t)[3], Aux&, double spread, const double (&u)[3], double s, double c) {
+  __device__ static __forceinline__ void add_entropy(double (&t)[3], Aux&, double spread, const double (&u)[3]) {
+    double s, c; fast_sincos(t[2], &s, &c);
     const double ex = spread * (u[0] - 0.5), ey = spread * (u[1] - 0.5), et = spread * (u[2] - 0.5);
     t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] = wrap_pi(t[2] + et);
   }
 
-  // per-particle constants of the root-find, computed once (not once per inflation cycle).  Both directions of the
-  // Pose2Pose2 residual  r(z; p, q) = ( p.t + R(θp) z_t - q.t , wrap(θp + zθ - θq) )  are affine in the unknown once its
-  // heading is fixed, so everything the solvers need from (z, fixed particle) folds into the point a:
-  //   dir 0 (solve q): a = p ∘ exp_ϵ(z) = (p.t + R(θp) z_t, θp + zθ)            r(q) = (a.t - q.t, wrap(aθ - qθ))
-  //   dir 1 (solve p): a = (q.t - R(θq - zθ) z_t, θq - zθ)                       r(p) = (p.t - a.t, wrap(pθ - aθ)) at pθ ≡ aθ
-  //   prior row:       a = z   (the sample is the proposal)
-  // (dir 1: the Jacobian is block-triangular -- r_θ depends on θ only -- so the Newton step solves θ first and takes the
-  // translation step with R at the UPDATED heading θq - zθ: R(θq - zθ) z_t is loop-invariant and is hoisted here.)
+  // The root of the residual  r(z; p, q) = ( p.t + R(θp) z_t - q.t , wrap(θp + zθ - θq) )  (SURVEY A.5), per particle, for both
+  // directions in ONE branch-free form (the direction is a per-thread value in k_conv_flat, where a wave spans two table rows):
+  //   dir 0 (solve q): a = p ∘ exp_ϵ(z) = (p.t + R(θp) z_t, θp + zθ)
+  //   dir 1 (solve p): a = (q.t - R(θq - zθ) z_t, θq - zθ)
+  //   prior row:       a = z   = dir 0 about the identity pose (R(0) z_t + 0 is exact)
+  // Rounding is pinned by explicit fma (the packed sweep, the wave-per-row kernel and the per-factor entry points agree bit for bit).
   struct Prep { double a0, a1, a2; };
   __device__ static __forceinline__ Prep prepare(const Consts& K, const double (&z)[3], const double (&fxc)[3]) {
+    const bool pr = K.dir == kDirPrior, back = K.dir == 1;
+    const double f0 = pr ? 0.0 : fxc[0], f1 = pr ? 0.0 : fxc[1], f2 = pr ? 0.0 : fxc[2];
+    const double thr = back ? f2 - z[2] : f2;
+    double s, c; fast_sincos(thr, &s, &c);
+    const double vx = __builtin_fma(c, z[0], -(s * z[1])), vy = __builtin_fma(s, z[0], c * z[1]);
     Prep P;
-    if (K.dir == 0) {
-      double s, c; fast_sincos(fxc[2], &s, &c);
-      P.a0 = fxc[0] + c * z[0] - s * z[1]; P.a1 = fxc[1] + s * z[0] + c * z[1]; P.a2 = fxc[2] + z[2];
-    } else if (K.dir == 1) {
-      P.a2 = fxc[2] - z[2];
-      double s, c; fast_sincos(P.a2, &s, &c);
-      P.a0 = fxc[0] - (c * z[0] - s * z[1]); P.a1 = fxc[1] - (s * z[0] + c * z[1]);
-    } else { P.a0 = z[0]; P.a1 = z[1]; P.a2 = z[2]; }
+    P.a0 = back ? f0 - vx : f0 + vx;
+    P.a1 = back ? f1 - vy : f1 + vy;
+    P.a2 = back ? thr : f2 + z[2];
     return P;
   }
-  // sin/cos of the current target heading for the entropy step (u0 ∘ exp_ϵ(jitter))
-  template <int SOLVER>
-  __device__ static __forceinline__ void heading_sincos(const Consts&, const Prep&, int, int, const double (&t)[3], double* s, double* c) {
-    if constexpr (SOLVER == kSolverNelderMead) fast_sincos(t[2], s, c);
-    else {  // unique root: the frame of the jitter only reaches the start point -> hardware single-precision sin/cos (|θ| <= π)
-      const float th = (float)t[2];
-      *s = (double)__sinf(th); *c = (double)__cosf(th);
-    }
+  // the residual FUNCTOR itself (src/factors/Pose2D.jl:51-67 / PriorPose2.jl:37-47, through points) at the target point t
+  __device__ static __forceinline__ void functor(const Consts& K, const double (&z)[3], const double (&fxc)[3], const double (&t)[3], double (&r)[3]) {
+    const Se2 T = se2_from_coords(t[0], t[1], t[2]);
+    if (K.dir == kDirPrior) { residual_priorpose2(se2_from_coords(z[0], z[1], z[2]), T, r); return; }
+    const Se2 F = se2_from_coords(fxc[0], fxc[1], fxc[2]);
+    double sz, cz; fast_sincos(z[2], &sz, &cz);
+    if (K.dir == 0) residual_pose2pose2(z[0], z[1], cz, sz, F, T, r); else residual_pose2pose2(z[0], z[1], cz, sz, T, F, r);
   }
-
-  // one Newton step from t (J = ∓I in the coordinates above); returns true when max|r| <= tol at t (then t is left untouched)
-  __device__ static __forceinline__ bool newton_step(const Prep& P, double (&t)[3], double tol) {
-    const double r0 = P.a0 - t[0], r1 = P.a1 - t[1], r2 = wrap_pi(P.a2 - t[2]);
-    const bool ok = fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol;
-    t[0] = ok ? t[0] : t[0] + r0; t[1] = ok ? t[1] : t[1] + r1; t[2] = ok ? t[2] : t[2] + r2;
-    return ok;
+  // status of a directly returned root: max|r| of the functor there against tol
+  __device__ static __forceinline__ int verify(const Consts& K, const double (&z)[3], const double (&fxc)[3], const double (&t)[3], const Aux&, double tol) {
+    double r[3]; functor(K, z, fxc, t, r);
+    return fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2]))) <= tol ? 0 : 1;
+  }
+  // Gauss-Newton on the functor (the oracle's p2p2_newton): evaluate r at the current point; dir 0: J = -I; dir 1: J = [I, R'(θ) z_t; 0, 1]
+  __device__ static __forceinline__ int gauss_newton(const Consts& K, const double (&z)[3], const double (&fxc)[3], double (&t)[3], int max_iters, double tol) {
+    for (int it = 0; it < max_iters; ++it) {
+      double r[3]; functor(K, z, fxc, t, r);
+      if (fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2]))) <= tol) return 0;
+      if (K.dir == 0) { t[0] += r[0]; t[1] += r[1]; t[2] += r[2]; }
+      else {
+        double s, c; fast_sincos(t[2], &s, &c);
+        const double J13 = -s * z[0] - c * z[1], J23 = c * z[0] - s * z[1], dth = -r[2];
+        t[0] += -r[0] - J13 * dth; t[1] += -r[1] - J23 * dth; t[2] += dth;
+      }
+    }
+    return 1;
   }
 
   template <int SOLVER>
   __device__ static __forceinline__ int solve(const Consts& K, const Prep& P, const double (&z)[3], const double (&fxc)[3],
                                               double (&t)[3], Aux&, int max_iters, double tol) {
     int st = 0;
-    if (K.dir == kDirPrior) {  // PriorPose2 row: the sample exp_ϵ(hat(μ + Lξ)) itself is the proposal
+    if (K.dir == kDirPrior || SOLVER == kSolverClosedForm || SOLVER == kSolverNewton) {
+      // PriorPose2 row: the sample exp_ϵ(hat(μ + Lξ)) itself is the proposal; relative rows: the unique root
       t[0] = P.a0; t[1] = P.a1; t[2] = wrap_pi(P.a2);
       return 0;
     }
-    if constexpr (SOLVER == kSolverClosedForm) { t[0] = P.a0; t[1] = P.a1; t[2] = P.a2; }
-    else if constexpr (SOLVER == kSolverNewton) {
-      // the residual is affine: the first step lands on the root, the second evaluates max|r| <= tol there.  Two predicated
-      // iterations in straight-line code (both particles of a lane interleave), the general loop only for what is left.
-      bool ok = false;
-      if (max_iters > 0) ok = newton_step(P, t, tol);   // (wave-uniform branches; a converged lane's step leaves t untouched,
-      if (max_iters > 1) ok = newton_step(P, t, tol);   //  so re-evaluating it returns the same verdict)
-      st = ok ? 0 : 1;
-      for (int it = 2; it < max_iters && st; ++it) st = newton_step(P, t, tol) ? 0 : 1;
-    } else {
+    if constexpr (SOLVER == kSolverGaussNewton) st = gauss_newton(K, z, fxc, t, max_iters, tol);
+    else {
       P2P2Cost cost{z[0], z[1], 0.0, 0.0, 0.0, K.dir};
       if (K.dir == 0) { cost.a0 = P.a0; cost.a1 = P.a1; cost.a2 = P.a2; }
       else { cost.a0 = fxc[0]; cost.a1 = fxc[1]; cost.a2 = P.a2; }
@@ -247,12 +225,16 @@ struct BRCost {
 
 template <int DIR>
 struct BR {
-  static constexpr int DF = DIR == 0 ? 3 : 2, DT = DIR == 0 ? 2 : 3, DZ = 2;
+  static constexpr int DF = DIR == 0 ? 3 : 2, DT = DIR == 0 ? 2 : 3, DZ = 2, NL = 2, NK = 4;
   static constexpr int kHypoDir = DIR;  // multihypo over the landmark slot: DIR 0 target is fractional, DIR 1 fixed is fractional
   static constexpr bool kUniqueRoot = DIR == 0;   // pose direction: 2 equations / 3 unknowns, a ring of roots around the landmark
   struct Consts { double mu[2]; double sg[2]; };
   __device__ static __forceinline__ Consts load(const ConvArgs& a, int f, int) {
     Consts K; K.mu[0] = a.mu[2 * f]; K.mu[1] = a.mu[2 * f + 1]; K.sg[0] = a.L[2 * f]; K.sg[1] = a.L[2 * f + 1];
+    return K;
+  }
+  __device__ static __forceinline__ Consts from_lds(const double* sk, int) {
+    Consts K; K.mu[0] = sk[0]; K.mu[1] = sk[1]; K.sg[0] = sk[2]; K.sg[1] = sk[3];
     return K;
   }
   __device__ static __forceinline__ void measurement(const Consts& K, const double (&xi)[2], double (&z)[2]) {
@@ -266,8 +248,9 @@ struct BR {
     }
   }
   __device__ static __forceinline__ void canonical(double (&t)[DT]) { if constexpr (DT == 3) t[2] = wrap_pi(t[2]); }
+  // landmark direction: unique root, only the start-dependent solvers cycle; pose direction: every solver starts from the belief point
   __device__ static __forceinline__ bool needs_cycles(int solver, const Consts&) {
-    return !(solver == kSolverClosedForm && DIR == 0);
+    return DIR == 1 || solver == kSolverNelderMead || solver == kSolverGaussNewton;
   }
   struct Aux {};
   __device__ static __forceinline__ Aux init_aux(const double (&)[DT]) { return Aux{}; }
@@ -288,22 +271,17 @@ struct BR {
     if constexpr (DT == 3) return spread_se2<PPL>(t, act, inv, den);
     else return spread_r2<PPL>(t, act, inv, den);
   }
-  template <int PPL, int SOLVER>
-  __device__ static __forceinline__ double cycle_spread(const double (&t)[PPL][DT], const Aux (&A)[PPL], const bool (&act)[PPL], double inv, double den) {
-    if constexpr (DIR == 0 && SOLVER != kSolverNelderMead) return spread_r2_fast<PPL>(t, act, inv, den);   // landmark from pose: unique root
-    else return spread<PPL>(t, A, act, inv, den);   // the pose direction has a one-parameter family of roots: the start point matters
-  }
-  __device__ static __forceinline__ void add_entropy(double (&t)[DT], Aux&, double spread, const double (&u)[DT], double s, double c) {
+  __device__ static __forceinline__ void add_entropy(double (&t)[DT], Aux&, double spread, const double (&u)[DT]) {
     if constexpr (DT == 3) {
+      double s, c; fast_sincos(t[2], &s, &c);
       const double ex = spread * (u[0] - 0.5), ey = spread * (u[1] - 0.5), et = spread * (u[2] - 0.5);
       t[0] += c * ex - s * ey; t[1] += s * ex + c * ey; t[2] = wrap_pi(t[2] + et);
     } else { t[0] += spread * (u[0] - 0.5); t[1] += spread * (u[1] - 0.5); }
   }
   // Solver form of the residual (src/factors/BearingRange2D.jl:48-64): pl = R(θp)ᵀ (l − p.t) has norm n = ‖l − p.t‖ and angle
   // ψ − θp with ψ = atan2(l − p.t) the world bearing, so  r = ( sym_rem(b − (ψ − θp)), ρ − n )  without a sin/cos per evaluation
-  // (same function as residual_bearingrange up to rounding; the residual entry points keep the reference's literal form).
-  //   DIR 0 (landmark): the exact polar Newton step about the pose lands on  l* = p.t + ρ (cos, sin)(θp + b)  whatever the start:
-  //                     l* is prepared once (one sincos), a step is "evaluate r, go to l*".
+  // (same function as residual_bearingrange up to rounding; the residual entry points and GAUSS_NEWTON keep the literal form).
+  //   DIR 0 (landmark): unique root  l* = p.t + ρ (cos, sin)(θp + b), prepared once (one sincos) -- CLOSED_FORM and NEWTON return it.
   //   DIR 1 (pose):     2 equations / 3 unknowns.  The block step keeps the ray landmark -> pose: move along it to the measured
   //                     range, then turn to the measured bearing (what the minimum-norm Gauss-Newton step approaches for ρ >> 1).
   struct Prep { double a0, a1; };
@@ -315,48 +293,69 @@ struct BR {
     }
     return P;
   }
-  template <int SOLVER>
-  __device__ static __forceinline__ void heading_sincos(const Consts&, const Prep&, int, int, const double (&t)[DT], double* s, double* c) {
-    if constexpr (DT == 3) fast_sincos(t[2], s, c); else { *s = 0.0; *c = 1.0; }
+  // the residual FUNCTOR itself at the target point t (pose fixed / landmark target, or the reverse)
+  __device__ static __forceinline__ void functor(const double (&z)[2], const double (&fx)[DF], const double (&t)[DT], double (&r)[2]) {
+    if constexpr (DIR == 0) residual_bearingrange(z[0], z[1], se2_from_coords(fx[0], fx[1], fx[2]), t[0], t[1], r);
+    else residual_bearingrange(z[0], z[1], se2_from_coords(t[0], t[1], t[2]), fx[0], fx[1], r);
   }
-  __device__ static __forceinline__ bool newton_step(const Prep& P, const double (&z)[2], const double (&fx)[DF], double (&t)[DT], double tol) {
-    if constexpr (DIR == 0) {
-      const double dx = t[0] - fx[0], dy = t[1] - fx[1];
-      const double n = fast_sqrt(dx * dx + dy * dy), psi = fast_atan2(dy, dx);
-      const double r0 = sym_rem(z[0] - (psi - fx[2])), r1 = z[1] - n;
-      const bool ok = fmax(fabs(r0), fabs(r1)) <= tol;
-      t[0] = ok ? t[0] : P.a0; t[1] = ok ? t[1] : P.a1;
-      return ok;
-    } else {
-      const double dx = fx[0] - t[0], dy = fx[1] - t[1];
-      const double n2 = dx * dx + dy * dy;
-      const double n = fast_sqrt(n2), psi = fast_atan2(dy, dx);
-      const double r0 = sym_rem(z[0] - (psi - t[2])), r1 = z[1] - n;
-      const bool ok = fmax(fabs(r0), fabs(r1)) <= tol;
-      const double k = n > 0.0 ? z[1] / n : 0.0;                       // pose coincides with the landmark: leave along +x
-      const double nx = n > 0.0 ? fx[0] - k * dx : fx[0] - z[1], ny = fx[1] - k * dy;
-      t[0] = ok ? t[0] : nx; t[1] = ok ? t[1] : ny; t[2] = ok ? t[2] : psi - z[0];
-      return ok;
-    }
+  __device__ static __forceinline__ int verify(const Consts&, const double (&z)[2], const double (&fx)[DF], const double (&t)[DT], const Aux&, double tol) {
+    double r[2]; functor(z, fx, t, r);
+    return fmax(fabs(r[0]), fabs(r[1])) <= tol ? 0 : 1;
   }
-  template <int SOLVER>
-  __device__ static __forceinline__ int solve(const Consts&, const Prep& P, const double (&z)[2], const double (&fx)[DF],
-                                              double (&t)[DT], Aux&, int max_iters, double tol) {
-    int st = 0;
-    if constexpr (SOLVER == kSolverClosedForm) {
-      if constexpr (DIR == 0) { t[0] = P.a0; t[1] = P.a1; }
-      else {
+  // pose direction, Newton: residual in the solver form, block step along the ray
+  __device__ static __forceinline__ bool newton_step(const double (&z)[2], const double (&fx)[DF], double (&t)[DT], double tol) {
+    static_assert(DIR == 1, "the landmark direction returns its unique root directly");
+    const double dx = fx[0] - t[0], dy = fx[1] - t[1];
+    const double n2 = dx * dx + dy * dy;
+    const double n = fast_sqrt(n2), psi = fast_atan2(dy, dx);
+    const double r0 = sym_rem(z[0] - (psi - t[2])), r1 = z[1] - n;
+    const bool ok = fmax(fabs(r0), fabs(r1)) <= tol;
+    const double k = n > 0.0 ? z[1] / n : 0.0;                       // pose coincides with the landmark: leave along +x
+    const double nx = n > 0.0 ? fx[0] - k * dx : fx[0] - z[1], ny = fx[1] - k * dy;
+    t[0] = ok ? t[0] : nx; t[1] = ok ? t[1] : ny; t[2] = ok ? t[2] : psi - z[0];
+    return ok;
+  }
+  // Gauss-Newton on the functor (the oracle's br_newton): r through residual_bearingrange at the current point;
+  //   DIR 0: exact Newton step in the pose-frame polar chart of the landmark, (φ, n) += (r0, r1);  DIR 1: the block step along the ray
+  __device__ static __forceinline__ int gauss_newton(const double (&z)[2], const double (&fx)[DF], double (&t)[DT], int max_iters, double tol) {
+    for (int it = 0; it < max_iters; ++it) {
+      double r[2]; functor(z, fx, t, r);
+      if (fmax(fabs(r[0]), fabs(r[1])) <= tol) return 0;
+      if constexpr (DIR == 0) {
+        double s, c; fast_sincos(fx[2], &s, &c);
+        const double dx = t[0] - fx[0], dy = t[1] - fx[1];
+        const double plx = c * dx + s * dy, ply = c * dy - s * dx;
+        const double nn = fast_sqrt(plx * plx + ply * ply) + r[1], an = fast_atan2(ply, plx) + r[0];
+        double sa, ca; fast_sincos(an, &sa, &ca);
+        const double qx = nn * ca, qy = nn * sa;
+        t[0] = fx[0] + c * qx - s * qy; t[1] = fx[1] + s * qx + c * qy;
+      } else {
         const double dx = fx[0] - t[0], dy = fx[1] - t[1];
         const double n = fast_sqrt(dx * dx + dy * dy);
         const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
         t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = fast_atan2(uy, ux) - z[0];
       }
+    }
+    return 1;
+  }
+  template <int SOLVER>
+  __device__ static __forceinline__ int solve(const Consts&, const Prep& P, const double (&z)[2], const double (&fx)[DF],
+                                              double (&t)[DT], Aux&, int max_iters, double tol) {
+    int st = 0;
+    if constexpr (DIR == 0 && (SOLVER == kSolverClosedForm || SOLVER == kSolverNewton)) { t[0] = P.a0; t[1] = P.a1; return 0; }
+    else if constexpr (SOLVER == kSolverClosedForm) {
+      const double dx = fx[0] - t[0], dy = fx[1] - t[1];
+      const double n = fast_sqrt(dx * dx + dy * dy);
+      const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
+      t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = fast_atan2(uy, ux) - z[0];
     } else if constexpr (SOLVER == kSolverNewton) {
       bool ok = false;
-      if (max_iters > 0) ok = newton_step(P, z, fx, t, tol);   // lands on a root
-      if (max_iters > 1) ok = newton_step(P, z, fx, t, tol);   // evaluates the residual there (wave-uniform branches)
+      if (max_iters > 0) ok = newton_step(z, fx, t, tol);   // lands on a root
+      if (max_iters > 1) ok = newton_step(z, fx, t, tol);   // evaluates the residual there (wave-uniform branches)
       st = ok ? 0 : 1;
-      for (int it = 2; it < max_iters && st; ++it) st = newton_step(P, z, fx, t, tol) ? 0 : 1;
+      for (int it = 2; it < max_iters && st; ++it) st = newton_step(z, fx, t, tol) ? 0 : 1;
+    } else if constexpr (SOLVER == kSolverGaussNewton) {
+      st = gauss_newton(z, fx, t, max_iters, tol);
     } else {
       BRCost<DIR> cost{z[0], z[1], {fx[0], fx[1], DF == 3 ? fx[DF - 1] : 0.0}};
       st = nelder_mead<DT>(cost, t, max_iters, tol);
@@ -390,7 +389,7 @@ struct P3P3Cost {
 };
 
 struct P3P3 {
-  static constexpr int DF = 6, DT = 6, DZ = 6;
+  static constexpr int DF = 6, DT = 6, DZ = 6, NL = 21, NK = 27;
   static constexpr int kHypoDir = -1;
   static constexpr bool kUniqueRoot = true;
   struct Consts { double mu[6]; const double* L; int dir; };
@@ -399,6 +398,14 @@ struct P3P3 {
 #pragma unroll
     for (int k = 0; k < 6; ++k) K.mu[k] = a.mu[6 * f + k];
     K.L = a.L + 21 * (size_t)f;  // 21 wave-uniform doubles, read through the scalar cache at use
+    K.dir = dr;
+    return K;
+  }
+  __device__ static __forceinline__ Consts from_lds(const double* sk, int dr) {
+    Consts K;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) K.mu[k] = sk[k];
+    K.L = sk + 6;
     K.dir = dr;
     return K;
   }
@@ -414,7 +421,7 @@ struct P3P3 {
   }
   __device__ static __forceinline__ void canonical(double (&)[6]) {}   // finalize() writes the principal rotation vector
   __device__ static __forceinline__ bool needs_cycles(int solver, const Consts& K) {
-    return solver != kSolverClosedForm && K.dir != kDirPrior;
+    return (solver == kSolverNelderMead || solver == kSolverGaussNewton) && K.dir != kDirPrior;
   }
   struct Aux { double q[4]; };
   // start point u0 -> state.  The reference takes X0c = vee(log(ϵ, u0)) of the start point, and Manifolds' log returns θ = π exactly
@@ -465,38 +472,6 @@ struct P3P3 {
     for (int j = 0; j < 6; ++j) acc += fmax(0.0, (s[2 * j + 1] - s[2 * j] * s[2 * j] * inv) * den);
     return fast_sqrt(acc);
   }
-  // inflation spread of a cycle (see P2P2::cycle_spread): unique root, so closed form / Newton take single-precision moments
-  template <int PPL, int SOLVER>
-  __device__ static __forceinline__ double cycle_spread(const double (&t)[PPL][6], const Aux (&A)[PPL], const bool (&act)[PPL], double inv, double den) {
-    if constexpr (SOLVER == kSolverNelderMead) return spread<PPL>(t, A, act, inv, den);
-    else {
-      double c0[3], q0[4];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) c0[k] = readlane_f64(t[0][k], 0);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) q0[k] = readlane_f64(A[0].q[k], 0);
-      float s[7];
-#pragma unroll
-      for (int j = 0; j < 7; ++j) s[j] = 0.0f;
-#pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        double e[4];
-        float w[3];
-        quat_cmul(q0, A[k].q, e); quat_log_f32(e, w);   // single-precision Log (the spread only scales a start-point jitter)
-        const float d[6] = {(float)(t[k][0] - c0[0]), (float)(t[k][1] - c0[1]), (float)(t[k][2] - c0[2]), w[0], w[1], w[2]};
-        if (act[k]) {
-#pragma unroll
-          for (int j = 0; j < 6; ++j) { s[j] += d[j]; s[6] = fmaf(d[j], d[j], s[6]); }
-        }
-      }
-      wave_sum_n_f32<7>(s);   // Σ_k var_k = (Σ|d|² - Σ_k (Σ d_k)² / N) / (N - 1)
-      const float fi = (float)inv, fd = (float)den;
-      float m2 = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) m2 = fmaf(s[j], s[j], m2);
-      return (double)fminf(__builtin_sqrtf(fmaxf(0.0f, (s[6] - m2 * fi) * fd)), 3.0e38f);
-    }
-  }
   // The root (a, qa) of the residual, prepared once per particle for both directions (cf. P2P2::Prep): with the rotation
   // solved first, the translation residual is affine with R at the root rotation, so R(qa) z_t is loop-invariant:
   //   dir 0 (solve q): qa = q_p ⊗ q_z,        a = p.t + R_p z_t
@@ -527,12 +502,8 @@ struct P3P3 {
     }
     return P;
   }
-  template <int SOLVER>
-  __device__ static __forceinline__ void heading_sincos(const Consts&, const Prep&, int, int, const double (&)[6], double* s, double* c) {
-    *s = 0.0; *c = 1.0;
-  }
   // u0 ∘ exp_ϵ(hat e), e = spread·(u − ½):  t += R e_t,  R ← R Exp(e_ω)
-  __device__ static __forceinline__ void add_entropy(double (&t)[6], Aux& A, double spread, const double (&u)[6], double, double) {
+  __device__ static __forceinline__ void add_entropy(double (&t)[6], Aux& A, double spread, const double (&u)[6]) {
     double e[6], v[3], qe[4], qn[4];
 #pragma unroll
     for (int k = 0; k < 6; ++k) e[k] = spread * (u[k] - 0.5);
@@ -542,40 +513,74 @@ struct P3P3 {
 #pragma unroll
     for (int k = 0; k < 4; ++k) A.q[k] = qn[k];
   }
-  // One Newton step on the group from (t, q): the rotation step q ← q ⊗ (conj(q) ⊗ qa) is exact (right-perturbation update
-  // with the residual itself, no Exp / Log), the translation follows.  Returns true when the residual at (t, q) is within
-  // tol (then the state is left untouched).  |Log e| = 2·atan2(|e_v|, |e_w|): below 2e-10 rad it is 2·e_v to 1e-30.
-  __device__ static __forceinline__ bool newton_step(const Prep& P, double (&t)[6], Aux& A, double tol) {
-    double e[4], qn[4];
-    quat_cmul(A.q, P.qa, e);
-    const double r0 = P.a[0] - t[0], r1 = P.a[1] - t[1], r2 = P.a[2] - t[2];
-    const double n2 = e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
-    const double m = fmax(fmax(fabs(r0), fabs(r1)), fmax(fabs(r2), 2.0 * fmax(fabs(e[1]), fmax(fabs(e[2]), fabs(e[3])))));
-    const bool ok = n2 <= 1e-20 && m <= tol;
-    quat_mul(A.q, e, qn);
+  // the residual FUNCTOR itself (src/factors/Pose3Pose3.jl:17-29 / Pose3D.jl:15-19, through 3x3 frames) at the target (t, R(q))
+  __device__ static __forceinline__ void quat_to_mat(const double (&q)[4], double* R) {   // column-major
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y + w * z);       R[2] = 2.0 * (x * z - w * y);
+    R[3] = 2.0 * (x * y - w * z);       R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z + w * x);
+    R[6] = 2.0 * (x * z + w * y);       R[7] = 2.0 * (y * z - w * x);       R[8] = 1.0 - 2.0 * (x * x + y * y);
+  }
+  __device__ static __forceinline__ void functor(const Consts& K, const double (&z)[6], const double* Z, const Se3& F, const Se3& T, double (&r)[6]) {
+    if (K.dir == kDirPrior) { Se3 M; se3_from_coords(z, M); residual_priorpose3(M, T, r); }
+    else if (K.dir == 0) residual_pose3pose3(z, Z, F, T, r);
+    else residual_pose3pose3(z, Z, T, F, r);
+  }
+  __device__ static __forceinline__ int verify(const Consts& K, const double (&z)[6], const double (&fxc)[6], const double (&t)[6], const Aux& A, double tol) {
+    Se3 F, T; double Z[9], r[6];
+    se3_from_coords(fxc, F); so3_exp(&z[3], Z);
+    T.t[0] = t[0]; T.t[1] = t[1]; T.t[2] = t[2]; quat_to_mat(A.q, T.R);
+    functor(K, z, Z, F, T, r);
+    double m = 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) A.q[k] = ok ? A.q[k] : qn[k];
-    t[0] = ok ? t[0] : t[0] + r0; t[1] = ok ? t[1] : t[1] + r1; t[2] = ok ? t[2] : t[2] + r2;
-    return ok;
+    for (int k = 0; k < 6; ++k) m = fmax(m, fabs(r[k]));
+    return m <= tol ? 0 : 1;
+  }
+  // Gauss-Newton on the functor (the oracle's p3p3_newton_pt): right-perturbation updates on the group that zero the residual,
+  //   dir 0: R_q ← R_q Exp(r_ω), q.t += r_t;   dir 1: R_p ← R_p Exp(−Z r_ω), p.t ← q.t − R_p z_t
+  __device__ static __forceinline__ int gauss_newton(const Consts& K, const double (&z)[6], const double (&fxc)[6], double (&t)[6], Aux& A, int max_iters, double tol) {
+    Se3 F, T; double Z[9];
+    se3_from_coords(fxc, F); so3_exp(&z[3], Z);
+    T.t[0] = t[0]; T.t[1] = t[1]; T.t[2] = t[2]; quat_to_mat(A.q, T.R);
+    int st = 1;
+    for (int it = 0; it < max_iters; ++it) {
+      double r[6];
+      functor(K, z, Z, F, T, r);
+      double m = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) m = fmax(m, fabs(r[k]));
+      if (m <= tol) { st = 0; break; }
+      double E[9], Rn[9];
+      if (K.dir == 0) {
+        so3_exp(r + 3, E); mat3_mul(T.R, E, Rn);
+        T.t[0] += r[0]; T.t[1] += r[1]; T.t[2] += r[2];
+      } else {
+        double d[3], v[3];
+        mat3_vec(Z, r + 3, d); d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2];
+        so3_exp(d, E); mat3_mul(T.R, E, Rn);
+        mat3_vec(Rn, z, v);
+        T.t[0] = F.t[0] - v[0]; T.t[1] = F.t[1] - v[1]; T.t[2] = F.t[2] - v[2];
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) T.R[k] = Rn[k];
+    }
+    double w[3];
+    so3_log(T.R, w); quat_exp(w, A.q);
+    t[0] = T.t[0]; t[1] = T.t[1]; t[2] = T.t[2];
+    return st;
   }
   template <int SOLVER>
   __device__ static __forceinline__ int solve(const Consts& K, const Prep& P, const double (&z)[6], const double (&fxc)[6],
                                               double (&t)[6], Aux& A, int max_iters, double tol) {
     int st = 0;
-    if (K.dir == kDirPrior || SOLVER == kSolverClosedForm) {   // the prepared root itself
+    if (K.dir == kDirPrior || SOLVER == kSolverClosedForm || SOLVER == kSolverNewton) {   // the prepared root itself
 #pragma unroll
       for (int k = 0; k < 3; ++k) t[k] = P.a[k];
 #pragma unroll
       for (int k = 0; k < 4; ++k) A.q[k] = P.qa[k];
       return 0;
     }
-    if constexpr (SOLVER == kSolverNewton) {
-      bool ok = false;
-      if (max_iters > 0) ok = newton_step(P, t, A, tol);   // lands on the root
-      if (max_iters > 1) ok = newton_step(P, t, A, tol);   // evaluates the residual there (wave-uniform branches)
-      st = ok ? 0 : 1;
-      for (int it = 2; it < max_iters && st; ++it) st = newton_step(P, t, A, tol) ? 0 : 1;
-    } else if constexpr (SOLVER == kSolverNelderMead) {
+    if constexpr (SOLVER == kSolverGaussNewton) st = gauss_newton(K, z, fxc, t, A, max_iters, tol);
+    else if constexpr (SOLVER == kSolverNelderMead) {
       P3P3Cost cost;
 #pragma unroll
       for (int k = 0; k < 3; ++k) cost.zt[k] = z[k];
@@ -591,10 +596,10 @@ struct P3P3 {
 };
 
 // ------------------------------------------------------------------------------------------
-// the convolution kernel
+// the convolution kernels
 // ------------------------------------------------------------------------------------------
 #ifndef ROME_P3_MINBLK
-#define ROME_P3_MINBLK 1   // (round 1 pinned 3 waves/SIMD here; with the root prepared once the kernel needs far fewer registers)
+#define ROME_P3_MINBLK 1
 #endif
 #ifndef ROME_MIN_WAVES
 #define ROME_MIN_WAVES 1
@@ -602,17 +607,44 @@ struct P3P3 {
 #ifndef ROME_NM_MINWAVES
 #define ROME_NM_MINWAVES 4
 #endif
-// LEAN: the plain sweep -- in-kernel noise, all four table columns present, no multihypo / nullhypo rows.  The same code with
-// those features compiled out: the table row is four scalar loads issued together, nothing stands between the belief loads
-// and the Philox / Box-Muller block (which then runs under the load latency), and the register allocation is not pinned by
-// the feature paths.  launch_ppl picks it whenever the arguments allow.
-template <class FP, int SOLVER, int PPL, bool LEAN>
 #ifndef ROME_WPB
-#define ROME_WPB 4   // wavefronts (= convolutions) per workgroup
+#define ROME_WPB 4   // wavefronts (= convolutions) per workgroup of k_conv
 #endif
+
+// slot k of lane `lane` -> particle: a lane owns NEIGHBOURING particles (2l, 2l+1), then (128 + 2l, 128 + 2l + 1), ...: the two
+// particles that share a Box-Muller pair (rng_normals<3>) sit in one lane and are adjacent in every SoA row
+template <int PPL>
+__device__ __forceinline__ int slot_particle(int lane, int k) {
+  if constexpr (PPL == 1) return lane;
+  else return ((k >> 1) << 7) + 2 * lane + (k & 1);
+}
+// D == 3 normals with ONE particle per lane (N <= 64): the odd lane takes words (z, w) of its even neighbour's call by DPP
+// (quad_perm [0,0,2,2]) instead of repeating that Philox call
+__device__ __forceinline__ void rng_normals3_lane(uint64_t seed, uint64_t stream, uint32_t particle, double (&out)[3]) {
+  const u32x4 w = noise_words(seed, stream, particle, 0u);
+  box_muller(w.x, w.y, &out[0], &out[1]);
+  const uint32_t wz = (uint32_t)__builtin_amdgcn_mov_dpp((int)w.z, 0xA0, 0xF, 0xF, true);
+  const uint32_t ww = (uint32_t)__builtin_amdgcn_mov_dpp((int)w.w, 0xA0, 0xF, 0xF, true);
+  double c, s;
+  box_muller(wz, ww, &c, &s);
+  out[2] = (particle & 1u) ? s : c;
+}
+
+// separator rows are duplicated into the exchange buffer: block m of mirror_out for row c with mirror_map[c] = m >= 0
+// (any number of rows), or -- the older form -- for the up to four rows listed in mirror_row
+__device__ __forceinline__ int mirror_slot(const ConvArgs& a, int c_raw) {
+  if (a.mirror_map) return a.mirror_map[c_raw];
+  int m = -1;
+  for (int q = 0; q < a.n_mirror; ++q) m = a.mirror_row[q] == c_raw ? q : m;
+  return m;
+}
+
+// LEAN: the plain sweep -- in-kernel noise, all four table columns present, no multihypo / nullhypo rows.  The same code with
+// those features compiled out: the table row is one 16-byte scalar load, nothing stands between the belief loads and the
+// Philox / Box-Muller block, and the register allocation is not pinned by the feature paths.
+template <class FP, int SOLVER, int PPL, bool LEAN>
 // Nelder-Mead on the 2-D/3-D factors is latency-bound (long dependent select/compare chains): asking for 4 waves/SIMD
-// (<= 128 VGPRs) is 5 % faster there; the Newton / closed-form kernels are issue-bound and lose 5-40 % when capped.
-// (the SE(3) kernels need their 256 VGPRs: capped at 3-4 waves/SIMD they spill and run 2.7x slower)
+// (<= 128 VGPRs) is 5 % faster there; (the SE(3) kernels need their 256 VGPRs: capped at 3-4 waves/SIMD they spill and run 2.7x slower)
 __global__ void __launch_bounds__(64 * ROME_WPB, (SOLVER == kSolverNelderMead && FP::DT <= 3) ? ROME_NM_MINWAVES : ((SOLVER != kSolverNelderMead && FP::DT == 6) ? ROME_P3_MINBLK : ROME_MIN_WAVES))
 k_conv(const ConvArgs a) {
   const int lane = threadIdx.x & 63;
@@ -644,32 +676,24 @@ k_conv(const ConvArgs a) {
   typename FP::Aux aux[PPL];   // state a policy keeps beside the coordinates (Pose3: the rotation as a unit quaternion)
   bool act[PPL];
   [[maybe_unused]] double xi_odd[3];   // normals of the odd slot, produced together with the even slot's (shared Box-Muller pair)
-  [[maybe_unused]] EntropyWords ew[PPL];   // cheap-entropy words: slot k (even) serves particles k and k+1
-#ifndef ROME_NOISE_FIRST
-#define ROME_NOISE_FIRST 1
-#endif
   // measurement samples first (they depend on nothing but the convolution id), then the belief loads: the loaded particles
   // are then not live across the Philox / Box-Muller block (fewer registers at the kernel's pressure peak)
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
-    const int i = lane + 64 * k;
+    const int i = slot_particle<PPL>(lane, k);
     act[k] = i < N;
     const int ii = act[k] ? i : 0;  // idle lanes shadow particle 0 (keeps the math finite, never stored)
-    if constexpr (!ROME_NOISE_FIRST) {
-#pragma unroll
-      for (int d = 0; d < FP::DF; ++d) fx[k][d] = fb[d * N + ii];
-#pragma unroll
-      for (int d = 0; d < FP::DT; ++d) t[k][d] = tb[d * N + ii];
-    }
     double xi[FP::DZ];
     if (!LEAN && a.noise) {
       const double* nb = a.noise + (size_t)c * FP::DZ * N;
 #pragma unroll
       for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
     } else if constexpr (FP::DZ == 3 && PPL >= 2) {
-      // slots k (even) and k+1 of a lane are particles p and p+64: they share the third Box-Muller pair (rng_normals)
-      if ((k & 1) == 0) { ew[k] = EntropyWords{0u, 0u, 0u, 0u}; rng_normals3_pair(a.seed, stream, (uint32_t)i, xi, xi_odd, &ew[k].x, &ew[k].z); }
+      // slots k (even) and k+1 of a lane are the neighbours 2j, 2j+1: they share the third Box-Muller pair (rng_normals)
+      if ((k & 1) == 0) rng_normals3_pair(a.seed, stream, (uint32_t)i, xi, xi_odd);
       else { xi[0] = xi_odd[0]; xi[1] = xi_odd[1]; xi[2] = xi_odd[2]; }
+    } else if constexpr (FP::DZ == 3) {
+      rng_normals3_lane(a.seed, stream, (uint32_t)i, xi);   // (every lane takes part in the DPP exchange: i, not ii)
     } else {
       rng_normals<FP::DZ>(a.seed, stream, (uint32_t)ii, xi);
     }
@@ -680,14 +704,12 @@ k_conv(const ConvArgs a) {
   }
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
-    const int i = lane + 64 * k;
+    const int i = slot_particle<PPL>(lane, k);
     const int ii = act[k] ? i : 0;
-    if constexpr (ROME_NOISE_FIRST) {
 #pragma unroll
-      for (int d = 0; d < FP::DF; ++d) fx[k][d] = fb[d * N + ii];
+    for (int d = 0; d < FP::DF; ++d) fx[k][d] = fb[d * N + ii];
 #pragma unroll
-      for (int d = 0; d < FP::DT; ++d) t[k][d] = tb[d * N + ii];
-    }
+    for (int d = 0; d < FP::DT; ++d) t[k][d] = tb[d * N + ii];
     FP::canonical(t[k]);
     aux[k] = FP::init_aux(t[k]);
     prep[k] = FP::prepare(K, z[k], fx[k]);
@@ -716,7 +738,7 @@ k_conv(const ConvArgs a) {
       const double* __restrict__ ab = (hd == 1 ? a.bel_fixed + (size_t)av * FP::DF * N : a.bel_target + (size_t)av * FP::DT * N);
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
-        const int i = lane + 64 * k, ii = act[k] ? i : 0;
+        const int i = slot_particle<PPL>(lane, k), ii = act[k] ? i : 0;
         const u32x4 hw = philox4x32_10(u32x4{(uint32_t)ii, (uint32_t)stream, (uint32_t)(stream >> 32), (4u << 16)},
                                        (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
         const bool primary = ((double)hw.x + 0.5) * (1.0 / 4294967296.0) < w;
@@ -732,7 +754,7 @@ k_conv(const ConvArgs a) {
         double sm[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < PPL; ++k) if (act[k]) {
-          const int i = lane + 64 * k;
+          const int i = slot_particle<PPL>(lane, k);
           sm[0] += t[k][0]; sm[1] += t[k][1]; sm[2] += ab[i]; sm[3] += ab[N + i];
         }
         wave_sum_n<4>(sm);
@@ -754,39 +776,26 @@ k_conv(const ConvArgs a) {
     nh0_spread = N > 1 ? a.spread_nh * (sd0 > 1e-10 ? sd0 : 1.0) : 0.0;   // calcStdBasicSpread fallback, as the inflation spread
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
-      const uint32_t ii = (uint32_t)(act[k] ? lane + 64 * k : 0);
+      const uint32_t ii = (uint32_t)(act[k] ? slot_particle<PPL>(lane, k) : 0);
       const u32x4 w0 = philox4x32_10(u32x4{ii, (uint32_t)stream, (uint32_t)(stream >> 32), (5u << 16)}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
       nullh[k] = ((double)w0.x + 0.5) * (1.0 / 4294967296.0) < p_null;   // (the entropy words are re-drawn after the cycles:
     }                                                                      //  nothing but this flag stays live across the solve)
   }
 
+  // Inflation cycles (IIF inflateCycles x {addEntropyOnManifold!, N x solve}) apply to the solvers that start from the belief point;
+  // the jitter is drawn exactly as the oracle defines it (ro_rng_entropy).  CLOSED_FORM / NEWTON on a unique-root factor return the
+  // root, which no start point can change: one pass, no statistic, no entropy.
   const bool cyc_on = FP::needs_cycles(SOLVER, K);
   const int ncyc = cyc_on ? (a.cycles < 1 ? 1 : a.cycles) : 1;
-  // Where the jitter can reach the proposal (Nelder-Mead stops ~1e-4 from the root; the bearing-range pose direction has a
-  // ring of roots) it is drawn exactly as the oracle defines it; elsewhere (unique root, Newton / closed form) cheap narrow uniforms.
-  constexpr bool kExactEntropy = SOLVER == kSolverNelderMead || !FP::kUniqueRoot;
-  // Cycle elision: IIF repeats {inflate, solve} inflateCycles times.  Once every particle of a unique-root factor has converged
-  // (max|r| <= tol) a further cycle re-jitters the start and lands on the same root again (to the solver tolerance, 1e-12):
-  // the remaining cycles are skipped.  Guarded by the parity tests against the oracle, which always runs all cycles.
-  constexpr bool kElide = SOLVER == kSolverNewton && FP::kUniqueRoot;
-  constexpr int CPC = FP::DT <= 3 ? 3 : 1;  // inflation cycles served by one cheap-entropy Philox call
-  // cycle 0 of a Pose2 measurement with in-kernel noise: two spare words of the noise calls hold its 2 x 3 x 7 entropy bits
-  const bool spare0 = !kExactEntropy && FP::DZ == 3 && PPL >= 2 && (LEAN || a.noise == nullptr);
-  int have_call = -1;
+  // Cycle elision (GAUSS_NEWTON on a unique-root factor): once every particle has converged (max|r| <= tol) a further cycle
+  // re-jitters the start and lands on the same root again (to the solver tolerance): the remaining cycles are skipped.
+  // Guarded by the parity tests against the oracle, which always runs all cycles.
+  constexpr bool kElide = SOLVER == kSolverGaussNewton && FP::kUniqueRoot;
   for (int cyc = 0; cyc < ncyc; ++cyc) {
     double spread = 0.0;
     if (cyc_on && a.inflation > 0.0 && N > 1) {
-      const double sd = FP::template cycle_spread<PPL, SOLVER>(t, aux, act, a.inv_n, a.inv_nm1);
+      const double sd = FP::template spread<PPL>(t, aux, act, a.inv_n, a.inv_nm1);
       spread = a.inflation * (sd > 1e-10 ? sd : 1.0);   // IIF calcStdBasicSpread: "if no std yet, set to 1"
-    }
-    if constexpr (!kExactEntropy) {
-      if (spread > 0.0 && !(spare0 && cyc == 0) && have_call != cyc / CPC) {  // wave-uniform
-        have_call = cyc / CPC;
-#pragma unroll
-        for (int k = 0; k < PPL; ++k) {   // slots k (even) and k+1 = particles p, p+64 share the call of p (rng_entropy_from_words)
-          if ((k & 1) == 0) ew[k] = rng_entropy_words(a.seed, stream, (uint32_t)(lane + 64 * k), have_call);
-        }
-      }
     }
     int bad = 0;
 #pragma unroll
@@ -794,13 +803,8 @@ k_conv(const ConvArgs a) {
       if (act[k] && sel[k] && !nullh[k]) {
         if (spread > 0.0) {
           double u[FP::DT];
-          if constexpr (kExactEntropy) rng_entropy_exact<FP::DT>(a.seed, stream, (uint32_t)(lane + 64 * k), cyc, u);
-          // k is a compile-time constant after unrolling: static indices only
-          else if (k & 1) rng_entropy_from_words<FP::DT, 1>(ew[k & ~1], cyc % CPC, u);
-          else rng_entropy_from_words<FP::DT, 0>(ew[k], cyc % CPC, u);
-          double hs, hc;
-          FP::template heading_sincos<SOLVER>(K, prep[k], st[k], cyc, t[k], &hs, &hc);
-          FP::add_entropy(t[k], aux[k], spread, u, hs, hc);
+          rng_entropy_exact<FP::DT>(a.seed, stream, (uint32_t)slot_particle<PPL>(lane, k), cyc, u);
+          FP::add_entropy(t[k], aux[k], spread, u);
         }
         st[k] = FP::template solve<SOLVER>(K, prep[k], z[k], fx[k], t[k], aux[k], a.max_iters, a.tol);
         bad |= st[k];
@@ -810,12 +814,20 @@ k_conv(const ConvArgs a) {
       if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) break;   // wave-uniform
     }
   }
+  // NEWTON on a unique-root factor: the status is the residual FUNCTOR evaluated at the returned root (only when asked for)
+  if constexpr (SOLVER == kSolverNewton && FP::kUniqueRoot) {
+    if (a.status) {
+#pragma unroll
+      for (int k = 0; k < PPL; ++k)
+        if (act[k] && sel[k] && !nullh[k]) st[k] = FP::verify(K, z[k], fx[k], t[k], aux[k], a.tol);
+    }
+  }
 
   if (p_null > 0.0 && nh0_spread > 0.0) {
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       if (act[k] && nullh[k]) {
-        const uint32_t ii = (uint32_t)(lane + 64 * k);
+        const uint32_t ii = (uint32_t)slot_particle<PPL>(lane, k);
         const u32x4 w0 = philox4x32_10(u32x4{ii, (uint32_t)stream, (uint32_t)(stream >> 32), (5u << 16)}, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
         double u[FP::DT];
         const uint32_t e0[3] = {w0.y, w0.z, w0.w};
@@ -827,9 +839,7 @@ k_conv(const ConvArgs a) {
 #pragma unroll
           for (int d = 3; d < FP::DT; ++d) u[d] = ((double)e1[d - 3] + 0.5) * (1.0 / 4294967296.0);
         }
-        double hs, hc;
-        FP::template heading_sincos<kSolverNelderMead>(K, prep[k], 1, 0, t[k], &hs, &hc);   // this jitter IS the output: full precision
-        FP::add_entropy(t[k], aux[k], nh0_spread, u, hs, hc);
+        FP::add_entropy(t[k], aux[k], nh0_spread, u);
       }
     }
   }
@@ -839,7 +849,7 @@ k_conv(const ConvArgs a) {
       if (act[k] && !sel[k]) {  // the other hypothesis holds for this particle: entropy only
         // the words of the hypothesis draw are re-drawn here (same Philox call) instead of staying live across the cycles: kept in
         // per-slot arrays they were parked in LDS by the compiler
-        const u32x4 hw = philox4x32_10(u32x4{(uint32_t)(lane + 64 * k), (uint32_t)stream, (uint32_t)(stream >> 32), (4u << 16)},
+        const u32x4 hw = philox4x32_10(u32x4{(uint32_t)slot_particle<PPL>(lane, k), (uint32_t)stream, (uint32_t)(stream >> 32), (4u << 16)},
                                        (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
         t[k][0] += nh_spread * (((double)hw.y + 0.5) * (1.0 / 4294967296.0) - 0.5);
         t[k][1] += nh_spread * (((double)hw.z + 0.5) * (1.0 / 4294967296.0) - 0.5);
@@ -847,36 +857,126 @@ k_conv(const ConvArgs a) {
       }
     }
   }
+  const int mslot = (a.n_mirror > 0 || a.mirror_map) ? mirror_slot(a, c_raw) : -1;   // wave-uniform
+  double* mb = (mslot >= 0 && valid) ? a.mirror_out + (size_t)mslot * FP::DT * N : nullptr;
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
-    const int i = lane + 64 * k;
+    const int i = slot_particle<PPL>(lane, k);
     if (act[k] && valid) {
       FP::finalize(t[k], aux[k]);
 #pragma unroll
       for (int d = 0; d < FP::DT; ++d) ob[d * N + i] = t[k][d];
       if (a.status) a.status[(size_t)c * N + i] = st[k];
-    }
-  }
-  for (int m = 0; m < a.n_mirror; ++m) {  // wave-uniform: separator rows are duplicated into the exchange buffer
-    if (a.mirror_row[m] == c_raw) {
-      double* mb = a.mirror_out + (size_t)m * FP::DT * N;
+      if (mb) {
 #pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        const int i = lane + 64 * k;
-        if (act[k]) {
-#pragma unroll
-          for (int d = 0; d < FP::DT; ++d) mb[d * N + i] = t[k][d];
-        }
+        for (int d = 0; d < FP::DT; ++d) mb[d * N + i] = t[k][d];
       }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------
+// k_conv_flat -- the plain sweep of a UNIQUE-ROOT factor (Pose2Pose2 + PriorPose2 rows, bearing-range -> landmark, Pose3Pose3) with
+// CLOSED_FORM / NEWTON and in-kernel noise: nothing couples the particles of a convolution (no inflation statistic), so the
+// particles of consecutive table rows are packed densely onto the threads of a block:
+//   thread  = one PAIR of neighbouring particles (2j, 2j+1) of one row: the two share a Box-Muller pair (D = 3) and are adjacent
+//             in every SoA row -> one 16-byte load / store per coordinate;
+//   block   = CPB consecutive rows x H = ceil(N/2) pairs  (N = 100: 5 rows x 50 = 250 of 256 threads, against 100 of 128
+//             lane-slots with one wavefront per row);
+//   per-factor constants (μ, chol Σ) are staged ONCE per block through LDS by the first CPB x 16 threads and read back by every
+//             thread at its row's slot (conflict-free broadcasts); the table row itself is a 16-byte load per thread.
+// The root comes from FP::prepare (the same function the wave-per-row kernel and the per-factor entry points use: bit-identical
+// proposals); NEWTON additionally evaluates the residual functor at the root when a status array is asked for.
+// Any N >= 2; the start points u0 are never read (48 B of HBM traffic per Pose2 particle: fixed 24 + proposal 24).
+// ------------------------------------------------------------------------------------------
+constexpr int kFlatThreads = 256;
+constexpr int kFlatMaxRows = 16;    // rows per block (staging: 16 threads per row)
+template <class FP> struct FlatStage { static constexpr int kLanes = FP::NK <= 16 ? 16 : 32; };
+
+template <class FP, bool VERIFY, bool VEC2>
+__global__ void __launch_bounds__(kFlatThreads) k_conv_flat(const ConvArgs a, int H, int CPB, uint32_t magic) {
+  constexpr int SL = FlatStage<FP>::kLanes;
+  __shared__ double s_K[kFlatMaxRows][SL + 2];   // (+2: rows of a wave's two convolutions start in different banks)
+  const int tid = threadIdx.x;
+  const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int c0 = blk * CPB;
+  const int N = a.N;
+  // ---- stage the per-factor constants of the block's rows: thread (row lr, entry q) loads one double
+  {
+    const int lr = tid / SL, q = tid % SL;
+    if (lr < CPB && q < FP::NK) {
+      const int cr = min(c0 + lr, a.n_conv - 1);
+      const int f = a.rows4[4 * (size_t)cr];
+      s_K[lr][q] = q < FP::DZ ? a.mu[(size_t)FP::DZ * f + q] : a.L[(size_t)FP::NL * f + (q - FP::DZ)];
+    }
+  }
+  // ---- this thread's (row, pair)
+  const int lc_raw = (int)(((uint32_t)tid * magic) >> 16);   // tid / H
+  const int j = tid - lc_raw * H;
+  const bool live = lc_raw < CPB && c0 + lc_raw < a.n_conv;
+  const int lc = lc_raw < CPB ? lc_raw : CPB - 1;
+  const int c = min(c0 + lc, a.n_conv - 1);
+  const int4 row = *reinterpret_cast<const int4*>(a.rows4 + 4 * (size_t)c);
+  const int dr = (FP::kHypoDir < 0 || FP::kHypoDir == 2) ? row.y : a.dir_all;
+  const int i0 = 2 * j;                       // particles i0, i0 + 1
+  const bool act1 = i0 + 1 < N;               // (odd N: the last pair is a single particle)
+  const double* __restrict__ fb = a.bel_fixed + (size_t)row.z * FP::DF * N;
+  double fx[2][FP::DF];
+  if (VEC2) {
+#pragma unroll
+    for (int d = 0; d < FP::DF; ++d) {
+      const double2 v = *reinterpret_cast<const double2*>(fb + (size_t)d * N + i0);
+      fx[0][d] = v.x; fx[1][d] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < FP::DF; ++d) { fx[0][d] = fb[(size_t)d * N + i0]; fx[1][d] = fb[(size_t)d * N + (act1 ? i0 + 1 : i0)]; }
+  }
+  // ---- measurement noise (depends on the row id only: runs under the load latency)
+  const uint64_t stream = a.stream_offset + (uint64_t)c;
+  double xi[2][FP::DZ];
+  if constexpr (FP::DZ == 3) rng_normals3_pair(a.seed, stream, (uint32_t)i0, xi[0], xi[1]);
+  else { rng_normals<FP::DZ>(a.seed, stream, (uint32_t)i0, xi[0]); rng_normals<FP::DZ>(a.seed, stream, (uint32_t)(i0 + 1), xi[1]); }
+  __syncthreads();
+  const typename FP::Consts K = FP::from_lds(&s_K[lc][0], dr);
+  double t[2][FP::DT];
+  int st[2] = {0, 0};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    double z[FP::DZ];
+    FP::measurement(K, xi[k], z);
+    const typename FP::Prep P = FP::prepare(K, z, fx[k]);
+    typename FP::Aux A;
+    FP::template solve<kSolverClosedForm>(K, P, z, fx[k], t[k], A, 0, 0.0);
+    if constexpr (VERIFY) st[k] = FP::verify(K, z, fx[k], t[k], A, a.tol);   // NEWTON with a status array: the functor at the root
+    FP::finalize(t[k], A);
+  }
+  if (!live) return;
+  double* __restrict__ ob = a.out + (size_t)c * FP::DT * N;
+  const int mslot = (a.n_mirror > 0 || a.mirror_map) ? mirror_slot(a, c) : -1;
+  double* mb = mslot >= 0 ? a.mirror_out + (size_t)mslot * FP::DT * N : nullptr;
+  if (VEC2) {
+#pragma unroll
+    for (int d = 0; d < FP::DT; ++d) {
+      const double2 v = {t[0][d], t[1][d]};
+      *reinterpret_cast<double2*>(ob + (size_t)d * N + i0) = v;
+      if (mb) *reinterpret_cast<double2*>(mb + (size_t)d * N + i0) = v;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < FP::DT; ++d) {
+      ob[(size_t)d * N + i0] = t[0][d]; if (act1) ob[(size_t)d * N + i0 + 1] = t[1][d];
+      if (mb) { mb[(size_t)d * N + i0] = t[0][d]; if (act1) mb[(size_t)d * N + i0 + 1] = t[1][d]; }
+    }
+  }
+  if (a.status) { a.status[(size_t)c * N + i0] = st[0]; if (act1) a.status[(size_t)c * N + i0 + 1] = st[1]; }
+}
+
+// ------------------------------------------------------------------------------------------
 // N > 512: the same convolution with the particles walked in chunks of 128 instead of living in registers for the whole
 // kernel.  Cycle by cycle: (1) the spread of ALL N current points (the start points u0 in cycle 0, the previous cycle's
 // solutions afterwards -- they are re-read from the proposal block itself), (2) chunk by chunk: load, re-draw the measurement
-// samples (counter-based: the same every time), jitter with the oracle's full-width uniforms, solve, store.  Cycle elision as in
+// samples (counter-based: the same every time), jitter with the oracle's uniforms, solve, store.  Cycle elision as in
 // k_conv.  One wavefront per convolution; multihypo / nullhypo rows are not served here (the launcher refuses them).
 // ------------------------------------------------------------------------------------------
 template <class FP, int SOLVER>
@@ -902,7 +1002,7 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
   const uint64_t stream = a.stream_offset + (uint64_t)c;
   const bool cyc_on = FP::needs_cycles(SOLVER, K);
   const int ncyc = cyc_on ? (a.cycles < 1 ? 1 : a.cycles) : 1;
-  constexpr bool kElide = SOLVER == kSolverNewton && FP::kUniqueRoot;
+  constexpr bool kElide = SOLVER == kSolverGaussNewton && FP::kUniqueRoot;
   if (!valid) return;   // (nothing below synchronises across waves; surplus waves of the last block have no row)
   for (int cyc = 0; cyc < ncyc; ++cyc) {
     const double* cur = cyc == 0 ? tb : ob;
@@ -940,10 +1040,9 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
       typename FP::Aux aux[PPL];
       bool act[PPL];
       [[maybe_unused]] double xi_odd[3];
-      [[maybe_unused]] uint32_t sp0, sp1;
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
-        const int i = base + lane + 64 * k;
+        const int i = base + 2 * lane + k;
         act[k] = i < N;
         const int ii = act[k] ? i : 0;
 #pragma unroll
@@ -955,8 +1054,8 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
           const double* nb = a.noise + (size_t)c * FP::DZ * N;
 #pragma unroll
           for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
-        } else if constexpr (FP::DZ == 3) {   // particles p, p + 64 of a 128-chunk share the third Box-Muller pair (rng_normals)
-          if ((k & 1) == 0) rng_normals3_pair(a.seed, stream, (uint32_t)i, xi, xi_odd, &sp0, &sp1);
+        } else if constexpr (FP::DZ == 3) {   // the neighbours 2j, 2j+1 share the third Box-Muller pair (rng_normals)
+          if ((k & 1) == 0) rng_normals3_pair(a.seed, stream, (uint32_t)i, xi, xi_odd);
           else { xi[0] = xi_odd[0]; xi[1] = xi_odd[1]; xi[2] = xi_odd[2]; }
         } else rng_normals<FP::DZ>(a.seed, stream, (uint32_t)ii, xi);
         if (a.noise && a.noise_is_meas) {
@@ -968,16 +1067,16 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
       }
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
-        const int i = base + lane + 64 * k;
+        const int i = base + 2 * lane + k;
         if (act[k]) {
           const typename FP::Prep prep = FP::prepare(K, z[k], fx[k]);
           if (spread > 0.0) {
-            double u[FP::DT], hs, hc;
+            double u[FP::DT];
             rng_entropy_exact<FP::DT>(a.seed, stream, (uint32_t)i, cyc, u);
-            FP::template heading_sincos<kSolverNelderMead>(K, prep, 1, cyc, t[k], &hs, &hc);
-            FP::add_entropy(t[k], aux[k], spread, u, hs, hc);
+            FP::add_entropy(t[k], aux[k], spread, u);
           }
-          const int st = FP::template solve<SOLVER>(K, prep, z[k], fx[k], t[k], aux[k], a.max_iters, a.tol);
+          int st = FP::template solve<SOLVER>(K, prep, z[k], fx[k], t[k], aux[k], a.max_iters, a.tol);
+          if constexpr (SOLVER == kSolverNewton && FP::kUniqueRoot) { if (a.status) st = FP::verify(K, z[k], fx[k], t[k], aux[k], a.tol); }
           bad |= st;
           FP::finalize(t[k], aux[k]);
 #pragma unroll
@@ -1134,36 +1233,64 @@ hipError_t launch_coords_to_points(int n, int dim, const double* c, double* pts,
   if (n > 0) hipLaunchKernelGGL(k_coords_to_points, dim3((n + 255) / 256), dim3(256), 0, s, n, dim, c, pts);
   return hipGetLastError();
 }
-static int lds_pad_bytes() {   // experiment knob: unused dynamic LDS per block caps the resident blocks per CU (ROME_LDS_PAD=bytes)
-  static const int v = [] { const char* e = getenv("ROME_LDS_PAD"); return e ? atoi(e) : 0; }();
-  return v;
-}
 template <class FP, int SOLVER, bool LEAN>
 static hipError_t launch_ppl_v(const ConvArgs& a, hipStream_t s) {
   const int nb = (a.n_conv + ROME_WPB - 1) / ROME_WPB;
   if (nb == 0) return hipSuccess;
-  const int pad = lds_pad_bytes();
-  if (a.N <= 64)       hipLaunchKernelGGL((k_conv<FP, SOLVER, 1, LEAN>), dim3(nb), dim3(64 * ROME_WPB), pad, s, a);
-  else if (a.N <= 128) hipLaunchKernelGGL((k_conv<FP, SOLVER, 2, LEAN>), dim3(nb), dim3(64 * ROME_WPB), pad, s, a);
-  else if (a.N <= 256) hipLaunchKernelGGL((k_conv<FP, SOLVER, 4, LEAN>), dim3(nb), dim3(64 * ROME_WPB), pad, s, a);
-  else if (a.N <= 512) hipLaunchKernelGGL((k_conv<FP, SOLVER, 8, LEAN>), dim3(nb), dim3(64 * ROME_WPB), pad, s, a);
+  if (a.N <= 64)       hipLaunchKernelGGL((k_conv<FP, SOLVER, 1, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  else if (a.N <= 128) hipLaunchKernelGGL((k_conv<FP, SOLVER, 2, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  else if (a.N <= 256) hipLaunchKernelGGL((k_conv<FP, SOLVER, 4, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  else if (a.N <= 512) hipLaunchKernelGGL((k_conv<FP, SOLVER, 8, LEAN>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
   else {   // particles walked in chunks (k_conv_big); rows with multihypo / nullhypo / mirrors stay on the register-resident kernels
-    if (a.alt_var || a.nullhypo || a.n_mirror > 0) return hipErrorInvalidValue;
+    if (a.alt_var || a.nullhypo || a.n_mirror > 0 || a.mirror_map) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_conv_big<FP, SOLVER>), dim3(nb), dim3(64 * ROME_WPB), 0, s, a);
+  }
+  return hipGetLastError();
+}
+// the packed sweep (k_conv_flat): H = ceil(N/2) pair-threads per row, CPB rows per 256-thread block
+template <class FP, int SOLVER>
+static hipError_t launch_flat(const ConvArgs& a, hipStream_t s) {
+  const int H = (a.N + 1) / 2;
+  int CPB = kFlatThreads / H;
+  const int cap = kFlatThreads / FlatStage<FP>::kLanes;   // staging threads: kLanes per row
+  if (CPB > cap) CPB = cap;
+  if (CPB > kFlatMaxRows) CPB = kFlatMaxRows;
+  const uint32_t magic = (65536u + (uint32_t)H - 1u) / (uint32_t)H;   // tid / H == (tid * magic) >> 16 for tid < 256 (checked below)
+  for (int t = 0; t < kFlatThreads; ++t) if ((int)(((uint32_t)t * magic) >> 16) != t / H) return hipErrorInvalidValue;
+  const int nb = (a.n_conv + CPB - 1) / CPB;
+  if (nb == 0) return hipSuccess;
+  // 16-byte accesses need an even N (row starts stay 16-byte aligned) and 16-byte aligned arrays
+  const bool vec2 = (a.N % 2 == 0) && (((uintptr_t)a.bel_fixed | (uintptr_t)a.out | (uintptr_t)a.mirror_out) % 16 == 0);
+  // (the functor evaluation is a separate instantiation: compiled into the plain sweep it would pin its register allocation)
+  const bool verify = SOLVER == kSolverNewton && a.status != nullptr;
+  if (verify) {
+    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, true, true>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    else      hipLaunchKernelGGL((k_conv_flat<FP, true, false>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+  } else {
+    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, false, true>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    else      hipLaunchKernelGGL((k_conv_flat<FP, false, false>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
   }
   return hipGetLastError();
 }
 template <class FP, int SOLVER>
 static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
   const bool lean = a.rows4 != nullptr && a.noise == nullptr && a.alt_var == nullptr && a.nullhypo == nullptr;
+  if constexpr (FP::kUniqueRoot && (SOLVER == kSolverClosedForm || SOLVER == kSolverNewton)) {
+    // plain sweep of a unique-root factor: the packed kernel (rows of >= 8 pair-threads; tiny N stays one wavefront per row)
+    if (lean && a.N >= 16 && (a.N + 1) / 2 <= kFlatThreads) return launch_flat<FP, SOLVER>(a, s);
+    // NEWTON without a status array IS the closed form on these factors: one instantiation (the functor evaluation of the
+    // status path would otherwise pin the register allocation of the plain launch)
+    if constexpr (SOLVER == kSolverNewton) { if (!a.status) return launch_ppl<FP, kSolverClosedForm>(a, s); }
+  }
   return lean ? launch_ppl_v<FP, SOLVER, true>(a, s) : launch_ppl_v<FP, SOLVER, false>(a, s);
 }
 template <class FP>
 static hipError_t launch_solver(const ConvArgs& a, int solver, hipStream_t s) {
   switch (solver) {
-    case kSolverClosedForm: return launch_ppl<FP, kSolverClosedForm>(a, s);
-    case kSolverNewton:     return launch_ppl<FP, kSolverNewton>(a, s);
-    case kSolverNelderMead: return launch_ppl<FP, kSolverNelderMead>(a, s);
+    case kSolverClosedForm:  return launch_ppl<FP, kSolverClosedForm>(a, s);
+    case kSolverNewton:      return launch_ppl<FP, kSolverNewton>(a, s);
+    case kSolverNelderMead:  return launch_ppl<FP, kSolverNelderMead>(a, s);
+    case kSolverGaussNewton: return launch_ppl<FP, kSolverGaussNewton>(a, s);
     default: return hipErrorInvalidValue;
   }
 }

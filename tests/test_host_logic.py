@@ -30,12 +30,12 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "librome_mi355.so does not export %s" % name
     assert declared == set(R._lib.SIGNATURES), declared ^ set(R._lib.SIGNATURES)
-    assert lib.rome_version() == 100
+    assert lib.rome_version() == 110
 
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(R._lib.Opts) == 72
-    assert ctypes.sizeof(R._lib.ConvDev) == 8 + 11 * 8 + 24 + 8 + 16 + 8 + 8   # ... + rows4
+    assert ctypes.sizeof(R._lib.ConvDev) == 8 + 11 * 8 + 24 + 8 + 16 + 8 + 8 + 8   # ... + rows4 + mirror_map
     o = R.make_opts(solver=R.SOLVER_NELDER_MEAD)
     assert (o.n_particles, o.max_iters, o.inflate_cycles, o.tol, o.inflation) == (100, 1000, 3, 1e-8, 5.0)
     o = R.make_opts(N=64)
@@ -231,16 +231,16 @@ def _bm_exact(wa, wb):
 
 def test_normal_generator_definition():
     # normals, d = 3: 0, 1 from the particle's own call; 2 = first / second output of the second Box-Muller pair of the call made
-    # for particle p & ~64 (Philox domain 1): particles p and p ^ 64 share that pair
-    a, b = ro.rng_normals(7, 3, 5, 3), ro.rng_normals(7, 3, 5 + 64, 3)
-    w5 = ro.philox([5, 3, 0, (1 << 16) | 0], [7, 0]); w69 = ro.philox([5 + 64, 3, 0, (1 << 16) | 0], [7, 0])
+    # for the even particle p & ~1 (Philox domain 1): neighbouring particles 2j, 2j+1 share that pair
+    a, b = ro.rng_normals(7, 3, 4, 3), ro.rng_normals(7, 3, 5, 3)
+    w5 = ro.philox([4, 3, 0, (1 << 16) | 0], [7, 0]); w69 = ro.philox([5, 3, 0, (1 << 16) | 0], [7, 0])
     assert np.array_equal(a[:2], ro.box_muller(w5[0], w5[1])) and np.array_equal(b[:2], ro.box_muller(w69[0], w69[1]))
     sh = ro.box_muller(w5[2], w5[3])
     assert a[2] == sh[0] and b[2] == sh[1] and not np.allclose(a[:2], b[:2])
     e0, e1 = _bm_exact([w5[2]], [w5[3]])
     assert abs(sh[0] - e0[0]) < 1e-4 and abs(sh[1] - e1[0]) < 1e-4
     # d = 2 / 6: pairs in call order
-    n6 = ro.rng_normals(7, 3, 5, 6); w5b = ro.philox([5, 3, 0, (1 << 16) | 1], [7, 0])
+    n6 = ro.rng_normals(7, 3, 4, 6); w5b = ro.philox([4, 3, 0, (1 << 16) | 1], [7, 0])
     assert np.array_equal(n6, list(ro.box_muller(w5[0], w5[1])) + list(ro.box_muller(w5[2], w5[3])) + list(ro.box_muller(w5b[0], w5b[1])))
     # edge words: the largest radius (6.66 sigma), the zero radius, the four mirror quadrants
     big = ro.box_muller(0, 0x20000000)
@@ -249,7 +249,7 @@ def test_normal_generator_definition():
     assert sg == [(1, 1), (1, -1), (-1, 1), (-1, -1)]
     n3 = np.array([ro.rng_normals(11, 2, i, 3) for i in range(2048)])
     assert np.abs(n3.mean(0)).max() < 0.08 and np.abs(n3.std(0) - 1).max() < 0.06
-    assert abs(np.corrcoef(n3[:64, 2], n3[64:128, 2])[0, 1]) < 0.35              # the two outputs of a shared pair are uncorrelated
+    assert abs(np.corrcoef(n3[0::2, 2], n3[1::2, 2])[0, 1]) < 0.1                # the two outputs of a shared pair are uncorrelated
 
 
 def test_normal_generator_law():
