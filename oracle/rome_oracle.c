@@ -100,17 +100,34 @@ void ro_box_muller(uint32_t wa, uint32_t wb, double* n0, double* n1) {
   *n0 = (double)((wb & 0x80000000u) ? -m0 : m0);
   *n1 = (double)((wb & 0x40000000u) ? -m1 : m1);
 }
-/* d == 3: particles p and p ^ 1 (neighbours 2j, 2j+1) share the second Box-Muller pair of the call of the EVEN particle p & ~1
- * (cosine branch for the even particle, sine branch for the odd one) instead of each discarding one normal -- same rule as
- * rng_normals<3> in the HIP path, where one thread owns both particles of a pair (two Philox calls, three pairs, 16-byte loads). */
+/* Neighbouring particles 2j, 2j+1 draw from the SAME Philox calls, made with the EVEN particle id as counter -- the same rule as
+ * rng_normals / rng_normals_pair in the HIP path, where one thread owns both particles (RNG stream unpinned by the reference).
+ *   d = 2, 6: the words of calls b = 0 .. d/2-1 in order; the even particle takes words [0, d), the odd one [d, 2d); consecutive
+ *             word pairs (radius word, angle word) -> one Box-Muller pair.
+ *   d = 3:    ONE call for the six normals of the two particles, its 128 bits cut into six 21-bit fields:
+ *             fields 0/1 = top 21 bits of words 0/1 -> normals 0, 1 of the even particle; fields 2/3 = top 21 bits of words 2/3 ->
+ *             normals 0, 1 of the odd one; field 4 = low 11 bits of word 0 then bits 10..1 of word 1, field 5 = the same of
+ *             words 2, 3 -> normal 2 of the even (first output) and the odd particle (second).  A field f enters ro_box_muller as
+ *             the word (f << 11) | 0x400 (the centre of its bin).
+ *   other d (not used by the supported factors): the particle's own calls, pairs in call order. */
 void ro_rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, int d, double* out) {
+  const uint32_t pe = particle & ~1u;
+  const int odd = (int)(particle & 1u);
   if (d == 3) {
-    uint32_t w[4], wb[4];
+    uint32_t w[4];
     double c, s;
-    ro_noise_words(seed, stream, particle, 0, w);
-    ro_box_muller(w[0], w[1], &out[0], &out[1]);
-    if (particle & 1u) { ro_noise_words(seed, stream, particle & ~1u, 0, wb); ro_box_muller(wb[2], wb[3], &c, &s); out[2] = s; }
-    else { ro_box_muller(w[2], w[3], &c, &s); out[2] = c; }
+    ro_noise_words(seed, stream, pe, 0, w);
+    const uint32_t r1 = ((odd ? w[2] : w[0]) & 0xFFFFF800u) | 0x400u, a1 = ((odd ? w[3] : w[1]) & 0xFFFFF800u) | 0x400u;
+    const uint32_t rc = (w[0] << 21) | ((w[1] & 0x7FEu) << 10) | 0x400u, ac = (w[2] << 21) | ((w[3] & 0x7FEu) << 10) | 0x400u;
+    ro_box_muller(r1, a1, &out[0], &out[1]);
+    ro_box_muller(rc, ac, &c, &s);
+    out[2] = odd ? s : c;
+    return;
+  }
+  if (d == 2 || d == 6) {
+    uint32_t ww[12];
+    for (int b = 0; b < d / 2; ++b) ro_noise_words(seed, stream, pe, (uint32_t)b, ww + 4 * b);
+    for (int k = 0; k < d; k += 2) ro_box_muller(ww[odd * d + k], ww[odd * d + k + 1], &out[k], &out[k + 1]);
     return;
   }
   int ncall = (d + 3) / 4;

@@ -144,7 +144,9 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
   for (int r = 0; r < 10; ++r) {
     // one v_mad_u64_u32 per product (218 vs 319 SIMD-cycles per call for the mul_hi/mul_lo pair form)
     const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
-    c = u32x4{(uint32_t)(p1 >> 32) ^ c.y ^ k0, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k1, (uint32_t)p0};
+    // (three-input xor: one v_bitop3_b32 on gfx950 instead of two v_xor_b32)
+    c = u32x4{(uint32_t)__builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c.y, k0, 0x96), (uint32_t)p1,
+              (uint32_t)__builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c.w, k1, 0x96), (uint32_t)p0};
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   return c;
@@ -200,51 +202,78 @@ __device__ __forceinline__ u32x4 noise_words(uint64_t seed, uint64_t stream, uin
                        (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
-// D standard normals for (seed, stream, particle): Box-Muller on Philox words, two pairs per Philox call.
-// D == 3 (Pose2 measurements) would discard one normal of its second pair; instead the NEIGHBOURING particles 2j and 2j + 1 -- the two
-// particles one thread owns in the convolution kernels (adjacent in the SoA belief rows: one 16-byte load per coordinate) -- SHARE
-// that pair: normals 0, 1 come from words (x, y) of the particle's own call, normal 2 from words (z, w) of the call of the EVEN
-// particle p & ~1, its cosine branch for the even particle, its sine branch for the odd one.  The two branches of a Box-Muller pair
-// are independent N(0,1), the rule depends on the particle id only (not on N or the launch shape), and a thread then evaluates
-// three pairs for its two particles instead of four (rng_normals3_pair).  Oracle: ro_rng_normals.
+// D standard normals for (seed, stream, particle): Box-Muller on Philox words.  NEIGHBOURING particles 2j and 2j + 1 -- the two
+// particles one thread owns in the convolution kernels (adjacent in every SoA belief row: one 16-byte access per coordinate) --
+// draw from the SAME Philox calls, made with the EVEN particle id as counter (the rule depends on the particle id only, not on N or
+// the launch shape).  Oracle: ro_rng_normals.
+//   D = 2, 6 (bearing-range, Pose3):  the 4·(D/2) words of calls b = 0 .. D/2 - 1 in order; the even particle takes words [0, D), the
+//                                     odd one words [D, 2D); consecutive word pairs (radius word, angle word) -> one Box-Muller pair
+//   D = 3 (Pose2 measurements):       ONE call for the six normals of the two particles: its 128 bits are cut into six 21-bit fields
+//        field 0 / 1 = top 21 bits of x / y   -> pair A -> normals 0, 1 of the even particle
+//        field 2 / 3 = top 21 bits of z / w   -> pair B -> normals 0, 1 of the odd particle
+//        field 4     = low 11 bits of x, then bits 10..1 of y ; field 5 = the same of z, w
+//                                              -> pair C -> normal 2 of the even particle (first output) and of the odd one (second)
+//        a field f enters box_muller as the word (f << 11) | 0x400, i.e. the centre of its bin: the radius is
+//        sqrt(-2 ln((f + 0.5) / 2^21)) <= 5.52, the angle has 19 bits below the two quadrant bits.  The draws differ from N(0,1)
+//        by < 2e-6 in Kolmogorov distance (tests/test_host_logic.py); a Pose2 convolution of N = 100 particles costs 50 Philox calls.
 template <int D>
-__device__ __forceinline__ void rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, double (&out)[D]) {
+__device__ __forceinline__ void normals3_fields(const u32x4& w, uint32_t (&r)[3], uint32_t (&a)[3]) {
+  r[0] = (w.x & 0xFFFFF800u) | 0x400u; a[0] = (w.y & 0xFFFFF800u) | 0x400u;
+  r[1] = (w.z & 0xFFFFF800u) | 0x400u; a[1] = (w.w & 0xFFFFF800u) | 0x400u;
+  r[2] = (w.x << 21) | ((w.y & 0x7FEu) << 10) | 0x400u;
+  a[2] = (w.z << 21) | ((w.w & 0x7FEu) << 10) | 0x400u;
+}
+// the normals of particles p_even (even) and p_even + 1 together
+template <int D>
+__device__ __forceinline__ void rng_normals_pair(uint64_t seed, uint64_t stream, uint32_t p_even, double (&oe)[D], double (&oo)[D]) {
+  static_assert(D == 2 || D == 3 || D == 6, "measurement dimensions of the supported factors");
   if constexpr (D == 3) {
-    const u32x4 w = noise_words(seed, stream, particle, 0u);
-    box_muller(w.x, w.y, &out[0], &out[1]);
-    double c, s;
-    if (particle & 1u) {
-      const u32x4 wb = noise_words(seed, stream, particle & ~1u, 0u);
-      box_muller(wb.z, wb.w, &c, &s);
-      out[2] = s;
-    } else {
-      box_muller(w.z, w.w, &c, &s);
-      out[2] = c;
-    }
+    const u32x4 w = noise_words(seed, stream, p_even, 0u);
+    uint32_t r[3], a[3];
+    normals3_fields<3>(w, r, a);
+    box_muller(r[0], a[0], &oe[0], &oe[1]);
+    box_muller(r[1], a[1], &oo[0], &oo[1]);
+    box_muller(r[2], a[2], &oe[2], &oo[2]);
   } else {
-    constexpr int NC = (D + 3) / 4;
+    uint32_t ww[2 * D];
 #pragma unroll
-    for (int b = 0; b < NC; ++b) {
-      const u32x4 w = noise_words(seed, stream, particle, (uint32_t)b);
-      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    for (int b = 0; b < D / 2; ++b) {
+      const u32x4 w = noise_words(seed, stream, p_even, (uint32_t)b);
+      ww[4 * b] = w.x; ww[4 * b + 1] = w.y; ww[4 * b + 2] = w.z; ww[4 * b + 3] = w.w;
+    }
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        if (4 * b + 2 * p < D) {
-          double n0, n1;
-          box_muller(ww[2 * p], ww[2 * p + 1], &n0, &n1);
-          out[4 * b + 2 * p] = n0;
-          if (4 * b + 2 * p + 1 < D) out[4 * b + 2 * p + 1] = n1;
-        }
-      }
+    for (int k = 0; k < D; k += 2) {
+      box_muller(ww[k], ww[k + 1], &oe[k], &oe[k + 1]);
+      box_muller(ww[D + k], ww[D + k + 1], &oo[k], &oo[k + 1]);
     }
   }
 }
-// the D == 3 normals of particles p_even (even) and p_even + 1 together: two Philox calls, three Box-Muller pairs
-__device__ __forceinline__ void rng_normals3_pair(uint64_t seed, uint64_t stream, uint32_t p_even, double (&oe)[3], double (&oo)[3]) {
-  const u32x4 we = noise_words(seed, stream, p_even, 0u), wo = noise_words(seed, stream, p_even + 1u, 0u);
-  box_muller(we.x, we.y, &oe[0], &oe[1]);
-  box_muller(wo.x, wo.y, &oo[0], &oo[1]);
-  box_muller(we.z, we.w, &oe[2], &oo[2]);
+// one particle on its own (prior sampling, one-particle-per-lane launches): only the calls / pairs it needs
+template <int D>
+__device__ __forceinline__ void rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, double (&out)[D]) {
+  static_assert(D == 2 || D == 3 || D == 6, "measurement dimensions of the supported factors");
+  const uint32_t pe = particle & ~1u;
+  const bool odd = (particle & 1u) != 0u;
+  if constexpr (D == 3) {
+    const u32x4 w = noise_words(seed, stream, pe, 0u);
+    uint32_t r[3], a[3];
+    normals3_fields<3>(w, r, a);
+    box_muller(odd ? r[1] : r[0], odd ? a[1] : a[0], &out[0], &out[1]);
+    double c, s;
+    box_muller(r[2], a[2], &c, &s);
+    out[2] = odd ? s : c;
+  } else if constexpr (D == 2) {
+    const u32x4 w = noise_words(seed, stream, pe, 0u);
+    box_muller(odd ? w.z : w.x, odd ? w.w : w.y, &out[0], &out[1]);
+  } else {   // D == 6: even -> call 0 (x,y | z,w) + call 1 (x,y); odd -> call 1 (z,w) + call 2 (x,y | z,w)
+    const u32x4 w1 = noise_words(seed, stream, pe, 1u);
+    const u32x4 w02 = noise_words(seed, stream, pe, odd ? 2u : 0u);
+    if (odd) {
+      box_muller(w1.z, w1.w, &out[0], &out[1]); box_muller(w02.x, w02.y, &out[2], &out[3]); box_muller(w02.z, w02.w, &out[4], &out[5]);
+    } else {
+      box_muller(w02.x, w02.y, &out[0], &out[1]); box_muller(w02.z, w02.w, &out[2], &out[3]); box_muller(w1.x, w1.y, &out[4], &out[5]);
+    }
+  }
 }
 
 // The entropy uniforms as the oracle defines them (ro_rng_entropy): one Philox call per particle and cycle (two for D = 6), one

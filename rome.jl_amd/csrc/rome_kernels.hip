@@ -148,13 +148,14 @@ struct P2P2 {
   __device__ static __forceinline__ Prep prepare(const Consts& K, const double (&z)[3], const double (&fxc)[3]) {
     const bool pr = K.dir == kDirPrior, back = K.dir == 1;
     const double f0 = pr ? 0.0 : fxc[0], f1 = pr ? 0.0 : fxc[1], f2 = pr ? 0.0 : fxc[2];
-    const double thr = back ? f2 - z[2] : f2;
+    const double sg = back ? -1.0 : 1.0;          // a = f ± (...) as one fma with an exact ±1 factor: the rounding of the sum / difference
+    Prep P;
+    P.a2 = __builtin_fma(sg, z[2], f2);
+    const double thr = back ? P.a2 : f2;
     double s, c; fast_sincos(thr, &s, &c);
     const double vx = __builtin_fma(c, z[0], -(s * z[1])), vy = __builtin_fma(s, z[0], c * z[1]);
-    Prep P;
-    P.a0 = back ? f0 - vx : f0 + vx;
-    P.a1 = back ? f1 - vy : f1 + vy;
-    P.a2 = back ? thr : f2 + z[2];
+    P.a0 = __builtin_fma(sg, vx, f0);
+    P.a1 = __builtin_fma(sg, vy, f1);
     return P;
   }
   // the residual FUNCTOR itself (src/factors/Pose2D.jl:51-67 / PriorPose2.jl:37-47, through points) at the target point t
@@ -618,16 +619,12 @@ __device__ __forceinline__ int slot_particle(int lane, int k) {
   if constexpr (PPL == 1) return lane;
   else return ((k >> 1) << 7) + 2 * lane + (k & 1);
 }
-// D == 3 normals with ONE particle per lane (N <= 64): the odd lane takes words (z, w) of its even neighbour's call by DPP
-// (quad_perm [0,0,2,2]) instead of repeating that Philox call
-__device__ __forceinline__ void rng_normals3_lane(uint64_t seed, uint64_t stream, uint32_t particle, double (&out)[3]) {
-  const u32x4 w = noise_words(seed, stream, particle, 0u);
-  box_muller(w.x, w.y, &out[0], &out[1]);
-  const uint32_t wz = (uint32_t)__builtin_amdgcn_mov_dpp((int)w.z, 0xA0, 0xF, 0xF, true);
-  const uint32_t ww = (uint32_t)__builtin_amdgcn_mov_dpp((int)w.w, 0xA0, 0xF, 0xF, true);
-  double c, s;
-  box_muller(wz, ww, &c, &s);
-  out[2] = (particle & 1u) ? s : c;
+// streaming (non-temporal) stores for data the launch does not read again
+__device__ __forceinline__ void store_stream(double* p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void store_stream2(double* p, const double2& v) {
+  typedef double dvec2 __attribute__((ext_vector_type(2)));
+  const dvec2 vv = {v.x, v.y};
+  __builtin_nontemporal_store(vv, reinterpret_cast<dvec2*>(p));
 }
 
 // separator rows are duplicated into the exchange buffer: block m of mirror_out for row c with mirror_map[c] = m >= 0
@@ -675,7 +672,7 @@ k_conv(const ConvArgs a) {
   typename FP::Prep prep[PPL];
   typename FP::Aux aux[PPL];   // state a policy keeps beside the coordinates (Pose3: the rotation as a unit quaternion)
   bool act[PPL];
-  [[maybe_unused]] double xi_odd[3];   // normals of the odd slot, produced together with the even slot's (shared Box-Muller pair)
+  [[maybe_unused]] double xi_odd[FP::DZ];   // normals of the odd slot, produced together with the even slot's (shared Philox calls)
   // measurement samples first (they depend on nothing but the convolution id), then the belief loads: the loaded particles
   // are then not live across the Philox / Box-Muller block (fewer registers at the kernel's pressure peak)
 #pragma unroll
@@ -688,12 +685,13 @@ k_conv(const ConvArgs a) {
       const double* nb = a.noise + (size_t)c * FP::DZ * N;
 #pragma unroll
       for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
-    } else if constexpr (FP::DZ == 3 && PPL >= 2) {
-      // slots k (even) and k+1 of a lane are the neighbours 2j, 2j+1: they share the third Box-Muller pair (rng_normals)
-      if ((k & 1) == 0) rng_normals3_pair(a.seed, stream, (uint32_t)i, xi, xi_odd);
-      else { xi[0] = xi_odd[0]; xi[1] = xi_odd[1]; xi[2] = xi_odd[2]; }
-    } else if constexpr (FP::DZ == 3) {
-      rng_normals3_lane(a.seed, stream, (uint32_t)i, xi);   // (every lane takes part in the DPP exchange: i, not ii)
+    } else if constexpr (PPL >= 2) {
+      // slots k (even) and k+1 of a lane are the neighbours 2j, 2j+1: they draw from the same Philox calls (rng_normals_pair)
+      if ((k & 1) == 0) rng_normals_pair<FP::DZ>(a.seed, stream, (uint32_t)i, xi, xi_odd);
+      else {
+#pragma unroll
+        for (int d = 0; d < FP::DZ; ++d) xi[d] = xi_odd[d];
+      }
     } else {
       rng_normals<FP::DZ>(a.seed, stream, (uint32_t)ii, xi);
     }
@@ -865,11 +863,11 @@ k_conv(const ConvArgs a) {
     if (act[k] && valid) {
       FP::finalize(t[k], aux[k]);
 #pragma unroll
-      for (int d = 0; d < FP::DT; ++d) ob[d * N + i] = t[k][d];
+      for (int d = 0; d < FP::DT; ++d) store_stream(ob + d * N + i, t[k][d]);   // (not read again by this launch: written through)
       if (a.status) a.status[(size_t)c * N + i] = st[k];
       if (mb) {
 #pragma unroll
-        for (int d = 0; d < FP::DT; ++d) mb[d * N + i] = t[k][d];
+        for (int d = 0; d < FP::DT; ++d) store_stream(mb + d * N + i, t[k][d]);
       }
     }
   }
@@ -893,23 +891,20 @@ constexpr int kFlatThreads = 256;
 constexpr int kFlatMaxRows = 16;    // rows per block (staging: 16 threads per row)
 template <class FP> struct FlatStage { static constexpr int kLanes = FP::NK <= 16 ? 16 : 32; };
 
+#ifndef ROME_FLAT_MINWAVES
+#define ROME_FLAT_MINWAVES 8   // Pose2 / Point2 sweeps: 8 waves per SIMD (<= 64 VGPRs)
+#endif
 template <class FP, bool VERIFY, bool VEC2>
-__global__ void __launch_bounds__(kFlatThreads) k_conv_flat(const ConvArgs a, int H, int CPB, uint32_t magic) {
+__global__ void __launch_bounds__(kFlatThreads, (FP::DT <= 3 && !VERIFY) ? ROME_FLAT_MINWAVES : 1) k_conv_flat(const ConvArgs a, int H, int CPB, uint32_t magic) {
   constexpr int SL = FlatStage<FP>::kLanes;
   __shared__ double s_K[kFlatMaxRows][SL + 2];   // (+2: rows of a wave's two convolutions start in different banks)
   const int tid = threadIdx.x;
+#ifdef ROME_FLAT_TRACE   // experiment build (scripts/flat_trace.py): per-block timestamps instead of the status array
+  const uint64_t trace_t0 = wall_clock64();
+#endif
   const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int c0 = blk * CPB;
   const int N = a.N;
-  // ---- stage the per-factor constants of the block's rows: thread (row lr, entry q) loads one double
-  {
-    const int lr = tid / SL, q = tid % SL;
-    if (lr < CPB && q < FP::NK) {
-      const int cr = min(c0 + lr, a.n_conv - 1);
-      const int f = a.rows4[4 * (size_t)cr];
-      s_K[lr][q] = q < FP::DZ ? a.mu[(size_t)FP::DZ * f + q] : a.L[(size_t)FP::NL * f + (q - FP::DZ)];
-    }
-  }
   // ---- this thread's (row, pair)
   const int lc_raw = (int)(((uint32_t)tid * magic) >> 16);   // tid / H
   const int j = tid - lc_raw * H;
@@ -920,6 +915,17 @@ __global__ void __launch_bounds__(kFlatThreads) k_conv_flat(const ConvArgs a, in
   const int dr = (FP::kHypoDir < 0 || FP::kHypoDir == 2) ? row.y : a.dir_all;
   const int i0 = 2 * j;                       // particles i0, i0 + 1
   const bool act1 = i0 + 1 < N;               // (odd N: the last pair is a single particle)
+  // ---- per-factor constants -> LDS: the first threads of every row load one entry each of THEIR OWN row's factor (the factor
+  //      index arrives with the row they need anyway: the load is issued beside the belief loads, nothing waits for it here;
+  //      branch-free: every thread loads SOME valid entry, only the first NK of a row publish theirs)
+  constexpr int KP = (FP::NK + 7) / 8;   // passes (H >= 8 pair-threads per row)
+  double kst[KP];
+#pragma unroll
+  for (int e = 0; e < KP; ++e) {
+    const int q = min(j + e * H, FP::NK - 1);
+    const double* src = q < FP::DZ ? a.mu + (size_t)FP::DZ * row.x + q : a.L + (size_t)FP::NL * row.x + (q - FP::DZ);
+    kst[e] = *src;
+  }
   const double* __restrict__ fb = a.bel_fixed + (size_t)row.z * FP::DF * N;
   double fx[2][FP::DF];
   if (VEC2) {
@@ -932,11 +938,20 @@ __global__ void __launch_bounds__(kFlatThreads) k_conv_flat(const ConvArgs a, in
 #pragma unroll
     for (int d = 0; d < FP::DF; ++d) { fx[0][d] = fb[(size_t)d * N + i0]; fx[1][d] = fb[(size_t)d * N + (act1 ? i0 + 1 : i0)]; }
   }
-  // ---- measurement noise (depends on the row id only: runs under the load latency)
+  // ---- measurement noise (depends on the row id only).  The two compiler fences keep the order {loads issued} -> {Philox /
+  //      Box-Muller} -> {first use of a loaded value}, so that the generator runs under the load latency (left alone, the
+  //      compiler sinks the generator below the LDS write and its s_waitcnt vmcnt(0))
+  asm volatile("" ::: "memory");
   const uint64_t stream = a.stream_offset + (uint64_t)c;
   double xi[2][FP::DZ];
-  if constexpr (FP::DZ == 3) rng_normals3_pair(a.seed, stream, (uint32_t)i0, xi[0], xi[1]);
-  else { rng_normals<FP::DZ>(a.seed, stream, (uint32_t)i0, xi[0]); rng_normals<FP::DZ>(a.seed, stream, (uint32_t)(i0 + 1), xi[1]); }
+  rng_normals_pair<FP::DZ>(a.seed, stream, (uint32_t)i0, xi[0], xi[1]);
+#pragma unroll
+  for (int d = 0; d < FP::DZ; ++d) asm volatile("" : "+v"(xi[0][d]), "+v"(xi[1][d]) :: "memory");
+#pragma unroll
+  for (int e = 0; e < KP; ++e) {
+    const int q = j + e * H;
+    if (lc_raw < CPB && q < FP::NK) s_K[lc][q] = kst[e];
+  }
   __syncthreads();
   const typename FP::Consts K = FP::from_lds(&s_K[lc][0], dr);
   double t[2][FP::DT];
@@ -951,6 +966,9 @@ __global__ void __launch_bounds__(kFlatThreads) k_conv_flat(const ConvArgs a, in
     if constexpr (VERIFY) st[k] = FP::verify(K, z, fx[k], t[k], A, a.tol);   // NEWTON with a status array: the functor at the root
     FP::finalize(t[k], A);
   }
+#ifdef ROME_FLAT_TRACE
+  const uint64_t trace_t1 = wall_clock64();
+#endif
   if (!live) return;
   double* __restrict__ ob = a.out + (size_t)c * FP::DT * N;
   const int mslot = (a.n_mirror > 0 || a.mirror_map) ? mirror_slot(a, c) : -1;
@@ -959,17 +977,27 @@ __global__ void __launch_bounds__(kFlatThreads) k_conv_flat(const ConvArgs a, in
 #pragma unroll
     for (int d = 0; d < FP::DT; ++d) {
       const double2 v = {t[0][d], t[1][d]};
-      *reinterpret_cast<double2*>(ob + (size_t)d * N + i0) = v;
-      if (mb) *reinterpret_cast<double2*>(mb + (size_t)d * N + i0) = v;
+      // streaming stores: the proposals are not read again by this launch; written through, they are not left dirty in the L2
+      // for the end-of-kernel write-back (measured: 9.1 -> 7.8 µs per Manhattan sweep)
+      store_stream2(ob + (size_t)d * N + i0, v);
+      if (mb) store_stream2(mb + (size_t)d * N + i0, v);
     }
   } else {
 #pragma unroll
     for (int d = 0; d < FP::DT; ++d) {
-      ob[(size_t)d * N + i0] = t[0][d]; if (act1) ob[(size_t)d * N + i0 + 1] = t[1][d];
-      if (mb) { mb[(size_t)d * N + i0] = t[0][d]; if (act1) mb[(size_t)d * N + i0 + 1] = t[1][d]; }
+      store_stream(ob + (size_t)d * N + i0, t[0][d]); if (act1) store_stream(ob + (size_t)d * N + i0 + 1, t[1][d]);
+      if (mb) { store_stream(mb + (size_t)d * N + i0, t[0][d]); if (act1) store_stream(mb + (size_t)d * N + i0 + 1, t[1][d]); }
     }
   }
+#ifdef ROME_FLAT_TRACE
+  if (a.status && tid == 0) {
+    uint64_t* tr = reinterpret_cast<uint64_t*>(a.status) + 4 * (size_t)blockIdx.x;
+    tr[0] = trace_t0; tr[1] = trace_t1; tr[2] = wall_clock64();
+    tr[3] = (uint64_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);   // HW_ID, XCC_ID
+  }
+#else
   if (a.status) { a.status[(size_t)c * N + i0] = st[0]; if (act1) a.status[(size_t)c * N + i0 + 1] = st[1]; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1039,7 +1067,7 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
       double fx[PPL][FP::DF], t[PPL][FP::DT], z[PPL][FP::DZ];
       typename FP::Aux aux[PPL];
       bool act[PPL];
-      [[maybe_unused]] double xi_odd[3];
+      [[maybe_unused]] double xi_odd[FP::DZ];
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
         const int i = base + 2 * lane + k;
@@ -1054,10 +1082,13 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
           const double* nb = a.noise + (size_t)c * FP::DZ * N;
 #pragma unroll
           for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
-        } else if constexpr (FP::DZ == 3) {   // the neighbours 2j, 2j+1 share the third Box-Muller pair (rng_normals)
-          if ((k & 1) == 0) rng_normals3_pair(a.seed, stream, (uint32_t)i, xi, xi_odd);
-          else { xi[0] = xi_odd[0]; xi[1] = xi_odd[1]; xi[2] = xi_odd[2]; }
-        } else rng_normals<FP::DZ>(a.seed, stream, (uint32_t)ii, xi);
+        } else {   // the neighbours 2j, 2j+1 draw from the same Philox calls (rng_normals_pair)
+          if ((k & 1) == 0) rng_normals_pair<FP::DZ>(a.seed, stream, (uint32_t)i, xi, xi_odd);
+          else {
+#pragma unroll
+            for (int d = 0; d < FP::DZ; ++d) xi[d] = xi_odd[d];
+          }
+        }
         if (a.noise && a.noise_is_meas) {
 #pragma unroll
           for (int d = 0; d < FP::DZ; ++d) z[k][d] = xi[d];

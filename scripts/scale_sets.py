@@ -26,7 +26,7 @@ for F in SIZES:
         for _ in range(reps): plan()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        alg = tb["C_rel"] * 100 * 72 + tb["P"] * 100 * 24
+        alg = tb["C_rel"] * 100 * 48 + tb["P"] * 100 * 24   # closed form / Newton: fixed 24 + proposal 24 bytes per particle (u0 not read)
         print("F=%8d poses=%8d convs=%8d %-11s %9.3f ms/sweep  %.3e conv/s  %7.1f GB/s algorithmic  (store %.1f MB, proposals %.1f MB)"
               % (F, bel.shape[0], tb["C"], name, ms, tb["C"] / ms * 1e3, alg / ms / 1e6, bel.nbytes / 1e6, out.numel() * 8 / 1e6))
     del dg

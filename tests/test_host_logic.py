@@ -230,26 +230,45 @@ def _bm_exact(wa, wb):
 
 
 def test_normal_generator_definition():
-    # normals, d = 3: 0, 1 from the particle's own call; 2 = first / second output of the second Box-Muller pair of the call made
-    # for the even particle p & ~1 (Philox domain 1): neighbouring particles 2j, 2j+1 share that pair
+    """Neighbouring particles 2j, 2j+1 draw from the SAME Philox calls (counter = the even particle id, domain 1)."""
+    f21 = lambda f: (f << 11) | 0x400                                    # a 21-bit field enters box_muller as the centre of its bin
+    w = ro.philox([4, 3, 0, (1 << 16) | 0], [7, 0])
+    # d = 3: ONE call per pair, six 21-bit fields
     a, b = ro.rng_normals(7, 3, 4, 3), ro.rng_normals(7, 3, 5, 3)
-    w5 = ro.philox([4, 3, 0, (1 << 16) | 0], [7, 0]); w69 = ro.philox([5, 3, 0, (1 << 16) | 0], [7, 0])
-    assert np.array_equal(a[:2], ro.box_muller(w5[0], w5[1])) and np.array_equal(b[:2], ro.box_muller(w69[0], w69[1]))
-    sh = ro.box_muller(w5[2], w5[3])
+    top = [x >> 11 for x in w]
+    f4 = ((w[0] & 0x7FF) << 10) | ((w[1] & 0x7FE) >> 1); f5 = ((w[2] & 0x7FF) << 10) | ((w[3] & 0x7FE) >> 1)
+    assert np.array_equal(a[:2], ro.box_muller(f21(top[0]), f21(top[1]))) and np.array_equal(b[:2], ro.box_muller(f21(top[2]), f21(top[3])))
+    sh = ro.box_muller(f21(f4), f21(f5))
     assert a[2] == sh[0] and b[2] == sh[1] and not np.allclose(a[:2], b[:2])
-    e0, e1 = _bm_exact([w5[2]], [w5[3]])
+    e0, e1 = _bm_exact([f21(f4)], [f21(f5)])
     assert abs(sh[0] - e0[0]) < 1e-4 and abs(sh[1] - e1[0]) < 1e-4
-    # d = 2 / 6: pairs in call order
-    n6 = ro.rng_normals(7, 3, 4, 6); w5b = ro.philox([4, 3, 0, (1 << 16) | 1], [7, 0])
-    assert np.array_equal(n6, list(ro.box_muller(w5[0], w5[1])) + list(ro.box_muller(w5[2], w5[3])) + list(ro.box_muller(w5b[0], w5b[1])))
-    # edge words: the largest radius (6.66 sigma), the zero radius, the four mirror quadrants
+    # d = 2: the even particle takes words (0, 1) of the call, the odd one words (2, 3)
+    assert np.array_equal(ro.rng_normals(7, 3, 4, 2), ro.box_muller(w[0], w[1])) and np.array_equal(ro.rng_normals(7, 3, 5, 2), ro.box_muller(w[2], w[3]))
+    # d = 6: three calls per pair; even = words 0..5, odd = words 6..11
+    w1 = ro.philox([4, 3, 0, (1 << 16) | 1], [7, 0]); w2 = ro.philox([4, 3, 0, (1 << 16) | 2], [7, 0])
+    assert np.array_equal(ro.rng_normals(7, 3, 4, 6), list(ro.box_muller(w[0], w[1])) + list(ro.box_muller(w[2], w[3])) + list(ro.box_muller(w1[0], w1[1])))
+    assert np.array_equal(ro.rng_normals(7, 3, 5, 6), list(ro.box_muller(w1[2], w1[3])) + list(ro.box_muller(w2[0], w2[1])) + list(ro.box_muller(w2[2], w2[3])))
+    # edge words: the largest radius (6.66 sigma; 5.52 for a 21-bit field), the zero radius, the four mirror quadrants
     big = ro.box_muller(0, 0x20000000)
     assert abs(np.hypot(*big) - np.sqrt(2 * 32 * np.log(2))) < 1e-5 and ro.box_muller(0xFFFFFFFF, 123) == (0.0, 0.0)
+    assert abs(np.hypot(*ro.box_muller(f21(0), 0x20000000)) - np.sqrt(2 * 22 * np.log(2))) < 1e-3
     sg = [tuple(np.sign(ro.box_muller(12345, q << 30 | 0x1234567))) for q in range(4)]
     assert sg == [(1, 1), (1, -1), (-1, 1), (-1, -1)]
-    n3 = np.array([ro.rng_normals(11, 2, i, 3) for i in range(2048)])
-    assert np.abs(n3.mean(0)).max() < 0.08 and np.abs(n3.std(0) - 1).max() < 0.06
-    assert abs(np.corrcoef(n3[0::2, 2], n3[1::2, 2])[0, 1]) < 0.1                # the two outputs of a shared pair are uncorrelated
+    for d in (2, 3, 6):
+        nd = np.array([ro.rng_normals(11, 2, i, d) for i in range(4096)])
+        assert np.abs(nd.mean(0)).max() < 0.06 and np.abs(nd.std(0) - 1).max() < 0.05
+        cc = np.corrcoef(np.concatenate([nd[0::2], nd[1::2]], 1).T)                # the 2d draws of a pair of particles are uncorrelated
+        assert np.abs(cc - np.eye(2 * d)).max() < 0.08
+
+
+def test_normal_generator_law_21bit_fields():
+    """Pose2 measurement normals (21-bit radius and angle fields): Kolmogorov distance to N(0,1) below 2e-6 by construction (the bins
+    of the radius and angle are 2^-21 / 2^-19 wide); checked here on 6e5 draws against N(0,1) (KS) with exact moments."""
+    from scipy import stats
+    n3 = np.array([ro.rng_normals(5, s, i, 3) for s in range(100) for i in range(2000)])
+    assert stats.kstest(n3.ravel(), "norm").pvalue > 1e-3
+    assert np.abs(n3.mean(0)).max() < 0.01 and np.abs(n3.std(0) - 1).max() < 0.01
+    assert abs(stats.kurtosis(n3.ravel())) < 0.03 and np.abs(n3).max() < 5.6
 
 
 def test_normal_generator_law():
