@@ -211,29 +211,40 @@ def main():
     #  add their own dispatch gaps to the period they measure)
     stride = max(1, args.steps // 20) if args.steps >= 200 else args.steps
     marks = list(range(0, args.steps, stride))
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(marks) + 1)]
-    barrier()
-    t0 = time.perf_counter()
-    j = 0
-    for k in range(args.steps):
-        if j < len(marks) and k == marks[j]:
-            ev[j].record(); j += 1
-        sweep()
-    ev[len(marks)].record()
-    if strong:
-        pipe.wait()
-    elif multi:
-        pipe.drain()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    # N>1: even and odd steps run on two side streams (PipelinedSegmentSweep), which events on the caller's stream do not
-    # bracket: the launch period is then this rank's wall-clock between the barriers
-    kern_ms = 1e3 * (t1 - t0) / args.steps if multi else float(ev[0].elapsed_time(ev[len(marks)])) / args.steps
+
+    def timed_block():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides -> (wall seconds, max over ranks; event ms per step)"""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(marks) + 1)]
+        barrier()
+        t0 = time.perf_counter()
+        j = 0
+        for k in range(args.steps):
+            if j < len(marks) and k == marks[j]:
+                ev[j].record(); j += 1
+            sweep()
+        ev[len(marks)].record()
+        if strong:
+            pipe.wait()
+        elif multi:
+            pipe.drain()
+        barrier()
+        t1 = time.perf_counter()
+        el = t1 - t0
+        if multi:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        # N>1: even and odd steps run on side streams, which events on the caller's stream do not bracket: the launch period is
+        # then this rank's wall-clock between the barriers
+        km = 1e3 * (t1 - t0) / args.steps if multi else float(ev[0].elapsed_time(ev[len(marks)])) / args.steps
+        return el, km
+
+    # short runs (the driver's --steps 20: a 0.2 ms region in which the two barriers weigh 10 %): the block of K steps is repeated
+    # and the MEDIAN block is reported (every block is exactly K steps between barriers; all block times are listed)
+    n_blocks = 1 if args.steps >= 1000 else (5 if args.steps >= 100 else 9)
+    blocks = [timed_block() for _ in range(n_blocks)]
+    order = sorted(range(n_blocks), key=lambda i: blocks[i][0])
+    elapsed, kern_ms = blocks[order[n_blocks // 2]]
 
     data_kind = "synthetic" if (not args.g2o or args.g2o == "synthetic") else \
         "Manhattan M3500 dataset (measurements); beliefs synthetic: dead-reckoned means + N(0, sigma) particles"
@@ -247,7 +258,8 @@ def main():
     out = {
         "metric": "factor convolutions/sec (N=100) on Manhattan-3500; solveTree! wall-clock",
         "value": value, "unit": "convolutions/s", "n_gpus": (dist.get_world_size() if multi else 1), "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "timed_blocks_ms_per_step": [1e3 * b[0] / args.steps for b in blocks],
+        "timed_block": "median of %d blocks of exactly %d steps, each between barrier + synchronize" % (n_blocks, args.steps), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f64", "data": data_kind,
         "config": {"workload": workload, "poses_per_gpu": len(pk.labels[R.Pose2]), "pose2pose2_factors_per_gpu": tb["F"],
                    "convolutions_per_step_per_gpu": (pipe.n_rows if strong else n_conv_step), "particles": N, "solver": args.solver,
@@ -257,45 +269,51 @@ def main():
                                   (("1 graph segment per GPU, separator all_gather (%s, pipeline depth %d)" % ("RCCL direct" if comms else "torch.distributed", depth))
                                    if multi else "single GPU"),
                    "ranks_seen_by_rccl": (dist.get_world_size() if multi else 1)},
-        "roofline": {"bound": "hbm", "kernel": "rome::k_conv<P2P2,%s,PPL=2,lean>" % args.solver,
+        "roofline": {"bound": "hbm", "kernel": ("rome::k_conv_flat<P2P2> (packed unique-root sweep)" if args.solver in ("newton", "closed_form")
+                                                else "rome::k_conv<P2P2,%s,PPL=2,lean>" % args.solver),
+                     "bytes_per_particle": BYTES_PER_PARTICLE_P2P2[args.solver],
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms, "traffic": None},
     }
-    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tfile):
+    # counter-measured HBM traffic of the same kernel on the same table (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    # scripts/profile_round.sh; PMC counters need rocprofv3 around the process, so this run quotes the stored pass)
+    tfile = os.path.join(ROOT, "profiles", "r03_hbm_traffic_%s.json" % args.solver)
+    if os.path.exists(tfile) and world == 1:
         try:
             with open(tfile) as f:
                 tj = json.load(f)
             if tj.get("solver") == args.solver and tj.get("n_conv") == tb["C"]:
                 out["roofline"]["traffic"] = tj.get("bytes_per_launch")
-                out["roofline"]["traffic_kind"] = "stored"   # PMC counters need rocprofv3 around the process: not measured in this run
+                out["roofline"]["traffic_kind"] = "stored"
                 out["roofline"]["traffic_source"] = tj.get("source")
+                # both fractions side by side: algorithmic bytes / period (frac) and counter-measured HBM bytes / period
+                out["roofline"]["hbm_measured"] = {"achieved": tj["bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, "unit": "GB/s",
+                                                   "frac": tj["bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                   "read_bytes": tj.get("read_bytes_per_launch"), "write_bytes": tj.get("write_bytes_per_launch")}
         except Exception:
             pass
 
-    sfile = os.path.join(ROOT, "profiles", "sq_counters.json")
-    if args.solver == "newton" and os.path.exists(sfile):
+    sfile = os.path.join(ROOT, "profiles", "r03_sq_counters_%s.json" % args.solver)
+    if os.path.exists(sfile) and world == 1:
         try:
             with open(sfile) as f:
                 sj = json.load(f)
-            # context for the low HBM fraction: the kernel is VALU-issue bound (SQ counters, separate rocprofv3 pass)
-            out["roofline"]["valu_busy_frac_pmc"] = sj["derived"]["valu_busy_fraction"]
             out["roofline"]["valu_instructions_per_wave_pmc"] = sj["derived"]["valu_instructions_per_wave"]
             # secondary bound: VALU issue.  Busy quad-cycles of the PMC pass (a property of the instruction stream, same
-            # kernel, same table) against the SIMD cycles available in THIS run's measured launch period at the measured 2.45 GHz clock (>= the 2.4 GHz of the guide).
-            if abs(sj.get("SQ_WAVES", 0) - tb["C"]) < 4 and world == 1:   # (the grid is rounded up to whole 4-wave blocks)
-                busy_cycles = 4.0 * sj["SQ_ACTIVE_INST_VALU_quadcycles"]
-                clk = max(2.4e9, 1e9 * float(sj["derived"].get("clock_GHz", 2.4)))   # guide: 2.4 GHz max; the PMC pass measured 2.45
-                avail = 256 * 4 * clk * kern_ms * 1e-3
-                out["roofline"]["secondary"] = {"bound": "valu_issue", "achieved": busy_cycles / (kern_ms * 1e-3) / 1e12,
-                                                "peak": 256 * 4 * clk / 1e12, "unit": "T SIMD-cycles/s", "frac": busy_cycles / avail,
-                                                "source": "SQ_ACTIVE_INST_VALU (profiles/sq_counters.json) / (256 CUs x 4 SIMDs x %.2f GHz x kernel time of this run)" % (clk / 1e9)}
+            # kernel, same table) against the SIMD cycles available in THIS run's measured launch period at 2.4 GHz
+            busy_cycles = 4.0 * sj["SQ_ACTIVE_INST_VALU_quadcycles"]
+            clk = 2.4e9
+            avail = 256 * 4 * clk * kern_ms * 1e-3
+            out["roofline"]["secondary"] = {"bound": "valu_issue", "achieved": busy_cycles / (kern_ms * 1e-3) / 1e12,
+                                            "peak": 256 * 4 * clk / 1e12, "unit": "T SIMD-cycles/s", "frac": busy_cycles / avail,
+                                            "source": "SQ_ACTIVE_INST_VALU (profiles/r03_sq_counters_%s.json) / (256 CUs x 4 SIMDs x 2.4 GHz x launch period of this run)" % args.solver}
         except Exception:
             pass
 
     if rank == 0 and world == 1 and not args.no_modes:
         modes = {}
-        for name, sv in (("closed_form", R.SOLVER_CLOSED_FORM), ("newton", R.SOLVER_NEWTON), ("nelder_mead", R.SOLVER_NELDER_MEAD)):
+        for name, sv in (("closed_form", R.SOLVER_CLOSED_FORM), ("newton", R.SOLVER_NEWTON), ("gauss_newton", R.SOLVER_GAUSS_NEWTON),
+                         ("nelder_mead", R.SOLVER_NELDER_MEAD)):
             o2 = R.make_opts(N=N, solver=sv, seed=0x524F4D45)
             reps = 20 if sv == R.SOLVER_NELDER_MEAD else 1000
             pl = dg.plan_sweep_pose2pose2(o2, prop)
@@ -361,8 +379,15 @@ def main():
         gpu = dict(out.get("gpu_convolutions_per_s_by_solver", {}))
         gpu[args.solver] = value
         # every GPU/CPU ratio is same-solver (the CPU side at its best thread count)
-        out["cpu_baseline"]["gpu_over_cpu_same_solver"] = {k: gpu[k] / out["cpu_baseline"]["by_solver"][k]["conv_per_s"]
-                                                           for k in gpu if k in out["cpu_baseline"]["by_solver"]}
+        # the oracle's Newton mode is the Gauss-Newton iteration on the residual functor: the CPU counterpart of BOTH device modes
+        # "newton" (same roots; the device returns them analytically) and "gauss_newton" (same algorithm)
+        cpu_of = {"closed_form": "closed_form", "newton": "newton", "gauss_newton": "newton", "nelder_mead": "nelder_mead"}
+        by = out["cpu_baseline"].get("by_solver") or {}
+        out["cpu_baseline"]["gpu_over_cpu_same_solver"] = {k: gpu[k] / by[cpu_of[k]]["conv_per_s"] for k in gpu if cpu_of[k] in by}
+        if cpu_of[args.solver] in by:   # the pair to read next to `value`: same solver on both sides
+            out["cpu_baseline"]["same_solver"] = cpu_of[args.solver]
+            out["cpu_baseline"]["same_solver_value"] = by[cpu_of[args.solver]]["conv_per_s"]
+            out["cpu_baseline"]["same_solver_cores"] = by[cpu_of[args.solver]].get("threads")
 
     # the JSON line must be the LAST thing on stdout: RCCL's version banner sits in the C stdio buffer of the ranks that
     # initialised a communicator and would otherwise be flushed at exit, after the line

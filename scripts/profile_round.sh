@@ -3,12 +3,12 @@
 # rocprofv3 evidence for profiles/: kernel traces of bench.py for the three solvers, HBM traffic (FETCH_SIZE / WRITE_SIZE in
 # separate --pmc passes + the copy8 calibration), SQ counters.  Raw rocprof output stays in /tmp; only summaries go to
 # gpurun_out/<tag>/ (copy what is to be judged into profiles/).
-tag=${1:-r02}
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$tag; T=/tmp/prof_$tag; mkdir -p $O $T
 cd /tmp && export TMPDIR=/tmp
 if [ -z "$SKIP_TRACES" ]; then
 # 1. kernel traces (same command as the bench line: defaults = 4000 settle+warm-up launches, 2000 timed)
-for s in newton closed_form nelder_mead; do
+for s in newton closed_form gauss_newton nelder_mead; do
   st=2000; wu=2000; [ $s = nelder_mead ] && st=20 && wu=10
   timeout 400 rocprofv3 --kernel-trace --stats -d $T/trace_$s -o $s -- python $R/bench.py --solver $s --steps $st --warmup $wu --no-cpu-baseline --no-modes > $T/trace_$s.log 2>&1
   db=$(find $T/trace_$s -name "*_results.db" | head -1)
@@ -20,12 +20,12 @@ fi
 [ -x $R/scripts/ubench/copy8 ] || hipcc --offload-arch=gfx950 -O3 -o $R/scripts/ubench/copy8 $R/scripts/ubench/copy8.hip
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --pmc $c --kernel-trace -d $T/cal_$c -o cal -- $R/scripts/ubench/copy8 > $T/cal_$c.log 2>&1
-  for s in newton closed_form; do
+  for s in newton closed_form gauss_newton; do
     timeout 300 rocprofv3 --pmc $c --kernel-trace -d $T/${s}_$c -o $s -- python $R/bench.py --solver $s --steps 20 --warmup 2 --no-cpu-baseline --no-modes > $T/${s}_$c.log 2>&1
   done
 done
 # 3. SQ counters
-for s in newton closed_form; do
+for s in newton closed_form gauss_newton; do
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-trace -d $T/sqa_$s -o a -- python $R/bench.py --solver $s --steps 10 --warmup 2 --no-cpu-baseline --no-modes > $T/sqa_$s.log 2>&1
   timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS --kernel-trace -d $T/sqb_$s -o b -- python $R/bench.py --solver $s --steps 10 --warmup 2 --no-cpu-baseline --no-modes > $T/sqb_$s.log 2>&1
 done
@@ -43,7 +43,8 @@ def counters(pattern, like):
     return out
 cal = {c: counters("%s/cal_%s/**/*_results.db" % (T, c), "copy")[c][0] for c in ("FETCH_SIZE", "WRITE_SIZE")}
 fetch_scale = 2.0 if cal["FETCH_SIZE"] < 0.75 * 2097152 else 1.0   # copy8 reads 2 GiB: gfx950 FETCH_SIZE reports half of it
-for s in ("newton", "closed_form"):
+ALG = {"newton": 10906 * 100 * 48 + 2400, "closed_form": 10906 * 100 * 48 + 2400, "gauss_newton": 10906 * 100 * 72 + 2400}   # bench.py BYTES_PER_PARTICLE_P2P2
+for s in ("newton", "closed_form", "gauss_newton"):
     f = counters("%s/%s_FETCH_SIZE/**/*_results.db" % (T, s), "k_conv"); w = counters("%s/%s_WRITE_SIZE/**/*_results.db" % (T, s), "k_conv")
     rd = f["FETCH_SIZE"][0] * 1024 * fetch_scale; wr = w["WRITE_SIZE"][0] * 1024
     json.dump({"source": "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), bench.py --solver %s --steps 20; "
@@ -51,7 +52,7 @@ for s in ("newton", "closed_form"):
                          % (s, fetch_scale, cal["FETCH_SIZE"], cal["WRITE_SIZE"]),
                "solver": s, "n_conv": 10907, "kernel": f["FETCH_SIZE"][2], "fetch_size_kb_raw": f["FETCH_SIZE"][0], "write_size_kb_raw": w["WRITE_SIZE"][0],
                "launches_averaged": f["FETCH_SIZE"][1], "bytes_per_launch": int(rd + wr), "read_bytes_per_launch": int(rd), "write_bytes_per_launch": int(wr),
-               "algorithmic_bytes_per_launch": 78525600}, open("%s/hbm_traffic_%s.json" % (O, s), "w"), indent=1)
+               "algorithmic_bytes_per_launch": ALG[s]}, open("%s/hbm_traffic_%s.json" % (O, s), "w"), indent=1)
     a = counters("%s/sqa_%s/**/*_results.db" % (T, s), "k_conv"); b = counters("%s/sqb_%s/**/*_results.db" % (T, s), "k_conv")
     dur = sum(a["_dur"]) / len(a["_dur"])
     waves = a["SQ_WAVES"][0]
