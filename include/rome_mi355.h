@@ -220,6 +220,47 @@ typedef struct rome_clique_host {
 int rome_clique_proposals(rome_ctx*, const rome_opts*, const rome_clique_host*);
 
 /* ---------------------------------------------------------------------------------------------
+ * Clique up-solve, device-resident: IIF `upGibbsCliqueDensity` (the loop behind every clique of `solveTree!`,
+ * examples/ManhattanDatasetBatch.jl:43, src/services/AdditionalUtils.jl:18-19):
+ *     gibbsIters x  for each variable to update (the clique's frontals, in order):
+ *                       proposalbeliefs! (one approxConvBelief per factor of the variable)  ->  manikde! of every proposal
+ *                       -> manifoldProduct -> setValKDE!
+ * in ONE call: beliefs and tables cross PCIe once, then gibbs_iters x {one convolution launch per factor family, manikde!
+ * bandwidths of the proposals, multiscale Gibbs product, write-back into the device belief store} run back to back on the
+ * context's stream; the new beliefs of the updated variables and their manikde! bandwidths come back at the end.
+ *   clique      beliefs of ALL variables of the clique (frontals + separators) and the family row tables, exactly as for
+ *               rome_clique_proposals (out_* are ignored and may be NULL).  Every row must TARGET an updated variable, and the rows
+ *               of each family must be grouped by target in the order of the update list (checked: ROME_ERR_INVALID_ARG).
+ *   up_type/up_var [n_up]   the variables to update, in Gibbs order: type 0 Pose2 / 1 Point2 / 2 Pose3, index into bel_<type>
+ *   schedule    ROME_UPSOLVE_SEQUENTIAL: IIF's order -- one variable at a time, each seeing the beliefs already updated in this
+ *               iteration; ROME_UPSOLVE_JACOBI: all updated variables from the beliefs of the previous iteration (fewer launches)
+ *   msg_<type>  optional upward messages of child cliques: n_msg_<type> extra densities of N points each ([.][dim][N], layout per
+ *               opts) on the updated variable at position msg_<type>_up[m] of the update list; they enter every product of
+ *               that variable beside the factor proposals (their manikde! bandwidths are computed once)
+ *   new_<type>  [number of updated variables of the type, in update order][dim][N] new beliefs (layout per opts)
+ *   bw_<type>   [same][dim] their manikde! bandwidths (what setValKDE! stores)
+ * Philox streams: convolution row r of a family in iteration i draws stream_offset + (i << 32) + family offset + r (the streams of
+ * the device graph's sweep i); the product of the k-th updated variable of a type draws + (3, 4, 6 << 28 for Pose2, Point2, Pose3) + k.
+ * N <= 128 (the multiscale Gibbs product). */
+enum { ROME_UPSOLVE_SEQUENTIAL = 0, ROME_UPSOLVE_JACOBI = 1 };
+typedef struct rome_clique_upsolve_host {
+  rome_clique_host clique;
+  int32_t gibbs_iters;    /* IIF gibbsIters, default 3 */
+  int32_t product_iters;  /* AMP manifoldProduct Niter, default 1 */
+  int32_t schedule;       /* ROME_UPSOLVE_* */
+  int32_t n_up;
+  const int32_t* up_type; const int32_t* up_var;
+  int32_t n_msg_pose2, n_msg_point2, n_msg_pose3, reserved0;
+  const double* msg_pose2; const int32_t* msg_pose2_up;
+  const double* msg_point2; const int32_t* msg_point2_up;
+  const double* msg_pose3; const int32_t* msg_pose3_up;
+  double* new_pose2; double* bw_pose2;
+  double* new_point2; double* bw_point2;
+  double* new_pose3; double* bw_pose3;
+} rome_clique_upsolve_host;
+int rome_clique_upsolve(rome_ctx*, const rome_opts*, const rome_clique_upsolve_host*);
+
+/* ---------------------------------------------------------------------------------------------
  * Graph-indexed DEVICE-pointer variant: beliefs stay resident in HBM (SoA blocks [var][dim][N]),
  * one launch sweeps a whole table of (factor, direction) convolutions.  This is what a clique /
  * whole-graph sweep of `solveTree!` (examples/ManhattanDatasetBatch.jl:43) issues.

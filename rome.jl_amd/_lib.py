@@ -94,6 +94,7 @@ SIGNATURES = {
     "rome_product_bw_dev": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rome_product_dev": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rome_clique_proposals": (C.c_int, [_CTX, _PO, C.c_void_p]),
+    "rome_clique_upsolve": (C.c_int, [_CTX, _PO, C.c_void_p]),
     "rome_product_gibbs_dev": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                          C.c_void_p, C.c_uint32, C.c_int32, C.c_int32]),
     "rome_dev_alloc": (C.c_int, [_CTX, C.c_uint64, C.POINTER(C.c_void_p)]),

@@ -90,12 +90,8 @@ class CliqueBatch:
                 out[k] = self.fg.getVal(l)
         return out
 
-    def run(self, opts, ctx=None):
-        """-> {family: (rows, dt, N) proposals} through rome_clique_proposals (ONE call)."""
-        ctx = ctx or api.default_context()
-        q = CliqueHost()
-        keep = []
-
+    def _fill(self, q, keep, with_out=True):
+        """row tables, factor tables and beliefs of the clique -> the fields of a rome_clique_host"""
         def ptr(a, dt=np.float64):
             a = np.ascontiguousarray(a, dtype=dt); keep.append(a)
             return a.ctypes.data_as(C.c_void_p) if a.size else None
@@ -105,7 +101,7 @@ class CliqueBatch:
         q.bel_pose2, q.bel_point2, q.bel_pose3 = ptr(bel[Pose2]), ptr(bel[Point2]), ptr(bel[Pose3])
         out = {}
         for fam, dt in (("p2p2", 3), ("br1", 3), ("br0", 2), ("p3p3", 6)):
-            out[fam] = np.zeros((len(self.fam_rows[fam]), dt, self.N))
+            out[fam] = np.zeros((len(self.fam_rows[fam]) if with_out else 0, dt, self.N))
         t = self.tabs
         q.n_p2p2, q.f_p2p2 = len(self.fam_rows["p2p2"]), len(t["p2p2"]["mu"])
         q.p2p2_rows4 = ptr(np.array(self.fam_rows["p2p2"], dtype=np.int32).reshape(-1, 4), np.int32)
@@ -119,10 +115,97 @@ class CliqueBatch:
         q.p3p3_mu, q.p3p3_cov = ptr(np.array(t["p3p3"]["mu"]).reshape(-1, 6)), ptr(np.array(t["p3p3"]["spread"]).reshape(-1, 36))
         q.out_p2p2, q.out_br1, q.out_br0, q.out_p3p3 = (out[f].ctypes.data_as(C.c_void_p) if out[f].size else None
                                                        for f in ("p2p2", "br1", "br0", "p3p3"))
+        return out
+
+    def run(self, opts, ctx=None):
+        """-> {family: (rows, dt, N) proposals} through rome_clique_proposals (ONE call)."""
+        ctx = ctx or api.default_context()
+        q = CliqueHost()
+        keep = []
+        out = self._fill(q, keep)
         o = _lib.Opts.from_buffer_copy(opts)
         o.layout = _lib.LAYOUT_SOA
         _lib.check(_lib.load().rome_clique_proposals(ctx.handle, C.byref(o), C.byref(q)), ctx.handle)
         return out
+
+    def upsolve(self, opts, up_labels, gibbs_iters=3, product_iters=1, schedule="sequential", messages=None, ctx=None):
+        """IIF `upGibbsCliqueDensity` on the device in ONE call (rome_clique_upsolve): gibbs_iters x {proposals of every
+        (factor, target) pair, manikde! bandwidths, multiscale Gibbs product, write-back} for the variables `up_labels` (the
+        clique's frontals, in Gibbs order; the pairs of this batch must be grouped by target in that order).
+        messages: {label: [(dim, N) points, ...]} upward messages of child cliques on updated variables.
+        -> {label: (points (dim, N), bandwidths (dim,))}"""
+        ctx = ctx or api.default_context()
+        u = CliqueUpsolveHost()
+        keep = []
+        self._fill(u.clique, keep, with_out=False)
+        types = (Pose2, Point2, Pose3)
+        u.gibbs_iters, u.product_iters = int(gibbs_iters), int(product_iters)
+        u.schedule = {"sequential": 0, "jacobi": 1}[schedule]
+        u.n_up = len(up_labels)
+        upt = np.array([types.index(self.fg.variables[l]) for l in up_labels], dtype=np.int32)
+        upv = np.array([self.vidx[l] for l in up_labels], dtype=np.int32)
+        keep += [upt, upv]
+        u.up_type, u.up_var = upt.ctypes.data_as(C.c_void_p), upv.ctypes.data_as(C.c_void_p)
+        names = ("pose2", "point2", "pose3")
+        res = {}
+        for ti, vt in enumerate(types):
+            ls = [l for l in up_labels if self.fg.variables[l] is vt]
+            new = np.zeros((len(ls), vt.dim, self.N)); bw = np.zeros((len(ls), vt.dim))
+            keep += [new, bw]
+            res[vt] = (ls, new, bw)
+            setattr(u, "new_" + names[ti], new.ctypes.data_as(C.c_void_p) if new.size else None)
+            setattr(u, "bw_" + names[ti], bw.ctypes.data_as(C.c_void_p) if bw.size else None)
+            msgs, pos = [], []
+            for l, plist in (messages or {}).items():
+                if self.fg.variables[l] is vt:
+                    for pts in plist:
+                        msgs.append(np.asarray(pts, dtype=float)); pos.append(list(up_labels).index(l))
+            setattr(u, "n_msg_" + names[ti], len(msgs))
+            if msgs:
+                m = np.ascontiguousarray(np.stack(msgs)); pp = np.array(pos, dtype=np.int32)
+                keep += [m, pp]
+                setattr(u, "msg_" + names[ti], m.ctypes.data_as(C.c_void_p)); setattr(u, "msg_" + names[ti] + "_up", pp.ctypes.data_as(C.c_void_p))
+        o = _lib.Opts.from_buffer_copy(opts)
+        o.layout = _lib.LAYOUT_SOA
+        _lib.check(_lib.load().rome_clique_upsolve(ctx.handle, C.byref(o), C.byref(u)), ctx.handle)
+        return {l: (new[k].copy(), bw[k].copy()) for vt, (ls, new, bw) in res.items() for k, l in enumerate(ls)}
+
+
+class CliqueUpsolveHost(C.Structure):
+    _fields_ = [("clique", CliqueHost), ("gibbs_iters", C.c_int32), ("product_iters", C.c_int32), ("schedule", C.c_int32), ("n_up", C.c_int32),
+                ("up_type", C.c_void_p), ("up_var", C.c_void_p),
+                ("n_msg_pose2", C.c_int32), ("n_msg_point2", C.c_int32), ("n_msg_pose3", C.c_int32), ("reserved0", C.c_int32),
+                ("msg_pose2", C.c_void_p), ("msg_pose2_up", C.c_void_p), ("msg_point2", C.c_void_p), ("msg_point2_up", C.c_void_p),
+                ("msg_pose3", C.c_void_p), ("msg_pose3_up", C.c_void_p),
+                ("new_pose2", C.c_void_p), ("bw_pose2", C.c_void_p), ("new_point2", C.c_void_p), ("bw_point2", C.c_void_p),
+                ("new_pose3", C.c_void_p), ("bw_pose3", C.c_void_p)]
+
+
+def upGibbsCliqueDensity(fg, frontals, factor_labels=None, gibbsIters=3, Niter=1, schedule="sequential", messages=None,
+                         solver=_lib.SOLVER_NEWTON, seed=None, ctx=None, setvals=True, **optkw):
+    """IIF `upGibbsCliqueDensity` for one clique: Gibbs over the `frontals` (in order) with the factors `factor_labels` (default:
+    every factor of a frontal whose other variable has a belief), all on the device in one library call
+    (`rome_clique_upsolve`).  With `setvals` the new beliefs are stored in `fg` (IIF setValKDE!).
+    -> {frontal: (points (dim, N), manikde! bandwidths (dim,))}"""
+    pairs = []
+    for dest in frontals:
+        for flabel, labels, _ in fg.factors:
+            if dest not in labels or (factor_labels is not None and flabel not in factor_labels):
+                continue
+            if not all(fg.isInitialized(l) or l in frontals for l in labels if l != dest):
+                continue
+            pairs.append((flabel, dest))
+    batch = CliqueBatch(fg, pairs)
+    for l in frontals:   # a frontal without any usable factor still needs its slot in the clique's arrays
+        if l not in batch.vidx:
+            t = fg.variables[l]
+            batch.vidx[l] = len(batch.vars[t]); batch.vars[t].append(l)
+    opts = api.make_opts(N=fg.N, solver=solver, seed=seed, **optkw)
+    res = batch.upsolve(opts, list(frontals), gibbs_iters=gibbsIters, product_iters=Niter, schedule=schedule, messages=messages, ctx=ctx)
+    if setvals:
+        for l, (pts, _) in res.items():
+            fg.initVariable(l, pts)
+    return res
 
 
 def proposalbeliefs(fg, destlabels, factor_labels=None, solver=_lib.SOLVER_NEWTON, seed=None, ctx=None, **optkw):
@@ -147,19 +230,26 @@ def predictbelief(fg, destlabel, factor_labels=None, solver=_lib.SOLVER_NEWTON, 
     """IIF `predictbelief(dfg, destlbl, factors; N)`: the proposals of every usable factor of `destlabel` (one library call,
     `proposalbeliefs`) multiplied by `manifoldProduct` (multiscale Gibbs product on the `manikde!` bandwidths, one more call) ->
     (dim, N) points of the predicted belief.  A factor is usable when its other variable has a belief (priors always are).
-    Multihypo factors go through `approxConv`."""
-    usable = []
+    Multihypo factors take the per-factor path (`approxConv`, which routes them to the `*_mh` entry points); their proposals are
+    stacked with the others before the product."""
+    from .convolution import approxConv
+    usable, mh = [], []
     for flabel, labels, f in fg.factors:
         if destlabel not in labels or (factor_labels is not None and flabel not in factor_labels):
             continue
-        if fg.multihypo.get(flabel) is not None:
+        if not all(fg.isInitialized(l) for l in labels if l != destlabel):
             continue
-        if all(fg.isInitialized(l) for l in labels if l != destlabel):
-            usable.append(flabel)
-    if not usable:
+        (mh if fg.multihypo.get(flabel) is not None else usable).append(flabel)
+    if not usable and not mh:
         raise ValueError("predictbelief: no factor of %s has initialised neighbours" % destlabel)
-    props, _ = proposalbeliefs(fg, destlabel, factor_labels=usable, solver=solver, seed=seed, ctx=ctx, **optkw)
-    P = np.stack([props[(fl, destlabel)] for fl in usable])
+    plist = []
+    if usable:
+        props, _ = proposalbeliefs(fg, destlabel, factor_labels=usable, solver=solver, seed=seed, ctx=ctx, **optkw)
+        plist += [props[(fl, destlabel)] for fl in usable]
+    for fl in mh:
+        plist.append(np.asarray(approxConv(fg, fl, destlabel, solver=solver, seed=seed, ctx=ctx, **optkw)))
+    P = np.stack(plist)
+    usable = usable + mh
     if len(usable) == 1:
         return P[0]
     return api.manifoldProduct(P, Niter=Niter, opts=api.make_opts(N=fg.N, seed=seed, **{k: v for k, v in optkw.items() if k == "stream_offset"}), ctx=ctx)

@@ -657,6 +657,224 @@ int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_hos
   return ROME_OK;
 }
 
+/* ---- clique up-solve: gibbs_iters x {proposals -> manikde! bandwidths -> multiscale Gibbs product -> write-back}, device-resident ---- */
+int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsolve_host* u) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || !u) return ROME_ERR_INVALID_ARG;
+  const rome_clique_host* q = &u->clique;
+  const int N = o->n_particles;
+  if (N > 128) return ROME_ERR_UNSUPPORTED_N;   // the multiscale Gibbs product: lane = output sample, two wavefronts per variable
+  if (N < 2 || u->n_up < 0 || (u->n_up > 0 && (!u->up_type || !u->up_var))) return ROME_ERR_INVALID_ARG;
+  if (u->schedule != ROME_UPSOLVE_SEQUENTIAL && u->schedule != ROME_UPSOLVE_JACOBI) return ROME_ERR_INVALID_ARG;
+  const int gi = u->gibbs_iters > 0 ? u->gibbs_iters : 3, pi = u->product_iters > 0 ? u->product_iters : 1;
+  const int nv[3] = {q->n_pose2, q->n_point2, q->n_pose3};
+  const int vdim[3] = {3, 2, 6};
+  const double* vhost[3] = {q->bel_pose2, q->bel_point2, q->bel_pose3};
+  const uint32_t circ_bw[3] = {0b100u, 0u, 0b111000u}, circ_prod[3] = {0b100u, 0u, 0u};
+  const uint64_t prod_off[3] = {3ull << 28, 4ull << 28, 6ull << 28};
+  for (int t = 0; t < 3; ++t) if (nv[t] < 0 || (nv[t] > 0 && !vhost[t])) return ROME_ERR_INVALID_ARG;
+  // ---- update list: (type, variable) -> global position k and position within the type's list
+  std::vector<int> kpos[3], uplist[3];
+  for (int t = 0; t < 3; ++t) kpos[t].assign((size_t)nv[t], -1);
+  std::vector<int> up_cnt_before((size_t)u->n_up * 3 + 3, 0);   // [k][t]: updates of type t among the first k
+  for (int k = 0; k < u->n_up; ++k) {
+    const int t = u->up_type[k], v = u->up_var[k];
+    if (t < 0 || t > 2 || v < 0 || v >= nv[t] || kpos[t][v] >= 0) return ROME_ERR_INVALID_ARG;
+    kpos[t][v] = k;
+    for (int tt = 0; tt < 3; ++tt) up_cnt_before[3 * (size_t)(k + 1) + tt] = up_cnt_before[3 * (size_t)k + tt] + (tt == t ? 1 : 0);
+    uplist[t].push_back(v);
+  }
+  // device order of a type's beliefs: updated variables first (in update order), then the others
+  std::vector<int> newidx[3];
+  for (int t = 0; t < 3; ++t) {
+    newidx[t].assign((size_t)nv[t], -1);
+    int nx = 0;
+    for (int v : uplist[t]) newidx[t][v] = nx++;
+    for (int v = 0; v < nv[t]; ++v) if (newidx[t][v] < 0) newidx[t][v] = nx++;
+  }
+  struct Fam { int n; const int32_t* rows4; int F; const double* mu; const double* spread; int dz, nL, dfx, dt; int vf, vt; int dir_all; uint64_t off; int kind; int base; };
+  Fam fam[4] = {
+    {q->n_p2p2, q->p2p2_rows4, q->f_p2p2, q->p2p2_mu, q->p2p2_cov, 3, 6, 3, 3, 0, 0, 0, 0ull, 0, 0},
+    {q->n_br1, q->br1_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 2, 3, 1, 0, 1, 1ull << 28, 1, q->n_p2p2},
+    {q->n_br0, q->br0_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 3, 2, 0, 1, 0, 2ull << 28, 1, 0},
+    {q->n_p3p3, q->p3p3_rows4, q->f_p3p3, q->p3p3_mu, q->p3p3_cov, 6, 21, 6, 6, 2, 2, 0, 5ull << 28, 2, 0}};
+  const int n_msg[3] = {u->n_msg_pose2, u->n_msg_point2, u->n_msg_pose3};
+  const double* msg_host[3] = {u->msg_pose2, u->msg_point2, u->msg_pose3};
+  const int32_t* msg_up[3] = {u->msg_pose2_up, u->msg_point2_up, u->msg_pose3_up};
+  double* new_host[3] = {u->new_pose2, u->new_point2, u->new_pose3};
+  double* bw_host[3] = {u->bw_pose2, u->bw_point2, u->bw_pose3};
+  int prop_rows_t[3] = {0, 0, 0}, msg_base[3];
+  for (const Fam& f : fam) { if (f.n < 0 || f.F < 0 || (f.n > 0 && (!f.rows4 || !f.mu || !f.spread || f.F == 0))) return ROME_ERR_INVALID_ARG; prop_rows_t[f.vt] += f.n; }
+  for (int t = 0; t < 3; ++t) {
+    if (n_msg[t] < 0 || (n_msg[t] > 0 && (!msg_host[t] || !msg_up[t]))) return ROME_ERR_INVALID_ARG;
+    if (!uplist[t].empty() && (!new_host[t] || !bw_host[t])) return ROME_ERR_INVALID_ARG;
+    msg_base[t] = prop_rows_t[t]; prop_rows_t[t] += n_msg[t];
+  }
+  // ---- rows: validate, remap the variable indices to the device order, find the row range of every update position
+  std::vector<int32_t> rows_dev[4];
+  std::vector<int> fam_lo[4], fam_hi[4];   // rows of family f that target update position k: [lo[k], hi[k])
+  std::vector<std::vector<int>> csr[3];    // per type: proposal rows (in the type's buffer) of every updated variable
+  for (int t = 0; t < 3; ++t) csr[t].resize(uplist[t].size());
+  for (int k4 = 0; k4 < 4; ++k4) {
+    const Fam& f = fam[k4];
+    rows_dev[k4].resize((size_t)f.n * 4);
+    fam_lo[k4].assign((size_t)u->n_up + 1, 0); fam_hi[k4].assign((size_t)u->n_up + 1, 0);
+    int prev = -1;
+    for (int r = 0; r < f.n; ++r) {
+      const int32_t* e = f.rows4 + 4 * (size_t)r;
+      if (e[0] < 0 || e[0] >= f.F || e[2] < 0 || e[2] >= nv[f.vf] || e[3] < 0 || e[3] >= nv[f.vt] || e[1] < 0 || e[1] > 2) return ROME_ERR_INVALID_ARG;
+      const int k = kpos[f.vt][e[3]];
+      if (k < 0 || k < prev) return ROME_ERR_INVALID_ARG;   // every row targets an updated variable; rows grouped in update order
+      if (k != prev) { for (int kk = prev + 1; kk <= k; ++kk) fam_lo[k4][kk] = r; }
+      fam_hi[k4][k] = r + 1; prev = k;
+      int32_t* d = rows_dev[k4].data() + 4 * (size_t)r;
+      d[0] = e[0]; d[1] = e[1]; d[2] = newidx[f.vf][e[2]]; d[3] = newidx[f.vt][e[3]];
+      csr[f.vt][(size_t)newidx[f.vt][e[3]]].push_back(f.base + r);
+    }
+    for (int kk = prev + 1; kk <= u->n_up; ++kk) fam_lo[k4][kk] = f.n;
+    for (int kk = 0; kk < u->n_up; ++kk) if (fam_hi[k4][kk] < fam_lo[k4][kk]) fam_hi[k4][kk] = fam_lo[k4][kk];
+  }
+  for (int t = 0; t < 3; ++t)
+    for (int m = 0; m < n_msg[t]; ++m) {
+      const int k = msg_up[t][m];
+      if (k < 0 || k >= u->n_up || u->up_type[k] != t) return ROME_ERR_INVALID_ARG;
+      csr[t][(size_t)newidx[t][u->up_var[k]]].push_back(msg_base[t] + m);
+    }
+  int max_k[3] = {1, 1, 1};
+  std::vector<int32_t> ptr_h[3], rws_h[3];
+  for (int t = 0; t < 3; ++t) {
+    ptr_h[t].push_back(0);
+    for (const auto& l : csr[t]) { for (int r : l) rws_h[t].push_back(r); ptr_h[t].push_back((int32_t)rws_h[t].size()); if ((int)l.size() > max_k[t]) max_k[t] = (int)l.size(); }
+    if (rws_h[t].empty()) rws_h[t].push_back(0);
+  }
+  // ---- arena
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  size_t need = 4096;
+  for (int t = 0; t < 3; ++t) {
+    const size_t blk = (size_t)vdim[t] * N * 8;
+    need += al(nv[t] * blk) + al(uplist[t].size() * blk) + al((size_t)prop_rows_t[t] * blk) + al((size_t)prop_rows_t[t] * vdim[t] * 8)
+          + al(ptr_h[t].size() * 4) + al(rws_h[t].size() * 4) + al(uplist[t].size() * vdim[t] * 8);
+  }
+  for (const Fam& f : fam) need += al((size_t)f.n * 16) + al((size_t)f.F * f.dz * 8) + al((size_t)f.F * f.nL * 8);
+  ROME_BIND(c);
+  void* arena_v = nullptr;
+  if ((rc = ensure(c, 9, need, &arena_v))) return rc;
+  unsigned char* arena = (unsigned char*)arena_v;
+  size_t used = 0;
+  hipStream_t s = c->stream;
+  auto put = [&](const void* src, size_t bytes, void** dst) -> int {
+    *dst = arena + used;
+    if (bytes) ROME_HIP(c, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
+    used += al(bytes);
+    return ROME_OK;
+  };
+  auto take = [&](size_t bytes) -> void* { void* p = arena + used; used += al(bytes); return p; };
+  // beliefs: host blocks in the device order, staged like rome_clique_proposals (layout conversion included)
+  std::vector<double> tmp, perm_host[3];
+  double* d_store[3]; double* d_tmp[3]; double* d_prop[3]; double* d_pbw[3]; int32_t* d_ptr[3]; int32_t* d_rws[3]; double* d_bwout[3];
+  for (int t = 0; t < 3; ++t) {
+    const size_t plen = (o->layout == ROME_LAYOUT_AOS_POINTS ? (size_t)point_len(vdim[t]) : (size_t)vdim[t]) * N;
+    perm_host[t].resize((size_t)nv[t] * plen);
+    for (int v = 0; v < nv[t]; ++v) std::memcpy(perm_host[t].data() + (size_t)newidx[t][v] * plen, vhost[t] + (size_t)v * plen, plen * 8);
+    void* dv = nullptr;
+    if ((rc = stage_beliefs(c, o, nv[t], vdim[t], perm_host[t].data(), tmp, &dv, &used, arena, need))) return rc;
+    d_store[t] = (double*)dv;
+    const size_t blk = (size_t)vdim[t] * N * 8;
+    d_tmp[t] = (double*)take(uplist[t].size() * blk);
+    d_prop[t] = (double*)take((size_t)prop_rows_t[t] * blk);
+    d_pbw[t] = (double*)take((size_t)prop_rows_t[t] * vdim[t] * 8);
+    d_bwout[t] = (double*)take(uplist[t].size() * vdim[t] * 8);
+    void* p;
+    if ((rc = put(ptr_h[t].data(), ptr_h[t].size() * 4, &p))) return rc; d_ptr[t] = (int32_t*)p;
+    if ((rc = put(rws_h[t].data(), rws_h[t].size() * 4, &p))) return rc; d_rws[t] = (int32_t*)p;
+    if (n_msg[t] > 0) {   // upward messages: appended to the type's proposal buffer, bandwidths once
+      void* dm = nullptr; size_t used_m = 0;
+      unsigned char* mb = (unsigned char*)(d_prop[t] + (size_t)msg_base[t] * vdim[t] * N);
+      if ((rc = stage_beliefs(c, o, n_msg[t], vdim[t], msg_host[t], tmp, &dm, &used_m, mb, (size_t)n_msg[t] * blk + 256))) return rc;
+      ROME_HIP(c, rome::launch_kde_bandwidth(vdim[t], n_msg[t], N, (const double*)mb, circ_bw[t], 1e-2, 1e-6,
+                                             d_pbw[t] + (size_t)msg_base[t] * vdim[t], nullptr, s));
+    }
+  }
+  std::vector<std::vector<double>> Ls(4);
+  const int32_t* d_rows[4] = {nullptr, nullptr, nullptr, nullptr}; const double* d_mu[4]; const double* d_L[4];
+  for (int k4 = 0; k4 < 4; ++k4) {
+    const Fam& f = fam[k4];
+    d_mu[k4] = d_L[k4] = nullptr;
+    if (f.n == 0) continue;
+    const double* Lsrc = f.spread;
+    if (f.kind != 1) {
+      Ls[k4].resize((size_t)f.F * f.nL);
+      if ((rc = rome_cholesky_lower(f.dz, f.F, f.spread, Ls[k4].data()))) return rc;
+      Lsrc = Ls[k4].data();
+    }
+    void* p;
+    if ((rc = put(rows_dev[k4].data(), (size_t)f.n * 16, &p))) return rc; d_rows[k4] = (const int32_t*)p;
+    if ((rc = put(f.mu, (size_t)f.F * f.dz * 8, &p))) return rc; d_mu[k4] = (const double*)p;
+    if ((rc = put(Lsrc, (size_t)f.F * f.nL * 8, &p))) return rc; d_L[k4] = (const double*)p;
+  }
+  size_t tree_need = 8;
+  for (int t = 0; t < 3; ++t) { const size_t b = rome::gibbs_workspace_bytes(vdim[t], prop_rows_t[t], (int)uplist[t].size()); if (b > tree_need) tree_need = b; }
+  void* trees = nullptr;
+  if ((rc = ensure(c, 10, tree_need, &trees))) return rc;
+  // ---- the loop
+  for (int it = 0; it < gi; ++it) {
+    const uint64_t base = o->stream_offset + ((uint64_t)it << 32);
+    const int nsteps = u->schedule == ROME_UPSOLVE_JACOBI ? (u->n_up > 0 ? 1 : 0) : u->n_up;
+    for (int st = 0; st < nsteps; ++st) {
+      const int k0 = u->schedule == ROME_UPSOLVE_JACOBI ? 0 : st, k1 = u->schedule == ROME_UPSOLVE_JACOBI ? u->n_up : st + 1;
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const Fam& f = fam[k4];
+        const int lo = fam_lo[k4][k0], hi = f.n == 0 ? 0 : (k1 < u->n_up ? fam_lo[k4][k1] : f.n);
+        if (hi <= lo) continue;
+        rome::ConvArgs a;
+        rome_opts of = *o; of.stream_offset = base + f.off + (uint64_t)lo;
+        fill_args(a, &of);
+        a.n_conv = hi - lo; a.dir_all = f.dir_all; a.rows4 = d_rows[k4] + 4 * (size_t)lo;
+        a.mu = d_mu[k4]; a.L = d_L[k4];
+        a.bel_fixed = d_store[f.vf]; a.bel_target = d_store[f.vt];
+        a.out = d_prop[f.vt] + (size_t)(f.base + lo) * f.dt * N;
+        hipError_t e = f.kind == 0 ? rome::launch_conv_pose2pose2(a, o->solver, s) : (f.kind == 1 ? rome::launch_conv_bearingrange(a, o->solver, s)
+                                                                                                : rome::launch_conv_pose3pose3(a, o->solver, s));
+        ROME_HIP(c, e);
+        ROME_HIP(c, rome::launch_kde_bandwidth(f.dt, hi - lo, N, a.out, circ_bw[f.vt], 1e-2, 1e-6, d_pbw[f.vt] + (size_t)(f.base + lo) * f.dt, nullptr, s));
+      }
+      for (int t = 0; t < 3; ++t) {
+        const int pa = up_cnt_before[3 * (size_t)k0 + t], pb = up_cnt_before[3 * (size_t)k1 + t];
+        if (pb <= pa || prop_rows_t[t] == 0) continue;
+        const size_t blk = (size_t)vdim[t] * N;
+        ROME_HIP(c, rome::launch_product_gibbs(vdim[t], pb - pa, N, prop_rows_t[t], d_ptr[t] + pa, d_rws[t], d_prop[t], d_pbw[t],
+                                               d_store[t] + (size_t)pa * blk, d_tmp[t] + (size_t)pa * blk, trees, circ_prod[t], pi, max_k[t],
+                                               o->seed, base + prod_off[t] + (uint64_t)pa, s));
+        ROME_HIP(c, hipMemcpyAsync(d_store[t] + (size_t)pa * blk, d_tmp[t] + (size_t)pa * blk, (size_t)(pb - pa) * blk * 8, hipMemcpyDeviceToDevice, s));
+      }
+    }
+  }
+  // ---- results: the updated beliefs (first blocks of every store) and their manikde! bandwidths
+  std::vector<std::vector<double>> hout(3);
+  for (int t = 0; t < 3; ++t) {
+    const int nu = (int)uplist[t].size();
+    if (nu == 0) continue;
+    ROME_HIP(c, rome::launch_kde_bandwidth(vdim[t], nu, N, d_store[t], circ_bw[t], 1e-2, 1e-6, d_bwout[t], nullptr, s));
+    ROME_HIP(c, hipMemcpyAsync(bw_host[t], d_bwout[t], (size_t)nu * vdim[t] * 8, hipMemcpyDeviceToHost, s));
+    const size_t cnt = (size_t)nu * vdim[t] * N;
+    if (o->layout == ROME_LAYOUT_SOA) ROME_HIP(c, hipMemcpyAsync(new_host[t], d_store[t], cnt * 8, hipMemcpyDeviceToHost, s));
+    else { hout[t].resize(cnt); ROME_HIP(c, hipMemcpyAsync(hout[t].data(), d_store[t], cnt * 8, hipMemcpyDeviceToHost, s)); }
+  }
+  ROME_HIP(c, hipStreamSynchronize(s));
+  if (o->layout != ROME_LAYOUT_SOA)
+    for (int t = 0; t < 3; ++t) {
+      const int nu = (int)uplist[t].size();
+      if (nu == 0) continue;
+      if (o->layout == ROME_LAYOUT_AOS || vdim[t] == 2) from_soa(hout[t].data(), nu, N, vdim[t], ROME_LAYOUT_AOS, new_host[t]);
+      else {
+        std::vector<double> aos(hout[t].size());
+        from_soa(hout[t].data(), nu, N, vdim[t], ROME_LAYOUT_AOS, aos.data());
+        if ((rc = convert_rows(c, vdim[t], (size_t)nu * N, aos.data(), new_host[t], false))) return rc;
+      }
+    }
+  return ROME_OK;
+}
+
 /* ---- native point containers <-> coordinates ---- */
 int rome_points_to_coords(rome_ctx* c, int32_t dim, int32_t n, const double* pts, double* coords) {
   if (!c || n < 0 || (dim != 2 && dim != 3 && dim != 6) || (n > 0 && (!pts || !coords))) return ROME_ERR_INVALID_ARG;

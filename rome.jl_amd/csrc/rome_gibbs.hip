@@ -381,6 +381,15 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
   const int k0 = a.prop_ptr[v], K = a.prop_ptr[v + 1] - k0;
   auto circ_bit = [&](int d) -> bool { if constexpr (CM >= 0) return (CM >> d) & 1; else return (a.circ >> d) & 1u; };
   double* ob = a.bel_out + (size_t)v * D * N;
+  // Arguments of the public entry that would index out of bounds -- more proposals than the caller's max_proposals sized the LDS
+  // for, or a proposal row outside the tree workspace -- fail LOUDLY: the variable's belief becomes NaN (block-uniform test, no
+  // out-of-bounds access); nothing is silently truncated.
+  bool bad = K < 0 || K > a.max_k;
+  for (int j = 0; j < K && !bad; ++j) { const int r = a.prop_rows[k0 + j]; bad = r < 0 || r >= a.n_rows; }
+  if (bad) {
+    for (int q = tid; q < D * N; q += kGibbsThreads) ob[q] = __builtin_nan("");
+    return;
+  }
   if (K <= 1) {   // K = 0: the belief is kept; K = 1: the proposal is the product
     const double* src = K == 0 ? a.bel_in + (size_t)v * D * N : a.prop + (size_t)a.prop_rows[k0] * D * N;
     for (int q = tid; q < D * N; q += kGibbsThreads) ob[q] = src[q];

@@ -338,6 +338,7 @@ class TargetShardedSweep:
             idx = torch.as_tensor(order, device=tb["alt"].device)
             self.alt, self.w = tb["alt"][idx].contiguous(), torch.as_tensor(tb["w"])[idx.to(torch.as_tensor(tb["w"]).device)].contiguous()
             mh = dict(alt_var=self.alt[self.row_lo:self.row_hi], hypo_w=self.w[self.row_lo:self.row_hi])
+        self._mh = mh
         self.plan = dg._plan(tb["fn"], o, n_conv=n, dir_all=tb["dir_all"], rows4=self.rows4[self.row_lo:self.row_hi], mu=tb["mu"], L=tb["L"],
                              bel_fixed=self.store, bel_target=self.store, out=self.prop[self.row_lo:self.row_hi], **mh) if n else (lambda: None)
         self.mine = self.store[rank * q:(rank + 1) * q]
@@ -362,9 +363,12 @@ class TargetShardedSweep:
         if not hasattr(self, "_solve"):
             dev = self.store.device
             n, d = self.prop.shape[0], self.store.shape[1]
+            lo_v0 = self.rank * self.q
             self._solve = dict(bw=torch.zeros((max(n, 1), d), dtype=self.store.dtype, device=dev),
-                               ptr=torch.as_tensor(self.ptr.astype(np.int32), device=dev),
-                               rows=torch.arange(max(n, 1), dtype=torch.int32, device=dev),
+                               # CSR of the OWNED variables over the OWNED rows only (rebased to row_lo): the tree build and the
+                               # bandwidths then touch this rank's rows and nothing else
+                               ptr=torch.as_tensor((self.ptr[lo_v0:lo_v0 + self.q + 1] - self.row_lo).astype(np.int32), device=dev),
+                               rows=torch.arange(max(self.n_rows, 1), dtype=torch.int32, device=dev),
                                out=torch.zeros_like(self.mine),
                                max_k=int(max(1, np.diff(self.ptr).max())))
         S = self._solve
@@ -382,17 +386,22 @@ class TargetShardedSweep:
                                                   S["bw"][self.row_lo:self.row_hi].data_ptr()), h)
         op = type(opts).from_buffer_copy(opts)
         op.stream_offset = opts.stream_offset + (sweep << 32) + dg.STREAM_PROD2 + lo_v      # product stream = global variable id
-        # CSR of the owned variables: ptr entries are absolute rows of the sorted table; only rows [row_lo, row_hi) are read
-        _lib.check(lib.rome_product_gibbs_dev(h, C.byref(op), d, q, S["ptr"][lo_v:lo_v + q + 1].data_ptr(), S["rows"].data_ptr(),
-                                              self.prop.data_ptr(), S["bw"].data_ptr(), self.prop.shape[0], self.mine.data_ptr(),
-                                              S["out"].data_ptr(), circ, int(gibbs_iters), S["max_k"]), h)
+        _lib.check(lib.rome_product_gibbs_dev(h, C.byref(op), d, q, S["ptr"].data_ptr(), S["rows"].data_ptr(),
+                                              self.prop[self.row_lo:].data_ptr(), S["bw"][self.row_lo:].data_ptr(), self.n_rows,
+                                              self.mine.data_ptr(), S["out"].data_ptr(), circ, int(gibbs_iters), S["max_k"]), h)
         self.mine.copy_(S["out"])
         self.exchange()
 
     def _sweep_plan(self, o):
-        tb = self.dg.family_table(self.family)
-        return self.dg._plan(tb["fn"], o, n_conv=self.n_rows, dir_all=tb["dir_all"], rows4=self.rows4[self.row_lo:self.row_hi], mu=tb["mu"], L=tb["L"],
-                             bel_fixed=self.store, bel_target=self.store, out=self.prop[self.row_lo:self.row_hi])
+        """The launch of the owned rows (multihypo columns included) with the Philox streams of `o`: built once, afterwards only
+        the stream offset of the cached descriptor's options changes."""
+        if getattr(self, "_solve_plan", None) is None:
+            tb = self.dg.family_table(self.family)
+            self._solve_plan = self.dg._plan(tb["fn"], o, n_conv=self.n_rows, dir_all=tb["dir_all"], rows4=self.rows4[self.row_lo:self.row_hi],
+                                             mu=tb["mu"], L=tb["L"], bel_fixed=self.store, bel_target=self.store,
+                                             out=self.prop[self.row_lo:self.row_hi], **self._mh)
+        self._solve_plan._keep[1].stream_offset = o.stream_offset
+        return self._solve_plan
 
     def exchange(self):
         if not self.collective:

@@ -64,3 +64,77 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
         if Fb:
             bell = ro.product(mk(S["PRODL"]), 2, ptrl, rowsl, propl, bell, ro.kde_bandwidths(propl, 0) if lcv else None)
     return bel2, bell
+
+
+def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iters=1, schedule="sequential", solver=1, messages=None):
+    """Oracle-side restatement of rome_clique_upsolve / R.upGibbsCliqueDensity (IIF upGibbsCliqueDensity): same pairs, same row
+    tables, same Philox streams; every convolution, bandwidth and product through oracle/ (CPU).  -> {label: points (dim, N)}"""
+    from rome_jl_amd.clique import CliqueBatch
+    pairs = []
+    for dest in frontals:
+        for flabel, labels, _ in fg.factors:
+            if dest in labels and all(fg.isInitialized(l) or l in frontals for l in labels if l != dest):
+                pairs.append((flabel, dest))
+    batch = CliqueBatch(fg, pairs)
+    for l in frontals:
+        if l not in batch.vidx:
+            t = fg.variables[l]
+            batch.vidx[l] = len(batch.vars[t]); batch.vars[t].append(l)
+    types = (R.Pose2, R.Point2, R.Pose3)
+    bel = {vt: batch.beliefs(vt) for vt in types}
+    T = batch.tabs
+    rows = {f: np.array(batch.fam_rows[f], dtype=np.int64).reshape(-1, 4) for f in ("p2p2", "br1", "br0", "p3p3")}
+    mu2 = np.array(T["p2p2"]["mu"]).reshape(-1, 3); L2 = np.array([ro.cholesky_lower(np.asarray(c).reshape(3, 3)) for c in T["p2p2"]["spread"]]).reshape(-1, 6)
+    mub = np.array(T["br"]["mu"]).reshape(-1, 2); sgb = np.array(T["br"]["spread"]).reshape(-1, 2)
+    S = dict(p2p2=0, br1=1 << 28, br0=2 << 28)
+    PROD = {R.Pose2: 3 << 28, R.Point2: 4 << 28}
+    circ = {R.Pose2: 0b100, R.Point2: 0}
+    pos_in_type = {}
+    for l in frontals:
+        vt = fg.variables[l]
+        pos_in_type[l] = sum(1 for m in frontals[:frontals.index(l)] if fg.variables[m] is vt)
+
+    def proposals_for(targets, base):
+        """{label: list of (dim, N) proposals in the device's CSR order (p2p2 rows, br1 rows | br0 rows, messages)}"""
+        out = {l: [] for l in targets}
+        for fam in ("p2p2", "br1", "br0"):
+            rw = rows[fam]
+            vt = R.Point2 if fam == "br0" else R.Pose2
+            tv = {batch.vidx[l]: l for l in targets if fg.variables[l] is vt}
+            sel = [r for r in range(len(rw)) if rw[r, 3] in tv]
+            for r in sel:
+                o = ro.make_opts(N=N, solver=solver, seed=seed, stream_offset=base + S[fam] + r)
+                f, d, fx, tg = rw[r]
+                if fam == "p2p2" and d == 2:
+                    p = ro.sample_priorpose2(ro.make_opts(N=N, seed=seed, stream_offset=base + S[fam] + r), mu2[f], L2[f])[0]
+                elif fam == "p2p2":
+                    p = ro.conv_pose2pose2(o, mu2, L2, bel[R.Pose2], [fx], [tg], [d], factor=[f])[0]
+                elif fam == "br1":
+                    p = ro.conv_pose2point2br(o, 1, mub, sgb, bel[R.Point2], bel[R.Pose2], [fx], [tg], factor=[f])[0]
+                else:
+                    p = ro.conv_pose2point2br(o, 0, mub, sgb, bel[R.Pose2], bel[R.Point2], [fx], [tg], factor=[f])[0]
+                out[tv[tg]].append(p)
+        for l in targets:
+            for pts in (messages or {}).get(l, []):
+                out[l].append(np.asarray(pts, dtype=float))
+        return out
+
+    for it in range(gibbs_iters):
+        base = it << 32
+        steps = [[l] for l in frontals] if schedule == "sequential" else [list(frontals)]
+        for group in steps:
+            props = proposals_for(group, base)
+            new = {}
+            for l in group:
+                vt = fg.variables[l]; v = batch.vidx[l]
+                P = props[l]
+                if not P:
+                    continue
+                P = np.stack(P)
+                bw = ro.kde_bandwidths(P, circ[vt])
+                o = ro.make_opts(N=N, seed=seed, stream_offset=base + PROD[vt] + pos_in_type[l])
+                new[l] = ro.product_msgibbs(o, vt.dim, np.array([0, len(P)], dtype=np.int32), np.arange(len(P), dtype=np.int32), P, bw,
+                                            bel[vt][v:v + 1], circ[vt], product_iters)[0]
+            for l, b in new.items():
+                bel[fg.variables[l]][batch.vidx[l]] = b
+    return {l: bel[fg.variables[l]][batch.vidx[l]].copy() for l in frontals}
