@@ -20,7 +20,7 @@ from .graph import (FactorGraph, initfg, fifoFreeze, isMarginalized, importG2o, 
                     PackedGraph, dead_reckon_init)
 from .canonical import (generateGraph_ZeroPose, buildGraphChain, generateGraph_TwoPoseOdo, calcHelix_T, generateGraph_Helix2D,
                         generateGraph_Helix2DSlew, generateGraph_Helix2DSpiral, generateGraph_Boxes2D, generateGraph_Beehive,
-                        generateGraph_Honeycomb, exportG2o, stringG2o, getPPE, setPPE, accumulateFactorMeans)
+                        generateGraph_Honeycomb, synth_beehive_mh, exportG2o, stringG2o, getPPE, setPPE, accumulateFactorMeans)
 from .convolution import approxConv, approxConvBelief
 from .clique import proposalbeliefs, predictbelief, CliqueBatch, upGibbsCliqueDensity
 from .serialization import loadDFG, saveDFG, packFactor, unpackFactor, packBelief, unpackBelief

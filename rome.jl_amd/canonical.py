@@ -291,6 +291,34 @@ def generateGraph_Beehive(poseCountTarget=10, locality=1.0, yaw0=None, seed=None
     return fg
 
 
+def synth_beehive_mh(poseCountTarget=36, ambiguous_every=2, weights=(0.5, 0.5), N=100, **kw):
+    """BASELINE configs[3] in one graph: the honeycomb of `generateGraph_Honeycomb` (legs μ = (10, 0, ±π/3), Σ = diag(0.1²);
+    landmarks sighted straight ahead at 20 m, GenerateHoneycomb.jl:59-100) in which every `ambiguous_every`-th RE-sighting of a
+    known landmark is an uncertain data association between that landmark and the nearest other one:
+    `addFactor!(fg, [pose; l_a; l_b], p2br, multihypo=[1.0; 0.5; 0.5])` as in test/testMultimodalRangeBearing.jl:53.
+    -> fg (simulated ground truth kept under fg._sim as for the other generators)"""
+    base = generateGraph_Honeycomb(poseCountTarget=poseCountTarget, N=N, **kw)
+    sim = _sim(base)
+    fg = initfg(N)
+    fg._sim = dict(sim)
+    for l, t in base.variables.items():
+        fg.addVariable(l, t)
+    lms = [l for l, t in base.variables.items() if t is Point2]
+    seen, resight = set(), 0
+    for flabel, labels, f in base.factors:
+        if isinstance(f, Pose2Point2BearingRange):
+            pose, lm = labels
+            if lm in seen and len(lms) > 1:
+                resight += 1
+                if resight % ambiguous_every == 0:
+                    other = min((l for l in lms if l != lm), key=lambda l: np.hypot(*(sim[l] - sim[lm])))
+                    fg.addFactor([pose, lm, other], f, multihypo=[1.0, weights[0], weights[1]])
+                    continue
+            seen.add(lm)
+        fg.addFactor(labels, f)
+    return fg
+
+
 # ------------------------------------------------------------------------------------------ g2o export
 def _jl(x):
     """Shortest round-trip decimal of a double, written the way Julia's `string(::Float64)` writes it."""

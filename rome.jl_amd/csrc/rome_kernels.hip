@@ -19,6 +19,11 @@
 // Blocks are 256 threads = 4 convolutions; blockIdx is remapped so that each XCD (own L2) works on
 // a contiguous range of the convolution table (neighbouring factors share variables).
 #include <cstdlib>
+// Floating-point contraction by SOURCE EXPRESSION (a*b + c written in one expression is one fma), not across statements at the
+// optimizer's discretion (hipcc's default, -ffp-contract=fast): the same inlined function then rounds identically in every kernel
+// instantiation it is inlined into -- the packed sweep, the wave-per-row kernel (lean or not) and the per-factor entry points agree
+// bit for bit for every solver (tests/test_gpu_config4.py), which "fast" does not guarantee.
+#pragma clang fp contract(on)
 #include "rome_device_math.hpp"
 #include "rome_kernels.h"
 

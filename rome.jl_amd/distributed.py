@@ -99,7 +99,7 @@ class SeparatorPipeline:
 
     Every rank holds its own segment as a DeviceGraph in which the remote separator variables appear as *ghost* variables.
     `publish`: [(family, conv_row)] -- proposal rows of this rank whose block is the message for the neighbours (the sweep
-    kernel itself mirrors them into the RCCL send buffer, `rome_conv_dev.mirror_*`: no gather kernel; at most 4 per family);
+    kernel itself mirrors them into the RCCL send buffer through `rome_conv_dev.mirror_map`: no gather kernel, any number of rows);
     the k-th published block of a variable type is that type's *slot* k.  Every rank must publish the same number of blocks
     per variable type (one fixed-size all-gather per step carries all types).
     `ghosts`: [(vartype, local_ghost_index, source_rank, source_slot)].
@@ -138,8 +138,9 @@ class SeparatorPipeline:
         for ff, _ in publish:
             if ff not in fams:
                 raise ValueError("publish: family %r is not in this graph" % (ff,))
-        if any(len(v) > 4 for v in pub_by_f.values()):
-            raise ValueError("at most 4 published rows per family (rome_conv_dev.mirror_row)")
+        for f, v in pub_by_f.items():
+            if len(set(v)) != len(v):
+                raise ValueError("family %s publishes a row twice" % f)
         slot0, npub = {}, {vt: 0 for vt in vts}
         for f in fams:
             vt = ftab[f]["vt_target"]
@@ -222,8 +223,10 @@ class SeparatorPipeline:
                     kw.update(alt_var=alt, hypo_w=tb["w"])
                 if pub_by_f[f]:
                     lo = sec_off[vt_t] + slot0[f] * dim[vt_t] * N
-                    kw.update(n_mirror=len(pub_by_f[f]), mirror_row=tuple(pub_by_f[f]),
-                              mirror_out=self.send[b][lo: lo + len(pub_by_f[f]) * dim[vt_t] * N])
+                    # any number of separator rows per family: row -> slot map (rome_conv_dev.mirror_map), -1 = not published
+                    mm = torch.full((tb["n"],), -1, dtype=torch.int32)
+                    mm[torch.as_tensor(pub_by_f[f], dtype=torch.long)] = torch.arange(len(pub_by_f[f]), dtype=torch.int32)
+                    kw.update(mirror_map=mm.to(dev), mirror_out=self.send[b][lo: lo + len(pub_by_f[f]) * dim[vt_t] * N])
                 if slot_ctx[b] is not None:
                     kw["_ctx"] = slot_ctx[b]
                 plans_b.append(dg._plan(tb["fn"], opts, **kw))

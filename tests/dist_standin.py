@@ -46,6 +46,9 @@ class OracleDG:
         out, mu, L = kw["out"], kw["mu"], kw["L"]
         bf, bt = kw["bel_fixed"], kw["bel_target"]
         mirror_rows, mirror_out = kw.get("mirror_row", ()), kw.get("mirror_out")
+        if kw.get("mirror_map") is not None:   # row -> slot map: the rows in slot order
+            mm = kw["mirror_map"].numpy()
+            mirror_rows = [int(np.nonzero(mm == m)[0][0]) for m in range(int(mm.max()) + 1)] if (mm >= 0).any() else ()
         alt = kw["alt_var"].numpy() if kw.get("alt_var") is not None else None
         hw = np.asarray(kw["hypo_w"], dtype=np.float64) if kw.get("hypo_w") is not None else None
         base = int(opts.stream_offset) if opts is not None else 0

@@ -404,3 +404,115 @@ def test_row_sharded_linearisation_gives_the_unsharded_solution(world):
     assert np.sqrt(((ref[:, :2] - gt[:, :2]) ** 2).sum(1).mean()) < 1.0       # the stand-in solves the graph
     for r in range(world):
         assert np.array_equal(ret[r], ref), r                                   # every rank, bit for bit
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] sharded: the honeycomb lattice with multihypo re-sightings (R.synth_beehive_mh), one segment per rank, cut
+# through the lattice: SIX pose separators and FIVE landmark separators per rank (more than the four rows the old mirror_row form
+# could publish -> rome_conv_dev.mirror_map), both bearing-range directions with hypotheses, ONE all-gather per step.
+_BH_POSES = (2, 5, 8, 11, 14, 17)
+_BH_LMS = 5
+
+
+def _beehive_segment(R, rank, N):
+    rng = np.random.default_rng(90 + rank)
+    fg = R.synth_beehive_mh(20, N=N)
+    lms = [l for l, t in fg.variables.items() if t is R.Point2]
+    leg = R.Pose2Pose2(R.MvNormal([10.0, 0.0, np.pi / 3], np.diag(np.square([0.1, 0.1, 0.1]))))
+    sight = lambda: R.Pose2Point2BearingRange(R.Normal(0.0, 0.03), R.Normal(20.0, 0.5))
+    for k, p in enumerate(_BH_POSES):      # cut legs: the neighbour's pose k enters as a ghost one leg before x_p
+        fg.addVariable("gp%d" % k, R.Pose2)
+        fg.addFactor(["gp%d" % k, "x%d" % p], leg)
+    for k in range(_BH_LMS):               # cut sightings: a neighbour's landmark, twice as the ALTERNATIVE of an ambiguous sighting
+        fg.addVariable("gl%d" % k, R.Point2)
+        if k % 2 == 0:
+            fg.addFactor(["x%d" % (3 * k + 1), lms[k], "gl%d" % k], sight(), multihypo=[1.0, 0.5, 0.5])
+        else:
+            fg.addFactor(["x%d" % (3 * k + 1), "gl%d" % k], sight())
+    R.dead_reckon_init(fg, seed=7 + rank)
+    sim = fg._sim
+    for l, t in fg.variables.items():
+        if t is R.Point2:
+            c = np.asarray(sim[l]) if l in sim else np.array([5.0 * rank, 3.0])
+            fg.initVariable(l, c[:, None] + 0.5 * rng.standard_normal((2, N)))
+    return fg
+
+
+def _beehive_layout(pk, d):
+    """published rows: Pose2 slots = the proposals of x_p from their incoming honeycomb leg (p2p2 rows), Point2 slots = the first
+    bearing-range -> landmark row of the first five landmarks"""
+    rows_p = []
+    for p in _BH_POSES:
+        f = int(np.nonzero((pk.p2p2["var_from"] == pk.index["x%d" % (p - 1)]) & (pk.p2p2["var_to"] == pk.index["x%d" % p]))[0][0])
+        rows_p.append(2 * f)
+    r0 = d.family_table("br0")["rows4"].numpy()
+    lm_idx = [pk.index[l] for l in pk.labels[__import__("rome_jl_amd").Point2][:_BH_LMS]]
+    rows_l = [int(np.nonzero(r0[:, 3] == li)[0][0]) for li in lm_idx]
+    return rows_p, rows_l
+
+
+def _beehive_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import rome_jl_amd as R
+        import oracle as ro
+        from rome_jl_amd.distributed import SeparatorPipeline
+        N = 16
+        fg = _beehive_segment(R, rank, N)
+        dg = _OracleDG(R, fg, 0)
+        pk = dg.packed
+        rows_p, rows_l = _beehive_layout(pk, dg)
+        pipe = SeparatorPipeline(dg, ro.make_opts(N=N, stream_offset=rank << 32), dist, world, rank,
+                                 publish=[("p2p2", r) for r in rows_p] + [("br0", r) for r in rows_l],
+                                 ghosts=[(R.Pose2, pk.index["gp%d" % k], rank - 1, k) for k in range(len(_BH_POSES))] +
+                                        [(R.Point2, pk.index["gl%d" % k], rank - 1, k) for k in range(_BH_LMS)])
+        hist = []
+        for k in range(4):
+            pipe.step()
+            hist.append({f: pipe.out[k % 2][f].clone().numpy() for f in pipe.families})
+        pipe.drain()
+        ret[rank] = hist
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_beehive_multihypo_lattice_cut_two_ranks_matches_emulation():
+    world = 2
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_beehive_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import rome_jl_amd as R
+    import oracle as ro
+    N = 16
+    dgs = [_OracleDG(R, _beehive_segment(R, r, N), 0) for r in range(world)]
+    lay = [_beehive_layout(d.packed, d) for d in dgs]
+    assert any(d.family_table("br1")["alt"] is not None for d in dgs)
+    hist = [[] for _ in range(world)]
+    for k in range(4):
+        for r, d in enumerate(dgs):
+            pk = d.packed
+            bel = {vt: d.bel[vt].clone() for vt in (R.Pose2, R.Point2)}
+            if k >= 2:   # step k reads what the previous rank published in step k-2
+                src = (r - 1) % world
+                for s, row in enumerate(lay[src][0]):
+                    bel[R.Pose2][pk.index["gp%d" % s]] = torch.as_tensor(hist[src][k - 2]["p2p2"][row])
+                for s, row in enumerate(lay[src][1]):
+                    bel[R.Point2][pk.index["gl%d" % s]] = torch.as_tensor(hist[src][k - 2]["br0"][row])
+            outs = {}
+            for f in d.families():
+                tb = d.family_table(f)
+                out = torch.zeros((tb["n"], tb["vt_target"].dim, N), dtype=torch.float64)
+                mh = {} if tb["alt"] is None else dict(alt_var=tb["alt"], hypo_w=tb["w"])
+                d._plan(tb["fn"], ro.make_opts(N=N, stream_offset=r << 32), rows4=tb["rows4"], mu=tb["mu"], L=tb["L"],
+                        bel_fixed=bel[tb["vt_fixed"]], bel_target=bel[tb["vt_target"]], out=out, **mh)()
+                outs[f] = out.numpy()
+            hist[r].append(outs)
+    for r in range(world):
+        for k in range(4):
+            for f in ("p2p2", "br1", "br0"):
+                assert np.array_equal(ret[r][k][f], hist[r][k][f]), (r, k, f)
+    # the ghosts really arrive: proposals through the cut legs change once the messages are in
+    assert not np.array_equal(ret[0][2]["p2p2"], ret[0][0]["p2p2"]) and not np.array_equal(ret[1][2]["br1"], ret[1][0]["br1"])
