@@ -324,20 +324,6 @@ def main():
             torch.cuda.synchronize()
             modes[name] = tb["C"] * reps / (time.perf_counter() - a)
         out["gpu_convolutions_per_s_by_solver"] = modes
-        # context: independent sweeps issued alternately on two streams overlap one launch's tail with the next one's ramp
-        # (what the N>1 path does to hide the separator join; the headline keeps one launch at a time so that the launch
-        # period is the kernel duration rocprofv3 reports)
-        pl2 = [dg.plan_sweep_pose2pose2(opts, torch.empty_like(prop)) for _ in range(2)]
-        st2 = [torch.cuda.Stream(dev) for _ in range(2)]
-        for st in st2:
-            st.wait_stream(torch.cuda.current_stream(dev))
-        def two_streams(reps):
-            for r in range(reps):
-                with torch.cuda.stream(st2[r & 1]):
-                    pl2[r & 1]()
-        two_streams(200); torch.cuda.synchronize()
-        a = time.perf_counter(); two_streams(2000); torch.cuda.synchronize()
-        out["gpu_convolutions_per_s_two_streams"] = tb["C"] * 2000 / (time.perf_counter() - a)
         # the other half of the metric ("solveTree! wall-clock"): one iteration of the device-resident solve loop on the
         # same graph = all convolutions (one launch) + the proposal product of every variable (one launch); DESIGN.md §11
         o3 = R.make_opts(N=N, solver=R.SOLVER_NEWTON, seed=0x524F4D45)
@@ -366,12 +352,49 @@ def main():
         out["solve_loop"]["ms_per_iteration_reference_product"] = (time.perf_counter() - a) * 1e3 / 5
         out["solve_loop"]["what_reference_product"] = "conv sweep + manikde! bandwidths of all proposals + multiscale Gibbs product (manifoldProduct restated) of all variables; whole-graph Jacobi schedule, no Bayes tree"
         dg.bel[R.Pose2].copy_(saved)
-        # ... and the whole pipeline a user runs on this graph: parametric solve (batched Jacobian kernel + sparse LM on the host)
-        # followed by 10 non-parametric iterations started from it
+        # ---- solve-level number (the other half of the metric): run to a stated convergence criterion with the reference's
+        # operations (conv sweep + manikde! bandwidths + multiscale Gibbs product per iteration, whole-graph Jacobi schedule).
+        # Start: the parametric solution (IIF initialises the non-parametric solve from solveGraphParametric: initParametricFrom!).
+        # Criterion: the RMS distance of the pose means to the parametric solution changes by < 1e-3 m over a block of 5 iterations.
+        def pose_means():
+            m, _ = dg.belief_stats(R.Pose2)
+            return m.cpu().numpy()[:len(pk.labels[R.Pose2])]
         a = time.perf_counter(); xp = R.solveGraphParametric(fg); t_par = time.perf_counter() - a
+        mp = np.array([xp[l] for l in pk.labels[R.Pose2]])
+
+        def rms_to_parametric():
+            d = pose_means() - mp
+            return float(np.sqrt(np.mean(np.sum(d[:, :2] ** 2, axis=1))))
+        rms_dead = rms_to_parametric()
         dg.init_from_means(xp); torch.cuda.synchronize()
-        a = time.perf_counter(); dg.solve(o3, n_sweeps=10); torch.cuda.synchronize(); t_np = time.perf_counter() - a
-        out["solve_loop"]["pipeline_seconds"] = {"parametric_solve": t_par, "ten_nonparametric_iterations": t_np}
+        trace = [rms_to_parametric()]
+        it, t_np, conv_at = 0, 0.0, None
+        while it < 200:
+            torch.cuda.synchronize(); a = time.perf_counter()
+            for s in range(5):
+                dg.conv_step(o3, 1000 + it + s); dg.product_step(o3, 1000 + it + s, "lcv", "gibbs")
+            torch.cuda.synchronize(); t_np += time.perf_counter() - a
+            it += 5
+            trace.append(rms_to_parametric())
+            if it >= 10 and abs(trace[-1] - trace[-2]) < 1e-3:
+                conv_at = it
+                break
+        out["solve"] = {"what": "Manhattan-3500, N=100: parametric solve (batched Jacobian kernel + sparse LM on the host) -> non-parametric iterations "
+                                "(conv sweep + manikde! bandwidths + multiscale Gibbs product; whole-graph Jacobi schedule, no Bayes tree) until the RMS "
+                                "distance of the pose means to the parametric solution changes by < 1e-3 m over 5 iterations",
+                        "parametric_solve_s": t_par, "nonparametric_iterations": conv_at, "nonparametric_s": t_np, "wall_clock_s": t_par + t_np,
+                        "rms_translation_to_parametric_m": trace[-1], "rms_trace_every_5_iterations": trace,
+                        "converged": conv_at is not None}
+        # the same loop started from the dead-reckoned beliefs: a Jacobi schedule moves information one factor per iteration, so
+        # the 3500-pose chain does NOT converge in any practical number of iterations (the reference's solveTree! eliminates on
+        # the Bayes tree instead) -- stated, not hidden
+        dg.bel[R.Pose2].copy_(saved); torch.cuda.synchronize()
+        a = time.perf_counter()
+        for s in range(100):
+            dg.conv_step(o3, 3000 + s); dg.product_step(o3, 3000 + s, "lcv", "gibbs")
+        torch.cuda.synchronize()
+        out["solve"]["from_dead_reckoning"] = {"rms_to_parametric_m_start": rms_dead, "rms_to_parametric_m_after_100_iterations": rms_to_parametric(),
+                                               "seconds_100_iterations": time.perf_counter() - a}
         dg.bel[R.Pose2].copy_(saved)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,5 +1,7 @@
 """Belief statistics, proposal product and the whole-graph solve loop on the GPU vs the oracle, plus the
 reference's statistical hexagon windows (test/testHexagonal2D_CliqByCliq.jl:37-79)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,7 @@ from solve_ref import solve_ref
 
 pytestmark = pytest.mark.gpu
 R = None
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -496,3 +499,22 @@ def test_initall_and_solvegraph_hexagonal():
     assert set(R.initAll(fg3)) == {"a", "b"}                      # no prior anywhere
     with pytest.raises(ValueError):
         R.solveGraph(fg3)
+
+
+@pytest.mark.timeout(900)
+def test_manhattan3500_two_solve_iterations_equal_the_oracle_loop():
+    """FULL-SIZE loop parity (BASELINE configs[1]): two iterations of the device solve loop with the reference's operations
+    (convolution sweep, manikde! bandwidths, multiscale Gibbs product) on the whole M3500 graph against the oracle's restatement of
+    the same loop under the shared RNG: every pose mean within 1e-3 (north_star tolerance), the particle sets almost identical."""
+    N, S = 100, 2
+    fg = R.loadG2o(os.path.join(GOLDEN, "manhattan.g2o"), N=N)
+    R.dead_reckon_init(fg, seed=11)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    dg.solve(R.make_opts(N=N, solver=1, seed=19), n_sweeps=S, bandwidth="lcv", product="gibbs")
+    got = dg.bel[R.Pose2].cpu().numpy()[:3500]
+    b2, _ = solve_ref(R, fg, S, N, seed=19, bandwidth="lcv", product="gibbs")
+    d = got - b2; d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    assert np.mean(np.abs(d) < 1e-6) > 0.97, np.mean(np.abs(d) < 1e-6)
+    m_d, _ = R.belief_stats(got); m_o, _ = R.belief_stats(b2)
+    dm = m_d - m_o; dm[:, 2] = np.arctan2(np.sin(dm[:, 2]), np.cos(dm[:, 2]))
+    assert np.abs(dm).max() < 1e-3, (np.abs(dm).max(), np.argmax(np.abs(dm).max(1)))
