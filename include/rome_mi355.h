@@ -62,8 +62,9 @@ enum {
  *   NEWTON        (default) unique-root factors (Pose2Pose2, PriorPose2, bearing-range -> landmark, Pose3Pose3): the root of the
  *                 residual is unique, so no start point or inflation cycle can change it: the kernel returns the analytic root
  *                 and, when a `status` array is given, evaluates the residual FUNCTOR there (status = max|r| <= tol ? 0 : 1).
- *                 The start points are not read.  Bearing-range -> pose: Newton iteration from the jittered start point to
- *                 max|r| <= tol (inflate_cycles x {entropy, iterate}).
+ *                 The start points are not read.  Bearing-range -> pose (a ring of roots): inflate_cycles x {entropy, the exact
+ *                 step onto the ring member the jittered start selects} -- the same points as CLOSED_FORM -- and the functor at
+ *                 the final point for `status`.
  *   NELDER_MEAD   Optim.jl's NelderMead() with its defaults on Σ r², i.e. the reference's algorithm, inflate_cycles x
  *                 {entropy, minimise} from the start points
  *   GAUSS_NEWTON  numerical root-find on the residual FUNCTOR itself (the reference's CalcFactor evaluated through points /

@@ -308,19 +308,6 @@ struct BR {
     double r[2]; functor(z, fx, t, r);
     return fmax(fabs(r[0]), fabs(r[1])) <= tol ? 0 : 1;
   }
-  // pose direction, Newton: residual in the solver form, block step along the ray
-  __device__ static __forceinline__ bool newton_step(const double (&z)[2], const double (&fx)[DF], double (&t)[DT], double tol) {
-    static_assert(DIR == 1, "the landmark direction returns its unique root directly");
-    const double dx = fx[0] - t[0], dy = fx[1] - t[1];
-    const double n2 = dx * dx + dy * dy;
-    const double n = fast_sqrt(n2), psi = fast_atan2(dy, dx);
-    const double r0 = sym_rem(z[0] - (psi - t[2])), r1 = z[1] - n;
-    const bool ok = fmax(fabs(r0), fabs(r1)) <= tol;
-    const double k = n > 0.0 ? z[1] / n : 0.0;                       // pose coincides with the landmark: leave along +x
-    const double nx = n > 0.0 ? fx[0] - k * dx : fx[0] - z[1], ny = fx[1] - k * dy;
-    t[0] = ok ? t[0] : nx; t[1] = ok ? t[1] : ny; t[2] = ok ? t[2] : psi - z[0];
-    return ok;
-  }
   // Gauss-Newton on the functor (the oracle's br_newton): r through residual_bearingrange at the current point;
   //   DIR 0: exact Newton step in the pose-frame polar chart of the landmark, (φ, n) += (r0, r1);  DIR 1: the block step along the ray
   __device__ static __forceinline__ int gauss_newton(const double (&z)[2], const double (&fx)[DF], double (&t)[DT], int max_iters, double tol) {
@@ -355,11 +342,12 @@ struct BR {
       const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
       t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = fast_atan2(uy, ux) - z[0];
     } else if constexpr (SOLVER == kSolverNewton) {
-      bool ok = false;
-      if (max_iters > 0) ok = newton_step(z, fx, t, tol);   // lands on a root
-      if (max_iters > 1) ok = newton_step(z, fx, t, tol);   // evaluates the residual there (wave-uniform branches)
-      st = ok ? 0 : 1;
-      for (int it = 2; it < max_iters && st; ++it) st = newton_step(z, fx, t, tol) ? 0 : 1;
+      // pose direction: the block step from ANY start lands exactly on the member of the ring of roots that the start selects (the
+      // closed form above IS that step); the residual there is evaluated only for the status array (verify_ring, after the last cycle)
+      const double dx = fx[0] - t[0], dy = fx[1] - t[1];
+      const double n = fast_sqrt(dx * dx + dy * dy);
+      const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
+      t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = fast_atan2(uy, ux) - z[0];
     } else if constexpr (SOLVER == kSolverGaussNewton) {
       st = gauss_newton(z, fx, t, max_iters, tol);
     } else {
@@ -817,8 +805,8 @@ k_conv(const ConvArgs a) {
       if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) break;   // wave-uniform
     }
   }
-  // NEWTON on a unique-root factor: the status is the residual FUNCTOR evaluated at the returned root (only when asked for)
-  if constexpr (SOLVER == kSolverNewton && FP::kUniqueRoot) {
+  // NEWTON: the status is the residual FUNCTOR evaluated at the returned root (only when asked for)
+  if constexpr (SOLVER == kSolverNewton) {
     if (a.status) {
 #pragma unroll
       for (int k = 0; k < PPL; ++k)
@@ -1112,7 +1100,7 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
             FP::add_entropy(t[k], aux[k], spread, u);
           }
           int st = FP::template solve<SOLVER>(K, prep, z[k], fx[k], t[k], aux[k], a.max_iters, a.tol);
-          if constexpr (SOLVER == kSolverNewton && FP::kUniqueRoot) { if (a.status) st = FP::verify(K, z[k], fx[k], t[k], aux[k], a.tol); }
+          if constexpr (SOLVER == kSolverNewton) { if (a.status) st = FP::verify(K, z[k], fx[k], t[k], aux[k], a.tol); }
           bad |= st;
           FP::finalize(t[k], aux[k]);
 #pragma unroll
@@ -1314,10 +1302,11 @@ static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
   if constexpr (FP::kUniqueRoot && (SOLVER == kSolverClosedForm || SOLVER == kSolverNewton)) {
     // plain sweep of a unique-root factor: the packed kernel (rows of >= 8 pair-threads; tiny N stays one wavefront per row)
     if (lean && a.N >= 16 && (a.N + 1) / 2 <= kFlatThreads) return launch_flat<FP, SOLVER>(a, s);
-    // NEWTON without a status array IS the closed form on these factors: one instantiation (the functor evaluation of the
-    // status path would otherwise pin the register allocation of the plain launch)
-    if constexpr (SOLVER == kSolverNewton) { if (!a.status) return launch_ppl<FP, kSolverClosedForm>(a, s); }
   }
+  // NEWTON without a status array IS the closed form on every factor here (unique roots; the bearing-range pose direction steps
+  // exactly onto the ring member its start selects): one instantiation (the functor evaluation of the status path would otherwise
+  // pin the register allocation of the plain launch)
+  if constexpr (SOLVER == kSolverNewton) { if (!a.status) return launch_ppl<FP, kSolverClosedForm>(a, s); }
   return lean ? launch_ppl_v<FP, SOLVER, true>(a, s) : launch_ppl_v<FP, SOLVER, false>(a, s);
 }
 template <class FP>

@@ -20,16 +20,26 @@ def timeit(fn, reps):
 fg = R.synth_helix3d(P=10000, N=100); R.dead_reckon_init_pose3(fg, seed=2)
 dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
 tb = dg.tab["p3p3"]; out = torch.empty((tb["C"], 6, 100), dtype=torch.float64, device="cuda")
-for name, sv, reps in (("closed_form", 0, 20), ("newton", 1, 20), ("nelder_mead", 2, 2)):
+QUICK = os.environ.get("ROME_OTHER_QUICK") == "1"   # profiling passes: few launches, no Nelder-Mead on the big tables
+SOLVERS = (("closed_form", 0), ("newton", 1), ("gauss_newton", 3), ("nelder_mead", 2))
+# algorithmic bytes per particle (in-kernel RNG): unique-root closed form / Newton do not read the start point u0
+B_P3 = {"closed_form": 96, "newton": 96, "gauss_newton": 144, "nelder_mead": 144}
+B_BR0 = {"closed_form": 40, "newton": 40, "gauss_newton": 56, "nelder_mead": 56}   # pose 24 (+ u0 16) + landmark 16
+B_BR1 = {k: 64 for k in B_P3}                                                       # landmark 16 + u0 24 + pose 24
+for name, sv in SOLVERS:
+    if QUICK and name == "nelder_mead": continue
+    reps = 2 if name == "nelder_mead" else (3 if QUICK else 20)
     o = R.make_opts(N=100, solver=sv)
     ms = timeit(lambda: dg.sweep_pose3pose3(o, out=out), reps)
-    print("Pose3Pose3 helix: %6d convs %-11s %9.3f ms/sweep  %.3e conv/s  %7.1f GB/s algorithmic" % (tb["C"], name, ms, tb["C"] / ms * 1e3, tb["C_rel"] * 100 * 144 / ms / 1e6))
+    print("Pose3Pose3 helix: %6d convs %-12s %9.4f ms/sweep  %.3e conv/s  %7.1f GB/s algorithmic (%d B/particle) = %.2f of 8 TB/s" % (tb["C"], name, ms, tb["C"] / ms * 1e3, tb["C_rel"] * 100 * B_P3[name] / ms / 1e6, B_P3[name], tb["C_rel"] * 100 * B_P3[name] / ms / 1e6 / 8000))
 del dg
 fg = R.synth_mit_br(P=8080, n_landmarks=2000, N=100); R.dead_reckon_init(fg, seed=4)
 dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
 F = dg.tab["br"]["F"]
 for d in (0, 1):
-    for name, sv, reps in (("closed_form", 0, 50), ("newton", 1, 50), ("nelder_mead", 2, 5)):
+    for name, sv in SOLVERS:
+        reps = 5 if name == "nelder_mead" else (3 if QUICK else 50)
         o = R.make_opts(N=100, solver=sv)
         ms = timeit(lambda: dg.sweep_bearingrange(o, d), reps)
-        print("BearingRange dir %d: %6d convs %-11s %9.3f ms/sweep  %.3e conv/s" % (d, F, name, ms, F / ms * 1e3))
+        B = (B_BR0 if d == 0 else B_BR1)[name]
+        print("BearingRange dir %d: %6d convs %-12s %9.4f ms/sweep  %.3e conv/s  %7.1f GB/s algorithmic (%d B/particle) = %.2f of 8 TB/s" % (d, F, name, ms, F / ms * 1e3, F * 100 * B / ms / 1e6, B, F * 100 * B / ms / 1e6 / 8000))
