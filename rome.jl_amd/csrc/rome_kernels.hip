@@ -61,17 +61,16 @@ struct P2P2Cost {
 template <int PPL>
 __device__ __forceinline__ double spread_se2(const double (&t)[PPL][3], const bool (&act)[PPL], double inv, double den) {
   const double x0 = readlane_f64(t[0][0], 0), y0 = readlane_f64(t[0][1], 0), th0 = readlane_f64(t[0][2], 0);
-  double s[6] = {0, 0, 0, 0, 0, 0};
+  double s[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {
     const double dx = t[k][0] - x0, dy = t[k][1] - y0, dt = wrap_pi(t[k][2] - th0);
-    if (act[k]) { s[0] += dx; s[1] += dx * dx; s[2] += dy; s[3] += dy * dy; s[4] += dt; s[5] += dt * dt; }
+    if (act[k]) { s[0] += dx; s[1] += dy; s[2] += dt; s[3] += dx * dx + dy * dy + dt * dt; }
   }
-  wave_sum_n<6>(s);
-  const double vx = fmax(0.0, (s[1] - s[0] * s[0] * inv) * den);
-  const double vy = fmax(0.0, (s[3] - s[2] * s[2] * inv) * den);
-  const double vt = fmax(0.0, (s[5] - s[4] * s[4] * inv) * den);
-  return fast_sqrt(vx + vy + vt);   // Manifolds.std: root of the corrected Fréchet variance (sum of the coordinate variances)
+  // only the SUM of the coordinate variances is needed:  Σ_k var_k = (Σ_i |d_i|² − Σ_k (Σ_i d_ik)² / N) / (N − 1) -> four wave sums
+  wave_sum_n<4>(s);
+  const double v = fmax(0.0, (s[3] - (s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) * inv) * den);
+  return fast_sqrt(v);   // Manifolds.std: root of the corrected Fréchet variance (sum of the coordinate variances)
 }
 template <int PPL>
 __device__ __forceinline__ double spread_r2(const double (&t)[PPL][2], const bool (&act)[PPL], double inv, double den) {
@@ -331,23 +330,30 @@ struct BR {
     }
     return 1;
   }
+  // pose direction: move along the ray landmark -> pose to the measured range, then turn to the measured bearing.  One reciprocal
+  // square root (v_rsq_f64 + two Newton steps) serves the unit vector; the world bearing is atan2 of the ray itself.
+  __device__ static __forceinline__ void ring_step(const double (&z)[2], const double (&fx)[DF], double (&t)[DT]) {
+    const double dx = fx[0] - t[0], dy = fx[1] - t[1];
+    const double n2 = dx * dx + dy * dy;
+    double y = __builtin_amdgcn_rsq(n2);
+    y = y * __builtin_fma(-0.5 * n2 * y, y, 1.5);
+    y = y * __builtin_fma(-0.5 * n2 * y, y, 1.5);
+    const bool ok = n2 > 0.0;                                   // pose on the landmark: leave along +x
+    const double k = ok ? z[1] * y : 0.0;
+    t[0] = ok ? fx[0] - k * dx : fx[0] - z[1]; t[1] = fx[1] - k * dy;
+    if constexpr (DT == 3) t[2] = (ok ? fast_atan2(dy, dx) : 0.0) - z[0];
+  }
   template <int SOLVER>
   __device__ static __forceinline__ int solve(const Consts&, const Prep& P, const double (&z)[2], const double (&fx)[DF],
                                               double (&t)[DT], Aux&, int max_iters, double tol) {
     int st = 0;
     if constexpr (DIR == 0 && (SOLVER == kSolverClosedForm || SOLVER == kSolverNewton)) { t[0] = P.a0; t[1] = P.a1; return 0; }
     else if constexpr (SOLVER == kSolverClosedForm) {
-      const double dx = fx[0] - t[0], dy = fx[1] - t[1];
-      const double n = fast_sqrt(dx * dx + dy * dy);
-      const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
-      t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = fast_atan2(uy, ux) - z[0];
+      ring_step(z, fx, t);
     } else if constexpr (SOLVER == kSolverNewton) {
       // pose direction: the block step from ANY start lands exactly on the member of the ring of roots that the start selects (the
       // closed form above IS that step); the residual there is evaluated only for the status array (verify_ring, after the last cycle)
-      const double dx = fx[0] - t[0], dy = fx[1] - t[1];
-      const double n = fast_sqrt(dx * dx + dy * dy);
-      const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
-      t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = fast_atan2(uy, ux) - z[0];
+      ring_step(z, fx, t);
     } else if constexpr (SOLVER == kSolverGaussNewton) {
       st = gauss_newton(z, fx, t, max_iters, tol);
     } else {
