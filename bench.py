@@ -150,6 +150,7 @@ def main():
     pipe = None
     comms = None
     depth = 0
+    strong_unit = "convolution sweep"
     if strong:
         from rome_jl_amd.distributed import TargetShardedSweep
         comm = None
@@ -163,7 +164,18 @@ def main():
         pipe = TargetShardedSweep(dg, opts, dist, world, rank, always_collective=(world == 1), rccl_comm=comm)
         comms = [comm] if comm else None
         n_conv_step = tb["C"]          # the whole graph per step, over all ranks
-        sweep = pipe.step
+        # the unit that shards is the SOLVE iteration (sweep of the owned rows + manikde! bandwidths + multiscale Gibbs product of the
+        # owned variables, ~2.9 ms on one GPU), followed by ONE all-gather of the changed beliefs; a conv-only step (8 µs) would be
+        # all exchange.  ROME_BENCH_STRONG_CONV_ONLY=1 times that conv-only step instead (context).
+        if os.environ.get("ROME_BENCH_STRONG_CONV_ONLY") == "1":
+            sweep = pipe.step
+        else:
+            _it = [0]
+
+            def sweep():
+                pipe.solve_step(opts, sweep=_it[0]); _it[0] += 1
+            args.settle_launches = min(args.settle_launches, 50)
+            strong_unit = "solve iteration"
     elif multi:
         from rome_jl_amd.distributed import PipelinedSegmentSweep
         # proposal rows that carry the updated separator estimates (odometry convolutions targeting them)
@@ -264,8 +276,8 @@ def main():
         "config": {"workload": workload, "poses_per_gpu": len(pk.labels[R.Pose2]), "pose2pose2_factors_per_gpu": tb["F"],
                    "convolutions_per_step_per_gpu": (pipe.n_rows if strong else n_conv_step), "particles": N, "solver": args.solver,
                    "inflate_cycles": int(opts.inflate_cycles), "inflation": float(opts.inflation), "noise": "in-kernel philox",
-                   "parallelism": ("ONE graph: rows sharded by target ownership (%d of %d on rank 0), all_gather of the owned belief blocks (%s)"
-                                   % (pipe.n_rows, tb["C"], "RCCL direct, in place" if comms else "torch.distributed")) if strong else
+                   "parallelism": ("ONE graph, one %s per step: rows sharded by target ownership (%d of %d on rank 0), all_gather of the owned belief blocks (%s)"
+                                   % (strong_unit, pipe.n_rows, tb["C"], "RCCL direct, in place" if comms else "torch.distributed")) if strong else
                                   (("1 graph segment per GPU, separator all_gather (%s, pipeline depth %d)" % ("RCCL direct" if comms else "torch.distributed", depth))
                                    if multi else "single GPU"),
                    "ranks_seen_by_rccl": (dist.get_world_size() if multi else 1)},

@@ -54,6 +54,15 @@ enum {
 #define ROME_MAX_PARTICLES 4096   /* convolutions / prior sampling: N <= 512 lives in registers, larger N is walked in chunks of 128;
                                     the KDE and importance-product entries take N <= 512, the Gibbs product N <= 128 */
 #define ROME_MAX_PARTICLES_REGISTER 512
+/* per-stage particle limits of ONE solve iteration (every entry fails with ROME_ERR_UNSUPPORTED_N / ROME_ERR_INVALID_ARG above its
+ * limit, nothing is truncated; rome_jl_amd.solveGraph / DeviceGraph.solve check them before the first launch):
+ *   convolutions / prior sampling  ROME_MAX_PARTICLES (4096)      manikde! bandwidths, getKDEMax   ROME_MAX_PARTICLES_KDE (512)
+ *   importance product             ROME_MAX_PARTICLES_PRODUCT (512; Pose3: 256)
+ *   multiscale Gibbs product, rome_clique_upsolve                 ROME_MAX_PARTICLES_GIBBS (128) */
+#define ROME_MAX_PARTICLES_KDE 512
+#define ROME_MAX_PARTICLES_PRODUCT 512
+#define ROME_MAX_PARTICLES_PRODUCT_POSE3 256
+#define ROME_MAX_PARTICLES_GIBBS 128
 
 /* Solvers for the per-particle root-find (replaces Optim.optimize(cost, X0c, NelderMead()) in IIF
  * `_solveLambdaNumeric`, called for every particle of every convolution):

@@ -301,9 +301,37 @@ class DeviceGraph:
     def solve(self, opts, n_sweeps=10, bandwidth="silverman", product="importance", gibbs_iters=1):
         """n_sweeps x (convolution sweep, product): whole-graph nonparametric inference, a Jacobi schedule in place of the
         clique-by-clique Gibbs of `solveTree!` (no Bayes tree)."""
+        self.check_particle_limits(bandwidth, product)
         for s in range(n_sweeps):
             self.conv_step(opts, s)
             self.product_step(opts, s, bandwidth, product, gibbs_iters)
+
+    # ---- row-range forms of the two `next` stages, as the sharded drivers call them (rome_jl_amd.distributed) ----
+    def kde_bandwidth_rows(self, dim, n_rows, prop, circ, bw_out):
+        """manikde! bandwidths of `n_rows` proposal blocks (a contiguous device slice) -> bw_out [n_rows][dim]"""
+        self._bind_stream()
+        _lib.check(self._lib.rome_kde_bandwidth_dev(self.ctx.handle, dim, n_rows, self.N, prop.data_ptr(), circ, 0.0, 0.0, bw_out.data_ptr()),
+                   self.ctx.handle)
+
+    def product_gibbs_rows(self, opts, dim, V, ptr, rows, prop, bw, n_rows, bel_in, bel_out, circ, iters, max_k):
+        """multiscale Gibbs product of V variables whose proposals are `rows` (CSR `ptr`) of the slice `prop` / `bw`"""
+        self._bind_stream()
+        _lib.check(self._lib.rome_product_gibbs_dev(self.ctx.handle, C.byref(opts), dim, V, ptr.data_ptr(), rows.data_ptr(), prop.data_ptr(),
+                                                    bw.data_ptr(), n_rows, bel_in.data_ptr(), bel_out.data_ptr(), circ, iters, max_k),
+                   self.ctx.handle)
+
+    def check_particle_limits(self, bandwidth="silverman", product="importance"):
+        """The stages of one solve iteration have different particle limits (include/rome_mi355.h): fail BEFORE the first launch,
+        naming the stage, instead of part-way through an iteration."""
+        N = self.N
+        if product == "gibbs" and N > _lib.MAX_PARTICLES_GIBBS:
+            raise ValueError("product='gibbs' (multiscale Gibbs product, the reference's manifoldProduct) takes N <= %d particles; this graph has "
+                             "N = %d.  Use product='importance' (N <= %d) or fewer particles." % (_lib.MAX_PARTICLES_GIBBS, N, _lib.MAX_PARTICLES_PRODUCT))
+        if (bandwidth == "lcv" or product == "gibbs") and N > _lib.MAX_PARTICLES_KDE:
+            raise ValueError("manikde! bandwidths (bandwidth='lcv') take N <= %d particles; N = %d" % (_lib.MAX_PARTICLES_KDE, N))
+        lim = _lib.MAX_PARTICLES_PRODUCT_POSE3 if self.bel[Pose3].shape[0] else _lib.MAX_PARTICLES_PRODUCT
+        if product == "importance" and N > lim:
+            raise ValueError("the importance product takes N <= %d particles here; N = %d (convolution sweeps alone go to %d)" % (lim, N, _lib.MAX_PARTICLES))
 
     def init_from_means(self, means, sigma=None, seed=3):
         """Beliefs = per-variable mean ⊕ N(0, diag σ²) jitter: e.g. means from solveGraphParametric (IIF can

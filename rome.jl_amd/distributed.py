@@ -359,8 +359,6 @@ class TargetShardedSweep:
         those proposals, multiscale Gibbs product (manifoldProduct) of the owned variables -- whose proposals are a contiguous
         row range of the target-sorted table -- then the all-gather of the owned beliefs.  Everything but the final exchange is
         rank-local; bandwidths and product (5.7 of the 5.9 ms of a Manhattan iteration) shard perfectly."""
-        import ctypes as C
-        from . import _lib
         dg, torch = self.dg, self.dg.torch
         self.wait()
         if not hasattr(self, "_solve"):
@@ -377,21 +375,17 @@ class TargetShardedSweep:
         S = self._solve
         d, N = self.store.shape[1], self.store.shape[2]
         circ = 0b100 if d == 3 else 0
-        lib, h = dg._lib, dg.ctx.handle
-        dg._bind_stream()
         o = type(opts).from_buffer_copy(opts)
         o.stream_offset = opts.stream_offset + (sweep << 32) + self.row_lo
         lo_v, q = self.rank * self.q, self.q
         if self.n_rows:
-            # the sweep of the owned rows with this iteration's Philox streams
+            # the sweep of the owned rows with this iteration's Philox streams, then the manikde! bandwidths of those proposals
             self._sweep_plan(o)()
-            _lib.check(lib.rome_kde_bandwidth_dev(h, d, self.n_rows, N, self.prop[self.row_lo:self.row_hi].data_ptr(), circ, 0.0, 0.0,
-                                                  S["bw"][self.row_lo:self.row_hi].data_ptr()), h)
+            dg.kde_bandwidth_rows(d, self.n_rows, self.prop[self.row_lo:self.row_hi], circ, S["bw"][self.row_lo:self.row_hi])
         op = type(opts).from_buffer_copy(opts)
         op.stream_offset = opts.stream_offset + (sweep << 32) + dg.STREAM_PROD2 + lo_v      # product stream = global variable id
-        _lib.check(lib.rome_product_gibbs_dev(h, C.byref(op), d, q, S["ptr"].data_ptr(), S["rows"].data_ptr(),
-                                              self.prop[self.row_lo:].data_ptr(), S["bw"][self.row_lo:].data_ptr(), self.n_rows,
-                                              self.mine.data_ptr(), S["out"].data_ptr(), circ, int(gibbs_iters), S["max_k"]), h)
+        dg.product_gibbs_rows(op, d, q, S["ptr"], S["rows"], self.prop[self.row_lo:], S["bw"][self.row_lo:], self.n_rows,
+                              self.mine, S["out"], circ, int(gibbs_iters), S["max_k"])
         self.mine.copy_(S["out"])
         self.exchange()
 

@@ -36,6 +36,10 @@ def _load(torch):
         lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         lib.ncclGetErrorString.restype = C.c_char_p
         lib.ncclGetErrorString.argtypes = [C.c_int]
+        lib.ncclGroupStart.restype = C.c_int
+        lib.ncclGroupStart.argtypes = []
+        lib.ncclGroupEnd.restype = C.c_int
+        lib.ncclGroupEnd.argtypes = []
         _lib = lib
     return _lib
 
@@ -43,12 +47,9 @@ def _load(torch):
 class RcclComm:
     """One communicator; `all_gather_f64(send_ptr, recv_ptr, count, stream_ptr)` enqueues ncclAllGather on the given HIP stream."""
 
-    def __init__(self, lib, world, rank, uid):
+    def __init__(self, lib, handle):
         self._lib = lib
-        self.comm = C.c_void_p()
-        rc = lib.ncclCommInitRank(C.byref(self.comm), int(world), uid, int(rank))
-        if rc != 0:
-            raise RuntimeError("ncclCommInitRank: %s" % lib.ncclGetErrorString(rc).decode())
+        self.comm = handle
         self._ag = lib.ncclAllGather
 
     def all_gather_f64(self, send_ptr, recv_ptr, count, stream_ptr):
@@ -62,9 +63,29 @@ class RcclComm:
             self.comm = C.c_void_p()
 
 
+def _init_group(torch, device, lib, world, rank, uids, out):
+    """ALL n communicators inside ONE ncclGroupStart / ncclGroupEnd: every rank enters the same single collective initialisation
+    (no rank can sit inside ncclCommInitRank of communicator k while another one has already given up on communicator k-1)."""
+    if getattr(device, "type", "cpu") == "cuda":
+        torch.cuda.set_device(device)   # (the current HIP device is per thread: the watchdog thread starts on device 0)
+    handles = [C.c_void_p() for _ in uids]
+    rc = lib.ncclGroupStart()
+    if rc == 0:
+        for h, uid in zip(handles, uids):
+            r = lib.ncclCommInitRank(C.byref(h), int(world), uid, int(rank))
+            rc = rc or r
+        r = lib.ncclGroupEnd()
+        rc = rc or r
+    out["rc"], out["handles"] = rc, handles
+
+
 def create_comms(torch, dist, world, rank, device, n):
-    """n independent communicators over the ranks of the default process group, or None (on every rank) if any rank failed."""
-    comms, ok = [], 1
+    """n independent communicators over the ranks of the default process group, or None -- ON EVERY RANK -- if anything failed
+    anywhere.  Failure is agreed ONCE before the collective initialisation (unique ids) and ONCE after it; the initialisation
+    itself is one ncclGroup over all n communicators, run under a watchdog (ROME_RCCL_INIT_TIMEOUT_S, default 120 s): a rank whose
+    peers never arrive reports failure through torch.distributed instead of blocking its main thread forever."""
+    import threading
+    comms, ok, lib = [], 1, None
     try:
         lib = _load(torch)
         ids = torch.zeros((n, NCCL_UNIQUE_ID_BYTES), dtype=torch.uint8, device=device)
@@ -79,28 +100,35 @@ def create_comms(torch, dist, world, rank, device, n):
         ok = 0
         ids = torch.zeros((n, NCCL_UNIQUE_ID_BYTES), dtype=torch.uint8, device=device)
     if world > 1:
-        # agree BEFORE the (collective, blocking) ncclCommInitRank calls: either every rank enters them or none does
+        # agree BEFORE the (collective, blocking) initialisation: either every rank enters it or none does
         pre = torch.tensor([ok], dtype=torch.int32, device=device)
         dist.all_reduce(pre, op=dist.ReduceOp.MIN)
         ok = int(pre.item())
         if ok:
             dist.broadcast(ids, src=0)
+    handles = []
     if ok:
         try:
             host = ids.cpu().numpy()
-            for k in range(n):
-                uid = _UniqueId.from_buffer_copy(host[k].tobytes())
-                comms.append(RcclComm(lib, world, rank, uid))
+            uids = [_UniqueId.from_buffer_copy(host[k].tobytes()) for k in range(n)]
+            res = {}
+            th = threading.Thread(target=_init_group, args=(torch, device, lib, world, rank, uids, res), daemon=True)
+            th.start()
+            th.join(float(os.environ.get("ROME_RCCL_INIT_TIMEOUT_S", "120")))
+            if th.is_alive() or res.get("rc", 1) != 0:
+                ok = 0     # (a thread still inside ncclGroupEnd is left behind: its communicators are never used)
+            else:
+                handles = res["handles"]
         except Exception:   # noqa: BLE001
             ok = 0
     flag = torch.tensor([ok], dtype=torch.int32, device=device)
     if world > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
-        for c in comms:
+        for h in handles:
             try:
-                c.close()
+                lib.ncclCommDestroy(h)
             except Exception:   # noqa: BLE001
                 pass
         return None
-    return comms
+    return [RcclComm(lib, h) for h in handles]

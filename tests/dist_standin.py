@@ -51,10 +51,11 @@ class OracleDG:
             mirror_rows = [int(np.nonzero(mm == m)[0][0]) for m in range(int(mm.max()) + 1)] if (mm >= 0).any() else ()
         alt = kw["alt_var"].numpy() if kw.get("alt_var") is not None else None
         hw = np.asarray(kw["hypo_w"], dtype=np.float64) if kw.get("hypo_w") is not None else None
-        base = int(opts.stream_offset) if opts is not None else 0
+        o_keep = type(opts).from_buffer_copy(opts) if opts is not None else None   # (a cached plan's stream offset may be updated in place)
         seed = self.seed
 
         def launch():
+            base = int(o_keep.stream_offset) if o_keep is not None else 0
             n = len(rows)
             res = np.zeros(tuple(out.shape))
             for k in range(n):   # one oracle call per row: Philox stream = base + row position, like the kernel
@@ -72,4 +73,17 @@ class OracleDG:
             for m, r in enumerate(mirror_rows):
                 blk = out[r].reshape(-1)
                 mirror_out[m * blk.numel():(m + 1) * blk.numel()].copy_(blk)
+        launch._keep = (None, o_keep)
         return launch
+
+    # ---- the row-range stages of TargetShardedSweep.solve_step, computed by the oracle ----
+    STREAM_PROD2 = 3 << 28
+
+    def kde_bandwidth_rows(self, dim, n_rows, prop, circ, bw_out):
+        bw_out.copy_(torch.as_tensor(self.ro.kde_bandwidths(prop[:n_rows].numpy(), circ)))
+
+    def product_gibbs_rows(self, opts, dim, V, ptr, rows, prop, bw, n_rows, bel_in, bel_out, circ, iters, max_k):
+        o = self.ro.make_opts(N=self.N, seed=self.seed, stream_offset=int(opts.stream_offset))
+        out = self.ro.product_msgibbs(o, dim, ptr.numpy(), rows.numpy(), prop[:max(n_rows, 1)].numpy(), bw[:max(n_rows, 1)].numpy(),
+                                      bel_in.numpy(), circ, iters)
+        bel_out.copy_(torch.as_tensor(out))

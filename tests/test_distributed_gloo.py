@@ -516,3 +516,56 @@ def test_beehive_multihypo_lattice_cut_two_ranks_matches_emulation():
                 assert np.array_equal(ret[r][k][f], hist[r][k][f]), (r, k, f)
     # the ghosts really arrive: proposals through the cut legs change once the messages are in
     assert not np.array_equal(ret[0][2]["p2p2"], ret[0][0]["p2p2"]) and not np.array_equal(ret[1][2]["br1"], ret[1][0]["br1"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# TargetShardedSweep.solve_step: the unit that strong-scales -- sweep of the owned rows, manikde! bandwidths, multiscale Gibbs product
+# of the owned variables, ONE all-gather of the changed beliefs -- over 3 ranks equals the single-rank sequence (partition-independent
+# Philox streams: row index / global variable id).
+def _solve_step_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import rome_jl_amd as R
+        import oracle as ro
+        from rome_jl_amd.distributed import TargetShardedSweep
+        N = 16
+        fg = R.synth_manhattan(P=40, loops=15, seed=9, N=N)
+        R.dead_reckon_init(fg, seed=2)
+        dg = _OracleDG(R, fg, 5)
+        o = ro.make_opts(N=N, seed=5, stream_offset=11)
+        sh = TargetShardedSweep(dg, o, dist, world, rank)
+        for s in range(2):
+            sh.solve_step(o, sweep=s)
+        sh.wait()
+        ret[rank] = (sh.store[:dg.bel[R.Pose2].shape[0]].numpy().copy(), (sh.row_lo, sh.row_hi))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_target_sharded_solve_step_three_ranks_equals_one_rank():
+    world = 3
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_solve_step_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import rome_jl_amd as R
+    import oracle as ro
+    from rome_jl_amd.distributed import TargetShardedSweep
+    N = 16
+    fg = R.synth_manhattan(P=40, loops=15, seed=9, N=N)
+    R.dead_reckon_init(fg, seed=2)
+    dg = _OracleDG(R, fg, 5)
+    o = ro.make_opts(N=N, seed=5, stream_offset=11)
+    one = TargetShardedSweep(dg, o, None, 1, 0)
+    before = one.store.clone()
+    for s in range(2):
+        one.solve_step(o, sweep=s)
+    V = dg.bel[R.Pose2].shape[0]
+    ref = one.store[:V].numpy()
+    assert not np.array_equal(ref, before[:V].numpy())
+    spans = sorted(ret[r][1] for r in range(world))
+    assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1)) and spans[-1][1] == one.prop.shape[0]
+    for r in range(world):
+        assert np.array_equal(ret[r][0], ref), r

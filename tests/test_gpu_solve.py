@@ -518,3 +518,24 @@ def test_manhattan3500_two_solve_iterations_equal_the_oracle_loop():
     m_d, _ = R.belief_stats(got); m_o, _ = R.belief_stats(b2)
     dm = m_d - m_o; dm[:, 2] = np.arctan2(np.sin(dm[:, 2]), np.cos(dm[:, 2]))
     assert np.abs(dm).max() < 1e-3, (np.abs(dm).max(), np.argmax(np.abs(dm).max(1)))
+
+
+def test_particle_limits_fail_before_the_first_launch():
+    """include/rome_mi355.h per-stage limits: the Gibbs product takes N <= 128, manikde! bandwidths and the importance product N <= 512;
+    DeviceGraph.solve / solveGraph name the stage and fail before any launch instead of part-way through an iteration."""
+    fg = R.generateGraph_Hexagonal(N=200)
+    R.dead_reckon_init(fg, seed=5)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    before = dg.bel[R.Pose2].clone()
+    with pytest.raises(ValueError, match="multiscale Gibbs product"):
+        dg.solve(R.make_opts(N=200, seed=3), n_sweeps=1, bandwidth="lcv", product="gibbs")
+    assert bool((dg.bel[R.Pose2] == before).all())
+    dg.solve(R.make_opts(N=200, seed=3), n_sweeps=1, bandwidth="lcv", product="importance")   # N = 200 is fine for these stages
+    fg2 = R.generateGraph_Hexagonal(N=600)
+    R.dead_reckon_init(fg2, seed=5)
+    dg2 = R.DeviceGraph(fg2); dg2.upload_beliefs(fg2)
+    with pytest.raises(ValueError, match="manikde"):
+        dg2.solve(R.make_opts(N=600, seed=3), n_sweeps=1, bandwidth="lcv")
+    with pytest.raises(ValueError, match="importance product"):
+        dg2.solve(R.make_opts(N=600, seed=3), n_sweeps=1)
+    dg2.conv_step(R.make_opts(N=600, seed=3), 0)                                               # convolution sweeps alone: up to 4096
