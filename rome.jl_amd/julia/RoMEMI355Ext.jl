@@ -182,17 +182,14 @@ end
 
 const _accelerated = Union{Pose2Pose2, PriorPose2, Pose2Point2BearingRange{<:Normal,<:Normal}, Pose3Pose3, PriorPose3}
 
-function IncrementalInference.proposalbeliefs!(dfg::AbstractDFG, destlbl::Symbol, factors::AbstractVector{<:DFGFactor},
-                                                dens::AbstractVector, measurement::AbstractVector=Tuple[];
-                                                solveKey::Symbol=:default, N::Integer=getSolverParams(dfg).N, kw...)
-  fast = [fc for fc in factors if getFactorType(fc) isa _accelerated && isnothing(getSolverData(fc).multihypo)]
-  slow = [fc for fc in factors if !(fc in fast)]
+# row tables of a list of (factor, destination) pairs over the variables they touch: what rome_clique_host carries
+function _clique_tables(dfg::AbstractDFG, pairs::AbstractVector; solveKey::Symbol=:default, extra_vars::AbstractVector{Symbol}=Symbol[])
   vidx = Dict{Symbol,Int32}(); vars = Dict(Pose2 => Symbol[], Point2 => Symbol[], Pose3 => Symbol[])
   var!(l) = get!(vidx, l) do; T = typeof(getVariableType(dfg, l)); push!(vars[T], l); Int32(length(vars[T]) - 1); end
   rows = Dict(:p2p2 => Int32[], :br1 => Int32[], :br0 => Int32[], :p3p3 => Int32[])
   tabμ = Dict(:p2p2 => Float64[], :br => Float64[], :p3p3 => Float64[]); tabΣ = Dict(:p2p2 => Float64[], :br => Float64[], :p3p3 => Float64[])
   nfac = Dict(:p2p2 => 0, :br => 0, :p3p3 => 0); order = Tuple{Symbol,Int}[]
-  for fc in fast
+  for (fc, destlbl) in pairs
     f = getFactorType(fc); vo = getVariableOrder(fc)
     if f isa Union{PriorPose2,PriorPose3}
       fam = f isa PriorPose2 ? :p2p2 : :p3p3
@@ -210,31 +207,108 @@ function IncrementalInference.proposalbeliefs!(dfg::AbstractDFG, destlbl::Symbol
     end
     push!(order, (fam, length(rows[fam]) ÷ 4))
   end
+  foreach(var!, extra_vars)
   # beliefs: the reference's point containers as they are for Pose2 (6 doubles) / Pose3 (12 doubles) = ROME_LAYOUT_AOS_POINTS
   blk(T) = isempty(vars[T]) ? Float64[] : reduce(vcat, [reinterpret(Float64, getVal(dfg, l; solveKey)) for l in vars[T]])
-  b2, bl, b3 = blk(Pose2), blk(Point2), blk(Pose3)
-  out(fam, w) = Vector{Float64}(undef, (length(rows[fam]) ÷ 4) * N * w)
+  (; vidx, vars, rows, tabμ, tabΣ, nfac, order, b2 = blk(Pose2), bl = blk(Point2), b3 = blk(Pose3))
+end
+_p(x) = isempty(x) ? Ptr{eltype(x)}(C_NULL) : pointer(x)
+_clique_host(t, o2, o1, o0, o3) =
+  RomeCliqueHost(length(t.vars[Pose2]), length(t.vars[Point2]), length(t.vars[Pose3]), 0, _p(t.b2), _p(t.bl), _p(t.b3),
+                 length(t.rows[:p2p2]) ÷ 4, t.nfac[:p2p2], _p(t.rows[:p2p2]), _p(t.tabμ[:p2p2]), _p(t.tabΣ[:p2p2]), _p(o2),
+                 length(t.rows[:br1]) ÷ 4, length(t.rows[:br0]) ÷ 4, t.nfac[:br], 0, _p(t.rows[:br1]), _p(t.rows[:br0]), _p(t.tabμ[:br]), _p(t.tabΣ[:br]), _p(o1), _p(o0),
+                 length(t.rows[:p3p3]) ÷ 4, t.nfac[:p3p3], _p(t.rows[:p3p3]), _p(t.tabμ[:p3p3]), _p(t.tabΣ[:p3p3]), _p(o3))
+_points_opts(dfg, N) = (d0 = default_opts(dfg);
+  RomeOpts(Int32(N), d0.solver, d0.max_iters, d0.inflate_cycles, d0.tol, d0.inflation, d0.seed, d0.stream_offset, 2 #=points=#, 0, d0.spread_nh, 0.0))
+
+# The clique-level batch as a function of its own.  It is NOT installed over IIF's `proposalbeliefs!` by loading this file (that would
+# be method piracy on generic argument types): call `enable_clique_batch!()` to opt in.  Returns what IIF's method returns -- the
+# inferred dimension per factor (`ipc`): full dimension (1.0) for every accelerated factor, then the fallback's values.
+function proposalbeliefs_mi355!(dfg::AbstractDFG, destlbl::Symbol, factors::AbstractVector{<:DFGFactor},
+                                dens::AbstractVector, measurement::AbstractVector=Tuple[];
+                                solveKey::Symbol=:default, N::Integer=getSolverParams(dfg).N, kw...)
+  fast = [fc for fc in factors if getFactorType(fc) isa _accelerated && isnothing(getSolverData(fc).multihypo)]
+  slow = [fc for fc in factors if !(fc in fast)]
+  t = _clique_tables(dfg, [(fc, destlbl) for fc in fast]; solveKey)
+  out(fam, w) = Vector{Float64}(undef, (length(t.rows[fam]) ÷ 4) * N * w)
   o2, o1, o0, o3 = out(:p2p2, 6), out(:br1, 6), out(:br0, 2), out(:p3p3, 12)
-  d0 = default_opts(dfg)
-  o = RomeOpts(Int32(N), d0.solver, d0.max_iters, d0.inflate_cycles, d0.tol, d0.inflation, d0.seed, d0.stream_offset, 2 #=points=#, 0, d0.spread_nh, 0.0)
-  p(x) = isempty(x) ? Ptr{eltype(x)}(C_NULL) : pointer(x)
-  GC.@preserve b2 bl b3 o2 o1 o0 o3 rows tabμ tabΣ begin
-    q = RomeCliqueHost(length(vars[Pose2]), length(vars[Point2]), length(vars[Pose3]), 0, p(b2), p(bl), p(b3),
-                       length(rows[:p2p2]) ÷ 4, nfac[:p2p2], p(rows[:p2p2]), p(tabμ[:p2p2]), p(tabΣ[:p2p2]), p(o2),
-                       length(rows[:br1]) ÷ 4, length(rows[:br0]) ÷ 4, nfac[:br], 0, p(rows[:br1]), p(rows[:br0]), p(tabμ[:br]), p(tabΣ[:br]), p(o1), p(o0),
-                       length(rows[:p3p3]) ÷ 4, nfac[:p3p3], p(rows[:p3p3]), p(tabμ[:p3p3]), p(tabΣ[:p3p3]), p(o3))
+  o = _points_opts(dfg, N)
+  GC.@preserve t o2 o1 o0 o3 begin
+    q = _clique_host(t, o2, o1, o0, o3)
     check(ccall((:rome_clique_proposals, LIB), Cint, (Ptr{Cvoid}, Ref{RomeOpts}, Ref{RomeCliqueHost}), ctx().h, o, q))
   end
   T = typeof(getVariableType(dfg, destlbl)); M = getManifold(T)
   P = eltype(getVal(dfg, destlbl; solveKey))
-  for (fam, r) in order
+  for (fam, r) in t.order
     buf, w = fam == :p2p2 ? (o2, 6) : fam == :br1 ? (o1, 6) : fam == :br0 ? (o0, 2) : (o3, 12)
     pts = collect(reinterpret(P, view(buf, (r - 1) * N * w + 1 : r * N * w)))
     push!(dens, manikde!(M, pts))             # the KDE wrap (bandwidth selection) stays in AMP; rome_kde_bandwidth can supply it
   end
-  isempty(slow) || invoke(IncrementalInference.proposalbeliefs!, Tuple{AbstractDFG,Symbol,AbstractVector,AbstractVector,AbstractVector},
-                          dfg, destlbl, slow, dens, measurement; solveKey, N, kw...)
-  return nothing     # (IIF returns the inferred dimensions per factor; callers in 0.35 ignore it for full-dimension factors)
+  ipc = ones(Float64, length(fast))
+  if !isempty(slow)
+    rest = invoke(IncrementalInference.proposalbeliefs!, Tuple{AbstractDFG,Symbol,AbstractVector,AbstractVector,AbstractVector},
+                  dfg, destlbl, slow, dens, measurement; solveKey, N, kw...)
+    rest isa AbstractVector && append!(ipc, rest)
+  end
+  return ipc
+end
+
+const _clique_batch_enabled = Ref(false)
+function enable_clique_batch!()
+  _clique_batch_enabled[] && return nothing
+  @eval IncrementalInference.proposalbeliefs!(dfg::AbstractDFG, destlbl::Symbol, factors::AbstractVector{<:DFGFactor},
+                                              dens::AbstractVector, measurement::AbstractVector=Tuple[]; kw...) =
+    proposalbeliefs_mi355!(dfg, destlbl, factors, dens, measurement; kw...)
+  _clique_batch_enabled[] = true
+  nothing
+end
+
+# ---- clique up-solve: IIF upGibbsCliqueDensity in ONE library call (rome_clique_upsolve) ---------------------------------------
+# gibbsIters x for each frontal {proposalbeliefs! -> manikde! -> manifoldProduct -> setValKDE!} stays on the device; the beliefs of the
+# clique's variables cross PCIe once, the new frontal beliefs and their manikde! bandwidths come back.  Python twin (what the tests
+# drive): rome_jl_amd.upGibbsCliqueDensity, tests/test_gpu_upsolve.py.
+struct RomeCliqueUpsolveHost     # include/rome_mi355.h: rome_clique_upsolve_host
+  clique::RomeCliqueHost
+  gibbs_iters::Int32; product_iters::Int32; schedule::Int32; n_up::Int32
+  up_type::Ptr{Int32}; up_var::Ptr{Int32}
+  n_msg_pose2::Int32; n_msg_point2::Int32; n_msg_pose3::Int32; reserved0::Int32
+  msg_pose2::Ptr{Float64}; msg_pose2_up::Ptr{Int32}; msg_point2::Ptr{Float64}; msg_point2_up::Ptr{Int32}
+  msg_pose3::Ptr{Float64}; msg_pose3_up::Ptr{Int32}
+  new_pose2::Ptr{Float64}; bw_pose2::Ptr{Float64}; new_point2::Ptr{Float64}; bw_point2::Ptr{Float64}
+  new_pose3::Ptr{Float64}; bw_pose3::Ptr{Float64}
+end
+
+function upsolve_clique!(dfg::AbstractDFG, frontals::AbstractVector{Symbol}, factors::AbstractVector{<:DFGFactor};
+                         gibbsIters::Integer=3, Niter::Integer=1, sequential::Bool=true,
+                         solveKey::Symbol=:default, N::Integer=getSolverParams(dfg).N)
+  # pairs grouped by frontal in Gibbs order (the library checks the grouping)
+  pairs = [(fc, l) for l in frontals for fc in factors
+           if l in getVariableOrder(fc) && getFactorType(fc) isa _accelerated && isnothing(getSolverData(fc).multihypo)]
+  t = _clique_tables(dfg, pairs; solveKey, extra_vars = collect(frontals))
+  tcode(l) = (T = typeof(getVariableType(dfg, l)); T === Pose2 ? Int32(0) : T === Point2 ? Int32(1) : Int32(2))
+  upt = Int32[tcode(l) for l in frontals]; upv = Int32[t.vidx[l] for l in frontals]
+  cnt(c) = count(==(Int32(c)), upt)
+  n2, nl, n3 = cnt(0), cnt(1), cnt(2)
+  new2, bw2 = Vector{Float64}(undef, n2 * N * 6), Vector{Float64}(undef, n2 * 3)
+  newl, bwl = Vector{Float64}(undef, nl * N * 2), Vector{Float64}(undef, nl * 2)
+  new3, bw3 = Vector{Float64}(undef, n3 * N * 12), Vector{Float64}(undef, n3 * 6)
+  o = _points_opts(dfg, N)
+  GC.@preserve t upt upv new2 bw2 newl bwl new3 bw3 begin
+    u = RomeCliqueUpsolveHost(_clique_host(t, Float64[], Float64[], Float64[], Float64[]),
+                              Int32(gibbsIters), Int32(Niter), Int32(sequential ? 0 : 1), Int32(length(frontals)), pointer(upt), pointer(upv),
+                              0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
+                              _p(new2), _p(bw2), _p(newl), _p(bwl), _p(new3), _p(bw3))
+    check(ccall((:rome_clique_upsolve, LIB), Cint, (Ptr{Cvoid}, Ref{RomeOpts}, Ref{RomeCliqueUpsolveHost}), ctx().h, o, u))
+  end
+  k = Dict(0 => 0, 1 => 0, 2 => 0)
+  for (l, tc) in zip(frontals, upt)
+    buf, bwb, w, d = tc == 0 ? (new2, bw2, 6, 3) : tc == 1 ? (newl, bwl, 2, 2) : (new3, bw3, 12, 6)
+    r = k[Int(tc)]; k[Int(tc)] += 1
+    P = eltype(getVal(dfg, l; solveKey)); M = getManifold(typeof(getVariableType(dfg, l)))
+    pts = collect(reinterpret(P, view(buf, r * N * w + 1 : (r + 1) * N * w)))
+    setValKDE!(dfg, l, manikde!(M, pts; bw = bwb[r * d + 1 : (r + 1) * d]), false, 1.0; solveKey)   # the bandwidth the device selected
+  end
+  nothing
 end
 
 # ---- parametric path: batched whitened residuals + Jacobians (rome_linearize) ------------------------------
