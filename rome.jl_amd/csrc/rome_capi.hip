@@ -501,7 +501,7 @@ static int dev_common(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t, b
   if (!c || !t || t->n_conv < 0) return ROME_ERR_INVALID_ARG;
   if (t->n_conv > 0 && (!t->mu || !t->L || !t->out)) return ROME_ERR_INVALID_ARG;
   if (t->n_conv > 0 && need_beliefs && (!t->bel_fixed || !t->bel_target)) return ROME_ERR_INVALID_ARG;
-  if (t->mirror_out && t->n_mirror > 4) return ROME_ERR_INVALID_ARG;   // at most 4 separator rows per launch: never silently dropped
+  if (t->mirror_out && !t->mirror_map && t->n_mirror > 4) return ROME_ERR_INVALID_ARG;   // mirror_row holds 4 rows (never silently dropped); more: mirror_map
   ROME_BIND(c);
   return ROME_OK;
 }
@@ -516,6 +516,23 @@ int rome_conv_pose2point2br_dev(rome_ctx* c, const rome_opts* o, const rome_conv
   if (t->dir != nullptr || (t->dir_all != 0 && t->dir_all != 1)) return ROME_ERR_INVALID_ARG;
   rome::ConvArgs a; args_from_dev(a, o, t);
   ROME_HIP(c, rome::launch_conv_bearingrange(a, o->solver, c->stream));
+  return ROME_OK;
+}
+int rome_sweep_pose2_dev(rome_ctx* c, const rome_opts* o, const rome_conv_dev* p2p2, const rome_conv_dev* br1, const rome_conv_dev* br0,
+                         const uint64_t* family_stream_offset) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || (!p2p2 && !br1 && !br0)) return ROME_ERR_INVALID_ARG;
+  const rome_conv_dev* t[3] = {p2p2, br1, br0};
+  rome::ConvArgs a[3];
+  for (int k = 0; k < 3; ++k) {
+    if (!t[k]) continue;
+    if ((rc = dev_common(c, o, t[k], true))) return rc;
+    if (k > 0 && (t[k]->dir != nullptr || t[k]->dir_all != (k == 1 ? 1 : 0))) return ROME_ERR_INVALID_ARG;
+    rome_opts of = *o;
+    if (family_stream_offset) of.stream_offset = o->stream_offset + family_stream_offset[k];
+    args_from_dev(a[k], &of, t[k]);
+  }
+  ROME_HIP(c, rome::launch_sweep_pose2(p2p2 ? &a[0] : nullptr, br1 ? &a[1] : nullptr, br0 ? &a[2] : nullptr, o->solver, c->stream));
   return ROME_OK;
 }
 int rome_conv_pose3pose3_dev(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t) {

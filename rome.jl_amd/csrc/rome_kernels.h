@@ -47,6 +47,7 @@ struct ConvArgs {
 hipError_t launch_conv_pose2pose2(const ConvArgs& a, int solver, hipStream_t s);
 hipError_t launch_conv_bearingrange(const ConvArgs& a, int solver, hipStream_t s);
 hipError_t launch_conv_pose3pose3(const ConvArgs& a, int solver, hipStream_t s);
+hipError_t launch_sweep_pose2(const ConvArgs* p2p2, const ConvArgs* br1, const ConvArgs* br0, int solver, hipStream_t s);
 hipError_t launch_sample_priorpose2(const ConvArgs& a, hipStream_t s);
 hipError_t launch_sample_priorpose3(const ConvArgs& a, hipStream_t s);
 

@@ -635,6 +635,8 @@ __device__ __forceinline__ int mirror_slot(const ConvArgs& a, int c_raw) {
   return m;
 }
 
+template <class FP, int SOLVER, int PPL, bool LEAN> __device__ __forceinline__ void conv_wave_body(const ConvArgs& a, int blk);
+
 // LEAN: the plain sweep -- in-kernel noise, all four table columns present, no multihypo / nullhypo rows.  The same code with
 // those features compiled out: the table row is one 16-byte scalar load, nothing stands between the belief loads and the
 // Philox / Box-Muller block, and the register allocation is not pinned by the feature paths.
@@ -643,10 +645,14 @@ template <class FP, int SOLVER, int PPL, bool LEAN>
 // (<= 128 VGPRs) is 5 % faster there; (the SE(3) kernels need their 256 VGPRs: capped at 3-4 waves/SIMD they spill and run 2.7x slower)
 __global__ void __launch_bounds__(64 * ROME_WPB, (SOLVER == kSolverNelderMead && FP::DT <= 3) ? ROME_NM_MINWAVES : ((SOLVER != kSolverNelderMead && FP::DT == 6) ? ROME_P3_MINBLK : ROME_MIN_WAVES))
 k_conv(const ConvArgs a) {
+  conv_wave_body<FP, SOLVER, PPL, LEAN>(a, xcd_contiguous_block(blockIdx.x, gridDim.x));
+}
+template <class FP, int SOLVER, int PPL, bool LEAN>
+__device__ __forceinline__ void conv_wave_body(const ConvArgs& a, int blk) {
   const int lane = threadIdx.x & 63;
   // no early exit: the (at most ROME_WPB - 1) surplus waves of the last block redo the last row and skip its stores, so that
   // no kernel-argument load has to wait for the n_conv comparison (all of them are issued together)
-  const int c_raw = __builtin_amdgcn_readfirstlane(xcd_contiguous_block(blockIdx.x, gridDim.x) * ROME_WPB + (int)(threadIdx.x >> 6));
+  const int c_raw = __builtin_amdgcn_readfirstlane(blk * ROME_WPB + (int)(threadIdx.x >> 6));
   const bool valid = c_raw < a.n_conv;
   const int c = valid ? c_raw : a.n_conv - 1;
   const int N = a.N;
@@ -894,14 +900,19 @@ template <class FP> struct FlatStage { static constexpr int kLanes = FP::NK <= 1
 #define ROME_FLAT_MINWAVES 8   // Pose2 / Point2 sweeps: 8 waves per SIMD (<= 64 VGPRs)
 #endif
 template <class FP, bool VERIFY, bool VEC2>
+__device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB, uint32_t magic, int blk, double* __restrict__ s_K);
+template <class FP, bool VERIFY, bool VEC2>
 __global__ void __launch_bounds__(kFlatThreads, (FP::DT <= 3 && !VERIFY) ? ROME_FLAT_MINWAVES : 1) k_conv_flat(const ConvArgs a, int H, int CPB, uint32_t magic) {
-  constexpr int SL = FlatStage<FP>::kLanes;
-  __shared__ double s_K[kFlatMaxRows][SL + 2];   // (+2: rows of a wave's two convolutions start in different banks)
+  __shared__ double s_K[kFlatMaxRows * (FlatStage<FP>::kLanes + 2)];
+  conv_flat_body<FP, VERIFY, VEC2>(a, H, CPB, magic, xcd_contiguous_block(blockIdx.x, gridDim.x), s_K);
+}
+template <class FP, bool VERIFY, bool VEC2>
+__device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB, uint32_t magic, int blk, double* __restrict__ s_K) {
+  constexpr int SLP = FlatStage<FP>::kLanes + 2;   // (+2: rows of a wave's two convolutions start in different banks)
   const int tid = threadIdx.x;
 #ifdef ROME_FLAT_TRACE   // experiment build (scripts/flat_trace.py): per-block timestamps instead of the status array
   const uint64_t trace_t0 = wall_clock64();
 #endif
-  const int blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int c0 = blk * CPB;
   const int N = a.N;
   // ---- this thread's (row, pair)
@@ -949,10 +960,10 @@ __global__ void __launch_bounds__(kFlatThreads, (FP::DT <= 3 && !VERIFY) ? ROME_
 #pragma unroll
   for (int e = 0; e < KP; ++e) {
     const int q = j + e * H;
-    if (lc_raw < CPB && q < FP::NK) s_K[lc][q] = kst[e];
+    if (lc_raw < CPB && q < FP::NK) s_K[lc * SLP + q] = kst[e];
   }
   __syncthreads();
-  const typename FP::Consts K = FP::from_lds(&s_K[lc][0], dr);
+  const typename FP::Consts K = FP::from_lds(s_K + lc * SLP, dr);
   double t[2][FP::DT];
   int st[2] = {0, 0};
 #pragma unroll
@@ -997,6 +1008,29 @@ __global__ void __launch_bounds__(kFlatThreads, (FP::DT <= 3 && !VERIFY) ? ROME_
 #else
   if (a.status) { a.status[(size_t)c * N + i0] = st[0]; if (act1) a.status[(size_t)c * N + i0 + 1] = st[1]; }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep_fused -- ONE launch for the whole sweep of a Pose2 / Point2 graph (MIT- / beehive-shaped: odometry + bearing-range
+// sightings): the block range selects the family -- [bearing-range -> pose rows, one wavefront each | Pose2Pose2 + PriorPose2 rows,
+// packed | bearing-range -> landmark rows, packed] -- and runs the SAME body as the family's own kernel (bit-identical proposals).
+// A sub-generation table (a few thousand sightings) does not fill the chip and pays a launch each; fused, the long bearing-range ->
+// pose waves are dispatched first and the packed blocks fill the machine around them.  CLOSED_FORM / NEWTON without status, plain
+// rows (no pre-sampled noise / multihypo / nullhypo), 64 < N <= 128; anything else takes the per-family launches.
+// ------------------------------------------------------------------------------------------
+struct FusedArgs {
+  ConvArgs br1, p2p2, br0;
+  int nb_br1, nb_p2p2, nb_br0;       // blocks per part (each a multiple of 8: block b runs on XCD b % 8)
+  int H, CPB2, CPB0;                 // packed parts: pair-threads per row, rows per block
+  uint32_t magic;
+};
+template <bool VEC2>
+__global__ void __launch_bounds__(256) k_sweep_fused(const FusedArgs f) {
+  __shared__ double s_K[kFlatMaxRows * (FlatStage<P2P2>::kLanes + 2)];
+  const int b = blockIdx.x;
+  if (b < f.nb_br1) conv_wave_body<BR<1>, kSolverClosedForm, 2, true>(f.br1, xcd_contiguous_block(b, f.nb_br1));
+  else if (b < f.nb_br1 + f.nb_p2p2) conv_flat_body<P2P2, false, VEC2>(f.p2p2, f.H, f.CPB2, f.magic, xcd_contiguous_block(b - f.nb_br1, f.nb_p2p2), s_K);
+  else conv_flat_body<BR<0>, false, VEC2>(f.br0, f.H, f.CPB0, f.magic, xcd_contiguous_block(b - f.nb_br1 - f.nb_p2p2, f.nb_br0), s_K);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1330,6 +1364,39 @@ hipError_t launch_conv_pose2pose2(const ConvArgs& a, int solver, hipStream_t s) 
 hipError_t launch_conv_pose3pose3(const ConvArgs& a, int solver, hipStream_t s) { return launch_solver<P3P3>(a, solver, s); }
 hipError_t launch_conv_bearingrange(const ConvArgs& a, int solver, hipStream_t s) {
   return a.dir_all == 0 ? launch_solver<BR<0>>(a, solver, s) : launch_solver<BR<1>>(a, solver, s);
+}
+static bool plain_rows(const ConvArgs& a) { return a.rows4 && !a.noise && !a.alt_var && !a.nullhypo && !a.status; }
+// the whole sweep of a Pose2 / Point2 graph: fused into one launch when every family takes its plain kernel, else family by family
+hipError_t launch_sweep_pose2(const ConvArgs* p2p2, const ConvArgs* br1, const ConvArgs* br0, int solver, hipStream_t s) {
+  const int N = p2p2 ? p2p2->N : (br1 ? br1->N : (br0 ? br0->N : 0));
+  const bool fusable = p2p2 && br1 && br0 && p2p2->n_conv > 0 && br1->n_conv > 0 && br0->n_conv > 0 &&
+                       (solver == kSolverClosedForm || solver == kSolverNewton) && N > 64 && N <= 128 && br1->N == N && br0->N == N &&
+                       plain_rows(*p2p2) && plain_rows(*br1) && plain_rows(*br0) && br1->dir_all == 1 && br0->dir_all == 0;
+  if (!fusable) {
+    hipError_t e = hipSuccess;
+    if (br1 && br1->n_conv > 0 && (e = launch_conv_bearingrange(*br1, solver, s)) != hipSuccess) return e;
+    if (p2p2 && p2p2->n_conv > 0 && (e = launch_conv_pose2pose2(*p2p2, solver, s)) != hipSuccess) return e;
+    if (br0 && br0->n_conv > 0 && (e = launch_conv_bearingrange(*br0, solver, s)) != hipSuccess) return e;
+    return e;
+  }
+  FusedArgs f;
+  f.br1 = *br1; f.p2p2 = *p2p2; f.br0 = *br0;
+  f.H = (N + 1) / 2;
+  const int cpb = kFlatThreads / f.H;
+  f.CPB2 = cpb < kFlatMaxRows ? cpb : kFlatMaxRows; f.CPB0 = f.CPB2;
+  f.magic = (65536u + (uint32_t)f.H - 1u) / (uint32_t)f.H;
+  for (int t = 0; t < kFlatThreads; ++t) if ((int)(((uint32_t)t * f.magic) >> 16) != t / f.H) return hipErrorInvalidValue;
+  auto up8 = [](int n) { return (n + 7) & ~7; };
+  f.nb_br1 = up8((br1->n_conv + ROME_WPB - 1) / ROME_WPB);
+  f.nb_p2p2 = up8((p2p2->n_conv + f.CPB2 - 1) / f.CPB2);
+  f.nb_br0 = up8((br0->n_conv + f.CPB0 - 1) / f.CPB0);
+  const uintptr_t al = (uintptr_t)p2p2->bel_fixed | (uintptr_t)p2p2->out | (uintptr_t)p2p2->mirror_out | (uintptr_t)br0->bel_fixed |
+                       (uintptr_t)br0->out | (uintptr_t)br0->mirror_out;
+  const bool vec2 = (N % 2 == 0) && (al % 16 == 0);
+  const int nb = f.nb_br1 + f.nb_p2p2 + f.nb_br0;
+  if (vec2) hipLaunchKernelGGL((k_sweep_fused<true>), dim3(nb), dim3(256), 0, s, f);
+  else      hipLaunchKernelGGL((k_sweep_fused<false>), dim3(nb), dim3(256), 0, s, f);
+  return hipGetLastError();
 }
 template <int D>
 static hipError_t launch_prior(const ConvArgs& a, hipStream_t s) {

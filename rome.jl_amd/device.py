@@ -245,12 +245,17 @@ class DeviceGraph:
         family/direction).  Philox streams: base + sweep·2³² + family offset + row."""
         base = sweep << 32
         C2 = self.tab["p2p2"]["C"] if "p2p2" in self.tab else 0
-        if C2:
-            self.sweep_pose2pose2(self._opts_at(opts, base + self.STREAM_P2P2), out=self.prop[Pose2][:C2])
-        if "br" in self.tab:
+        if C2 and "br" in self.tab and self.tab["br"]["F"] and self.tab["br"]["F0"]:
+            # a Pose2 / Point2 graph: ONE library call for the three families (one fused launch when the tables are plain)
             Fb, Fb0 = self.tab["br"]["F"], self.tab["br"]["F0"]
-            self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR1), 1, out=self.prop[Pose2][C2:C2 + Fb])
-            self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR0), 0, out=self.prop[Point2][:Fb0])
+            self.sweep_graph_pose2(self._opts_at(opts, base), self.prop[Pose2][:C2], self.prop[Pose2][C2:C2 + Fb], self.prop[Point2][:Fb0])
+        else:
+            if C2:
+                self.sweep_pose2pose2(self._opts_at(opts, base + self.STREAM_P2P2), out=self.prop[Pose2][:C2])
+            if "br" in self.tab:
+                Fb, Fb0 = self.tab["br"]["F"], self.tab["br"]["F0"]
+                self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR1), 1, out=self.prop[Pose2][C2:C2 + Fb])
+                self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR0), 0, out=self.prop[Point2][:Fb0])
         if "p3p3" in self.tab and self.tab["p3p3"]["C"]:
             self.sweep_pose3pose3(self._opts_at(opts, base + self.STREAM_P3P3), out=self.prop[Pose3][:self.tab["p3p3"]["C"]])
 
@@ -448,6 +453,37 @@ class DeviceGraph:
         self._launch(self._lib.rome_conv_pose2point2br_dev, opts, n_conv=nrow, dir_all=int(direction), dir=None,
                      mu=tb["mu"], L=tb["sigma"], noise=noise, out=out, status=status, **kw)
         return out
+
+    def _conv_dev(self, keep, **kw):
+        cd = _lib.ConvDev()
+        for k, v in kw.items():
+            if isinstance(v, int):
+                setattr(cd, k, v)
+            elif v is not None:
+                keep.append(v)
+                setattr(cd, k, v.data_ptr())
+        return cd
+
+    def sweep_graph_pose2(self, opts, out_p2p2, out_br1, out_br0, family_offsets=None):
+        """The whole convolution sweep of a Pose2 / Point2 graph in ONE library call (rome_sweep_pose2_dev): Pose2Pose2 + PriorPose2
+        rows, bearing-range -> pose rows, bearing-range -> landmark rows.  Plain tables run as one fused launch; tables with multihypo
+        columns take the per-family launches inside the library -- the proposals are the same bit for bit either way.
+        family_offsets: Philox stream offsets of the three families (default: STREAM_P2P2 / STREAM_BR1 / STREAM_BR0)."""
+        keep = []
+        t2, tb = self.tab["p2p2"], self.tab["br"]
+        mh2 = dict(alt_var=t2["alt"], hypo_w=t2["w"]) if t2["mh"] else {}
+        c2 = self._conv_dev(keep, n_conv=t2["C"], dir_all=0, rows4=t2["rows4"], factor=t2["factor"], dir=t2["dir"], fixed_var=t2["fixed"],
+                            target_var=t2["target"], mu=t2["mu"], L=t2["L"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Pose2], out=out_p2p2, **mh2)
+        mh1 = dict(alt_var=tb["alt"], hypo_w=tb["w"]) if tb["mh"] else {}
+        c1 = self._conv_dev(keep, n_conv=tb["F"], dir_all=1, rows4=tb["rows4_1"], fixed_var=tb["point"], target_var=tb["pose"], mu=tb["mu"],
+                            L=tb["sigma"], bel_fixed=self.bel[Point2], bel_target=self.bel[Pose2], out=out_br1, **mh1)
+        mh0 = dict(alt_var=tb["alt0"], hypo_w=tb["w0"]) if tb["mh"] else {}
+        c0 = self._conv_dev(keep, n_conv=tb["F0"], dir_all=0, rows4=tb["rows4_0"], factor=tb["factor0"], fixed_var=tb["pose0"],
+                            target_var=tb["point0"], mu=tb["mu"], L=tb["sigma"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Point2],
+                            out=out_br0, **mh0)
+        offs = (C.c_uint64 * 3)(*(family_offsets if family_offsets is not None else (self.STREAM_P2P2, self.STREAM_BR1, self.STREAM_BR0)))
+        self._bind_stream()
+        _lib.check(self._lib.rome_sweep_pose2_dev(self.ctx.handle, C.byref(opts), C.byref(c2), C.byref(c1), C.byref(c0), offs), self.ctx.handle)
 
     def sample_priors(self, opts, kind="prior2", out=None, noise=None):
         tb = self.tab[kind]

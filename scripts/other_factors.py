@@ -43,3 +43,17 @@ for d in (0, 1):
         ms = timeit(lambda: dg.sweep_bearingrange(o, d), reps)
         B = (B_BR0 if d == 0 else B_BR1)[name]
         print("BearingRange dir %d: %6d convs %-12s %9.4f ms/sweep  %.3e conv/s  %7.1f GB/s algorithmic (%d B/particle) = %.2f of 8 TB/s" % (d, F, name, ms, F / ms * 1e3, F * 100 * B / ms / 1e6, B, F * 100 * B / ms / 1e6 / 8000))
+
+# ---- the whole sweep of the MIT-like graph: three per-family launches vs ONE fused launch (rome_sweep_pose2_dev) ----
+o = R.make_opts(N=100, solver=1)
+C2, Fb, Fb0 = dg.tab["p2p2"]["C"], dg.tab["br"]["F"], dg.tab["br"]["F0"]
+a2 = torch.empty((C2, 3, 100), dtype=torch.float64, device="cuda"); a1 = torch.empty((Fb, 3, 100), dtype=torch.float64, device="cuda")
+a0 = torch.empty((Fb0, 2, 100), dtype=torch.float64, device="cuda")
+def three():
+    dg.sweep_pose2pose2(o, out=a2); dg.sweep_bearingrange(o, 1, out=a1); dg.sweep_bearingrange(o, 0, out=a0)
+alg = dg.tab["p2p2"]["C_rel"] * 100 * 48 + dg.tab["p2p2"]["P"] * 2400 + Fb * 100 * 64 + Fb0 * 100 * 40
+for name, fn in (("three launches (per family)", three), ("ONE fused launch (k_sweep_fused)", lambda: dg.sweep_graph_pose2(o, a2, a1, a0))):
+    ms = timeit(fn, 3 if QUICK else 50)
+    n = C2 + Fb + Fb0
+    print("MIT-like graph sweep: %6d convs (%d p2p2 + %d br->pose + %d br->landmark) %-34s %9.4f ms/sweep  %.3e conv/s  %7.1f GB/s algorithmic = %.2f of 8 TB/s"
+          % (n, C2, Fb, Fb0, name, ms, n / ms * 1e3, alg / ms / 1e6, alg / ms / 1e6 / 8000))

@@ -35,6 +35,8 @@ scale = 2.0 if cal_f < 0.75 * 2097152 else 1.0
 F, W, S = ctr("pmc_FETCH_SIZE"), ctr("pmc_WRITE_SIZE"), ctr("sq")
 # workload sizes of scripts/other_factors.py: helix 23991 rows (23990 relative + 1 prior), MIT-like 5978 sightings; N = 100
 def alg(name):
+    if "k_sweep_fused" in name:   # the whole MIT-like sweep in one launch: 16158 relative + 1 prior p2p2 rows, 5978 + 5978 sightings
+        return 16158 * 100 * 48 + 2400 + 5978 * 100 * 64 + 5978 * 100 * 40, 16159 + 2 * 5978
     m = re.search(r"k_conv(_flat)?<rome::(P2P2|P3P3|BR<(\d)>), *(\w+)", name)
     if not m: return None
     flat, fam, d, sv = m.group(1), m.group(2), m.group(3), m.group(4)
@@ -50,7 +52,7 @@ lines = ["Non-headline factor kernels, N = 100, scripts/other_factors.py under r
          "| kernel | launches | avg µs | vgpr | scratch | rows | alg MB | alg GB/s | frac of 8 TB/s | HBM MB (PMC) | HBM GB/s | VALU/wave | VALU busy | FP64-VALU note |",
          "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for n in sorted(dur, key=lambda k: -dur[k][0] * dur[k][1]):
-    if "rome::k_conv" not in n: continue
+    if "rome::k_conv" not in n and "rome::k_sweep_fused" not in n: continue
     c, a, v, s, l, sc = dur[n]
     ab = alg(n)
     f = F.get(n, {}).get("FETCH_SIZE"); w = W.get(n, {}).get("WRITE_SIZE")

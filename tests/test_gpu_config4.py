@@ -145,3 +145,36 @@ def test_cut_lattice_through_separator_pipeline_one_rank_rccl():
     off = -(-(9 * 3 * N) // U) * U
     gotl = recv[off:off + 5 * 2 * N].reshape(5, 2, N)
     assert np.array_equal(gotl, np.stack([outs["br0"][r] for r in (0, 1, 3, 6, 8)]))
+
+
+@pytest.mark.parametrize("N", [100, 128, 66])
+def test_fused_graph_sweep_equals_per_family_launches_bit_for_bit(N):
+    """rome_sweep_pose2_dev: the three families of a Pose2 / Point2 graph (plain tables: one fused launch, k_sweep_fused) against the
+    per-family entry points with the same Philox streams -- identical bits; a table with multihypo columns takes the per-family
+    launches inside the library and agrees as well."""
+    fg = R.synth_mit_br(P=300, n_landmarks=60, N=N)
+    R.dead_reckon_init(fg, seed=4)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    assert not dg.tab["br"]["mh"]
+    for solver in (R.SOLVER_NEWTON, R.SOLVER_CLOSED_FORM):
+        o = R.make_opts(N=N, solver=solver, seed=12, stream_offset=5 << 32)
+        C2, Fb, Fb0 = dg.tab["p2p2"]["C"], dg.tab["br"]["F"], dg.tab["br"]["F0"]
+        a2 = torch_empty(dg, (C2, 3, N)); a1 = torch_empty(dg, (Fb, 3, N)); a0 = torch_empty(dg, (Fb0, 2, N))
+        dg.sweep_graph_pose2(o, a2, a1, a0)
+        b2 = dg.sweep_pose2pose2(dg._opts_at(o, dg.STREAM_P2P2)); b1 = dg.sweep_bearingrange(dg._opts_at(o, dg.STREAM_BR1), 1)
+        b0 = dg.sweep_bearingrange(dg._opts_at(o, dg.STREAM_BR0), 0)
+        for x, y in ((a2, b2), (a1, b1), (a0, b0)):
+            assert np.array_equal(x.cpu().numpy(), y.cpu().numpy())
+    fg2 = _graph(20, 100)                                      # beehive with multihypo: falls back inside the library
+    dg2 = R.DeviceGraph(fg2); dg2.upload_beliefs(fg2)
+    assert dg2.tab["br"]["mh"]
+    o = R.make_opts(N=100, solver=1, seed=12)
+    C2, Fb, Fb0 = dg2.tab["p2p2"]["C"], dg2.tab["br"]["F"], dg2.tab["br"]["F0"]
+    a2 = torch_empty(dg2, (C2, 3, 100)); a1 = torch_empty(dg2, (Fb, 3, 100)); a0 = torch_empty(dg2, (Fb0, 2, 100))
+    dg2.sweep_graph_pose2(o, a2, a1, a0)
+    assert np.array_equal(a1.cpu().numpy(), dg2.sweep_bearingrange(dg2._opts_at(o, dg2.STREAM_BR1), 1).cpu().numpy())
+    assert np.array_equal(a0.cpu().numpy(), dg2.sweep_bearingrange(dg2._opts_at(o, dg2.STREAM_BR0), 0).cpu().numpy())
+
+
+def torch_empty(dg, shape):
+    return dg.torch.zeros(shape, dtype=dg.torch.float64, device=dg.device)
