@@ -899,23 +899,28 @@ template <class FP> struct FlatStage { static constexpr int kLanes = FP::NK <= 1
 #ifndef ROME_FLAT_MINWAVES
 #define ROME_FLAT_MINWAVES 8   // Pose2 / Point2 sweeps: 8 waves per SIMD (<= 64 VGPRs)
 #endif
-template <class FP, bool VERIFY, bool VEC2>
+template <class FP, bool VERIFY, bool VEC2, int PP>
 __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB, uint32_t magic, int blk, double* __restrict__ s_K);
-template <class FP, bool VERIFY, bool VEC2>
-__global__ void __launch_bounds__(kFlatThreads, (FP::DT <= 3 && !VERIFY) ? ROME_FLAT_MINWAVES : 1) k_conv_flat(const ConvArgs a, int H, int CPB, uint32_t magic) {
+#ifndef ROME_FLAT_PP
+#define ROME_FLAT_PP 1   // neighbouring particle pairs per thread of the packed sweep (Pose2 / Point2 factors).  Measured: 2 pairs per
+                          // thread (fewer, fatter waves, one generation) need 96 VGPRs + spills and run 21.8 µs against 8.0 µs: one pair it is
+#endif
+template <class FP, bool VERIFY, bool VEC2, int PP>
+__global__ void __launch_bounds__(kFlatThreads, (FP::DT <= 3 && !VERIFY) ? (PP == 1 ? ROME_FLAT_MINWAVES : 5) : 1) k_conv_flat(const ConvArgs a, int H, int CPB, uint32_t magic) {
   __shared__ double s_K[kFlatMaxRows * (FlatStage<FP>::kLanes + 2)];
-  conv_flat_body<FP, VERIFY, VEC2>(a, H, CPB, magic, xcd_contiguous_block(blockIdx.x, gridDim.x), s_K);
+  conv_flat_body<FP, VERIFY, VEC2, PP>(a, H, CPB, magic, xcd_contiguous_block(blockIdx.x, gridDim.x), s_K);
 }
-template <class FP, bool VERIFY, bool VEC2>
+template <class FP, bool VERIFY, bool VEC2, int PP>
 __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB, uint32_t magic, int blk, double* __restrict__ s_K) {
   constexpr int SLP = FlatStage<FP>::kLanes + 2;   // (+2: rows of a wave's two convolutions start in different banks)
+  constexpr int NP = 2 * PP;                        // particles per thread: PP neighbouring pairs (2·PP consecutive particles)
   const int tid = threadIdx.x;
 #ifdef ROME_FLAT_TRACE   // experiment build (scripts/flat_trace.py): per-block timestamps instead of the status array
   const uint64_t trace_t0 = wall_clock64();
 #endif
   const int c0 = blk * CPB;
   const int N = a.N;
-  // ---- this thread's (row, pair)
+  // ---- this thread's (row, particle group)
   const int lc_raw = (int)(((uint32_t)tid * magic) >> 16);   // tid / H
   const int j = tid - lc_raw * H;
   const bool live = lc_raw < CPB && c0 + lc_raw < a.n_conv;
@@ -923,12 +928,11 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
   const int c = min(c0 + lc, a.n_conv - 1);
   const int4 row = *reinterpret_cast<const int4*>(a.rows4 + 4 * (size_t)c);
   const int dr = (FP::kHypoDir < 0 || FP::kHypoDir == 2) ? row.y : a.dir_all;
-  const int i0 = 2 * j;                       // particles i0, i0 + 1
-  const bool act1 = i0 + 1 < N;               // (odd N: the last pair is a single particle)
+  const int i0 = NP * j;                      // particles i0 .. i0 + NP - 1 (the tail of a row may be shorter)
   // ---- per-factor constants -> LDS: the first threads of every row load one entry each of THEIR OWN row's factor (the factor
   //      index arrives with the row they need anyway: the load is issued beside the belief loads, nothing waits for it here;
   //      branch-free: every thread loads SOME valid entry, only the first NK of a row publish theirs)
-  constexpr int KP = (FP::NK + 7) / 8;   // passes (H >= 8 pair-threads per row)
+  constexpr int KP = (FP::NK + 7) / 8;   // passes (H >= 8 threads per row)
   double kst[KP];
 #pragma unroll
   for (int e = 0; e < KP; ++e) {
@@ -937,26 +941,37 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
     kst[e] = *src;
   }
   const double* __restrict__ fb = a.bel_fixed + (size_t)row.z * FP::DF * N;
-  double fx[2][FP::DF];
-  if (VEC2) {
+  double fx[NP][FP::DF];
 #pragma unroll
-    for (int d = 0; d < FP::DF; ++d) {
-      const double2 v = *reinterpret_cast<const double2*>(fb + (size_t)d * N + i0);
-      fx[0][d] = v.x; fx[1][d] = v.y;
+  for (int p = 0; p < PP; ++p) {
+    const int ip = i0 + 2 * p;
+    if (VEC2) {   // (N even: a pair is inside the row or entirely beyond it)
+      const int ii = ip < N ? ip : 0;
+#pragma unroll
+      for (int d = 0; d < FP::DF; ++d) {
+        const double2 v = *reinterpret_cast<const double2*>(fb + (size_t)d * N + ii);
+        fx[2 * p][d] = v.x; fx[2 * p + 1][d] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < FP::DF; ++d) {
+        fx[2 * p][d] = fb[(size_t)d * N + (ip < N ? ip : 0)]; fx[2 * p + 1][d] = fb[(size_t)d * N + (ip + 1 < N ? ip + 1 : 0)];
+      }
     }
-  } else {
-#pragma unroll
-    for (int d = 0; d < FP::DF; ++d) { fx[0][d] = fb[(size_t)d * N + i0]; fx[1][d] = fb[(size_t)d * N + (act1 ? i0 + 1 : i0)]; }
   }
   // ---- measurement noise (depends on the row id only).  The two compiler fences keep the order {loads issued} -> {Philox /
   //      Box-Muller} -> {first use of a loaded value}, so that the generator runs under the load latency (left alone, the
   //      compiler sinks the generator below the LDS write and its s_waitcnt vmcnt(0))
   asm volatile("" ::: "memory");
   const uint64_t stream = a.stream_offset + (uint64_t)c;
-  double xi[2][FP::DZ];
-  rng_normals_pair<FP::DZ>(a.seed, stream, (uint32_t)i0, xi[0], xi[1]);
+  double xi[NP][FP::DZ];
 #pragma unroll
-  for (int d = 0; d < FP::DZ; ++d) asm volatile("" : "+v"(xi[0][d]), "+v"(xi[1][d]) :: "memory");
+  for (int p = 0; p < PP; ++p) rng_normals_pair<FP::DZ>(a.seed, stream, (uint32_t)(i0 + 2 * p), xi[2 * p], xi[2 * p + 1]);
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+#pragma unroll
+    for (int d = 0; d < FP::DZ; ++d) asm volatile("" : "+v"(xi[k][d]) :: "memory");
+  }
 #pragma unroll
   for (int e = 0; e < KP; ++e) {
     const int q = j + e * H;
@@ -964,11 +979,12 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
   }
   __syncthreads();
   const typename FP::Consts K = FP::from_lds(s_K + lc * SLP, dr);
-  double t[2][FP::DT];
-  int st[2] = {0, 0};
+  double t[NP][FP::DT];
+  int st[NP];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < NP; ++k) {
     double z[FP::DZ];
+    st[k] = 0;
     FP::measurement(K, xi[k], z);
     const typename FP::Prep P = FP::prepare(K, z, fx[k]);
     typename FP::Aux A;
@@ -983,21 +999,30 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
   double* __restrict__ ob = a.out + (size_t)c * FP::DT * N;
   const int mslot = (a.n_mirror > 0 || a.mirror_map) ? mirror_slot(a, c) : -1;
   double* mb = mslot >= 0 ? a.mirror_out + (size_t)mslot * FP::DT * N : nullptr;
-  if (VEC2) {
 #pragma unroll
-    for (int d = 0; d < FP::DT; ++d) {
-      const double2 v = {t[0][d], t[1][d]};
-      // streaming stores: the proposals are not read again by this launch; written through, they are not left dirty in the L2
-      // for the end-of-kernel write-back (measured: 9.1 -> 7.8 µs per Manhattan sweep)
-      store_stream2(ob + (size_t)d * N + i0, v);
-      if (mb) store_stream2(mb + (size_t)d * N + i0, v);
-    }
-  } else {
+  for (int p = 0; p < PP; ++p) {
+    const int ip = i0 + 2 * p;
+    if (ip >= N) continue;
+    const bool act1 = ip + 1 < N;               // (odd N: the last pair is a single particle)
+    if (VEC2) {
 #pragma unroll
-    for (int d = 0; d < FP::DT; ++d) {
-      store_stream(ob + (size_t)d * N + i0, t[0][d]); if (act1) store_stream(ob + (size_t)d * N + i0 + 1, t[1][d]);
-      if (mb) { store_stream(mb + (size_t)d * N + i0, t[0][d]); if (act1) store_stream(mb + (size_t)d * N + i0 + 1, t[1][d]); }
+      for (int d = 0; d < FP::DT; ++d) {
+        const double2 v = {t[2 * p][d], t[2 * p + 1][d]};
+        // streaming stores: the proposals are not read again by this launch; written through, they are not left dirty in the L2
+        // for the end-of-kernel write-back (measured: 9.1 -> 7.8 µs per Manhattan sweep)
+        store_stream2(ob + (size_t)d * N + ip, v);
+        if (mb) store_stream2(mb + (size_t)d * N + ip, v);
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < FP::DT; ++d) {
+        store_stream(ob + (size_t)d * N + ip, t[2 * p][d]); if (act1) store_stream(ob + (size_t)d * N + ip + 1, t[2 * p + 1][d]);
+        if (mb) { store_stream(mb + (size_t)d * N + ip, t[2 * p][d]); if (act1) store_stream(mb + (size_t)d * N + ip + 1, t[2 * p + 1][d]); }
+      }
     }
+#ifndef ROME_FLAT_TRACE
+    if (a.status) { a.status[(size_t)c * N + ip] = st[2 * p]; if (act1) a.status[(size_t)c * N + ip + 1] = st[2 * p + 1]; }
+#endif
   }
 #ifdef ROME_FLAT_TRACE
   if (a.status && tid == 0) {
@@ -1005,8 +1030,6 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
     tr[0] = trace_t0; tr[1] = trace_t1; tr[2] = wall_clock64();
     tr[3] = (uint64_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);   // HW_ID, XCC_ID
   }
-#else
-  if (a.status) { a.status[(size_t)c * N + i0] = st[0]; if (act1) a.status[(size_t)c * N + i0 + 1] = st[1]; }
 #endif
 }
 
@@ -1029,8 +1052,8 @@ __global__ void __launch_bounds__(256) k_sweep_fused(const FusedArgs f) {
   __shared__ double s_K[kFlatMaxRows * (FlatStage<P2P2>::kLanes + 2)];
   const int b = blockIdx.x;
   if (b < f.nb_br1) conv_wave_body<BR<1>, kSolverClosedForm, 2, true>(f.br1, xcd_contiguous_block(b, f.nb_br1));
-  else if (b < f.nb_br1 + f.nb_p2p2) conv_flat_body<P2P2, false, VEC2>(f.p2p2, f.H, f.CPB2, f.magic, xcd_contiguous_block(b - f.nb_br1, f.nb_p2p2), s_K);
-  else conv_flat_body<BR<0>, false, VEC2>(f.br0, f.H, f.CPB0, f.magic, xcd_contiguous_block(b - f.nb_br1 - f.nb_p2p2, f.nb_br0), s_K);
+  else if (b < f.nb_br1 + f.nb_p2p2) conv_flat_body<P2P2, false, VEC2, 1>(f.p2p2, f.H, f.CPB2, f.magic, xcd_contiguous_block(b - f.nb_br1, f.nb_p2p2), s_K);
+  else conv_flat_body<BR<0>, false, VEC2, 1>(f.br0, f.H, f.CPB0, f.magic, xcd_contiguous_block(b - f.nb_br1 - f.nb_p2p2, f.nb_br0), s_K);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1314,10 +1337,12 @@ static hipError_t launch_ppl_v(const ConvArgs& a, hipStream_t s) {
 // the packed sweep (k_conv_flat): H = ceil(N/2) pair-threads per row, CPB rows per 256-thread block
 template <class FP, int SOLVER>
 static hipError_t launch_flat(const ConvArgs& a, hipStream_t s) {
-  const int H = (a.N + 1) / 2;
+  // PP neighbouring pairs per thread: Pose2 / Point2 rows of >= 64 particles take ROME_FLAT_PP, everything else one pair
+  constexpr int PPC = FP::DT <= 3 ? ROME_FLAT_PP : 1;
+  const bool verify = SOLVER == kSolverNewton && a.status != nullptr;
+  const int pp = (PPC > 1 && a.N >= 64 && !verify) ? PPC : 1;
+  const int H = (a.N + 2 * pp - 1) / (2 * pp);
   int CPB = kFlatThreads / H;
-  const int cap = kFlatThreads / FlatStage<FP>::kLanes;   // staging threads: kLanes per row
-  if (CPB > cap) CPB = cap;
   if (CPB > kFlatMaxRows) CPB = kFlatMaxRows;
   const uint32_t magic = (65536u + (uint32_t)H - 1u) / (uint32_t)H;   // tid / H == (tid * magic) >> 16 for tid < 256 (checked below)
   for (int t = 0; t < kFlatThreads; ++t) if ((int)(((uint32_t)t * magic) >> 16) != t / H) return hipErrorInvalidValue;
@@ -1326,13 +1351,15 @@ static hipError_t launch_flat(const ConvArgs& a, hipStream_t s) {
   // 16-byte accesses need an even N (row starts stay 16-byte aligned) and 16-byte aligned arrays
   const bool vec2 = (a.N % 2 == 0) && (((uintptr_t)a.bel_fixed | (uintptr_t)a.out | (uintptr_t)a.mirror_out) % 16 == 0);
   // (the functor evaluation is a separate instantiation: compiled into the plain sweep it would pin its register allocation)
-  const bool verify = SOLVER == kSolverNewton && a.status != nullptr;
   if (verify) {
-    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, true, true>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
-    else      hipLaunchKernelGGL((k_conv_flat<FP, true, false>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, true, true, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    else      hipLaunchKernelGGL((k_conv_flat<FP, true, false, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+  } else if (pp == 1) {
+    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, false, true, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    else      hipLaunchKernelGGL((k_conv_flat<FP, false, false, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
   } else {
-    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, false, true>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
-    else      hipLaunchKernelGGL((k_conv_flat<FP, false, false>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, false, true, PPC>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    else      hipLaunchKernelGGL((k_conv_flat<FP, false, false, PPC>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
   }
   return hipGetLastError();
 }
