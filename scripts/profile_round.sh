@@ -24,8 +24,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --kernel-trace -d $T/${s}_$c -o $s -- python $R/bench.py --solver $s --steps 20 --warmup 2 --no-cpu-baseline --no-modes > $T/${s}_$c.log 2>&1
   done
 done
-# 3. SQ counters
-for s in newton closed_form gauss_newton; do
+# 3. SQ counters (Nelder-Mead too: its bound is FP64-VALU issue, the busy fraction is the roofline that applies)
+for s in newton closed_form gauss_newton nelder_mead; do
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-trace -d $T/sqa_$s -o a -- python $R/bench.py --solver $s --steps 10 --warmup 2 --no-cpu-baseline --no-modes > $T/sqa_$s.log 2>&1
   timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS --kernel-trace -d $T/sqb_$s -o b -- python $R/bench.py --solver $s --steps 10 --warmup 2 --no-cpu-baseline --no-modes > $T/sqb_$s.log 2>&1
 done
@@ -43,16 +43,18 @@ def counters(pattern, like):
     return out
 cal = {c: counters("%s/cal_%s/**/*_results.db" % (T, c), "copy")[c][0] for c in ("FETCH_SIZE", "WRITE_SIZE")}
 fetch_scale = 2.0 if cal["FETCH_SIZE"] < 0.75 * 2097152 else 1.0   # copy8 reads 2 GiB: gfx950 FETCH_SIZE reports half of it
-ALG = {"newton": 10906 * 100 * 48 + 2400, "closed_form": 10906 * 100 * 48 + 2400, "gauss_newton": 10906 * 100 * 72 + 2400}   # bench.py BYTES_PER_PARTICLE_P2P2
-for s in ("newton", "closed_form", "gauss_newton"):
-    f = counters("%s/%s_FETCH_SIZE/**/*_results.db" % (T, s), "k_conv"); w = counters("%s/%s_WRITE_SIZE/**/*_results.db" % (T, s), "k_conv")
-    rd = f["FETCH_SIZE"][0] * 1024 * fetch_scale; wr = w["WRITE_SIZE"][0] * 1024
-    json.dump({"source": "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), bench.py --solver %s --steps 20; "
-                         "FETCH_SIZE x%.0f per the gfx950 correction, calibrated in the same run on scripts/ubench/copy8 (2 GiB read reported %.4g KB, 2 GiB written reported %.4g KB)"
-                         % (s, fetch_scale, cal["FETCH_SIZE"], cal["WRITE_SIZE"]),
-               "solver": s, "n_conv": 10907, "kernel": f["FETCH_SIZE"][2], "fetch_size_kb_raw": f["FETCH_SIZE"][0], "write_size_kb_raw": w["WRITE_SIZE"][0],
-               "launches_averaged": f["FETCH_SIZE"][1], "bytes_per_launch": int(rd + wr), "read_bytes_per_launch": int(rd), "write_bytes_per_launch": int(wr),
-               "algorithmic_bytes_per_launch": ALG[s]}, open("%s/hbm_traffic_%s.json" % (O, s), "w"), indent=1)
+ALG = {"newton": 10906 * 100 * 48 + 2400, "closed_form": 10906 * 100 * 48 + 2400, "gauss_newton": 10906 * 100 * 72 + 2400,
+       "nelder_mead": 10906 * 100 * 72 + 2400}   # bench.py BYTES_PER_PARTICLE_P2P2
+for s in ("newton", "closed_form", "gauss_newton", "nelder_mead"):
+    if s != "nelder_mead":   # (Nelder-Mead: counters only -- 2.3 ms of arithmetic per 78 MB, no FETCH/WRITE pass)
+        f = counters("%s/%s_FETCH_SIZE/**/*_results.db" % (T, s), "k_conv"); w = counters("%s/%s_WRITE_SIZE/**/*_results.db" % (T, s), "k_conv")
+        rd = f["FETCH_SIZE"][0] * 1024 * fetch_scale; wr = w["WRITE_SIZE"][0] * 1024
+        json.dump({"source": "scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), bench.py --solver %s --steps 20; "
+                             "FETCH_SIZE x%.0f per the gfx950 correction, calibrated in the same run on scripts/ubench/copy8 (2 GiB read reported %.4g KB, 2 GiB written reported %.4g KB)"
+                             % (s, fetch_scale, cal["FETCH_SIZE"], cal["WRITE_SIZE"]),
+                   "solver": s, "n_conv": 10907, "kernel": f["FETCH_SIZE"][2], "fetch_size_kb_raw": f["FETCH_SIZE"][0], "write_size_kb_raw": w["WRITE_SIZE"][0],
+                   "launches_averaged": f["FETCH_SIZE"][1], "bytes_per_launch": int(rd + wr), "read_bytes_per_launch": int(rd), "write_bytes_per_launch": int(wr),
+                   "algorithmic_bytes_per_launch": ALG[s]}, open("%s/hbm_traffic_%s.json" % (O, s), "w"), indent=1)
     a = counters("%s/sqa_%s/**/*_results.db" % (T, s), "k_conv"); b = counters("%s/sqb_%s/**/*_results.db" % (T, s), "k_conv")
     dur = sum(a["_dur"]) / len(a["_dur"])
     waves = a["SQ_WAVES"][0]
