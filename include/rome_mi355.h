@@ -267,6 +267,12 @@ typedef struct rome_clique_upsolve_host {
   double* new_pose2; double* bw_pose2;
   double* new_point2; double* bw_point2;
   double* new_pose3; double* bw_pose3;
+  /* optional: update GROUPS [n_up], nondecreasing.  Variables of one group are updated together (from the beliefs left by the previous
+   * groups), groups one after the other -- replaces `schedule` when given.  A FRONTIER of independent cliques (no frontal of one is a
+   * variable of another's factors as anything but a read-only separator) goes through ONE call this way: group g = the g-th frontal of
+   * every clique, so that every launch covers all cliques of the frontier ("cliques on the current Bayes-tree frontier
+   * are independent").  NULL: groups follow `schedule` (one variable per group / one group). */
+  const int32_t* up_group;
 } rome_clique_upsolve_host;
 int rome_clique_upsolve(rome_ctx*, const rome_opts*, const rome_clique_upsolve_host*);
 

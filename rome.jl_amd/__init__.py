@@ -22,7 +22,7 @@ from .canonical import (generateGraph_ZeroPose, buildGraphChain, generateGraph_T
                         generateGraph_Helix2DSlew, generateGraph_Helix2DSpiral, generateGraph_Boxes2D, generateGraph_Beehive,
                         generateGraph_Honeycomb, synth_beehive_mh, exportG2o, stringG2o, getPPE, setPPE, accumulateFactorMeans)
 from .convolution import approxConv, approxConvBelief
-from .clique import proposalbeliefs, predictbelief, CliqueBatch, upGibbsCliqueDensity
+from .clique import proposalbeliefs, predictbelief, CliqueBatch, upGibbsCliqueDensity, upGibbsCliqueFrontier
 from .serialization import loadDFG, saveDFG, packFactor, unpackFactor, packBelief, unpackBelief
 from .parametric import solveGraphParametric, initParametric
 from .device import DeviceGraph

@@ -128,7 +128,7 @@ class CliqueBatch:
         _lib.check(_lib.load().rome_clique_proposals(ctx.handle, C.byref(o), C.byref(q)), ctx.handle)
         return out
 
-    def upsolve(self, opts, up_labels, gibbs_iters=3, product_iters=1, schedule="sequential", messages=None, ctx=None):
+    def upsolve(self, opts, up_labels, gibbs_iters=3, product_iters=1, schedule="sequential", messages=None, ctx=None, groups=None):
         """IIF `upGibbsCliqueDensity` on the device in ONE call (rome_clique_upsolve): gibbs_iters x {proposals of every
         (factor, target) pair, manikde! bandwidths, multiscale Gibbs product, write-back} for the variables `up_labels` (the
         clique's frontals, in Gibbs order; the pairs of this batch must be grouped by target in that order).
@@ -146,6 +146,9 @@ class CliqueBatch:
         upv = np.array([self.vidx[l] for l in up_labels], dtype=np.int32)
         keep += [upt, upv]
         u.up_type, u.up_var = upt.ctypes.data_as(C.c_void_p), upv.ctypes.data_as(C.c_void_p)
+        if groups is not None:   # variables of one group are updated together, groups in order (a frontier of independent cliques)
+            grp = np.ascontiguousarray(groups, dtype=np.int32); keep.append(grp)
+            u.up_group = grp.ctypes.data_as(C.c_void_p)
         names = ("pose2", "point2", "pose3")
         res = {}
         for ti, vt in enumerate(types):
@@ -178,7 +181,49 @@ class CliqueUpsolveHost(C.Structure):
                 ("msg_pose2", C.c_void_p), ("msg_pose2_up", C.c_void_p), ("msg_point2", C.c_void_p), ("msg_point2_up", C.c_void_p),
                 ("msg_pose3", C.c_void_p), ("msg_pose3_up", C.c_void_p),
                 ("new_pose2", C.c_void_p), ("bw_pose2", C.c_void_p), ("new_point2", C.c_void_p), ("bw_point2", C.c_void_p),
-                ("new_pose3", C.c_void_p), ("bw_pose3", C.c_void_p)]
+                ("new_pose3", C.c_void_p), ("bw_pose3", C.c_void_p), ("up_group", C.c_void_p)]
+
+
+def upGibbsCliqueFrontier(fg, cliques, gibbsIters=3, Niter=1, solver=_lib.SOLVER_NEWTON, seed=None, ctx=None, setvals=True, **optkw):
+    """A FRONTIER of independent cliques through ONE `rome_clique_upsolve` call: `cliques` = list of frontal lists (Gibbs
+    order inside each); the g-th frontals of all cliques form update group g, so every launch covers the whole frontier.  The cliques
+    must be independent: a frontal of one may appear in another's factors only as a fixed (separator) variable that is not itself a
+    frontal of the frontier.  -> {frontal: (points, bandwidths)}"""
+    allf = [l for c in cliques for l in c]
+    if len(set(allf)) != len(allf):
+        raise ValueError("a variable is frontal in two cliques of the frontier")
+    fset = set(allf)
+    depth = max(len(c) for c in cliques)
+    order, groups = [], []
+    for g in range(depth):
+        for c in cliques:
+            if len(c) > g:
+                order.append(c[g]); groups.append(g)
+    owner = {l: k for k, c in enumerate(cliques) for l in c}
+    by_var = {}
+    for flabel, labels, _ in fg.factors:            # one pass over the factors (a frontier has thousands of destinations)
+        for l in labels:
+            if l in fset:
+                by_var.setdefault(l, []).append((flabel, labels))
+    pairs = []
+    for dest in order:
+        for flabel, labels in by_var.get(dest, ()):
+            others = [l for l in labels if l != dest]
+            if any(l in fset and owner[l] != owner[dest] for l in others):
+                raise ValueError("cliques of the frontier are not independent: %s links %s and a frontal of another clique" % (flabel, dest))
+            if all(fg.isInitialized(l) or l in fset for l in others):
+                pairs.append((flabel, dest))
+    batch = CliqueBatch(fg, pairs)
+    for l in order:
+        if l not in batch.vidx:
+            t = fg.variables[l]
+            batch.vidx[l] = len(batch.vars[t]); batch.vars[t].append(l)
+    opts = api.make_opts(N=fg.N, solver=solver, seed=seed, **optkw)
+    res = batch.upsolve(opts, order, gibbs_iters=gibbsIters, product_iters=Niter, groups=groups, ctx=ctx)
+    if setvals:
+        for l, (pts, _) in res.items():
+            fg.initVariable(l, pts)
+    return res
 
 
 def upGibbsCliqueDensity(fg, frontals, factor_labels=None, gibbsIters=3, Niter=1, schedule="sequential", messages=None,

@@ -833,12 +833,24 @@ int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsol
   for (int t = 0; t < 3; ++t) { const size_t b = rome::gibbs_workspace_bytes(vdim[t], prop_rows_t[t], (int)uplist[t].size()); if (b > tree_need) tree_need = b; }
   void* trees = nullptr;
   if ((rc = ensure(c, 10, tree_need, &trees))) return rc;
+  // ---- steps: ranges [k0, k1) of the update list that are updated together
+  std::vector<int> step_k;   // boundaries
+  step_k.push_back(0);
+  if (u->up_group) {
+    for (int k = 1; k < u->n_up; ++k) {
+      if (u->up_group[k] < u->up_group[k - 1]) return ROME_ERR_INVALID_ARG;
+      if (u->up_group[k] != u->up_group[k - 1]) step_k.push_back(k);
+    }
+  } else if (u->schedule == ROME_UPSOLVE_SEQUENTIAL) {
+    for (int k = 1; k < u->n_up; ++k) step_k.push_back(k);
+  }
+  step_k.push_back(u->n_up);
   // ---- the loop
   for (int it = 0; it < gi; ++it) {
     const uint64_t base = o->stream_offset + ((uint64_t)it << 32);
-    const int nsteps = u->schedule == ROME_UPSOLVE_JACOBI ? (u->n_up > 0 ? 1 : 0) : u->n_up;
+    const int nsteps = u->n_up > 0 ? (int)step_k.size() - 1 : 0;
     for (int st = 0; st < nsteps; ++st) {
-      const int k0 = u->schedule == ROME_UPSOLVE_JACOBI ? 0 : st, k1 = u->schedule == ROME_UPSOLVE_JACOBI ? u->n_up : st + 1;
+      const int k0 = step_k[st], k1 = step_k[st + 1];
       for (int k4 = 0; k4 < 4; ++k4) {
         const Fam& f = fam[k4];
         const int lo = fam_lo[k4][k0], hi = f.n == 0 ? 0 : (k1 < u->n_up ? fam_lo[k4][k1] : f.n);

@@ -389,13 +389,13 @@ __device__ __forceinline__ void residual_pose2pose2(double zx, double zy, double
   const double h21 = p.s * cz + p.c * sz;
   const double U11 = q.c * h11 + q.s * h21;
   const double U21 = q.c * h21 - q.s * h11;
-  r[0] = qhx - q.x; r[1] = qhy - q.y; r[2] = atan2(U21, U11);
+  r[0] = qhx - q.x; r[1] = qhy - q.y; r[2] = fast_atan2(U21, U11);   // (<= 2 ulp; the reference's KATs hold at 1e-14)
 }
 // PriorPose2: r = vee(log(p, m))
 __device__ __forceinline__ void residual_priorpose2(const Se2& m, const Se2& p, double (&r)[3]) {
   const double U11 = p.c * m.c + p.s * m.s;
   const double U21 = p.c * m.s - p.s * m.c;
-  r[0] = m.x - p.x; r[1] = m.y - p.y; r[2] = atan2(U21, U11);
+  r[0] = m.x - p.x; r[1] = m.y - p.y; r[2] = fast_atan2(U21, U11);
 }
 // Pose2Point2BearingRange: pl = p.Rᵀ (l - p.t);  r = (sym_rem(b - atan2(pl)), ρ - ‖pl‖)
 __device__ __forceinline__ void residual_bearingrange(double b, double rho, const Se2& p, double lx, double ly,

@@ -162,27 +162,36 @@ struct P2P2 {
     P.a1 = __builtin_fma(sg, vy, f1);
     return P;
   }
-  // the residual FUNCTOR itself (src/factors/Pose2D.jl:51-67 / PriorPose2.jl:37-47, through points) at the target point t
-  __device__ static __forceinline__ void functor(const Consts& K, const double (&z)[3], const double (&fxc)[3], const double (&t)[3], double (&r)[3]) {
+  // the residual FUNCTOR itself (src/factors/Pose2D.jl:51-67 / PriorPose2.jl:37-47, through points) at the target point t.
+  // Fn = what does not change over the iterates of a root-find: the fixed point (or the prior's sample point) and sin/cos of z_θ
+  struct Fn { Se2 F; double sz, cz; };
+  __device__ static __forceinline__ Fn functor_setup(const Consts& K, const double (&z)[3], const double (&fxc)[3]) {
+    Fn f;
+    if (K.dir == kDirPrior) { f.F = se2_from_coords(z[0], z[1], z[2]); f.sz = 0.0; f.cz = 1.0; }
+    else { f.F = se2_from_coords(fxc[0], fxc[1], fxc[2]); fast_sincos(z[2], &f.sz, &f.cz); }
+    return f;
+  }
+  __device__ static __forceinline__ void functor(const Consts& K, const Fn& f, const double (&z)[3], const double (&t)[3], double (&r)[3],
+                                                 double* st = nullptr, double* ct = nullptr) {
     const Se2 T = se2_from_coords(t[0], t[1], t[2]);
-    if (K.dir == kDirPrior) { residual_priorpose2(se2_from_coords(z[0], z[1], z[2]), T, r); return; }
-    const Se2 F = se2_from_coords(fxc[0], fxc[1], fxc[2]);
-    double sz, cz; fast_sincos(z[2], &sz, &cz);
-    if (K.dir == 0) residual_pose2pose2(z[0], z[1], cz, sz, F, T, r); else residual_pose2pose2(z[0], z[1], cz, sz, T, F, r);
+    if (st) { *st = T.s; *ct = T.c; }   // (the Gauss-Newton step of dir 1 needs R'(θ) at the same θ)
+    if (K.dir == kDirPrior) residual_priorpose2(f.F, T, r);
+    else if (K.dir == 0) residual_pose2pose2(z[0], z[1], f.cz, f.sz, f.F, T, r);
+    else residual_pose2pose2(z[0], z[1], f.cz, f.sz, T, f.F, r);
   }
   // status of a directly returned root: max|r| of the functor there against tol
   __device__ static __forceinline__ int verify(const Consts& K, const double (&z)[3], const double (&fxc)[3], const double (&t)[3], const Aux&, double tol) {
-    double r[3]; functor(K, z, fxc, t, r);
+    double r[3]; functor(K, functor_setup(K, z, fxc), z, t, r);
     return fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2]))) <= tol ? 0 : 1;
   }
   // Gauss-Newton on the functor (the oracle's p2p2_newton): evaluate r at the current point; dir 0: J = -I; dir 1: J = [I, R'(θ) z_t; 0, 1]
   __device__ static __forceinline__ int gauss_newton(const Consts& K, const double (&z)[3], const double (&fxc)[3], double (&t)[3], int max_iters, double tol) {
+    const Fn f = functor_setup(K, z, fxc);
     for (int it = 0; it < max_iters; ++it) {
-      double r[3]; functor(K, z, fxc, t, r);
+      double r[3], s, c; functor(K, f, z, t, r, &s, &c);
       if (fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2]))) <= tol) return 0;
       if (K.dir == 0) { t[0] += r[0]; t[1] += r[1]; t[2] += r[2]; }
       else {
-        double s, c; fast_sincos(t[2], &s, &c);
         const double J13 = -s * z[0] - c * z[1], J23 = c * z[0] - s * z[1], dth = -r[2];
         t[0] += -r[0] - J13 * dth; t[1] += -r[1] - J23 * dth; t[2] += dth;
       }

@@ -21,6 +21,7 @@ class FactorGraph:
         self.factors = []                    # (label, [var labels], factor)
         self.vals = {}                       # label -> (dim, N) coordinates (belief particles)
         self.multihypo = {}                  # factor label -> (w1, w2)
+        self._findex = {}                    # factor label -> (label, [var labels], factor)   (getFactor in O(1))
 
     # -- DFG-style API --
     def addVariable(self, label, vartype):
@@ -67,6 +68,7 @@ class FactorGraph:
             k += 1
         flabel = "".join(labels) + "f%d" % k
         self.factors.append((flabel, labels, factor))
+        self._findex[flabel] = self.factors[-1]
         if extra is not None:
             self.multihypo[flabel] = (w[1], w[2])
         return flabel
@@ -77,10 +79,14 @@ class FactorGraph:
         if not k:
             raise KeyError(flabel)
         self.factors.pop(k[0])
+        self._findex.pop(flabel, None)
         self.multihypo.pop(flabel, None)
 
     def getFactor(self, flabel):
-        for f in self.factors:
+        f = getattr(self, "_findex", {}).get(flabel)
+        if f is not None:
+            return f
+        for f in self.factors:               # (graphs whose factor list was filled directly, e.g. by a loader)
             if f[0] == flabel:
                 return f
         raise KeyError(flabel)

@@ -276,6 +276,7 @@ struct RomeCliqueUpsolveHost     # include/rome_mi355.h: rome_clique_upsolve_hos
   msg_pose3::Ptr{Float64}; msg_pose3_up::Ptr{Int32}
   new_pose2::Ptr{Float64}; bw_pose2::Ptr{Float64}; new_point2::Ptr{Float64}; bw_point2::Ptr{Float64}
   new_pose3::Ptr{Float64}; bw_pose3::Ptr{Float64}
+  up_group::Ptr{Int32}          # optional update groups (a frontier of independent cliques in one call); C_NULL: follow `schedule`
 end
 
 function upsolve_clique!(dfg::AbstractDFG, frontals::AbstractVector{Symbol}, factors::AbstractVector{<:DFGFactor};
@@ -297,7 +298,7 @@ function upsolve_clique!(dfg::AbstractDFG, frontals::AbstractVector{Symbol}, fac
     u = RomeCliqueUpsolveHost(_clique_host(t, Float64[], Float64[], Float64[], Float64[]),
                               Int32(gibbsIters), Int32(Niter), Int32(sequential ? 0 : 1), Int32(length(frontals)), pointer(upt), pointer(upv),
                               0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
-                              _p(new2), _p(bw2), _p(newl), _p(bwl), _p(new3), _p(bw3))
+                              _p(new2), _p(bw2), _p(newl), _p(bwl), _p(new3), _p(bw3), Ptr{Int32}(C_NULL))
     check(ccall((:rome_clique_upsolve, LIB), Cint, (Ptr{Cvoid}, Ref{RomeOpts}, Ref{RomeCliqueUpsolveHost}), ctx().h, o, u))
   end
   k = Dict(0 => 0, 1 => 0, 2 => 0)

@@ -66,7 +66,8 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
     return bel2, bell
 
 
-def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iters=1, schedule="sequential", solver=1, messages=None):
+def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iters=1, schedule="sequential", solver=1, messages=None,
+                groups=None):
     """Oracle-side restatement of rome_clique_upsolve / R.upGibbsCliqueDensity (IIF upGibbsCliqueDensity): same pairs, same row
     tables, same Philox streams; every convolution, bandwidth and product through oracle/ (CPU).  -> {label: points (dim, N)}"""
     from rome_jl_amd.clique import CliqueBatch
@@ -121,7 +122,10 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
 
     for it in range(gibbs_iters):
         base = it << 32
-        steps = [[l] for l in frontals] if schedule == "sequential" else [list(frontals)]
+        if groups is not None:   # update groups: variables of one group together, groups in order
+            steps = [[l for l, g in zip(frontals, groups) if g == gg] for gg in sorted(set(groups))]
+        else:
+            steps = [[l] for l in frontals] if schedule == "sequential" else [list(frontals)]
         for group in steps:
             props = proposals_for(group, base)
             new = {}

@@ -109,3 +109,51 @@ def test_upsolve_pcie_inclusive_time_per_clique():
         f.write("rome_clique_upsolve, hexagon cliques %s, N=100, gibbsIters=3, host beliefs in -> host beliefs out (PCIe + Python included):\n"
                 "  sequential schedule %.3f ms per clique (median of 20 passes)\n  jacobi schedule     %.3f ms per clique\n" % (CLIQUES, ms, msj))
     assert ms < 50.0
+
+
+def test_frontier_of_independent_cliques_in_one_call_equals_the_oracle():
+    """cliques on the current frontier are independent -> ONE rome_clique_upsolve call with update groups (group g = the
+    g-th frontal of every clique), against the oracle's restatement with the same groups."""
+    N = 100
+    fg_d, fg_o = _hex(N), _hex(N)
+    frontier = [["x0", "x1"], ["x3"], ["x5"]]       # x2, x4, x6, l1 only appear as fixed separators
+    res = R.upGibbsCliqueFrontier(fg_d, frontier, gibbsIters=3, seed=41)
+    order = ["x0", "x3", "x5", "x1"]; groups = [0, 0, 0, 1]
+    ref = upsolve_ref(R, fg_o, order, N, seed=41, gibbs_iters=3, groups=groups)
+    assert set(res) == set(order)
+    for l in order:
+        d = _wrapdiff(res[l][0].copy(), ref[l], 3)
+        assert np.mean(np.abs(d) < 1e-6) > 0.9 and np.abs(d.mean(1)).max() < 1e-3, (l, np.mean(np.abs(d) < 1e-6))
+    with pytest.raises(ValueError):
+        R.upGibbsCliqueFrontier(_hex(N), [["x0"], ["x1"]])          # x0 - x1 share a factor: not independent
+    with pytest.raises(ValueError):
+        R.upGibbsCliqueFrontier(_hex(N), [["x0"], ["x0", "x3"]])
+
+
+def test_manhattan_frontier_throughput():
+    """A frontier of ~1000 single-frontal cliques of the M3500 graph (an independent set of poses) through ONE call, PCIe and Python
+    included: ms per clique -> gpurun_out/ for profiles/."""
+    import time
+    N = 100
+    fg = R.loadG2o(os.path.join(ROOT, "tests", "golden", "manhattan.g2o"), N=N)
+    R.dead_reckon_init(fg, seed=11)
+    nbr = {l: set() for l in fg.variables}
+    for _, labels, _ in fg.factors:
+        for a in labels:
+            nbr[a].update(b for b in labels if b != a)
+    chosen, blocked = [], set()
+    for l in fg.variables:                         # greedy independent set
+        if l not in blocked:
+            chosen.append(l); blocked.add(l); blocked.update(nbr[l])
+    assert len(chosen) > 900
+    frontier = [[l] for l in chosen]
+    R.upGibbsCliqueFrontier(fg, frontier[:10], gibbsIters=3, seed=1, setvals=False)
+    t0 = time.perf_counter()
+    res = R.upGibbsCliqueFrontier(fg, frontier, gibbsIters=3, seed=2, setvals=False)
+    dt = time.perf_counter() - t0
+    assert len(res) == len(chosen) and all(np.isfinite(p).all() and (bw > 0).all() for p, bw in res.values())
+    moved = np.mean([np.abs(res[l][0][:2].mean(1) - fg.getVal(l)[:2].mean(1)).max() for l in chosen[:200]])
+    assert moved > 1e-4
+    with open(os.path.join(ROOT, "gpurun_out", "r03_clique_frontier.txt"), "w") as f:
+        f.write("rome_clique_upsolve with update groups: a frontier of %d independent single-frontal cliques of the M3500 graph (N=100, gibbsIters=3) in ONE call,\n"
+                "host beliefs in -> host beliefs out (PCIe + Python table building included): %.1f ms total = %.4f ms per clique\n" % (len(chosen), 1e3 * dt, 1e3 * dt / len(chosen)))
