@@ -422,6 +422,54 @@ class TargetShardedSweep:
             self.comm = None
 
 
+class FrontierShard:
+    """The clique FRONTIER sharded across GPUs (north_star: "the Bayes-tree clique frontier shards naturally across the 8
+    GPUs with separator-belief messages exchanged via RCCL"): the independent cliques of a frontier are dealt round-robin to the ranks,
+    every rank up-solves its share in ONE `rome_clique_upsolve` call (`upGibbsCliqueFrontier`), and ONE all-gather of the updated frontal
+    beliefs -- fixed-size blocks of 6N doubles, padded to the largest share -- leaves every rank with all new beliefs: the separator
+    messages the next frontier reads.  Every rank knows the clique list, so the block order needs no metadata exchange.
+    Philox streams: rank r draws stream_offset + (r << 40) + ...: the result equals running the shares one after the other in one
+    process with those offsets (tests/test_distributed_gloo.py)."""
+
+    def __init__(self, torch, dist, world, rank, device="cpu", upsolve=None):
+        self.torch, self.dist, self.world, self.rank, self.device = torch, dist, world, rank, device
+        if upsolve is None:
+            from .clique import upGibbsCliqueFrontier
+            upsolve = upGibbsCliqueFrontier
+        self.upsolve = upsolve
+
+    def shares(self, cliques):
+        return [list(cliques[r::self.world]) for r in range(self.world)]
+
+    def step(self, fg, cliques, seed=0x524F4D45, stream_offset=0, **kw):
+        """up-solve the frontier, store ALL new frontal beliefs in `fg` on every rank -> {label: points}"""
+        torch, N = self.torch, fg.N
+        shares = self.shares(cliques)
+        mine = shares[self.rank]
+        res = self.upsolve(fg, mine, seed=seed, stream_offset=stream_offset + (self.rank << 40), setvals=False, **kw) if mine else {}
+        order = [[l for c in sh for l in c] for sh in shares]
+        U = 6 * N
+        width = max(1, max(len(o) for o in order))
+        send = torch.zeros(width * U, dtype=torch.float64)
+        for k, l in enumerate(order[self.rank]):
+            pts = np.asarray(res[l][0], dtype=np.float64)
+            send[k * U: k * U + pts.size] = torch.as_tensor(pts.reshape(-1))
+        send = send.to(self.device)
+        recv = torch.empty(self.world * width * U, dtype=torch.float64, device=self.device)
+        if self.world > 1 or getattr(self, "always_collective", False):
+            self.dist.all_gather_into_tensor(recv, send)
+        else:
+            recv.copy_(send)
+        host = recv.cpu().numpy().reshape(self.world, width, U)
+        out = {}
+        for r in range(self.world):
+            for k, l in enumerate(order[r]):
+                d = fg.variables[l].dim
+                out[l] = host[r, k, :d * N].reshape(d, N).copy()
+                fg.initVariable(l, out[l])
+        return out
+
+
 class LinearizeShard:
     """Row-sharded `rome_linearize` for the parametric solver (`solveGraphParametric(..., shard=LinearizeShard(...))`): rank k
     evaluates rows shard_range(F, world, k) of every factor kind and an `all_gather` of the padded (r, Ja, Jb) blocks gives every

@@ -67,7 +67,7 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
 
 
 def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iters=1, schedule="sequential", solver=1, messages=None,
-                groups=None):
+                groups=None, stream_offset=0):
     """Oracle-side restatement of rome_clique_upsolve / R.upGibbsCliqueDensity (IIF upGibbsCliqueDensity): same pairs, same row
     tables, same Philox streams; every convolution, bandwidth and product through oracle/ (CPU).  -> {label: points (dim, N)}"""
     from rome_jl_amd.clique import CliqueBatch
@@ -121,7 +121,7 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
         return out
 
     for it in range(gibbs_iters):
-        base = it << 32
+        base = stream_offset + (it << 32)
         if groups is not None:   # update groups: variables of one group together, groups in order
             steps = [[l for l, g in zip(frontals, groups) if g == gg] for gg in sorted(set(groups))]
         else:

@@ -569,3 +569,72 @@ def test_target_sharded_solve_step_three_ranks_equals_one_rank():
     assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1)) and spans[-1][1] == one.prop.shape[0]
     for r in range(world):
         assert np.array_equal(ret[r][0], ref), r
+
+
+# ---------------------------------------------------------------------------------------------------------
+# FrontierShard: the independent cliques of a frontier dealt to 2 ranks, each up-solving its share (here: the oracle's restatement of
+# rome_clique_upsolve with update groups), ONE all-gather of the new frontal beliefs -> every rank holds all of them; equals the two
+# shares run one after the other in one process with the same stream offsets.
+def _oracle_frontier(R, N):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from solve_ref import upsolve_ref
+
+    def upsolve(fg, cliques, seed=0, stream_offset=0, setvals=False, **kw):
+        depth = max(len(c) for c in cliques)
+        order, groups = [], []
+        for g in range(depth):
+            for c in cliques:
+                if len(c) > g:
+                    order.append(c[g]); groups.append(g)
+        ref = upsolve_ref(R, fg, order, N, seed=seed, gibbs_iters=2, groups=groups, stream_offset=stream_offset)
+        return {l: (ref[l], None) for l in order}
+    return upsolve
+
+
+def _frontier_graph(R, N):
+    fg = R.generateGraph_Hexagonal(N=N)
+    R.dead_reckon_init(fg, seed=5)
+    fg.initVariable("l1", np.array([[20.0], [0.0]]) + np.random.default_rng(1).standard_normal((2, N)))
+    return fg
+
+
+_FRONTIER = [["x0", "x1"], ["x3"], ["x5"]]
+
+
+def _frontier_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import rome_jl_amd as R
+        from rome_jl_amd.distributed import FrontierShard
+        N = 32
+        fg = _frontier_graph(R, N)
+        sh = FrontierShard(torch, dist, world, rank, upsolve=_oracle_frontier(R, N))
+        out = sh.step(fg, _FRONTIER, seed=21)
+        ret[rank] = {l: fg.getVal(l).copy() for l in out}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_frontier_shard_two_ranks_equals_the_shares_run_in_one_process():
+    world = 2
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_frontier_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import rome_jl_amd as R
+    N = 32
+    fg = _frontier_graph(R, N)
+    ups = _oracle_frontier(R, N)
+    ref = {}
+    for r in range(world):                      # both shares read the SAME incoming beliefs (they are independent cliques)
+        share = _FRONTIER[r::world]
+        for l, (pts, _) in ups(fg, share, seed=21, stream_offset=r << 40).items():
+            ref[l] = pts
+    assert set(ref) == {"x0", "x1", "x3", "x5"}
+    for r in range(world):
+        assert set(ret[r]) == set(ref)
+        for l in ref:
+            assert np.array_equal(ret[r][l], ref[l]), (r, l)
+    assert not np.array_equal(ref["x3"], fg.getVal("x3"))

@@ -157,3 +157,27 @@ def test_manhattan_frontier_throughput():
     with open(os.path.join(ROOT, "gpurun_out", "r03_clique_frontier.txt"), "w") as f:
         f.write("rome_clique_upsolve with update groups: a frontier of %d independent single-frontal cliques of the M3500 graph (N=100, gibbsIters=3) in ONE call,\n"
                 "host beliefs in -> host beliefs out (PCIe + Python table building included): %.1f ms total = %.4f ms per clique\n" % (len(chosen), 1e3 * dt, 1e3 * dt / len(chosen)))
+
+
+def test_frontier_shard_one_rank_rccl_equals_the_direct_call():
+    """rome_jl_amd.distributed.FrontierShard (the clique frontier dealt to the ranks + ONE all-gather of the new frontal beliefs) with one
+    rank and the collective forced through RCCL: same beliefs as the direct frontier call; the multi-rank form runs over gloo in
+    tests/test_distributed_gloo.py."""
+    import torch
+    import torch.distributed as dist
+    from rome_jl_amd.distributed import FrontierShard
+    N = 100
+    frontier = [["x0", "x1"], ["x3"], ["x5"]]
+    fg_a, fg_b = _hex(N), _hex(N)
+    direct = R.upGibbsCliqueFrontier(fg_a, frontier, gibbsIters=2, seed=5)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = "29581"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sh = FrontierShard(torch, dist, 1, 0, device=torch.device("cuda", 0))
+        sh.always_collective = True
+        out = sh.step(fg_b, frontier, seed=5, gibbsIters=2)
+    finally:
+        dist.destroy_process_group()
+    assert set(out) == set(direct)
+    for l in out:
+        assert np.array_equal(out[l], direct[l][0]) and np.array_equal(fg_b.getVal(l), fg_a.getVal(l))
