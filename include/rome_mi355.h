@@ -295,7 +295,7 @@ typedef struct rome_conv_dev {
   const double* noise;       /* [C][dz][N] or NULL                                                */
   double* out;               /* [C][dt][N] proposals                                              */
   int32_t* status;           /* [C][N] or NULL                                                    */
-  /* optional: up to 4 convolution rows whose proposal block is ALSO written to mirror_out[m] ([dt][N] each),
+  /* optional: up to 4 convolution rows (more: mirror_map below) whose proposal block is ALSO written to mirror_out[m] ([dt][N] each),
    * e.g. separator beliefs straight into an RCCL send buffer (no gather kernel between sweep and collective) */
   int32_t n_mirror;
   int32_t mirror_row[4];
@@ -312,8 +312,9 @@ typedef struct rome_conv_dev {
   const double* nullhypo;
   /* optional: the four table columns interleaved, [C][4] int32 = (factor, dir, fixed_var, target_var) per row.  When given it
    * REPLACES the column pointers above (which may then be NULL) and, for rows without pre-sampled noise / multihypo /
-   * nullhypo, selects the lean sweep kernel: one 16-byte scalar load per convolution instead of four dependent ones
-   * (Manhattan-3500 Newton sweep 18.0 -> see profiles/).  Bearing-range rows ignore the dir entry. */
+   * nullhypo, selects the plain sweep kernels: the packed sweep (k_conv_flat: thread = two neighbouring particles, 5 rows per
+   * 256-thread block at N = 100, per-factor constants staged through LDS) for the unique-root factors under CLOSED_FORM / NEWTON, the
+   * lean wave-per-row kernel otherwise.  Bearing-range rows ignore the dir entry. */
   const int32_t* rows4;
   /* optional: ANY number of mirrored rows (replaces n_mirror / mirror_row when given): mirror_map[c] = block of mirror_out that
    * row c's proposal is also written to, -1 = none.  A Bayes-tree cut / the beehive lattice publishes more than four separators. */

@@ -1407,7 +1407,11 @@ hipError_t launch_sweep_pose2(const ConvArgs* p2p2, const ConvArgs* br1, const C
   const int N = p2p2 ? p2p2->N : (br1 ? br1->N : (br0 ? br0->N : 0));
   const bool fusable = p2p2 && br1 && br0 && p2p2->n_conv > 0 && br1->n_conv > 0 && br0->n_conv > 0 &&
                        (solver == kSolverClosedForm || solver == kSolverNewton) && N > 64 && N <= 128 && br1->N == N && br0->N == N &&
-                       plain_rows(*p2p2) && plain_rows(*br1) && plain_rows(*br0) && br1->dir_all == 1 && br0->dir_all == 0;
+                       plain_rows(*p2p2) && plain_rows(*br1) && plain_rows(*br0) && br1->dir_all == 1 && br0->dir_all == 0 &&
+                       // the fused kernel runs every part at the register allocation of the bearing-range pose body (88 VGPRs, 5 waves
+                       // per SIMD instead of the packed sweep's 8): worth two saved launches unless the odometry table is both huge and
+                       // dominant
+                       (p2p2->n_conv <= 100000 || 10 * (br1->n_conv + br0->n_conv) >= p2p2->n_conv);
   if (!fusable) {
     hipError_t e = hipSuccess;
     if (br1 && br1->n_conv > 0 && (e = launch_conv_bearingrange(*br1, solver, s)) != hipSuccess) return e;
