@@ -729,13 +729,13 @@ int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsol
   }
   // ---- rows: validate, remap the variable indices to the device order, find the row range of every update position
   std::vector<int32_t> rows_dev[4];
-  std::vector<int> fam_lo[4], fam_hi[4];   // rows of family f that target update position k: [lo[k], hi[k])
+  std::vector<int> fam_lo[4];              // first row of family f that targets update position >= k (rows are grouped in update order)
   std::vector<std::vector<int>> csr[3];    // per type: proposal rows (in the type's buffer) of every updated variable
   for (int t = 0; t < 3; ++t) csr[t].resize(uplist[t].size());
   for (int k4 = 0; k4 < 4; ++k4) {
     const Fam& f = fam[k4];
     rows_dev[k4].resize((size_t)f.n * 4);
-    fam_lo[k4].assign((size_t)u->n_up + 1, 0); fam_hi[k4].assign((size_t)u->n_up + 1, 0);
+    fam_lo[k4].assign((size_t)u->n_up + 1, 0);
     int prev = -1;
     for (int r = 0; r < f.n; ++r) {
       const int32_t* e = f.rows4 + 4 * (size_t)r;
@@ -743,13 +743,12 @@ int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsol
       const int k = kpos[f.vt][e[3]];
       if (k < 0 || k < prev) return ROME_ERR_INVALID_ARG;   // every row targets an updated variable; rows grouped in update order
       if (k != prev) { for (int kk = prev + 1; kk <= k; ++kk) fam_lo[k4][kk] = r; }
-      fam_hi[k4][k] = r + 1; prev = k;
+      prev = k;
       int32_t* d = rows_dev[k4].data() + 4 * (size_t)r;
       d[0] = e[0]; d[1] = e[1]; d[2] = newidx[f.vf][e[2]]; d[3] = newidx[f.vt][e[3]];
       csr[f.vt][(size_t)newidx[f.vt][e[3]]].push_back(f.base + r);
     }
     for (int kk = prev + 1; kk <= u->n_up; ++kk) fam_lo[k4][kk] = f.n;
-    for (int kk = 0; kk < u->n_up; ++kk) if (fam_hi[k4][kk] < fam_lo[k4][kk]) fam_hi[k4][kk] = fam_lo[k4][kk];
   }
   for (int t = 0; t < 3; ++t)
     for (int m = 0; m < n_msg[t]; ++m) {

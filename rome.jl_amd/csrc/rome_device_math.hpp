@@ -536,21 +536,6 @@ __device__ __forceinline__ void quat_log(const double (&q)[4], double* w) {
   k = q[0] < 0.0 ? -k : k;
   w[0] = k * q[1]; w[1] = k * q[2]; w[2] = k * q[3];
 }
-// Single-precision Log for the inflation-spread statistic only (|error| <= 3e-5 rad): asin by a degree-4 polynomial in x² on
-// x <= 1/√2 (the branch selection of quat_angle), one hardware sqrt / rcp; no library call, ~25 instructions.
-__device__ __forceinline__ void quat_log_f32(const double (&q)[4], float (&w)[3]) {
-  const float x = (float)q[1], y = (float)q[2], z = (float)q[3], aw = fabsf((float)q[0]);
-  const float n2 = fmaf(x, x, fmaf(y, y, z * z));
-  const float n = __builtin_sqrtf(n2);
-  const float m = fminf(n, aw), m2 = m * m;
-  float p = 0.09535770863294601f;
-  p = fmaf(p, m2, 0.008225217461585999f); p = fmaf(p, m2, 0.08268097043037415f); p = fmaf(p, m2, 0.16607673466205597f); p = fmaf(p, m2, 1.000010371208191f);
-  const float as = m * p;
-  const float th = n <= aw ? 2.0f * as : 3.14159265358979f - 2.0f * as;
-  float k = n2 > 1e-12f ? th * __builtin_amdgcn_rcpf(n) : 2.0f;
-  k = q[0] < 0.0 ? -k : k;
-  w[0] = k * x; w[1] = k * y; w[2] = k * z;
-}
 __device__ __forceinline__ void quat_mul(const double (&a)[4], const double (&b)[4], double (&o)[4]) {
   o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
   o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];

@@ -895,15 +895,16 @@ __device__ __forceinline__ void conv_wave_body(const ConvArgs& a, int blk) {
 //             in every SoA row -> one 16-byte load / store per coordinate;
 //   block   = CPB consecutive rows x H = ceil(N/2) pairs  (N = 100: 5 rows x 50 = 250 of 256 threads, against 100 of 128
 //             lane-slots with one wavefront per row);
-//   per-factor constants (μ, chol Σ) are staged ONCE per block through LDS by the first CPB x 16 threads and read back by every
-//             thread at its row's slot (conflict-free broadcasts); the table row itself is a 16-byte load per thread.
+//   per-factor constants (μ, chol Σ) are staged ONCE per block through LDS: the first NK threads of every row load one entry each of
+//             their own row's factor, every thread reads its row's slot back (broadcast reads); the table row itself is a 16-byte
+//             load per thread.
 // The root comes from FP::prepare (the same function the wave-per-row kernel and the per-factor entry points use: bit-identical
 // proposals); NEWTON additionally evaluates the residual functor at the root when a status array is asked for.
 // Any N >= 2; the start points u0 are never read (48 B of HBM traffic per Pose2 particle: fixed 24 + proposal 24).
 // ------------------------------------------------------------------------------------------
 constexpr int kFlatThreads = 256;
-constexpr int kFlatMaxRows = 16;    // rows per block (staging: 16 threads per row)
-template <class FP> struct FlatStage { static constexpr int kLanes = FP::NK <= 16 ? 16 : 32; };
+constexpr int kFlatMaxRows = 16;    // rows per block (rows of >= 8 pair-threads: N >= 16)
+template <class FP> struct FlatStage { static constexpr int kLanes = FP::NK <= 16 ? 16 : 32; };   // LDS doubles per row (>= NK)
 
 #ifndef ROME_FLAT_MINWAVES
 #define ROME_FLAT_MINWAVES 8   // Pose2 / Point2 sweeps: 8 waves per SIMD (<= 64 VGPRs)
