@@ -203,6 +203,11 @@ int rome_sample_priorpose2(rome_ctx*, const rome_opts*, int32_t C, const double*
                            const double* noise /*C*N*3 or NULL*/, double* out /*C*N*3*/);
 int rome_sample_priorpose3(rome_ctx*, const rome_opts*, int32_t C, const double* mu /*C*6*/, const double* cov /*C*36*/,
                            const double* noise /*C*N*6 or NULL*/, double* out /*C*N*6*/);
+/* PriorPoint2 (src/factors/Point2D.jl:8-18) in the NON-parametric path: N samples of the landmark prior MvNormal(mu, cov) -- the
+ * proposal a landmark prior contributes to the product of its variable (test/testBearingRange2D.jl:324 puts one on the landmark of the
+ * "solve for pose" test). */
+int rome_sample_priorpoint2(rome_ctx*, const rome_opts*, int32_t C, const double* mu /*C*2*/, const double* cov /*C*4*/,
+                            const double* noise /*C*N*2 or NULL*/, double* out /*C*N*2*/);
 
 /* ---------------------------------------------------------------------------------------------
  * Clique-level batch from HOST beliefs: every (factor, direction) convolution of a clique -- or of one variable, what IIF
@@ -334,6 +339,7 @@ int rome_sweep_pose2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev* p2p2,
                          const uint64_t* family_stream_offset /*[3] or NULL*/);
 int rome_sample_priorpose2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*); /* uses factor, mu, L, noise, out */
 int rome_sample_priorpose3_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);
+int rome_sample_priorpoint2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);   /* L = [F][3] packed Cholesky of the 2x2 covariances */
 
 /* ---------------------------------------------------------------------------------------------
  * Parametric path: batched whitened residuals + analytic Jacobians at the

@@ -223,6 +223,16 @@ def sample_priorpose2(opts, mu, L, factor=None, noise=None, C_=None):
     return out
 
 
+def sample_priorpoint2(opts, mu, L, factor=None, noise=None, C_=None):
+    mu, pmu = _d(np.atleast_2d(mu)); L, pL = _d(np.atleast_2d(L)); fa, pfa = _i(factor)
+    Cn = C_ if C_ is not None else (len(fa) if fa is not None else mu.shape[0])
+    nz, pn = (None, None) if noise is None else _d(noise)
+    out = np.zeros((Cn, 2, opts.n_particles))
+    rc = lib().ro_sample_priorpoint2(C.byref(opts), Cn, pfa, pmu, pL, pn, out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    return out
+
+
 def conv_pose3pose3(opts, mu, L, bel, fixed_var, target_var, dirs, factor=None, noise=None, want_status=False):
     mu, pmu = _d(mu); L, pL = _d(L); bel, pb = _d(bel)
     fv, pfv = _i(fixed_var); tv, ptv = _i(target_var); dr, pdr = _i(dirs); fa, pfa = _i(factor)

@@ -766,6 +766,25 @@ int ro_sample_priorpose2(const ro_opts* o, int C, const int32_t* factor, const d
   return 0;
 }
 
+/* ---- PriorPoint2: N samples μ + Lξ of the landmark prior (src/factors/Point2D.jl:8-18; ⚠IIF samplePoint) ---- */
+int ro_sample_priorpoint2(const ro_opts* o, int C, const int32_t* factor, const double* mu, const double* L,
+                          const double* noise, double* out) {
+  const int N = o->n_particles;
+  for (int c = 0; c < C; ++c) {
+    const int f = get_idx(factor, c);
+    const double* m = mu + 2 * f; const double* Lf = L + 3 * f;
+    double* ob = out + (size_t)c * 2 * N;
+    for (int i = 0; i < N; ++i) {
+      double xi[2];
+      if (noise) { xi[0] = noise[(size_t)c * 2 * N + i]; xi[1] = noise[(size_t)c * 2 * N + N + i]; }
+      else ro_rng_normals(o->seed, o->stream_offset + (uint64_t)c, (uint32_t)i, 2, xi);
+      ob[i] = m[0] + Lf[0] * xi[0];
+      ob[N + i] = m[1] + Lf[1] * xi[0] + Lf[2] * xi[1];
+    }
+  }
+  return 0;
+}
+
 /* ---- Pose2Point2BearingRange ---- */
 typedef struct { double z[2]; double fixed[3]; int dir; } br_ctx;
 static void br_resid(const double z[2], const double pose[3], const double l[2], double r[2]) {

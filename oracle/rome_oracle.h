@@ -107,6 +107,8 @@ int ro_conv_pose2point2br_mh(const ro_opts* o, int C, const int32_t* factor, int
                              const int32_t* alt_var /*[C] or NULL*/, const double* hypo_w /*[C]*/, double spread_nh);
 int ro_sample_priorpose2(const ro_opts* o, int C, const int32_t* factor,
                          const double* mu, const double* L, const double* noise, double* out /*[C][3][N]*/);
+int ro_sample_priorpoint2(const ro_opts* o, int C, const int32_t* factor,
+                          const double* mu /*[F][2]*/, const double* L /*[F][3]*/, const double* noise, double* out /*[C][2][N]*/);
 int ro_conv_pose3pose3(const ro_opts* o, int C, const int32_t* factor, const int32_t* dir,
                        const int32_t* fixed_var, const int32_t* target_var,
                        const double* mu /*[F][6]*/, const double* L /*[F][21]*/,

@@ -14,7 +14,7 @@ from .factors import (MvNormal, Normal, Uniform, Pose2, Point2, Pose3, Pose2Pose
 from .api import (linearize, belief_stats, kde_bandwidth, kde_max, manifoldProduct, calcPPE, points_to_coords, coords_to_points, calcFactorResidualTemporary, make_opts, cholesky_lower, default_context,
                   residual_pose2pose2, residual_priorpose2, residual_pose2point2br, residual_pose2point2br_pt,
                   residual_pose3pose3, residual_pose3pose3_pt, residual_priorpose3,
-                  conv_pose2pose2, conv_pose2point2br, conv_pose3pose3, sample_priorpose2, sample_priorpose3)
+                  conv_pose2pose2, conv_pose2point2br, conv_pose3pose3, sample_priorpose2, sample_priorpose3, sample_priorpoint2)
 from .graph import (FactorGraph, initfg, fifoFreeze, isMarginalized, importG2o, parseG2oInstruction, loadG2o, synth_manhattan,
                     synth_manhattan_edges, synth_pose2_tables, synth_helix3d, synth_mit_br, add_synthetic_landmarks, dead_reckon_init_pose3, generateGraph_Circle, generateGraph_Hexagonal,
                     PackedGraph, dead_reckon_init)

@@ -79,12 +79,14 @@ SIGNATURES = {
     "rome_conv_pose3pose3": (C.c_int, [_CTX, _PO, C.c_int32, _PI, _PD, _PD, _PD, _PD, _PD, _PI]),
     "rome_sample_priorpose2": (C.c_int, [_CTX, _PO, C.c_int32, _PD, _PD, _PD, _PD]),
     "rome_sample_priorpose3": (C.c_int, [_CTX, _PO, C.c_int32, _PD, _PD, _PD, _PD]),
+    "rome_sample_priorpoint2": (C.c_int, [_CTX, _PO, C.c_int32, _PD, _PD, _PD, _PD]),
     "rome_conv_pose2pose2_dev": (C.c_int, [_CTX, _PO, _PT]),
     "rome_conv_pose2point2br_dev": (C.c_int, [_CTX, _PO, _PT]),
     "rome_conv_pose3pose3_dev": (C.c_int, [_CTX, _PO, _PT]),
     "rome_sweep_pose2_dev": (C.c_int, [_CTX, _PO, _PT, _PT, _PT, C.POINTER(C.c_uint64)]),
     "rome_sample_priorpose2_dev": (C.c_int, [_CTX, _PO, _PT]),
     "rome_sample_priorpose3_dev": (C.c_int, [_CTX, _PO, _PT]),
+    "rome_sample_priorpoint2_dev": (C.c_int, [_CTX, _PO, _PT]),
     "rome_linearize": (C.c_int, [_CTX, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
     "rome_linearize_dev": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rome_belief_stats_dev": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -336,7 +336,7 @@ def _sample_prior(fn, d, opts, mu, cov, noise, ctx):
     mu = np.atleast_2d(_d(mu)); C_ = mu.shape[0]; N = opts.n_particles
     cov = _d(cov, (C_, d, d))
     noise = None if noise is None else _blocks(noise, C_, N, d, opts.layout, points_ok=False)
-    pl = {3: 6, 6: 12}[d] if opts.layout == _lib.LAYOUT_AOS_POINTS else d
+    pl = {2: 2, 3: 6, 6: 12}[d] if opts.layout == _lib.LAYOUT_AOS_POINTS else d
     out = np.empty((C_, d, N) if opts.layout == _lib.LAYOUT_SOA else (C_, N, pl))
     _lib.check(fn(ctx.handle, C.byref(opts), C_, _p(mu), _p(cov), _p(noise), _p(out)), ctx.handle)
     return out
@@ -348,3 +348,8 @@ def sample_priorpose2(opts, mu, cov, noise=None, ctx=None):
 
 def sample_priorpose3(opts, mu, cov, noise=None, ctx=None):
     return _sample_prior(_lib.load().rome_sample_priorpose3, 6, opts, mu, cov, noise, ctx)
+
+
+def sample_priorpoint2(opts, mu, cov, noise=None, ctx=None):
+    """N samples of `PriorPoint2(MvNormal(mu, cov))` (src/factors/Point2D.jl:8-18): the proposal a landmark prior contributes"""
+    return _sample_prior(_lib.load().rome_sample_priorpoint2, 2, opts, mu, cov, noise, ctx)

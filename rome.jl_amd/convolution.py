@@ -3,7 +3,7 @@ test/testBasicPose2Conv.jl:25, test/TestPoseAndPoint2Constraints.jl:36,97)."""
 import numpy as np
 
 from . import _lib, api
-from .factors import Pose2Pose2, PriorPose2, Pose2Point2BearingRange, Pose3Pose3, PriorPose3
+from .factors import Pose2Pose2, PriorPose2, Pose2Point2BearingRange, Pose3Pose3, PriorPose3, PriorPoint2
 
 
 def approxConv(fg, flabel, target, solver=_lib.SOLVER_NEWTON, seed=None, ctx=None, **optkw):
@@ -17,6 +17,8 @@ def approxConv(fg, flabel, target, solver=_lib.SOLVER_NEWTON, seed=None, ctx=Non
         return api.sample_priorpose2(opts, [f.Z.mu], [f.Z.cov], ctx=ctx)[0]
     if isinstance(f, PriorPose3):
         return api.sample_priorpose3(opts, [f.Z.mu], [f.Z.cov], ctx=ctx)[0]
+    if isinstance(f, PriorPoint2):
+        return api.sample_priorpoint2(opts, [f.Z.mu], [f.Z.cov], ctx=ctx)[0]
     mh = fg.multihypo.get(flabel)
     if mh is not None and isinstance(f, Pose2Pose2):   # Pose2Pose2 over [a, b1, b2]
         a, b1, b2 = labels

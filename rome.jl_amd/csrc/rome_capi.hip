@@ -145,7 +145,7 @@ void from_soa(const double* src, int C, int N, int d, int layout, double* dst) {
   }
 }
 
-enum FactorKind { kP2P2, kBR, kP3P3, kPrior2, kPrior3 };
+enum FactorKind { kP2P2, kBR, kP3P3, kPrior2, kPrior3, kPriorPt2 };
 
 inline int point_len(int dim) { return dim == 3 ? 6 : (dim == 6 ? 12 : dim); }
 
@@ -176,7 +176,7 @@ int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const i
   if (o->layout == ROME_LAYOUT_AOS_POINTS) {
     // the reference's native point containers: convert to AoS coordinates on the device, run, convert back
     rome_opts oc = *o; oc.layout = ROME_LAYOUT_AOS;
-    const bool has_fx = (kind != kPrior2 && kind != kPrior3);
+    const bool has_fx = (kind != kPrior2 && kind != kPrior3 && kind != kPriorPt2);
     const size_t rows = (size_t)C * N;
     std::vector<double> cf, ct(rows * dt), ca;
     int rc2;
@@ -193,7 +193,7 @@ int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const i
   }
   ROME_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  const bool has_fixed = (kind != kPrior2 && kind != kPrior3);
+  const bool has_fixed = (kind != kPrior2 && kind != kPrior3 && kind != kPriorPt2);
   const bool mh = alt && hypo_w;   // multihypo: the alternative landmark blocks are appended behind the landmark-side array
   const size_t blk_f = (size_t)C * N * df, blk_t = (size_t)C * N * dt;
   const size_t n_fixed = has_fixed ? blk_f * ((mh && dir_all == 1) ? 2 : 1) : 0;
@@ -266,6 +266,7 @@ int host_conv(rome_ctx* ctx, const rome_opts* o, FactorKind kind, int C, const i
     case kP3P3: e = rome::launch_conv_pose3pose3(a, o->solver, s); break;
     case kPrior2: e = rome::launch_sample_priorpose2(a, s); break;
     case kPrior3: e = rome::launch_sample_priorpose3(a, s); break;
+    case kPriorPt2: e = rome::launch_sample_priorpoint2(a, s); break;
   }
   ROME_HIP(ctx, e);
   ROME_HIP(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * blk_t, hipMemcpyDeviceToHost, s));
@@ -495,6 +496,17 @@ int rome_sample_priorpose3(rome_ctx* c, const rome_opts* o, int32_t C, const dou
   return host_conv(c, o, kPrior3, C, nullptr, 0, 6, 6, 6, mu, L.data(), 21, nullptr, noise, out, nullptr);
 }
 
+int rome_sample_priorpoint2(rome_ctx* c, const rome_opts* o, int32_t C, const double* mu, const double* cov, const double* noise, double* out) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || C < 0 || (C > 0 && (!mu || !cov || !out))) return ROME_ERR_INVALID_ARG;
+  if (C == 0) return ROME_OK;
+  std::vector<double> L((size_t)C * 3);
+  if ((rc = rome_cholesky_lower(2, C, cov, L.data()))) return rc;
+  rome_opts oc = *o;
+  if (oc.layout == ROME_LAYOUT_AOS_POINTS) oc.layout = ROME_LAYOUT_AOS;   // a Point2 point IS its coordinates
+  return host_conv(c, &oc, kPriorPt2, C, nullptr, 0, 2, 2, 2, mu, L.data(), 3, nullptr, noise, out, nullptr);
+}
+
 /* ---- device-pointer convolutions ---- */
 static int dev_common(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t, bool need_beliefs) {
   int rc = check_opts(o); if (rc) return rc;
@@ -551,6 +563,12 @@ int rome_sample_priorpose3_dev(rome_ctx* c, const rome_opts* o, const rome_conv_
   int rc = dev_common(c, o, t, false); if (rc) return rc;
   rome::ConvArgs a; args_from_dev(a, o, t);
   ROME_HIP(c, rome::launch_sample_priorpose3(a, c->stream));
+  return ROME_OK;
+}
+int rome_sample_priorpoint2_dev(rome_ctx* c, const rome_opts* o, const rome_conv_dev* t) {
+  int rc = dev_common(c, o, t, false); if (rc) return rc;
+  rome::ConvArgs a; args_from_dev(a, o, t);
+  ROME_HIP(c, rome::launch_sample_priorpoint2(a, c->stream));
   return ROME_OK;
 }
 

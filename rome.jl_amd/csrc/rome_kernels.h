@@ -50,6 +50,7 @@ hipError_t launch_conv_pose3pose3(const ConvArgs& a, int solver, hipStream_t s);
 hipError_t launch_sweep_pose2(const ConvArgs* p2p2, const ConvArgs* br1, const ConvArgs* br0, int solver, hipStream_t s);
 hipError_t launch_sample_priorpose2(const ConvArgs& a, hipStream_t s);
 hipError_t launch_sample_priorpose3(const ConvArgs& a, hipStream_t s);
+hipError_t launch_sample_priorpoint2(const ConvArgs& a, hipStream_t s);
 
 hipError_t launch_residual_pose2pose2(int n, const double* z, const double* p, const double* q, double* r, hipStream_t s);
 hipError_t launch_residual_priorpose2(int n, const double* m, const double* p, double* r, hipStream_t s);

@@ -1221,7 +1221,7 @@ __global__ void __launch_bounds__(256) k_sample_prior(const ConvArgs a) {
         zc[r] = s;
       }
       if constexpr (D == 3) zc[2] = wrap_pi(zc[2]);
-      else { Se3 P; se3_from_coords(zc, P); se3_to_coords(P, zc); }
+      else if constexpr (D == 6) { Se3 P; se3_from_coords(zc, P); se3_to_coords(P, zc); }   // (D == 2: a Point2, the sample itself)
 #pragma unroll
       for (int d = 0; d < D; ++d) ob[d * N + i] = zc[d];
     }
@@ -1453,6 +1453,7 @@ static hipError_t launch_prior(const ConvArgs& a, hipStream_t s) {
 }
 hipError_t launch_sample_priorpose2(const ConvArgs& a, hipStream_t s) { return launch_prior<3>(a, s); }
 hipError_t launch_sample_priorpose3(const ConvArgs& a, hipStream_t s) { return launch_prior<6>(a, s); }
+hipError_t launch_sample_priorpoint2(const ConvArgs& a, hipStream_t s) { return launch_prior<2>(a, s); }
 
 static inline dim3 rows_grid(int n) { return dim3((n + 255) / 256); }
 hipError_t launch_residual_pose2pose2(int n, const double* z, const double* p, const double* q, double* r, hipStream_t s) {

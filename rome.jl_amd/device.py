@@ -77,7 +77,7 @@ class DeviceGraph:
                                   alt0=t(r0["alt"], i32), w0=t(r0["w"], f64),
                                   rows4_0=t(np.stack([r0["factor"], np.zeros(len(r0["factor"]), np.int32), r0["pose"], r0["point"]], axis=1), i32),
                                   rows4_1=t(np.stack([np.arange(b["F"], dtype=np.int32), np.ones(b["F"], np.int32), b["point"], b["pose"]], axis=1), i32))
-        for name, tab, d in (("prior2", pk.prior2, 3), ("prior3", pk.prior3, 6)):
+        for name, tab, d in (("prior2", pk.prior2, 3), ("prior3", pk.prior3, 6), ("priorpt2", pk.priorpt2, 2)):
             if tab["F"]:
                 self.tab[name] = dict(F=tab["F"], mu=t(tab["mu"], f64), L=t(cholesky_lower(tab["cov"]), f64), var=t(tab["var"], i32))
 
@@ -91,17 +91,19 @@ class DeviceGraph:
         Fb = self.tab["br"]["F"] if "br" in self.tab else 0
         Fb0 = self.tab["br"]["F0"] if "br" in self.tab else 0
         C3 = self.tab["p3p3"]["C"] if "p3p3" in self.tab else 0
-        self.n_prop = {Pose2: C2 + Fb, Point2: Fb0, Pose3: C3}
+        Ppt = self.tab["priorpt2"]["F"] if "priorpt2" in self.tab else 0   # landmark priors: one proposal row each, behind the sightings
+        self.n_prop = {Pose2: C2 + Fb, Point2: Fb0 + Ppt, Pose3: C3}
         self.prop_bw = {}
         self.prop = {Pose2: torch.zeros((max(C2 + Fb, 1), 3, self.N), dtype=f64, device=self.device),
-                     Point2: torch.zeros((max(Fb0, 1), 2, self.N), dtype=f64, device=self.device),
+                     Point2: torch.zeros((max(Fb0 + Ppt, 1), 2, self.N), dtype=f64, device=self.device),
                      Pose3: torch.zeros((max(C3, 1), 6, self.N), dtype=f64, device=self.device)}
         self.bel_next = {vt: torch.zeros_like(self.bel[vt]) for vt in (Pose2, Point2, Pose3)}
         tgt2 = [self.tab["p2p2"]["target"].cpu().numpy()] if C2 else []
         if Fb:
             tgt2.append(pk.br["pose"])
         self._prop_targets = {Pose2: np.concatenate(tgt2) if tgt2 else np.zeros(0, np.int32),
-                              Point2: pk.br["rows0"]["point"] if Fb else np.zeros(0, np.int32),
+                              Point2: np.concatenate([pk.br["rows0"]["point"] if Fb else np.zeros(0, np.int32),
+                                                      pk.priorpt2["var"] if Ppt else np.zeros(0, np.int32)]),
                               Pose3: self.tab["p3p3"]["target"].cpu().numpy() if C3 else np.zeros(0, np.int32)}
         self.frozen = set()
         self._build_csr()
@@ -232,8 +234,8 @@ class DeviceGraph:
         return self._plan(fn, opts, n_conv=tb["F"], dir_all=0, mu=tb["mu"], L=tb["L"], noise=noise, out=out)
 
     # ---- solve loop pieces ----
-    STREAM_P2P2, STREAM_BR1, STREAM_BR0, STREAM_PROD2, STREAM_PRODL, STREAM_P3P3, STREAM_PROD3 = \
-        0, 1 << 28, 2 << 28, 3 << 28, 4 << 28, 5 << 28, 6 << 28
+    STREAM_P2P2, STREAM_BR1, STREAM_BR0, STREAM_PROD2, STREAM_PRODL, STREAM_P3P3, STREAM_PROD3, STREAM_PRIORPT2 = \
+        0, 1 << 28, 2 << 28, 3 << 28, 4 << 28, 5 << 28, 6 << 28, 7 << 28
 
     def _opts_at(self, opts, offset):
         o = _lib.Opts.from_buffer_copy(opts)
@@ -256,6 +258,11 @@ class DeviceGraph:
                 Fb, Fb0 = self.tab["br"]["F"], self.tab["br"]["F0"]
                 self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR1), 1, out=self.prop[Pose2][C2:C2 + Fb])
                 self.sweep_bearingrange(self._opts_at(opts, base + self.STREAM_BR0), 0, out=self.prop[Point2][:Fb0])
+        if "priorpt2" in self.tab:   # PriorPoint2 (src/factors/Point2D.jl:8-18): the landmark priors' samples, rows behind the sightings
+            tp = self.tab["priorpt2"]
+            Fb0 = self.tab["br"]["F0"] if "br" in self.tab else 0
+            self._launch(self._lib.rome_sample_priorpoint2_dev, self._opts_at(opts, base + self.STREAM_PRIORPT2), n_conv=tp["F"], dir_all=0,
+                         mu=tp["mu"], L=tp["L"], out=self.prop[Point2][Fb0:Fb0 + tp["F"]])
         if "p3p3" in self.tab and self.tab["p3p3"]["C"]:
             self.sweep_pose3pose3(self._opts_at(opts, base + self.STREAM_P3P3), out=self.prop[Pose3][:self.tab["p3p3"]["C"]])
 

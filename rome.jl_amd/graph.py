@@ -479,7 +479,7 @@ class PackedGraph:
 
         self.prior2 = prior_tables(pr2, 3)
         self.prior3 = prior_tables(pr3, 6)
-        self.priorpt2 = prior_tables(prpt, 2)   # parametric path only (no sweep kernel row yet)
+        self.priorpt2 = prior_tables(prpt, 2)   # landmark priors: parametric rows AND one proposal row each in the solve loop
 
     @classmethod
     def from_pose2_tables(cls, N, n_poses, mu, cov, var_from, var_to, prior_mu=None, prior_cov=None, prior_var=None):

@@ -27,6 +27,10 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
     tg2 = np.concatenate([target, pk.br["pose"]]) if Fb else target
     r0 = pk.br["rows0"]; Fb0 = len(r0["factor"])
     tgl = r0["point"] if Fb else np.zeros(0, np.int32)
+    Ppt = pk.priorpt2["F"]                                   # landmark priors (PriorPoint2): proposal rows behind the sightings
+    if Ppt:
+        tgl = np.concatenate([tgl, pk.priorpt2["var"]])
+        Lpt = np.array([ro.cholesky_lower(c) for c in pk.priorpt2["cov"].reshape(Ppt, 2, 2)])
     mh = bool((pk.br["alt"] >= 0).any()) if Fb else False
 
     def csr(tg, nv):
@@ -48,20 +52,22 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
         for k in range(P):
             o = ro.make_opts(N=N, seed=seed, stream_offset=base + S["P2P2"] + 2 * F + k)
             prop2[2 * F + k] = ro.sample_priorpose2(o, mu[F + k], L[F + k])[0]
-        propl = np.zeros((Fb0, 2, N))
+        propl = np.zeros((Fb0 + Ppt, 2, N))
+        if Ppt:
+            propl[Fb0:] = ro.sample_priorpoint2(mk(7 << 28), pk.priorpt2["mu"].reshape(Ppt, 2), Lpt)
         if Fb:
             prop2[C2:] = ro.conv_pose2point2br(mk(S["BR1"]), 1, pk.br["mu"], pk.br["sigma"], bell, bel2, pk.br["point"], pk.br["pose"],
                                                alt_var=pk.br["alt"] if mh else None, hypo_w=pk.br["w"] if mh else None)
-            propl[:] = ro.conv_pose2point2br(mk(S["BR0"]), 0, pk.br["mu"], pk.br["sigma"], bel2, bell, r0["pose"], r0["point"], factor=r0["factor"],
+            propl[:Fb0] = ro.conv_pose2point2br(mk(S["BR0"]), 0, pk.br["mu"], pk.br["sigma"], bel2, bell, r0["pose"], r0["point"], factor=r0["factor"],
                                              alt_var=r0["alt"] if mh else None, hypo_w=r0["w"] if mh else None)
         lcv = bandwidth == "lcv"
         if product == "gibbs":   # the reference's product: multiscale Gibbs sampling on the manikde! bandwidths of the proposals
             bel2 = ro.product_msgibbs(mk(S["PROD2"]), 3, ptr2, rows2, prop2, ro.kde_bandwidths(prop2, 0b100), bel2, 0b100, 1)
-            if Fb:
+            if Fb or Ppt:
                 bell = ro.product_msgibbs(mk(S["PRODL"]), 2, ptrl, rowsl, propl, ro.kde_bandwidths(propl, 0), bell, 0, 1)
             continue
         bel2 = ro.product(mk(S["PROD2"]), 3, ptr2, rows2, prop2, bel2, ro.kde_bandwidths(prop2, 0b100) if lcv else None)
-        if Fb:
+        if Fb or Ppt:
             bell = ro.product(mk(S["PRODL"]), 2, ptrl, rowsl, propl, bell, ro.kde_bandwidths(propl, 0) if lcv else None)
     return bel2, bell
 

@@ -204,3 +204,30 @@ def test_pose3pose3_nullhypo_against_reference_validation_samples():
         # the factor-following share is as tight as the reference's in translation
         ratio_a = got[:3, ga].std(axis=1) / ref[:3, ra].std(axis=1)
         assert (ratio_a > 1 / 3.0).all() and (ratio_a < 3.0).all(), ratio_a
+
+
+def test_priorpoint2_nonparametric_sampling_and_solve_loop_vs_oracle():
+    """PriorPoint2 (src/factors/Point2D.jl:8-18) in the non-parametric path: the per-factor entry = the oracle's sampler; in the solve
+    loop a landmark prior contributes one proposal row to the product of its landmark (device loop = oracle loop), and it pins the
+    landmark: the setup of test/testBearingRange2D.jl:314-330 (landmark prior at (20, 0), a sighting from x0 straight ahead at 20 m)."""
+    from solve_ref import solve_ref
+    import oracle as ro
+    N = 100
+    cov = np.array([[0.04, 0.01], [0.01, 0.09]])
+    got = R.sample_priorpoint2(R.make_opts(N=N, seed=8, stream_offset=77), [[20.0, 1.0]], [cov])[0]
+    ref = ro.sample_priorpoint2(ro.make_opts(N=N, seed=8, stream_offset=77), [[20.0, 1.0]], [ro.cholesky_lower(cov)])[0]
+    assert np.abs(got - ref).max() < 1e-12 and abs(got[0].mean() - 20.0) < 0.1 and abs(got[1].std() - 0.3) < 0.08
+    fg = R.initfg(N)
+    fg.addVariable("x0", R.Pose2); fg.addFactor(["x0"], R.PriorPose2(R.MvNormal([0.0, 0, 0], np.diag([0.5, 0.5, 0.05]) ** 2)))
+    fg.addVariable("l1", R.Point2); fg.addFactor(["l1"], R.PriorPoint2(R.MvNormal([20.0, 0.0], np.diag([0.1, 0.1]) ** 2)))
+    fg.addFactor(["x0", "l1"], R.Pose2Point2BearingRange(R.Normal(0, 0.1), R.Normal(20.0, 0.1)))
+    assert np.allclose(R.approxConv(fg, "l1f1", "l1", seed=3).mean(1), [20.0, 0.0], atol=0.05)
+    R.initAll(fg, seed=4)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    assert dg.n_prop[R.Point2] == 2                      # the sighting's proposal + the prior's
+    dg.solve(R.make_opts(N=N, solver=1, seed=31), n_sweeps=4, bandwidth="lcv", product="gibbs")
+    b2, bl = solve_ref(R, fg, 4, N, seed=31, bandwidth="lcv", product="gibbs")
+    gl = dg.bel[R.Point2].cpu().numpy(); g2 = dg.bel[R.Pose2].cpu().numpy()
+    assert np.mean(np.abs(gl - bl) < 1e-6) > 0.9 and np.mean(np.abs(_wd(g2, b2)) < 1e-6) > 0.9
+    assert np.abs(gl[0].mean(1) - [20.0, 0.0]).max() < 0.2 and gl[0].std(1).max() < 0.3      # pinned by its prior
+    assert np.abs(g2[0, :2].mean(1)).max() < 0.5
