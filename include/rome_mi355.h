@@ -222,7 +222,7 @@ int rome_sample_priorpoint2(rome_ctx*, const rome_opts*, int32_t C, const double
  *              fixed_var = target_var; bearing-range: br1 rows solve the pose from the landmark, br0 the landmark from the pose)
  *   *_mu/_cov  factor tables ([F][dz], [F][dz*dz] row-major covariances; bearing-range: [F][2] sigmas, < 0 = Uniform half-width)
  *   out_*      [rows][dt][N] proposals in the same layout as the beliefs
- * Philox stream of row r of a family = opts->stream_offset + family offset (0, 1<<28, 2<<28, 5<<28 for p2p2, br1, br0, p3p3: the
+ * Philox stream of row r of a family = opts->stream_offset + family offset (0, 1<<28, 2<<28, 5<<28, 7<<28 for p2p2, br1, br0, p3p3, prpt2: the
  * same as the device-resident graph sweeps) + r, so a clique call reproduces the per-factor calls made with those streams.  */
 typedef struct rome_clique_host {
   int32_t n_pose2, n_point2, n_pose3, reserved0;
@@ -231,6 +231,10 @@ typedef struct rome_clique_host {
   int32_t n_br1, n_br0; int32_t f_br, reserved1; const int32_t* br1_rows4; const int32_t* br0_rows4;
   const double* br_mu; const double* br_sigma; double* out_br1; double* out_br0;
   int32_t n_p3p3, f_p3p3; const int32_t* p3p3_rows4; const double* p3p3_mu; const double* p3p3_cov; double* out_p3p3;
+  /* landmark priors (PriorPoint2, src/factors/Point2D.jl:8-18): rows (factor, ROME_DIR_PRIOR, var, var) over bel_point2; mu [F][2],
+   * cov [F][4]; proposals [rows][2][N]; Philox family offset 7 << 28.  In rome_clique_upsolve their proposals follow the
+   * bearing-range -> landmark rows in the product of their landmark. */
+  int32_t n_prpt2, f_prpt2; const int32_t* prpt2_rows4; const double* prpt2_mu; const double* prpt2_cov; double* out_prpt2;
 } rome_clique_host;
 int rome_clique_proposals(rome_ctx*, const rome_opts*, const rome_clique_host*);
 

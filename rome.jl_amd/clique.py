@@ -12,9 +12,9 @@ import ctypes as C
 import numpy as np
 
 from . import _lib, api
-from .factors import (Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange, Pose3Pose3, PriorPose3)
+from .factors import (Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange, Pose3Pose3, PriorPose3, PriorPoint2)
 
-FAMILY_STREAM = {"p2p2": 0, "br1": 1 << 28, "br0": 2 << 28, "p3p3": 5 << 28}   # = DeviceGraph.STREAM_* / rome_clique_proposals
+FAMILY_STREAM = {"p2p2": 0, "br1": 1 << 28, "br0": 2 << 28, "p3p3": 5 << 28, "prpt2": 7 << 28}   # = DeviceGraph.STREAM_* / rome_clique_proposals
 
 
 class CliqueHost(C.Structure):
@@ -26,7 +26,9 @@ class CliqueHost(C.Structure):
                 ("br1_rows4", C.c_void_p), ("br0_rows4", C.c_void_p), ("br_mu", C.c_void_p), ("br_sigma", C.c_void_p),
                 ("out_br1", C.c_void_p), ("out_br0", C.c_void_p),
                 ("n_p3p3", C.c_int32), ("f_p3p3", C.c_int32), ("p3p3_rows4", C.c_void_p), ("p3p3_mu", C.c_void_p), ("p3p3_cov", C.c_void_p),
-                ("out_p3p3", C.c_void_p)]
+                ("out_p3p3", C.c_void_p),
+                ("n_prpt2", C.c_int32), ("f_prpt2", C.c_int32), ("prpt2_rows4", C.c_void_p), ("prpt2_mu", C.c_void_p), ("prpt2_cov", C.c_void_p),
+                ("out_prpt2", C.c_void_p)]
 
 
 class CliqueBatch:
@@ -40,8 +42,8 @@ class CliqueBatch:
         self.vars = {Pose2: [], Point2: [], Pose3: []}
         self.vidx = {}
         self.rows = {}
-        tabs = {k: dict(rows4=[], fidx={}, mu=[], spread=[]) for k in ("p2p2", "br", "p3p3")}
-        self.fam_rows = {"p2p2": [], "br1": [], "br0": [], "p3p3": []}
+        tabs = {k: dict(rows4=[], fidx={}, mu=[], spread=[]) for k in ("p2p2", "br", "p3p3", "prpt2")}
+        self.fam_rows = {"p2p2": [], "br1": [], "br0": [], "p3p3": [], "prpt2": []}
 
         def var(l):
             if l not in self.vidx:
@@ -68,6 +70,9 @@ class CliqueBatch:
                 row = (fac(fam, flabel, f.Z.mu, f.Z.cov), d, var(other), var(target))
             elif isinstance(f, (PriorPose2, PriorPose3)):
                 fam = "p2p2" if isinstance(f, PriorPose2) else "p3p3"
+                row = (fac(fam, flabel, f.Z.mu, f.Z.cov), 2, var(target), var(target))
+            elif isinstance(f, PriorPoint2):   # landmark prior: its samples are the proposal
+                fam = "prpt2"
                 row = (fac(fam, flabel, f.Z.mu, f.Z.cov), 2, var(target), var(target))
             elif isinstance(f, Pose2Point2BearingRange):
                 d = 0 if labels[1] == target else 1
@@ -100,7 +105,7 @@ class CliqueBatch:
         q.n_pose2, q.n_point2, q.n_pose3 = (len(self.vars[t]) for t in (Pose2, Point2, Pose3))
         q.bel_pose2, q.bel_point2, q.bel_pose3 = ptr(bel[Pose2]), ptr(bel[Point2]), ptr(bel[Pose3])
         out = {}
-        for fam, dt in (("p2p2", 3), ("br1", 3), ("br0", 2), ("p3p3", 6)):
+        for fam, dt in (("p2p2", 3), ("br1", 3), ("br0", 2), ("p3p3", 6), ("prpt2", 2)):
             out[fam] = np.zeros((len(self.fam_rows[fam]) if with_out else 0, dt, self.N))
         t = self.tabs
         q.n_p2p2, q.f_p2p2 = len(self.fam_rows["p2p2"]), len(t["p2p2"]["mu"])
@@ -113,8 +118,11 @@ class CliqueBatch:
         q.n_p3p3, q.f_p3p3 = len(self.fam_rows["p3p3"]), len(t["p3p3"]["mu"])
         q.p3p3_rows4 = ptr(np.array(self.fam_rows["p3p3"], dtype=np.int32).reshape(-1, 4), np.int32)
         q.p3p3_mu, q.p3p3_cov = ptr(np.array(t["p3p3"]["mu"]).reshape(-1, 6)), ptr(np.array(t["p3p3"]["spread"]).reshape(-1, 36))
-        q.out_p2p2, q.out_br1, q.out_br0, q.out_p3p3 = (out[f].ctypes.data_as(C.c_void_p) if out[f].size else None
-                                                       for f in ("p2p2", "br1", "br0", "p3p3"))
+        q.n_prpt2, q.f_prpt2 = len(self.fam_rows["prpt2"]), len(t["prpt2"]["mu"])
+        q.prpt2_rows4 = ptr(np.array(self.fam_rows["prpt2"], dtype=np.int32).reshape(-1, 4), np.int32)
+        q.prpt2_mu, q.prpt2_cov = ptr(np.array(t["prpt2"]["mu"]).reshape(-1, 2)), ptr(np.array(t["prpt2"]["spread"]).reshape(-1, 4))
+        q.out_p2p2, q.out_br1, q.out_br0, q.out_p3p3, q.out_prpt2 = (out[f].ctypes.data_as(C.c_void_p) if out[f].size else None
+                                                                    for f in ("p2p2", "br1", "br0", "p3p3", "prpt2"))
         return out
 
     def run(self, opts, ctx=None):

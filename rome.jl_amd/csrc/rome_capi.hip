@@ -605,11 +605,13 @@ int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_hos
   const int N = o->n_particles;
   struct Fam { int n; const int32_t* rows4; int F; const double* mu; const double* spread; int dz, nL, dfx, dt; double* out; int vf, vt; int dir_all; uint64_t off; int kind; };
   // variable types: 0 Pose2, 1 Point2, 2 Pose3
-  Fam fam[4] = {
+  constexpr int NF = 5;   // kind: 0 Pose2Pose2 (+ PriorPose2 rows), 1 bearing-range, 2 Pose3Pose3 (+ PriorPose3 rows), 3 PriorPoint2 sampler
+  Fam fam[NF] = {
     {q->n_p2p2, q->p2p2_rows4, q->f_p2p2, q->p2p2_mu, q->p2p2_cov, 3, 6, 3, 3, q->out_p2p2, 0, 0, 0, 0ull, 0},
     {q->n_br1, q->br1_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 2, 3, q->out_br1, 1, 0, 1, 1ull << 28, 1},
     {q->n_br0, q->br0_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 3, 2, q->out_br0, 0, 1, 0, 2ull << 28, 1},
-    {q->n_p3p3, q->p3p3_rows4, q->f_p3p3, q->p3p3_mu, q->p3p3_cov, 6, 21, 6, 6, q->out_p3p3, 2, 2, 0, 5ull << 28, 2}};
+    {q->n_p3p3, q->p3p3_rows4, q->f_p3p3, q->p3p3_mu, q->p3p3_cov, 6, 21, 6, 6, q->out_p3p3, 2, 2, 0, 5ull << 28, 2},
+    {q->n_prpt2, q->prpt2_rows4, q->f_prpt2, q->prpt2_mu, q->prpt2_cov, 2, 3, 2, 2, q->out_prpt2, 1, 1, 0, 7ull << 28, 3}};
   const int nv[3] = {q->n_pose2, q->n_point2, q->n_pose3};
   const int vdim[3] = {3, 2, 6};
   const double* vhost[3] = {q->bel_pose2, q->bel_point2, q->bel_pose3};
@@ -635,9 +637,9 @@ int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_hos
   void* dbel[3];
   for (int t = 0; t < 3; ++t) if ((rc = stage_beliefs(c, o, nv[t], vdim[t], vhost[t], tmp, &dbel[t], &used, arena, cap))) return rc;
   hipStream_t s = c->stream;
-  std::vector<std::vector<double>> Ls(4);
-  double* dout[4] = {nullptr, nullptr, nullptr, nullptr};
-  for (int k = 0; k < 4; ++k) {
+  std::vector<std::vector<double>> Ls(NF);
+  double* dout[NF] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (int k = 0; k < NF; ++k) {
     const Fam& f = fam[k];
     if (f.n == 0) continue;
     const double* Lsrc = f.spread;
@@ -665,12 +667,12 @@ int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_hos
     a.mu = (const double*)d_mu; a.L = (const double*)d_L;
     a.bel_fixed = (const double*)dbel[f.vf]; a.bel_target = (const double*)dbel[f.vt]; a.out = dout[k];
     hipError_t e = f.kind == 0 ? rome::launch_conv_pose2pose2(a, o->solver, s) : (f.kind == 1 ? rome::launch_conv_bearingrange(a, o->solver, s)
-                                                                                            : rome::launch_conv_pose3pose3(a, o->solver, s));
+                               : (f.kind == 2 ? rome::launch_conv_pose3pose3(a, o->solver, s) : rome::launch_sample_priorpoint2(a, s)));
     ROME_HIP(c, e);
   }
   // proposals back to the host in the caller's layout
-  std::vector<std::vector<double>> hout(4);
-  for (int k = 0; k < 4; ++k) {
+  std::vector<std::vector<double>> hout(NF);
+  for (int k = 0; k < NF; ++k) {
     const Fam& f = fam[k];
     if (f.n == 0) continue;
     const size_t cnt = (size_t)f.n * f.dt * N;
@@ -679,7 +681,7 @@ int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_hos
   }
   ROME_HIP(c, hipStreamSynchronize(s));
   if (o->layout != ROME_LAYOUT_SOA)
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NF; ++k) {
       const Fam& f = fam[k];
       if (f.n == 0) continue;
       if (o->layout == ROME_LAYOUT_AOS || f.dt == 2) from_soa(hout[k].data(), f.n, N, f.dt, ROME_LAYOUT_AOS, f.out);
@@ -728,11 +730,13 @@ int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsol
     for (int v = 0; v < nv[t]; ++v) if (newidx[t][v] < 0) newidx[t][v] = nx++;
   }
   struct Fam { int n; const int32_t* rows4; int F; const double* mu; const double* spread; int dz, nL, dfx, dt; int vf, vt; int dir_all; uint64_t off; int kind; int base; };
-  Fam fam[4] = {
+  constexpr int NF = 5;
+  Fam fam[NF] = {
     {q->n_p2p2, q->p2p2_rows4, q->f_p2p2, q->p2p2_mu, q->p2p2_cov, 3, 6, 3, 3, 0, 0, 0, 0ull, 0, 0},
     {q->n_br1, q->br1_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 2, 3, 1, 0, 1, 1ull << 28, 1, q->n_p2p2},
     {q->n_br0, q->br0_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 3, 2, 0, 1, 0, 2ull << 28, 1, 0},
-    {q->n_p3p3, q->p3p3_rows4, q->f_p3p3, q->p3p3_mu, q->p3p3_cov, 6, 21, 6, 6, 2, 2, 0, 5ull << 28, 2, 0}};
+    {q->n_p3p3, q->p3p3_rows4, q->f_p3p3, q->p3p3_mu, q->p3p3_cov, 6, 21, 6, 6, 2, 2, 0, 5ull << 28, 2, 0},
+    {q->n_prpt2, q->prpt2_rows4, q->f_prpt2, q->prpt2_mu, q->prpt2_cov, 2, 3, 2, 2, 1, 1, 0, 7ull << 28, 3, q->n_br0}};
   const int n_msg[3] = {u->n_msg_pose2, u->n_msg_point2, u->n_msg_pose3};
   const double* msg_host[3] = {u->msg_pose2, u->msg_point2, u->msg_pose3};
   const int32_t* msg_up[3] = {u->msg_pose2_up, u->msg_point2_up, u->msg_pose3_up};
@@ -746,11 +750,11 @@ int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsol
     msg_base[t] = prop_rows_t[t]; prop_rows_t[t] += n_msg[t];
   }
   // ---- rows: validate, remap the variable indices to the device order, find the row range of every update position
-  std::vector<int32_t> rows_dev[4];
-  std::vector<int> fam_lo[4];              // first row of family f that targets update position >= k (rows are grouped in update order)
+  std::vector<int32_t> rows_dev[NF];
+  std::vector<int> fam_lo[NF];              // first row of family f that targets update position >= k (rows are grouped in update order)
   std::vector<std::vector<int>> csr[3];    // per type: proposal rows (in the type's buffer) of every updated variable
   for (int t = 0; t < 3; ++t) csr[t].resize(uplist[t].size());
-  for (int k4 = 0; k4 < 4; ++k4) {
+  for (int k4 = 0; k4 < NF; ++k4) {
     const Fam& f = fam[k4];
     rows_dev[k4].resize((size_t)f.n * 4);
     fam_lo[k4].assign((size_t)u->n_up + 1, 0);
@@ -829,9 +833,9 @@ int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsol
                                              d_pbw[t] + (size_t)msg_base[t] * vdim[t], nullptr, s));
     }
   }
-  std::vector<std::vector<double>> Ls(4);
-  const int32_t* d_rows[4] = {nullptr, nullptr, nullptr, nullptr}; const double* d_mu[4]; const double* d_L[4];
-  for (int k4 = 0; k4 < 4; ++k4) {
+  std::vector<std::vector<double>> Ls(NF);
+  const int32_t* d_rows[NF] = {nullptr, nullptr, nullptr, nullptr, nullptr}; const double* d_mu[NF]; const double* d_L[NF];
+  for (int k4 = 0; k4 < NF; ++k4) {
     const Fam& f = fam[k4];
     d_mu[k4] = d_L[k4] = nullptr;
     if (f.n == 0) continue;
@@ -868,7 +872,7 @@ int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsol
     const int nsteps = u->n_up > 0 ? (int)step_k.size() - 1 : 0;
     for (int st = 0; st < nsteps; ++st) {
       const int k0 = step_k[st], k1 = step_k[st + 1];
-      for (int k4 = 0; k4 < 4; ++k4) {
+      for (int k4 = 0; k4 < NF; ++k4) {
         const Fam& f = fam[k4];
         const int lo = fam_lo[k4][k0], hi = f.n == 0 ? 0 : (k1 < u->n_up ? fam_lo[k4][k1] : f.n);
         if (hi <= lo) continue;
@@ -880,7 +884,7 @@ int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsol
         a.bel_fixed = d_store[f.vf]; a.bel_target = d_store[f.vt];
         a.out = d_prop[f.vt] + (size_t)(f.base + lo) * f.dt * N;
         hipError_t e = f.kind == 0 ? rome::launch_conv_pose2pose2(a, o->solver, s) : (f.kind == 1 ? rome::launch_conv_bearingrange(a, o->solver, s)
-                                                                                                : rome::launch_conv_pose3pose3(a, o->solver, s));
+                                   : (f.kind == 2 ? rome::launch_conv_pose3pose3(a, o->solver, s) : rome::launch_sample_priorpoint2(a, s)));
         ROME_HIP(c, e);
         ROME_HIP(c, rome::launch_kde_bandwidth(f.dt, hi - lo, N, a.out, circ_bw[f.vt], 1e-2, 1e-6, d_pbw[f.vt] + (size_t)(f.base + lo) * f.dt, nullptr, s));
       }

@@ -1197,7 +1197,7 @@ __global__ void __launch_bounds__(256) k_sample_prior(const ConvArgs a) {
   const int c = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
   if (c >= a.n_conv) return;
   const int N = a.N;
-  const int f = a.factor ? a.factor[c] : c;
+  const int f = a.rows4 ? a.rows4[4 * (size_t)c] : (a.factor ? a.factor[c] : c);   // (clique tables: the factor is column 0 of the row)
   constexpr int NL = D * (D + 1) / 2;
   const double* mu = a.mu + (size_t)D * f;
   const double* L = a.L + (size_t)NL * f;

@@ -178,6 +178,7 @@ struct RomeCliqueHost            # include/rome_mi355.h: rome_clique_host
   n_br1::Int32; n_br0::Int32; f_br::Int32; reserved1::Int32
   br1_rows4::Ptr{Int32}; br0_rows4::Ptr{Int32}; br_mu::Ptr{Float64}; br_sigma::Ptr{Float64}; out_br1::Ptr{Float64}; out_br0::Ptr{Float64}
   n_p3p3::Int32; f_p3p3::Int32; p3p3_rows4::Ptr{Int32}; p3p3_mu::Ptr{Float64}; p3p3_cov::Ptr{Float64}; out_p3p3::Ptr{Float64}
+  n_prpt2::Int32; f_prpt2::Int32; prpt2_rows4::Ptr{Int32}; prpt2_mu::Ptr{Float64}; prpt2_cov::Ptr{Float64}; out_prpt2::Ptr{Float64}   # PriorPoint2 rows
 end
 
 const _accelerated = Union{Pose2Pose2, PriorPose2, Pose2Point2BearingRange{<:Normal,<:Normal}, Pose3Pose3, PriorPose3}
@@ -217,7 +218,8 @@ _clique_host(t, o2, o1, o0, o3) =
   RomeCliqueHost(length(t.vars[Pose2]), length(t.vars[Point2]), length(t.vars[Pose3]), 0, _p(t.b2), _p(t.bl), _p(t.b3),
                  length(t.rows[:p2p2]) ÷ 4, t.nfac[:p2p2], _p(t.rows[:p2p2]), _p(t.tabμ[:p2p2]), _p(t.tabΣ[:p2p2]), _p(o2),
                  length(t.rows[:br1]) ÷ 4, length(t.rows[:br0]) ÷ 4, t.nfac[:br], 0, _p(t.rows[:br1]), _p(t.rows[:br0]), _p(t.tabμ[:br]), _p(t.tabΣ[:br]), _p(o1), _p(o0),
-                 length(t.rows[:p3p3]) ÷ 4, t.nfac[:p3p3], _p(t.rows[:p3p3]), _p(t.tabμ[:p3p3]), _p(t.tabΣ[:p3p3]), _p(o3))
+                 length(t.rows[:p3p3]) ÷ 4, t.nfac[:p3p3], _p(t.rows[:p3p3]), _p(t.tabμ[:p3p3]), _p(t.tabΣ[:p3p3]), _p(o3),
+                 0, 0, Ptr{Int32}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL))   # (PriorPoint2 rows: not batched by this shim yet)
 _points_opts(dfg, N) = (d0 = default_opts(dfg);
   RomeOpts(Int32(N), d0.solver, d0.max_iters, d0.inflate_cycles, d0.tol, d0.inflation, d0.seed, d0.stream_offset, 2 #=points=#, 0, d0.spread_nh, 0.0))
 

@@ -90,11 +90,12 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
     types = (R.Pose2, R.Point2, R.Pose3)
     bel = {vt: batch.beliefs(vt) for vt in types}
     T = batch.tabs
-    rows = {f: np.array(batch.fam_rows[f], dtype=np.int64).reshape(-1, 4) for f in ("p2p2", "br1", "br0", "p3p3")}
+    rows = {f: np.array(batch.fam_rows[f], dtype=np.int64).reshape(-1, 4) for f in ("p2p2", "br1", "br0", "p3p3", "prpt2")}
+    mupt = np.array(T["prpt2"]["mu"]).reshape(-1, 2); Lpt = np.array([ro.cholesky_lower(np.asarray(c).reshape(2, 2)) for c in T["prpt2"]["spread"]]).reshape(-1, 3)
     mu2 = np.array(T["p2p2"]["mu"]).reshape(-1, 3); L2 = np.array([ro.cholesky_lower(np.asarray(c).reshape(3, 3)) for c in T["p2p2"]["spread"]]).reshape(-1, 6)
     mub = np.array(T["br"]["mu"]).reshape(-1, 2); sgb = np.array(T["br"]["spread"]).reshape(-1, 2)
     mu3 = np.array(T["p3p3"]["mu"]).reshape(-1, 6); L3 = np.array([ro.cholesky_lower(np.asarray(c).reshape(6, 6)) for c in T["p3p3"]["spread"]]).reshape(-1, 21)
-    S = dict(p2p2=0, br1=1 << 28, br0=2 << 28, p3p3=5 << 28)
+    S = dict(p2p2=0, br1=1 << 28, br0=2 << 28, p3p3=5 << 28, prpt2=7 << 28)
     PROD = {R.Pose2: 3 << 28, R.Point2: 4 << 28, R.Pose3: 6 << 28}
     circ = {R.Pose2: 0b100, R.Point2: 0, R.Pose3: 0}            # product: SE(3) rotations are handled in the chart of each proposal
     circ_bw = {R.Pose2: 0b100, R.Point2: 0, R.Pose3: 0b111000}  # manikde! bandwidth rule: which coordinates are angles
@@ -106,9 +107,9 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
     def proposals_for(targets, base):
         """{label: list of (dim, N) proposals in the device's CSR order (p2p2 rows, br1 rows | br0 rows, messages)}"""
         out = {l: [] for l in targets}
-        for fam in ("p2p2", "br1", "br0", "p3p3"):
+        for fam in ("p2p2", "br1", "br0", "prpt2", "p3p3"):
             rw = rows[fam]
-            vt = R.Point2 if fam == "br0" else (R.Pose3 if fam == "p3p3" else R.Pose2)
+            vt = R.Point2 if fam in ("br0", "prpt2") else (R.Pose3 if fam == "p3p3" else R.Pose2)
             tv = {batch.vidx[l]: l for l in targets if fg.variables[l] is vt}
             sel = [r for r in range(len(rw)) if rw[r, 3] in tv]
             for r in sel:
@@ -118,6 +119,8 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
                     p = ro.sample_priorpose2(ro.make_opts(N=N, seed=seed, stream_offset=base + S[fam] + r), mu2[f], L2[f])[0]
                 elif fam == "p2p2":
                     p = ro.conv_pose2pose2(o, mu2, L2, bel[R.Pose2], [fx], [tg], [d], factor=[f])[0]
+                elif fam == "prpt2":
+                    p = ro.sample_priorpoint2(ro.make_opts(N=N, seed=seed, stream_offset=base + S[fam] + r), mupt[f], Lpt[f])[0]
                 elif fam == "p3p3" and d == 2:
                     p = ro.sample_priorpose3(ro.make_opts(N=N, seed=seed, stream_offset=base + S[fam] + r), mu3[f], L3[f])[0]
                 elif fam == "p3p3":

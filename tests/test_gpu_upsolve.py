@@ -201,3 +201,26 @@ def test_pose3_clique_upsolve_equals_the_oracle_loop():
             assert np.abs(pts[:3].mean(1) - ref[l][:3].mean(1)).max() < 1e-3
             assert (res[l][1] > 0).all()
             fg_o.initVariable(l, ref[l])
+
+
+def test_landmark_prior_rows_in_the_clique_entries():
+    """PriorPoint2 rows in rome_clique_proposals / rome_clique_upsolve: the prior's samples are a proposal of its landmark (family
+    offset 7 << 28), behind the bearing-range -> landmark rows in the product; clique call == per-factor call, up-solve == oracle."""
+    from rome_jl_amd.clique import FAMILY_STREAM
+    N = 100
+    def graph():
+        fg = _hex(N)
+        fg.addFactor(["l1"], R.PriorPoint2(R.MvNormal([20.0, 0.0], np.diag([0.3, 0.3]) ** 2)))
+        return fg
+    fg_d, fg_o = graph(), graph()
+    props, batch = R.proposalbeliefs(fg_d, "l1", seed=9, stream_offset=100)
+    assert len(props) == 3 and ("l1f1", "l1") in props
+    fam, r = batch.rows[("l1f1", "l1")]
+    assert fam == "prpt2"
+    assert np.array_equal(props[("l1f1", "l1")], R.approxConv(fg_d, "l1f1", "l1", seed=9, stream_offset=100 + FAMILY_STREAM["prpt2"] + r))
+    res = R.upGibbsCliqueDensity(fg_d, ["x6", "l1"], gibbsIters=3, seed=61)
+    ref = upsolve_ref(R, fg_o, ["x6", "l1"], N, seed=61, gibbs_iters=3)
+    for l, dim in (("x6", 3), ("l1", 2)):
+        d = _wrapdiff(res[l][0].copy(), ref[l], dim)
+        assert np.mean(np.abs(d) < 1e-6) > 0.9 and np.abs(d.mean(1)).max() < 1e-3, (l, np.mean(np.abs(d) < 1e-6))
+    assert np.abs(res["l1"][0].mean(1) - [20.0, 0.0]).max() < 0.5
