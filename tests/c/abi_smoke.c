@@ -2,7 +2,9 @@
  * Build: gcc tests/c/abi_smoke.c -Iinclude -Lrome.jl_amd -lrome_mi355 -lm -o /tmp/abi_smoke
  * Checks, with no oracle: (1) reference known answers of the Pose2Pose2 residual functor
  * (test/testParametricSimulated.jl:42-46), (2) a Pose2Pose2 convolution with pre-sampled noise against the
- * closed-form root of SURVEY Appendix A.5 computed right here, (3) error codes. */
+ * closed-form root of SURVEY Appendix A.5 computed right here, (3) error codes, (4) a clique up-solve (IIF upGibbsCliqueDensity) in one
+ * call: x1 with an odometry factor from x0 and its own prior -> the product sits where both agree. */
+#include <string.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,6 +52,34 @@ int main(void) {
   if (rome_conv_pose2pose2(ctx, &o, 1, dir, mu, cov, fixed, noise, target, status) != ROME_ERR_UNSUPPORTED_N) { printf("FAIL maxN\n"); return 1; }
   if (rome_conv_pose2pose2(NULL, &o, 1, dir, mu, cov, fixed, noise, target, status) != ROME_ERR_UNSUPPORTED_N &&
       rome_conv_pose2pose2(NULL, &o, 1, dir, mu, cov, fixed, noise, target, status) != ROME_ERR_INVALID_ARG) { printf("FAIL null ctx\n"); return 1; }
+  /* (4) rome_clique_upsolve: variables x0 (index 0), x1 (index 1); rows targeting x1: odometry x0 -> x1 (dir 0) and PriorPose2(x1) */
+  {
+    static double bel[2 * 3 * N], nb[3 * N], bw[3];
+    rome_opts ou; rome_opts_default(&ou, ROME_SOLVER_NEWTON); ou.n_particles = N; ou.layout = ROME_LAYOUT_SOA; ou.seed = 5;
+    for (int i = 0; i < N; ++i) {
+      bel[0 * N + i] = 0.05 * sin(7.0 * i); bel[1 * N + i] = 0.05 * cos(3.0 * i); bel[2 * N + i] = 0.01 * sin(1.3 * i);   /* x0 around the origin */
+      bel[3 * N + 0 * N + i] = 3.0 + sin(0.7 * i); bel[3 * N + 1 * N + i] = cos(0.9 * i); bel[3 * N + 2 * N + i] = 0.3 * sin(2.1 * i);  /* x1: poor start */
+    }
+    const int32_t rows[8] = {0, 0, 0, 1,   /* factor 0, dir 0 (solve the 2nd variable), fixed x0, target x1 */
+                             1, 2, 1, 1};  /* factor 1, prior row on x1 */
+    const double mu2[6] = {10.0, 0.0, 0.0, 10.0, 0.0, 0.0};
+    const double cv2[18] = {0.01, 0, 0, 0, 0.01, 0, 0, 0, 0.0001,   0.01, 0, 0, 0, 0.01, 0, 0, 0, 0.0001};
+    const int32_t upt[1] = {0}, upv[1] = {1};
+    rome_clique_upsolve_host u; memset(&u, 0, sizeof(u));
+    u.clique.n_pose2 = 2; u.clique.bel_pose2 = bel;
+    u.clique.n_p2p2 = 2; u.clique.f_p2p2 = 2; u.clique.p2p2_rows4 = rows; u.clique.p2p2_mu = mu2; u.clique.p2p2_cov = cv2;
+    u.gibbs_iters = 3; u.product_iters = 1; u.schedule = ROME_UPSOLVE_SEQUENTIAL; u.n_up = 1; u.up_type = upt; u.up_var = upv;
+    u.new_pose2 = nb; u.bw_pose2 = bw;
+    CHECK(rome_clique_upsolve(ctx, &ou, &u));
+    double mx = 0, my = 0, mt = 0;
+    for (int i = 0; i < N; ++i) { mx += nb[i] / N; my += nb[N + i] / N; mt += nb[2 * N + i] / N; }
+    if (fabs(mx - 10.0) > 0.1 || fabs(my) > 0.1 || fabs(mt) > 0.05 || !(bw[0] > 0 && bw[1] > 0 && bw[2] > 0)) {
+      printf("FAIL clique up-solve: mean (%g, %g, %g), bw (%g, %g, %g)\n", mx, my, mt, bw[0], bw[1], bw[2]); return 1;
+    }
+    const int32_t upv_bad[1] = {0};   /* the rows target x1, the update list says x0 */
+    u.up_var = upv_bad;
+    if (rome_clique_upsolve(ctx, &ou, &u) != ROME_ERR_INVALID_ARG) { printf("FAIL up-solve argument check\n"); return 1; }
+  }
   rome_ctx_destroy(ctx);
   printf("abi_smoke ok (max |Δ| vs closed form %.2e)\n", worst);
   return 0;
