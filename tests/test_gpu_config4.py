@@ -147,11 +147,12 @@ def test_cut_lattice_through_separator_pipeline_one_rank_rccl():
     assert np.array_equal(gotl, np.stack([outs["br0"][r] for r in (0, 1, 3, 6, 8)]))
 
 
-@pytest.mark.parametrize("N", [100, 128, 66])
+@pytest.mark.parametrize("N", [100, 128, 66, 65, 64, 200])
 def test_fused_graph_sweep_equals_per_family_launches_bit_for_bit(N):
     """rome_sweep_pose2_dev: the three families of a Pose2 / Point2 graph (plain tables: one fused launch, k_sweep_fused) against the
     per-family entry points with the same Philox streams -- identical bits; a table with multihypo columns takes the per-family
-    launches inside the library and agrees as well."""
+    launches inside the library and agrees as well.  N = 65: odd (scalar accesses in the fused kernel); N = 64 / 200: outside the fused
+    kernel's range (per-family launches inside the library)."""
     fg = R.synth_mit_br(P=300, n_landmarks=60, N=N)
     R.dead_reckon_init(fg, seed=4)
     dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
