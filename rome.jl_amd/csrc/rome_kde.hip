@@ -284,7 +284,7 @@ __device__ __forceinline__ void lcv_eval_blk(const BlkPlan<B>& pl, const float* 
       *o0 = s0; *o1 = s1;
     } else {
       float s0 = 0.0f, s1 = 0.0f;
-      for (int k = 0; k < nb; ++k) { s0 += row0[k * B]; s1 += row1[k * B]; }
+      for (int k = 0; k < nb; ++k) { s0 += row0[k * B]; s1 += row1[k * B]; }   // (unrolled with all reads in flight: measured slower, 1.35 -> 1.40 ms -- registers)
       *o0 = (double)s0; *o1 = (double)s1;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // the cells are rewritten next
@@ -306,7 +306,97 @@ __device__ __forceinline__ void lcv_eval_blk(const BlkPlan<B>& pl, const float* 
   *negll = uniform_f64(-(ll - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528)));
 }
 
+// ---- the same evaluation with the pair exponents held in REGISTERS across the whole search (B <= 10) ---------------------------------
+// The search evaluates the SAME B x B pairs ~20 times with different h: e_ij = -½ log2(e) d_ij² (wrapped for a circular coordinate) is
+// computed once per task (lcv_pre_blk) and an evaluation is multiply, v_exp_f32, two accumulates per pair -- 4 VALU instructions
+// against 6 (Euclidean) / 9 (circular); the derivative sums use Σ w e = -½ log2(e) Σ w d².  B² = 100 more live registers: the kernel
+// runs at two or three waves per SIMD instead of four (the unrolled body has the instruction-level parallelism to cover that).
 template <bool CIRC, int B>
+__device__ __forceinline__ void lcv_pre_blk(const BlkPlan<B>& pl, const float* __restrict__ xs, float (&e)[B * B]) {
+  float xi[B], xj[B];
+#pragma unroll
+  for (int u = 0; u < B; ++u) { xi[u] = xs[pl.a * B + u]; xj[u] = xs[pl.b * B + u]; }
+#pragma unroll
+  for (int ii = 0; ii < B; ++ii) {
+#pragma unroll
+    for (int jj = 0; jj < B; ++jj) {
+      float d = xi[ii] - xj[jj];
+      if (CIRC) d = fmaf(-6.2831853071795865f, rintf(d * 0.15915494309189535f), d);
+      e[ii * B + jj] = (d * d) * -0.72134752f;
+    }
+  }
+}
+template <bool WITH_T, int B>
+__device__ __forceinline__ void lcv_eval_pre(const BlkPlan<B>& pl, const float (&e)[B * B], float* __restrict__ M, int N, int lane,
+                                             double h, double* negll, double* g) {
+  const float hf = (float)h;
+  const float s = 1.0f / (hf * hf);
+  const int nb = pl.nb;
+  float r[B], c[B];
+  [[maybe_unused]] float tr[B], tc[B];
+#pragma unroll
+  for (int u = 0; u < B; ++u) { r[u] = 0.0f; c[u] = 0.0f; if (WITH_T) { tr[u] = 0.0f; tc[u] = 0.0f; } }
+#pragma unroll
+  for (int ii = 0; ii < B; ++ii) {
+#pragma unroll
+    for (int jj = 0; jj < B; ++jj) {
+      const float ev = e[ii * B + jj];
+      float w = __builtin_amdgcn_exp2f(ev * s);
+      if (ii == jj) w = pl.diag ? 0.0f : w;
+      r[ii] += w; c[jj] += w;
+      if (WITH_T) { tr[ii] = fmaf(w, ev, tr[ii]); tc[jj] = fmaf(w, ev, tc[jj]); }
+    }
+    asm volatile("" : "+v"(r[ii]));
+    if (WITH_T) asm volatile("" : "+v"(tr[ii]));
+    if (ii + 1 < B) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) { asm volatile("" : "+v"(c[u])); if (WITH_T) asm volatile("" : "+v"(tc[u])); }
+    }
+  }
+  float* cr = M + (pl.a * nb + pl.b) * B;
+  float* cc = M + (pl.b * nb + pl.a) * B;
+  const int i0 = lane, i1 = lane + 64;
+  const bool act0 = i0 < N, act1 = i1 < N;
+  const int b0 = i0 / B, b1 = (act1 ? i1 : 0) / B;
+  const float* row0 = M + b0 * nb * B + (i0 - b0 * B);
+  const float* row1 = M + b1 * nb * B + ((act1 ? i1 : 0) - b1 * B);
+  auto exchange = [&](const float (&pr)[B], const float (&pc)[B], double* o0, double* o1) {
+    if (pl.ok) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) cr[u] = pr[u];
+      if (!pl.diag) {
+#pragma unroll
+        for (int u = 0; u < B; ++u) cc[u] = pc[u];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (WITH_T) {
+      double s0 = 0.0, s1 = 0.0;
+      for (int k = 0; k < nb; ++k) { s0 += (double)row0[k * B]; s1 += (double)row1[k * B]; }
+      *o0 = s0; *o1 = s1;
+    } else {
+      float s0 = 0.0f, s1 = 0.0f;
+      for (int k = 0; k < nb; ++k) { s0 += row0[k * B]; s1 += row1[k * B]; }   // (unrolled with all reads in flight: measured slower, 1.35 -> 1.40 ms -- registers)
+      *o0 = (double)s0; *o1 = (double)s1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  };
+  double S0, S1, T0 = 0.0, T1 = 0.0;
+  exchange(r, c, &S0, &S1);
+  if (WITH_T) exchange(tr, tc, &T0, &T1);
+  constexpr double kUnscale = -1.0 / (double)0.72134752f;   // Σ w e -> Σ w d²
+  const double s0 = act0 ? fmax(S0, 1e-300) : 1.0, s1 = act1 ? fmax(S1, 1e-300) : 1.0;
+  double mant = __builtin_amdgcn_frexp_mant(s0) * __builtin_amdgcn_frexp_mant(s1);
+  int expo = __builtin_amdgcn_frexp_exp(s0) + __builtin_amdgcn_frexp_exp(s1);
+  double gg = 0.0;
+  if (WITH_T) gg = kUnscale * ((act0 ? T0 * rcp_pos_f64(s0) : 0.0) + (act1 ? T1 * rcp_pos_f64(s1) : 0.0));
+  wave_prod_frexp(&mant, &expo);
+  const double ll = uniform_f64(fast_log(mant) + (double)expo * 0.693147180559945309417);
+  if (WITH_T) *g = uniform_f64(wave_sum(gg) - (double)N * h * h); else *g = 0.0;
+  *negll = uniform_f64(-(ll - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528)));
+}
+
+template <bool CIRC, int B, bool PRE>
 __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bool (&act)[2], const double* __restrict__ pts,
                                                   float* __restrict__ xs, float* __restrict__ M, double* __restrict__ wbuf, int N, int lane,
                                                   double tol, int* n_evals) {
@@ -323,6 +413,8 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   const BlkPlan<B> pl = blk_plan<B>(N, lane);
+  [[maybe_unused]] float epre[PRE ? B * B : 1];
+  if constexpr (PRE) lcv_pre_blk<CIRC, B>(pl, xs, epre);
   {   // smallest pair distance, in double on the particles themselves: the lane's block pair, every unordered pair once
     double pi[B];
 #pragma unroll
@@ -361,8 +453,13 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
   double hq = x1;
   for (;;) {
     double fv, gv;
-    if (finish) lcv_eval_blk<CIRC, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
-    else lcv_eval_blk<CIRC, false, B>(pl, xs, M, N, lane, hq, &fv, &gv);
+    if constexpr (PRE) {
+      if (finish) lcv_eval_pre<true, B>(pl, epre, M, N, lane, hq, &fv, &gv);
+      else lcv_eval_pre<false, B>(pl, epre, M, N, lane, hq, &fv, &gv);
+    } else {
+      if (finish) lcv_eval_blk<CIRC, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
+      else lcv_eval_blk<CIRC, false, B>(pl, xs, M, N, lane, hq, &fv, &gv);
+    }
     ++ne;
     if (phase == 0) { f1 = fv; g1 = gv; hq = x2; phase = 1; continue; }
     if (phase == 1) { f2 = fv; g2 = gv; phase = 2; }
@@ -452,8 +549,17 @@ __global__ void __launch_bounds__(64 * kKdeWaves) k_kde_bandwidth(int T, int dim
 // the fast path as its own kernel per block size (register allocation is per kernel: the B = 13 bodies must not set the occupancy of
 // the N = 100 case); four waves per SIMD (128 VGPRs: measured faster than three without the ~70 spills, which sit in the rare
 // double-precision paths) -- left alone the scheduler spreads the unrolled block bodies over > 400 VGPRs
-template <int B>
-__global__ void __launch_bounds__(64 * kKdeWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
+#ifndef ROME_KDE_PRE
+#define ROME_KDE_PRE 0   // 1: pair exponents of the fast path held in registers (B <= 10).  Measured on the proposals of a Manhattan sweep:
+                         // 419 / 593 VALU per evaluation instead of 617..1097, but 231 VGPRs = two waves per SIMD: 1.41 ms (three waves
+                         // with spills: 1.36 ms) against 1.345 ms for the four-wave kernel -- the exchange / reduction / logarithm part of an
+                         // evaluation is latency-bound and needs the four waves.  Off; kept as a parity-tested experiment build.
+#endif
+#ifndef ROME_KDE_PRE_WAVES
+#define ROME_KDE_PRE_WAVES 2
+#endif
+template <int B, bool PRE>
+__global__ void __launch_bounds__(64 * kKdeWaves) __attribute__((amdgpu_waves_per_eu(PRE ? ROME_KDE_PRE_WAVES : 4, 8)))
 k_kde_bandwidth_fast(int T, int dim, int N, const double* __restrict__ bel, uint32_t circ_mask, double tol_e, double tol_c,
                      double* __restrict__ bw, int32_t* __restrict__ evals) {
   __shared__ double pts[kKdeWaves][128];
@@ -477,8 +583,8 @@ k_kde_bandwidth_fast(int T, int dim, int N, const double* __restrict__ bel, uint
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   int ne = 0;
   float* M = cellbuf + wave * kdeCells<B>(N);
-  const double h = circ ? lcv_golden_fast<true, B>(x, act, pts[wave], xsbuf[wave], M, wex[wave], N, lane, tol_c, &ne)
-                        : lcv_golden_fast<false, B>(x, act, pts[wave], xsbuf[wave], M, wex[wave], N, lane, tol_e, &ne);
+  const double h = circ ? lcv_golden_fast<true, B, PRE>(x, act, pts[wave], xsbuf[wave], M, wex[wave], N, lane, tol_c, &ne)
+                        : lcv_golden_fast<false, B, PRE>(x, act, pts[wave], xsbuf[wave], M, wex[wave], N, lane, tol_e, &ne);
   if (lane == 0) { bw[t] = h; if (evals) evals[t] = ne; }
 }
 
@@ -542,13 +648,13 @@ hipError_t launch_kde_bandwidth(int dim, int V, int N, const double* bel, uint32
 #define ROME_LAUNCH_KDE(SS) hipLaunchKernelGGL((k_kde_bandwidth<SS>), grid, block, 0, s, T, dim, N, bel, circ_mask, tol_e, tol_c, bw, evals)
   if (N < 8) ROME_LAUNCH_KDE(1);
   else if (N <= 70)
-    hipLaunchKernelGGL((k_kde_bandwidth_fast<7>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<7>(N), s, T, dim, N, bel, circ_mask,
+    hipLaunchKernelGGL((k_kde_bandwidth_fast<7, ROME_KDE_PRE != 0>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<7>(N), s, T, dim, N, bel, circ_mask,
                        tol_e, tol_c, bw, evals);
   else if (N <= 100)
-    hipLaunchKernelGGL((k_kde_bandwidth_fast<10>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<10>(N), s, T, dim, N, bel, circ_mask,
+    hipLaunchKernelGGL((k_kde_bandwidth_fast<10, ROME_KDE_PRE != 0>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<10>(N), s, T, dim, N, bel, circ_mask,
                        tol_e, tol_c, bw, evals);
   else if (N <= 128)
-    hipLaunchKernelGGL((k_kde_bandwidth_fast<13>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<13>(N), s, T, dim, N, bel, circ_mask,
+    hipLaunchKernelGGL((k_kde_bandwidth_fast<13, false>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<13>(N), s, T, dim, N, bel, circ_mask,
                        tol_e, tol_c, bw, evals);
   else if (N <= 256) ROME_LAUNCH_KDE(4);
   else ROME_LAUNCH_KDE(8);
