@@ -212,7 +212,7 @@ __device__ __forceinline__ double uniform_f64(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 template <int B>
-__host__ __device__ constexpr int kdeCells(int N) { const int nb = (N + B - 1) / B; return nb * nb * B; }   // floats per wave
+__host__ __device__ constexpr int kdeCells(int N) { const int nb = (N + B - 1) / B; return nb * B * 12 > nb * nb * B ? nb * B * 12 : nb * nb * B; }   // floats per wave (either cell layout)
 template <int B>
 struct BlkPlan { int nb, a, b; bool ok, diag; };
 template <int B>
@@ -226,12 +226,114 @@ __device__ __forceinline__ BlkPlan<B> blk_plan(int N, int lane) {
   return p;
 }
 
+// The tail of one evaluation: partial sums -> LDS cells -> row sums -> -LL (and g).  Cell layout (ROME_KDE_ROWCELLS, default):
+// row-major, cell(i, q) = partial sum of particle i against block q at M[i * kKdeRowPitch + q] -- a row's <= 10 partials are 40
+// contiguous bytes, read back with three 16-byte LDS reads in flight (the block-major layout before it walked them with a loop of
+// dependent 4-byte reads: ten LDS round trips per evaluation on the critical path of a search that is sequential by nature).
+// Columns q >= nb are zeroed once per task (lcv_cells_init) and never written: the sums keep their order and their bits.
+#ifndef ROME_KDE_ROWCELLS
+#define ROME_KDE_ROWCELLS 1
+#endif
+constexpr int kKdeRowPitch = 12;   // floats per row of cells (10 used; 48 bytes: 16-byte aligned rows)
+template <int B>
+__device__ __forceinline__ void lcv_cells_init(float* __restrict__ M, int N, int lane) {
+#if ROME_KDE_ROWCELLS
+  const int nb = (N + B - 1) / B;
+  for (int q = lane; q < nb * B * kKdeRowPitch; q += 64) M[q] = 0.0f;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#endif
+}
+template <bool WITH_T, int B>
+__device__ __forceinline__ void lcv_tail(const BlkPlan<B>& pl, const float (&r)[B], const float (&c)[B], const float (&tr)[B], const float (&tc)[B],
+                                         float* __restrict__ M, int N, int lane, double h, double tscale, double* negll, double* g) {
+  const int nb = pl.nb;
+  const int i0 = lane, i1 = lane + 64;
+  const bool act0 = i0 < N, act1 = i1 < N;
+#if ROME_KDE_ROWCELLS
+  float* cr = M + (pl.a * B) * kKdeRowPitch + pl.b;
+  float* cc = M + (pl.b * B) * kKdeRowPitch + pl.a;
+  const float* row0 = M + i0 * kKdeRowPitch;
+  const float* row1 = M + (act1 ? i1 : 0) * kKdeRowPitch;
+  auto exchange = [&](const float (&pr)[B], const float (&pc)[B], double* o0, double* o1) {
+    if (pl.ok) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) cr[u * kKdeRowPitch] = pr[u];
+      if (!pl.diag) {
+#pragma unroll
+        for (int u = 0; u < B; ++u) cc[u * kKdeRowPitch] = pc[u];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    float v0[12], v1[12];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(row0 + 4 * q), b = *reinterpret_cast<const float4*>(row1 + 4 * q);
+      v0[4 * q] = a.x; v0[4 * q + 1] = a.y; v0[4 * q + 2] = a.z; v0[4 * q + 3] = a.w;
+      v1[4 * q] = b.x; v1[4 * q + 1] = b.y; v1[4 * q + 2] = b.z; v1[4 * q + 3] = b.w;
+    }
+    if (WITH_T) {   // the derivative finish resolves 1e-6: the <= 10 partials of a row are folded in double (as the ring scheme did)
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) { s0 += (double)v0[k]; s1 += (double)v1[k]; }
+      *o0 = s0; *o1 = s1;
+    } else {
+      float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) { s0 += v0[k]; s1 += v1[k]; }
+      *o0 = (double)s0; *o1 = (double)s1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // the cells are rewritten next
+  };
+#else
+  float* cr = M + (pl.a * nb + pl.b) * B;
+  float* cc = M + (pl.b * nb + pl.a) * B;
+  const int b0 = i0 / B, b1 = (act1 ? i1 : 0) / B;
+  const float* row0 = M + b0 * nb * B + (i0 - b0 * B);
+  const float* row1 = M + b1 * nb * B + ((act1 ? i1 : 0) - b1 * B);
+  auto exchange = [&](const float (&pr)[B], const float (&pc)[B], double* o0, double* o1) {
+    if (pl.ok) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) cr[u] = pr[u];
+      if (!pl.diag) {
+#pragma unroll
+        for (int u = 0; u < B; ++u) cc[u] = pc[u];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (WITH_T) {
+      double s0 = 0.0, s1 = 0.0;
+      for (int k = 0; k < nb; ++k) { s0 += (double)row0[k * B]; s1 += (double)row1[k * B]; }
+      *o0 = s0; *o1 = s1;
+    } else {
+      float s0 = 0.0f, s1 = 0.0f;
+      for (int k = 0; k < nb; ++k) { s0 += row0[k * B]; s1 += row1[k * B]; }
+      *o0 = (double)s0; *o1 = (double)s1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // the cells are rewritten next
+  };
+#endif
+  double S0, S1, T0 = 0.0, T1 = 0.0;
+  exchange(r, c, &S0, &S1);
+  if (WITH_T) exchange(tr, tc, &T0, &T1);
+  // Σ_i log S_i = log Π_i S_i: mantissas multiplied, exponents added (wave_prod_frexp), ONE logarithm per evaluation instead of
+  // two per lane
+  const double s0 = act0 ? fmax(S0, 1e-300) : 1.0, s1 = act1 ? fmax(S1, 1e-300) : 1.0;
+  double mant = __builtin_amdgcn_frexp_mant(s0) * __builtin_amdgcn_frexp_mant(s1);   // in [0.25, 1)
+  int expo = __builtin_amdgcn_frexp_exp(s0) + __builtin_amdgcn_frexp_exp(s1);
+  double gg = 0.0;
+  if (WITH_T) gg = tscale * ((act0 ? T0 * rcp_pos_f64(s0) : 0.0) + (act1 ? T1 * rcp_pos_f64(s1) : 0.0));
+  wave_prod_frexp(&mant, &expo);
+  const double ll = uniform_f64(fast_log(mant) + (double)expo * 0.693147180559945309417);
+  if (WITH_T) *g = uniform_f64(wave_sum(gg) - (double)N * h * h); else *g = 0.0;
+  // (wave-uniform by construction; saying so lets the search state live in scalar registers across the unrolled block body)
+  *negll = uniform_f64(-(ll - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528)));
+}
+
 template <bool CIRC, bool WITH_T, int B>
 __device__ __forceinline__ void lcv_eval_blk(const BlkPlan<B>& pl, const float* __restrict__ xs, float* __restrict__ M, int N, int lane,
                                              double h, double* negll, double* g) {
   const float hf = (float)h;
   const float a2 = -0.72134752f / (hf * hf);   // -½ log2(e) / h²
-  const int nb = pl.nb;
   float xi[B], xj[B], r[B], c[B];
   [[maybe_unused]] float tr[B], tc[B];
 #pragma unroll
@@ -261,49 +363,8 @@ __device__ __forceinline__ void lcv_eval_blk(const BlkPlan<B>& pl, const float* 
       asm volatile("" : "+v"(xi[ii + 1]));
     }
   }
-  float* cr = M + (pl.a * nb + pl.b) * B;
-  float* cc = M + (pl.b * nb + pl.a) * B;
-  const int i0 = lane, i1 = lane + 64;
-  const bool act0 = i0 < N, act1 = i1 < N;
-  const int b0 = i0 / B, b1 = (act1 ? i1 : 0) / B;
-  const float* row0 = M + b0 * nb * B + (i0 - b0 * B);
-  const float* row1 = M + b1 * nb * B + ((act1 ? i1 : 0) - b1 * B);
-  auto exchange = [&](const float (&pr)[B], const float (&pc)[B], double* o0, double* o1) {
-    if (pl.ok) {
-#pragma unroll
-      for (int u = 0; u < B; ++u) cr[u] = pr[u];
-      if (!pl.diag) {
-#pragma unroll
-        for (int u = 0; u < B; ++u) cc[u] = pc[u];
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    if (WITH_T) {   // the derivative finish resolves 1e-6: the <= 10 partials of a row are folded in double (as the ring scheme did)
-      double s0 = 0.0, s1 = 0.0;
-      for (int k = 0; k < nb; ++k) { s0 += (double)row0[k * B]; s1 += (double)row1[k * B]; }
-      *o0 = s0; *o1 = s1;
-    } else {
-      float s0 = 0.0f, s1 = 0.0f;
-      for (int k = 0; k < nb; ++k) { s0 += row0[k * B]; s1 += row1[k * B]; }   // (unrolled with all reads in flight: measured slower, 1.35 -> 1.40 ms -- registers)
-      *o0 = (double)s0; *o1 = (double)s1;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // the cells are rewritten next
-  };
-  double S0, S1, T0 = 0.0, T1 = 0.0;
-  exchange(r, c, &S0, &S1);
-  if (WITH_T) exchange(tr, tc, &T0, &T1);
-  // Σ_i log S_i = log Π_i S_i: mantissas multiplied, exponents added (wave_prod_frexp), ONE logarithm per evaluation instead of
-  // two per lane
-  const double s0 = act0 ? fmax(S0, 1e-300) : 1.0, s1 = act1 ? fmax(S1, 1e-300) : 1.0;
-  double mant = __builtin_amdgcn_frexp_mant(s0) * __builtin_amdgcn_frexp_mant(s1);   // in [0.25, 1)
-  int expo = __builtin_amdgcn_frexp_exp(s0) + __builtin_amdgcn_frexp_exp(s1);
-  double gg = 0.0;
-  if (WITH_T) gg = (act0 ? T0 * rcp_pos_f64(s0) : 0.0) + (act1 ? T1 * rcp_pos_f64(s1) : 0.0);
-  wave_prod_frexp(&mant, &expo);
-  const double ll = uniform_f64(fast_log(mant) + (double)expo * 0.693147180559945309417);
-  if (WITH_T) *g = uniform_f64(wave_sum(gg) - (double)N * h * h); else *g = 0.0;
-  // (wave-uniform by construction; saying so lets the search state live in scalar registers across the unrolled block body)
-  *negll = uniform_f64(-(ll - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528)));
+  if constexpr (!WITH_T) { lcv_tail<false, B>(pl, r, c, r, c, M, N, lane, h, 1.0, negll, g); }
+  else { lcv_tail<true, B>(pl, r, c, tr, tc, M, N, lane, h, 1.0, negll, g); }
 }
 
 // ---- the same evaluation with the pair exponents held in REGISTERS across the whole search (B <= 10) ---------------------------------
@@ -331,7 +392,6 @@ __device__ __forceinline__ void lcv_eval_pre(const BlkPlan<B>& pl, const float (
                                              double h, double* negll, double* g) {
   const float hf = (float)h;
   const float s = 1.0f / (hf * hf);
-  const int nb = pl.nb;
   float r[B], c[B];
   [[maybe_unused]] float tr[B], tc[B];
 #pragma unroll
@@ -353,47 +413,9 @@ __device__ __forceinline__ void lcv_eval_pre(const BlkPlan<B>& pl, const float (
       for (int u = 0; u < B; ++u) { asm volatile("" : "+v"(c[u])); if (WITH_T) asm volatile("" : "+v"(tc[u])); }
     }
   }
-  float* cr = M + (pl.a * nb + pl.b) * B;
-  float* cc = M + (pl.b * nb + pl.a) * B;
-  const int i0 = lane, i1 = lane + 64;
-  const bool act0 = i0 < N, act1 = i1 < N;
-  const int b0 = i0 / B, b1 = (act1 ? i1 : 0) / B;
-  const float* row0 = M + b0 * nb * B + (i0 - b0 * B);
-  const float* row1 = M + b1 * nb * B + ((act1 ? i1 : 0) - b1 * B);
-  auto exchange = [&](const float (&pr)[B], const float (&pc)[B], double* o0, double* o1) {
-    if (pl.ok) {
-#pragma unroll
-      for (int u = 0; u < B; ++u) cr[u] = pr[u];
-      if (!pl.diag) {
-#pragma unroll
-        for (int u = 0; u < B; ++u) cc[u] = pc[u];
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    if (WITH_T) {
-      double s0 = 0.0, s1 = 0.0;
-      for (int k = 0; k < nb; ++k) { s0 += (double)row0[k * B]; s1 += (double)row1[k * B]; }
-      *o0 = s0; *o1 = s1;
-    } else {
-      float s0 = 0.0f, s1 = 0.0f;
-      for (int k = 0; k < nb; ++k) { s0 += row0[k * B]; s1 += row1[k * B]; }   // (unrolled with all reads in flight: measured slower, 1.35 -> 1.40 ms -- registers)
-      *o0 = (double)s0; *o1 = (double)s1;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-  };
-  double S0, S1, T0 = 0.0, T1 = 0.0;
-  exchange(r, c, &S0, &S1);
-  if (WITH_T) exchange(tr, tc, &T0, &T1);
   constexpr double kUnscale = -1.0 / (double)0.72134752f;   // Σ w e -> Σ w d²
-  const double s0 = act0 ? fmax(S0, 1e-300) : 1.0, s1 = act1 ? fmax(S1, 1e-300) : 1.0;
-  double mant = __builtin_amdgcn_frexp_mant(s0) * __builtin_amdgcn_frexp_mant(s1);
-  int expo = __builtin_amdgcn_frexp_exp(s0) + __builtin_amdgcn_frexp_exp(s1);
-  double gg = 0.0;
-  if (WITH_T) gg = kUnscale * ((act0 ? T0 * rcp_pos_f64(s0) : 0.0) + (act1 ? T1 * rcp_pos_f64(s1) : 0.0));
-  wave_prod_frexp(&mant, &expo);
-  const double ll = uniform_f64(fast_log(mant) + (double)expo * 0.693147180559945309417);
-  if (WITH_T) *g = uniform_f64(wave_sum(gg) - (double)N * h * h); else *g = 0.0;
-  *negll = uniform_f64(-(ll - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528)));
+  if constexpr (!WITH_T) { lcv_tail<false, B>(pl, r, c, r, c, M, N, lane, h, 1.0, negll, g); }
+  else { lcv_tail<true, B>(pl, r, c, tr, tc, M, N, lane, h, kUnscale, negll, g); }
 }
 
 template <bool CIRC, int B, bool PRE>
@@ -415,6 +437,7 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
   const BlkPlan<B> pl = blk_plan<B>(N, lane);
   [[maybe_unused]] float epre[PRE ? B * B : 1];
   if constexpr (PRE) lcv_pre_blk<CIRC, B>(pl, xs, epre);
+  lcv_cells_init<B>(M, N, lane);
   {   // smallest pair distance, in double on the particles themselves: the lane's block pair, every unordered pair once
     double pi[B];
 #pragma unroll
