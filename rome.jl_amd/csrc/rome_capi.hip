@@ -597,6 +597,9 @@ int stage_beliefs(rome_ctx* c, const rome_opts* o, int n, int dim, const double*
   *used += (cnt * sizeof(double) + 255) & ~(size_t)255;
   return ROME_OK;
 }
+// host vectors feed / receive asynchronous copies: whatever way a clique entry returns (an error in the middle included), the stream is
+// drained before those vectors are destroyed (declare the guard AFTER them)
+struct DrainOnExit { hipStream_t s; ~DrainOnExit() { (void)hipStreamSynchronize(s); } };
 }  // namespace
 
 int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_host* q) {
@@ -637,7 +640,8 @@ int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_hos
   void* dbel[3];
   for (int t = 0; t < 3; ++t) if ((rc = stage_beliefs(c, o, nv[t], vdim[t], vhost[t], tmp, &dbel[t], &used, arena, cap))) return rc;
   hipStream_t s = c->stream;
-  std::vector<std::vector<double>> Ls(NF);
+  std::vector<std::vector<double>> Ls(NF), hout(NF);
+  DrainOnExit drain{s};
   double* dout[NF] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int k = 0; k < NF; ++k) {
     const Fam& f = fam[k];
@@ -671,7 +675,6 @@ int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_hos
     ROME_HIP(c, e);
   }
   // proposals back to the host in the caller's layout
-  std::vector<std::vector<double>> hout(NF);
   for (int k = 0; k < NF; ++k) {
     const Fam& f = fam[k];
     if (f.n == 0) continue;
@@ -809,6 +812,8 @@ int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsol
   auto take = [&](size_t bytes) -> void* { void* p = arena + used; used += al(bytes); return p; };
   // beliefs: host blocks in the device order, staged like rome_clique_proposals (layout conversion included)
   std::vector<double> tmp, perm_host[3];
+  std::vector<std::vector<double>> Ls(NF), hout(3);
+  DrainOnExit drain{s};
   double* d_store[3]; double* d_tmp[3]; double* d_prop[3]; double* d_pbw[3]; int32_t* d_ptr[3]; int32_t* d_rws[3]; double* d_bwout[3];
   for (int t = 0; t < 3; ++t) {
     const size_t plen = (o->layout == ROME_LAYOUT_AOS_POINTS ? (size_t)point_len(vdim[t]) : (size_t)vdim[t]) * N;
@@ -833,7 +838,6 @@ int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsol
                                              d_pbw[t] + (size_t)msg_base[t] * vdim[t], nullptr, s));
     }
   }
-  std::vector<std::vector<double>> Ls(NF);
   const int32_t* d_rows[NF] = {nullptr, nullptr, nullptr, nullptr, nullptr}; const double* d_mu[NF]; const double* d_L[NF];
   for (int k4 = 0; k4 < NF; ++k4) {
     const Fam& f = fam[k4];
@@ -900,7 +904,6 @@ int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsol
     }
   }
   // ---- results: the updated beliefs (first blocks of every store) and their manikde! bandwidths
-  std::vector<std::vector<double>> hout(3);
   for (int t = 0; t < 3; ++t) {
     const int nu = (int)uplist[t].size();
     if (nu == 0) continue;
