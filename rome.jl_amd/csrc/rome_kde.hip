@@ -367,58 +367,7 @@ __device__ __forceinline__ void lcv_eval_blk(const BlkPlan<B>& pl, const float* 
   else { lcv_tail<true, B>(pl, r, c, tr, tc, M, N, lane, h, 1.0, negll, g); }
 }
 
-// ---- the same evaluation with the pair exponents held in REGISTERS across the whole search (B <= 10) ---------------------------------
-// The search evaluates the SAME B x B pairs ~20 times with different h: e_ij = -½ log2(e) d_ij² (wrapped for a circular coordinate) is
-// computed once per task (lcv_pre_blk) and an evaluation is multiply, v_exp_f32, two accumulates per pair -- 4 VALU instructions
-// against 6 (Euclidean) / 9 (circular); the derivative sums use Σ w e = -½ log2(e) Σ w d².  B² = 100 more live registers: the kernel
-// runs at two or three waves per SIMD instead of four (the unrolled body has the instruction-level parallelism to cover that).
 template <bool CIRC, int B>
-__device__ __forceinline__ void lcv_pre_blk(const BlkPlan<B>& pl, const float* __restrict__ xs, float (&e)[B * B]) {
-  float xi[B], xj[B];
-#pragma unroll
-  for (int u = 0; u < B; ++u) { xi[u] = xs[pl.a * B + u]; xj[u] = xs[pl.b * B + u]; }
-#pragma unroll
-  for (int ii = 0; ii < B; ++ii) {
-#pragma unroll
-    for (int jj = 0; jj < B; ++jj) {
-      float d = xi[ii] - xj[jj];
-      if (CIRC) d = fmaf(-6.2831853071795865f, rintf(d * 0.15915494309189535f), d);
-      e[ii * B + jj] = (d * d) * -0.72134752f;
-    }
-  }
-}
-template <bool WITH_T, int B>
-__device__ __forceinline__ void lcv_eval_pre(const BlkPlan<B>& pl, const float (&e)[B * B], float* __restrict__ M, int N, int lane,
-                                             double h, double* negll, double* g) {
-  const float hf = (float)h;
-  const float s = 1.0f / (hf * hf);
-  float r[B], c[B];
-  [[maybe_unused]] float tr[B], tc[B];
-#pragma unroll
-  for (int u = 0; u < B; ++u) { r[u] = 0.0f; c[u] = 0.0f; if (WITH_T) { tr[u] = 0.0f; tc[u] = 0.0f; } }
-#pragma unroll
-  for (int ii = 0; ii < B; ++ii) {
-#pragma unroll
-    for (int jj = 0; jj < B; ++jj) {
-      const float ev = e[ii * B + jj];
-      float w = __builtin_amdgcn_exp2f(ev * s);
-      if (ii == jj) w = pl.diag ? 0.0f : w;
-      r[ii] += w; c[jj] += w;
-      if (WITH_T) { tr[ii] = fmaf(w, ev, tr[ii]); tc[jj] = fmaf(w, ev, tc[jj]); }
-    }
-    asm volatile("" : "+v"(r[ii]));
-    if (WITH_T) asm volatile("" : "+v"(tr[ii]));
-    if (ii + 1 < B) {
-#pragma unroll
-      for (int u = 0; u < B; ++u) { asm volatile("" : "+v"(c[u])); if (WITH_T) asm volatile("" : "+v"(tc[u])); }
-    }
-  }
-  constexpr double kUnscale = -1.0 / (double)0.72134752f;   // Σ w e -> Σ w d²
-  if constexpr (!WITH_T) { lcv_tail<false, B>(pl, r, c, r, c, M, N, lane, h, 1.0, negll, g); }
-  else { lcv_tail<true, B>(pl, r, c, tr, tc, M, N, lane, h, kUnscale, negll, g); }
-}
-
-template <bool CIRC, int B, bool PRE>
 __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bool (&act)[2], const double* __restrict__ pts,
                                                   float* __restrict__ xs, float* __restrict__ M, double* __restrict__ wbuf, int N, int lane,
                                                   double tol, int* n_evals) {
@@ -435,8 +384,6 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   const BlkPlan<B> pl = blk_plan<B>(N, lane);
-  [[maybe_unused]] float epre[PRE ? B * B : 1];
-  if constexpr (PRE) lcv_pre_blk<CIRC, B>(pl, xs, epre);
   lcv_cells_init<B>(M, N, lane);
   {   // smallest pair distance, in double on the particles themselves: the lane's block pair, every unordered pair once
     double pi[B];
@@ -476,13 +423,8 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
   double hq = x1;
   for (;;) {
     double fv, gv;
-    if constexpr (PRE) {
-      if (finish) lcv_eval_pre<true, B>(pl, epre, M, N, lane, hq, &fv, &gv);
-      else lcv_eval_pre<false, B>(pl, epre, M, N, lane, hq, &fv, &gv);
-    } else {
-      if (finish) lcv_eval_blk<CIRC, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
-      else lcv_eval_blk<CIRC, false, B>(pl, xs, M, N, lane, hq, &fv, &gv);
-    }
+    if (finish) lcv_eval_blk<CIRC, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
+    else lcv_eval_blk<CIRC, false, B>(pl, xs, M, N, lane, hq, &fv, &gv);
     ++ne;
     if (phase == 0) { f1 = fv; g1 = gv; hq = x2; phase = 1; continue; }
     if (phase == 1) { f2 = fv; g2 = gv; phase = 2; }
@@ -572,17 +514,10 @@ __global__ void __launch_bounds__(64 * kKdeWaves) k_kde_bandwidth(int T, int dim
 // the fast path as its own kernel per block size (register allocation is per kernel: the B = 13 bodies must not set the occupancy of
 // the N = 100 case); four waves per SIMD (128 VGPRs: measured faster than three without the ~70 spills, which sit in the rare
 // double-precision paths) -- left alone the scheduler spreads the unrolled block bodies over > 400 VGPRs
-#ifndef ROME_KDE_PRE
-#define ROME_KDE_PRE 0   // 1: pair exponents of the fast path held in registers (B <= 10).  Measured on the proposals of a Manhattan sweep:
-                         // 419 / 593 VALU per evaluation instead of 617..1097, but 231 VGPRs = two waves per SIMD: 1.41 ms (three waves
-                         // with spills: 1.36 ms) against 1.345 ms for the four-wave kernel -- the exchange / reduction / logarithm part of an
-                         // evaluation is latency-bound and needs the four waves.  Off; kept as a parity-tested experiment build.
-#endif
-#ifndef ROME_KDE_PRE_WAVES
-#define ROME_KDE_PRE_WAVES 2
-#endif
-template <int B, bool PRE>
-__global__ void __launch_bounds__(64 * kKdeWaves) __attribute__((amdgpu_waves_per_eu(PRE ? ROME_KDE_PRE_WAVES : 4, 8)))
+// (tried: the pair exponents -½ log2(e) d² of a task held in registers across its ~20 evaluations -- 419 / 593 VALU instructions per
+// evaluation instead of 617 .. 1097, but 231 VGPRs = two waves per SIMD: 1.41 ms against 1.345 ms, profiles/r03_kde_experiments.txt)
+template <int B>
+__global__ void __launch_bounds__(64 * kKdeWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_kde_bandwidth_fast(int T, int dim, int N, const double* __restrict__ bel, uint32_t circ_mask, double tol_e, double tol_c,
                      double* __restrict__ bw, int32_t* __restrict__ evals) {
   __shared__ double pts[kKdeWaves][128];
@@ -606,8 +541,8 @@ k_kde_bandwidth_fast(int T, int dim, int N, const double* __restrict__ bel, uint
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   int ne = 0;
   float* M = cellbuf + wave * kdeCells<B>(N);
-  const double h = circ ? lcv_golden_fast<true, B, PRE>(x, act, pts[wave], xsbuf[wave], M, wex[wave], N, lane, tol_c, &ne)
-                        : lcv_golden_fast<false, B, PRE>(x, act, pts[wave], xsbuf[wave], M, wex[wave], N, lane, tol_e, &ne);
+  const double h = circ ? lcv_golden_fast<true, B>(x, act, pts[wave], xsbuf[wave], M, wex[wave], N, lane, tol_c, &ne)
+                        : lcv_golden_fast<false, B>(x, act, pts[wave], xsbuf[wave], M, wex[wave], N, lane, tol_e, &ne);
   if (lane == 0) { bw[t] = h; if (evals) evals[t] = ne; }
 }
 
@@ -671,13 +606,13 @@ hipError_t launch_kde_bandwidth(int dim, int V, int N, const double* bel, uint32
 #define ROME_LAUNCH_KDE(SS) hipLaunchKernelGGL((k_kde_bandwidth<SS>), grid, block, 0, s, T, dim, N, bel, circ_mask, tol_e, tol_c, bw, evals)
   if (N < 8) ROME_LAUNCH_KDE(1);
   else if (N <= 70)
-    hipLaunchKernelGGL((k_kde_bandwidth_fast<7, ROME_KDE_PRE != 0>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<7>(N), s, T, dim, N, bel, circ_mask,
+    hipLaunchKernelGGL((k_kde_bandwidth_fast<7>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<7>(N), s, T, dim, N, bel, circ_mask,
                        tol_e, tol_c, bw, evals);
   else if (N <= 100)
-    hipLaunchKernelGGL((k_kde_bandwidth_fast<10, ROME_KDE_PRE != 0>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<10>(N), s, T, dim, N, bel, circ_mask,
+    hipLaunchKernelGGL((k_kde_bandwidth_fast<10>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<10>(N), s, T, dim, N, bel, circ_mask,
                        tol_e, tol_c, bw, evals);
   else if (N <= 128)
-    hipLaunchKernelGGL((k_kde_bandwidth_fast<13, false>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<13>(N), s, T, dim, N, bel, circ_mask,
+    hipLaunchKernelGGL((k_kde_bandwidth_fast<13>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<13>(N), s, T, dim, N, bel, circ_mask,
                        tol_e, tol_c, bw, evals);
   else if (N <= 256) ROME_LAUNCH_KDE(4);
   else ROME_LAUNCH_KDE(8);
