@@ -29,6 +29,10 @@ class Opts(C.Structure):
 
 def make_opts(N=100, solver=SOLVER_NEWTON, max_iters=None, inflate_cycles=3, tol=None, inflation=5.0,
               seed=0x524F4D45, stream_offset=0, nullhypo=0.0, spread_nh=3.0):
+    if solver == 3:   # the device library's ROME_SOLVER_GAUSS_NEWTON: the oracle's Newton mode IS that iteration on the functor
+        solver = SOLVER_NEWTON
+    if solver not in (SOLVER_CLOSED_FORM, SOLVER_NEWTON, SOLVER_NELDER_MEAD):
+        raise ValueError("oracle: unknown solver %r" % (solver,))
     if max_iters is None:
         max_iters = 1000 if solver == SOLVER_NELDER_MEAD else 20
     if tol is None:
