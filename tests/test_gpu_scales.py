@@ -1,0 +1,165 @@
+"""Magnitude / conditioning sweeps of the convolution kernels against the oracle (through the C ABI): coordinate scales from
+millimetres to 100 km, headings many turns away from (-pi, pi], measurement sigmas from 1e-8 to 1e2, odd and minimal particle counts,
+degenerate geometry (pose on the landmark, zero range, identity measurements).  Tolerances are RELATIVE to the coordinate scale
+(1e-9 x max(1, scale) on translations -- a few hundred ulp at that magnitude -- and 1e-9 on angles)."""
+import numpy as np
+import pytest
+
+import oracle as ro
+
+pytestmark = pytest.mark.gpu
+R = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _pkg():
+    global R
+    import rome_jl_amd
+    R = rome_jl_amd
+    R.default_context()
+    yield
+
+
+def _wrap(a):
+    return np.arctan2(np.sin(a), np.cos(a))
+
+
+SCALES = [1e-3, 1.0, 1e3, 1e5]
+SIGMAS = [1e-8, 1e-2, 1e2]
+
+
+@pytest.mark.parametrize("solver", [0, 1, 3])
+@pytest.mark.parametrize("sig", SIGMAS)
+@pytest.mark.parametrize("scale", SCALES)
+def test_pose2pose2_scales(scale, sig, solver):
+    rng = np.random.default_rng(int(np.log10(scale) * 7 + np.log10(sig) * 3 + 100 + solver))
+    for N in (2, 3, 17, 100, 127):
+        C_ = 11
+        mu = np.concatenate([rng.standard_normal((C_, 2)) * scale, rng.uniform(-40, 40, (C_, 1))], 1)   # headings many turns out
+        cov = np.stack([np.diag([(sig * scale) ** 2, (sig * scale) ** 2, min(sig, 1.0) ** 2]) for _ in range(C_)])
+        ctr = lambda: np.concatenate([rng.standard_normal((C_, 2, 1)) * 10 * scale, rng.uniform(-60, 60, (C_, 1, 1))], 1)
+        spread = np.array([0.3 * scale, 0.3 * scale, 0.1])[None, :, None]
+        fixed = rng.standard_normal((C_, 3, N)) * spread + ctr()
+        target = rng.standard_normal((C_, 3, N)) * spread + ctr()
+        dirs = rng.integers(0, 2, C_).astype(np.int32)
+        for noise in (rng.standard_normal((C_, 3, N)), None):
+            o = R.make_opts(N=N, solver=solver, seed=31 + N)
+            out, st = R.conv_pose2pose2(o, mu, cov, fixed, target, dirs=dirs, noise=noise, want_status=True)
+            L = np.array([ro.cholesky_lower(c) for c in cov])
+            ref, rst = ro.conv_pose2pose2(ro.make_opts(N=N, solver=solver, seed=31 + N), mu, L, np.concatenate([fixed, target], 0),
+                                          np.arange(C_), C_ + np.arange(C_), dirs, noise=noise, want_status=True)
+            tol_t = 1e-9 * max(1.0, scale) * max(1.0, sig)
+            assert np.isfinite(out).all()
+            assert np.abs(out[:, :2] - ref[:, :2]).max() < tol_t, (N, noise is None)
+            assert np.abs(_wrap(out[:, 2] - ref[:, 2])).max() < 1e-9
+            assert np.abs(out[:, 2]).max() <= np.pi + 1e-12          # headings come back wrapped
+            # (the status is max|r| <= tol with an ABSOLUTE tol = 1e-12: above metre scale that is below one ulp of a coordinate and the
+            #  flag is rounding noise on both sides)
+            if scale <= 1.0:
+                assert (st == rst).all()
+
+
+@pytest.mark.parametrize("direction", [0, 1])
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("scale", SCALES)
+def test_bearingrange_scales(scale, solver, direction):
+    rng = np.random.default_rng(int(np.log10(scale) * 5 + 50 + solver + 2 * direction))
+    for N in (2, 3, 65, 100, 127):
+        C_ = 9
+        mu = np.stack([rng.uniform(-30, 30, C_), rng.uniform(0.5, 25, C_) * scale], 1)    # bearings many turns out
+        sigma = np.stack([rng.uniform(1e-6, 0.1, C_), rng.uniform(1e-6, 0.15, C_) * mu[:, 1]], 1)   # sampled ranges stay positive (>= 6 sigma)
+        pose = np.concatenate([rng.standard_normal((C_, 2, N)) * 0.3 * scale + rng.standard_normal((C_, 2, 1)) * 10 * scale,
+                               rng.standard_normal((C_, 1, N)) * 0.1 + rng.uniform(-50, 50, (C_, 1, 1))], 1)
+        pt = rng.standard_normal((C_, 2, N)) * 0.5 * scale + rng.standard_normal((C_, 2, 1)) * 15 * scale
+        fixed, target = (pose, pt) if direction == 0 else (pt, pose)
+        for noise in (rng.standard_normal((C_, 2, N)), None):
+            o = R.make_opts(N=N, solver=solver, seed=77 + N)
+            out, st = R.conv_pose2point2br(o, direction, mu, sigma, fixed, target, noise=noise, want_status=True)
+            ref, rst = ro.conv_pose2point2br(ro.make_opts(N=N, solver=solver, seed=77 + N), direction, mu, sigma, fixed, target,
+                                             np.arange(C_), np.arange(C_), noise=noise, want_status=True)
+            assert np.isfinite(out).all()
+            # the pose direction passes the start point through three inflation cycles: rounding differences are amplified by the
+            # ring geometry (range / distance), hence one more digit than the landmark direction
+            tol = (1e-9 if direction == 0 else 1e-8) * max(1.0, scale)
+            assert np.abs(out[:, :2] - ref[:, :2]).max() < tol, (N, noise is None)
+            if direction == 1:
+                assert np.abs(_wrap(out[:, 2] - ref[:, 2])).max() < 1e-8
+            if scale <= 1.0:
+                assert (st == rst).all()
+
+
+def test_bearingrange_degenerate_geometry():
+    """pose exactly on the landmark (the ray has no direction: the kernel leaves along +x, as the oracle), zero measured range, N = 2"""
+    N, C_ = 2, 3
+    mu = np.array([[0.3, 5.0], [0.0, 0.0], [-1.0, 2.0]])
+    sigma = np.full((C_, 2), 1e-9)
+    pt = np.array([[[1.0, 1.0], [2.0, 2.0]], [[0.0, 0.0], [0.0, 0.0]], [[-3.0, -3.0], [4.0, 4.0]]])
+    pose = np.concatenate([pt.copy(), np.zeros((C_, 1, N))], 1)                     # every pose starts ON its landmark
+    noise = np.zeros((C_, 2, N))
+    for solver in (0, 1):
+        o = R.make_opts(N=N, solver=solver, inflate_cycles=1, inflation=0.0)
+        out = R.conv_pose2point2br(o, 1, mu, sigma, pt, pose, noise=noise)
+        ref = ro.conv_pose2point2br(ro.make_opts(N=N, solver=solver, inflate_cycles=1, inflation=0.0), 1, mu, sigma, pt, pose,
+                                    np.arange(C_), np.arange(C_), noise=noise)
+        assert np.isfinite(out).all() and np.abs(out - ref).max() < 1e-12
+        # landmark direction with zero range: the landmark is the pose position
+        out0 = R.conv_pose2point2br(o, 0, mu[1:2], sigma[1:2], pose[1:2], pt[1:2], noise=noise[1:2])
+        assert np.abs(out0 - pose[1:2, :2]).max() < 1e-9
+
+
+def test_bearingrange_negative_sampled_range_is_flagged():
+    """sigma_range >> mean range: some sampled ranges are negative and r = (.., rho - ||pl||) has NO root.  Both sides must say so
+    (status != 0 under NEWTON) and stay finite; the positions of such particles are not comparable (the oracle's iteration
+    flips sides until max_iters, the kernel's exact ring step is applied once per cycle)."""
+    N, C_ = 100, 4
+    rng = np.random.default_rng(5)
+    mu = np.stack([rng.uniform(-1, 1, C_), np.full(C_, 1.0)], 1)
+    sigma = np.stack([np.full(C_, 0.01), np.full(C_, 5.0)], 1)
+    pt = rng.standard_normal((C_, 2, N)) * 0.1 + rng.standard_normal((C_, 2, 1)) * 5
+    pose = np.concatenate([rng.standard_normal((C_, 2, N)) + rng.standard_normal((C_, 2, 1)) * 5, rng.standard_normal((C_, 1, N))], 1)
+    noise = rng.standard_normal((C_, 2, N))
+    neg = (mu[:, 1, None] + sigma[:, 1, None] * noise[:, 1]) < 0
+    assert neg.any() and (~neg).any()
+    out, st = R.conv_pose2point2br(R.make_opts(N=N, solver=1, seed=3), 1, mu, sigma, pt, pose, noise=noise, want_status=True)
+    ref, rst = ro.conv_pose2point2br(ro.make_opts(N=N, solver=1, seed=3), 1, mu, sigma, pt, pose, np.arange(C_), np.arange(C_),
+                                     noise=noise, want_status=True)
+    assert np.isfinite(out).all()
+    assert (st[neg] != 0).all() and (rst[neg] != 0).all()
+    assert (st[~neg] == 0).all() and (rst[~neg] == 0).all()
+    # the particles WITH a root sit on their ring (their positions on it are not comparable either: the inflation spread is a
+    # statistic over all particles of the convolution, the rootless ones included)
+    z = mu[:, :, None] + sigma[:, :, None] * noise
+    rows = lambda a, d: a.transpose(0, 2, 1).reshape(-1, d)
+    for res in (out, ref):
+        r = R.residual_pose2point2br(rows(z, 2), rows(res, 3), rows(pt, 2))
+        assert np.abs(r[(~neg).reshape(-1)]).max() < 1e-9
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 1e4])
+def test_pose3pose3_scales(scale, solver):
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(int(np.log10(scale) * 3 + 20 + solver))
+    for N in (2, 33, 100):
+        C_ = 7
+        rv = lambda n, m: (lambda v: v / np.linalg.norm(v, axis=1, keepdims=True) * rng.uniform(0, m, (n, 1, v.shape[2])))(rng.standard_normal((n, 3, N if False else 1)))
+        mu = np.concatenate([rng.standard_normal((C_, 3)) * 2 * scale, rv(C_, 2.5)[:, :, 0]], 1)
+        cov = np.stack([np.diag([(0.01 * scale) ** 2] * 3 + [1e-4] * 3) for _ in range(C_)])
+        def blk():
+            ctr = np.concatenate([rng.standard_normal((C_, 3, 1)) * 8 * scale, rv(C_, 2.8)], 1)
+            return ctr + rng.standard_normal((C_, 6, N)) * np.array([0.2 * scale] * 3 + [0.02] * 3)[None, :, None]
+        fixed, target = blk(), blk()
+        dirs = rng.integers(0, 2, C_).astype(np.int32)
+        noise = rng.standard_normal((C_, 6, N))
+        out, st = R.conv_pose3pose3(R.make_opts(N=N, solver=solver, seed=5), mu, cov, fixed, target, dirs=dirs, noise=noise, want_status=True)
+        L = np.array([ro.cholesky_lower(c) for c in cov])
+        ref, rst = ro.conv_pose3pose3(ro.make_opts(N=N, solver=solver, seed=5), mu, L, np.concatenate([fixed, target], 0), np.arange(C_),
+                                      C_ + np.arange(C_), dirs, noise=noise, want_status=True)
+        assert np.isfinite(out).all()
+        assert np.abs(out[:, :3] - ref[:, :3]).max() < 1e-9 * max(1.0, scale)
+        ang = (Rot.from_rotvec(out[:, 3:].transpose(0, 2, 1).reshape(-1, 3)).inv() *
+               Rot.from_rotvec(ref[:, 3:].transpose(0, 2, 1).reshape(-1, 3))).magnitude()
+        near = np.linalg.norm(ref[:, 3:], axis=1).reshape(-1) > np.pi - 1e-2
+        assert ang[~near].max() < 1e-9 and (not near.any() or ang[near].max() < 1e-6)
+        if scale <= 1.0:
+            assert (st == rst).all()
