@@ -1515,7 +1515,9 @@ static int msg_node(const msg_tree* T, int l, int z, double* mean, double* var, 
 }
 static inline uint32_t msg_xorshift(uint32_t r) { r ^= r << 13; r ^= r >> 17; r ^= r << 5; return r; }
 /* Candidate arithmetic: IEEE single precision, every operation written out (this file is compiled with -ffp-contract=off; fmaf is
- * the correctly rounded fused operation).  The device evaluates two candidates per lane with packed instructions: same values. */
+ * the correctly rounded fused operation).  The device evaluates two candidates per lane with packed instructions: same values --
+ * except msg_exp32 / msg_ln32, which its shipped build takes from the hardware transcendentals within an ulp of the polynomials below
+ * (these stay the definition; a draw can differ only when a uniform lands within an ulp of a cumulative boundary). */
 #define MSG_ABSENT (-3.0e38f)   /* log p of "no candidate"; also the initial running maximum */
 static inline float msg_f32_from_bits(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline uint32_t msg_bits_from_f32(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
