@@ -1,7 +1,7 @@
 """Gibbs product throughput against the LDS footprint of a block (= resident waves per SIMD): 3500 variables x 3 proposals, the
 launch sized for max_k = 3 .. 14 proposals (what the largest variable of a graph dictates for everyone).  profiles/r02_gibbs_occupancy.txt"""
 import sys, time, numpy as np, ctypes as C
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch, rome_jl_amd as R
 from rome_jl_amd import _lib
 ctx = R.default_context(); dev = torch.device("cuda", 0); lib = _lib.load()
