@@ -65,25 +65,11 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// value of lane (l ^ j), j a power of two < 64 (a constant once the sort is unrolled): DPP moves inside a 16-lane row (quad permutes
-// for 1 and 2; for 4 and 8 a left and a right row shift, each kept by the banks it is valid for), ds_bpermute across rows.
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int j) {
-  const int x = (int)v;
-  switch (j) {
-    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
-    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
-    case 4: { const int a = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);
-              return (uint32_t)__builtin_amdgcn_update_dpp(a, x, 0x114, 0xF, 0xA, false); }
-    case 8: { const int a = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xF, 0x3, false);
-              return (uint32_t)__builtin_amdgcn_update_dpp(a, x, 0x118, 0xF, 0xC, false); }
-    default: return (uint32_t)__shfl_xor(x, j, 64);
-  }
-}
-
 // one wavefront builds tree `T` of proposal `P` ([D][N] doubles, bandwidths h); scr: 2 x 128 x D ints of per-wave scratch
 template <int D>
 __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restrict__ P, const double* __restrict__ hb, int row,
-                            int N, int L, uint32_t circ, int lane, float* __restrict__ ybuf /*[128][D]*/, int* __restrict__ ext /*[128][2D]*/) {
+                            int N, int L, uint32_t circ, int lane, float* __restrict__ ybuf /*[128][D]*/, int* __restrict__ ext /*[128][2D]*/,
+                            uint64_t* __restrict__ kb /*[128]*/) {
   // ---- offsets from point 0, single precision; positions p = lane, lane + 64
   float y[2][D];
   int id[2];
@@ -112,7 +98,7 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
   if (lane < D) { T->ref[lane] = P[lane * N]; T->h[lane] = fmax(hb[lane], 1e-6); }
   if (lane == 0) T->row = row;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-  // ---- top-down: per level one bitonic sort of (node, key along the node's widest coordinate, id)
+  // ---- top-down: per level the points of every node are ordered by (key along the node's widest coordinate, id)
   for (int l = 0; l < L; ++l) {
     const int nn = 1 << l;
     for (int q = lane; q < nn * 2 * D; q += 64) ext[q] = (q & 1) ? (int)0x80000000 : 0x7FFFFFFF;   // (min, max) per node and coordinate
@@ -150,27 +136,39 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
         key[s] = ((uint64_t)z[s] << 40) | ((uint64_t)fkey(kv) << 8) | (uint64_t)id[s];
       } else key[s] = ~0ull;
     }
-    // bitonic sort of the 128 keys (position p = lane + 64 s), ascending
+    // The positions of a node are already its own (the level above ordered by node): ordering WITHIN the node is all that is left, and
+    // a point's place is the node's first position + the number of the node's points with a smaller (key, id) -- counted against
+    // the node's keys in LDS (lanes of one node read the same address: broadcasts).  Σ_l N / 2^l = 2N compare steps per point
+    // instead of the 28 exchange stages of a full 128-key bitonic sort at every level (which this replaced: 223 -> 207 µs per
+    // Manhattan sweep of proposals); the same order (keys are unique by id).
+    {
+      int na[2], nbnd[2];
 #pragma unroll
-    for (int k2 = 2; k2 <= 128; k2 <<= 1) {
-#pragma unroll
-      for (int j2 = k2 >> 1; j2 >= 1; j2 >>= 1) {
-        if (j2 == 64) {   // partner = other slot of the same lane (only in the last stage: ascending everywhere)
-          const uint64_t a = key[0] < key[1] ? key[0] : key[1], b = key[0] < key[1] ? key[1] : key[0];
-          key[0] = a; key[1] = b;
-        } else {
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int p = lane + 64 * s;
-            const uint32_t plo = lane_xor((uint32_t)key[s], j2), phi = lane_xor((uint32_t)(key[s] >> 32), j2);
-            const uint64_t other = ((uint64_t)phi << 32) | plo;
-            const bool up = (p & k2) == 0;              // ascending block
-            const bool lower = (p & j2) == 0;           // this position keeps the smaller key of the pair when ascending
-            const bool keep_min = up == lower;
-            key[s] = keep_min ? (key[s] < other ? key[s] : other) : (key[s] < other ? other : key[s]);
-          }
-        }
+      for (int s = 0; s < 2; ++s) {
+        const int p = lane + 64 * s;
+        na[s] = 0; nbnd[s] = 0;
+        if (p < N) { node_range(N, l, z[s], &na[s], &nbnd[s]); kb[p] = key[s] & 0xFFFFFFFFFFull; }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      const int span = (N + nn - 1) / nn;          // the largest node of this level
+      int rank[2] = {0, 0};
+      const uint64_t mine0 = key[0] & 0xFFFFFFFFFFull, mine1 = key[1] & 0xFFFFFFFFFFull;
+      for (int t = 0; t < span; ++t) {
+        const int j0 = na[0] + t, j1 = na[1] + t;
+        const uint64_t o0 = kb[j0 < nbnd[0] ? j0 : na[0]], o1 = kb[j1 < nbnd[1] ? j1 : na[1]];
+        rank[0] += (j0 < nbnd[0] && o0 < mine0) ? 1 : 0;
+        rank[1] += (j1 < nbnd[1] && o1 < mine1) ? 1 : 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // every key has been read
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int p = lane + 64 * s;
+        if (p < N) kb[na[s] + rank[s]] = key[s];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < 2; ++s) { const int p = lane + 64 * s; key[s] = p < N ? kb[p] : ~0ull; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // kb is rewritten at the next level
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -259,11 +257,12 @@ template <int D>
 __global__ void __launch_bounds__(256) k_gibbs_trees(const GibbsArgs a) {
   __shared__ float ybuf[4][kGibbsMaxN * D];
   __shared__ int ext[4][64 * 2 * D];
+  __shared__ uint64_t kb[4][kGibbsMaxN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
   if (row >= a.n_rows) return;   // wave-uniform; waves never synchronise with each other
   GibbsTree<D>* T = reinterpret_cast<GibbsTree<D>*>(a.trees) + row;
-  gibbs_build<D>(T, a.prop + (size_t)row * D * a.N, a.prop_bw + (size_t)row * D, row, a.N, a.L, a.circ, lane, ybuf[wave], ext[wave]);
+  gibbs_build<D>(T, a.prop + (size_t)row * D * a.N, a.prop_bw + (size_t)row * D, row, a.N, a.L, a.circ, lane, ybuf[wave], ext[wave], kb[wave]);
 }
 
 // ---- candidate arithmetic: IEEE single precision, every operation spelled out (explicit fma, contraction off), so that the
