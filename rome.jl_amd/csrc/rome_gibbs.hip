@@ -203,29 +203,43 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
 #pragma unroll
     for (int d = 0; d < D; ++d) { m[s][d] = n[s] > 0 ? (double)T->ys[d][a] : 0.0; M2[s][d] = 0.0; }
   }
-  for (int l = L - 1; l >= 0; --l) {
+  // 1 / v for a positive normal double: v_rcp_f64 + two Newton steps (relative error ~1e-16; an IEEE division is four times the
+  // instructions, and a level needs a dozen).  The oracle's msg_build divides: the statistics agree to an ulp of double before they
+  // are rounded to single precision.
+  auto rcp64 = [](double v) -> double {
+    double y = __builtin_amdgcn_rcp(v);
+    y = __builtin_fma(__builtin_fma(-v, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-v, y, 1.0), y, y);
+    return y;
+  };
+  // node zz = lane of level l (at most 64 nodes: slot 0) <- children 2 zz, 2 zz + 1 of level l + 1; child c lives in slot c >> 6,
+  // lane c & 63 (both children in the same slot; only the deepest step has children in slot 1).  Same recurrences as msg_build.
+  auto merge_level = [&](int l, auto two_slots) {
 #pragma clang fp contract(off)
-    // node zz = lane of level l (at most 64 nodes: slot 0) <- children 2 zz, 2 zz + 1 of level l + 1; child c lives in slot c >> 6,
-    // lane c & 63 (both children in the same slot).  Same arithmetic, in the same order, as msg_build in the oracle.
+    constexpr bool kTwo = decltype(two_slots)::value;
     const int zz = lane;
-    const int c0 = (2 * zz) & 127, sl = c0 >> 6, la = c0 & 63, lb = (la + 1) & 63;
-    const int nl0 = __shfl(n[0], la, 64), nl1 = __shfl(n[1], la, 64), nr0 = __shfl(n[0], lb, 64), nr1 = __shfl(n[1], lb, 64);
-    const int nl = sl ? nl1 : nl0, nr = sl ? nr1 : nr0;
+    const int c0 = (2 * zz) & 127, sl = kTwo ? (c0 >> 6) : 0, la = c0 & 63, lb = (la + 1) & 63;
+    int nl = __shfl(n[0], la, 64), nr = __shfl(n[0], lb, 64);
+    if constexpr (kTwo) { const int nl1 = __shfl(n[1], la, 64), nr1 = __shfl(n[1], lb, 64); nl = sl ? nl1 : nl; nr = sl ? nr1 : nr; }
     const bool livep = zz < (1 << l);
+    const double nt = (double)(nl + nr);
+    const double inv_nt = nl + nr > 0 ? rcp64(nt) : 0.0;
     double pm[D], pM[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const double ml0 = shfl_f64(m[0][d], la), ml1 = shfl_f64(m[1][d], la), mr0 = shfl_f64(m[0][d], lb), mr1 = shfl_f64(m[1][d], lb);
-      const double Ml0 = shfl_f64(M2[0][d], la), Ml1 = shfl_f64(M2[1][d], la), Mr0 = shfl_f64(M2[0][d], lb), Mr1 = shfl_f64(M2[1][d], lb);
-      const double ml = sl ? ml1 : ml0, mr = sl ? mr1 : mr0, Ml = sl ? Ml1 : Ml0, Mr = sl ? Mr1 : Mr0;
+      double ml = shfl_f64(m[0][d], la), mr = shfl_f64(m[0][d], lb), Ml = shfl_f64(M2[0][d], la), Mr = shfl_f64(M2[0][d], lb);
+      if constexpr (kTwo) {
+        const double ml1 = shfl_f64(m[1][d], la), mr1 = shfl_f64(m[1][d], lb), Ml1 = shfl_f64(M2[1][d], la), Mr1 = shfl_f64(M2[1][d], lb);
+        ml = sl ? ml1 : ml; mr = sl ? mr1 : mr; Ml = sl ? Ml1 : Ml; Mr = sl ? Mr1 : Mr;
+      }
       double mm = 0.0, MM = 0.0;
       if (nl + nr > 0) {
         if (nr == 0) { mm = ml; MM = Ml; }
         else if (nl == 0) { mm = mr; MM = Mr; }
         else {
-          const double dl = ml - mr, nt = (double)(nl + nr);
-          mm = ((double)nl * ml + (double)nr * mr) / nt;
-          MM = Ml + Mr + (double)nl * (double)nr / nt * dl * dl;
+          const double dl = ml - mr;
+          mm = ((double)nl * ml + (double)nr * mr) * inv_nt;
+          MM = Ml + Mr + (double)nl * (double)nr * inv_nt * dl * dl;
         }
       }
       pm[d] = mm; pM[d] = MM;
@@ -238,13 +252,15 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
       double lg = 0.0;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        const double v = M2[0][d] / (double)n[0] + h2[d];
-        T->mean[d][idn] = (float)m[0][d]; T->var[d][idn] = (float)v; T->ivar[d][idn] = (float)(1.0 / v);
-        lg += log(v);
+        const double v = M2[0][d] * inv_nt + h2[d];
+        T->mean[d][idn] = (float)m[0][d]; T->var[d][idn] = (float)v; T->ivar[d][idn] = (float)rcp64(v);
+        lg += fast_log(v);   // (fdlibm kernel, < 1 ulp: the library call is twice the instructions)
       }
-      T->cz[idn] = (float)(log((double)n[0] / (double)N) - 0.5 * lg);
+      T->cz[idn] = (float)(fast_log(nt * (1.0 / (double)N)) - 0.5 * lg);
     }
-  }
+  };
+  if (L >= 1) merge_level(L - 1, std::true_type{});
+  for (int l = L - 2; l >= 0; --l) merge_level(l, std::false_type{});
   if (lane == 0) {
     double lg = 0.0;
 #pragma unroll
