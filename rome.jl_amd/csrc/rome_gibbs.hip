@@ -203,15 +203,8 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
 #pragma unroll
     for (int d = 0; d < D; ++d) { m[s][d] = n[s] > 0 ? (double)T->ys[d][a] : 0.0; M2[s][d] = 0.0; }
   }
-  // 1 / v for a positive normal double: v_rcp_f64 + two Newton steps (relative error ~1e-16; an IEEE division is four times the
-  // instructions, and a level needs a dozen).  The oracle's msg_build divides: the statistics agree to an ulp of double before they
-  // are rounded to single precision.
-  auto rcp64 = [](double v) -> double {
-    double y = __builtin_amdgcn_rcp(v);
-    y = __builtin_fma(__builtin_fma(-v, y, 1.0), y, y);
-    y = __builtin_fma(__builtin_fma(-v, y, 1.0), y, y);
-    return y;
-  };
+  // (fast_rcp: v_rcp_f64 + two Newton steps; a level needs a dozen reciprocals.  The oracle's msg_build divides: the statistics agree to
+  //  an ulp of double before they are rounded to single precision.)
   // node zz = lane of level l (at most 64 nodes: slot 0) <- children 2 zz, 2 zz + 1 of level l + 1; child c lives in slot c >> 6,
   // lane c & 63 (both children in the same slot; only the deepest step has children in slot 1).  Same recurrences as msg_build.
   auto merge_level = [&](int l, auto two_slots) {
@@ -223,7 +216,7 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
     if constexpr (kTwo) { const int nl1 = __shfl(n[1], la, 64), nr1 = __shfl(n[1], lb, 64); nl = sl ? nl1 : nl; nr = sl ? nr1 : nr; }
     const bool livep = zz < (1 << l);
     const double nt = (double)(nl + nr);
-    const double inv_nt = nl + nr > 0 ? rcp64(nt) : 0.0;
+    const double inv_nt = nl + nr > 0 ? fast_rcp(nt) : 0.0;
     double pm[D], pM[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -253,7 +246,7 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const double v = M2[0][d] * inv_nt + h2[d];
-        T->mean[d][idn] = (float)m[0][d]; T->var[d][idn] = (float)v; T->ivar[d][idn] = (float)rcp64(v);
+        T->mean[d][idn] = (float)m[0][d]; T->var[d][idn] = (float)v; T->ivar[d][idn] = (float)fast_rcp(v);
         lg += fast_log(v);   // (fdlibm kernel, < 1 ulp: the library call is twice the instructions)
       }
       T->cz[idn] = (float)(fast_log(nt * (1.0 / (double)N)) - 0.5 * lg);
@@ -535,7 +528,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
         prec += iv; num += iv * dev;
       }
       const double xi = normal();
-      x[d] = mu0 + num / prec + xi / fast_sqrt(prec);
+      x[d] = mu0 + num * fast_rcp(prec) + xi * fast_rsqrt(prec);   // (reciprocals by hardware seed + Newton: an ulp from the oracle's divisions)
     }
     if constexpr (D == 6) {
       double B[4] = {1.0, 0.0, 0.0, 0.0}, prec[3] = {0.0, 0.0, 0.0}, num[3] = {0.0, 0.0, 0.0};
@@ -564,7 +557,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
       }
       double e[3], E[4];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { const double xi = normal(); e[k] = num[k] / prec[k] + xi / fast_sqrt(prec[k]); }
+      for (int k = 0; k < 3; ++k) { const double xi = normal(); e[k] = num[k] * fast_rcp(prec[k]) + xi * fast_rsqrt(prec[k]); }
       quat_exp(e, E); quat_mul(B, E, xq);
     }
     if (l == L + 1) break;
@@ -630,7 +623,8 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
             if (circ_bit(d)) dev = gwrap(dev);
             prec += iv; num += iv * dev;
           }
-          Mx[d] = mu0 + num / prec - c.ref[d]; Cx[d] = 1.0 / prec;
+          const double ip = fast_rcp(prec);
+          Mx[d] = mu0 + num * ip - c.ref[d]; Cx[d] = ip;
           if (circ_bit(d)) Mx[d] = gwrap(Mx[d]);
         }
         if constexpr (D == 6) {
@@ -650,7 +644,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
           }
           double e[3], E[4], QM[4], r[4];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) { e[k] = num[k] / prec[k]; Cx[3 + k] = 1.0 / prec[k]; }
+          for (int k = 0; k < 3; ++k) { const double ip = fast_rcp(prec[k]); e[k] = num[k] * ip; Cx[3 + k] = ip; }
           quat_exp(e, E); quat_mul(B, E, QM); quat_cmul(c.q0, QM, r); quat_log(r, Mx + 3);
         }
         float mx[D], cx[D];
