@@ -135,7 +135,7 @@ __device__ __forceinline__ double fast_atan2(double y, double x) {
   const double mx = fmax(ax, ay), mn = fmin(ax, ay);
   const bool red = mn > 0.41421356237309503 * mx;
   const double num = red ? mn - mx : mn, den = red ? mn + mx : mx;
-  const double b = den > 0.0 ? num / den : 0.0;
+  const double b = den > 0.0 ? num / den : 0.0;   // (reciprocal seed + Newton instead of the IEEE division: no measurable gain in the bearing-range kernels)
   const double z = b * b, w = z * z;
   const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02),
                                                   6.66107313738753120669e-02), 9.09088713343650656196e-02),
