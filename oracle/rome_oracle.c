@@ -1515,9 +1515,8 @@ static int msg_node(const msg_tree* T, int l, int z, double* mean, double* var, 
 }
 static inline uint32_t msg_xorshift(uint32_t r) { r ^= r << 13; r ^= r >> 17; r ^= r << 5; return r; }
 /* Candidate arithmetic: IEEE single precision, every operation written out (this file is compiled with -ffp-contract=off; fmaf is
- * the correctly rounded fused operation).  The device evaluates two candidates per lane with packed instructions: same values --
- * except msg_exp32 / msg_ln32, which its shipped build takes from the hardware transcendentals within an ulp of the polynomials below
- * (these stay the definition; a draw can differ only when a uniform lands within an ulp of a cumulative boundary). */
+ * the correctly rounded fused operation).  The device evaluates two candidates per lane with packed instructions: same values
+ * (its opt-in ROME_GIBBS_HWTRANS build takes msg_exp32 / msg_ln32 from the hardware transcendentals, within an ulp of these). */
 #define MSG_ABSENT (-3.0e38f)   /* log p of "no candidate"; also the initial running maximum */
 static inline float msg_f32_from_bits(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline uint32_t msg_bits_from_f32(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
@@ -1558,8 +1557,10 @@ static inline float msg_wrap32(float e) {
   e = fmaf(k, -6.28125f, e);
   return fmaf(k, -1.9353072e-3f, e);
 }
-/* one-pass categorical draw over candidate PAIRS (A, B): running maximum M of log p, total T of exp(log p - M); a candidate
- * replaces the selection when float(r | 255)·T < a·2^32 (u = its top 24 bits, never 0), r the next state of a xorshift32 stream */
+/* one-pass categorical draw over candidate PAIRS (A, B): running maximum M of log p, total T of exp(log p - M).  ONE uniform per pair
+ * (u = the top 24 bits of the next state r of a xorshift32 stream, never 0; compared as float(r | 255)·T_B against a·2^32): with T_B the
+ * total including both candidates, B replaces the selection when u T_B < a_B, A when a_B <= u T_B < a_A + a_B, else the selection is
+ * kept -- probabilities a_B / T_B, a_A / T_B, T_0 / T_B, the same as drawing after each candidate in turn. */
 typedef struct { float M, T; uint32_t r; int sel; } msg_res;
 static inline void msg_res_init(msg_res* R, uint32_t seed_word) { R->M = MSG_ABSENT; R->T = 0.0f; R->r = seed_word | 1u; R->sel = 0; }
 static inline void msg_res_pair(msg_res* R, int zA, int zB, float lpA, float lpB) {
@@ -1568,9 +1569,9 @@ static inline void msg_res_pair(msg_res* R, int zA, int zB, float lpA, float lpB
   const float aA = msg_exp32(lpA - Mn), aB = msg_exp32(lpB - Mn);
   const float TA = T0 + aA, TB = TA + aB;
   R->r = msg_xorshift(R->r);
-  if ((float)(R->r | 0xFFu) * TA < aA * 4294967296.0f) R->sel = zA;
-  R->r = msg_xorshift(R->r);
-  if ((float)(R->r | 0xFFu) * TB < aB * 4294967296.0f) R->sel = zB;
+  const float lhs = (float)(R->r | 0xFFu) * TB, sAB = aA + aB;
+  if (lhs < sAB * 4294967296.0f) R->sel = zA;
+  if (lhs < aB * 4294967296.0f) R->sel = zB;
   R->T = TB; R->M = Mn;
 }
 /* Σ_d s_d / v_d over a group of gd <= 3 coordinates with one division: (Σ_d s_d Π_{e≠d} v_e) / Π_d v_d; *pv = Π_d v_d */

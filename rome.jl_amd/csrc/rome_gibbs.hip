@@ -275,8 +275,8 @@ __global__ void __launch_bounds__(256) k_gibbs_trees(const GibbsArgs a) {
 }
 
 // ---- candidate arithmetic: IEEE single precision, every operation spelled out (explicit fma, contraction off), so that the
-// oracle (msg_exp32 / msg_ln32 / msg_wrap32 / msg_res_pair in oracle/rome_oracle.c) reproduces it bit for bit -- except exp and log,
-// which the shipped build takes from the hardware within an ulp of the specification (ROME_GIBBS_HWTRANS below).  Written on
+// oracle (msg_exp32 / msg_ln32 / msg_wrap32 / msg_res_pair in oracle/rome_oracle.c) reproduces it bit for bit (an opt-in build takes exp and log from the
+// hardware instead: ROME_GIBBS_HWTRANS below).  Written on
 // f32x2 = two CANDIDATES of the same lane (nodes z, z + 1: their statistics are one 8-byte LDS broadcast), which the compiler maps to
 // the packed v_pk_{add,mul,fma}_f32 instructions: half the VALU issue slots of the one-candidate-at-a-time form.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -286,13 +286,15 @@ constexpr float kAbsent = -3.0e38f;   // log p of "no candidate" (odd N at the l
 
 __device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
 // exp(max(x, -80)), x <= 0 (never 0: e^-80 = 1.8e-35 is below every acceptance threshold and every total); k = rint(x log2 e), Cody-Waite r = x - k ln2, Cephes expf polynomial, scaled by 2^k on the exponent field
-// ROME_GIBBS_HWTRANS (default 1): exp and log of the candidate arithmetic on the hardware transcendentals (v_exp_f32 / v_log_f32,
-// within 1 ulp of the specified polynomials below, which the oracle evaluates: msg_exp32 / msg_ln32).  A categorical draw can then
-// differ from the oracle's only when a uniform lands within an ulp of a cumulative boundary -- measured: 50 784 of 50 784 product
-// samples identical (scripts/gibbs_identical.py) -- and the sampling kernel runs 13 % faster (1.23 -> 1.05 ms per Manhattan sweep:
-// the two polynomial exponentials were 65 of ~300 issue cycles of a candidate pair).  0 builds the bit-specified polynomials.
+// ROME_GIBBS_HWTRANS (default 0; 1 is an opt-in build): exp and log of the candidate arithmetic on the hardware transcendentals
+// (v_exp_f32 / v_log_f32, within 1 ulp of the specified polynomials below, which the oracle evaluates: msg_exp32 / msg_ln32).  13 %
+// faster (1.20 -> 1.02 ms per Manhattan sweep: the two polynomial exponentials are 65 of ~300 issue cycles of a candidate pair) and
+// 50 784 of 50 784 product samples of the unit problems identical (scripts/gibbs_identical.py) -- but a categorical draw differs
+// whenever a uniform lands within an ulp of a cumulative boundary, and over the 8e9 draws of two Manhattan-3500 solve iterations
+// that happens: one of the 3500 pose means moved by 1.7e-3 against the oracle loop (north_star's bar is 1e-3).  Parity first: the
+// shipped build evaluates the specified polynomials, bit for bit the oracle's.
 #ifndef ROME_GIBBS_HWTRANS
-#define ROME_GIBBS_HWTRANS 1
+#define ROME_GIBBS_HWTRANS 0
 #endif
 __device__ __forceinline__ f32x2 exp32_neg(f32x2 x) {
 #pragma clang fp contract(off)
@@ -345,8 +347,9 @@ __device__ __forceinline__ f32x2 wrap32(f32x2 e) {
   e = __builtin_elementwise_fma(k, splat(-6.28125f), e);
   return __builtin_elementwise_fma(k, splat(-1.9353072e-3f), e);
 }
-// one-pass categorical draw over candidate PAIRS: running maximum M of log p, total T of exp(log p - M); candidate z replaces the
-// selection when u T < a_z, u the top 24 bits of a xorshift32 stream (written as float(r | 255)·T < a·2^32: both products of the spec)
+// one-pass categorical draw over candidate PAIRS (A, B): running maximum M of log p, total T of exp(log p - M); ONE uniform u per pair
+// (top 24 bits of a xorshift32 stream, written as float(r | 255)·T_B against a·2^32): B replaces the selection when u T_B < a_B, A when
+// a_B <= u T_B < a_A + a_B -- the probabilities of drawing after each candidate in turn, with half the generator steps (msg_res_pair)
 struct Reservoir {
   float M, T; uint32_t r; int sel;
   __device__ __forceinline__ void init(uint32_t w) { M = kAbsent; T = 0.0f; r = w | 1u; sel = 0; }
@@ -357,12 +360,10 @@ struct Reservoir {
     const f32x2 a = exp32_neg(lp - Mn);
     const float TA = T + a.x, TB = TA + a.y;
     r ^= r << 13; r ^= r >> 17; r ^= r << 5;
-    const uint32_t rA = r;
-    r ^= r << 13; r ^= r >> 17; r ^= r << 5;
-    const f32x2 lhs = f32x2{(float)(rA | 0xFFu), (float)(r | 0xFFu)} * f32x2{TA, TB};   // u in (0, 1]: 24 bits, never 0
-    const f32x2 rhs = a * 4294967296.0f;
-    sel = lhs.x < rhs.x ? zA : sel;
-    sel = lhs.y < rhs.y ? zB : sel;
+    const float lhs = (float)(r | 0xFFu) * TB;   // u in (0, 1]: 24 bits, never 0
+    const f32x2 rhs = f32x2{a.x + a.y, a.y} * 4294967296.0f;
+    sel = lhs < rhs.x ? zA : sel;
+    sel = lhs < rhs.y ? zB : sel;
     T = TB; M = Mn;
   }
 };
