@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define ROME_MI355_VERSION 110 /* 0.1.1: ROME_SOLVER_GAUSS_NEWTON, rome_conv_dev.mirror_map, rome_clique_upsolve */
+#define ROME_MI355_VERSION 120 /* 0.1.2: multihypo / nullhypo / stream-id columns in rome_clique_host; rome_store + rome_upsolve_plan
+                                 * (device-resident clique up-solves: beliefs stay in HBM across frontiers) */
 
 enum {
   ROME_OK = 0,
@@ -235,6 +236,25 @@ typedef struct rome_clique_host {
    * cov [F][4]; proposals [rows][2][N]; Philox family offset 7 << 28.  In rome_clique_upsolve their proposals follow the
    * bearing-range -> landmark rows in the product of their landmark. */
   int32_t n_prpt2, f_prpt2; const int32_t* prpt2_rows4; const double* prpt2_mu; const double* prpt2_cov; double* out_prpt2;
+  /* optional per-row hypothesis columns (NULL = none), as IIF attaches them per factor: `multihypo=[1, w, 1-w]`
+   * (addFactor!(fg, [:x0;:l1;:l2], p2br, multihypo=[1.0;0.5;0.5]), test/testMultimodalRangeBearing.jl:53,
+   * examples/MultimodalRangeBearing.jl:33) and `nullhypo=p` (test/testPose3Pose3NH.jl:118); IIF resolves both inside the same
+   * proposalbeliefs! / upGibbsCliqueDensity loop (computeAcrossHypothesis!).
+   *   <fam>_alt [rows]      index of the OTHER candidate of the factor's second variable, -1 = ordinary row: for rows that solve the
+   *                         first variable (p2p2 dir 1, br1) it indexes the belief array of the FIXED side (the fixed particle is drawn
+   *                         per particle from (fixed_var with probability hypo_w, alt)); for rows that solve a candidate (p2p2 dir 0,
+   *                         br0) the array of the TARGET side (particles drawn for the other candidate keep their value + spreadNH entropy)
+   *   <fam>_hypo_w [rows]   probability that the row's own candidate is the one the measurement belongs to (required with _alt)
+   *   <fam>_nullhypo [rows] probability that the factor does not apply to a particle (0 = ordinary)                              */
+  const int32_t* p2p2_alt; const double* p2p2_hypo_w; const double* p2p2_nullhypo;
+  const int32_t* br1_alt;  const double* br1_hypo_w;  const double* br1_nullhypo;
+  const int32_t* br0_alt;  const double* br0_hypo_w;  const double* br0_nullhypo;
+  const double* p3p3_nullhypo;
+  /* optional per-row Philox stream ids (NULL = the row's index in its table): row r of a family draws stream
+   * opts->stream_offset + family offset + <fam>_stream[r] (0 <= id < 2^28).  A clique / frontier that is a SUBSET of a larger table
+   * (one rank's share of a frontier, a clique of a graph-wide table) then draws exactly what the whole table draws: results do not
+   * depend on how the work was partitioned. */
+  const int32_t* p2p2_stream; const int32_t* br1_stream; const int32_t* br0_stream; const int32_t* p3p3_stream; const int32_t* prpt2_stream;
 } rome_clique_host;
 int rome_clique_proposals(rome_ctx*, const rome_opts*, const rome_clique_host*);
 
@@ -282,8 +302,59 @@ typedef struct rome_clique_upsolve_host {
    * every clique, so that every launch covers all cliques of the frontier ("cliques on the current Bayes-tree frontier
    * are independent").  NULL: groups follow `schedule` (one variable per group / one group). */
   const int32_t* up_group;
+  /* optional [n_up]: Philox stream id of the product of updated variable k (NULL: its position among the updated variables of its
+   * type): the product draws stream_offset + (it << 32) + (3, 4, 6 << 28) + up_stream[k] -- e.g. the variable's global id, so that a
+   * frontier dealt to several ranks draws what the single call draws. */
+  const int32_t* up_stream;
+  /* optional [n_up], rome_upsolve_plan only: block of the plan's mirror buffer (rome_upsolve_plan_run `mirror_out`) that the new belief
+   * of updated variable k is ALSO written to by the product kernel itself, -1 = none: new frontal beliefs land straight in an RCCL send
+   * buffer (no gather kernel, no host copy). */
+  const int32_t* up_mirror;
 } rome_clique_upsolve_host;
 int rome_clique_upsolve(rome_ctx*, const rome_opts*, const rome_clique_upsolve_host*);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident clique up-solves: a belief STORE that lives in HBM across calls, and up-solve PLANS over it.
+ * rome_clique_upsolve moves every belief of the clique over PCIe on every call; a tree solve visits thousands of cliques and
+ * a frontier of independent cliques per tree level, and the separator beliefs one frontier writes are what the
+ * next one reads.  With a store the beliefs of the whole graph cross PCIe ONCE; a plan holds the validated row tables of one
+ * clique / frontier on the device, and running it issues only kernel launches on the context's stream (no copy, no
+ * synchronisation): gibbs_iters x {one convolution launch per factor family -> manikde! bandwidths -> multiscale Gibbs product
+ * writing the new beliefs IN PLACE into the store (and, optionally, into an RCCL send buffer)}.
+ *   rome_store_create      device blocks [n][dim][N] per variable type (SoA), zero-initialised
+ *   rome_store_wrap        the same over caller-owned device memory (e.g. a torch tensor): NULL for an empty type
+ *   rome_store_upload / _download   `count` beliefs of one type from `first`, host layout per `layout` (ROME_LAYOUT_*)
+ *   rome_store_ptr         device pointer of a type's blocks (for collectives that land in the store)
+ * Replaces: the setValKDE! / getBelief traffic around IIF upGibbsCliqueDensity inside solveTree!
+ * (src/services/AdditionalUtils.jl:18-19, examples/ManhattanDatasetBatch.jl:43).                                               */
+typedef struct rome_store rome_store;
+int  rome_store_create(rome_ctx*, int32_t n_particles, int32_t n_pose2, int32_t n_point2, int32_t n_pose3, rome_store** out);
+int  rome_store_wrap(rome_ctx*, int32_t n_particles, int32_t n_pose2, double* dev_pose2, int32_t n_point2, double* dev_point2,
+                     int32_t n_pose3, double* dev_pose3, rome_store** out);
+void rome_store_destroy(rome_store*);
+int  rome_store_upload(rome_store*, int32_t layout, int32_t type, int32_t first, int32_t count, const double* host);
+int  rome_store_download(rome_store*, int32_t layout, int32_t type, int32_t first, int32_t count, double* host);
+int  rome_store_ptr(rome_store*, int32_t type, void** dev, int32_t* n_blocks);
+/* A plan = one rome_clique_upsolve_host description bound to a store: `clique.bel_*` and `clique.out_*` are ignored (the variable
+ * indices of the row tables, of up_var and of the *_alt columns address the STORE; clique.n_* must not exceed the store's counts),
+ * msg_* densities are copied at creation.  new_* / bw_* may be NULL: nothing is downloaded and rome_upsolve_plan_run returns without
+ * synchronising (the device-resident mode); when given, the new beliefs / manikde! bandwidths are downloaded at the end of every
+ * run.  opts at creation fix n_particles and the host layout of new_* / msg_*; opts at run time give solver, seed, stream_offset,
+ * inflation etc. (n_particles must match).
+ * rome_upsolve_plan_run(plan, opts, mirror_out, mirror_stride): mirror_out = DEVICE buffer the up_mirror blocks are written to, block
+ * m at mirror_out + m * mirror_stride doubles (stride >= dim * N; 0 = 6 N); NULL when the plan has no mirrors. */
+typedef struct rome_upsolve_plan rome_upsolve_plan;
+int  rome_upsolve_plan_create(rome_ctx*, rome_store*, const rome_opts*, const rome_clique_upsolve_host*, rome_upsolve_plan** out);
+int  rome_upsolve_plan_run(rome_upsolve_plan*, const rome_opts*, double* mirror_out, int64_t mirror_stride);
+void rome_upsolve_plan_destroy(rome_upsolve_plan*);
+/* A scatter plan: the receive side of a frontier exchange.  After an all-gather of the ranks' send buffers, block src_block[k] of the
+ * receive buffer (units of `stride` doubles, 0 = 6 N) is the new belief of variable (type[k], var[k]) of the store; the lists are
+ * uploaded once, a run is ONE launch on the context's stream. */
+typedef struct rome_scatter_plan rome_scatter_plan;
+int  rome_scatter_plan_create(rome_ctx*, rome_store*, int32_t n, const int32_t* type, const int32_t* var, const int32_t* src_block,
+                              int64_t stride, rome_scatter_plan** out);
+int  rome_scatter_plan_run(rome_scatter_plan*, const double* src_dev);
+void rome_scatter_plan_destroy(rome_scatter_plan*);
 
 /* ---------------------------------------------------------------------------------------------
  * Graph-indexed DEVICE-pointer variant: beliefs stay resident in HBM (SoA blocks [var][dim][N]),

@@ -99,6 +99,18 @@ SIGNATURES = {
     "rome_product_dev": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rome_clique_proposals": (C.c_int, [_CTX, _PO, C.c_void_p]),
     "rome_clique_upsolve": (C.c_int, [_CTX, _PO, C.c_void_p]),
+    "rome_store_create": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "rome_store_wrap": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rome_store_destroy": (None, [C.c_void_p]),
+    "rome_store_upload": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _PD]),
+    "rome_store_download": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _PD]),
+    "rome_store_ptr": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), _PI]),
+    "rome_upsolve_plan_create": (C.c_int, [_CTX, C.c_void_p, _PO, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rome_upsolve_plan_run": (C.c_int, [C.c_void_p, _PO, C.c_void_p, C.c_int64]),
+    "rome_upsolve_plan_destroy": (None, [C.c_void_p]),
+    "rome_scatter_plan_create": (C.c_int, [_CTX, C.c_void_p, C.c_int32, _PI, _PI, _PI, C.c_int64, C.POINTER(C.c_void_p)]),
+    "rome_scatter_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rome_scatter_plan_destroy": (None, [C.c_void_p]),
     "rome_product_gibbs_dev": (C.c_int, [_CTX, _PO, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                          C.c_void_p, C.c_uint32, C.c_int32, C.c_int32]),
     "rome_dev_alloc": (C.c_int, [_CTX, C.c_uint64, C.POINTER(C.c_void_p)]),

@@ -14,7 +14,7 @@ struct rome_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipError_t last_hip = hipSuccess;
-  static constexpr int kBufs = 11;
+  static constexpr int kBufs = 13;   // 9 clique arena, 10 Gibbs trees, 11 / 12 temporary store / plan of the one-shot up-solve
   void* dbuf[kBufs] = {nullptr};
   size_t dcap[kBufs] = {0};
   // pinned host staging of the host-pointer entry points (layout conversion writes straight into DMA-able memory)
@@ -597,38 +597,133 @@ int stage_beliefs(rome_ctx* c, const rome_opts* o, int n, int dim, const double*
   *used += (cnt * sizeof(double) + 255) & ~(size_t)255;
   return ROME_OK;
 }
+// SoA device blocks -> host blocks in the caller's layout (synchronises)
+int fetch_beliefs(rome_ctx* c, int layout, int n, int dim, int N, const double* dev, double* host) {
+  if (n == 0) return ROME_OK;
+  const size_t cnt = (size_t)n * dim * N;
+  if (layout == ROME_LAYOUT_SOA) {
+    ROME_HIP(c, hipMemcpyAsync(host, dev, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+    ROME_HIP(c, hipStreamSynchronize(c->stream));
+    return ROME_OK;
+  }
+  std::vector<double> soa(cnt);
+  ROME_HIP(c, hipMemcpyAsync(soa.data(), dev, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+  ROME_HIP(c, hipStreamSynchronize(c->stream));
+  if (layout == ROME_LAYOUT_AOS || dim == 2) { from_soa(soa.data(), n, N, dim, ROME_LAYOUT_AOS, host); return ROME_OK; }
+  std::vector<double> aos(cnt);
+  from_soa(soa.data(), n, N, dim, ROME_LAYOUT_AOS, aos.data());
+  return convert_rows(c, dim, (size_t)n * N, aos.data(), host, false);
+}
 // host vectors feed / receive asynchronous copies: whatever way a clique entry returns (an error in the middle included), the stream is
 // drained before those vectors are destroyed (declare the guard AFTER them)
 struct DrainOnExit { hipStream_t s; ~DrainOnExit() { (void)hipStreamSynchronize(s); } };
+
+// the five row families of a rome_clique_host.  kind: 0 Pose2Pose2 (+ PriorPose2 rows), 1 bearing-range, 2 Pose3Pose3 (+ PriorPose3 rows),
+// 3 PriorPoint2 sampler; variable types: 0 Pose2, 1 Point2, 2 Pose3; valt = type of the array an `alt` entry indexes (-1: no multihypo);
+// base = first row of the family in the proposal buffer of its target type (rome_clique_upsolve)
+struct Fam {
+  int n; const int32_t* rows4; int F; const double* mu; const double* spread; int dz, nL, dfx, dt; double* out; int vf, vt; int dir_all;
+  uint64_t off; int kind; int base;
+  const int32_t* alt; const double* hw; const double* nh; const int32_t* sid; int valt;
+};
+constexpr int NF = 5;
+void make_fams(const rome_clique_host* q, Fam (&fam)[NF]) {
+  const Fam f[NF] = {
+    {q->n_p2p2, q->p2p2_rows4, q->f_p2p2, q->p2p2_mu, q->p2p2_cov, 3, 6, 3, 3, q->out_p2p2, 0, 0, 0, 0ull, 0, 0,
+     q->p2p2_alt, q->p2p2_hypo_w, q->p2p2_nullhypo, q->p2p2_stream, 0},
+    {q->n_br1, q->br1_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 2, 3, q->out_br1, 1, 0, 1, 1ull << 28, 1, q->n_p2p2,
+     q->br1_alt, q->br1_hypo_w, q->br1_nullhypo, q->br1_stream, 1},
+    {q->n_br0, q->br0_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 3, 2, q->out_br0, 0, 1, 0, 2ull << 28, 1, 0,
+     q->br0_alt, q->br0_hypo_w, q->br0_nullhypo, q->br0_stream, 1},
+    {q->n_p3p3, q->p3p3_rows4, q->f_p3p3, q->p3p3_mu, q->p3p3_cov, 6, 21, 6, 6, q->out_p3p3, 2, 2, 0, 5ull << 28, 2, 0,
+     nullptr, nullptr, q->p3p3_nullhypo, q->p3p3_stream, -1},
+    {q->n_prpt2, q->prpt2_rows4, q->f_prpt2, q->prpt2_mu, q->prpt2_cov, 2, 3, 2, 2, q->out_prpt2, 1, 1, 0, 7ull << 28, 3, q->n_br0,
+     nullptr, nullptr, nullptr, q->prpt2_stream, -1}};
+  for (int k = 0; k < NF; ++k) fam[k] = f[k];
+}
+// table entries must address the arrays they index (nv = variables per type); hypothesis / stream columns in range
+int check_fam_rows(const Fam& f, const int (&nv)[3]) {
+  if (f.n < 0 || f.F < 0 || (f.n > 0 && (!f.rows4 || !f.mu || !f.spread || f.F == 0))) return ROME_ERR_INVALID_ARG;
+  if (f.alt && !f.hw) return ROME_ERR_INVALID_ARG;
+  for (int r = 0; r < f.n; ++r) {
+    const int32_t* e = f.rows4 + 4 * (size_t)r;
+    if (e[0] < 0 || e[0] >= f.F || e[2] < 0 || e[2] >= nv[f.vf] || e[3] < 0 || e[3] >= nv[f.vt] || e[1] < 0 || e[1] > 2) return ROME_ERR_INVALID_ARG;
+    if (f.alt && f.alt[r] >= 0) {
+      if (f.alt[r] >= nv[f.valt] || !(f.hw[r] >= 0.0 && f.hw[r] <= 1.0)) return ROME_ERR_INVALID_ARG;
+    } else if (f.alt && f.alt[r] < -1) return ROME_ERR_INVALID_ARG;
+    if (f.nh && !(f.nh[r] >= 0.0 && f.nh[r] <= 1.0)) return ROME_ERR_INVALID_ARG;
+    if (f.sid && (f.sid[r] < 0 || f.sid[r] >= (1 << 28))) return ROME_ERR_INVALID_ARG;
+  }
+  return ROME_OK;
+}
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+// bytes of a family's device tables (rows4, mu, L, the optional columns)
+size_t fam_table_bytes(const Fam& f) {
+  return al256((size_t)f.n * 16) + al256((size_t)f.F * f.dz * 8) + al256((size_t)f.F * f.nL * 8) + 256 +
+         (f.alt ? al256((size_t)f.n * 4) + al256((size_t)f.n * 8) : 0) + (f.nh ? al256((size_t)f.n * 8) : 0) + (f.sid ? al256((size_t)f.n * 4) : 0);
+}
+struct FamDev { const int32_t* rows = nullptr; const double* mu = nullptr; const double* L = nullptr; const int32_t* alt = nullptr;
+                const double* hw = nullptr; const double* nh = nullptr; const int32_t* sid = nullptr; };
+// uploads a family's tables into `arena` (asynchronously: `Ls` must outlive the stream work); MvNormal factors get their packed Cholesky
+int upload_fam(rome_ctx* c, const Fam& f, unsigned char* arena, size_t* used, std::vector<double>& Ls, FamDev& d) {
+  d = FamDev{};
+  if (f.n == 0) return ROME_OK;
+  hipStream_t s = c->stream;
+  const double* Lsrc = f.spread;
+  int rc;
+  if (f.kind != 1) {   // MvNormal factors: packed lower Cholesky of every covariance
+    Ls.resize((size_t)f.F * f.nL);
+    if ((rc = rome_cholesky_lower(f.dz, f.F, f.spread, Ls.data()))) return rc;
+    Lsrc = Ls.data();
+  }
+  auto put = [&](const void* src, size_t bytes) -> void* {
+    void* dst = arena + *used;
+    if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+    *used += al256(bytes);
+    return dst;
+  };
+#define ROME_PUT(dst, T, src, bytes) do { void* _p = put((src), (bytes)); if (!_p) return hip_fail(c, hipGetLastError()); (dst) = (const T*)_p; } while (0)
+  ROME_PUT(d.rows, int32_t, f.rows4, (size_t)f.n * 16);
+  ROME_PUT(d.mu, double, f.mu, (size_t)f.F * f.dz * 8);
+  ROME_PUT(d.L, double, Lsrc, (size_t)f.F * f.nL * 8);
+  if (f.alt) { ROME_PUT(d.alt, int32_t, f.alt, (size_t)f.n * 4); ROME_PUT(d.hw, double, f.hw, (size_t)f.n * 8); }
+  if (f.nh) ROME_PUT(d.nh, double, f.nh, (size_t)f.n * 8);
+  if (f.sid) ROME_PUT(d.sid, int32_t, f.sid, (size_t)f.n * 4);
+#undef ROME_PUT
+  return ROME_OK;
+}
+// rows [lo, hi) of a family: one convolution launch into `out` (the block of row `lo`)
+hipError_t launch_fam(const Fam& f, const FamDev& d, const rome_opts* o, uint64_t stream_base, int lo, int hi, const double* bel_fixed,
+                      const double* bel_target, double* out, hipStream_t s) {
+  rome::ConvArgs a;
+  rome_opts of = *o;
+  of.stream_offset = stream_base + f.off + (d.sid ? 0ull : (uint64_t)lo);   // family offsets of the device graph (DeviceGraph.STREAM_*)
+  fill_args(a, &of);
+  a.n_conv = hi - lo; a.dir_all = f.dir_all; a.rows4 = d.rows + 4 * (size_t)lo;
+  a.mu = d.mu; a.L = d.L;
+  a.bel_fixed = bel_fixed; a.bel_target = bel_target; a.out = out;
+  a.alt_var = d.alt ? d.alt + lo : nullptr; a.hypo_w = d.alt ? d.hw + lo : nullptr;
+  a.nullhypo = d.nh ? d.nh + lo : nullptr;
+  a.row_stream = d.sid ? d.sid + lo : nullptr;
+  return f.kind == 0 ? rome::launch_conv_pose2pose2(a, o->solver, s) : (f.kind == 1 ? rome::launch_conv_bearingrange(a, o->solver, s)
+                     : (f.kind == 2 ? rome::launch_conv_pose3pose3(a, o->solver, s) : rome::launch_sample_priorpoint2(a, s)));
+}
 }  // namespace
 
 int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_host* q) {
   int rc = check_opts(o); if (rc) return rc;
   if (!c || !q) return ROME_ERR_INVALID_ARG;
   const int N = o->n_particles;
-  struct Fam { int n; const int32_t* rows4; int F; const double* mu; const double* spread; int dz, nL, dfx, dt; double* out; int vf, vt; int dir_all; uint64_t off; int kind; };
-  // variable types: 0 Pose2, 1 Point2, 2 Pose3
-  constexpr int NF = 5;   // kind: 0 Pose2Pose2 (+ PriorPose2 rows), 1 bearing-range, 2 Pose3Pose3 (+ PriorPose3 rows), 3 PriorPoint2 sampler
-  Fam fam[NF] = {
-    {q->n_p2p2, q->p2p2_rows4, q->f_p2p2, q->p2p2_mu, q->p2p2_cov, 3, 6, 3, 3, q->out_p2p2, 0, 0, 0, 0ull, 0},
-    {q->n_br1, q->br1_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 2, 3, q->out_br1, 1, 0, 1, 1ull << 28, 1},
-    {q->n_br0, q->br0_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 3, 2, q->out_br0, 0, 1, 0, 2ull << 28, 1},
-    {q->n_p3p3, q->p3p3_rows4, q->f_p3p3, q->p3p3_mu, q->p3p3_cov, 6, 21, 6, 6, q->out_p3p3, 2, 2, 0, 5ull << 28, 2},
-    {q->n_prpt2, q->prpt2_rows4, q->f_prpt2, q->prpt2_mu, q->prpt2_cov, 2, 3, 2, 2, q->out_prpt2, 1, 1, 0, 7ull << 28, 3}};
+  Fam fam[NF]; make_fams(q, fam);
   const int nv[3] = {q->n_pose2, q->n_point2, q->n_pose3};
   const int vdim[3] = {3, 2, 6};
   const double* vhost[3] = {q->bel_pose2, q->bel_point2, q->bel_pose3};
   size_t need = 0;
-  for (int t = 0; t < 3; ++t) { if (nv[t] < 0 || (nv[t] > 0 && !vhost[t])) return ROME_ERR_INVALID_ARG; need += (((size_t)nv[t] * vdim[t] * N * 8) + 255) & ~(size_t)255; }
+  for (int t = 0; t < 3; ++t) { if (nv[t] < 0 || (nv[t] > 0 && !vhost[t])) return ROME_ERR_INVALID_ARG; need += al256((size_t)nv[t] * vdim[t] * N * 8); }
   for (const Fam& f : fam) {
-    if (f.n < 0 || f.F < 0 || (f.n > 0 && (!f.rows4 || !f.mu || !f.spread || !f.out || f.F == 0))) return ROME_ERR_INVALID_ARG;
-    for (int r = 0; r < f.n; ++r) {   // table entries must address the clique's own arrays
-      const int32_t* e = f.rows4 + 4 * (size_t)r;
-      if (e[0] < 0 || e[0] >= f.F || e[2] < 0 || e[2] >= nv[f.vf] || e[3] < 0 || e[3] >= nv[f.vt] || e[1] < 0 || e[1] > 2) return ROME_ERR_INVALID_ARG;
-    }
-    need += (((size_t)f.n * f.dt * N * 8) + 255) & ~(size_t)255;             // proposals
-    need += (((size_t)f.n * 16) + 255) & ~(size_t)255;                       // rows4
-    need += (((size_t)f.F * (f.dz + f.nL) * 8) + 511) & ~(size_t)255;        // mu + L
+    if ((rc = check_fam_rows(f, nv))) return rc;
+    if (f.n > 0 && !f.out) return ROME_ERR_INVALID_ARG;
+    need += al256((size_t)f.n * f.dt * N * 8) + fam_table_bytes(f);
   }
   ROME_BIND(c);
   void* arena_v = nullptr;
@@ -646,33 +741,11 @@ int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_hos
   for (int k = 0; k < NF; ++k) {
     const Fam& f = fam[k];
     if (f.n == 0) continue;
-    const double* Lsrc = f.spread;
-    if (f.kind != 1) {   // MvNormal factors: packed lower Cholesky of every covariance
-      Ls[k].resize((size_t)f.F * f.nL);
-      if ((rc = rome_cholesky_lower(f.dz, f.F, f.spread, Ls[k].data()))) return rc;
-      Lsrc = Ls[k].data();
-    }
-    auto put = [&](const void* src, size_t bytes, void** dst) -> int {
-      *dst = arena + used;
-      ROME_HIP(c, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
-      used += (bytes + 255) & ~(size_t)255;
-      return ROME_OK;
-    };
-    void *d_rows, *d_mu, *d_L;
-    if ((rc = put(f.rows4, (size_t)f.n * 16, &d_rows))) return rc;
-    if ((rc = put(f.mu, (size_t)f.F * f.dz * 8, &d_mu))) return rc;
-    if ((rc = put(Lsrc, (size_t)f.F * f.nL * 8, &d_L))) return rc;
+    FamDev d;
+    if ((rc = upload_fam(c, f, arena, &used, Ls[k], d))) return rc;
     dout[k] = (double*)(arena + used);
-    used += (((size_t)f.n * f.dt * N * 8) + 255) & ~(size_t)255;
-    rome::ConvArgs a;
-    rome_opts of = *o; of.stream_offset = o->stream_offset + f.off;   // family offsets of the device graph (DeviceGraph.STREAM_*)
-    fill_args(a, &of);
-    a.n_conv = f.n; a.dir_all = f.dir_all; a.rows4 = (const int32_t*)d_rows;
-    a.mu = (const double*)d_mu; a.L = (const double*)d_L;
-    a.bel_fixed = (const double*)dbel[f.vf]; a.bel_target = (const double*)dbel[f.vt]; a.out = dout[k];
-    hipError_t e = f.kind == 0 ? rome::launch_conv_pose2pose2(a, o->solver, s) : (f.kind == 1 ? rome::launch_conv_bearingrange(a, o->solver, s)
-                               : (f.kind == 2 ? rome::launch_conv_pose3pose3(a, o->solver, s) : rome::launch_sample_priorpoint2(a, s)));
-    ROME_HIP(c, e);
+    used += al256((size_t)f.n * f.dt * N * 8);
+    ROME_HIP(c, launch_fam(f, d, o, o->stream_offset, 0, f.n, (const double*)dbel[f.vf], (const double*)dbel[f.vt], dout[k], s));
   }
   // proposals back to the host in the caller's layout
   for (int k = 0; k < NF; ++k) {
@@ -697,235 +770,425 @@ int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_hos
   return ROME_OK;
 }
 
-/* ---- clique up-solve: gibbs_iters x {proposals -> manikde! bandwidths -> multiscale Gibbs product -> write-back}, device-resident ---- */
-int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsolve_host* u) {
-  int rc = check_opts(o); if (rc) return rc;
-  if (!c || !u) return ROME_ERR_INVALID_ARG;
+}  // extern "C"
+
+/* ---- belief store + up-solve plans: gibbs_iters x {proposals -> manikde! bandwidths -> multiscale Gibbs product -> in-place write},
+ *      device-resident across calls ---- */
+struct rome_store {
+  rome_ctx* ctx = nullptr;
+  int N = 0;
+  int nv[3] = {0, 0, 0};
+  double* bel[3] = {nullptr, nullptr, nullptr};
+  bool owned = false;
+};
+struct rome_scatter_plan {
+  rome_ctx* ctx = nullptr; rome_store* st = nullptr;
+  int n = 0; int64_t stride = 0;
+  int32_t* d_ent = nullptr;   // [n][4] = (dim, var, src_block, type)
+};
+struct rome_upsolve_plan {
+  rome_ctx* ctx = nullptr; rome_store* st = nullptr;
+  int N = 0, layout = 0, gi = 3, pi = 1, n_up = 0;
+  Fam fam[NF]; FamDev fd[NF];
+  std::vector<int> fam_lo[NF];            // first row of family f that targets update position >= k (rows are grouped in update order)
+  std::vector<int> step_k;                // boundaries of the update steps (ranges of the update list updated together)
+  std::vector<int> up_cnt_before;         // [k][t]: updates of type t among the first k
+  int n_upt[3] = {0, 0, 0}, prop_rows_t[3] = {0, 0, 0}, max_k[3] = {1, 1, 1};
+  double* d_prop[3] = {nullptr, nullptr, nullptr}; double* d_pbw[3] = {nullptr, nullptr, nullptr};
+  int32_t* d_ptr[3] = {nullptr, nullptr, nullptr}; int32_t* d_rws[3] = {nullptr, nullptr, nullptr};
+  int32_t* d_upblock[3] = {nullptr, nullptr, nullptr}; int32_t* d_upstream[3] = {nullptr, nullptr, nullptr};
+  int32_t* d_upmirror[3] = {nullptr, nullptr, nullptr};
+  int32_t* d_gather[3] = {nullptr, nullptr, nullptr};   // (dim, var, position, type) per updated variable: store -> contiguous download buffer
+  double* d_newout[3] = {nullptr, nullptr, nullptr}; double* d_bwout[3] = {nullptr, nullptr, nullptr};
+  double* new_host[3] = {nullptr, nullptr, nullptr}; double* bw_host[3] = {nullptr, nullptr, nullptr};
+  bool has_mirror = false, has_upstream = false;
+  void* arena = nullptr; bool arena_owned = false;
+  size_t tree_need = 8;
+};
+
+namespace {
+const int kVdim[3] = {3, 2, 6};
+const uint32_t kCircBw[3] = {0b100u, 0u, 0b111000u}, kCircProd[3] = {0b100u, 0u, 0u};
+const uint64_t kProdOff[3] = {3ull << 28, 4ull << 28, 6ull << 28};
+
+// builds a plan over `st`; ctx_arena: carve the plan's device memory from the context's arena (the one-shot host entry) instead of an
+// allocation the plan owns
+int plan_build(rome_ctx* c, rome_store* st, const rome_opts* o, const rome_clique_upsolve_host* u, rome_upsolve_plan* P, bool ctx_arena) {
   const rome_clique_host* q = &u->clique;
   const int N = o->n_particles;
-  if (N > 128) return ROME_ERR_UNSUPPORTED_N;   // the multiscale Gibbs product: lane = output sample, two wavefronts per variable
+  if (N > ROME_MAX_PARTICLES_GIBBS) return ROME_ERR_UNSUPPORTED_N;   // the multiscale Gibbs product: lane = output sample, two wavefronts per variable
+  if (N != st->N) return ROME_ERR_INVALID_ARG;
   if (N < 2 || u->n_up < 0 || (u->n_up > 0 && (!u->up_type || !u->up_var))) return ROME_ERR_INVALID_ARG;
   if (u->schedule != ROME_UPSOLVE_SEQUENTIAL && u->schedule != ROME_UPSOLVE_JACOBI) return ROME_ERR_INVALID_ARG;
-  const int gi = u->gibbs_iters > 0 ? u->gibbs_iters : 3, pi = u->product_iters > 0 ? u->product_iters : 1;
-  const int nv[3] = {q->n_pose2, q->n_point2, q->n_pose3};
-  const int vdim[3] = {3, 2, 6};
-  const double* vhost[3] = {q->bel_pose2, q->bel_point2, q->bel_pose3};
-  const uint32_t circ_bw[3] = {0b100u, 0u, 0b111000u}, circ_prod[3] = {0b100u, 0u, 0u};
-  const uint64_t prod_off[3] = {3ull << 28, 4ull << 28, 6ull << 28};
-  for (int t = 0; t < 3; ++t) if (nv[t] < 0 || (nv[t] > 0 && !vhost[t])) return ROME_ERR_INVALID_ARG;
+  P->ctx = c; P->st = st; P->N = N; P->layout = o->layout; P->n_up = u->n_up;
+  P->gi = u->gibbs_iters > 0 ? u->gibbs_iters : 3; P->pi = u->product_iters > 0 ? u->product_iters : 1;
+  const int nv[3] = {st->nv[0], st->nv[1], st->nv[2]};
+  if (q->n_pose2 > nv[0] || q->n_point2 > nv[1] || q->n_pose3 > nv[2]) return ROME_ERR_INVALID_ARG;
   // ---- update list: (type, variable) -> global position k and position within the type's list
   std::vector<int> kpos[3], uplist[3];
   for (int t = 0; t < 3; ++t) kpos[t].assign((size_t)nv[t], -1);
-  std::vector<int> up_cnt_before((size_t)u->n_up * 3 + 3, 0);   // [k][t]: updates of type t among the first k
+  P->up_cnt_before.assign((size_t)u->n_up * 3 + 3, 0);
   for (int k = 0; k < u->n_up; ++k) {
     const int t = u->up_type[k], v = u->up_var[k];
     if (t < 0 || t > 2 || v < 0 || v >= nv[t] || kpos[t][v] >= 0) return ROME_ERR_INVALID_ARG;
+    if (u->up_stream && (u->up_stream[k] < 0 || u->up_stream[k] >= (1 << 28))) return ROME_ERR_INVALID_ARG;
+    if (u->up_mirror && u->up_mirror[k] < -1) return ROME_ERR_INVALID_ARG;
     kpos[t][v] = k;
-    for (int tt = 0; tt < 3; ++tt) up_cnt_before[3 * (size_t)(k + 1) + tt] = up_cnt_before[3 * (size_t)k + tt] + (tt == t ? 1 : 0);
-    uplist[t].push_back(v);
+    for (int tt = 0; tt < 3; ++tt) P->up_cnt_before[3 * (size_t)(k + 1) + tt] = P->up_cnt_before[3 * (size_t)k + tt] + (tt == t ? 1 : 0);
+    uplist[t].push_back(k);
   }
-  // device order of a type's beliefs: updated variables first (in update order), then the others
-  std::vector<int> newidx[3];
-  for (int t = 0; t < 3; ++t) {
-    newidx[t].assign((size_t)nv[t], -1);
-    int nx = 0;
-    for (int v : uplist[t]) newidx[t][v] = nx++;
-    for (int v = 0; v < nv[t]; ++v) if (newidx[t][v] < 0) newidx[t][v] = nx++;
-  }
-  struct Fam { int n; const int32_t* rows4; int F; const double* mu; const double* spread; int dz, nL, dfx, dt; int vf, vt; int dir_all; uint64_t off; int kind; int base; };
-  constexpr int NF = 5;
-  Fam fam[NF] = {
-    {q->n_p2p2, q->p2p2_rows4, q->f_p2p2, q->p2p2_mu, q->p2p2_cov, 3, 6, 3, 3, 0, 0, 0, 0ull, 0, 0},
-    {q->n_br1, q->br1_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 2, 3, 1, 0, 1, 1ull << 28, 1, q->n_p2p2},
-    {q->n_br0, q->br0_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 3, 2, 0, 1, 0, 2ull << 28, 1, 0},
-    {q->n_p3p3, q->p3p3_rows4, q->f_p3p3, q->p3p3_mu, q->p3p3_cov, 6, 21, 6, 6, 2, 2, 0, 5ull << 28, 2, 0},
-    {q->n_prpt2, q->prpt2_rows4, q->f_prpt2, q->prpt2_mu, q->prpt2_cov, 2, 3, 2, 2, 1, 1, 0, 7ull << 28, 3, q->n_br0}};
+  make_fams(q, P->fam);
   const int n_msg[3] = {u->n_msg_pose2, u->n_msg_point2, u->n_msg_pose3};
   const double* msg_host[3] = {u->msg_pose2, u->msg_point2, u->msg_pose3};
   const int32_t* msg_up[3] = {u->msg_pose2_up, u->msg_point2_up, u->msg_pose3_up};
   double* new_host[3] = {u->new_pose2, u->new_point2, u->new_pose3};
   double* bw_host[3] = {u->bw_pose2, u->bw_point2, u->bw_pose3};
-  int prop_rows_t[3] = {0, 0, 0}, msg_base[3];
-  for (const Fam& f : fam) { if (f.n < 0 || f.F < 0 || (f.n > 0 && (!f.rows4 || !f.mu || !f.spread || f.F == 0))) return ROME_ERR_INVALID_ARG; prop_rows_t[f.vt] += f.n; }
+  int msg_base[3];
+  int rc;
+  for (int t = 0; t < 3; ++t) P->prop_rows_t[t] = 0;
+  for (const Fam& f : P->fam) { if ((rc = check_fam_rows(f, nv))) return rc; P->prop_rows_t[f.vt] += f.n; }
   for (int t = 0; t < 3; ++t) {
     if (n_msg[t] < 0 || (n_msg[t] > 0 && (!msg_host[t] || !msg_up[t]))) return ROME_ERR_INVALID_ARG;
-    if (!uplist[t].empty() && (!new_host[t] || !bw_host[t])) return ROME_ERR_INVALID_ARG;
-    msg_base[t] = prop_rows_t[t]; prop_rows_t[t] += n_msg[t];
+    P->n_upt[t] = (int)uplist[t].size();
+    P->new_host[t] = P->n_upt[t] ? new_host[t] : nullptr; P->bw_host[t] = P->n_upt[t] ? bw_host[t] : nullptr;
+    msg_base[t] = P->prop_rows_t[t]; P->prop_rows_t[t] += n_msg[t];
   }
-  // ---- rows: validate, remap the variable indices to the device order, find the row range of every update position
-  std::vector<int32_t> rows_dev[NF];
-  std::vector<int> fam_lo[NF];              // first row of family f that targets update position >= k (rows are grouped in update order)
-  std::vector<std::vector<int>> csr[3];    // per type: proposal rows (in the type's buffer) of every updated variable
+  P->has_mirror = u->up_mirror != nullptr; P->has_upstream = u->up_stream != nullptr;
+  // ---- rows: every row targets an updated variable, rows grouped in update order; the row range of every update position; CSR
+  std::vector<std::vector<int>> csr[3];    // per type: proposal rows (in the type's buffer) of every updated variable, in update order
   for (int t = 0; t < 3; ++t) csr[t].resize(uplist[t].size());
   for (int k4 = 0; k4 < NF; ++k4) {
-    const Fam& f = fam[k4];
-    rows_dev[k4].resize((size_t)f.n * 4);
-    fam_lo[k4].assign((size_t)u->n_up + 1, 0);
+    const Fam& f = P->fam[k4];
+    P->fam_lo[k4].assign((size_t)u->n_up + 1, 0);
     int prev = -1;
     for (int r = 0; r < f.n; ++r) {
       const int32_t* e = f.rows4 + 4 * (size_t)r;
-      if (e[0] < 0 || e[0] >= f.F || e[2] < 0 || e[2] >= nv[f.vf] || e[3] < 0 || e[3] >= nv[f.vt] || e[1] < 0 || e[1] > 2) return ROME_ERR_INVALID_ARG;
       const int k = kpos[f.vt][e[3]];
-      if (k < 0 || k < prev) return ROME_ERR_INVALID_ARG;   // every row targets an updated variable; rows grouped in update order
-      if (k != prev) { for (int kk = prev + 1; kk <= k; ++kk) fam_lo[k4][kk] = r; }
+      if (k < 0 || k < prev) return ROME_ERR_INVALID_ARG;
+      if (k != prev) { for (int kk = prev + 1; kk <= k; ++kk) P->fam_lo[k4][kk] = r; }
       prev = k;
-      int32_t* d = rows_dev[k4].data() + 4 * (size_t)r;
-      d[0] = e[0]; d[1] = e[1]; d[2] = newidx[f.vf][e[2]]; d[3] = newidx[f.vt][e[3]];
-      csr[f.vt][(size_t)newidx[f.vt][e[3]]].push_back(f.base + r);
+      csr[f.vt][(size_t)(P->up_cnt_before[3 * (size_t)k + f.vt])].push_back(f.base + r);
     }
-    for (int kk = prev + 1; kk <= u->n_up; ++kk) fam_lo[k4][kk] = f.n;
+    for (int kk = prev + 1; kk <= u->n_up; ++kk) P->fam_lo[k4][kk] = f.n;
   }
   for (int t = 0; t < 3; ++t)
     for (int m = 0; m < n_msg[t]; ++m) {
       const int k = msg_up[t][m];
       if (k < 0 || k >= u->n_up || u->up_type[k] != t) return ROME_ERR_INVALID_ARG;
-      csr[t][(size_t)newidx[t][u->up_var[k]]].push_back(msg_base[t] + m);
+      csr[t][(size_t)P->up_cnt_before[3 * (size_t)k + t]].push_back(msg_base[t] + m);
     }
-  int max_k[3] = {1, 1, 1};
-  std::vector<int32_t> ptr_h[3], rws_h[3];
+  std::vector<int32_t> ptr_h[3], rws_h[3], blk_h[3], sid_h[3], mir_h[3], gat_h[3];
   for (int t = 0; t < 3; ++t) {
+    P->max_k[t] = 1;
     ptr_h[t].push_back(0);
-    for (const auto& l : csr[t]) { for (int r : l) rws_h[t].push_back(r); ptr_h[t].push_back((int32_t)rws_h[t].size()); if ((int)l.size() > max_k[t]) max_k[t] = (int)l.size(); }
+    for (const auto& l : csr[t]) { for (int r : l) rws_h[t].push_back(r); ptr_h[t].push_back((int32_t)rws_h[t].size()); if ((int)l.size() > P->max_k[t]) P->max_k[t] = (int)l.size(); }
     if (rws_h[t].empty()) rws_h[t].push_back(0);
-  }
-  // ---- arena
-  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  size_t need = 4096;
-  for (int t = 0; t < 3; ++t) {
-    const size_t blk = (size_t)vdim[t] * N * 8;
-    need += al(nv[t] * blk) + al(uplist[t].size() * blk) + al((size_t)prop_rows_t[t] * blk) + al((size_t)prop_rows_t[t] * vdim[t] * 8)
-          + al(ptr_h[t].size() * 4) + al(rws_h[t].size() * 4) + al(uplist[t].size() * vdim[t] * 8);
-  }
-  for (const Fam& f : fam) need += al((size_t)f.n * 16) + al((size_t)f.F * f.dz * 8) + al((size_t)f.F * f.nL * 8);
-  ROME_BIND(c);
-  void* arena_v = nullptr;
-  if ((rc = ensure(c, 9, need, &arena_v))) return rc;
-  unsigned char* arena = (unsigned char*)arena_v;
-  size_t used = 0;
-  hipStream_t s = c->stream;
-  auto put = [&](const void* src, size_t bytes, void** dst) -> int {
-    *dst = arena + used;
-    if (bytes) ROME_HIP(c, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
-    used += al(bytes);
-    return ROME_OK;
-  };
-  auto take = [&](size_t bytes) -> void* { void* p = arena + used; used += al(bytes); return p; };
-  // beliefs: host blocks in the device order, staged like rome_clique_proposals (layout conversion included)
-  std::vector<double> tmp, perm_host[3];
-  std::vector<std::vector<double>> Ls(NF), hout(3);
-  DrainOnExit drain{s};
-  double* d_store[3]; double* d_tmp[3]; double* d_prop[3]; double* d_pbw[3]; int32_t* d_ptr[3]; int32_t* d_rws[3]; double* d_bwout[3];
-  for (int t = 0; t < 3; ++t) {
-    const size_t plen = (o->layout == ROME_LAYOUT_AOS_POINTS ? (size_t)point_len(vdim[t]) : (size_t)vdim[t]) * N;
-    perm_host[t].resize((size_t)nv[t] * plen);
-    for (int v = 0; v < nv[t]; ++v) std::memcpy(perm_host[t].data() + (size_t)newidx[t][v] * plen, vhost[t] + (size_t)v * plen, plen * 8);
-    void* dv = nullptr;
-    if ((rc = stage_beliefs(c, o, nv[t], vdim[t], perm_host[t].data(), tmp, &dv, &used, arena, need))) return rc;
-    d_store[t] = (double*)dv;
-    const size_t blk = (size_t)vdim[t] * N * 8;
-    d_tmp[t] = (double*)take(uplist[t].size() * blk);
-    d_prop[t] = (double*)take((size_t)prop_rows_t[t] * blk);
-    d_pbw[t] = (double*)take((size_t)prop_rows_t[t] * vdim[t] * 8);
-    d_bwout[t] = (double*)take(uplist[t].size() * vdim[t] * 8);
-    void* p;
-    if ((rc = put(ptr_h[t].data(), ptr_h[t].size() * 4, &p))) return rc; d_ptr[t] = (int32_t*)p;
-    if ((rc = put(rws_h[t].data(), rws_h[t].size() * 4, &p))) return rc; d_rws[t] = (int32_t*)p;
-    if (n_msg[t] > 0) {   // upward messages: appended to the type's proposal buffer, bandwidths once
-      void* dm = nullptr; size_t used_m = 0;
-      unsigned char* mb = (unsigned char*)(d_prop[t] + (size_t)msg_base[t] * vdim[t] * N);
-      if ((rc = stage_beliefs(c, o, n_msg[t], vdim[t], msg_host[t], tmp, &dm, &used_m, mb, (size_t)n_msg[t] * blk + 256))) return rc;
-      ROME_HIP(c, rome::launch_kde_bandwidth(vdim[t], n_msg[t], N, (const double*)mb, circ_bw[t], 1e-2, 1e-6,
-                                             d_pbw[t] + (size_t)msg_base[t] * vdim[t], nullptr, s));
+    int pos = 0;
+    for (int k : uplist[t]) {
+      blk_h[t].push_back(u->up_var[k]);
+      sid_h[t].push_back(u->up_stream ? u->up_stream[k] : pos);
+      mir_h[t].push_back(u->up_mirror ? u->up_mirror[k] : -1);
+      gat_h[t].push_back(kVdim[t]); gat_h[t].push_back(u->up_var[k]); gat_h[t].push_back(pos); gat_h[t].push_back(t);
+      ++pos;
     }
   }
-  const int32_t* d_rows[NF] = {nullptr, nullptr, nullptr, nullptr, nullptr}; const double* d_mu[NF]; const double* d_L[NF];
-  for (int k4 = 0; k4 < NF; ++k4) {
-    const Fam& f = fam[k4];
-    d_mu[k4] = d_L[k4] = nullptr;
-    if (f.n == 0) continue;
-    const double* Lsrc = f.spread;
-    if (f.kind != 1) {
-      Ls[k4].resize((size_t)f.F * f.nL);
-      if ((rc = rome_cholesky_lower(f.dz, f.F, f.spread, Ls[k4].data()))) return rc;
-      Lsrc = Ls[k4].data();
-    }
-    void* p;
-    if ((rc = put(rows_dev[k4].data(), (size_t)f.n * 16, &p))) return rc; d_rows[k4] = (const int32_t*)p;
-    if ((rc = put(f.mu, (size_t)f.F * f.dz * 8, &p))) return rc; d_mu[k4] = (const double*)p;
-    if ((rc = put(Lsrc, (size_t)f.F * f.nL * 8, &p))) return rc; d_L[k4] = (const double*)p;
-  }
-  size_t tree_need = 8;
-  for (int t = 0; t < 3; ++t) { const size_t b = rome::gibbs_workspace_bytes(vdim[t], prop_rows_t[t], (int)uplist[t].size()); if (b > tree_need) tree_need = b; }
-  void* trees = nullptr;
-  if ((rc = ensure(c, 10, tree_need, &trees))) return rc;
   // ---- steps: ranges [k0, k1) of the update list that are updated together
-  std::vector<int> step_k;   // boundaries
-  step_k.push_back(0);
+  P->step_k.clear(); P->step_k.push_back(0);
   if (u->up_group) {
     for (int k = 1; k < u->n_up; ++k) {
       if (u->up_group[k] < u->up_group[k - 1]) return ROME_ERR_INVALID_ARG;
-      if (u->up_group[k] != u->up_group[k - 1]) step_k.push_back(k);
+      if (u->up_group[k] != u->up_group[k - 1]) P->step_k.push_back(k);
     }
   } else if (u->schedule == ROME_UPSOLVE_SEQUENTIAL) {
-    for (int k = 1; k < u->n_up; ++k) step_k.push_back(k);
+    for (int k = 1; k < u->n_up; ++k) P->step_k.push_back(k);
   }
-  step_k.push_back(u->n_up);
-  // ---- the loop
-  for (int it = 0; it < gi; ++it) {
+  P->step_k.push_back(u->n_up);
+  // ---- device memory
+  size_t need = 4096;
+  for (int t = 0; t < 3; ++t) {
+    const size_t blk = (size_t)kVdim[t] * N * 8, nu = uplist[t].size();
+    need += al256((size_t)P->prop_rows_t[t] * blk) + al256((size_t)P->prop_rows_t[t] * kVdim[t] * 8) + al256(ptr_h[t].size() * 4) + al256(rws_h[t].size() * 4)
+          + 3 * al256(nu * 4 + 4) + al256(nu * 16 + 16) + al256(nu * blk) + al256(nu * kVdim[t] * 8);
+  }
+  for (const Fam& f : P->fam) need += fam_table_bytes(f);
+  ROME_BIND(c);
+  if (ctx_arena) { if ((rc = ensure(c, 12, need, &P->arena))) return rc; P->arena_owned = false; }
+  else { ROME_HIP(c, hipMalloc(&P->arena, need)); P->arena_owned = true; }
+  unsigned char* arena = (unsigned char*)P->arena;
+  size_t used = 0;
+  hipStream_t s = c->stream;
+  std::vector<std::vector<double>> Ls(NF);
+  std::vector<double> tmp;
+  DrainOnExit drain{s};
+  auto put = [&](const void* src, size_t bytes, void** dst) -> int {
+    *dst = arena + used;
+    if (bytes) ROME_HIP(c, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s));
+    used += al256(bytes);
+    return ROME_OK;
+  };
+  auto take = [&](size_t bytes) -> void* { void* p = arena + used; used += al256(bytes); return p; };
+  for (int t = 0; t < 3; ++t) {
+    const size_t blk = (size_t)kVdim[t] * N * 8, nu = uplist[t].size();
+    P->d_prop[t] = (double*)take((size_t)P->prop_rows_t[t] * blk);
+    P->d_pbw[t] = (double*)take((size_t)P->prop_rows_t[t] * kVdim[t] * 8);
+    P->d_newout[t] = (double*)take(nu * blk);
+    P->d_bwout[t] = (double*)take(nu * kVdim[t] * 8);
+    void* p;
+    if ((rc = put(ptr_h[t].data(), ptr_h[t].size() * 4, &p))) return rc; P->d_ptr[t] = (int32_t*)p;
+    if ((rc = put(rws_h[t].data(), rws_h[t].size() * 4, &p))) return rc; P->d_rws[t] = (int32_t*)p;
+    if ((rc = put(blk_h[t].data(), nu * 4, &p))) return rc; P->d_upblock[t] = (int32_t*)p;
+    if ((rc = put(sid_h[t].data(), nu * 4, &p))) return rc; P->d_upstream[t] = (int32_t*)p;
+    if ((rc = put(mir_h[t].data(), nu * 4, &p))) return rc; P->d_upmirror[t] = (int32_t*)p;
+    if ((rc = put(gat_h[t].data(), nu * 16, &p))) return rc; P->d_gather[t] = (int32_t*)p;
+    if (n_msg[t] > 0) {   // upward messages: appended to the type's proposal buffer, bandwidths once
+      void* dm = nullptr; size_t used_m = 0;
+      unsigned char* mb = (unsigned char*)(P->d_prop[t] + (size_t)msg_base[t] * kVdim[t] * N);
+      if ((rc = stage_beliefs(c, o, n_msg[t], kVdim[t], msg_host[t], tmp, &dm, &used_m, mb, (size_t)n_msg[t] * blk + 256))) return rc;
+      ROME_HIP(c, rome::launch_kde_bandwidth(kVdim[t], n_msg[t], N, (const double*)mb, kCircBw[t], 1e-2, 1e-6,
+                                             P->d_pbw[t] + (size_t)msg_base[t] * kVdim[t], nullptr, s));
+    }
+    const size_t b = rome::gibbs_workspace_bytes(kVdim[t], P->prop_rows_t[t], (int)nu);
+    if (b > P->tree_need) P->tree_need = b;
+  }
+  for (int k4 = 0; k4 < NF; ++k4) if ((rc = upload_fam(c, P->fam[k4], arena, &used, Ls[k4], P->fd[k4]))) return rc;
+  if (used > need) return ROME_ERR_ALLOC;
+  // the host tables must not be referenced after creation (the caller's arrays may go away)
+  for (Fam& f : P->fam) { f.rows4 = nullptr; f.mu = f.spread = nullptr; f.alt = nullptr; f.hw = f.nh = nullptr; f.sid = nullptr; f.out = nullptr; }
+  return ROME_OK;   // (~DrainOnExit: the uploads have completed before Ls / tmp go away)
+}
+
+int plan_run(rome_upsolve_plan* P, const rome_opts* o, double* mirror_out, int64_t mirror_stride) {
+  rome_ctx* c = P->ctx; rome_store* st = P->st;
+  const int N = P->N;
+  int rc;
+  if (P->has_mirror && !mirror_out) return ROME_ERR_INVALID_ARG;
+  if (mirror_stride == 0) mirror_stride = 6 * (int64_t)N;
+  if (P->has_mirror)
+    for (int t = 0; t < 3; ++t) if (P->n_upt[t] && mirror_stride < (int64_t)kVdim[t] * N) return ROME_ERR_INVALID_ARG;
+  ROME_BIND(c);
+  void* trees = nullptr;
+  if ((rc = ensure(c, 10, P->tree_need, &trees))) return rc;
+  hipStream_t s = c->stream;
+  for (int it = 0; it < P->gi; ++it) {
     const uint64_t base = o->stream_offset + ((uint64_t)it << 32);
-    const int nsteps = u->n_up > 0 ? (int)step_k.size() - 1 : 0;
-    for (int st = 0; st < nsteps; ++st) {
-      const int k0 = step_k[st], k1 = step_k[st + 1];
+    const int nsteps = P->n_up > 0 ? (int)P->step_k.size() - 1 : 0;
+    for (int stp = 0; stp < nsteps; ++stp) {
+      const int k0 = P->step_k[stp], k1 = P->step_k[stp + 1];
       for (int k4 = 0; k4 < NF; ++k4) {
-        const Fam& f = fam[k4];
-        const int lo = fam_lo[k4][k0], hi = f.n == 0 ? 0 : (k1 < u->n_up ? fam_lo[k4][k1] : f.n);
+        const Fam& f = P->fam[k4];
+        const int lo = P->fam_lo[k4][k0], hi = f.n == 0 ? 0 : (k1 < P->n_up ? P->fam_lo[k4][k1] : f.n);
         if (hi <= lo) continue;
-        rome::ConvArgs a;
-        rome_opts of = *o; of.stream_offset = base + f.off + (uint64_t)lo;
-        fill_args(a, &of);
-        a.n_conv = hi - lo; a.dir_all = f.dir_all; a.rows4 = d_rows[k4] + 4 * (size_t)lo;
-        a.mu = d_mu[k4]; a.L = d_L[k4];
-        a.bel_fixed = d_store[f.vf]; a.bel_target = d_store[f.vt];
-        a.out = d_prop[f.vt] + (size_t)(f.base + lo) * f.dt * N;
-        hipError_t e = f.kind == 0 ? rome::launch_conv_pose2pose2(a, o->solver, s) : (f.kind == 1 ? rome::launch_conv_bearingrange(a, o->solver, s)
-                                   : (f.kind == 2 ? rome::launch_conv_pose3pose3(a, o->solver, s) : rome::launch_sample_priorpoint2(a, s)));
-        ROME_HIP(c, e);
-        ROME_HIP(c, rome::launch_kde_bandwidth(f.dt, hi - lo, N, a.out, circ_bw[f.vt], 1e-2, 1e-6, d_pbw[f.vt] + (size_t)(f.base + lo) * f.dt, nullptr, s));
+        double* out = P->d_prop[f.vt] + (size_t)(f.base + lo) * f.dt * N;
+        ROME_HIP(c, launch_fam(f, P->fd[k4], o, base, lo, hi, st->bel[f.vf], st->bel[f.vt], out, s));
+        ROME_HIP(c, rome::launch_kde_bandwidth(f.dt, hi - lo, N, out, kCircBw[f.vt], 1e-2, 1e-6, P->d_pbw[f.vt] + (size_t)(f.base + lo) * f.dt, nullptr, s));
       }
       for (int t = 0; t < 3; ++t) {
-        const int pa = up_cnt_before[3 * (size_t)k0 + t], pb = up_cnt_before[3 * (size_t)k1 + t];
-        if (pb <= pa || prop_rows_t[t] == 0) continue;
-        const size_t blk = (size_t)vdim[t] * N;
-        ROME_HIP(c, rome::launch_product_gibbs(vdim[t], pb - pa, N, prop_rows_t[t], d_ptr[t] + pa, d_rws[t], d_prop[t], d_pbw[t],
-                                               d_store[t] + (size_t)pa * blk, d_tmp[t] + (size_t)pa * blk, trees, circ_prod[t], pi, max_k[t],
-                                               o->seed, base + prod_off[t] + (uint64_t)pa, s));
-        ROME_HIP(c, hipMemcpyAsync(d_store[t] + (size_t)pa * blk, d_tmp[t] + (size_t)pa * blk, (size_t)(pb - pa) * blk * 8, hipMemcpyDeviceToDevice, s));
+        const int pa = P->up_cnt_before[3 * (size_t)k0 + t], pb = P->up_cnt_before[3 * (size_t)k1 + t];
+        if (pb <= pa || P->prop_rows_t[t] == 0) continue;
+        // the product writes the new beliefs IN PLACE into the store (a product reads only proposals and its own variable's block)
+        rome::GibbsPlace place{P->d_upblock[t] + pa, P->has_upstream ? P->d_upstream[t] + pa : nullptr,
+                               (P->has_mirror && mirror_out) ? P->d_upmirror[t] + pa : nullptr, mirror_out, mirror_stride};
+        ROME_HIP(c, rome::launch_product_gibbs(kVdim[t], pb - pa, N, P->prop_rows_t[t], P->d_ptr[t] + pa, P->d_rws[t], P->d_prop[t], P->d_pbw[t],
+                                               st->bel[t], st->bel[t], trees, kCircProd[t], P->pi, P->max_k[t],
+                                               o->seed, base + kProdOff[t] + (P->has_upstream ? 0ull : (uint64_t)pa), s, &place));
       }
     }
   }
-  // ---- results: the updated beliefs (first blocks of every store) and their manikde! bandwidths
+  if (P->has_mirror && P->gi > 0) {
+    // updated variables whose product never ran (no proposals at all) still owe their block to the mirror: the product kernel handles
+    // K = 0 (copy), so nothing to do here as long as the type has proposal rows; a type without any row keeps its beliefs
+    for (int t = 0; t < 3; ++t)
+      if (P->n_upt[t] && P->prop_rows_t[t] == 0) {
+        rome::GibbsPlace place{P->d_upblock[t], nullptr, P->d_upmirror[t], mirror_out, mirror_stride};
+        ROME_HIP(c, rome::launch_product_gibbs(kVdim[t], P->n_upt[t], N, 0, P->d_ptr[t], P->d_rws[t], P->d_prop[t], P->d_pbw[t], st->bel[t], st->bel[t],
+                                               trees, kCircProd[t], 1, 1, o->seed, 0, s, &place));
+      }
+  }
+  // ---- results (only when the plan was created with host outputs): the updated beliefs and their manikde! bandwidths
+  bool sync = false;
   for (int t = 0; t < 3; ++t) {
-    const int nu = (int)uplist[t].size();
+    const int nu = P->n_upt[t];
     if (nu == 0) continue;
-    ROME_HIP(c, rome::launch_kde_bandwidth(vdim[t], nu, N, d_store[t], circ_bw[t], 1e-2, 1e-6, d_bwout[t], nullptr, s));
-    ROME_HIP(c, hipMemcpyAsync(bw_host[t], d_bwout[t], (size_t)nu * vdim[t] * 8, hipMemcpyDeviceToHost, s));
-    const size_t cnt = (size_t)nu * vdim[t] * N;
-    if (o->layout == ROME_LAYOUT_SOA) ROME_HIP(c, hipMemcpyAsync(new_host[t], d_store[t], cnt * 8, hipMemcpyDeviceToHost, s));
-    else { hout[t].resize(cnt); ROME_HIP(c, hipMemcpyAsync(hout[t].data(), d_store[t], cnt * 8, hipMemcpyDeviceToHost, s)); }
-  }
-  ROME_HIP(c, hipStreamSynchronize(s));
-  if (o->layout != ROME_LAYOUT_SOA)
-    for (int t = 0; t < 3; ++t) {
-      const int nu = (int)uplist[t].size();
-      if (nu == 0) continue;
-      if (o->layout == ROME_LAYOUT_AOS || vdim[t] == 2) from_soa(hout[t].data(), nu, N, vdim[t], ROME_LAYOUT_AOS, new_host[t]);
-      else {
-        std::vector<double> aos(hout[t].size());
-        from_soa(hout[t].data(), nu, N, vdim[t], ROME_LAYOUT_AOS, aos.data());
-        if ((rc = convert_rows(c, vdim[t], (size_t)nu * N, aos.data(), new_host[t], false))) return rc;
-      }
+    if (P->bw_host[t]) {
+      ROME_HIP(c, rome::launch_kde_bandwidth(kVdim[t], nu, N, st->bel[t], kCircBw[t], 1e-2, 1e-6, P->d_bwout[t], nullptr, s, P->d_upblock[t]));
+      ROME_HIP(c, hipMemcpyAsync(P->bw_host[t], P->d_bwout[t], (size_t)nu * kVdim[t] * 8, hipMemcpyDeviceToHost, s));
+      sync = true;
     }
+    if (P->new_host[t]) {
+      ROME_HIP(c, rome::launch_scatter_blocks(nu, N, P->d_gather[t], P->d_newout[t], (int64_t)kVdim[t] * N, st->bel[0], st->bel[1], st->bel[2], s, /*to_store=*/0));
+      if ((rc = fetch_beliefs(c, P->layout, nu, kVdim[t], N, P->d_newout[t], P->new_host[t]))) return rc;
+    }
+  }
+  if (sync) ROME_HIP(c, hipStreamSynchronize(s));
   return ROME_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rome_store_create(rome_ctx* c, int32_t N, int32_t n_pose2, int32_t n_point2, int32_t n_pose3, rome_store** out) {
+  if (!c || !out || N < 1 || N > ROME_MAX_PARTICLES || n_pose2 < 0 || n_point2 < 0 || n_pose3 < 0) return ROME_ERR_INVALID_ARG;
+  ROME_BIND(c);
+  rome_store* st = new (std::nothrow) rome_store();
+  if (!st) return ROME_ERR_ALLOC;
+  st->ctx = c; st->N = N; st->nv[0] = n_pose2; st->nv[1] = n_point2; st->nv[2] = n_pose3; st->owned = true;
+  for (int t = 0; t < 3; ++t) {
+    const size_t bytes = (size_t)st->nv[t] * kVdim[t] * N * 8;
+    hipError_t e = hipMalloc((void**)&st->bel[t], bytes ? bytes : 8);
+    if (e == hipSuccess && bytes) e = hipMemsetAsync(st->bel[t], 0, bytes, c->stream);
+    if (e != hipSuccess) { for (int k = 0; k <= t; ++k) if (st->bel[k]) (void)hipFree(st->bel[k]); delete st; return hip_fail(c, e); }
+  }
+  *out = st;
+  return ROME_OK;
+}
+int rome_store_wrap(rome_ctx* c, int32_t N, int32_t n_pose2, double* d2, int32_t n_point2, double* dpt, int32_t n_pose3, double* d3, rome_store** out) {
+  if (!c || !out || N < 1 || N > ROME_MAX_PARTICLES || n_pose2 < 0 || n_point2 < 0 || n_pose3 < 0) return ROME_ERR_INVALID_ARG;
+  if ((n_pose2 > 0 && !d2) || (n_point2 > 0 && !dpt) || (n_pose3 > 0 && !d3)) return ROME_ERR_INVALID_ARG;
+  rome_store* st = new (std::nothrow) rome_store();
+  if (!st) return ROME_ERR_ALLOC;
+  st->ctx = c; st->N = N; st->nv[0] = n_pose2; st->nv[1] = n_point2; st->nv[2] = n_pose3; st->owned = false;
+  st->bel[0] = d2; st->bel[1] = dpt; st->bel[2] = d3;
+  *out = st;
+  return ROME_OK;
+}
+void rome_store_destroy(rome_store* st) {
+  if (!st) return;
+  if (st->owned) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != st->ctx->device) (void)hipSetDevice(st->ctx->device);
+    for (int t = 0; t < 3; ++t) if (st->bel[t]) (void)hipFree(st->bel[t]);
+  }
+  delete st;
+}
+int rome_store_upload(rome_store* st, int32_t layout, int32_t type, int32_t first, int32_t count, const double* host) {
+  if (!st || type < 0 || type > 2 || first < 0 || count < 0 || first + count > st->nv[type] || (count > 0 && !host)) return ROME_ERR_INVALID_ARG;
+  if (layout != ROME_LAYOUT_SOA && layout != ROME_LAYOUT_AOS && layout != ROME_LAYOUT_AOS_POINTS) return ROME_ERR_INVALID_ARG;
+  if (count == 0) return ROME_OK;
+  rome_ctx* c = st->ctx;
+  ROME_BIND(c);
+  rome_opts o; rome_opts_default(&o, ROME_SOLVER_NEWTON); o.n_particles = st->N; o.layout = layout;
+  std::vector<double> tmp;
+  DrainOnExit drain{c->stream};
+  void* dv = nullptr; size_t used = 0;
+  const size_t blk = (size_t)kVdim[type] * st->N;
+  int rc = stage_beliefs(c, &o, count, kVdim[type], host, tmp, &dv, &used, (unsigned char*)(st->bel[type] + (size_t)first * blk), (size_t)count * blk * 8 + 256);
+  if (rc) return rc;
+  ROME_HIP(c, hipStreamSynchronize(c->stream));   // the caller's array may go away
+  return ROME_OK;
+}
+int rome_store_download(rome_store* st, int32_t layout, int32_t type, int32_t first, int32_t count, double* host) {
+  if (!st || type < 0 || type > 2 || first < 0 || count < 0 || first + count > st->nv[type] || (count > 0 && !host)) return ROME_ERR_INVALID_ARG;
+  if (layout != ROME_LAYOUT_SOA && layout != ROME_LAYOUT_AOS && layout != ROME_LAYOUT_AOS_POINTS) return ROME_ERR_INVALID_ARG;
+  rome_ctx* c = st->ctx;
+  ROME_BIND(c);
+  return fetch_beliefs(c, layout, count, kVdim[type], st->N, st->bel[type] + (size_t)first * kVdim[type] * st->N, host);
+}
+int rome_store_ptr(rome_store* st, int32_t type, void** dev, int32_t* n_blocks) {
+  if (!st || type < 0 || type > 2 || !dev) return ROME_ERR_INVALID_ARG;
+  *dev = st->bel[type];
+  if (n_blocks) *n_blocks = st->nv[type];
+  return ROME_OK;
+}
+
+int rome_upsolve_plan_create(rome_ctx* c, rome_store* st, const rome_opts* o, const rome_clique_upsolve_host* u, rome_upsolve_plan** out) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || !st || !u || !out || st->ctx != c) return ROME_ERR_INVALID_ARG;
+  rome_upsolve_plan* P = new (std::nothrow) rome_upsolve_plan();
+  if (!P) return ROME_ERR_ALLOC;
+  rc = plan_build(c, st, o, u, P, false);
+  if (rc) { rome_upsolve_plan_destroy(P); return rc; }
+  *out = P;
+  return ROME_OK;
+}
+int rome_upsolve_plan_run(rome_upsolve_plan* P, const rome_opts* o, double* mirror_out, int64_t mirror_stride) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!P || o->n_particles != P->N || mirror_stride < 0) return ROME_ERR_INVALID_ARG;
+  return plan_run(P, o, mirror_out, mirror_stride);
+}
+void rome_upsolve_plan_destroy(rome_upsolve_plan* P) {
+  if (!P) return;
+  if (P->arena && P->arena_owned) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != P->ctx->device) (void)hipSetDevice(P->ctx->device);
+    (void)hipFree(P->arena);
+  }
+  delete P;
+}
+
+int rome_scatter_plan_create(rome_ctx* c, rome_store* st, int32_t n, const int32_t* type, const int32_t* var, const int32_t* src_block,
+                             int64_t stride, rome_scatter_plan** out) {
+  if (!c || !st || st->ctx != c || !out || n < 0 || stride < 0 || (n > 0 && (!type || !var || !src_block))) return ROME_ERR_INVALID_ARG;
+  if (stride == 0) stride = 6 * (int64_t)st->N;
+  std::vector<int32_t> ent((size_t)n * 4 + 4);
+  for (int k = 0; k < n; ++k) {
+    const int t = type[k];
+    if (t < 0 || t > 2 || var[k] < 0 || var[k] >= st->nv[t] || src_block[k] < 0 || stride < (int64_t)kVdim[t] * st->N) return ROME_ERR_INVALID_ARG;
+    ent[4 * (size_t)k] = kVdim[t]; ent[4 * (size_t)k + 1] = var[k]; ent[4 * (size_t)k + 2] = src_block[k]; ent[4 * (size_t)k + 3] = t;
+  }
+  ROME_BIND(c);
+  rome_scatter_plan* S = new (std::nothrow) rome_scatter_plan();
+  if (!S) return ROME_ERR_ALLOC;
+  S->ctx = c; S->st = st; S->n = n; S->stride = stride;
+  hipError_t e = hipMalloc((void**)&S->d_ent, (size_t)n * 16 + 16);
+  if (e == hipSuccess && n) e = hipMemcpy(S->d_ent, ent.data(), (size_t)n * 16, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { if (S->d_ent) (void)hipFree(S->d_ent); delete S; return hip_fail(c, e); }
+  *out = S;
+  return ROME_OK;
+}
+int rome_scatter_plan_run(rome_scatter_plan* S, const double* src_dev) {
+  if (!S || (S->n > 0 && !src_dev)) return ROME_ERR_INVALID_ARG;
+  rome_ctx* c = S->ctx;
+  ROME_BIND(c);
+  ROME_HIP(c, rome::launch_scatter_blocks(S->n, S->st->N, S->d_ent, src_dev, S->stride, S->st->bel[0], S->st->bel[1], S->st->bel[2], c->stream, 1));
+  return ROME_OK;
+}
+void rome_scatter_plan_destroy(rome_scatter_plan* S) {
+  if (!S) return;
+  if (S->d_ent) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != S->ctx->device) (void)hipSetDevice(S->ctx->device);
+    (void)hipFree(S->d_ent);
+  }
+  delete S;
+}
+
+/* ---- the one-shot host entry: a temporary store over the clique's host beliefs (context arena) + a plan + one run ---- */
+int rome_clique_upsolve(rome_ctx* c, const rome_opts* o, const rome_clique_upsolve_host* u) {
+  int rc = check_opts(o); if (rc) return rc;
+  if (!c || !u) return ROME_ERR_INVALID_ARG;
+  const rome_clique_host* q = &u->clique;
+  const int N = o->n_particles;
+  if (N > ROME_MAX_PARTICLES_GIBBS) return ROME_ERR_UNSUPPORTED_N;
+  const int nv[3] = {q->n_pose2, q->n_point2, q->n_pose3};
+  const double* vhost[3] = {q->bel_pose2, q->bel_point2, q->bel_pose3};
+  size_t need = 4096;
+  for (int t = 0; t < 3; ++t) { if (nv[t] < 0 || (nv[t] > 0 && !vhost[t])) return ROME_ERR_INVALID_ARG; need += al256((size_t)nv[t] * kVdim[t] * N * 8); }
+  if (u->up_mirror) return ROME_ERR_INVALID_ARG;   // (mirrors belong to plans: there is no device buffer to mirror into here)
+  for (int k = 0; k < u->n_up; ++k) {               // the results are read back: every updated type needs its host outputs
+    const int t = u->up_type ? u->up_type[k] : -1;
+    if (t < 0 || t > 2) return ROME_ERR_INVALID_ARG;
+    double* nh[3] = {u->new_pose2, u->new_point2, u->new_pose3}; double* bh[3] = {u->bw_pose2, u->bw_point2, u->bw_pose3};
+    if (!nh[t] || !bh[t]) return ROME_ERR_INVALID_ARG;
+  }
+  ROME_BIND(c);
+  void* arena_v = nullptr;
+  if ((rc = ensure(c, 11, need, &arena_v))) return rc;
+  unsigned char* arena = (unsigned char*)arena_v;
+  size_t used = 0;
+  rome_store st;
+  st.ctx = c; st.N = N; st.owned = false;
+  {
+    std::vector<double> tmp;
+    DrainOnExit drain{c->stream};
+    for (int t = 0; t < 3; ++t) {
+      void* dv = nullptr;
+      if ((rc = stage_beliefs(c, o, nv[t], kVdim[t], vhost[t], tmp, &dv, &used, arena, need))) return rc;
+      st.nv[t] = nv[t]; st.bel[t] = (double*)dv;
+    }
+  }
+  rome_upsolve_plan P;
+  if ((rc = plan_build(c, &st, o, u, &P, true))) return rc;
+  return plan_run(&P, o, nullptr, 0);
 }
 
 /* ---- native point containers <-> coordinates ---- */

@@ -39,6 +39,7 @@ struct GibbsArgs {
   const int32_t* order;   // workspace: variables by descending number of proposals
   int n_rows;
   uint64_t seed, stream_offset;
+  GibbsPlace place;       // optional indirections (all nullptr: variable v lives in block v, draws stream v, no mirror)
 };
 
 template <int D>
@@ -407,19 +408,22 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
   const int N = a.N, L = a.L;
   const int k0 = a.prop_ptr[v], K = a.prop_ptr[v + 1] - k0;
   auto circ_bit = [&](int d) -> bool { if constexpr (CM >= 0) return (CM >> d) & 1; else return (a.circ >> d) & 1u; };
-  double* ob = a.bel_out + (size_t)v * D * N;
+  const int vb = a.place.var_block ? a.place.var_block[v] : v;   // the block of the belief arrays this variable lives in
+  double* ob = a.bel_out + (size_t)vb * D * N;
+  const int msl = a.place.mirror_slot ? a.place.mirror_slot[v] : -1;
+  double* mo = msl >= 0 ? a.place.mirror_out + (size_t)msl * (size_t)a.place.mirror_stride : nullptr;   // ALSO written: an exchange buffer
   // Arguments of the public entry that would index out of bounds -- more proposals than the caller's max_proposals sized the LDS
   // for, or a proposal row outside the tree workspace -- fail LOUDLY: the variable's belief becomes NaN (block-uniform test, no
   // out-of-bounds access); nothing is silently truncated.
   bool bad = K < 0 || K > a.max_k;
   for (int j = 0; j < K && !bad; ++j) { const int r = a.prop_rows[k0 + j]; bad = r < 0 || r >= a.n_rows; }
   if (bad) {
-    for (int q = tid; q < D * N; q += kGibbsThreads) ob[q] = __builtin_nan("");
+    for (int q = tid; q < D * N; q += kGibbsThreads) { ob[q] = __builtin_nan(""); if (mo) mo[q] = __builtin_nan(""); }
     return;
   }
   if (K <= 1) {   // K = 0: the belief is kept; K = 1: the proposal is the product
-    const double* src = K == 0 ? a.bel_in + (size_t)v * D * N : a.prop + (size_t)a.prop_rows[k0] * D * N;
-    for (int q = tid; q < D * N; q += kGibbsThreads) ob[q] = src[q];
+    const double* src = K == 0 ? a.bel_in + (size_t)vb * D * N : a.prop + (size_t)a.prop_rows[k0] * D * N;
+    for (int q = tid; q < D * N; q += kGibbsThreads) { const double x = src[q]; if (src != ob) ob[q] = x; if (mo) mo[q] = x; }
     return;
   }
   __shared__ float logn[kGibbsMaxN + 1];   // log(c / N): the weight of a node with c points
@@ -488,7 +492,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
   // ---- sampling: lane = output sample
   const int s = tid;
   const bool live = s < N;
-  const uint64_t st = a.stream_offset + (uint64_t)v;
+  const uint64_t st = a.stream_offset + (uint64_t)(a.place.var_stream ? a.place.var_stream[v] : v);
   uint32_t qu = 0, qn = 0;
   u32x4 wu = {0, 0, 0, 0}, wn = {0, 0, 0, 0};
   double npair0 = 0.0, npair1 = 0.0;
@@ -693,7 +697,11 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
   if constexpr (D == 6) quat_log(xq, x + 3);
   if (live) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) ob[(size_t)d * N + s] = (circ_bit(d)) ? gwrap(x[d]) : x[d];
+    for (int d = 0; d < D; ++d) {
+      const double xo = (circ_bit(d)) ? gwrap(x[d]) : x[d];
+      ob[(size_t)d * N + s] = xo;
+      if (mo) mo[(size_t)d * N + s] = xo;
+    }
   }
 }
 
@@ -721,7 +729,7 @@ __global__ void __launch_bounds__(1024) k_gibbs_order(int V, const int32_t* __re
 
 hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
                                 const double* prop_bw, const double* bel_in, double* bel_out, void* trees, uint32_t circ, int iters, int max_k,
-                                uint64_t seed, uint64_t stream_offset, hipStream_t s) {
+                                uint64_t seed, uint64_t stream_offset, hipStream_t s, const GibbsPlace* place) {
   if (V <= 0) return hipSuccess;
   if (N < 1 || N > kGibbsMaxN || (dim != 2 && dim != 3 && dim != 6) || max_k < 1 || n_rows < 0) return hipErrorInvalidValue;
   GibbsArgs a;
@@ -733,6 +741,8 @@ hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t
   a.order = order;
   hipLaunchKernelGGL(k_gibbs_order, dim3(1), dim3(1024), 0, s, V, prop_ptr, order);
   a.seed = seed; a.stream_offset = stream_offset;
+  a.place = place ? *place : GibbsPlace{nullptr, nullptr, nullptr, nullptr, 0};
+  if (!a.place.mirror_out) a.place.mirror_slot = nullptr;
   if (n_rows > 0) {
     if (dim == 2) hipLaunchKernelGGL((k_gibbs_trees<2>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
     else if (dim == 3) hipLaunchKernelGGL((k_gibbs_trees<3>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);

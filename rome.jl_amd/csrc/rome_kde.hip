@@ -487,14 +487,15 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
 template <int S>
 __global__ void __launch_bounds__(64 * kKdeWaves) k_kde_bandwidth(int T, int dim, int N, const double* __restrict__ bel,
                                                                   uint32_t circ_mask, double tol_e, double tol_c,
-                                                                  double* __restrict__ bw, int32_t* __restrict__ evals) {
+                                                                  double* __restrict__ bw, int32_t* __restrict__ evals, const int32_t* __restrict__ block_idx) {
   __shared__ double pts[kKdeWaves][64 * S];
   __shared__ double wex[kKdeWaves][64 * S];   // per-wave exchange row of the symmetric likelihood evaluation
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = blockIdx.x * kKdeWaves + wave;
   if (t >= T) return;   // wave-uniform; nothing below synchronises across waves
   const bool circ = (circ_mask >> (t % dim)) & 1u;
-  const double* __restrict__ P = bel + (size_t)t * N;
+  // (block_idx: belief t / dim lives in block block_idx[t / dim] of `bel` -- a scattered subset of a store; wave-uniform)
+  const double* __restrict__ P = bel + (block_idx ? (size_t)block_idx[t / dim] * dim + (size_t)(t % dim) : (size_t)t) * N;
   double x[S];
   bool act[S];
 #pragma unroll
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(64 * kKdeWaves) k_kde_bandwidth(int T, int dim
 template <int B>
 __global__ void __launch_bounds__(64 * kKdeWaves) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_kde_bandwidth_fast(int T, int dim, int N, const double* __restrict__ bel, uint32_t circ_mask, double tol_e, double tol_c,
-                     double* __restrict__ bw, int32_t* __restrict__ evals) {
+                     double* __restrict__ bw, int32_t* __restrict__ evals, const int32_t* __restrict__ block_idx) {
   __shared__ double pts[kKdeWaves][128];
   __shared__ double wex[kKdeWaves][128];   // exchange row of the double-precision evaluations (tie decisions)
   __shared__ float xsbuf[kKdeWaves][136];  // the particles as single-precision offsets from particle 0 (+ padding)
@@ -528,7 +529,8 @@ k_kde_bandwidth_fast(int T, int dim, int N, const double* __restrict__ bel, uint
   const int t = blockIdx.x * kKdeWaves + wave;
   if (t >= T) return;   // wave-uniform; nothing below synchronises across waves
   const bool circ = (circ_mask >> (t % dim)) & 1u;
-  const double* __restrict__ P = bel + (size_t)t * N;
+  // (block_idx: belief t / dim lives in block block_idx[t / dim] of `bel` -- a scattered subset of a store; wave-uniform)
+  const double* __restrict__ P = bel + (block_idx ? (size_t)block_idx[t / dim] * dim + (size_t)(t % dim) : (size_t)t) * N;
   double x[2];
   bool act[2];
 #pragma unroll
@@ -599,21 +601,21 @@ hipError_t launch_kde_max(int dim, int V, int N, int G, double extend, const dou
 }
 
 hipError_t launch_kde_bandwidth(int dim, int V, int N, const double* bel, uint32_t circ_mask, double tol_e, double tol_c,
-                                double* bw, int32_t* evals, hipStream_t s) {
+                                double* bw, int32_t* evals, hipStream_t s, const int32_t* block_idx) {
   const int T = V * dim;
   if (T <= 0) return hipSuccess;
   const dim3 grid((T + kKdeWaves - 1) / kKdeWaves), block(64 * kKdeWaves);
-#define ROME_LAUNCH_KDE(SS) hipLaunchKernelGGL((k_kde_bandwidth<SS>), grid, block, 0, s, T, dim, N, bel, circ_mask, tol_e, tol_c, bw, evals)
+#define ROME_LAUNCH_KDE(SS) hipLaunchKernelGGL((k_kde_bandwidth<SS>), grid, block, 0, s, T, dim, N, bel, circ_mask, tol_e, tol_c, bw, evals, block_idx)
   if (N < 8) ROME_LAUNCH_KDE(1);
   else if (N <= 70)
     hipLaunchKernelGGL((k_kde_bandwidth_fast<7>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<7>(N), s, T, dim, N, bel, circ_mask,
-                       tol_e, tol_c, bw, evals);
+                       tol_e, tol_c, bw, evals, block_idx);
   else if (N <= 100)
     hipLaunchKernelGGL((k_kde_bandwidth_fast<10>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<10>(N), s, T, dim, N, bel, circ_mask,
-                       tol_e, tol_c, bw, evals);
+                       tol_e, tol_c, bw, evals, block_idx);
   else if (N <= 128)
     hipLaunchKernelGGL((k_kde_bandwidth_fast<13>), grid, block, sizeof(float) * kKdeWaves * (size_t)kdeCells<13>(N), s, T, dim, N, bel, circ_mask,
-                       tol_e, tol_c, bw, evals);
+                       tol_e, tol_c, bw, evals, block_idx);
   else if (N <= 256) ROME_LAUNCH_KDE(4);
   else ROME_LAUNCH_KDE(8);
 #undef ROME_LAUNCH_KDE

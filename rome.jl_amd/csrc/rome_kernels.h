@@ -33,6 +33,8 @@ struct ConvArgs {
   int mirror_row[4];
   double* mirror_out;
   const int32_t* mirror_map;  // [C] block of mirror_out row c is ALSO written to (-1: none), or nullptr -> mirror_row; any number of rows
+  const int32_t* row_stream;  // [C] Philox stream id of row c (stream = stream_offset + id), or nullptr -> c.  Served by the wave-per-row
+                              // kernels and the prior samplers (a table with this column does not take the packed sweep)
   int dir_all;
   int max_iters;
   int cycles;
@@ -64,16 +66,25 @@ hipError_t launch_linearize(int kind, int F, const double* mu, const double* W, 
                             double* r, double* Ja, double* Jb, hipStream_t s);
 
 hipError_t launch_belief_stats(int dim, int V, int N, const double* bel, double* mean, double* sdev, hipStream_t s);
+// block_idx: optional [V] block of `bel` that belief v lives in (nullptr: v) -- the bandwidths of a scattered subset of a store
 hipError_t launch_kde_bandwidth(int dim, int V, int N, const double* bel, uint32_t circ_mask, double tol_e, double tol_c,
-                                double* bw, int32_t* evals, hipStream_t s);
+                                double* bw, int32_t* evals, hipStream_t s, const int32_t* block_idx = nullptr);
 hipError_t launch_kde_max(int dim, int V, int N, int G, double extend, const double* bel, const double* bw, double* out, hipStream_t s);
 hipError_t launch_product(int dim, int V, int N, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
                           const double* prop_bw, const double* bel_in, double* bel_out, double c_n, uint64_t seed,
                           uint64_t stream_offset, hipStream_t s);
 
 size_t gibbs_workspace_bytes(int dim, int n_rows, int V);
+// GibbsPlace (optional): where the V variables of a launch live and what they draw -- var_block[v] = block of bel_in / bel_out
+// (nullptr: v; bel_in == bel_out is allowed then: a product only reads its own variable's block), var_stream[v] = Philox stream id
+// (nullptr: v), mirror_slot[v] = block of mirror_out (stride doubles apart) the new belief is ALSO written to (-1 / nullptr: none)
+struct GibbsPlace { const int32_t* var_block; const int32_t* var_stream; const int32_t* mirror_slot; double* mirror_out; int64_t mirror_stride; };
 hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
                                 const double* prop_bw, const double* bel_in, double* bel_out, void* trees, uint32_t circ, int iters, int max_k,
-                                uint64_t seed, uint64_t stream_offset, hipStream_t s);
+                                uint64_t seed, uint64_t stream_offset, hipStream_t s, const GibbsPlace* place = nullptr);
+// store <-> blocks of a device buffer, one launch: entry k = (dim, var, block, type); to_store: belief `var` of the type's store array
+// <- block `block` of buf (stride doubles apart); else the reverse (a contiguous download buffer <- scattered beliefs)
+hipError_t launch_scatter_blocks(int n, int N, const int32_t* ent /*[n][4]*/, const double* buf, int64_t stride,
+                                 double* st2, double* st_pt, double* st3, hipStream_t s, int to_store);
 
 }  // namespace rome

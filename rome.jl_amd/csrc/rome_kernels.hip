@@ -680,7 +680,7 @@ __device__ __forceinline__ void conv_wave_body(const ConvArgs& a, int blk) {
   const double* __restrict__ fb = a.bel_fixed + (size_t)fv * FP::DF * N;
   const double* __restrict__ tb = a.bel_target + (size_t)tv * FP::DT * N;
   double* __restrict__ ob = a.out + (size_t)c * FP::DT * N;
-  const uint64_t stream = a.stream_offset + (uint64_t)c;
+  const uint64_t stream = a.stream_offset + (uint64_t)((!LEAN && a.row_stream) ? a.row_stream[c] : c);
 
   double fx[PPL][FP::DF], t[PPL][FP::DT], z[PPL][FP::DZ];
   typename FP::Prep prep[PPL];
@@ -1093,7 +1093,7 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
   const double* __restrict__ fb = a.bel_fixed + (size_t)fv * FP::DF * N;
   const double* tb = a.bel_target + (size_t)tv * FP::DT * N;
   double* ob = a.out + (size_t)c * FP::DT * N;
-  const uint64_t stream = a.stream_offset + (uint64_t)c;
+  const uint64_t stream = a.stream_offset + (uint64_t)(a.row_stream ? a.row_stream[c] : c);
   const bool cyc_on = FP::needs_cycles(SOLVER, K);
   const int ncyc = cyc_on ? (a.cycles < 1 ? 1 : a.cycles) : 1;
   constexpr bool kElide = SOLVER == kSolverGaussNewton && FP::kUniqueRoot;
@@ -1202,7 +1202,7 @@ __global__ void __launch_bounds__(256) k_sample_prior(const ConvArgs a) {
   const double* mu = a.mu + (size_t)D * f;
   const double* L = a.L + (size_t)NL * f;
   double* ob = a.out + (size_t)c * D * N;
-  const uint64_t stream = a.stream_offset + (uint64_t)c;
+  const uint64_t stream = a.stream_offset + (uint64_t)(a.row_stream ? a.row_stream[c] : c);
 #pragma unroll(PPL <= 8 ? PPL : 1)
   for (int k = 0; k < PPL; ++k) {
     const int i = lane + 64 * k;
@@ -1375,7 +1375,7 @@ static hipError_t launch_flat(const ConvArgs& a, hipStream_t s) {
 }
 template <class FP, int SOLVER>
 static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
-  const bool lean = a.rows4 != nullptr && a.noise == nullptr && a.alt_var == nullptr && a.nullhypo == nullptr;
+  const bool lean = a.rows4 != nullptr && a.noise == nullptr && a.alt_var == nullptr && a.nullhypo == nullptr && a.row_stream == nullptr;
   if constexpr (FP::kUniqueRoot && (SOLVER == kSolverClosedForm || SOLVER == kSolverNewton)) {
     // plain sweep of a unique-root factor: the packed kernel (rows of >= 8 pair-threads; tiny N stays one wavefront per row)
     if (lean && a.N >= 16 && (a.N + 1) / 2 <= kFlatThreads) return launch_flat<FP, SOLVER>(a, s);
@@ -1402,7 +1402,7 @@ hipError_t launch_conv_pose3pose3(const ConvArgs& a, int solver, hipStream_t s) 
 hipError_t launch_conv_bearingrange(const ConvArgs& a, int solver, hipStream_t s) {
   return a.dir_all == 0 ? launch_solver<BR<0>>(a, solver, s) : launch_solver<BR<1>>(a, solver, s);
 }
-static bool plain_rows(const ConvArgs& a) { return a.rows4 && !a.noise && !a.alt_var && !a.nullhypo && !a.status; }
+static bool plain_rows(const ConvArgs& a) { return a.rows4 && !a.noise && !a.alt_var && !a.nullhypo && !a.status && !a.row_stream; }
 // the whole sweep of a Pose2 / Point2 graph: fused into one launch when every family takes its plain kernel, else family by family
 hipError_t launch_sweep_pose2(const ConvArgs* p2p2, const ConvArgs* br1, const ConvArgs* br0, int solver, hipStream_t s) {
   const int N = p2p2 ? p2p2->N : (br1 ? br1->N : (br0 ? br0->N : 0));
@@ -1454,6 +1454,23 @@ static hipError_t launch_prior(const ConvArgs& a, hipStream_t s) {
 hipError_t launch_sample_priorpose2(const ConvArgs& a, hipStream_t s) { return launch_prior<3>(a, s); }
 hipError_t launch_sample_priorpose3(const ConvArgs& a, hipStream_t s) { return launch_prior<6>(a, s); }
 hipError_t launch_sample_priorpoint2(const ConvArgs& a, hipStream_t s) { return launch_prior<2>(a, s); }
+
+// ---- store <-> blocks of a device buffer (the receive side of a frontier exchange / a contiguous download buffer): one 256-thread
+//      block per belief
+__global__ void __launch_bounds__(256) k_scatter_blocks(int N, const int4* __restrict__ ent, double* buf, long long stride,
+                                                        double* d2, double* dpt, double* d3, int to_store) {
+  const int4 e = ent[blockIdx.x];   // (dim, var, block, type)
+  double* sv = (e.w == 0 ? d2 : (e.w == 1 ? dpt : d3)) + (size_t)e.y * e.x * N;
+  double* bb = buf + (size_t)e.z * (size_t)stride;
+  if (to_store) { for (int q = threadIdx.x; q < e.x * N; q += 256) sv[q] = bb[q]; }
+  else { for (int q = threadIdx.x; q < e.x * N; q += 256) bb[q] = sv[q]; }
+}
+hipError_t launch_scatter_blocks(int n, int N, const int32_t* ent, const double* buf, int64_t stride, double* st2, double* st_pt, double* st3,
+                                 hipStream_t s, int to_store) {
+  if (n > 0) hipLaunchKernelGGL(k_scatter_blocks, dim3(n), dim3(256), 0, s, N, reinterpret_cast<const int4*>(ent), const_cast<double*>(buf), (long long)stride,
+                                st2, st_pt, st3, to_store);
+  return hipGetLastError();
+}
 
 static inline dim3 rows_grid(int n) { return dim3((n + 255) / 256); }
 hipError_t launch_residual_pose2pose2(int n, const double* z, const double* p, const double* q, double* r, hipStream_t s) {

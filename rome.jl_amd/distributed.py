@@ -423,51 +423,67 @@ class TargetShardedSweep:
 
 
 class FrontierShard:
-    """The clique FRONTIER sharded across GPUs (north_star: "the Bayes-tree clique frontier shards naturally across the 8
-    GPUs with separator-belief messages exchanged via RCCL"): the independent cliques of a frontier are dealt round-robin to the ranks,
-    every rank up-solves its share in ONE `rome_clique_upsolve` call (`upGibbsCliqueFrontier`), and ONE all-gather of the updated frontal
-    beliefs -- fixed-size blocks of 6N doubles, padded to the largest share -- leaves every rank with all new beliefs: the separator
-    messages the next frontier reads.  Every rank knows the clique list, so the block order needs no metadata exchange.
-    Philox streams: rank r draws stream_offset + (r << 40) + ...: the result equals running the shares one after the other in one
-    process with those offsets (tests/test_distributed_gloo.py)."""
+    """The clique FRONTIER sharded across GPUs, device-resident (north_star: "the Bayes-tree clique frontier shards
+    naturally across the 8 GPUs with separator-belief messages exchanged via RCCL over xGMI").
 
-    def __init__(self, torch, dist, world, rank, device="cpu", upsolve=None):
-        self.torch, self.dist, self.world, self.rank, self.device = torch, dist, world, rank, device
-        if upsolve is None:
-            from .clique import upGibbsCliqueFrontier
-            upsolve = upGibbsCliqueFrontier
-        self.upsolve = upsolve
+    Every rank holds the beliefs of the whole graph in a `DeviceStore` (8.4 MB for Manhattan-3500): uploaded ONCE.  A frontier of
+    independent cliques is dealt round-robin to the ranks; `plan(cliques)` builds, once per frontier (a tree level: reused by every
+    pass of the solve),
+      * an `UpsolvePlan` for this rank's share -- row tables on the device, Philox stream ids = positions in the WHOLE frontier's
+        tables (`plan_frontier`), so the shares together draw exactly what ONE unsharded call draws: the result does not depend on
+        the number of ranks (tests: world 2 and world 8 with empty shares == the single call, bit for bit);
+      * the exchange layout: blocks of 6N doubles, `width` = the largest share; rank r's k-th new frontal is block r * width + k of
+        the receive buffer -- every rank knows the clique list, so no metadata travels;
+      * a `ScatterPlan` (receive buffer -> store) over the blocks of the other ranks.
+    `step(plan, opts)` = the share's up-solve (its product kernel writes the new frontal beliefs in place AND into this rank's slice
+    of the receive buffer: no gather kernel), ONE all-gather in place (direct `ncclAllGather` on the context's stream when `comm` is
+    given, else torch.distributed), ONE scatter launch.  No belief crosses PCIe after the initial upload; nothing synchronises with
+    the host.
+    store_cls / plan_cls / scatter_cls: injected by the CPU tests (oracle-backed stand-ins over torch CPU tensors)."""
 
-    def shares(self, cliques):
-        return [list(cliques[r::self.world]) for r in range(self.world)]
+    def __init__(self, store, torch, dist, world, rank, device="cpu", comm=None, always_collective=False, plan_cls=None, scatter_cls=None):
+        self.store, self.torch, self.dist, self.world, self.rank, self.device = store, torch, dist, world, rank, device
+        self.comm, self.always_collective = comm, always_collective
+        if plan_cls is None:
+            from .clique import UpsolvePlan, ScatterPlan
+            plan_cls, scatter_cls = UpsolvePlan, ScatterPlan
+        self.plan_cls, self.scatter_cls = plan_cls, scatter_cls
 
-    def step(self, fg, cliques, seed=0x524F4D45, stream_offset=0, **kw):
-        """up-solve the frontier, store ALL new frontal beliefs in `fg` on every rank -> {label: points}"""
-        torch, N = self.torch, fg.N
-        shares = self.shares(cliques)
-        mine = shares[self.rank]
-        res = self.upsolve(fg, mine, seed=seed, stream_offset=stream_offset + (self.rank << 40), setvals=False, **kw) if mine else {}
-        order = [[l for c in sh for l in c] for sh in shares]
+    def shares(self, n_cliques):
+        return [list(range(r, n_cliques, self.world)) for r in range(self.world)]
+
+    def plan(self, cliques, gibbsIters=3, Niter=1, usable=None):
+        torch, N = self.torch, self.store.N
+        cliques = [list(c) for c in cliques]
+        shares = self.shares(len(cliques))
+        labels = [[l for k in sh for l in cliques[k]] for sh in shares]
         U = 6 * N
-        width = max(1, max(len(o) for o in order))
-        send = torch.zeros(width * U, dtype=torch.float64)
-        for k, l in enumerate(order[self.rank]):
-            pts = np.asarray(res[l][0], dtype=np.float64)
-            send[k * U: k * U + pts.size] = torch.as_tensor(pts.reshape(-1))
-        send = send.to(self.device)
-        recv = torch.empty(self.world * width * U, dtype=torch.float64, device=self.device)
-        if self.world > 1 or getattr(self, "always_collective", False):
-            self.dist.all_gather_into_tensor(recv, send)
-        else:
-            recv.copy_(send)
-        host = recv.cpu().numpy().reshape(self.world, width, U)
-        out = {}
-        for r in range(self.world):
-            for k, l in enumerate(order[r]):
-                d = fg.variables[l].dim
-                out[l] = host[r, k, :d * N].reshape(d, N).copy()
-                fg.initVariable(l, out[l])
-        return out
+        width = max(1, max(len(x) for x in labels))
+        recv = torch.zeros(self.world * width * U, dtype=torch.float64, device=self.device)
+        send = recv[self.rank * width * U:(self.rank + 1) * width * U]            # in place: this rank's slice of the receive buffer
+        mine = labels[self.rank]
+        up = self.plan_cls(self.store, cliques, share=shares[self.rank], gibbsIters=gibbsIters, Niter=Niter,
+                           mirror={l: k for k, l in enumerate(mine)}, usable=usable) if mine else None
+        # (always_collective: the one-rank measurement form -- the own blocks go through the exchange buffer and the scatter too)
+        others = [(l, r * width + k) for r in range(self.world) if r != self.rank or self.always_collective for k, l in enumerate(labels[r])]
+        sc = self.scatter_cls(self.store, [l for l, _ in others], [b for _, b in others], stride=U) if others else None
+        return dict(up=up, scatter=sc, recv=recv, send=send, width=width, U=U, labels=labels)
+
+    def step(self, plan, opts):
+        """up-solve this rank's share, exchange, scatter: afterwards every rank's store holds ALL new frontal beliefs"""
+        st = None
+        if getattr(self.device, "type", str(self.device)) == "cuda" and hasattr(self.store, "ctx"):
+            st = self.torch.cuda.current_stream(self.device).cuda_stream       # launches, collective and scatter on ONE stream
+            self.store.ctx.set_stream(st)
+        if plan["up"] is not None:
+            plan["up"].run(opts, mirror_out=plan["send"], mirror_stride=plan["U"])
+        if self.world > 1 or self.always_collective:
+            if self.comm is not None:
+                self.comm.all_gather_f64(plan["send"].data_ptr(), plan["recv"].data_ptr(), plan["send"].numel(), st)
+            else:
+                self.dist.all_gather_into_tensor(plan["recv"], plan["send"].clone())
+        if plan["scatter"] is not None:
+            plan["scatter"].run(plan["recv"])
 
 
 class LinearizeShard:

@@ -21,6 +21,7 @@ class FactorGraph:
         self.factors = []                    # (label, [var labels], factor)
         self.vals = {}                       # label -> (dim, N) coordinates (belief particles)
         self.multihypo = {}                  # factor label -> (w1, w2)
+        self.nullhypo = {}                   # factor label -> p (IIF addFactor!(...; nullhypo=p), test/testPose3Pose3NH.jl:118)
         self._findex = {}                    # factor label -> (label, [var labels], factor)   (getFactor in O(1))
 
     # -- DFG-style API --
@@ -36,8 +37,9 @@ class FactorGraph:
     def ls(self):
         return list(self.variables)
 
-    def addFactor(self, labels, factor, multihypo=None):
-        """multihypo=[1.0, w1, w2] (IIF kwarg, test/testMultimodalRangeBearing.jl:53): the SECOND variable of a two-variable factor is
+    def addFactor(self, labels, factor, multihypo=None, nullhypo=None):
+        """nullhypo=p (IIF kwarg, test/testPose3Pose3NH.jl:118): with probability p the factor does not apply to a particle.
+        multihypo=[1.0, w1, w2] (IIF kwarg, test/testMultimodalRangeBearing.jl:53): the SECOND variable of a two-variable factor is
         labels[1] with probability w1 or labels[2] with probability w2 -- a Pose2Point2BearingRange over [pose, l1, l2] (every use in
         the reference) or a Pose2Pose2 over [a, b1, b2] (IIF accepts the keyword on any factor)."""
         labels = list(labels)
@@ -71,6 +73,10 @@ class FactorGraph:
         self._findex[flabel] = self.factors[-1]
         if extra is not None:
             self.multihypo[flabel] = (w[1], w[2])
+        if nullhypo:
+            if not 0.0 <= float(nullhypo) <= 1.0:
+                raise ValueError("nullhypo must be a probability")
+            self.nullhypo[flabel] = float(nullhypo)
         return flabel
 
     def deleteFactor(self, flabel):
@@ -81,6 +87,7 @@ class FactorGraph:
         self.factors.pop(k[0])
         self._findex.pop(flabel, None)
         self.multihypo.pop(flabel, None)
+        self.nullhypo.pop(flabel, None)
 
     def getFactor(self, flabel):
         f = getattr(self, "_findex", {}).get(flabel)

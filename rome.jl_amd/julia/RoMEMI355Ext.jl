@@ -179,47 +179,82 @@ struct RomeCliqueHost            # include/rome_mi355.h: rome_clique_host
   br1_rows4::Ptr{Int32}; br0_rows4::Ptr{Int32}; br_mu::Ptr{Float64}; br_sigma::Ptr{Float64}; out_br1::Ptr{Float64}; out_br0::Ptr{Float64}
   n_p3p3::Int32; f_p3p3::Int32; p3p3_rows4::Ptr{Int32}; p3p3_mu::Ptr{Float64}; p3p3_cov::Ptr{Float64}; out_p3p3::Ptr{Float64}
   n_prpt2::Int32; f_prpt2::Int32; prpt2_rows4::Ptr{Int32}; prpt2_mu::Ptr{Float64}; prpt2_cov::Ptr{Float64}; out_prpt2::Ptr{Float64}   # PriorPoint2 rows
+  # per-row hypothesis columns (C_NULL = none): multihypo=[1, w, 1-w] -> <fam>_alt (index of the other candidate, -1 = ordinary row) +
+  # <fam>_hypo_w; nullhypo=p -> <fam>_nullhypo
+  p2p2_alt::Ptr{Int32}; p2p2_hypo_w::Ptr{Float64}; p2p2_nullhypo::Ptr{Float64}
+  br1_alt::Ptr{Int32}; br1_hypo_w::Ptr{Float64}; br1_nullhypo::Ptr{Float64}
+  br0_alt::Ptr{Int32}; br0_hypo_w::Ptr{Float64}; br0_nullhypo::Ptr{Float64}
+  p3p3_nullhypo::Ptr{Float64}
+  # per-row Philox stream ids (C_NULL = the row's index): see the header
+  p2p2_stream::Ptr{Int32}; br1_stream::Ptr{Int32}; br0_stream::Ptr{Int32}; p3p3_stream::Ptr{Int32}; prpt2_stream::Ptr{Int32}
 end
 
-const _accelerated = Union{Pose2Pose2, PriorPose2, Pose2Point2BearingRange{<:Normal,<:Normal}, Pose3Pose3, PriorPose3}
+const _accelerated = Union{Pose2Pose2, PriorPose2, Pose2Point2BearingRange{<:Normal,<:Normal}, Pose3Pose3, PriorPose3, PriorPoint2}
+# IIF keeps `multihypo=[1, w, 1-w]` / `nullhypo=p` in the factor's solver data; the batch carries them as per-row columns for a
+# bearing-range or Pose2Pose2 factor over [first, cand1, cand2] (every use in the reference: test/testMultimodalRangeBearing.jl:53)
+_mh(fc) = (m = getSolverData(fc).multihypo; (m === nothing || isempty(m)) ? nothing : m)
+_nh(fc) = (n = getSolverData(fc).nullhypo; n === nothing ? 0.0 : Float64(n))
+_batchable(fc) = (f = getFactorType(fc); f isa _accelerated &&
+                  (_mh(fc) === nothing || (f isa Union{Pose2Pose2,Pose2Point2BearingRange} && length(_mh(fc)) == 3 && _mh(fc)[1] == 1.0)))
 
 # row tables of a list of (factor, destination) pairs over the variables they touch: what rome_clique_host carries
 function _clique_tables(dfg::AbstractDFG, pairs::AbstractVector; solveKey::Symbol=:default, extra_vars::AbstractVector{Symbol}=Symbol[])
   vidx = Dict{Symbol,Int32}(); vars = Dict(Pose2 => Symbol[], Point2 => Symbol[], Pose3 => Symbol[])
   var!(l) = get!(vidx, l) do; T = typeof(getVariableType(dfg, l)); push!(vars[T], l); Int32(length(vars[T]) - 1); end
-  rows = Dict(:p2p2 => Int32[], :br1 => Int32[], :br0 => Int32[], :p3p3 => Int32[])
-  tabμ = Dict(:p2p2 => Float64[], :br => Float64[], :p3p3 => Float64[]); tabΣ = Dict(:p2p2 => Float64[], :br => Float64[], :p3p3 => Float64[])
-  nfac = Dict(:p2p2 => 0, :br => 0, :p3p3 => 0); order = Tuple{Symbol,Int}[]
+  fams = (:p2p2, :br1, :br0, :p3p3, :prpt2)
+  rows = Dict(f => Int32[] for f in fams)
+  alt = Dict(f => Int32[] for f in fams); hw = Dict(f => Float64[] for f in fams); nh = Dict(f => Float64[] for f in fams)
+  tabμ = Dict(f => Float64[] for f in (:p2p2, :br, :p3p3, :prpt2)); tabΣ = Dict(f => Float64[] for f in (:p2p2, :br, :p3p3, :prpt2))
+  nfac = Dict(:p2p2 => 0, :br => 0, :p3p3 => 0, :prpt2 => 0); order = Tuple{Symbol,Int}[]
   for (fc, destlbl) in pairs
-    f = getFactorType(fc); vo = getVariableOrder(fc)
-    if f isa Union{PriorPose2,PriorPose3}
-      fam = f isa PriorPose2 ? :p2p2 : :p3p3
-      append!(tabμ[fam], mean(f.Z)); append!(tabΣ[fam], vec(collect(cov(f.Z))'))
-      append!(rows[fam], Int32[nfac[fam], 2, var!(destlbl), var!(destlbl)]); nfac[fam] += 1
-    elseif f isa Union{Pose2Pose2,Pose3Pose3}
-      fam = f isa Pose2Pose2 ? :p2p2 : :p3p3
-      dir = vo[2] == destlbl ? 0 : 1; other = dir == 0 ? vo[1] : vo[2]
-      append!(tabμ[fam], mean(f.Z)); append!(tabΣ[fam], vec(collect(cov(f.Z))'))
-      append!(rows[fam], Int32[nfac[fam], dir, var!(other), var!(destlbl)]); nfac[fam] += 1
+    f = getFactorType(fc); vo = getVariableOrder(fc); m = _mh(fc)
+    a, w = Int32(-1), 1.0
+    if f isa Union{PriorPose2,PriorPose3,PriorPoint2}
+      fam = f isa PriorPose2 ? :p2p2 : f isa PriorPose3 ? :p3p3 : :prpt2; tab = fam
+      append!(tabμ[tab], mean(f.Z)); append!(tabΣ[tab], vec(collect(cov(f.Z))'))
+      append!(rows[fam], Int32[nfac[tab], 2, var!(destlbl), var!(destlbl)])
     else
-      dir = vo[2] == destlbl ? 0 : 1; other = dir == 0 ? vo[1] : vo[2]; fam = dir == 0 ? :br0 : :br1
-      append!(tabμ[:br], Float64[mean(f.bearing), mean(f.range)]); append!(tabΣ[:br], Float64[std(f.bearing), std(f.range)])
-      append!(rows[fam], Int32[nfac[:br], dir, var!(other), var!(destlbl)]); nfac[:br] += 1
+      if m === nothing
+        dir = vo[2] == destlbl ? 0 : 1; other = dir == 0 ? vo[1] : vo[2]
+      elseif destlbl == vo[1]                   # solve the first variable: the fixed candidate is drawn per particle
+        dir, other, a, w = 1, vo[2], var!(vo[3]), m[2]
+      else                                      # solve one of the candidates: particles drawn for the other one only get entropy
+        own, oth, w = destlbl == vo[2] ? (vo[2], vo[3], m[2]) : (vo[3], vo[2], m[3])
+        dir, other, a = 0, vo[1], var!(oth)
+      end
+      if f isa Union{Pose2Pose2,Pose3Pose3}
+        fam = f isa Pose2Pose2 ? :p2p2 : :p3p3; tab = fam
+        append!(tabμ[tab], mean(f.Z)); append!(tabΣ[tab], vec(collect(cov(f.Z))'))
+      else
+        fam = dir == 0 ? :br0 : :br1; tab = :br
+        append!(tabμ[tab], Float64[mean(f.bearing), mean(f.range)]); append!(tabΣ[tab], Float64[std(f.bearing), std(f.range)])
+      end
+      append!(rows[fam], Int32[nfac[tab], dir, var!(other), var!(destlbl)])
     end
+    nfac[tab] += 1
+    push!(alt[fam], a); push!(hw[fam], w); push!(nh[fam], f isa Union{PriorPose2,PriorPose3,PriorPoint2} ? 0.0 : _nh(fc))
     push!(order, (fam, length(rows[fam]) ÷ 4))
   end
   foreach(var!, extra_vars)
   # beliefs: the reference's point containers as they are for Pose2 (6 doubles) / Pose3 (12 doubles) = ROME_LAYOUT_AOS_POINTS
   blk(T) = isempty(vars[T]) ? Float64[] : reduce(vcat, [reinterpret(Float64, getVal(dfg, l; solveKey)) for l in vars[T]])
-  (; vidx, vars, rows, tabμ, tabΣ, nfac, order, b2 = blk(Pose2), bl = blk(Point2), b3 = blk(Pose3))
+  # hypothesis columns only where a row carries one (C_NULL otherwise: the plain kernels)
+  for fam in fams
+    any(>=(0), alt[fam]) || (empty!(alt[fam]); empty!(hw[fam]))
+    any(>(0.0), nh[fam]) || empty!(nh[fam])
+  end
+  (; vidx, vars, rows, alt, hw, nh, tabμ, tabΣ, nfac, order, b2 = blk(Pose2), bl = blk(Point2), b3 = blk(Pose3))
 end
 _p(x) = isempty(x) ? Ptr{eltype(x)}(C_NULL) : pointer(x)
-_clique_host(t, o2, o1, o0, o3) =
+_clique_host(t, o2, o1, o0, o3, opt = Float64[]) =
   RomeCliqueHost(length(t.vars[Pose2]), length(t.vars[Point2]), length(t.vars[Pose3]), 0, _p(t.b2), _p(t.bl), _p(t.b3),
                  length(t.rows[:p2p2]) ÷ 4, t.nfac[:p2p2], _p(t.rows[:p2p2]), _p(t.tabμ[:p2p2]), _p(t.tabΣ[:p2p2]), _p(o2),
                  length(t.rows[:br1]) ÷ 4, length(t.rows[:br0]) ÷ 4, t.nfac[:br], 0, _p(t.rows[:br1]), _p(t.rows[:br0]), _p(t.tabμ[:br]), _p(t.tabΣ[:br]), _p(o1), _p(o0),
                  length(t.rows[:p3p3]) ÷ 4, t.nfac[:p3p3], _p(t.rows[:p3p3]), _p(t.tabμ[:p3p3]), _p(t.tabΣ[:p3p3]), _p(o3),
-                 0, 0, Ptr{Int32}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL))   # (PriorPoint2 rows: not batched by this shim yet)
+                 length(t.rows[:prpt2]) ÷ 4, t.nfac[:prpt2], _p(t.rows[:prpt2]), _p(t.tabμ[:prpt2]), _p(t.tabΣ[:prpt2]), _p(opt),
+                 _p(t.alt[:p2p2]), _p(t.hw[:p2p2]), _p(t.nh[:p2p2]), _p(t.alt[:br1]), _p(t.hw[:br1]), _p(t.nh[:br1]),
+                 _p(t.alt[:br0]), _p(t.hw[:br0]), _p(t.nh[:br0]), _p(t.nh[:p3p3]),
+                 Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL))
 _points_opts(dfg, N) = (d0 = default_opts(dfg);
   RomeOpts(Int32(N), d0.solver, d0.max_iters, d0.inflate_cycles, d0.tol, d0.inflation, d0.seed, d0.stream_offset, 2 #=points=#, 0, d0.spread_nh, 0.0))
 
@@ -229,20 +264,20 @@ _points_opts(dfg, N) = (d0 = default_opts(dfg);
 function proposalbeliefs_mi355!(dfg::AbstractDFG, destlbl::Symbol, factors::AbstractVector{<:DFGFactor},
                                 dens::AbstractVector, measurement::AbstractVector=Tuple[];
                                 solveKey::Symbol=:default, N::Integer=getSolverParams(dfg).N, kw...)
-  fast = [fc for fc in factors if getFactorType(fc) isa _accelerated && isnothing(getSolverData(fc).multihypo)]
+  fast = [fc for fc in factors if _batchable(fc)]     # multihypo / nullhypo factors travel as per-row columns of the batch
   slow = [fc for fc in factors if !(fc in fast)]
   t = _clique_tables(dfg, [(fc, destlbl) for fc in fast]; solveKey)
   out(fam, w) = Vector{Float64}(undef, (length(t.rows[fam]) ÷ 4) * N * w)
-  o2, o1, o0, o3 = out(:p2p2, 6), out(:br1, 6), out(:br0, 2), out(:p3p3, 12)
+  o2, o1, o0, o3, opt = out(:p2p2, 6), out(:br1, 6), out(:br0, 2), out(:p3p3, 12), out(:prpt2, 2)
   o = _points_opts(dfg, N)
-  GC.@preserve t o2 o1 o0 o3 begin
-    q = _clique_host(t, o2, o1, o0, o3)
+  GC.@preserve t o2 o1 o0 o3 opt begin
+    q = _clique_host(t, o2, o1, o0, o3, opt)
     check(ccall((:rome_clique_proposals, LIB), Cint, (Ptr{Cvoid}, Ref{RomeOpts}, Ref{RomeCliqueHost}), ctx().h, o, q))
   end
   T = typeof(getVariableType(dfg, destlbl)); M = getManifold(T)
   P = eltype(getVal(dfg, destlbl; solveKey))
   for (fam, r) in t.order
-    buf, w = fam == :p2p2 ? (o2, 6) : fam == :br1 ? (o1, 6) : fam == :br0 ? (o0, 2) : (o3, 12)
+    buf, w = fam == :p2p2 ? (o2, 6) : fam == :br1 ? (o1, 6) : fam == :br0 ? (o0, 2) : fam == :prpt2 ? (opt, 2) : (o3, 12)
     pts = collect(reinterpret(P, view(buf, (r - 1) * N * w + 1 : r * N * w)))
     push!(dens, manikde!(M, pts))             # the KDE wrap (bandwidth selection) stays in AMP; rome_kde_bandwidth can supply it
   end
@@ -279,14 +314,20 @@ struct RomeCliqueUpsolveHost     # include/rome_mi355.h: rome_clique_upsolve_hos
   new_pose2::Ptr{Float64}; bw_pose2::Ptr{Float64}; new_point2::Ptr{Float64}; bw_point2::Ptr{Float64}
   new_pose3::Ptr{Float64}; bw_pose3::Ptr{Float64}
   up_group::Ptr{Int32}          # optional update groups (a frontier of independent cliques in one call); C_NULL: follow `schedule`
+  up_stream::Ptr{Int32}         # optional product stream ids (partition-independent frontiers); C_NULL: position within the type
+  up_mirror::Ptr{Int32}         # rome_upsolve_plan only: blocks of a device send buffer; C_NULL here
 end
 
 function upsolve_clique!(dfg::AbstractDFG, frontals::AbstractVector{Symbol}, factors::AbstractVector{<:DFGFactor};
                          gibbsIters::Integer=3, Niter::Integer=1, sequential::Bool=true,
                          solveKey::Symbol=:default, N::Integer=getSolverParams(dfg).N)
+  # Every factor of a frontal must be batchable: dropping one silently would write back a clique posterior that omits it.  A clique
+  # with any other factor (a user factor, a partial, a multihypo over more than two candidates) goes to IIF's own upGibbsCliqueDensity.
+  touching = [fc for fc in factors if any(in(getVariableOrder(fc)), frontals)]
+  bad = [getLabel(fc) for fc in touching if !_batchable(fc)]
+  isempty(bad) || throw(ArgumentError("upsolve_clique!: factors $(bad) are outside the accelerated set; use IIF's upGibbsCliqueDensity for this clique"))
   # pairs grouped by frontal in Gibbs order (the library checks the grouping)
-  pairs = [(fc, l) for l in frontals for fc in factors
-           if l in getVariableOrder(fc) && getFactorType(fc) isa _accelerated && isnothing(getSolverData(fc).multihypo)]
+  pairs = [(fc, l) for l in frontals for fc in touching if l in getVariableOrder(fc)]
   t = _clique_tables(dfg, pairs; solveKey, extra_vars = collect(frontals))
   tcode(l) = (T = typeof(getVariableType(dfg, l)); T === Pose2 ? Int32(0) : T === Point2 ? Int32(1) : Int32(2))
   upt = Int32[tcode(l) for l in frontals]; upv = Int32[t.vidx[l] for l in frontals]
@@ -300,7 +341,7 @@ function upsolve_clique!(dfg::AbstractDFG, frontals::AbstractVector{Symbol}, fac
     u = RomeCliqueUpsolveHost(_clique_host(t, Float64[], Float64[], Float64[], Float64[]),
                               Int32(gibbsIters), Int32(Niter), Int32(sequential ? 0 : 1), Int32(length(frontals)), pointer(upt), pointer(upv),
                               0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
-                              _p(new2), _p(bw2), _p(newl), _p(bwl), _p(new3), _p(bw3), Ptr{Int32}(C_NULL))
+                              _p(new2), _p(bw2), _p(newl), _p(bwl), _p(new3), _p(bw3), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL))
     check(ccall((:rome_clique_upsolve, LIB), Cint, (Ptr{Cvoid}, Ref{RomeOpts}, Ref{RomeCliqueUpsolveHost}), ctx().h, o, u))
   end
   k = Dict(0 => 0, 1 => 0, 2 => 0)

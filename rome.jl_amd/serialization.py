@@ -173,7 +173,6 @@ def loadDFG(path, solveKey="default"):
         mh = d.get("multihypo") or None
         fl = fg.addFactor(labels, fac, multihypo=mh)
         if d.get("nullhypo"):
-            fg.nullhypo = getattr(fg, "nullhypo", {})
             fg.nullhypo[fl] = float(d["nullhypo"])
     return fg
 

@@ -3,7 +3,10 @@
  * Checks, with no oracle: (1) reference known answers of the Pose2Pose2 residual functor
  * (test/testParametricSimulated.jl:42-46), (2) a Pose2Pose2 convolution with pre-sampled noise against the
  * closed-form root of SURVEY Appendix A.5 computed right here, (3) error codes, (4) a clique up-solve (IIF upGibbsCliqueDensity) in one
- * call: x1 with an odometry factor from x0 and its own prior -> the product sits where both agree. */
+ * call: x1 with an odometry factor from x0 and its own prior -> the product sits where both agree, (5) a `multihypo=[1,.5,.5]`
+ * bearing-range row in the clique entry (rome_clique_host.br1_alt / br1_hypo_w): the pose proposals land on the rings around BOTH
+ * landmark candidates, (6) the device-resident form: rome_store + rome_upsolve_plan + rome_scatter_plan reproduce (4) bit for bit
+ * with the beliefs staying on the device. */
 #include <string.h>
 #include <math.h>
 #include <stdio.h>
@@ -79,6 +82,57 @@ int main(void) {
     const int32_t upv_bad[1] = {0};   /* the rows target x1, the update list says x0 */
     u.up_var = upv_bad;
     if (rome_clique_upsolve(ctx, &ou, &u) != ROME_ERR_INVALID_ARG) { printf("FAIL up-solve argument check\n"); return 1; }
+    u.up_var = upv;
+    /* (6) the same up-solve device-resident: store <- beliefs once, a plan, a run; the new belief is written in place and mirrored
+     * into a device buffer, from which a scatter plan fills a second store */
+    rome_store *st = NULL, *st2 = NULL; rome_upsolve_plan* plan = NULL; rome_scatter_plan* sc = NULL;
+    static double nb2[3 * N], back[3 * N], back2[3 * N];
+    const int32_t mir[1] = {2};   /* block 2 of the mirror buffer */
+    void* dmir = NULL;
+    CHECK(rome_store_create(ctx, N, 2, 0, 0, &st));
+    CHECK(rome_store_create(ctx, N, 2, 0, 0, &st2));
+    CHECK(rome_store_upload(st, ROME_LAYOUT_SOA, 0, 0, 2, bel));
+    CHECK(rome_dev_alloc(ctx, 3 * 6 * N * sizeof(double), &dmir));
+    u.clique.bel_pose2 = NULL; u.new_pose2 = nb2; u.up_mirror = mir;
+    CHECK(rome_upsolve_plan_create(ctx, st, &ou, &u, &plan));
+    CHECK(rome_upsolve_plan_run(plan, &ou, (double*)dmir, 0));
+    CHECK(rome_store_download(st, ROME_LAYOUT_SOA, 0, 1, 1, back));
+    const int32_t sty[1] = {0}, sva[1] = {1}, sbl[1] = {2};
+    CHECK(rome_scatter_plan_create(ctx, st2, 1, sty, sva, sbl, 0, &sc));
+    CHECK(rome_scatter_plan_run(sc, (const double*)dmir));
+    CHECK(rome_ctx_synchronize(ctx));
+    CHECK(rome_store_download(st2, ROME_LAYOUT_SOA, 0, 1, 1, back2));
+    for (int k = 0; k < 3 * N; ++k)
+      if (nb2[k] != nb[k] || back[k] != nb[k] || back2[k] != nb[k]) { printf("FAIL plan != one-shot up-solve at %d: %g %g %g %g\n", k, nb[k], nb2[k], back[k], back2[k]); return 1; }
+    if (rome_upsolve_plan_run(plan, &ou, NULL, 0) != ROME_ERR_INVALID_ARG) { printf("FAIL plan mirror check\n"); return 1; }
+    rome_scatter_plan_destroy(sc); rome_upsolve_plan_destroy(plan); rome_store_destroy(st); rome_store_destroy(st2);
+    CHECK(rome_dev_free(ctx, dmir));
+  }
+  /* (5) multihypo in the clique entry: pose x0, landmarks l1 = (10, 0), l2 = (30, 0) (test/testMultimodalRangeBearing.jl:27-53) */
+  {
+    static double bp[3 * N], bl[2 * 2 * N], outp[3 * N];
+    rome_opts om; rome_opts_default(&om, ROME_SOLVER_NEWTON); om.n_particles = N; om.layout = ROME_LAYOUT_SOA; om.seed = 9;
+    for (int i = 0; i < N; ++i) {
+      bp[i] = 20.0 * sin(0.37 * i); bp[N + i] = sin(1.1 * i); bp[2 * N + i] = 0.05 * cos(0.3 * i);
+      bl[i] = 10.0 + sin(2.0 * i); bl[N + i] = cos(1.7 * i); bl[2 * N + i] = 30.0 + cos(0.9 * i); bl[3 * N + i] = sin(0.8 * i);
+    }
+    const int32_t rows1[4] = {0, 1, 0, 0};   /* factor 0, dir 1 (solve the pose), fixed l1, target x0 */
+    const int32_t alt1[1] = {1};              /* the other candidate: l2 */
+    const double hw1[1] = {0.5}, mub[2] = {0.0, 20.0}, sgb[2] = {0.1, 1.0};
+    rome_clique_host q; memset(&q, 0, sizeof(q));
+    q.n_pose2 = 1; q.bel_pose2 = bp; q.n_point2 = 2; q.bel_point2 = bl;
+    q.n_br1 = 1; q.f_br = 1; q.br1_rows4 = rows1; q.br_mu = mub; q.br_sigma = sgb; q.out_br1 = outp;
+    q.br1_alt = alt1; q.br1_hypo_w = hw1;
+    CHECK(rome_clique_proposals(ctx, &om, &q));
+    int on1 = 0, on2 = 0;
+    for (int i = 0; i < N; ++i) {
+      const double d1 = hypot(outp[i] - 10.0, outp[N + i]), d2 = hypot(outp[i] - 30.0, outp[N + i]);
+      on1 += fabs(d1 - 20.0) < 5.0; on2 += fabs(d2 - 20.0) < 5.0;
+    }
+    if (on1 < 20 || on1 > 80 || on2 < 20 || on2 > 80) { printf("FAIL multihypo clique row: %d on the l1 ring, %d on the l2 ring\n", on1, on2); return 1; }
+    const int32_t alt_bad[1] = {2};
+    q.br1_alt = alt_bad;
+    if (rome_clique_proposals(ctx, &om, &q) != ROME_ERR_INVALID_ARG) { printf("FAIL multihypo argument check\n"); return 1; }
   }
   rome_ctx_destroy(ctx);
   printf("abi_smoke ok (max |Δ| vs closed form %.2e)\n", worst);

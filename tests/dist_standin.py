@@ -87,3 +87,52 @@ class OracleDG:
         out = self.ro.product_msgibbs(o, dim, ptr.numpy(), rows.numpy(), prop[:max(n_rows, 1)].numpy(), bw[:max(n_rows, 1)].numpy(),
                                       bel_in.numpy(), circ, iters)
         bel_out.copy_(torch.as_tensor(out))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# stand-ins for rome_jl_amd.clique.DeviceStore / UpsolvePlan / ScatterPlan (the device-resident frontier path of FrontierShard): the
+# "device" is a private copy of the graph's beliefs, the up-solve is the oracle's restatement of rome_clique_upsolve with the stream ids
+# of plan_frontier, the mirror / scatter are torch copies -- so that FrontierShard's dealing, block layout and collective run for real.
+class OracleStore:
+    def __init__(self, R, fg):
+        import copy
+        self.R, self.fg, self.N = R, fg, fg.N
+        self.dev = copy.copy(fg)                 # same variables / factors, private belief dict = the "HBM" copy
+        self.dev.vals = {l: v.copy() for l, v in fg.vals.items()}
+        self.index = {}
+        cnt = {}
+        for l, t in fg.variables.items():
+            self.index[l] = cnt.get(t, 0); cnt[t] = cnt.get(t, 0) + 1
+
+    def get(self, label):
+        return self.dev.vals[label]
+
+
+class OraclePlan:
+    def __init__(self, store, cliques, share=None, gibbsIters=3, Niter=1, mirror=None, usable=None, outputs=False, seed_solver=1):
+        from rome_jl_amd.clique import plan_frontier
+        self.store, self.gi, self.pi, self.mirror = store, gibbsIters, Niter, mirror
+        self.fp = plan_frontier(store.fg, cliques, share, usable)
+
+    def run(self, opts, mirror_out=None, mirror_stride=0):
+        from solve_ref import upsolve_ref
+        st, fp = self.store, self.fp
+        ref = upsolve_ref(st.R, st.dev, fp["order"], st.N, seed=int(opts.seed), gibbs_iters=self.gi, product_iters=self.pi, groups=fp["groups"],
+                          stream_offset=int(opts.stream_offset), stream_ids=fp["stream_ids"], up_stream=fp["up_stream"], solver=int(opts.solver))
+        for l in fp["order"]:
+            st.dev.vals[l] = ref[l]
+            if self.mirror is not None and self.mirror.get(l, -1) >= 0:
+                blk = torch.as_tensor(ref[l].reshape(-1))
+                o = self.mirror[l] * int(mirror_stride or 6 * st.N)
+                mirror_out[o:o + blk.numel()].copy_(blk)
+
+
+class OracleScatter:
+    def __init__(self, store, labels, src_blocks, stride=0):
+        self.store, self.labels, self.blocks, self.stride = store, list(labels), list(src_blocks), int(stride or 6 * store.N)
+
+    def run(self, src):
+        st = self.store
+        for l, b in zip(self.labels, self.blocks):
+            d = st.fg.variables[l].dim
+            st.dev.vals[l] = src[b * self.stride:b * self.stride + d * st.N].numpy().reshape(d, st.N).copy()

@@ -73,14 +73,17 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
 
 
 def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iters=1, schedule="sequential", solver=1, messages=None,
-                groups=None, stream_offset=0):
+                groups=None, stream_offset=0, stream_ids=None, up_stream=None, usable=None):
     """Oracle-side restatement of rome_clique_upsolve / R.upGibbsCliqueDensity (IIF upGibbsCliqueDensity): same pairs, same row
-    tables, same Philox streams; every convolution, bandwidth and product through oracle/ (CPU).  -> {label: points (dim, N)}"""
+    tables (multihypo / nullhypo columns included), same Philox streams; every convolution, bandwidth and product through oracle/
+    (CPU).  stream_ids: {(factor, target): id within the family} / up_stream: {label: product stream id} (default: row index /
+    position within the type, as the library).  -> {label: points (dim, N)}"""
     from rome_jl_amd.clique import CliqueBatch
+    usable = usable or fg.isInitialized
     pairs = []
     for dest in frontals:
         for flabel, labels, _ in fg.factors:
-            if dest in labels and all(fg.isInitialized(l) or l in frontals for l in labels if l != dest):
+            if dest in labels and all(usable(l) or l in frontals for l in labels if l != dest):
                 pairs.append((flabel, dest))
     batch = CliqueBatch(fg, pairs)
     for l in frontals:
@@ -91,6 +94,10 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
     bel = {vt: batch.beliefs(vt) for vt in types}
     T = batch.tabs
     rows = {f: np.array(batch.fam_rows[f], dtype=np.int64).reshape(-1, 4) for f in ("p2p2", "br1", "br0", "p3p3", "prpt2")}
+    sid = {f: list(range(len(rows[f]))) for f in rows}
+    if stream_ids is not None:
+        for pair, (fam, r) in batch.rows.items():
+            sid[fam][r] = stream_ids[pair]
     mupt = np.array(T["prpt2"]["mu"]).reshape(-1, 2); Lpt = np.array([ro.cholesky_lower(np.asarray(c).reshape(2, 2)) for c in T["prpt2"]["spread"]]).reshape(-1, 3)
     mu2 = np.array(T["p2p2"]["mu"]).reshape(-1, 3); L2 = np.array([ro.cholesky_lower(np.asarray(c).reshape(3, 3)) for c in T["p2p2"]["spread"]]).reshape(-1, 6)
     mub = np.array(T["br"]["mu"]).reshape(-1, 2); sgb = np.array(T["br"]["spread"]).reshape(-1, 2)
@@ -103,6 +110,8 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
     for l in frontals:
         vt = fg.variables[l]
         pos_in_type[l] = sum(1 for m in frontals[:frontals.index(l)] if fg.variables[m] is vt)
+    if up_stream is not None:
+        pos_in_type = dict(up_stream)
 
     def proposals_for(targets, base):
         """{label: list of (dim, N) proposals in the device's CSR order (p2p2 rows, br1 rows | br0 rows, messages)}"""
@@ -113,22 +122,25 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
             tv = {batch.vidx[l]: l for l in targets if fg.variables[l] is vt}
             sel = [r for r in range(len(rw)) if rw[r, 3] in tv]
             for r in sel:
-                o = ro.make_opts(N=N, solver=solver, seed=seed, stream_offset=base + S[fam] + r)
+                alt, hw, nh = batch.fam_hyp[fam][r]
+                so = base + S[fam] + sid[fam][r]
+                o = ro.make_opts(N=N, solver=solver, seed=seed, stream_offset=so, nullhypo=nh)
+                mh = {} if alt < 0 else dict(alt_var=[alt], hypo_w=[hw])
                 f, d, fx, tg = rw[r]
                 if fam == "p2p2" and d == 2:
-                    p = ro.sample_priorpose2(ro.make_opts(N=N, seed=seed, stream_offset=base + S[fam] + r), mu2[f], L2[f])[0]
+                    p = ro.sample_priorpose2(ro.make_opts(N=N, seed=seed, stream_offset=so), mu2[f], L2[f])[0]
                 elif fam == "p2p2":
-                    p = ro.conv_pose2pose2(o, mu2, L2, bel[R.Pose2], [fx], [tg], [d], factor=[f])[0]
+                    p = ro.conv_pose2pose2(o, mu2, L2, bel[R.Pose2], [fx], [tg], [d], factor=[f], **mh)[0]
                 elif fam == "prpt2":
-                    p = ro.sample_priorpoint2(ro.make_opts(N=N, seed=seed, stream_offset=base + S[fam] + r), mupt[f], Lpt[f])[0]
+                    p = ro.sample_priorpoint2(ro.make_opts(N=N, seed=seed, stream_offset=so), mupt[f], Lpt[f])[0]
                 elif fam == "p3p3" and d == 2:
-                    p = ro.sample_priorpose3(ro.make_opts(N=N, seed=seed, stream_offset=base + S[fam] + r), mu3[f], L3[f])[0]
+                    p = ro.sample_priorpose3(ro.make_opts(N=N, seed=seed, stream_offset=so), mu3[f], L3[f])[0]
                 elif fam == "p3p3":
                     p = ro.conv_pose3pose3(o, mu3, L3, bel[R.Pose3], [fx], [tg], [d], factor=[f])[0]
                 elif fam == "br1":
-                    p = ro.conv_pose2point2br(o, 1, mub, sgb, bel[R.Point2], bel[R.Pose2], [fx], [tg], factor=[f])[0]
+                    p = ro.conv_pose2point2br(o, 1, mub, sgb, bel[R.Point2], bel[R.Pose2], [fx], [tg], factor=[f], **mh)[0]
                 else:
-                    p = ro.conv_pose2point2br(o, 0, mub, sgb, bel[R.Pose2], bel[R.Point2], [fx], [tg], factor=[f])[0]
+                    p = ro.conv_pose2point2br(o, 0, mub, sgb, bel[R.Pose2], bel[R.Point2], [fx], [tg], factor=[f], **mh)[0]
                 out[tv[tg]].append(p)
         for l in targets:
             for pts in (messages or {}).get(l, []):

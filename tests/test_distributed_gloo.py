@@ -572,25 +572,11 @@ def test_target_sharded_solve_step_three_ranks_equals_one_rank():
 
 
 # ---------------------------------------------------------------------------------------------------------
-# FrontierShard: the independent cliques of a frontier dealt to 2 ranks, each up-solving its share (here: the oracle's restatement of
-# rome_clique_upsolve with update groups), ONE all-gather of the new frontal beliefs -> every rank holds all of them; equals the two
-# shares run one after the other in one process with the same stream offsets.
-def _oracle_frontier(R, N):
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from solve_ref import upsolve_ref
-
-    def upsolve(fg, cliques, seed=0, stream_offset=0, setvals=False, **kw):
-        depth = max(len(c) for c in cliques)
-        order, groups = [], []
-        for g in range(depth):
-            for c in cliques:
-                if len(c) > g:
-                    order.append(c[g]); groups.append(g)
-        ref = upsolve_ref(R, fg, order, N, seed=seed, gibbs_iters=2, groups=groups, stream_offset=stream_offset)
-        return {l: (ref[l], None) for l in order}
-    return upsolve
-
-
+# FrontierShard (device-resident form): the independent cliques of a frontier dealt round-robin to the ranks, each up-solving its share
+# through an up-solve PLAN over a resident store (here: oracle-backed stand-ins, tests/dist_standin.py), the new frontal beliefs mirrored
+# into the rank's slice of the receive buffer, ONE all-gather in place, ONE scatter into the store.  Philox streams are positions in the
+# WHOLE frontier's tables (plan_frontier), so ANY number of ranks -- 2, or 8 with empty shares -- reproduces the single unsharded plan
+# bit for bit.
 def _frontier_graph(R, N):
     fg = R.generateGraph_Hexagonal(N=N)
     R.dead_reckon_init(fg, seed=5)
@@ -598,43 +584,67 @@ def _frontier_graph(R, N):
     return fg
 
 
-_FRONTIER = [["x0", "x1"], ["x3"], ["x5"]]
+_FRONTIERS = [[["x0", "x1"], ["x3"], ["x5"]], [["x2"], ["x4"], ["x6", "l1"]]]   # two tree levels: the second reads what the first wrote
 
 
 def _frontier_worker(rank, world, port, ret):
-    sys.path.insert(0, ROOT)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import rome_jl_amd as R
         from rome_jl_amd.distributed import FrontierShard
+        from dist_standin import OracleStore, OraclePlan, OracleScatter
         N = 32
         fg = _frontier_graph(R, N)
-        sh = FrontierShard(torch, dist, world, rank, upsolve=_oracle_frontier(R, N))
-        out = sh.step(fg, _FRONTIER, seed=21)
-        ret[rank] = {l: fg.getVal(l).copy() for l in out}
+        store = OracleStore(R, fg)
+        sh = FrontierShard(store, torch, dist, world, rank, plan_cls=OraclePlan, scatter_cls=OracleScatter)
+        plans = [sh.plan(f, gibbsIters=2) for f in _FRONTIERS]
+        for p in range(2):                                     # two passes over the two levels: the plans are reused
+            for k, pl in enumerate(plans):
+                sh.step(pl, R.make_opts(N=N, seed=21 + p, stream_offset=(2 * p + k) << 40))
+        ret[rank] = {l: store.get(l).copy() for f in _FRONTIERS for c in f for l in c}
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_frontier_shard_two_ranks_equals_the_shares_run_in_one_process():
-    world = 2
+def _frontier_reference(R, N):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_standin import OracleStore, OraclePlan
+    fg = _frontier_graph(R, N)
+    store = OracleStore(R, fg)
+    plans = [OraclePlan(store, f, gibbsIters=2) for f in _FRONTIERS]      # ONE unsharded plan per frontier
+    for p in range(2):
+        for k, pl in enumerate(plans):
+            pl.run(R.make_opts(N=N, seed=21 + p, stream_offset=(2 * p + k) << 40))
+    return fg, {l: store.get(l).copy() for f in _FRONTIERS for c in f for l in c}
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 8])
+def test_frontier_shard_any_world_equals_the_single_unsharded_plan(world):
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_frontier_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     import rome_jl_amd as R
     N = 32
-    fg = _frontier_graph(R, N)
-    ups = _oracle_frontier(R, N)
-    ref = {}
-    for r in range(world):                      # both shares read the SAME incoming beliefs (they are independent cliques)
-        share = _FRONTIER[r::world]
-        for l, (pts, _) in ups(fg, share, seed=21, stream_offset=r << 40).items():
-            ref[l] = pts
-    assert set(ref) == {"x0", "x1", "x3", "x5"}
-    for r in range(world):
+    fg, ref = _frontier_reference(R, N)
+    assert set(ref) == {"x0", "x1", "x2", "x3", "x4", "x5", "x6", "l1"}
+    for r in range(world):                                     # (world 8: ranks 3..7 have empty shares of a 3-clique frontier)
         assert set(ret[r]) == set(ref)
         for l in ref:
-            assert np.array_equal(ret[r][l], ref[l]), (r, l)
+            assert np.array_equal(ret[r][l], ref[l]), (world, r, l)
     assert not np.array_equal(ref["x3"], fg.getVal("x3"))
+
+
+def test_frontier_shard_validates_independence_over_the_whole_frontier():
+    """a factor linking frontals of two cliques is refused whichever rank owns them (plan_frontier checks the full clique list)"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rome_jl_amd as R
+    from rome_jl_amd.distributed import FrontierShard
+    from dist_standin import OracleStore, OraclePlan, OracleScatter
+    fg = _frontier_graph(R, 16)
+    for rank in range(2):
+        sh = FrontierShard(OracleStore(R, fg), torch, None, 2, rank, plan_cls=OraclePlan, scatter_cls=OracleScatter)
+        with pytest.raises(ValueError):
+            sh.plan([["x0"], ["x1"]])                          # x0 -- x1 share an odometry factor; each rank owns one of them

@@ -1,0 +1,270 @@
+"""`multihypo` / `nullhypo` factors inside the clique entries (rome_clique_proposals, rome_clique_upsolve) and the device-resident form
+of the up-solve (rome_store + rome_upsolve_plan): BASELINE configs[3] -- the beehive lattice with ambiguous re-sightings
+(test/testMultimodalRangeBearing.jl:53, src/canonical/GenerateHoneycomb.jl:59-100) -- through the clique / frontier path, against the
+oracle's restatement of the same loop (tests/solve_ref.py::upsolve_ref)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+import rome_jl_amd as R   # noqa: E402
+import oracle as ro       # noqa: E402
+from rome_jl_amd.clique import CliqueBatch, DeviceStore, UpsolvePlan, ScatterPlan, frontier_order, frontier_pairs   # noqa: E402
+from solve_ref import upsolve_ref   # noqa: E402
+
+
+def _beehive(P=20, N=100, seed=4):
+    fg = R.synth_beehive_mh(P, N=N)
+    R.dead_reckon_init(fg, seed=seed)
+    rng = np.random.default_rng(seed)
+    for l, t in fg.variables.items():
+        if t is R.Point2:
+            fg.initVariable(l, np.asarray(fg._sim[l])[:, None] + 0.5 * rng.standard_normal((2, N)))
+    return fg
+
+
+def _wrapdiff(a, b):
+    d = a - b
+    if d.shape[0] == 3:
+        d[2] = np.arctan2(np.sin(d[2]), np.cos(d[2]))
+    return d
+
+
+def _close(got, ref, frac=0.9):
+    """the bars of tests/test_gpu_upsolve.py: > 90 % of the particle coordinates identical to 1e-6, belief means within 1e-3"""
+    d = _wrapdiff(got.copy(), ref)
+    assert np.mean(np.abs(d) < 1e-6) > frac, np.mean(np.abs(d) < 1e-6)
+    assert np.abs(d.mean(axis=1)).max() < 1e-3, d.mean(axis=1)
+
+
+def _independent_frontier(fg, labels):
+    """greedy independent set of `labels` (no factor links two members), as single-frontal cliques"""
+    nb = {}
+    for _, ls, _ in fg.factors:
+        for a in ls:
+            nb.setdefault(a, set()).update(x for x in ls if x != a)
+    chosen = []
+    for l in labels:
+        if not nb.get(l, set()) & set(chosen):
+            chosen.append(l)
+    return [[l] for l in chosen]
+
+
+@pytest.mark.parametrize("solver", [R.SOLVER_NEWTON, R.SOLVER_GAUSS_NEWTON])
+def test_clique_proposals_with_multihypo_rows_equal_the_per_factor_path(solver):
+    """rome_clique_proposals with <fam>_alt / _hypo_w columns == approxConv (rome_conv_*_mh) given the row's Philox stream, bit for bit"""
+    fg = _beehive(20)
+    mh = sorted(fg.multihypo)
+    assert len(mh) >= 4
+    dests = sorted({l for fl in mh for l in fg.getFactor(fl)[1]})
+    props, batch = R.proposalbeliefs(fg, dests, solver=solver, seed=31)
+    n_mh = 0
+    for (fl, dest), (fam, r) in batch.rows.items():
+        ref = R.approxConv(fg, fl, dest, solver=solver, seed=31, stream_offset=R.clique.FAMILY_STREAM[fam] + r)
+        assert np.array_equal(props[(fl, dest)], ref), (fl, dest, fam, r)
+        n_mh += int(fl in fg.multihypo)
+    assert n_mh >= 3 * len(mh)   # every multihypo factor: the pose row and both candidate landmarks
+
+
+def test_clique_proposals_nullhypo_column_equals_the_per_factor_path():
+    N = 100
+    rng = np.random.default_rng(0)
+    fg = R.initfg(N)
+    for k in range(3):
+        fg.addVariable("x%d" % k, R.Pose2)
+        fg.initVariable("x%d" % k, np.array([[5.0 * k + (4.0 if k == 2 else 0.0)], [0.0], [0.0]]) + 0.2 * rng.standard_normal((3, N)))
+    cov = np.diag(np.square([0.1, 0.1, 0.02]))
+    f01 = fg.addFactor(["x0", "x1"], R.Pose2Pose2(R.MvNormal([5.0, 0, 0], cov)))
+    f12 = fg.addFactor(["x1", "x2"], R.Pose2Pose2(R.MvNormal([5.0, 0, 0], cov)), nullhypo=0.5)
+    f20 = fg.addFactor(["x2", "x0"], R.Pose2Pose2(R.MvNormal([-10.0, 0, 0], cov)), nullhypo=0.25)
+    props, batch = R.proposalbeliefs(fg, ["x0", "x1", "x2"], seed=5)
+    for (fl, dest), (fam, r) in batch.rows.items():
+        nh = fg.nullhypo.get(fl, 0.0)
+        ref = R.approxConv(fg, fl, dest, seed=5, stream_offset=R.clique.FAMILY_STREAM[fam] + r, nullhypo=nh)
+        assert np.array_equal(props[(fl, dest)], ref), (fl, dest)
+    # about half of x2's proposals through f12 keep their start value (+ entropy): they are not on the factor's solution
+    p = props[(f12, "x2")]
+    on = np.abs(p[0] - (fg.getVal("x1")[0] + 5.0)) < 1.0
+    assert 0.25 < on.mean() < 0.75
+
+
+def test_upsolve_cliques_of_the_beehive_with_multihypo_equal_the_oracle_loop():
+    """upGibbsCliqueDensity on cliques whose factors carry multihypo sightings (the cliques the library refused in round 3)"""
+    N = 100
+    fg_d, fg_o = _beehive(20, N), _beehive(20, N)
+    mh = sorted(fg_d.multihypo)
+    cliques = []
+    for fl in mh[:4]:
+        pose, l1, l2 = fg_d.getFactor(fl)[1]
+        cliques += [[pose, l1], [l2]]
+    seen = set()
+    for ci, fr in enumerate(cliques):
+        if set(fr) & seen:
+            continue
+        seen |= set(fr)
+        seed = 500 + ci
+        res = R.upGibbsCliqueDensity(fg_d, fr, gibbsIters=3, seed=seed)
+        ref = upsolve_ref(R, fg_o, fr, N, seed=seed, gibbs_iters=3)
+        for l in fr:
+            _close(res[l][0], ref[l])
+            bo = ro.kde_bandwidths(ref[l][None], 0b100 if ref[l].shape[0] == 3 else 0)[0]
+            assert np.allclose(res[l][1], bo, rtol=2e-2)
+            fg_o.initVariable(l, ref[l])
+
+
+def test_frontier_of_the_beehive_with_multihypo_in_one_call_equals_the_oracle():
+    N = 100
+    fg_d, fg_o = _beehive(20, N), _beehive(20, N)
+    poses = [l for l, t in fg_d.variables.items() if t is R.Pose2]
+    frontier = _independent_frontier(fg_d, poses)
+    touched = {l for c in frontier for l in c}
+    assert any(set(fg_d.getFactor(fl)[1]) & touched for fl in fg_d.multihypo) and len(frontier) >= 6
+    res = R.upGibbsCliqueFrontier(fg_d, frontier, gibbsIters=2, seed=91)
+    order, groups = frontier_order(frontier)
+    ref = upsolve_ref(R, fg_o, order, N, seed=91, gibbs_iters=2, groups=groups)
+    for l in order:
+        _close(res[l][0], ref[l])
+    # landmarks (both candidates of the ambiguous sightings) as the next frontier
+    lms = [l for l, t in fg_d.variables.items() if t is R.Point2]
+    for l in order:
+        fg_o.initVariable(l, ref[l])
+    fr2 = _independent_frontier(fg_d, lms)
+    res2 = R.upGibbsCliqueFrontier(fg_d, fr2, gibbsIters=2, seed=92)
+    o2, g2 = frontier_order(fr2)
+    ref2 = upsolve_ref(R, fg_o, o2, N, seed=92, gibbs_iters=2, groups=g2)
+    for l in o2:
+        _close(res2[l][0], ref2[l])
+
+
+def test_reference_multimodal_windows_through_the_clique_call():
+    """test/testMultimodalRangeBearing.jl:27-82 through upGibbsCliqueDensity: l1 ~ N((10,0),I), l2 ~ N((30,0),I), x0 with a north-south
+    prior stand-in, p2br multihypo=[1;.5;.5]: at least two of the reference's four x-windows hold particles of x0 (:73-76); then the
+    landmark testset (:84-130): l2 with x0 near the origin and l1 at (40, 0): some but not all l2 particles lie 20 m from x0."""
+    N = 100
+    rng = np.random.default_rng(1)
+    fg = R.initfg(N)
+    fg.addVariable("l1", R.Point2); fg.addVariable("l2", R.Point2); fg.addVariable("x0", R.Pose2)
+    fg.addFactor(["l1"], R.PriorPoint2(R.MvNormal([10.0, 0.0], np.eye(2))))
+    fg.addFactor(["l2"], R.PriorPoint2(R.MvNormal([30.0, 0.0], np.eye(2))))
+    fg.initVariable("l1", np.array([[10.0], [0.0]]) + rng.standard_normal((2, N)))
+    fg.initVariable("l2", np.array([[30.0], [0.0]]) + rng.standard_normal((2, N)))
+    fg.initVariable("x0", rng.standard_normal((3, N)) * np.array([[20.0], [1.0], [0.05]]))
+    # (NorthSouthPartial is outside the hot path: a wide prior in x, tight in y and heading, stands in for it)
+    fg.addFactor(["x0"], R.PriorPose2(R.MvNormal([20.0, 0.0, 0.0], np.diag(np.square([30.0, 1.0, 0.05])))))
+    fl = fg.addFactor(["x0", "l1", "l2"], R.Pose2Point2BearingRange(R.Normal(0, 0.1), R.Normal(20.0, 1.0)), multihypo=[1.0, 0.5, 0.5])
+    res = R.upGibbsCliqueDensity(fg, ["x0"], gibbsIters=3, seed=3, setvals=False)
+    X0 = res["x0"][0]
+    wins = [(-20, 0), (0, 20), (20, 40), (40, 60)]
+    assert sum(int(((X0[0] > a) & (X0[0] < b)).sum() > 0) for a, b in wins) >= 2
+    ref = upsolve_ref(R, fg, ["x0"], N, seed=3, gibbs_iters=3)["x0"]
+    _close(X0, ref)
+    # landmark direction: clique (l2) with the multihypo factor and its prior; x0 tight at the origin, l1 moved to 40 m
+    fg2 = R.initfg(N)
+    fg2.addVariable("x0", R.Pose2); fg2.addVariable("l1", R.Point2); fg2.addVariable("l2", R.Point2)
+    fg2.initVariable("x0", rng.standard_normal((3, N)) * np.array([[1.0], [1.0], [0.01]]))
+    fg2.initVariable("l1", np.array([[40.0], [0.0]]) + rng.standard_normal((2, N)))
+    fg2.initVariable("l2", np.array([[20.0], [0.0]]) + 10.0 * rng.standard_normal((2, N)))
+    fg2.addFactor(["x0", "l1", "l2"], R.Pose2Point2BearingRange(R.Normal(0, 0.1), R.Normal(20.0, 1.0)), multihypo=[1.0, 0.5, 0.5])
+    L2 = R.upGibbsCliqueDensity(fg2, ["l2"], gibbsIters=1, seed=4, setvals=False)["l2"][0]
+    m = (np.abs(np.hypot(L2[0], L2[1]) - 20.0) < 4.0).sum()
+    assert 5 < m < 95, m
+
+
+def test_pose3_nullhypo_clique_equals_the_oracle_loop():
+    N = 100
+    cov = np.diag(np.square([1, 1, 1, 0.01, 0.01, 0.01]))
+
+    def build():
+        fg = R.initfg(N)
+        fg.addVariable("x1", R.Pose3)
+        f1 = fg.addFactor(["x1"], R.PriorPose3(R.MvNormal(np.zeros(6), cov)))
+        fg.initVariable("x1", R.approxConv(fg, f1, "x1", seed=1))
+        fg.addVariable("x2", R.Pose3); f12 = fg.addFactor(["x1", "x2"], R.Pose3Pose3(R.MvNormal([25.0, 0, 0, 0, 0, 0], cov)))
+        fg.initVariable("x2", R.approxConv(fg, f12, "x2", seed=2))
+        fg.addVariable("x3", R.Pose3); f23 = fg.addFactor(["x2", "x3"], R.Pose3Pose3(R.MvNormal([25.0, 0, 0, 0, 0, 0], cov)))
+        fg.initVariable("x3", R.approxConv(fg, f23, "x3", seed=3))
+        fg.addFactor(["x3", "x1"], R.Pose3Pose3(R.MvNormal([-35.0, 0, 0, 0, 0, 0], cov)), nullhypo=0.5)   # test/testPose3Pose3NH.jl:118
+        return fg
+    fg_d, fg_o = build(), build()
+    res = R.upGibbsCliqueDensity(fg_d, ["x3"], gibbsIters=2, seed=8, setvals=False)["x3"][0]
+    ref = upsolve_ref(R, fg_o, ["x3"], N, seed=8, gibbs_iters=2)["x3"]
+    d = res - ref
+    assert np.mean(np.abs(d[:3]) < 1e-6) > 0.9 and np.abs(d[:3].mean(axis=1)).max() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ device-resident: store + plans
+def test_store_round_trip_and_plan_equals_the_one_shot_call():
+    N = 100
+    fg = _beehive(20, N)
+    store = DeviceStore(fg)
+    for l in list(fg.variables)[:5]:
+        assert np.array_equal(store.get(l), fg.getVal(l))
+    poses = [l for l, t in fg.variables.items() if t is R.Pose2]
+    frontier = _independent_frontier(fg, poses)
+    order, groups = frontier_order(frontier)
+    # one-shot call with the plan's stream ids (row index in the frontier's tables / position within the type: its defaults)
+    ref = R.upGibbsCliqueFrontier(fg, frontier, gibbsIters=2, seed=17, setvals=False)
+    plan = UpsolvePlan(store, frontier, gibbsIters=2, outputs=True)
+    got = plan.run(R.make_opts(N=N, seed=17))
+    for l in order:
+        assert np.array_equal(got[l][0], ref[l][0]), l
+        assert np.array_equal(got[l][1], ref[l][1]), l
+        assert np.array_equal(store.get(l), ref[l][0])      # written in place
+    other = [l for l in fg.variables if l not in order]
+    for l in other[:6]:
+        assert np.array_equal(store.get(l), fg.getVal(l))   # nothing else moved
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_shares_of_a_frontier_equal_the_unsharded_plan_bit_for_bit(world):
+    """partition independence (Philox stream = position in the WHOLE frontier's tables): the frontier dealt to `world` shares -- with
+    empty shares at world 8 -- writes the beliefs the single plan writes; the mirror blocks + a scatter plan reproduce the exchange"""
+    import torch
+    N = 100
+    fg = _beehive(20, N)
+    poses = [l for l, t in fg.variables.items() if t is R.Pose2]
+    frontier = _independent_frontier(fg, poses)[:6]
+    order, _ = frontier_order(frontier)
+    s_ref = DeviceStore(fg)
+    UpsolvePlan(s_ref, frontier, gibbsIters=2).run(R.make_opts(N=N, seed=23))
+    s_sh = DeviceStore(fg)
+    s_rx = DeviceStore(fg)                      # a "remote" replica that only sees the exchange buffer
+    U = 6 * N
+    width = -(-len(frontier) // world)
+    recv = torch.zeros(world * width * U, dtype=torch.float64, device="cuda")
+    labels_rx, blocks_rx = [], []
+    for r in range(world):
+        share = list(range(r, len(frontier), world))
+        mine = [l for k in share for l in frontier[k]]
+        mirror = {l: r * width + k for k, l in enumerate(mine)}
+        labels_rx += mine; blocks_rx += [mirror[l] for l in mine]
+        plan = UpsolvePlan(s_sh, frontier, share=share, gibbsIters=2, mirror=mirror)
+        plan.run(R.make_opts(N=N, seed=23), mirror_out=recv.data_ptr(), mirror_stride=U)
+    assert world == 2 or any(len(range(r, len(frontier), world)) == 0 for r in range(world))
+    ScatterPlan(s_rx, labels_rx, blocks_rx, stride=U).run(recv.data_ptr())
+    s_rx.ctx.synchronize()
+    for l in order:
+        a = s_ref.get(l)
+        assert np.array_equal(s_sh.get(l), a), l
+        assert np.array_equal(s_rx.get(l), a), l
+
+
+def test_plan_argument_checks():
+    N = 100
+    fg = _beehive(13, N)
+    store = DeviceStore(fg)
+    with pytest.raises(ValueError):
+        UpsolvePlan(store, [["x1"], ["x2"]])             # x1 -- x2 share an odometry factor: not independent
+    plan = UpsolvePlan(store, [["x1"], ["x3"]], mirror={"x1": 0, "x3": 1})
+    with pytest.raises(R.RomeError):
+        plan.run(R.make_opts(N=N, seed=1))               # a plan with mirrors needs the buffer
+    with pytest.raises(R.RomeError):
+        plan.run(R.make_opts(N=64, seed=1), mirror_out=1)
+    with pytest.raises(R.RomeError):
+        ScatterPlan(store, ["x1"], [0], stride=10)       # stride shorter than a Pose2 block
