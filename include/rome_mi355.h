@@ -119,7 +119,9 @@ void rome_opts_default(rome_opts* o, int32_t solver);
  * HIP device rome_ctx_create returns ROME_ERR_NO_DEVICE) */
 int  rome_ctx_create(rome_ctx** out, int device);
 void rome_ctx_destroy(rome_ctx* ctx);
-int  rome_ctx_set_stream(rome_ctx* ctx, void* hip_stream); /* launch on a caller-owned hipStream_t; NULL = HIP's default (null) stream */
+int  rome_ctx_set_stream(rome_ctx* ctx, void* hip_stream); /* launch on a caller-owned hipStream_t; NULL = HIP's default (null) stream.
+                                                             * When the stream CHANGES the previous one is drained first: the context's
+                                                             * workspaces are shared by everything launched through it */
 int  rome_ctx_use_own_stream(rome_ctx* ctx);               /* back to the context's private non-blocking stream (the default) */
 int  rome_ctx_synchronize(rome_ctx* ctx);
 int  rome_device_count(void);

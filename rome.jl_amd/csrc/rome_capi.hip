@@ -370,13 +370,18 @@ void rome_ctx_destroy(rome_ctx* c) {
 
 int rome_ctx_set_stream(rome_ctx* c, void* hip_stream) {
   if (!c) return ROME_ERR_INVALID_ARG;
+  if (c->stream != (hipStream_t)hip_stream) {
+    // the context's workspaces (staging arenas, the Gibbs tree workspace) are shared by everything launched through it: work queued
+    // on the previous stream must be done with them before launches on another stream may touch them
+    ROME_BIND(c);
+    ROME_HIP(c, hipStreamSynchronize(c->stream));
+  }
   c->stream = (hipStream_t)hip_stream;  // NULL is HIP's default (null) stream, e.g. torch's default stream
   return ROME_OK;
 }
 int rome_ctx_use_own_stream(rome_ctx* c) {
   if (!c) return ROME_ERR_INVALID_ARG;
-  c->stream = c->own_stream;
-  return ROME_OK;
+  return rome_ctx_set_stream(c, (void*)c->own_stream);
 }
 int rome_ctx_synchronize(rome_ctx* c) {
   if (!c) return ROME_ERR_INVALID_ARG;

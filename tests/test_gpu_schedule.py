@@ -1,0 +1,119 @@
+"""Ordered up-solve schedules (rome_jl_amd.schedule.OrderedSolve): the initAll!-style init pass and Gauss-Seidel sweeps, device-resident
+(DeviceStore + one UpsolvePlan per independent group), against the oracle's restatement of the same schedule (the stand-ins of
+tests/dist_standin.py drive tests/solve_ref.py::upsolve_ref with the same groups, `usable` sets and Philox stream ids)."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+import rome_jl_amd as R   # noqa: E402
+from rome_jl_amd.clique import DeviceStore   # noqa: E402
+from rome_jl_amd.schedule import OrderedSolve   # noqa: E402
+from dist_standin import OracleStore, OraclePlan   # noqa: E402
+
+
+def _wd(a, b):
+    d = a - b
+    if d.shape[0] == 3:
+        d[2] = np.arctan2(np.sin(d[2]), np.cos(d[2]))
+    return d
+
+
+def _compare(fg, kind, n_sweeps, seed):
+    N = fg.N
+    dev = OrderedSolve(DeviceStore(fg, upload=False), kind=kind)
+    orc = OrderedSolve(OracleStore(R, fg), kind=kind, plan_cls=OraclePlan)
+    assert [tuple(g) for g in dev.init_groups] == [tuple(g) for g in orc.init_groups]
+    o = R.make_opts(N=N, seed=seed)
+    dev.init(o); orc.init(o)
+    worst = []
+    for stage in range(n_sweeps + 1):
+        if stage:
+            dev.sweep(R.make_opts(N=N, seed=seed + stage)); orc.sweep(R.make_opts(N=N, seed=seed + stage))
+        fr, dm = [], []
+        for l in fg.variables:
+            d = _wd(dev.store.get(l), orc.store.get(l))
+            fr.append(np.mean(np.abs(d) < 1e-6)); dm.append(np.abs(d.mean(axis=1)).max())
+        worst.append((float(np.mean(fr)), float(np.max(dm))))
+    return worst
+
+
+@pytest.mark.parametrize("kind", ["colour", "levels"])
+def test_hexagon_schedule_equals_the_oracle_schedule(kind):
+    fg = R.generateGraph_Hexagonal(N=100)           # no beliefs at all: the init pass creates them
+    worst = _compare(fg, kind, 2, 11)
+    for frac, dmean in worst:
+        assert frac > 0.9 and dmean < 1e-3, worst   # north_star tolerance on the belief means
+    # and the windows of test/testHexagonal2D_CliqByCliq.jl:37-79 after init + 2 sweeps on the device
+    dev = OrderedSolve(DeviceStore(fg, upload=False), kind=kind)
+    dev.init(R.make_opts(N=100, seed=5)); dev.sweep(R.make_opts(N=100, seed=6), 2)
+    want = {"x0": (0, 0), "x1": (10, 0), "x2": (15, 8.66), "x3": (10, 17.32), "x4": (0, 17.32), "x5": (-5, 8.66), "x6": (0, 0), "l1": (20, 0)}
+    for l, (x, y) in want.items():
+        p = dev.store.get(l)
+        assert np.mean((np.abs(p[0] - x) < 3.0) & (np.abs(p[1] - y) < 3.0)) > 0.55, (l, p[:2].mean(1))
+
+
+def test_manhattan_prefix_schedule_equals_the_oracle_schedule():
+    """first 120 edges of manhattan.g2o (loop closures included): init pass + one coloured sweep, device == oracle"""
+    fg = R.loadG2o(os.path.join(ROOT, "tests", "golden", "manhattan.g2o"), N=64, max_edges=120)
+    worst = _compare(fg, "colour", 1, 21)
+    for frac, dmean in worst:
+        assert frac > 0.9 and dmean < 1e-3, worst
+
+
+def test_beehive_multihypo_schedule_runs_from_nothing():
+    """BASELINE configs[3]: the beehive with ambiguous re-sightings through the ordered schedule (multihypo rows inside the plans)"""
+    fg = R.synth_beehive_mh(20, N=100)
+    dev = OrderedSolve(DeviceStore(fg, upload=False), kind="colour")
+    dev.init(R.make_opts(N=100, seed=2)); dev.sweep(R.make_opts(N=100, seed=3), 3)
+    sim = fg._sim
+    err = [np.hypot(*(dev.store.get(l)[:2].mean(1) - np.asarray(sim[l])[:2])) for l in fg.variables if fg.variables[l] is R.Pose2]
+    assert np.isfinite(err).all() and np.median(err) < 3.0, np.median(err)
+
+
+def test_manhattan3500_from_init_all_trace():
+    """Manhattan-3500 from NOTHING (no dead reckoning, no parametric start): the init pass, then coloured Gauss-Seidel sweeps; RMS distance
+    of the pose means to the parametric solution per stage and the wall-clock of every stage -> gpurun_out/r04_ordered_solve.txt"""
+    import torch
+    N = 100
+    fg = R.loadG2o(os.path.join(ROOT, "tests", "golden", "manhattan.g2o"), N=N)
+    t0 = time.perf_counter(); xp = R.solveGraphParametric(R.dead_reckon_init(R.loadG2o(os.path.join(ROOT, "tests", "golden", "manhattan.g2o"), N=N), seed=1))
+    t_par = time.perf_counter() - t0
+    labels = [l for l in fg.variables]
+    mp = np.array([xp[l] for l in labels])
+    store = DeviceStore(fg, upload=False)
+    t0 = time.perf_counter(); osv = OrderedSolve(store, kind="colour"); t_plan = time.perf_counter() - t0
+    ptr, _ = store.device_ptr(R.Pose2)
+
+    def rms():
+        bel = np.zeros((len(labels), 3, N))
+        R._lib.check(R._lib.load().rome_store_download(store.handle, 0, 0, 0, len(labels), bel.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double))), store.ctx.handle)
+        m, _ = R.belief_stats(bel)
+        return float(np.sqrt(np.mean(np.sum((m[:, :2] - mp[:, :2]) ** 2, axis=1)))), float(np.median(bel[:, :2].std(axis=2)))
+    lines = []
+    store.ctx.synchronize(); t0 = time.perf_counter()
+    osv.init(R.make_opts(N=N, seed=1)); store.ctx.synchronize()
+    t_init = time.perf_counter() - t0
+    r0, s0 = rms()
+    lines.append("init pass (%d levels, %d groups): %.3f s -> RMS to the parametric solution %.3f m, median belief std %.3f m" % (len(osv.levels), len(osv.init_plans), t_init, r0, s0))
+    trace = [r0]
+    t_sw = 0.0
+    for k in range(20):
+        store.ctx.synchronize(); t0 = time.perf_counter()
+        osv.sweep(R.make_opts(N=N, seed=100 + k)); store.ctx.synchronize()
+        t_sw += time.perf_counter() - t0
+        r, s = rms(); trace.append(r)
+        if k < 5 or k % 5 == 4:
+            lines.append("sweep %2d (%d colour classes): cumulative %.3f s -> RMS %.3f m, median belief std %.3f m" % (k + 1, len(osv.sweep_plans), t_sw, r, s))
+    assert np.isfinite(trace).all() and trace[0] < 8.0 and trace[-1] < 8.0     # dead reckoning: 21.9 m; whole-graph Jacobi from it: 21.4 m after 100 iterations
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r04_ordered_solve.txt"), "w") as f:
+        f.write("OrderedSolve on Manhattan-3500 (N=100), device-resident (DeviceStore + one rome_upsolve_plan per independent group), from NO beliefs:\n"
+                "plans built in %.2f s (host, once); parametric reference solution %.2f s\n" % (t_plan, t_par) + "\n".join(lines) + "\n")

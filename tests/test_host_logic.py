@@ -364,3 +364,44 @@ def test_multihypo_is_accepted_on_pose2pose2_and_carried_by_the_graph_tables():
     assert list(ex["target"]) == [pk.index["b2"]] and list(ex["alt"]) == [pk.index["b1"]] and list(ex["w"]) == [0.4] and list(ex["dir"]) == [0]
     fg.deleteFactor(fl)
     assert fl not in fg.multihypo and R.PackedGraph(fg).p2p2["F"] == 0 and R.PackedGraph.conv_hypotheses(R.PackedGraph(fg).p2p2) is None
+
+
+# ------------------------------------------------------------------ ordered up-solve schedules (rome_jl_amd.schedule)
+def test_schedule_orderings_and_init_pass_over_oracle_standins():
+    """init_rounds / greedy_colouring and the OrderedSolve driver, with the oracle-backed stand-ins of tests/dist_standin.py in place of
+    the device plans: every variable is initialised from ALREADY initialised neighbours only, groups are independent sets, a sweep
+    visits every variable."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_standin import OracleStore, OraclePlan
+    from rome_jl_amd.schedule import OrderedSolve, init_rounds, greedy_colouring, adjacency
+    N = 24
+    fg = R.generateGraph_Hexagonal(N=N)
+    lv, left = init_rounds(fg)
+    assert not left
+    assert lv[0] == ["x0"] and set(lv[1]) == {"x1", "l1"} and sum(len(x) for x in lv) == len(fg.variables)
+    nb = adjacency(fg)
+    for cls in greedy_colouring(fg):
+        assert all(not (nb[a] & set(cls)) for a in cls)
+    store = OracleStore(R, fg)                      # no variable has a belief: the init pass must not need any
+    assert not fg.vals
+    osv = OrderedSolve(store, kind="colour", plan_cls=OraclePlan)
+    assert [g for g in osv.init_groups][0] == ["x0"]
+    seen = set()
+    for grp, plan in zip(osv.init_groups, osv.init_plans):
+        for fl, dest in plan.fp["pairs"]:            # every pair convolves from variables initialised BEFORE this group
+            assert all(l in seen for l in fg.getFactor(fl)[1] if l != dest), (fl, dest)
+        assert plan.fp["pairs"] or grp == [], grp
+        seen |= set(grp)
+    assert seen == set(fg.variables)
+    osv.init(R.make_opts(N=N, seed=3))
+    pts = {l: store.get(l) for l in fg.variables}
+    assert all(np.isfinite(p).all() for p in pts.values())
+    # the hexagon's geometry comes out of the init pass alone (prior at the origin, 10 m legs, 60 degree turns)
+    assert np.abs(pts["x1"][:2].mean(1) - [10.0, 0.0]).max() < 1.5 and np.abs(pts["x3"][:2].mean(1) - [10.0, 17.32]).max() < 4.0
+    before = {l: p.copy() for l, p in pts.items()}
+    osv.sweep(R.make_opts(N=N, seed=4))
+    assert all(not np.array_equal(store.get(l), before[l]) for l in fg.variables)
+    assert sorted(l for g in osv.sweep_groups for l in g) == sorted(fg.variables)
+    lvl = OrderedSolve(OracleStore(R, fg), kind="levels", plan_cls=OraclePlan)
+    assert lvl.sweep_groups[0] == ["x0"] and lvl.sweep_groups[-1] == ["x0"] and len(lvl.sweep_groups) == 2 * len(lvl.init_groups) - 1
