@@ -22,16 +22,35 @@ def _require_torch_cuda():
     return torch
 
 
+class _PlanStub:
+    """what DeviceGraph._plan returns on a plan-only graph: the launch descriptor's arguments, not a launch"""
+
+    def __init__(self, fn, opts, kw):
+        self.fn, self.kw = fn, kw
+        self.opts = _lib.Opts.from_buffer_copy(opts)
+        self._keep = (None, self.opts)
+
+    def __call__(self):
+        raise RuntimeError("plan-only DeviceGraph (bench.py --dry-run): there is no device to launch on")
+
+
 class DeviceGraph:
-    def __init__(self, fg_or_packed, device="cuda:0", ctx=None):
-        torch = _require_torch_cuda()
+    def __init__(self, fg_or_packed, device="cuda:0", ctx=None, plan_only=False):
+        """plan_only: build the same tables on CPU tensors WITHOUT a device or a context -- the multi-GPU drivers can then lay out
+        every rank's arena / exchange plan on a machine without GPUs (`bench.py --gpus 8 --dry-run`); nothing can be launched."""
+        self.plan_only = bool(plan_only)
+        if plan_only:
+            import torch
+            device = "cpu"
+        else:
+            torch = _require_torch_cuda()
         self.torch = torch
         self.device = torch.device(device)
         pk = fg_or_packed if isinstance(fg_or_packed, PackedGraph) else PackedGraph(fg_or_packed)
         self.packed = pk
         self.N = pk.N
-        self.ctx = ctx or _lib.Context(self.device.index or 0)
-        self._lib = _lib.load()
+        self.ctx = None if plan_only else (ctx or _lib.Context(self.device.index or 0))
+        self._lib = None if plan_only else _lib.load()
         t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=self.device)
         f64, i32 = torch.float64, torch.int32
         self.bel = {Pose2: torch.zeros((len(pk.labels[Pose2]), 3, self.N), dtype=f64, device=self.device),
@@ -154,7 +173,7 @@ class DeviceGraph:
     def family_table(self, fam):
         """-> dict(n, fn, vt_fixed, vt_target, dir_all, rows4 [n,4] int32 (factor, dir, fixed, target), mu, L, alt, w)."""
         name, vf, vt, d = self.FAMILIES[fam]
-        fn = getattr(self._lib, name)
+        fn = name if self.plan_only else getattr(self._lib, name)
         if fam in ("p2p2", "p3p3"):
             tb = self.tab[fam]
             return dict(n=tb["C"], fn=fn, vt_fixed=vf, vt_target=vt, dir_all=0, rows4=tb["rows4"], mu=tb["mu"], L=tb["L"],
@@ -186,6 +205,8 @@ class DeviceGraph:
         """Pre-builds the rome_conv_dev descriptor once; the returned callable only binds the current
         torch stream and issues the launch (what a captured / replayed step calls).  `_ctx`: a Context whose stream the
         caller has fixed (one per pipeline slot) -- the launch then is a single C call with no stream lookup."""
+        if self.plan_only:
+            return _PlanStub(fn, opts, kw)
         cd = _lib.ConvDev()
         keep = []
         for k, v in kw.items():

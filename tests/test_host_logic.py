@@ -405,3 +405,13 @@ def test_schedule_orderings_and_init_pass_over_oracle_standins():
     assert sorted(l for g in osv.sweep_groups for l in g) == sorted(fg.variables)
     lvl = OrderedSolve(OracleStore(R, fg), kind="levels", plan_cls=OraclePlan)
     assert lvl.sweep_groups[0] == ["x0"] and lvl.sweep_groups[-1] == ["x0"] and len(lvl.sweep_groups) == 2 * len(lvl.init_groups) - 1
+
+
+def test_bench_dry_run_builds_and_checks_every_rank_of_an_8_gpu_run():
+    """`bench.py --gpus 8 --dry-run`: every rank's tables / arena layout / exchange plan on CPU tensors, checked for consistency"""
+    import subprocess, sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["ok"] and out["n_gpus"] == 8 and out["checks"] > 100 and not out["failed"]
+    assert sum(out["strong"]["rows_per_rank"]) == 10907 and out["frontier"]["cliques"] > 900
