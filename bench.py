@@ -272,7 +272,8 @@ def main():
     n_conv_step = tb["C"]  # convolutions per step on this rank: 2 x F relative + the PriorPose2 row(s), ONE launch
     opts = R.make_opts(N=N, solver=solver, seed=0x524F4D45, stream_offset=0 if strong else rank * (1 << 32))
     prop = torch.empty((tb["C"], 3, N), dtype=torch.float64, device=dev)
-    sweep = dg.plan_sweep_pose2pose2(opts, prop)   # pre-built launch descriptor: one hipLaunchKernel per call
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)   # the context follows torch's current stream, set ONCE
+    sweep = dg.plan_sweep_pose2pose2(opts, prop, fixed_ctx=ctx)   # pre-built launch descriptor: one C call = one hipLaunchKernel per step
 
     pk = dg.packed
     pipe = None
@@ -347,27 +348,25 @@ def main():
     stride = max(1, args.steps // 20) if args.steps >= 200 else args.steps
     marks = list(range(0, args.steps, stride))
 
-    def timed_block():
+    def timed_block(with_events=True):
         """EXACTLY args.steps steps between barrier + synchronize on both sides -> (wall seconds, max over ranks; event ms per step)"""
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(marks) + 1)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(marks) + 1)] if with_events else None
         barrier()
         t0 = time.perf_counter()
-        j = 0
-        for k in range(args.steps):
-            if j < len(marks) and k == marks[j]:
-                ev[j].record(); j += 1
-            sweep()
-        ev[len(marks)].record()
+        if with_events:
+            j = 0
+            for k in range(args.steps):
+                if j < len(marks) and k == marks[j]:
+                    ev[j].record(); j += 1
+                sweep()
+            ev[len(marks)].record()
+        else:
+            for k in range(args.steps):
+                sweep()
         if strong:
             pipe.wait()
         elif multi:
             pipe.drain()
-        else:
-            # single GPU: poll the closing event before the blocking synchronize -- hipStreamSynchronize sleeps on an interrupt and
-            # notices completion ~10-20 us late, which a 0.2 ms region (the driver's --steps 20) would carry as 5-10 % of its time;
-            # the synchronize below still closes the bracket (it returns at once)
-            while not ev[len(marks)].query():
-                pass
         barrier()
         t1 = time.perf_counter()
         el = t1 - t0
@@ -377,17 +376,25 @@ def main():
             el = float(tt.item())
         # N>1: even and odd steps run on side streams, which events on the caller's stream do not bracket: the launch period is
         # then this rank's wall-clock between the barriers
-        km = 1e3 * (t1 - t0) / args.steps if multi else float(ev[0].elapsed_time(ev[len(marks)])) / args.steps
+        km = 1e3 * (t1 - t0) / args.steps if (multi or not with_events) else float(ev[0].elapsed_time(ev[len(marks)])) / args.steps
         return el, km
 
-    # short runs (the driver's --steps 20: a 0.2 ms region in which the two barriers weigh 10 %): the block of K steps is repeated
-    # and the MEDIAN block is reported (every block is exactly K steps between barriers; all block times are listed)
+    # short runs (the driver's --steps 20: a 0.17 ms region in which every host call between the two synchronizes counts --
+    # scripts/short_region_cost.py / profiles/r04_short_region_cost.txt: an event record is 4 us of host time and a barrier packet in the
+    # queue): the block of K steps is repeated and the MEDIAN block is reported (every block is exactly K steps between barrier +
+    # synchronize; all block times are listed).  The blocks behind `value` carry no event records; the launch period of the dominant
+    # kernel for the roofline comes from one more block of the same K steps WITH the two HIP events around it.
     n_blocks = 1 if args.steps >= 1000 else (5 if args.steps >= 100 else 9)
     if n_blocks > 1:
         timed_block()   # one UNTIMED block first: the first block after the barrier is cold (14.5 us per step against 9.5-11 in round 3)
-    blocks = [timed_block() for _ in range(n_blocks)]
+        ev_block = timed_block(True)
+        blocks = [timed_block(False) for _ in range(n_blocks)]
+    else:
+        blocks = [timed_block(True)]
+        ev_block = blocks[0]
     order = sorted(range(n_blocks), key=lambda i: blocks[i][0])
-    elapsed, kern_ms = blocks[order[n_blocks // 2]]
+    elapsed, _ = blocks[order[n_blocks // 2]]
+    kern_ms = ev_block[1]
 
     data_kind = "synthetic" if (not args.g2o or args.g2o == "synthetic") else \
         "Manhattan M3500 dataset (measurements); beliefs synthetic: dead-reckoned means + N(0, sigma) particles"
@@ -402,7 +409,7 @@ def main():
         "metric": "factor convolutions/sec (N=100) on Manhattan-3500; solveTree! wall-clock",
         "value": value, "unit": "convolutions/s", "n_gpus": (dist.get_world_size() if multi else 1), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "timed_blocks_ms_per_step": [1e3 * b[0] / args.steps for b in blocks],
-        "timed_block": "median of %d blocks of exactly %d steps, each between barrier + synchronize%s" % (n_blocks, args.steps, ", after one untimed block" if n_blocks > 1 else ""), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "timed_block": "median of %d blocks of exactly %d steps, each between barrier + synchronize%s" % (n_blocks, args.steps, ", after one untimed block; kernel_ms_per_launch from one more such block bracketed by two HIP events" if n_blocks > 1 else ""), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f64", "data": data_kind,
         "config": {"workload": workload, "poses_per_gpu": len(pk.labels[R.Pose2]), "pose2pose2_factors_per_gpu": tb["F"],
                    "convolutions_per_step_per_gpu": (pipe.n_rows if strong else n_conv_step), "particles": N, "solver": args.solver,

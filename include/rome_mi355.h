@@ -78,9 +78,11 @@ enum {
  *   NELDER_MEAD   Optim.jl's NelderMead() with its defaults on Σ r², i.e. the reference's algorithm, inflate_cycles x
  *                 {entropy, minimise} from the start points
  *   GAUSS_NEWTON  numerical root-find on the residual FUNCTOR itself (the reference's CalcFactor evaluated through points /
- *                 rotation matrices at every iterate) with analytic group updates, from the jittered start points,
- *                 inflate_cycles x {entropy, iterate to max|r| <= tol}; cycles after the one in which every particle of a
- *                 unique-root convolution has converged are skipped.  Same algorithm as the oracle's Newton mode.          */
+ *                 rotation matrices at every iterate) with analytic group updates, iterated to max|r| <= tol.  Unique-root
+ *                 factors: from the start points (the target's current belief), ONE pass -- a converged unique root does not
+ *                 depend on the start beyond `tol`, so the entropy / re-solve rounds of inflate_cycles are not run (a converged
+ *                 proposal is start- and cycle-count-independent only to `tol`: compared with the oracle's Newton mode, which
+ *                 runs every cycle, to 1e-9).  Bearing-range -> pose: inflate_cycles x {entropy, iterate}, as the oracle.      */
 enum { ROME_SOLVER_CLOSED_FORM = 0, ROME_SOLVER_NEWTON = 1, ROME_SOLVER_NELDER_MEAD = 2, ROME_SOLVER_GAUSS_NEWTON = 3 };
 enum { ROME_LAYOUT_SOA = 0, ROME_LAYOUT_AOS = 1, ROME_LAYOUT_AOS_POINTS = 2 };
 enum { ROME_DIR_TO = 0, ROME_DIR_FROM = 1, ROME_DIR_PRIOR = 2 };

@@ -146,10 +146,11 @@ void ro_rng_normals(uint64_t seed, uint64_t stream, uint32_t particle, int d, do
 /* d uniforms in (0,1) for the entropy inflation of cycle `cycle` (⚠IIF addEntropyOnManifold!:
  * spread·(rand(d) .- 0.5); RNG stream unpinned): one Philox call per particle and cycle (two for d = 6), one 32-bit word
  * per coordinate, u = (w + 0.5)/2^32.  Counter = (particle, stream, domain 2 | 2·cycle + block).
- * The HIP path draws exactly these wherever the jitter can reach the proposal (Nelder-Mead, the bearing-range pose
- * direction with its one-parameter family of roots); for Newton / closed form on the unique-root factors the start point
- * never reaches the result, so there it jitters with cheaper, narrower uniforms -- a difference the parity tests cannot
- * and need not see (Newton == closed form to 1e-9, tests/test_gpu_parity.py). */
+ * The HIP path draws exactly these in every kernel that jitters at all: Nelder-Mead (all factors) and every solver on the
+ * bearing-range pose direction (a one-parameter family of roots: the start selects the member).  On the unique-root factors the
+ * device's CLOSED_FORM / NEWTON return the analytic root and its GAUSS_NEWTON iterates from the UNJITTERED belief point without
+ * inflation cycles -- no start point can move a converged unique root by more than the solver tolerance -- whereas this oracle's
+ * Newton mode always runs every cycle with its jitter; the two are compared to <= 1e-9 (tests/test_gpu_parity.py). */
 void ro_rng_entropy(uint64_t seed, uint64_t stream, uint32_t particle, int cycle, int d, double* out) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
   for (int b = 0; 3 * b < d; ++b) {

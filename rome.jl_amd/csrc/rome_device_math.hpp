@@ -332,8 +332,42 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
+// gfx950 lane-group swaps: v + (the same lane of the neighbouring 16-lane row) / (of the other 32-lane half).  v_permlane16_swap
+// exchanges the odd rows of its first operand with the even rows of its second: fed two copies of v it leaves (r0, r0, r2, r2) and
+// (r1, r1, r3, r3), whose sum is the all-reduce of the row pairs; v_permlane32_swap does the same for the two halves of the wave.
+__device__ __forceinline__ double rowpair_allsum(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double halves_allsum(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+// FOUR sums at once, transposed: the first two butterfly steps HALVE the number of values a lane carries (even lanes keep v0, v1
+// and hand v2, v3 to their neighbour, then lanes 0/1 mod 4 keep one value each and hand the other over), the remaining four steps
+// run on ONE value per lane with partners that have the same lane mod 4 (row rotations by 4 and 8, then the row-pair / half swaps).
+// 37 VALU instructions instead of 4 x (6 steps x 3) = 72 + 16 for the masked steps; the total of v[k] ends in every lane whose
+// (lane & 3) is (0, 2, 1, 3)[k] and is read back through an SGPR pair.  (All convolution kernels take this function: identical bits.)
+__device__ __forceinline__ void wave_sum4(double (&v)[4]) {
+  const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const bool b0 = lane & 1u, b1 = lane & 2u;
+  const double kA = b0 ? v[2] : v[0], kB = b0 ? v[3] : v[1], sA = b0 ? v[0] : v[2], sB = b0 ? v[1] : v[3];
+  const double wA = kA + dpp_mov<0xB1>(sA), wB = kB + dpp_mov<0xB1>(sB);      // quad_perm [1,0,3,2]: partner lane ^ 1
+  const double kC = b1 ? wB : wA, sC = b1 ? wA : wB;
+  double x = kC + dpp_mov<0x4E>(sC);                                           // quad_perm [2,3,0,1]: partner lane ^ 2
+  x += dpp_mov<0x124>(x);                                                      // row_ror:4
+  x += dpp_mov<0x128>(x);                                                      // row_ror:8: every lane of a row holds the row sum of ITS value
+  x = rowpair_allsum(x);
+  x = halves_allsum(x);
+  v[0] = readlane_f64(x, 0); v[1] = readlane_f64(x, 2); v[2] = readlane_f64(x, 1); v[3] = readlane_f64(x, 3);
+}
 template <int K>
 __device__ __forceinline__ void wave_sum_n(double (&v)[K]) {
+  if constexpr (K == 4) { wave_sum4(v); return; }
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] += dpp_mov<0xB1>(v[k]);   // quad_perm [1,0,3,2]
 #pragma unroll

@@ -118,10 +118,12 @@ struct P2P2 {
     z[2] = K.mu[2] + K.L[3] * xi[0] + K.L[4] * xi[1] + K.L[5] * xi[2];
   }
   __device__ static __forceinline__ void canonical(double (&t)[3]) { t[2] = wrap_pi(t[2]); }
-  // do the inflation cycles (entropy + re-solve) apply?  Only to the solvers that START from the jittered belief point: Nelder-Mead
-  // and the Gauss-Newton iteration on the residual functor.  CLOSED_FORM and NEWTON return the unique root directly.
+  // do the inflation cycles (entropy + re-solve) apply?  Only to Nelder-Mead, whose answer (to its g_tol of 1e-8 on the simplex spread)
+  // depends on where it starts.  CLOSED_FORM and NEWTON return the unique root directly; GAUSS_NEWTON iterates on the residual functor
+  // from the belief point until max|r| <= tol (1e-12): the root is unique, so no start point -- jittered or not -- and no number of
+  // cycles can move the converged answer by more than the solver tolerance, and the entropy / re-solve rounds are not run.
   __device__ static __forceinline__ bool needs_cycles(int solver, const Consts& K) {
-    return (solver == kSolverNelderMead || solver == kSolverGaussNewton) && K.dir != kDirPrior;
+    return solver == kSolverNelderMead && K.dir != kDirPrior;
   }
   struct Aux {};
   __device__ static __forceinline__ Aux init_aux(const double (&)[3]) { return Aux{}; }
@@ -264,7 +266,7 @@ struct BR {
   __device__ static __forceinline__ void canonical(double (&t)[DT]) { if constexpr (DT == 3) t[2] = wrap_pi(t[2]); }
   // landmark direction: unique root, only the start-dependent solvers cycle; pose direction: every solver starts from the belief point
   __device__ static __forceinline__ bool needs_cycles(int solver, const Consts&) {
-    return DIR == 1 || solver == kSolverNelderMead || solver == kSolverGaussNewton;
+    return DIR == 1 || solver == kSolverNelderMead;   // (DIR 0 under GAUSS_NEWTON: unique root, see P2P2::needs_cycles)
   }
   struct Aux {};
   __device__ static __forceinline__ Aux init_aux(const double (&)[DT]) { return Aux{}; }
@@ -430,7 +432,7 @@ struct P3P3 {
   }
   __device__ static __forceinline__ void canonical(double (&)[6]) {}   // finalize() writes the principal rotation vector
   __device__ static __forceinline__ bool needs_cycles(int solver, const Consts& K) {
-    return (solver == kSolverNelderMead || solver == kSolverGaussNewton) && K.dir != kDirPrior;
+    return solver == kSolverNelderMead && K.dir != kDirPrior;
   }
   struct Aux { double q[4]; };
   // start point u0 -> state.  The reference takes X0c = vee(log(ϵ, u0)) of the start point, and Manifolds' log returns θ = π exactly
@@ -794,22 +796,18 @@ __device__ __forceinline__ void conv_wave_body(const ConvArgs& a, int blk) {
     }                                                                      //  nothing but this flag stays live across the solve)
   }
 
-  // Inflation cycles (IIF inflateCycles x {addEntropyOnManifold!, N x solve}) apply to the solvers that start from the belief point;
-  // the jitter is drawn exactly as the oracle defines it (ro_rng_entropy).  CLOSED_FORM / NEWTON on a unique-root factor return the
-  // root, which no start point can change: one pass, no statistic, no entropy.
+  // Inflation cycles (IIF inflateCycles x {addEntropyOnManifold!, N x solve}) apply where the start point can reach the answer: Nelder-Mead
+  // everywhere, every solver on the bearing-range pose direction (a ring of roots); the jitter is drawn exactly as the oracle defines
+  // it (ro_rng_entropy).  On a unique-root factor CLOSED_FORM / NEWTON return the root and GAUSS_NEWTON iterates to it from the belief
+  // point: one pass, no statistic, no entropy.
   const bool cyc_on = FP::needs_cycles(SOLVER, K);
   const int ncyc = cyc_on ? (a.cycles < 1 ? 1 : a.cycles) : 1;
-  // Cycle elision (GAUSS_NEWTON on a unique-root factor): once every particle has converged (max|r| <= tol) a further cycle
-  // re-jitters the start and lands on the same root again (to the solver tolerance): the remaining cycles are skipped.
-  // Guarded by the parity tests against the oracle, which always runs all cycles.
-  constexpr bool kElide = SOLVER == kSolverGaussNewton && FP::kUniqueRoot;
   for (int cyc = 0; cyc < ncyc; ++cyc) {
     double spread = 0.0;
     if (cyc_on && a.inflation > 0.0 && N > 1) {
       const double sd = FP::template spread<PPL>(t, aux, act, a.inv_n, a.inv_nm1);
       spread = a.inflation * (sd > 1e-10 ? sd : 1.0);   // IIF calcStdBasicSpread: "if no std yet, set to 1"
     }
-    int bad = 0;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
       if (act[k] && sel[k] && !nullh[k]) {
@@ -819,11 +817,7 @@ __device__ __forceinline__ void conv_wave_body(const ConvArgs& a, int blk) {
           FP::add_entropy(t[k], aux[k], spread, u);
         }
         st[k] = FP::template solve<SOLVER>(K, prep[k], z[k], fx[k], t[k], aux[k], a.max_iters, a.tol);
-        bad |= st[k];
       }
-    }
-    if constexpr (kElide) {
-      if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) break;   // wave-uniform
     }
   }
   // NEWTON: the status is the residual FUNCTOR evaluated at the returned root (only when asked for)
@@ -909,18 +903,22 @@ template <class FP> struct FlatStage { static constexpr int kLanes = FP::NK <= 1
 #ifndef ROME_FLAT_MINWAVES
 #define ROME_FLAT_MINWAVES 8   // Pose2 / Point2 sweeps: 8 waves per SIMD (<= 64 VGPRs)
 #endif
-template <class FP, bool VERIFY, bool VEC2, int PP>
+template <class FP, int SOLVER, bool VERIFY, bool VEC2, int PP>
 __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB, uint32_t magic, int blk, double* __restrict__ s_K);
 #ifndef ROME_FLAT_PP
 #define ROME_FLAT_PP 1   // neighbouring particle pairs per thread of the packed sweep (Pose2 / Point2 factors).  Measured: 2 pairs per
                           // thread (fewer, fatter waves, one generation) need 96 VGPRs + spills and run 21.8 µs against 8.0 µs: one pair it is
 #endif
-template <class FP, bool VERIFY, bool VEC2, int PP>
-__global__ void __launch_bounds__(kFlatThreads, (FP::DT <= 3 && !VERIFY) ? (PP == 1 ? ROME_FLAT_MINWAVES : 5) : 1) k_conv_flat(const ConvArgs a, int H, int CPB, uint32_t magic) {
+#ifndef ROME_FLAT_GN_MINWAVES
+#define ROME_FLAT_GN_MINWAVES 4   // the functor-iterating packed sweep (Pose2 / Point2): <= 128 VGPRs
+#endif
+template <class FP, int SOLVER, bool VERIFY, bool VEC2, int PP>
+__global__ void __launch_bounds__(kFlatThreads, FP::DT <= 3 ? ((SOLVER == kSolverClosedForm && !VERIFY) ? (PP == 1 ? ROME_FLAT_MINWAVES : 5) : ROME_FLAT_GN_MINWAVES) : 1)
+k_conv_flat(const ConvArgs a, int H, int CPB, uint32_t magic) {
   __shared__ double s_K[kFlatMaxRows * (FlatStage<FP>::kLanes + 2)];
-  conv_flat_body<FP, VERIFY, VEC2, PP>(a, H, CPB, magic, xcd_contiguous_block(blockIdx.x, gridDim.x), s_K);
+  conv_flat_body<FP, SOLVER, VERIFY, VEC2, PP>(a, H, CPB, magic, xcd_contiguous_block(blockIdx.x, gridDim.x), s_K);
 }
-template <class FP, bool VERIFY, bool VEC2, int PP>
+template <class FP, int SOLVER, bool VERIFY, bool VEC2, int PP>
 __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB, uint32_t magic, int blk, double* __restrict__ s_K) {
   constexpr int SLP = FlatStage<FP>::kLanes + 2;   // (+2: rows of a wave's two convolutions start in different banks)
   constexpr int NP = 2 * PP;                        // particles per thread: PP neighbouring pairs (2·PP consecutive particles)
@@ -952,6 +950,7 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
   }
   const double* __restrict__ fb = a.bel_fixed + (size_t)row.z * FP::DF * N;
   double fx[NP][FP::DF];
+  [[maybe_unused]] double t0[NP][FP::DT];   // GAUSS_NEWTON: the start points u0 (the target's current belief): +24 B per Pose2 particle
 #pragma unroll
   for (int p = 0; p < PP; ++p) {
     const int ip = i0 + 2 * p;
@@ -966,6 +965,13 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
 #pragma unroll
       for (int d = 0; d < FP::DF; ++d) {
         fx[2 * p][d] = fb[(size_t)d * N + (ip < N ? ip : 0)]; fx[2 * p + 1][d] = fb[(size_t)d * N + (ip + 1 < N ? ip + 1 : 0)];
+      }
+    }
+    if constexpr (SOLVER == kSolverGaussNewton) {
+      const double* __restrict__ tb = a.bel_target + (size_t)row.w * FP::DT * N;
+#pragma unroll
+      for (int d = 0; d < FP::DT; ++d) {
+        t0[2 * p][d] = tb[(size_t)d * N + (ip < N ? ip : 0)]; t0[2 * p + 1][d] = tb[(size_t)d * N + (ip + 1 < N ? ip + 1 : 0)];
       }
     }
   }
@@ -997,10 +1003,19 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
     st[k] = 0;
     FP::measurement(K, xi[k], z);
     const typename FP::Prep P = FP::prepare(K, z, fx[k]);
-    typename FP::Aux A;
-    FP::template solve<kSolverClosedForm>(K, P, z, fx[k], t[k], A, 0, 0.0);
-    if constexpr (VERIFY) st[k] = FP::verify(K, z, fx[k], t[k], A, a.tol);   // NEWTON with a status array: the functor at the root
-    FP::finalize(t[k], A);
+    if constexpr (SOLVER == kSolverGaussNewton) {   // the numerical root-find on the residual functor, from the belief point
+#pragma unroll
+      for (int d = 0; d < FP::DT; ++d) t[k][d] = t0[k][d];
+      FP::canonical(t[k]);
+      typename FP::Aux A = FP::init_aux(t[k]);
+      st[k] = FP::template solve<kSolverGaussNewton>(K, P, z, fx[k], t[k], A, a.max_iters, a.tol);
+      FP::finalize(t[k], A);
+    } else {
+      typename FP::Aux A;
+      FP::template solve<kSolverClosedForm>(K, P, z, fx[k], t[k], A, 0, 0.0);
+      if constexpr (VERIFY) st[k] = FP::verify(K, z, fx[k], t[k], A, a.tol);   // NEWTON with a status array: the functor at the root
+      FP::finalize(t[k], A);
+    }
   }
 #ifdef ROME_FLAT_TRACE
   const uint64_t trace_t1 = wall_clock64();
@@ -1062,16 +1077,15 @@ __global__ void __launch_bounds__(256) k_sweep_fused(const FusedArgs f) {
   __shared__ double s_K[kFlatMaxRows * (FlatStage<P2P2>::kLanes + 2)];
   const int b = blockIdx.x;
   if (b < f.nb_br1) conv_wave_body<BR<1>, kSolverClosedForm, 2, true>(f.br1, xcd_contiguous_block(b, f.nb_br1));
-  else if (b < f.nb_br1 + f.nb_p2p2) conv_flat_body<P2P2, false, VEC2, 1>(f.p2p2, f.H, f.CPB2, f.magic, xcd_contiguous_block(b - f.nb_br1, f.nb_p2p2), s_K);
-  else conv_flat_body<BR<0>, false, VEC2, 1>(f.br0, f.H, f.CPB0, f.magic, xcd_contiguous_block(b - f.nb_br1 - f.nb_p2p2, f.nb_br0), s_K);
+  else if (b < f.nb_br1 + f.nb_p2p2) conv_flat_body<P2P2, kSolverClosedForm, false, VEC2, 1>(f.p2p2, f.H, f.CPB2, f.magic, xcd_contiguous_block(b - f.nb_br1, f.nb_p2p2), s_K);
+  else conv_flat_body<BR<0>, kSolverClosedForm, false, VEC2, 1>(f.br0, f.H, f.CPB0, f.magic, xcd_contiguous_block(b - f.nb_br1 - f.nb_p2p2, f.nb_br0), s_K);
 }
 
 // ------------------------------------------------------------------------------------------
 // N > 512: the same convolution with the particles walked in chunks of 128 instead of living in registers for the whole
 // kernel.  Cycle by cycle: (1) the spread of ALL N current points (the start points u0 in cycle 0, the previous cycle's
 // solutions afterwards -- they are re-read from the proposal block itself), (2) chunk by chunk: load, re-draw the measurement
-// samples (counter-based: the same every time), jitter with the oracle's uniforms, solve, store.  Cycle elision as in
-// k_conv.  One wavefront per convolution; multihypo / nullhypo rows are not served here (the launcher refuses them).
+// samples (counter-based: the same every time), jitter with the oracle's uniforms, solve, store.  One wavefront per convolution; multihypo / nullhypo rows are not served here (the launcher refuses them).
 // ------------------------------------------------------------------------------------------
 template <class FP, int SOLVER>
 __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
@@ -1096,7 +1110,6 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
   const uint64_t stream = a.stream_offset + (uint64_t)(a.row_stream ? a.row_stream[c] : c);
   const bool cyc_on = FP::needs_cycles(SOLVER, K);
   const int ncyc = cyc_on ? (a.cycles < 1 ? 1 : a.cycles) : 1;
-  constexpr bool kElide = SOLVER == kSolverGaussNewton && FP::kUniqueRoot;
   if (!valid) return;   // (nothing below synchronises across waves; surplus waves of the last block have no row)
   for (int cyc = 0; cyc < ncyc; ++cyc) {
     const double* cur = cyc == 0 ? tb : ob;
@@ -1128,7 +1141,6 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
       const double sd = fast_sqrt(var);
       spread = a.inflation * (sd > 1e-10 ? sd : 1.0);
     }
-    int bad = 0;
     for (int base = 0; base < N; base += 64 * PPL) {
       double fx[PPL][FP::DF], t[PPL][FP::DT], z[PPL][FP::DZ];
       typename FP::Aux aux[PPL];
@@ -1174,7 +1186,6 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
           }
           int st = FP::template solve<SOLVER>(K, prep, z[k], fx[k], t[k], aux[k], a.max_iters, a.tol);
           if constexpr (SOLVER == kSolverNewton) { if (a.status) st = FP::verify(K, z[k], fx[k], t[k], aux[k], a.tol); }
-          bad |= st;
           FP::finalize(t[k], aux[k]);
 #pragma unroll
           for (int d = 0; d < FP::DT; ++d) ob[d * N + i] = t[k][d];
@@ -1184,9 +1195,6 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next cycle's spread pass reads what other lanes of this wave just wrote
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if constexpr (kElide) {
-      if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) break;
-    }
   }
 }
 
@@ -1350,7 +1358,7 @@ static hipError_t launch_flat(const ConvArgs& a, hipStream_t s) {
   // PP neighbouring pairs per thread: Pose2 / Point2 rows of >= 64 particles take ROME_FLAT_PP, everything else one pair
   constexpr int PPC = FP::DT <= 3 ? ROME_FLAT_PP : 1;
   const bool verify = SOLVER == kSolverNewton && a.status != nullptr;
-  const int pp = (PPC > 1 && a.N >= 64 && !verify) ? PPC : 1;
+  const int pp = (PPC > 1 && a.N >= 64 && !verify && SOLVER != kSolverGaussNewton) ? PPC : 1;
   const int H = (a.N + 2 * pp - 1) / (2 * pp);
   int CPB = kFlatThreads / H;
   if (CPB > kFlatMaxRows) CPB = kFlatMaxRows;
@@ -1361,23 +1369,29 @@ static hipError_t launch_flat(const ConvArgs& a, hipStream_t s) {
   // 16-byte accesses need an even N (row starts stay 16-byte aligned) and 16-byte aligned arrays
   const bool vec2 = (a.N % 2 == 0) && (((uintptr_t)a.bel_fixed | (uintptr_t)a.out | (uintptr_t)a.mirror_out) % 16 == 0);
   // (the functor evaluation is a separate instantiation: compiled into the plain sweep it would pin its register allocation)
-  if (verify) {
-    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, true, true, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
-    else      hipLaunchKernelGGL((k_conv_flat<FP, true, false, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+  constexpr int CF = kSolverClosedForm, GN = kSolverGaussNewton;
+  if constexpr (SOLVER == kSolverGaussNewton) {   // the functor-iterating packed sweep
+    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, GN, false, true, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    else      hipLaunchKernelGGL((k_conv_flat<FP, GN, false, false, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+  } else if (verify) {
+    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, CF, true, true, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    else      hipLaunchKernelGGL((k_conv_flat<FP, CF, true, false, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
   } else if (pp == 1) {
-    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, false, true, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
-    else      hipLaunchKernelGGL((k_conv_flat<FP, false, false, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, CF, false, true, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    else      hipLaunchKernelGGL((k_conv_flat<FP, CF, false, false, 1>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
   } else {
-    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, false, true, PPC>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
-    else      hipLaunchKernelGGL((k_conv_flat<FP, false, false, PPC>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    if (vec2) hipLaunchKernelGGL((k_conv_flat<FP, CF, false, true, PPC>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
+    else      hipLaunchKernelGGL((k_conv_flat<FP, CF, false, false, PPC>), dim3(nb), dim3(kFlatThreads), 0, s, a, H, CPB, magic);
   }
   return hipGetLastError();
 }
 template <class FP, int SOLVER>
 static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
   const bool lean = a.rows4 != nullptr && a.noise == nullptr && a.alt_var == nullptr && a.nullhypo == nullptr && a.row_stream == nullptr;
-  if constexpr (FP::kUniqueRoot && (SOLVER == kSolverClosedForm || SOLVER == kSolverNewton)) {
-    // plain sweep of a unique-root factor: the packed kernel (rows of >= 8 pair-threads; tiny N stays one wavefront per row)
+  if constexpr (FP::kUniqueRoot && (SOLVER == kSolverClosedForm || SOLVER == kSolverNewton || SOLVER == kSolverGaussNewton)) {
+    // plain sweep of a unique-root factor: the packed kernel (rows of >= 8 pair-threads; tiny N stays one wavefront per row) -- the
+    // analytic root, or the Gauss-Newton iteration on the residual functor from the belief point (nothing couples the particles of a
+    // row either way: no inflation statistic)
     if (lean && a.N >= 16 && (a.N + 1) / 2 <= kFlatThreads) return launch_flat<FP, SOLVER>(a, s);
   }
   // NEWTON without a status array IS the closed form on every factor here (unique roots; the bearing-range pose direction steps

@@ -241,9 +241,13 @@ class DeviceGraph:
         launch._keep = (keep, o, cd)
         return launch
 
-    def plan_sweep_pose2pose2(self, opts, out, noise=None, status=None):
+    def plan_sweep_pose2pose2(self, opts, out, noise=None, status=None, fixed_ctx=None):
+        """fixed_ctx: a Context whose stream the caller has set once (Context.set_stream): the launch is then ONE C call, without the
+        per-launch lookup of torch's current stream (5.4 -> ~2 us of host time per launch)"""
         tb = self.tab["p2p2"]
         mh = dict(alt_var=tb["alt"], hypo_w=tb["w"]) if tb["mh"] else {}
+        if fixed_ctx is not None:
+            mh["_ctx"] = fixed_ctx
         return self._plan(self._lib.rome_conv_pose2pose2_dev, opts, n_conv=tb["C"], dir_all=0,
                           factor=tb["factor"], dir=tb["dir"], fixed_var=tb["fixed"], target_var=tb["target"], rows4=tb["rows4"],
                           mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Pose2],

@@ -245,16 +245,36 @@ def test_pose3pose3_vs_oracle(solver, N):
     assert (st == 0).all() and (rst == 0).all()
 
 
-def test_pose3pose3_nelder_mead_small():
-    C_, N = 4, 64
-    mu, cov, fixed, target, dirs, noise = _p3_inputs(C_, N, 321)
-    o = R.make_opts(N=N, solver=2, inflate_cycles=1, inflation=0.0)
-    out = R.conv_pose3pose3(o, mu, cov, fixed, fixed.copy(), dirs=dirs, noise=noise)
-    L = np.array([ro.cholesky_lower(c) for c in cov])
-    exact = ro.conv_pose3pose3(ro.make_opts(N=N, solver=0), mu, L, np.concatenate([fixed, fixed], 0), np.arange(C_), C_ + np.arange(C_), dirs, noise=noise)
+def test_pose3pose3_nelder_mead_vs_oracle():
+    """Optim.jl's NelderMead() on the 6-D Pose3Pose3 cost, the same algorithm on both sides (cf. the Pose2 test above): the bulk of the
+    particles follows the oracle's trajectory exactly -- translation AND rotation --, the rest differs at the optimiser's own accuracy
+    (an ulp of difference in a transcendental can flip a simplex comparison); both sit equally far from the closed-form root."""
     from scipy.spatial.transform import Rotation as Rot
-    err_t = np.abs(out[:, :3] - exact[:, :3]).max(axis=1)
-    assert np.percentile(err_t, 90) < 5e-3
+    C_, N = 6, 64
+    mu, cov, fixed, target, dirs, noise = _p3_inputs(C_, N, 321)
+    L = np.array([ro.cholesky_lower(c) for c in cov])
+    bel = np.concatenate([fixed, target], 0)
+    for cycles, infl in ((1, 0.0), (3, 5.0)):
+        o = R.make_opts(N=N, solver=2, inflate_cycles=cycles, inflation=infl, seed=9)
+        out, st = R.conv_pose3pose3(o, mu, cov, fixed, target.copy(), dirs=dirs, noise=noise, want_status=True)
+        ref, rst = ro.conv_pose3pose3(ro.make_opts(N=N, solver=2, inflate_cycles=cycles, inflation=infl, seed=9), mu, L, bel, np.arange(C_), C_ + np.arange(C_),
+                                      dirs, noise=noise, want_status=True)
+        ang = (Rot.from_rotvec(out[:, 3:].transpose(0, 2, 1).reshape(-1, 3)).inv() *
+               Rot.from_rotvec(ref[:, 3:].transpose(0, 2, 1).reshape(-1, 3))).magnitude().reshape(C_, N)
+        d = np.maximum(np.abs(out[:, :3] - ref[:, :3]).max(axis=1), ang)        # (C, N): translation and rotation together
+        # one cycle: the bulk is identical to 1e-9.  Three cycles: the inflation spread is a sum over the particles in a different order on
+        # the two sides (wave butterfly vs sequential), an ulp of jitter that 3 x ~1000 simplex steps in 6-D amplify to ~1e-9 (measured
+        # median 1.1e-9): the bar there is 5e-9
+        assert np.median(d) < (1e-9 if cycles == 1 else 5e-9), (cycles, np.median(d))
+        assert np.mean(d < 1e-6) > 0.98, (cycles, np.mean(d < 1e-6))
+        exact = ro.conv_pose3pose3(ro.make_opts(N=N, solver=0), mu, L, bel, np.arange(C_), C_ + np.arange(C_), dirs, noise=noise)
+
+        def err(x):
+            a = (Rot.from_rotvec(x[:, 3:].transpose(0, 2, 1).reshape(-1, 3)).inv() *
+                 Rot.from_rotvec(exact[:, 3:].transpose(0, 2, 1).reshape(-1, 3))).magnitude().reshape(C_, N)
+            return np.maximum(np.abs(x[:, :3] - exact[:, :3]).max(axis=1), a)
+        e_gpu, e_ref = err(out), err(ref)
+        assert np.percentile(e_gpu, 90) < 5e-3 and abs(np.percentile(e_gpu, 90) - np.percentile(e_ref, 90)) < 1e-3, (np.percentile(e_gpu, 90), np.percentile(e_ref, 90))
 
 
 @pytest.mark.parametrize("d", [3, 6])
