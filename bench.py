@@ -420,14 +420,15 @@ def main():
                                    if multi else "single GPU"),
                    "ranks_seen_by_rccl": (dist.get_world_size() if multi else 1)},
         "roofline": {"bound": "hbm", "kernel": ("rome::k_conv_flat<P2P2> (packed unique-root sweep)" if args.solver in ("newton", "closed_form")
-                                                else "rome::k_conv<P2P2,%s,PPL=2,lean>" % args.solver),
+                                                else ("rome::k_conv_flat<P2P2, gauss_newton> (packed sweep, functor iteration)" if args.solver == "gauss_newton"
+                                                      else "rome::k_conv<P2P2,%s,PPL=2,lean>" % args.solver)),
                      "bytes_per_particle": BYTES_PER_PARTICLE_P2P2[args.solver],
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms, "traffic": None},
     }
     # counter-measured HBM traffic of the same kernel on the same table (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
     # scripts/profile_round.sh; PMC counters need rocprofv3 around the process, so this run quotes the stored pass)
-    tfile = os.path.join(ROOT, "profiles", "r03_hbm_traffic_%s.json" % args.solver)
+    tfile = os.path.join(ROOT, "profiles", "r04_hbm_traffic_%s.json" % args.solver)
     if os.path.exists(tfile) and world == 1:
         try:
             with open(tfile) as f:
@@ -443,7 +444,7 @@ def main():
         except Exception:
             pass
 
-    sfile = os.path.join(ROOT, "profiles", "r03_sq_counters_%s.json" % args.solver)
+    sfile = os.path.join(ROOT, "profiles", "r04_sq_counters_%s.json" % args.solver)
     if os.path.exists(sfile) and world == 1:
         try:
             with open(sfile) as f:
@@ -456,7 +457,7 @@ def main():
             avail = 256 * 4 * clk * kern_ms * 1e-3
             out["roofline"]["secondary"] = {"bound": "valu_issue", "achieved": busy_cycles / (kern_ms * 1e-3) / 1e12,
                                             "peak": 256 * 4 * clk / 1e12, "unit": "T SIMD-cycles/s", "frac": busy_cycles / avail,
-                                            "source": "SQ_ACTIVE_INST_VALU (profiles/r03_sq_counters_%s.json) / (256 CUs x 4 SIMDs x 2.4 GHz x launch period of this run)" % args.solver}
+                                            "source": "SQ_ACTIVE_INST_VALU (profiles/r04_sq_counters_%s.json) / (256 CUs x 4 SIMDs x 2.4 GHz x launch period of this run)" % args.solver}
         except Exception:
             pass
 

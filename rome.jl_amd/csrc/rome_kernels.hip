@@ -321,23 +321,19 @@ struct BR {
   // Gauss-Newton on the functor (the oracle's br_newton): r through residual_bearingrange at the current point;
   //   DIR 0: exact Newton step in the pose-frame polar chart of the landmark, (φ, n) += (r0, r1);  DIR 1: the block step along the ray
   __device__ static __forceinline__ int gauss_newton(const double (&z)[2], const double (&fx)[DF], double (&t)[DT], int max_iters, double tol) {
+    [[maybe_unused]] double s = 0.0, c = 1.0;
+    if constexpr (DIR == 0) fast_sincos(fx[2], &s, &c);   // the fixed pose's frame: the same for every iterate
     for (int it = 0; it < max_iters; ++it) {
       double r[2]; functor(z, fx, t, r);
       if (fmax(fabs(r[0]), fabs(r[1])) <= tol) return 0;
       if constexpr (DIR == 0) {
-        double s, c; fast_sincos(fx[2], &s, &c);
         const double dx = t[0] - fx[0], dy = t[1] - fx[1];
         const double plx = c * dx + s * dy, ply = c * dy - s * dx;
         const double nn = fast_sqrt(plx * plx + ply * ply) + r[1], an = fast_atan2(ply, plx) + r[0];
         double sa, ca; fast_sincos(an, &sa, &ca);
         const double qx = nn * ca, qy = nn * sa;
         t[0] = fx[0] + c * qx - s * qy; t[1] = fx[1] + s * qx + c * qy;
-      } else {
-        const double dx = fx[0] - t[0], dy = fx[1] - t[1];
-        const double n = fast_sqrt(dx * dx + dy * dy);
-        const double ux = n > 0 ? dx / n : 1.0, uy = n > 0 ? dy / n : 0.0;
-        t[0] = fx[0] - z[1] * ux; t[1] = fx[1] - z[1] * uy; t[2] = fast_atan2(uy, ux) - z[0];
-      }
+      } else ring_step(z, fx, t);   // the block step along the ray (reciprocal square root, no FP64 division)
     }
     return 1;
   }
@@ -548,35 +544,38 @@ struct P3P3 {
   }
   // Gauss-Newton on the functor (the oracle's p3p3_newton_pt): right-perturbation updates on the group that zero the residual,
   //   dir 0: R_q ← R_q Exp(r_ω), q.t += r_t;   dir 1: R_p ← R_p Exp(−Z r_ω), p.t ← q.t − R_p z_t
+  // The ITERATE lives as (translation, unit quaternion): every residual evaluation builds the target's 3x3 frame from it and calls the
+  // functor on frames, the update is a quaternion product -- 16 doubles of iterate state less than carrying R, Exp(·) and R·Exp(·) as
+  // matrices across the loop (228 -> ~150 VGPRs for the packed sweep: three waves per SIMD instead of two), and no Log/Exp round trip
+  // at the end.
   __device__ static __forceinline__ int gauss_newton(const Consts& K, const double (&z)[6], const double (&fxc)[6], double (&t)[6], Aux& A, int max_iters, double tol) {
-    Se3 F, T; double Z[9];
+    Se3 F; double Z[9];
     se3_from_coords(fxc, F); so3_exp(&z[3], Z);
-    T.t[0] = t[0]; T.t[1] = t[1]; T.t[2] = t[2]; quat_to_mat(A.q, T.R);
     int st = 1;
     for (int it = 0; it < max_iters; ++it) {
-      double r[6];
+      Se3 T; double r[6];
+      T.t[0] = t[0]; T.t[1] = t[1]; T.t[2] = t[2]; quat_to_mat(A.q, T.R);
       functor(K, z, Z, F, T, r);
       double m = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) m = fmax(m, fabs(r[k]));
       if (m <= tol) { st = 0; break; }
-      double E[9], Rn[9];
+      double qe[4], qn[4];
       if (K.dir == 0) {
-        so3_exp(r + 3, E); mat3_mul(T.R, E, Rn);
-        T.t[0] += r[0]; T.t[1] += r[1]; T.t[2] += r[2];
+        quat_exp(r + 3, qe); quat_mul(A.q, qe, qn);
+        t[0] += r[0]; t[1] += r[1]; t[2] += r[2];
       } else {
         double d[3], v[3];
         mat3_vec(Z, r + 3, d); d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2];
-        so3_exp(d, E); mat3_mul(T.R, E, Rn);
-        mat3_vec(Rn, z, v);
-        T.t[0] = F.t[0] - v[0]; T.t[1] = F.t[1] - v[1]; T.t[2] = F.t[2] - v[2];
+        quat_exp(d, qe); quat_mul(A.q, qe, qn);
+        quat_rot(qn, z, v);
+        t[0] = F.t[0] - v[0]; t[1] = F.t[1] - v[1]; t[2] = F.t[2] - v[2];
       }
+      // (renormalised: a product of unit quaternions drifts by an ulp per step; |q|² = 1 + ε, 1/|q| = 3/2 − |q|²/2 to O(ε²))
+      const double nn = __builtin_fma(-0.5, qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3], 1.5);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) T.R[k] = Rn[k];
+      for (int k = 0; k < 4; ++k) A.q[k] = qn[k] * nn;
     }
-    double w[3];
-    so3_log(T.R, w); quat_exp(w, A.q);
-    t[0] = T.t[0]; t[1] = T.t[1]; t[2] = T.t[2];
     return st;
   }
   template <int SOLVER>
@@ -912,8 +911,12 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
 #ifndef ROME_FLAT_GN_MINWAVES
 #define ROME_FLAT_GN_MINWAVES 4   // the functor-iterating packed sweep (Pose2 / Point2): <= 128 VGPRs
 #endif
+#ifndef ROME_FLAT_GN6_MINWAVES
+#define ROME_FLAT_GN6_MINWAVES 2   // SE(3) functor iteration: <= 256 VGPRs asked for; the sched barrier between a thread's two particles does the rest
+#endif
 template <class FP, int SOLVER, bool VERIFY, bool VEC2, int PP>
-__global__ void __launch_bounds__(kFlatThreads, FP::DT <= 3 ? ((SOLVER == kSolverClosedForm && !VERIFY) ? (PP == 1 ? ROME_FLAT_MINWAVES : 5) : ROME_FLAT_GN_MINWAVES) : 1)
+__global__ void __launch_bounds__(kFlatThreads, FP::DT <= 3 ? ((SOLVER == kSolverClosedForm && !VERIFY) ? (PP == 1 ? ROME_FLAT_MINWAVES : 5) : ROME_FLAT_GN_MINWAVES)
+                                                            : (SOLVER == kSolverGaussNewton ? ROME_FLAT_GN6_MINWAVES : 1))
 k_conv_flat(const ConvArgs a, int H, int CPB, uint32_t magic) {
   __shared__ double s_K[kFlatMaxRows * (FlatStage<FP>::kLanes + 2)];
   conv_flat_body<FP, SOLVER, VERIFY, VEC2, PP>(a, H, CPB, magic, xcd_contiguous_block(blockIdx.x, gridDim.x), s_K);
@@ -1004,6 +1007,9 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
     FP::measurement(K, xi[k], z);
     const typename FP::Prep P = FP::prepare(K, z, fx[k]);
     if constexpr (SOLVER == kSolverGaussNewton) {   // the numerical root-find on the residual functor, from the belief point
+      // SE(3): one particle's iteration holds two 3x3 frames, Exp(z_ω), the update and the residual (~110 VGPRs): the two particles of
+      // a thread run one AFTER the other (no interleaving across this point), or the allocation doubles and one wave per SIMD is left
+      if constexpr (FP::DT == 6) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int d = 0; d < FP::DT; ++d) t[k][d] = t0[k][d];
       FP::canonical(t[k]);
@@ -1079,6 +1085,19 @@ __global__ void __launch_bounds__(256) k_sweep_fused(const FusedArgs f) {
   if (b < f.nb_br1) conv_wave_body<BR<1>, kSolverClosedForm, 2, true>(f.br1, xcd_contiguous_block(b, f.nb_br1));
   else if (b < f.nb_br1 + f.nb_p2p2) conv_flat_body<P2P2, kSolverClosedForm, false, VEC2, 1>(f.p2p2, f.H, f.CPB2, f.magic, xcd_contiguous_block(b - f.nb_br1, f.nb_p2p2), s_K);
   else conv_flat_body<BR<0>, kSolverClosedForm, false, VEC2, 1>(f.br0, f.H, f.CPB0, f.magic, xcd_contiguous_block(b - f.nb_br1 - f.nb_p2p2, f.nb_br0), s_K);
+}
+
+// The same with `multihypo` / `nullhypo` columns on the bearing-range tables (the beehive of BASELINE configs[3]: ambiguous re-sightings,
+// test/testMultimodalRangeBearing.jl:53): both sighting directions run the feature-complete wave-per-row body (the fractional
+// hypotheses need statistics over a row's particles), the odometry table stays packed.  One launch instead of three for a graph whose
+// tables are all sub-generation; bit-identical to the per-family launches.
+template <bool VEC2>
+__global__ void __launch_bounds__(256) k_sweep_fused_mh(const FusedArgs f) {
+  __shared__ double s_K[kFlatMaxRows * (FlatStage<P2P2>::kLanes + 2)];
+  const int b = blockIdx.x;
+  if (b < f.nb_br1) conv_wave_body<BR<1>, kSolverClosedForm, 2, false>(f.br1, xcd_contiguous_block(b, f.nb_br1));
+  else if (b < f.nb_br1 + f.nb_p2p2) conv_flat_body<P2P2, kSolverClosedForm, false, VEC2, 1>(f.p2p2, f.H, f.CPB2, f.magic, xcd_contiguous_block(b - f.nb_br1, f.nb_p2p2), s_K);
+  else conv_wave_body<BR<0>, kSolverClosedForm, 2, false>(f.br0, xcd_contiguous_block(b - f.nb_br1 - f.nb_p2p2, f.nb_br0));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1417,17 +1436,23 @@ hipError_t launch_conv_bearingrange(const ConvArgs& a, int solver, hipStream_t s
   return a.dir_all == 0 ? launch_solver<BR<0>>(a, solver, s) : launch_solver<BR<1>>(a, solver, s);
 }
 static bool plain_rows(const ConvArgs& a) { return a.rows4 && !a.noise && !a.alt_var && !a.nullhypo && !a.status && !a.row_stream; }
+static bool hypo_rows(const ConvArgs& a) { return a.rows4 && !a.noise && !a.status && !a.row_stream && (a.alt_var || a.nullhypo); }
 // the whole sweep of a Pose2 / Point2 graph: fused into one launch when every family takes its plain kernel, else family by family
 hipError_t launch_sweep_pose2(const ConvArgs* p2p2, const ConvArgs* br1, const ConvArgs* br0, int solver, hipStream_t s) {
   const int N = p2p2 ? p2p2->N : (br1 ? br1->N : (br0 ? br0->N : 0));
-  const bool fusable = p2p2 && br1 && br0 && p2p2->n_conv > 0 && br1->n_conv > 0 && br0->n_conv > 0 &&
-                       (solver == kSolverClosedForm || solver == kSolverNewton) && N > 64 && N <= 128 && br1->N == N && br0->N == N &&
-                       plain_rows(*p2p2) && plain_rows(*br1) && plain_rows(*br0) && br1->dir_all == 1 && br0->dir_all == 0 &&
+  const bool shape_ok = p2p2 && br1 && br0 && p2p2->n_conv > 0 && br1->n_conv > 0 && br0->n_conv > 0 &&
+                        (solver == kSolverClosedForm || solver == kSolverNewton) && N > 64 && N <= 128 && br1->N == N && br0->N == N &&
+                        br1->dir_all == 1 && br0->dir_all == 0;
+  // sighting tables with multihypo / nullhypo columns: the fused launch with the feature-complete wave bodies for both directions
+  const bool fusable_mh = shape_ok && plain_rows(*p2p2) && (hypo_rows(*br1) || plain_rows(*br1)) && (hypo_rows(*br0) || plain_rows(*br0)) &&
+                          (hypo_rows(*br1) || hypo_rows(*br0));
+  const bool fusable = shape_ok &&
+                       plain_rows(*p2p2) && plain_rows(*br1) && plain_rows(*br0) &&
                        // the fused kernel runs every part at the register allocation of the bearing-range pose body (88 VGPRs, 5 waves
                        // per SIMD instead of the packed sweep's 8): worth two saved launches unless the odometry table is both huge and
                        // dominant
                        (p2p2->n_conv <= 100000 || 10 * (br1->n_conv + br0->n_conv) >= p2p2->n_conv);
-  if (!fusable) {
+  if (!fusable && !fusable_mh) {
     hipError_t e = hipSuccess;
     if (br1 && br1->n_conv > 0 && (e = launch_conv_bearingrange(*br1, solver, s)) != hipSuccess) return e;
     if (p2p2 && p2p2->n_conv > 0 && (e = launch_conv_pose2pose2(*p2p2, solver, s)) != hipSuccess) return e;
@@ -1444,13 +1469,18 @@ hipError_t launch_sweep_pose2(const ConvArgs* p2p2, const ConvArgs* br1, const C
   auto up8 = [](int n) { return (n + 7) & ~7; };
   f.nb_br1 = up8((br1->n_conv + ROME_WPB - 1) / ROME_WPB);
   f.nb_p2p2 = up8((p2p2->n_conv + f.CPB2 - 1) / f.CPB2);
-  f.nb_br0 = up8((br0->n_conv + f.CPB0 - 1) / f.CPB0);
+  f.nb_br0 = fusable_mh ? up8((br0->n_conv + ROME_WPB - 1) / ROME_WPB) : up8((br0->n_conv + f.CPB0 - 1) / f.CPB0);
   const uintptr_t al = (uintptr_t)p2p2->bel_fixed | (uintptr_t)p2p2->out | (uintptr_t)p2p2->mirror_out | (uintptr_t)br0->bel_fixed |
                        (uintptr_t)br0->out | (uintptr_t)br0->mirror_out;
   const bool vec2 = (N % 2 == 0) && (al % 16 == 0);
   const int nb = f.nb_br1 + f.nb_p2p2 + f.nb_br0;
-  if (vec2) hipLaunchKernelGGL((k_sweep_fused<true>), dim3(nb), dim3(256), 0, s, f);
-  else      hipLaunchKernelGGL((k_sweep_fused<false>), dim3(nb), dim3(256), 0, s, f);
+  if (fusable_mh) {
+    if (vec2) hipLaunchKernelGGL((k_sweep_fused_mh<true>), dim3(nb), dim3(256), 0, s, f);
+    else      hipLaunchKernelGGL((k_sweep_fused_mh<false>), dim3(nb), dim3(256), 0, s, f);
+  } else {
+    if (vec2) hipLaunchKernelGGL((k_sweep_fused<true>), dim3(nb), dim3(256), 0, s, f);
+    else      hipLaunchKernelGGL((k_sweep_fused<false>), dim3(nb), dim3(256), 0, s, f);
+  }
   return hipGetLastError();
 }
 template <int D>

@@ -3,7 +3,7 @@
 # k_conv_flat<BR<0>>, k_conv<BR<1>,*>, k_conv_flat<P3P3>, k_conv<*,gauss_newton>, k_conv<P2P2,nelder_mead> -- on
 # scripts/other_factors.py (helix 10k Pose3 + MIT-like bearing-range graph): kernel trace, FETCH_SIZE / WRITE_SIZE (separate passes
 # + copy8 calibration), SQ counters.  Summary -> gpurun_out/<tag>/<tag>_other_factors_trace.md
-tag=${1:-r03}
+tag=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$tag; T=/tmp/prof_other_$tag; mkdir -p $O $T
 cd /tmp && export TMPDIR=/tmp
 export ROME_OTHER_QUICK=1
@@ -40,7 +40,7 @@ def alg(name):
     m = re.search(r"k_conv(_flat)?<rome::(P2P2|P3P3|BR<(\d)>), *(\w+)", name)
     if not m: return None
     flat, fam, d, sv = m.group(1), m.group(2), m.group(3), m.group(4)
-    start = not flat and sv in ("2", "3")          # Nelder-Mead / Gauss-Newton read the start points; closed form (0) of unique-root factors does not
+    start = sv in ("2", "3")                       # Nelder-Mead / Gauss-Newton read the start points; closed form (0) of unique-root factors does not
     if fam == "P3P3": return 23990 * 100 * (144 if start else 96) + 100 * 48, 23991
     if fam == "BR<0>": return 5978 * 100 * (56 if start else 40), 5978
     if fam == "BR<1>": return 5978 * 100 * 64, 5978
@@ -48,7 +48,7 @@ def alg(name):
 lines = ["Non-headline factor kernels, N = 100, scripts/other_factors.py under rocprofv3 (ROME_OTHER_QUICK=1): kernel-trace average duration; HBM bytes per",
          "launch from --pmc FETCH_SIZE (x%.0f, gfx950 correction calibrated on scripts/ubench/copy8 in the same run) and --pmc WRITE_SIZE (separate passes);" % scale,
          "SQ counters from a third pass.  alg = algorithmic bytes per launch (SURVEY 8(d); unique-root closed form / Newton do not read the start points).",
-         "solver template argument: 0 closed form (= NEWTON without status), 2 Nelder-Mead, 3 Gauss-Newton; k_conv_flat = packed unique-root sweep.", "",
+         "solver template argument: 0 closed form (= NEWTON without status), 2 Nelder-Mead, 3 Gauss-Newton; k_conv_flat = packed unique-root sweep (closed form or Gauss-Newton).", "",
          "| kernel | launches | avg µs | vgpr | scratch | rows | alg MB | alg GB/s | frac of 8 TB/s | HBM MB (PMC) | HBM GB/s | VALU/wave | VALU busy | FP64-VALU note |",
          "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for n in sorted(dur, key=lambda k: -dur[k][0] * dur[k][1]):

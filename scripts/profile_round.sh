@@ -3,7 +3,7 @@
 # rocprofv3 evidence for profiles/: kernel traces of bench.py for the three solvers, HBM traffic (FETCH_SIZE / WRITE_SIZE in
 # separate --pmc passes + the copy8 calibration), SQ counters.  Raw rocprof output stays in /tmp; only summaries go to
 # gpurun_out/<tag>/ (copy what is to be judged into profiles/).
-tag=${1:-r03}
+tag=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$tag; T=/tmp/prof_$tag; mkdir -p $O $T
 cd /tmp && export TMPDIR=/tmp
 if [ -z "$SKIP_TRACES" ]; then

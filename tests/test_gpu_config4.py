@@ -166,7 +166,7 @@ def test_fused_graph_sweep_equals_per_family_launches_bit_for_bit(N):
         b0 = dg.sweep_bearingrange(dg._opts_at(o, dg.STREAM_BR0), 0)
         for x, y in ((a2, b2), (a1, b1), (a0, b0)):
             assert np.array_equal(x.cpu().numpy(), y.cpu().numpy())
-    fg2 = _graph(20, 100)                                      # beehive with multihypo: falls back inside the library
+    fg2 = _graph(20, 100)                                      # beehive with multihypo sightings: ONE fused launch too (k_sweep_fused_mh)
     dg2 = R.DeviceGraph(fg2); dg2.upload_beliefs(fg2)
     assert dg2.tab["br"]["mh"]
     o = R.make_opts(N=100, solver=1, seed=12)
@@ -175,6 +175,29 @@ def test_fused_graph_sweep_equals_per_family_launches_bit_for_bit(N):
     dg2.sweep_graph_pose2(o, a2, a1, a0)
     assert np.array_equal(a1.cpu().numpy(), dg2.sweep_bearingrange(dg2._opts_at(o, dg2.STREAM_BR1), 1).cpu().numpy())
     assert np.array_equal(a0.cpu().numpy(), dg2.sweep_bearingrange(dg2._opts_at(o, dg2.STREAM_BR0), 0).cpu().numpy())
+    assert np.array_equal(a2.cpu().numpy(), dg2.sweep_pose2pose2(dg2._opts_at(o, dg2.STREAM_P2P2)).cpu().numpy())
+    if N == 100:   # event-timed: the beehive sweep as three per-family launches against the one fused launch -> gpurun_out/
+        import torch
+
+        def timeit(fn, reps=300):
+            for _ in range(200):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return 1e3 * e0.elapsed_time(e1) / reps
+
+        def three():
+            dg2.sweep_bearingrange(dg2._opts_at(o, dg2.STREAM_BR1), 1, out=a1); dg2.sweep_pose2pose2(dg2._opts_at(o, dg2.STREAM_P2P2), out=a2)
+            dg2.sweep_bearingrange(dg2._opts_at(o, dg2.STREAM_BR0), 0, out=a0)
+        t3, t1 = timeit(three), timeit(lambda: dg2.sweep_graph_pose2(o, a2, a1, a0))
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "r04_beehive_fused_sweep.txt"), "w") as f:
+            f.write("beehive + multihypo sightings (synth_beehive_mh(20): %d p2p2 + %d br->pose + %d br->landmark rows, N=100), one convolution sweep, HIP events:\n"
+                    "  three per-family launches %.2f us | ONE fused launch (k_sweep_fused_mh: wave bodies with multihypo columns + packed odometry) %.2f us\n" % (C2, Fb, Fb0, t3, t1))
 
 
 def torch_empty(dg, shape):
