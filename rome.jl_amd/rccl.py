@@ -32,6 +32,8 @@ def _load(torch):
         lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
         lib.ncclCommDestroy.restype = C.c_int
         lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        lib.ncclCommAbort.restype = C.c_int
+        lib.ncclCommAbort.argtypes = [C.c_void_p]
         lib.ncclAllGather.restype = C.c_int
         lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         lib.ncclGetErrorString.restype = C.c_char_p
@@ -79,13 +81,23 @@ def _init_group(torch, device, lib, world, rank, uids, out):
     out["rc"], out["handles"] = rc, handles
 
 
+_unusable = False   # set when an initialisation timed out in THIS process: a thread may still sit inside ncclGroupEnd
+
+
 def create_comms(torch, dist, world, rank, device, n):
     """n independent communicators over the ranks of the default process group, or None -- ON EVERY RANK -- if anything failed
     anywhere.  Failure is agreed ONCE before the collective initialisation (unique ids) and ONCE after it; the initialisation
     itself is one ncclGroup over all n communicators, run under a watchdog (ROME_RCCL_INIT_TIMEOUT_S, default 120 s): a rank whose
-    peers never arrive reports failure through torch.distributed instead of blocking its main thread forever."""
+    peers never arrive reports failure through torch.distributed instead of blocking its main thread forever.
+    After a timeout the process is marked RCCL-unusable: the watchdog's thread may still be inside ncclGroupEnd on this device, so
+    every later create_comms in this process reports failure up front (agreed across ranks like any other failure) and the caller
+    stays on torch.distributed -- the documented fallback.  Communicators of a failed initialisation are ABORTED (ncclCommAbort:
+    no handshake with a peer that may still be initialising), never destroyed."""
     import threading
+    global _unusable
     comms, ok, lib = [], 1, None
+    if _unusable:
+        ok = 0
     try:
         lib = _load(torch)
         ids = torch.zeros((n, NCCL_UNIQUE_ID_BYTES), dtype=torch.uint8, device=device)
@@ -115,8 +127,12 @@ def create_comms(torch, dist, world, rank, device, n):
             th = threading.Thread(target=_init_group, args=(torch, device, lib, world, rank, uids, res), daemon=True)
             th.start()
             th.join(float(os.environ.get("ROME_RCCL_INIT_TIMEOUT_S", "120")))
-            if th.is_alive() or res.get("rc", 1) != 0:
+            if th.is_alive():
                 ok = 0     # (a thread still inside ncclGroupEnd is left behind: its communicators are never used)
+                _unusable = True
+            elif res.get("rc", 1) != 0:
+                ok = 0
+                handles = [h for h in res.get("handles", []) if h]   # partially created: aborted below
             else:
                 handles = res["handles"]
         except Exception:   # noqa: BLE001
@@ -127,7 +143,7 @@ def create_comms(torch, dist, world, rank, device, n):
     if int(flag.item()) == 0:
         for h in handles:
             try:
-                lib.ncclCommDestroy(h)
+                lib.ncclCommAbort(h)
             except Exception:   # noqa: BLE001
                 pass
         return None

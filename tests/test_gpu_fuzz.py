@@ -99,3 +99,41 @@ def test_random_configurations(trial):
         dt = np.abs(out[:, :3] - ref[:, :3]).max(axis=1).reshape(-1)
         assert dt[~near].max(initial=0.0) < 1e-8 and dt[near].max(initial=0.0) < 1e-4, (kind, N, kw)
         assert ang[~near].max(initial=0.0) < 1e-8 and ang[near].max(initial=0.0) < 2e-4, (kind, N, kw)
+
+
+def test_device_measurement_normals_law_independent_of_the_oracle():
+    """The in-kernel normal generator judged against N(0, 1) ITSELF -- scipy, no oracle -- on ~1e6 device draws per layout: Pose2
+    measurements (d = 3: ONE Philox call per particle pair cut into six 21-bit Box-Muller fields; particles 2j, 2j+1 share the radius
+    of the third pair), Point2 (d = 2) and Pose3 (d = 6) with full 32-bit words.  Moments, Kolmogorov-Smirnov, tail mass, and the
+    correlation -- of the values AND of their squares (a shared radius shows up there) -- between the same coordinate of neighbouring
+    particles.  The draws are read off prior samples with unit covariance (rome_sample_prior*: proposal = mu + L xi)."""
+    from scipy import stats
+    N = 100
+    for d, sample, C_ in ((3, R.sample_priorpose2, 3400), (2, R.sample_priorpoint2, 5000), (6, R.sample_priorpose3, 1700)):
+        scale = np.ones(d)
+        if d == 3:
+            scale[2] = 0.25          # the heading is wrapped to (-pi, pi]: sigma = 0.25 keeps 12 sigma inside
+        if d == 6:
+            scale[3:] = 0.05         # rotation vector: small angles, Log(Exp(w)) = w
+        cov = np.diag(scale ** 2)
+        out = sample(R.make_opts(N=N, seed=0x5EED + d), np.zeros((C_, d)), np.tile(cov, (C_, 1, 1)))     # (C, d, N)
+        xi = out / scale[None, :, None]
+        n = xi.size
+        assert n >= 1e6 - 1
+        flat = xi.reshape(-1)
+        assert abs(flat.mean()) < 4.0 / np.sqrt(n) and abs(flat.var() - 1.0) < 6.0 * np.sqrt(2.0 / n)
+        assert abs(stats.kurtosis(flat)) < 0.03 and abs(stats.skew(flat)) < 0.015
+        for k in range(d):
+            col = xi[:, k, :].reshape(-1)
+            ks = stats.kstest(col, "norm").statistic
+            assert ks < 2.2 / np.sqrt(col.size), (d, k, ks)                 # (the 1 % critical value is 1.63 / sqrt(n))
+            tail = np.mean(np.abs(col) > 3.0)
+            assert abs(tail - 2.0 * stats.norm.sf(3.0)) < 6.0 * np.sqrt(2.7e-3 / col.size), (d, k, tail)
+            a, b = xi[:, k, 0::2].reshape(-1), xi[:, k, 1::2].reshape(-1)   # the same coordinate of particles 2j and 2j+1
+            lim = 5.0 / np.sqrt(a.size)
+            assert abs(np.corrcoef(a, b)[0, 1]) < lim, (d, k)
+            assert abs(np.corrcoef(a * a, b * b)[0, 1]) < lim, (d, k, np.corrcoef(a * a, b * b)[0, 1])
+        # different coordinates of one particle are uncorrelated too (values and squares)
+        cc = np.corrcoef(xi.transpose(1, 0, 2).reshape(d, -1)); c2 = np.corrcoef((xi ** 2).transpose(1, 0, 2).reshape(d, -1))
+        off = ~np.eye(d, dtype=bool)
+        assert np.abs(cc[off]).max() < 5.0 / np.sqrt(C_ * N) and np.abs(c2[off]).max() < 5.0 / np.sqrt(C_ * N)
