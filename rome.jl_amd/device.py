@@ -81,8 +81,14 @@ class DeviceGraph:
                 alt = np.concatenate([alt2, np.full(P, -1, np.int32), ex["alt"]]); w = np.concatenate([w2, np.ones(P), ex["w"]])
                 factor = np.concatenate([factor, ex["factor"]]); dr = np.concatenate([dr, ex["dir"]])
                 fixed = np.concatenate([fixed, ex["fixed"]]); target = np.concatenate([target, ex["target"]])
+            # nullhypo=p factors: one probability per row (both directions and the extra row of the factor; prior rows 0)
+            nhf = tab.get("nh")
+            nh = None
+            if nhf is not None and np.any(nhf > 0):
+                nh = np.concatenate([np.repeat(nhf, 2), np.zeros(P)] + ([nhf[ex["factor"]]] if E else []))
             # rows4: the four table columns interleaved (one 16-byte scalar load per convolution; selects the lean kernel)
             self.tab[name] = dict(F=F, P=P, E=E, C_rel=2 * F, C=2 * F + P + E, mu=t(mu, f64), L=t(cholesky_lower(cov), f64),
+                                  nh=t(nh, f64) if nh is not None else None,
                                   factor=t(factor, i32), dir=t(dr, i32), fixed=t(fixed, i32), target=t(target, i32),
                                   rows4=t(np.stack([factor, dr, fixed, target], axis=1), i32), mh=hyp is not None,
                                   alt=t(alt, i32) if alt is not None else None, w=t(w, f64) if w is not None else None)
@@ -90,7 +96,10 @@ class DeviceGraph:
             b = pk.br
             r0 = b["rows0"]
             mh = bool((b["alt"] >= 0).any())
+            nhb = b.get("nh")
+            has_nh = nhb is not None and bool(np.any(nhb > 0))
             self.tab["br"] = dict(F=b["F"], F0=len(r0["factor"]), mh=mh, mu=t(b["mu"], f64), sigma=t(b["sigma"], f64),
+                                  nh=t(nhb, f64) if has_nh else None, nh0=t(nhb[r0["factor"]], f64) if has_nh else None,
                                   pose=t(b["pose"], i32), point=t(b["point"], i32), alt=t(b["alt"], i32), w=t(b["w"], f64),
                                   factor0=t(r0["factor"], i32), pose0=t(r0["pose"], i32), point0=t(r0["point"], i32),
                                   alt0=t(r0["alt"], i32), w0=t(r0["w"], f64),
@@ -177,13 +186,13 @@ class DeviceGraph:
         if fam in ("p2p2", "p3p3"):
             tb = self.tab[fam]
             return dict(n=tb["C"], fn=fn, vt_fixed=vf, vt_target=vt, dir_all=0, rows4=tb["rows4"], mu=tb["mu"], L=tb["L"],
-                        alt=tb["alt"] if tb["mh"] else None, w=tb["w"] if tb["mh"] else None)
+                        alt=tb["alt"] if tb["mh"] else None, w=tb["w"] if tb["mh"] else None, nh=tb["nh"])
         tb = self.tab["br"]
         if fam == "br1":
             return dict(n=tb["F"], fn=fn, vt_fixed=vf, vt_target=vt, dir_all=1, rows4=tb["rows4_1"], mu=tb["mu"], L=tb["sigma"],
-                        alt=tb["alt"] if tb["mh"] else None, w=tb["w"] if tb["mh"] else None)
+                        alt=tb["alt"] if tb["mh"] else None, w=tb["w"] if tb["mh"] else None, nh=tb["nh"])
         return dict(n=tb["F0"], fn=fn, vt_fixed=vf, vt_target=vt, dir_all=0, rows4=tb["rows4_0"], mu=tb["mu"], L=tb["sigma"],
-                    alt=tb["alt0"] if tb["mh"] else None, w=tb["w0"] if tb["mh"] else None)
+                    alt=tb["alt0"] if tb["mh"] else None, w=tb["w0"] if tb["mh"] else None, nh=tb["nh0"])
 
     # ---- belief store ----
     def upload_beliefs(self, fg):
@@ -246,6 +255,8 @@ class DeviceGraph:
         per-launch lookup of torch's current stream (5.4 -> ~2 us of host time per launch)"""
         tb = self.tab["p2p2"]
         mh = dict(alt_var=tb["alt"], hypo_w=tb["w"]) if tb["mh"] else {}
+        if tb["nh"] is not None:
+            mh["nullhypo"] = tb["nh"]
         if fixed_ctx is not None:
             mh["_ctx"] = fixed_ctx
         return self._plan(self._lib.rome_conv_pose2pose2_dev, opts, n_conv=tb["C"], dir_all=0,
@@ -448,6 +459,8 @@ class DeviceGraph:
             out = self.torch.empty((n, 3, self.N), dtype=self.torch.float64, device=self.device)
         o = _lib.Opts.from_buffer_copy(opts); o.stream_offset = opts.stream_offset + lo
         mh = dict(alt_var=tb["alt"][lo:hi], hypo_w=tb["w"][lo:hi]) if tb["mh"] else {}
+        if tb["nh"] is not None:
+            mh["nullhypo"] = tb["nh"][lo:hi]
         self._launch(self._lib.rome_conv_pose2pose2_dev, o, n_conv=n, dir_all=0,
                      factor=tb["factor"][lo:hi], dir=tb["dir"][lo:hi], fixed_var=tb["fixed"][lo:hi], target_var=tb["target"][lo:hi],
                      rows4=tb["rows4"][lo:hi], mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Pose2],
@@ -461,7 +474,7 @@ class DeviceGraph:
         self._launch(self._lib.rome_conv_pose3pose3_dev, opts, n_conv=tb["C"], dir_all=0,
                      factor=tb["factor"], dir=tb["dir"], fixed_var=tb["fixed"], target_var=tb["target"], rows4=tb["rows4"],
                      mu=tb["mu"], L=tb["L"], bel_fixed=self.bel[Pose3], bel_target=self.bel[Pose3],
-                     noise=noise, out=out, status=status)
+                     noise=noise, out=out, status=status, **({"nullhypo": tb["nh"]} if tb["nh"] is not None else {}))
         return out
 
     def sweep_bearingrange(self, opts, direction, out=None, noise=None, status=None):
@@ -477,11 +490,15 @@ class DeviceGraph:
                       bel_fixed=self.bel[Pose2], bel_target=self.bel[Point2])
             if tb["mh"]:
                 kw.update(alt_var=tb["alt0"], hypo_w=tb["w0"])
+            if tb["nh0"] is not None:
+                kw.update(nullhypo=tb["nh0"])
         else:
             kw = dict(factor=None, fixed_var=tb["point"], target_var=tb["pose"], rows4=tb["rows4_1"],
                       bel_fixed=self.bel[Point2], bel_target=self.bel[Pose2])
             if tb["mh"]:
                 kw.update(alt_var=tb["alt"], hypo_w=tb["w"])
+            if tb["nh"] is not None:
+                kw.update(nullhypo=tb["nh"])
         self._launch(self._lib.rome_conv_pose2point2br_dev, opts, n_conv=nrow, dir_all=int(direction), dir=None,
                      mu=tb["mu"], L=tb["sigma"], noise=noise, out=out, status=status, **kw)
         return out
@@ -504,12 +521,18 @@ class DeviceGraph:
         keep = []
         t2, tb = self.tab["p2p2"], self.tab["br"]
         mh2 = dict(alt_var=t2["alt"], hypo_w=t2["w"]) if t2["mh"] else {}
+        if t2["nh"] is not None:
+            mh2["nullhypo"] = t2["nh"]
         c2 = self._conv_dev(keep, n_conv=t2["C"], dir_all=0, rows4=t2["rows4"], factor=t2["factor"], dir=t2["dir"], fixed_var=t2["fixed"],
                             target_var=t2["target"], mu=t2["mu"], L=t2["L"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Pose2], out=out_p2p2, **mh2)
         mh1 = dict(alt_var=tb["alt"], hypo_w=tb["w"]) if tb["mh"] else {}
+        if tb["nh"] is not None:
+            mh1["nullhypo"] = tb["nh"]
         c1 = self._conv_dev(keep, n_conv=tb["F"], dir_all=1, rows4=tb["rows4_1"], fixed_var=tb["point"], target_var=tb["pose"], mu=tb["mu"],
                             L=tb["sigma"], bel_fixed=self.bel[Point2], bel_target=self.bel[Pose2], out=out_br1, **mh1)
         mh0 = dict(alt_var=tb["alt0"], hypo_w=tb["w0"]) if tb["mh"] else {}
+        if tb["nh0"] is not None:
+            mh0["nullhypo"] = tb["nh0"]
         c0 = self._conv_dev(keep, n_conv=tb["F0"], dir_all=0, rows4=tb["rows4_0"], factor=tb["factor0"], fixed_var=tb["pose0"],
                             target_var=tb["point0"], mu=tb["mu"], L=tb["sigma"], bel_fixed=self.bel[Pose2], bel_target=self.bel[Point2],
                             out=out_br0, **mh0)

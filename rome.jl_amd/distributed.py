@@ -221,6 +221,8 @@ class SeparatorPipeline:
                           bel_fixed=self.store[tb["vt_fixed"]], bel_target=self.store[vt_t], out=self.out[b][f])
                 if alt is not None:
                     kw.update(alt_var=alt, hypo_w=tb["w"])
+                if tb.get("nh") is not None:     # nullhypo= factors: one probability per row
+                    kw.update(nullhypo=tb["nh"])
                 if pub_by_f[f]:
                     lo = sec_off[vt_t] + slot0[f] * dim[vt_t] * N
                     # any number of separator rows per family: row -> slot map (rome_conv_dev.mirror_map), -1 = not published
@@ -341,6 +343,9 @@ class TargetShardedSweep:
             idx = torch.as_tensor(order, device=tb["alt"].device)
             self.alt, self.w = tb["alt"][idx].contiguous(), torch.as_tensor(tb["w"])[idx.to(torch.as_tensor(tb["w"]).device)].contiguous()
             mh = dict(alt_var=self.alt[self.row_lo:self.row_hi], hypo_w=self.w[self.row_lo:self.row_hi])
+        if tb.get("nh") is not None:   # nullhypo rows likewise
+            self.nh = tb["nh"][torch.as_tensor(order, device=tb["nh"].device)].contiguous()
+            mh["nullhypo"] = self.nh[self.row_lo:self.row_hi]
         self._mh = mh
         self.plan = dg._plan(tb["fn"], o, n_conv=n, dir_all=tb["dir_all"], rows4=self.rows4[self.row_lo:self.row_hi], mu=tb["mu"], L=tb["L"],
                              bel_fixed=self.store, bel_target=self.store, out=self.prop[self.row_lo:self.row_hi], **mh) if n else (lambda: None)

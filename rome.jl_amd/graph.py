@@ -437,6 +437,7 @@ class PackedGraph:
             self.index[l] = len(self.labels[t])
             self.labels[t].append(l)
         p2, br, p3, pr2, pr3, prpt = [], [], [], [], [], []
+        nullh = getattr(fg, "nullhypo", {})
         for flabel, labels, f in fg.factors:
             ids = [self.index[l] for l in labels]
             if isinstance(f, Pose2Pose2): p2.append((ids, f, flabel, fg.multihypo.get(flabel)))
@@ -451,12 +452,13 @@ class PackedGraph:
             F = len(items)
             mu = np.zeros((F, d)); cov = np.zeros((F, d, d))
             vfrom = np.zeros(F, dtype=np.int32); vto = np.zeros(F, dtype=np.int32)
-            alt = np.full(F, -1, dtype=np.int32); w = np.ones(F); w2 = np.zeros(F)
-            for k, (ids, f, _, mh) in enumerate(items):
+            alt = np.full(F, -1, dtype=np.int32); w = np.ones(F); w2 = np.zeros(F); nh = np.zeros(F)
+            for k, (ids, f, fl, mh) in enumerate(items):
                 mu[k] = f.Z.mu; cov[k] = f.Z.cov; vfrom[k], vto[k] = ids[:2]
+                nh[k] = nullh.get(fl, 0.0)      # IIF nullhypo= of the factor: every row of the factor carries it
                 if mh is not None:   # multihypo over the second pose: var_to with probability w, else alt
                     alt[k] = ids[2]; w[k], w2[k] = mh
-            return dict(F=F, mu=mu, cov=cov, var_from=vfrom, var_to=vto, alt=alt, w=w, w2=w2, labels=[it[2] for it in items])
+            return dict(F=F, mu=mu, cov=cov, var_from=vfrom, var_to=vto, alt=alt, w=w, w2=w2, nh=nh, labels=[it[2] for it in items])
 
         self.p2p2 = rel_tables(p2, 3)
         self.p3p3 = rel_tables(p3, 6)
@@ -474,6 +476,7 @@ class PackedGraph:
                        point=np.array([ids[1] for ids, _, _, _ in br], dtype=np.int32),
                        alt=np.array([(-1 if mh is None else ids[2]) for ids, _, _, mh in br], dtype=np.int32),
                        w=np.array([(1.0 if mh is None else mh[0]) for _, _, _, mh in br], dtype=np.float64),
+                       nh=np.array([nullh.get(fl, 0.0) for _, _, fl, _ in br], dtype=np.float64),
                        rows0={k: np.asarray(v, dtype=(np.float64 if k == "w" else np.int32)) for k, v in r0.items()},
                        labels=[it[2] for it in br])
 

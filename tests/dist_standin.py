@@ -49,6 +49,8 @@ class OracleDG:
         if kw.get("mirror_map") is not None:   # row -> slot map: the rows in slot order
             mm = kw["mirror_map"].numpy()
             mirror_rows = [int(np.nonzero(mm == m)[0][0]) for m in range(int(mm.max()) + 1)] if (mm >= 0).any() else ()
+        if kw.get("nullhypo") is not None:
+            raise NotImplementedError("the oracle stand-in does not model per-row nullhypo columns")
         alt = kw["alt_var"].numpy() if kw.get("alt_var") is not None else None
         hw = np.asarray(kw["hypo_w"], dtype=np.float64) if kw.get("hypo_w") is not None else None
         o_keep = type(opts).from_buffer_copy(opts) if opts is not None else None   # (a cached plan's stream offset may be updated in place)

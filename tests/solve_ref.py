@@ -39,15 +39,27 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
         return np.cumsum(ptr).astype(np.int32), order
     ptr2, rows2 = csr(tg2, bel2.shape[0]); ptrl, rowsl = csr(tgl, bell.shape[0])
     S = dict(P2P2=0, BR1=1 << 28, BR0=2 << 28, PROD2=3 << 28, PRODL=4 << 28)
+    nh2 = pk.p2p2.get("nh"); nhb = pk.br.get("nh") if Fb else None
+    nh2 = nh2 if (nh2 is not None and np.any(nh2 > 0)) else None
+    nhb = nhb if (nhb is not None and np.any(nhb > 0)) else None
     for s in range(n_sweeps):
         base = s << 32
-        mk = lambda off: ro.make_opts(N=N, solver=solver, seed=seed, stream_offset=base + off)
+        mk = lambda off, nh=0.0: ro.make_opts(N=N, solver=solver, seed=seed, stream_offset=base + off, nullhypo=float(nh))
         prop2 = np.zeros((C2 + Fb, 3, N))
         mhkw = {} if hyp is None else dict(alt_var=alt2, hypo_w=w2)
-        prop2[:2 * F] = ro.conv_pose2pose2(mk(S["P2P2"]), mu, L, bel2, fixed[:2 * F], target[:2 * F], dr[:2 * F], factor=factor[:2 * F], **mhkw)
+        if nh2 is None:
+            prop2[:2 * F] = ro.conv_pose2pose2(mk(S["P2P2"]), mu, L, bel2, fixed[:2 * F], target[:2 * F], dr[:2 * F], factor=factor[:2 * F], **mhkw)
+        else:   # nullhypo= factors: the oracle takes one probability per call -> row by row (Philox stream = row index either way)
+            for r in range(2 * F):
+                kw = {} if hyp is None else dict(alt_var=alt2[r:r + 1], hypo_w=w2[r:r + 1])
+                prop2[r] = ro.conv_pose2pose2(mk(S["P2P2"] + r, nh2[factor[r]]), mu, L, bel2, fixed[r:r + 1], target[r:r + 1], dr[r:r + 1],
+                                              factor=factor[r:r + 1], **kw)[0]
         if E:   # the proposals of the second candidates: rows behind the priors, Philox stream = row index
-            prop2[2 * F + P:C2] = ro.conv_pose2pose2(mk(S["P2P2"] + 2 * F + P), mu, L, bel2, ex["fixed"], ex["target"], ex["dir"],
-                                                     factor=ex["factor"], alt_var=ex["alt"], hypo_w=ex["w"])
+            for e in range(E):
+                r = 2 * F + P + e
+                prop2[r] = ro.conv_pose2pose2(mk(S["P2P2"] + r, 0.0 if nh2 is None else nh2[ex["factor"][e]]), mu, L, bel2, ex["fixed"][e:e + 1],
+                                              ex["target"][e:e + 1], ex["dir"][e:e + 1], factor=ex["factor"][e:e + 1], alt_var=ex["alt"][e:e + 1],
+                                              hypo_w=ex["w"][e:e + 1])[0]
         # prior rows: stream id = row index
         for k in range(P):
             o = ro.make_opts(N=N, seed=seed, stream_offset=base + S["P2P2"] + 2 * F + k)
@@ -55,11 +67,20 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
         propl = np.zeros((Fb0 + Ppt, 2, N))
         if Ppt:
             propl[Fb0:] = ro.sample_priorpoint2(mk(7 << 28), pk.priorpt2["mu"].reshape(Ppt, 2), Lpt)
-        if Fb:
+        if Fb and nhb is None:
             prop2[C2:] = ro.conv_pose2point2br(mk(S["BR1"]), 1, pk.br["mu"], pk.br["sigma"], bell, bel2, pk.br["point"], pk.br["pose"],
                                                alt_var=pk.br["alt"] if mh else None, hypo_w=pk.br["w"] if mh else None)
             propl[:Fb0] = ro.conv_pose2point2br(mk(S["BR0"]), 0, pk.br["mu"], pk.br["sigma"], bel2, bell, r0["pose"], r0["point"], factor=r0["factor"],
                                              alt_var=r0["alt"] if mh else None, hypo_w=r0["w"] if mh else None)
+        elif Fb:
+            for r in range(Fb):
+                kw = dict(alt_var=pk.br["alt"][r:r + 1], hypo_w=pk.br["w"][r:r + 1]) if mh else {}
+                prop2[C2 + r] = ro.conv_pose2point2br(mk(S["BR1"] + r, nhb[r]), 1, pk.br["mu"], pk.br["sigma"], bell, bel2, pk.br["point"][r:r + 1],
+                                                      pk.br["pose"][r:r + 1], factor=[r], **kw)[0]
+            for r in range(Fb0):
+                kw = dict(alt_var=r0["alt"][r:r + 1], hypo_w=r0["w"][r:r + 1]) if mh else {}
+                propl[r] = ro.conv_pose2point2br(mk(S["BR0"] + r, nhb[r0["factor"][r]]), 0, pk.br["mu"], pk.br["sigma"], bel2, bell, r0["pose"][r:r + 1],
+                                                 r0["point"][r:r + 1], factor=r0["factor"][r:r + 1], **kw)[0]
         lcv = bandwidth == "lcv"
         if product == "gibbs":   # the reference's product: multiscale Gibbs sampling on the manikde! bandwidths of the proposals
             bel2 = ro.product_msgibbs(mk(S["PROD2"]), 3, ptr2, rows2, prop2, ro.kde_bandwidths(prop2, 0b100), bel2, 0b100, 1)

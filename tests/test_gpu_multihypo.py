@@ -231,3 +231,50 @@ def test_priorpoint2_nonparametric_sampling_and_solve_loop_vs_oracle():
     assert np.mean(np.abs(gl - bl) < 1e-6) > 0.9 and np.mean(np.abs(_wd(g2, b2)) < 1e-6) > 0.9
     assert np.abs(gl[0].mean(1) - [20.0, 0.0]).max() < 0.2 and gl[0].std(1).max() < 0.3      # pinned by its prior
     assert np.abs(g2[0, :2].mean(1)).max() < 0.5
+
+
+def test_nullhypo_factors_in_the_device_graph_tables():
+    """`addFactor(..., nullhypo=p)` (test/testPose3Pose3NH.jl:118) on the GRAPH path: DeviceGraph carries one probability per table row;
+    every row of a whole-graph sweep = the per-factor call with the factor's nullhypo, bit for bit (Pose2Pose2, both bearing-range
+    directions, the fused sweep entry), and DeviceGraph.solve = the oracle's restatement of the loop."""
+    from solve_ref import solve_ref
+    N = 100
+    rng = np.random.default_rng(5)
+
+    def graph():
+        fg = R.initfg(N)
+        fg.addVariable("x0", R.Pose2); fg.addFactor(["x0"], R.PriorPose2(R.MvNormal([0.0, 0, 0], np.diag([0.1, 0.1, 0.01]) ** 2)))
+        cov = np.diag([0.1, 0.1, 0.01]) ** 2
+        for k in range(1, 5):
+            fg.addVariable("x%d" % k, R.Pose2)
+            fg.addFactor(["x%d" % (k - 1), "x%d" % k], R.Pose2Pose2(R.MvNormal([5.0, 0, 0.3], cov)), nullhypo=0.3 if k == 2 else None)
+        fg.addFactor(["x4", "x0"], R.Pose2Pose2(R.MvNormal([-3.0, -9.0, -1.2], cov)), nullhypo=0.5)     # a doubtful loop closure
+        fg.addVariable("l1", R.Point2)
+        fg.addFactor(["x0", "l1"], R.Pose2Point2BearingRange(R.Normal(0, 0.05), R.Normal(10.0, 0.3)))
+        fg.addFactor(["x3", "l1"], R.Pose2Point2BearingRange(R.Normal(1.0, 0.05), R.Normal(12.0, 0.3)), nullhypo=0.4)
+        R.dead_reckon_init(fg, seed=3)
+        return fg
+    fg = graph()
+    assert len(fg.nullhypo) == 3
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    assert dg.tab["p2p2"]["nh"] is not None and dg.tab["br"]["nh"] is not None
+    o = R.make_opts(N=N, seed=13)
+    dg.conv_step(o, 0)
+    p2 = dg.prop[R.Pose2].cpu().numpy(); pl = dg.prop[R.Point2].cpu().numpy()
+    pk = dg.packed
+    C2 = dg.tab["p2p2"]["C"]
+    for f, fl in enumerate(pk.p2p2["labels"]):
+        labels = fg.getFactor(fl)[1]
+        for d, tgt in ((0, labels[1]), (1, labels[0])):
+            ref = R.approxConv(fg, fl, tgt, seed=13, stream_offset=dg.STREAM_P2P2 + 2 * f + d, nullhypo=fg.nullhypo.get(fl, 0.0))
+            assert np.array_equal(p2[2 * f + d], ref), (fl, d)
+    for k, fl in enumerate(pk.br["labels"]):
+        labels = fg.getFactor(fl)[1]
+        nh = fg.nullhypo.get(fl, 0.0)
+        assert np.array_equal(p2[C2 + k], R.approxConv(fg, fl, labels[0], seed=13, stream_offset=dg.STREAM_BR1 + k, nullhypo=nh)), fl
+        assert np.array_equal(pl[k], R.approxConv(fg, fl, labels[1], seed=13, stream_offset=dg.STREAM_BR0 + k, nullhypo=nh)), fl
+    # the loop: device == oracle
+    dg.solve(R.make_opts(N=N, solver=1, seed=21), n_sweeps=2, bandwidth="lcv", product="gibbs")
+    b2, bl = solve_ref(R, graph(), 2, N, seed=21, bandwidth="lcv", product="gibbs")
+    g2 = dg.bel[R.Pose2].cpu().numpy(); gl = dg.bel[R.Point2].cpu().numpy()
+    assert np.mean(np.abs(_wd(g2, b2)) < 1e-6) > 0.9 and np.mean(np.abs(gl - bl) < 1e-6) > 0.9
