@@ -26,7 +26,7 @@ from .clique import proposalbeliefs, predictbelief, CliqueBatch, upGibbsCliqueDe
 from .serialization import loadDFG, saveDFG, packFactor, unpackFactor, packBelief, unpackBelief
 from .parametric import solveGraphParametric, initParametric
 from .device import DeviceGraph
-from .solve import initAll, solveGraph
+from .solve import initAll, initAllOrdered, solveGraph
 from . import distributed
 
 

@@ -43,16 +43,17 @@ def greedy_colouring(fg, labels=None, nb=None):
     return classes
 
 
-def init_rounds(fg):
+def init_rounds(fg, initialised=()):
     """IIF `initAll!` (initSolvableAll! / doautoinit!) as rounds: round r = the variables that have, before the round, at least one
     factor whose OTHER variables are all initialised (a prior has none, so the prior-carrying variables form round 0); repeated until
-    nothing more can be initialised.  On a pose chain this is the hop distance from the priors.  -> (rounds, unreachable labels)"""
+    nothing more can be initialised.  On a pose chain this is the hop distance from the priors.  `initialised`: variables that already
+    have a belief -- like IIF, the pass leaves them alone and starts from them.  -> (rounds, unreachable labels)"""
     by_var = {l: [] for l in fg.variables}
     for _, labels, _ in fg.factors:
         for l in labels:
             by_var[l].append([o for o in labels if o != l])
-    done, rounds = set(), []
-    pending = list(fg.variables)
+    done, rounds = set(initialised), []
+    pending = [l for l in fg.variables if l not in done]
     while pending:
         cand = [l for l in pending if any(all(o in done for o in others) for others in by_var[l])]
         if not cand:
@@ -68,7 +69,9 @@ class OrderedSolve:
     store: DeviceStore (or a stand-in with the same interface: the CPU tests inject oracle-backed ones through plan_cls).
     kind:  "colour" (sweep = the colour classes in order) or "levels" (sweep = the groups of the init rounds outward and back)."""
 
-    def __init__(self, store, kind="colour", gibbsIters=1, Niter=1, plan_cls=None):
+    def __init__(self, store, kind="colour", gibbsIters=1, Niter=1, plan_cls=None, keep=()):
+        """keep: labels whose beliefs in the store are to be KEPT by the init pass (IIF initAll! only touches uninitialised variables);
+        sweeps update them like every other variable."""
         if kind not in ("colour", "levels"):
             raise ValueError("kind must be 'colour' or 'levels'")
         if plan_cls is None:
@@ -77,12 +80,12 @@ class OrderedSolve:
         self.store, self.kind = store, kind
         fg = store.fg
         nb = adjacency(fg)
-        self.levels, self.unreachable = init_rounds(fg)
+        self.levels, self.unreachable = init_rounds(fg, keep)
         if self.unreachable:
             raise ValueError("variables without a path to a prior: %s" % self.unreachable[:5])
         # ---- init pass: level by level, each level split into independent sets; usable = what has been initialised before the group
         self.init_groups, self.init_plans = [], []
-        done = set()
+        done = set(keep)
         for lv in self.levels:
             for grp in greedy_colouring(fg, lv, nb):
                 snapshot = frozenset(done)

@@ -37,19 +37,42 @@ def initAll(fg, seed=1, solver=None):
     return [l for l in fg.ls() if not fg.isInitialized(l)]
 
 
+def initAllOrdered(fg, seed=1, ctx=None, sweeps=0, kind="colour", solver=None):
+    """IIF `initAll!` on the device, with IIF's semantics: every variable WITHOUT a belief gets the `manifoldProduct` of the proposals of
+    ALL factors whose other variables already have one (`doautoinit!` -> `predictbelief`), in rounds outward from the priors and from
+    the variables that are initialised already (`schedule.OrderedSolve`: beliefs resident in a `DeviceStore`, one up-solve plan per
+    independent group); then `sweeps` ordered Gauss-Seidel sweeps over the whole graph.  Beliefs are written back to `fg`.
+    -> the OrderedSolve (its store keeps the beliefs on the device for further sweeps)."""
+    from .api import make_opts
+    from .clique import DeviceStore
+    from .schedule import OrderedSolve
+    keep = [l for l in fg.variables if fg.isInitialized(l)]
+    store = DeviceStore(fg, ctx=ctx)
+    osv = OrderedSolve(store, kind=kind, keep=keep)
+    kw = {} if solver is None else {"solver": solver}
+    osv.init(make_opts(N=fg.N, seed=seed, **kw))
+    if sweeps:
+        osv.sweep(make_opts(N=fg.N, seed=seed + 1, **kw), sweeps)
+    store.download(fg)
+    return osv
+
+
 def solveGraph(fg, n_sweeps=10, seed=0x524F4D45, init="graph", bandwidth="silverman", frozen=None, opts=None, product="importance",
                gibbs_iters=1):
     """initialise -> device sweeps -> download -> setPPE.  init: "graph" (initAll for whatever has no belief yet), "parametric"
-    (beliefs around solveGraphParametric's solution, like IIF's initParametricFrom!) or None (beliefs must exist).
+    (beliefs around solveGraphParametric's solution, like IIF's initParametricFrom!), "ordered" (initAllOrdered: IIF's initAll! order with
+    the product of ALL usable factors per variable, device-resident) or None (beliefs must exist).
     product: "gibbs" = the reference's `manifoldProduct` (multiscale Gibbs product on `manikde!` bandwidths) per variable,
     "importance" = the round-1 stand-in; gibbs_iters = AMP's `Niter` (1 at the reference's default; the relative weight of the modes of
     a multimodal product needs ~3, tests/test_gpu_gibbs.py).  Returns the DeviceGraph (beliefs stay resident for further sweeps)."""
     from .api import make_opts
     from .canonical import setPPE
     from .device import DeviceGraph
-    if init not in ("graph", "parametric", None):
-        raise ValueError("init must be 'graph', 'parametric' or None")
-    if init is not None:
+    if init not in ("graph", "parametric", "ordered", None):
+        raise ValueError("init must be 'graph', 'parametric', 'ordered' or None")
+    if init == "ordered":
+        initAllOrdered(fg, seed=seed & 0xFFFF)
+    elif init is not None:
         left = initAll(fg, seed=seed & 0xFFFF)
         if left:
             raise ValueError("variables without a path to a prior: %s" % left[:5])

