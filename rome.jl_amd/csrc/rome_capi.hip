@@ -14,6 +14,7 @@ struct rome_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipError_t last_hip = hipSuccess;
+  bool ws_used = false;   // a context-owned device workspace has been handed to work on `stream` since the last drain
   static constexpr int kBufs = 13;   // 9 clique arena, 10 Gibbs trees, 11 / 12 temporary store / plan of the one-shot up-solve
   void* dbuf[kBufs] = {nullptr};
   size_t dcap[kBufs] = {0};
@@ -54,6 +55,7 @@ int ensure(rome_ctx* c, int idx, size_t bytes, void** out) {
     c->dcap[idx] = cap;
   }
   *out = c->dbuf[idx];
+  c->ws_used = true;
   return ROME_OK;
 }
 
@@ -370,11 +372,13 @@ void rome_ctx_destroy(rome_ctx* c) {
 
 int rome_ctx_set_stream(rome_ctx* c, void* hip_stream) {
   if (!c) return ROME_ERR_INVALID_ARG;
-  if (c->stream != (hipStream_t)hip_stream) {
+  if (c->stream != (hipStream_t)hip_stream && c->ws_used) {
     // the context's workspaces (staging arenas, the Gibbs tree workspace) are shared by everything launched through it: work queued
-    // on the previous stream must be done with them before launches on another stream may touch them
+    // on the previous stream must be done with them before launches on another stream may touch them.  (Entries that use none --
+    // the rome_conv_*_dev sweeps a pipeline alternates between streams -- switch without a drain.)
     ROME_BIND(c);
     ROME_HIP(c, hipStreamSynchronize(c->stream));
+    c->ws_used = false;
   }
   c->stream = (hipStream_t)hip_stream;  // NULL is HIP's default (null) stream, e.g. torch's default stream
   return ROME_OK;
@@ -386,6 +390,7 @@ int rome_ctx_use_own_stream(rome_ctx* c) {
 int rome_ctx_synchronize(rome_ctx* c) {
   if (!c) return ROME_ERR_INVALID_ARG;
   ROME_HIP(c, hipStreamSynchronize(c->stream));
+  c->ws_used = false;
   return ROME_OK;
 }
 

@@ -268,3 +268,25 @@ def test_plan_argument_checks():
         plan.run(R.make_opts(N=64, seed=1), mirror_out=1)
     with pytest.raises(R.RomeError):
         ScatterPlan(store, ["x1"], [0], stride=10)       # stride shorter than a Pose2 block
+
+
+def test_store_wrapped_over_caller_memory_equals_the_owned_store():
+    """rome_store_wrap: the store over caller-owned device memory (the belief tensors of a DeviceGraph) -- a plan run updates those
+    tensors in place, with the same bits as a store of the library's own"""
+    N = 100
+    fg = _beehive(20, N)
+    dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
+    wrapped = DeviceStore(fg, ctx=dg.ctx, wrap=dg.bel)
+    owned = DeviceStore(fg)
+    poses = [l for l, t in fg.variables.items() if t is R.Pose2]
+    frontier = _independent_frontier(fg, poses)
+    o = R.make_opts(N=N, seed=3)
+    UpsolvePlan(owned, frontier, gibbsIters=2).run(o)
+    dg._bind_stream()
+    UpsolvePlan(wrapped, frontier, gibbsIters=2).run(o)
+    dg.ctx.synchronize()
+    bel = dg.bel[R.Pose2].cpu().numpy()
+    for c in frontier:
+        k = dg.packed.labels[R.Pose2].index(c[0])
+        assert np.array_equal(bel[k], owned.get(c[0])) and not np.array_equal(bel[k], fg.getVal(c[0]))
+    assert np.array_equal(wrapped.get(poses[0]), bel[0])
