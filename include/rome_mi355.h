@@ -53,17 +53,17 @@ enum {
 };
 
 #define ROME_MAX_PARTICLES 4096   /* convolutions / prior sampling: N <= 512 lives in registers, larger N is walked in chunks of 128;
-                                    the KDE and importance-product entries take N <= 512, the Gibbs product N <= 128 */
+                                    the KDE and importance-product entries take N <= 512, the Gibbs product N <= 256 */
 #define ROME_MAX_PARTICLES_REGISTER 512
 /* per-stage particle limits of ONE solve iteration (every entry fails with ROME_ERR_UNSUPPORTED_N / ROME_ERR_INVALID_ARG above its
  * limit, nothing is truncated; rome_jl_amd.solveGraph / DeviceGraph.solve check them before the first launch):
  *   convolutions / prior sampling  ROME_MAX_PARTICLES (4096)      manikde! bandwidths, getKDEMax   ROME_MAX_PARTICLES_KDE (512)
  *   importance product             ROME_MAX_PARTICLES_PRODUCT (512; Pose3: 256)
- *   multiscale Gibbs product, rome_clique_upsolve                 ROME_MAX_PARTICLES_GIBBS (128) */
+ *   multiscale Gibbs product, rome_clique_upsolve, up-solve plans ROME_MAX_PARTICLES_GIBBS (256) */
 #define ROME_MAX_PARTICLES_KDE 512
 #define ROME_MAX_PARTICLES_PRODUCT 512
 #define ROME_MAX_PARTICLES_PRODUCT_POSE3 256
-#define ROME_MAX_PARTICLES_GIBBS 128
+#define ROME_MAX_PARTICLES_GIBBS 256   /* two kernel instantiations: N <= 128 (128-thread blocks, what the solve-loop numbers are quoted on) and N <= 256 */
 
 /* Solvers for the per-particle root-find (replaces Optim.optimize(cost, X0c, NelderMead()) in IIF
  * `_solveLambdaNumeric`, called for every particle of every convolution):
@@ -284,7 +284,7 @@ int rome_clique_proposals(rome_ctx*, const rome_opts*, const rome_clique_host*);
  *   bw_<type>   [same][dim] their manikde! bandwidths (what setValKDE! stores)
  * Philox streams: convolution row r of a family in iteration i draws stream_offset + (i << 32) + family offset + r (the streams of
  * the device graph's sweep i); the product of the k-th updated variable of a type draws + (3, 4, 6 << 28 for Pose2, Point2, Pose3) + k.
- * N <= 128 (the multiscale Gibbs product). */
+ * N <= 256 (the multiscale Gibbs product). */
 enum { ROME_UPSOLVE_SEQUENTIAL = 0, ROME_UPSOLVE_JACOBI = 1 };
 typedef struct rome_clique_upsolve_host {
   rome_clique_host clique;
@@ -486,7 +486,7 @@ int rome_product_bw_dev(rome_ctx*, const rome_opts*, int32_t dim, int32_t V, con
  *   context-owned workspace of 6.8 kB per row for Pose2).  dim 2 (Point2), 3 (Pose2) or 6 (Pose3: coordinates [t; rotation vector];
  *   the rotation coordinates of a proposal live in the chart at the rotation of its point 0 -- Log(R_0ᵀ R_i) -- where the tree and
  *   every candidate evaluation are Euclidean; only the product Gaussians of selected nodes change charts, by Exp / Log; pass
- *   circular_mask = 0), N <= 128.  Variables without proposals keep bel_in, with one proposal take it unchanged (as AMP does). */
+ *   circular_mask = 0), N <= 256.  Variables without proposals keep bel_in, with one proposal take it unchanged (as AMP does). */
 int rome_product_gibbs_dev(rome_ctx*, const rome_opts*, int32_t dim, int32_t V, const int32_t* prop_ptr, const int32_t* prop_rows,
                            const double* prop, const double* prop_bw, int32_t n_prop_rows, const double* bel_in, double* bel_out,
                            uint32_t circular_mask, int32_t gibbs_iters, int32_t max_proposals);

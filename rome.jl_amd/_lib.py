@@ -16,7 +16,7 @@ NOISE_STANDARD_NORMALS, NOISE_MEASUREMENTS = 0, 1
 LAYOUT_SOA, LAYOUT_AOS, LAYOUT_AOS_POINTS = 0, 1, 2
 MAX_PARTICLES = 4096            # ROME_MAX_PARTICLES (the register-resident kernels: MAX_PARTICLES_REGISTER)
 MAX_PARTICLES_REGISTER = 512
-MAX_PARTICLES_KDE, MAX_PARTICLES_PRODUCT, MAX_PARTICLES_PRODUCT_POSE3, MAX_PARTICLES_GIBBS = 512, 512, 256, 128   # per-stage limits (header)
+MAX_PARTICLES_KDE, MAX_PARTICLES_PRODUCT, MAX_PARTICLES_PRODUCT_POSE3, MAX_PARTICLES_GIBBS = 512, 512, 256, 256   # per-stage limits (header)
 FACTOR_PRIORPOSE2, FACTOR_POSE2POSE2, FACTOR_POSE2POINT2BR, FACTOR_PRIORPOINT2, FACTOR_POSE3POSE3, FACTOR_PRIORPOSE3 = range(6)
 
 

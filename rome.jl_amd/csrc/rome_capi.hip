@@ -957,7 +957,7 @@ int plan_build(rome_ctx* c, rome_store* st, const rome_opts* o, const rome_cliqu
       ROME_HIP(c, rome::launch_kde_bandwidth(kVdim[t], n_msg[t], N, (const double*)mb, kCircBw[t], 1e-2, 1e-6,
                                              P->d_pbw[t] + (size_t)msg_base[t] * kVdim[t], nullptr, s));
     }
-    const size_t b = rome::gibbs_workspace_bytes(kVdim[t], P->prop_rows_t[t], (int)nu);
+    const size_t b = rome::gibbs_workspace_bytes(kVdim[t], P->prop_rows_t[t], (int)nu, N);
     if (b > P->tree_need) P->tree_need = b;
   }
   for (int k4 = 0; k4 < NF; ++k4) if ((rc = upload_fam(c, P->fam[k4], arena, &used, Ls[k4], P->fd[k4]))) return rc;
@@ -1367,10 +1367,10 @@ int rome_product_gibbs_dev(rome_ctx* c, const rome_opts* o, int32_t dim, int32_t
   if (!c || V < 0 || n_prop_rows < 0 || (dim != 2 && dim != 3 && dim != 6) || max_proposals < 1) return ROME_ERR_INVALID_ARG;
   if (V > 0 && (!prop_ptr || !prop_rows || !bel_in || !bel_out)) return ROME_ERR_INVALID_ARG;
   if (n_prop_rows > 0 && (!prop || !prop_bw)) return ROME_ERR_INVALID_ARG;
-  if (o->n_particles > 128) return ROME_ERR_UNSUPPORTED_N;   /* lane = output sample, two wavefronts per variable */
+  if (o->n_particles > ROME_MAX_PARTICLES_GIBBS) return ROME_ERR_UNSUPPORTED_N;   /* lane = output sample: 128- or 256-thread blocks */
   ROME_BIND(c);
   void* trees = nullptr;   /* one ball tree per proposal row, context-owned workspace (grown on demand, kept) */
-  rc = ensure(c, 10, rome::gibbs_workspace_bytes(dim, n_prop_rows, V), &trees); if (rc) return rc;
+  rc = ensure(c, 10, rome::gibbs_workspace_bytes(dim, n_prop_rows, V, o->n_particles), &trees); if (rc) return rc;
   ROME_HIP(c, rome::launch_product_gibbs(dim, V, o->n_particles, n_prop_rows, prop_ptr, prop_rows, prop, prop_bw, bel_in, bel_out, trees,
                                          circular_mask, gibbs_iters, max_proposals, o->seed, o->stream_offset, c->stream));
   return ROME_OK;

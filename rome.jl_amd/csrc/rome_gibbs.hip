@@ -26,9 +26,9 @@
 
 namespace rome {
 
-constexpr int kGibbsThreads = 128;
-constexpr int kGibbsMaxN = 128;
-constexpr int kGibbsNodes = 127;   // internal nodes of levels 0 .. 6
+// Every kernel below is instantiated for NM = 128 (N <= 128: lane = output sample of a 128-thread block, two particles per lane of the
+// tree-building wavefront -- the sizes everything was tuned at) and NM = 256 (128 < N <= 256: twice the threads / slots / LDS images).
+constexpr int kGibbsMaxN = 256;
 
 struct GibbsArgs {
   int V, N, L, max_k, k_lds, iters;   // k_lds: level images resident in LDS per block (variables with more proposals stream them)
@@ -42,15 +42,15 @@ struct GibbsArgs {
   GibbsPlace place;       // optional indirections (all nullptr: variable v lives in block v, draws stream v, no mirror)
 };
 
-template <int D>
+template <int D, int NM>
 struct alignas(8) GibbsTree {
   double ref[D], h[D];
   double q0[4];   // D = 6 (Pose3): unit quaternion of point 0 -- coordinates 3..5 are Log(q0* ⊗ q_i), the chart at that rotation
-  float mean[D][128], var[D][128], ivar[D][128], cz[128];   // node (l, z) at index 2^l - 1 + z: a level is contiguous per coordinate
-  float ys[D][kGibbsMaxN];                                  // level L: the single points in sorted order
+  float mean[D][NM], var[D][NM], ivar[D][NM], cz[NM];   // node (l, z) at index 2^l - 1 + z: a level is contiguous per coordinate
+  float ys[D][NM];                                      // level L: the single points in sorted order
   float lvar[D], livar[D], lcz;
   int row;
-  uint8_t perm[kGibbsMaxN];
+  uint8_t perm[NM];
 };
 
 __device__ __forceinline__ double gwrap(double d) { return d - 6.283185307179586476925287 * rint(d * 0.15915494309189533576888); }
@@ -66,16 +66,19 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// one wavefront builds tree `T` of proposal `P` ([D][N] doubles, bandwidths h); scr: 2 x 128 x D ints of per-wave scratch
-template <int D>
-__device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restrict__ P, const double* __restrict__ hb, int row,
-                            int N, int L, uint32_t circ, int lane, float* __restrict__ ybuf /*[128][D]*/, int* __restrict__ ext /*[128][2D]*/,
-                            uint64_t* __restrict__ kb /*[128]*/) {
-  // ---- offsets from point 0, single precision; positions p = lane, lane + 64
-  float y[2][D];
-  int id[2];
+// one wavefront builds tree `T` of proposal `P` ([D][N] doubles, bandwidths h); per-wave LDS scratch ybuf / ext / kb.
+// S = NM / 64 positions per lane (2 for N <= 128, 4 up to 256); the NM = 128 instantiation is the code of rounds 2-3, statement by
+// statement.
+template <int D, int NM>
+__device__ void gibbs_build(GibbsTree<D, NM>* __restrict__ T, const double* __restrict__ P, const double* __restrict__ hb, int row,
+                            int N, int L, uint32_t circ, int lane, float* __restrict__ ybuf /*[NM][D]*/, int* __restrict__ ext /*[NM/2][2D]*/,
+                            uint64_t* __restrict__ kb /*[NM]*/) {
+  constexpr int S = NM / 64;
+  // ---- offsets from point 0, single precision; positions p = lane, lane + 64, ...
+  float y[S][D];
+  int id[S];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < S; ++s) {
     const int i = lane + 64 * s;
     id[s] = i;
     const int ii = i < N ? i : 0;
@@ -104,9 +107,9 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
     const int nn = 1 << l;
     for (int q = lane; q < nn * 2 * D; q += 64) ext[q] = (q & 1) ? (int)0x80000000 : 0x7FFFFFFF;   // (min, max) per node and coordinate
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    int z[2];
+    int z[S];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < S; ++s) {
       const int p = lane + 64 * s;
       z[s] = p < N ? (int)((((long long)(p + 1) << l) - 1) / N) : nn;   // node of position p (padding positions sort last)
       if (p < N) {
@@ -118,9 +121,9 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    uint64_t key[2];
+    uint64_t key[S];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < S; ++s) {
       const int p = lane + 64 * s;
       if (p < N) {
         int best = 0; float be = -1.0f;
@@ -143,36 +146,40 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
     // instead of the 28 exchange stages of a full 128-key bitonic sort at every level (which this replaced: 223 -> 207 µs per
     // Manhattan sweep of proposals); the same order (keys are unique by id).
     {
-      int na[2], nbnd[2];
+      int na[S], nbnd[S];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < S; ++s) {
         const int p = lane + 64 * s;
         na[s] = 0; nbnd[s] = 0;
         if (p < N) { node_range(N, l, z[s], &na[s], &nbnd[s]); kb[p] = key[s] & 0xFFFFFFFFFFull; }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
       const int span = (N + nn - 1) / nn;          // the largest node of this level
-      int rank[2] = {0, 0};
-      const uint64_t mine0 = key[0] & 0xFFFFFFFFFFull, mine1 = key[1] & 0xFFFFFFFFFFull;
+      int rank[S];
+      uint64_t mine[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) { rank[s] = 0; mine[s] = key[s] & 0xFFFFFFFFFFull; }
       for (int t = 0; t < span; ++t) {
-        const int j0 = na[0] + t, j1 = na[1] + t;
-        const uint64_t o0 = kb[j0 < nbnd[0] ? j0 : na[0]], o1 = kb[j1 < nbnd[1] ? j1 : na[1]];
-        rank[0] += (j0 < nbnd[0] && o0 < mine0) ? 1 : 0;
-        rank[1] += (j1 < nbnd[1] && o1 < mine1) ? 1 : 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const int j = na[s] + t;
+          const uint64_t o = kb[j < nbnd[s] ? j : na[s]];
+          rank[s] += (j < nbnd[s] && o < mine[s]) ? 1 : 0;
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // every key has been read
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < S; ++s) {
         const int p = lane + 64 * s;
         if (p < N) kb[na[s] + rank[s]] = key[s];
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int s = 0; s < 2; ++s) { const int p = lane + 64 * s; key[s] = p < N ? kb[p] : ~0ull; }
+      for (int s = 0; s < S; ++s) { const int p = lane + 64 * s; key[s] = p < N ? kb[p] : ~0ull; }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // kb is rewritten at the next level
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < S; ++s) {
       const int p = lane + 64 * s;
       id[s] = p < N ? (int)(key[s] & 0xFFu) : 0;
 #pragma unroll
@@ -180,7 +187,7 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
     }
   }
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < S; ++s) {
     const int p = lane + 64 * s;
     if (p < N) {
       T->perm[p] = (uint8_t)id[s];
@@ -193,10 +200,10 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
   double h2[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) { const double h = fmax(hb[d], 1e-6); h2[d] = h * h; }
-  int n[2];
-  double m[2][D], M2[2][D];
+  int n[S];
+  double m[S][D], M2[S][D];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < S; ++s) {
     const int zz = lane + 64 * s;
     int a = 0, b = 0;
     if (zz < (1 << L)) node_range(N, L, zz, &a, &b);
@@ -206,55 +213,72 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
   }
   // (fast_rcp: v_rcp_f64 + two Newton steps; a level needs a dozen reciprocals.  The oracle's msg_build divides: the statistics agree to
   //  an ulp of double before they are rounded to single precision.)
-  // node zz = lane of level l (at most 64 nodes: slot 0) <- children 2 zz, 2 zz + 1 of level l + 1; child c lives in slot c >> 6,
-  // lane c & 63 (both children in the same slot; only the deepest step has children in slot 1).  Same recurrences as msg_build.
+  // parent node zz = lane + 64 ps of level l <- children 2 zz, 2 zz + 1 of level l + 1: child c lives in slot c >> 6, lane c & 63, i.e.
+  // for parent slot ps in child slot 2 ps (lanes < 32) or 2 ps + 1 (kTwo: the child level has more than 64 nodes per pair of slots).
+  // Same recurrences as msg_build.  NM = 128: one parent slot, the statements of the two-slot form it replaces.
+  constexpr int PS = S / 2;
   auto merge_level = [&](int l, auto two_slots) {
 #pragma clang fp contract(off)
     constexpr bool kTwo = decltype(two_slots)::value;
-    const int zz = lane;
-    const int c0 = (2 * zz) & 127, sl = kTwo ? (c0 >> 6) : 0, la = c0 & 63, lb = (la + 1) & 63;
-    int nl = __shfl(n[0], la, 64), nr = __shfl(n[0], lb, 64);
-    if constexpr (kTwo) { const int nl1 = __shfl(n[1], la, 64), nr1 = __shfl(n[1], lb, 64); nl = sl ? nl1 : nl; nr = sl ? nr1 : nr; }
-    const bool livep = zz < (1 << l);
-    const double nt = (double)(nl + nr);
-    const double inv_nt = nl + nr > 0 ? fast_rcp(nt) : 0.0;
-    double pm[D], pM[D];
+    int pn[PS]; double pm[PS][D], pM[PS][D], pinv[PS]; bool plive[PS];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      double ml = shfl_f64(m[0][d], la), mr = shfl_f64(m[0][d], lb), Ml = shfl_f64(M2[0][d], la), Mr = shfl_f64(M2[0][d], lb);
-      if constexpr (kTwo) {
-        const double ml1 = shfl_f64(m[1][d], la), mr1 = shfl_f64(m[1][d], lb), Ml1 = shfl_f64(M2[1][d], la), Mr1 = shfl_f64(M2[1][d], lb);
-        ml = sl ? ml1 : ml; mr = sl ? mr1 : mr; Ml = sl ? Ml1 : Ml; Mr = sl ? Mr1 : Mr;
-      }
-      double mm = 0.0, MM = 0.0;
-      if (nl + nr > 0) {
-        if (nr == 0) { mm = ml; MM = Ml; }
-        else if (nl == 0) { mm = mr; MM = Mr; }
-        else {
-          const double dl = ml - mr;
-          mm = ((double)nl * ml + (double)nr * mr) * inv_nt;
-          MM = Ml + Mr + (double)nl * (double)nr * inv_nt * dl * dl;
-        }
-      }
-      pm[d] = mm; pM[d] = MM;
-    }
-    n[0] = livep ? nl + nr : 0; n[1] = 0;
-#pragma unroll
-    for (int d = 0; d < D; ++d) { m[0][d] = pm[d]; M2[0][d] = pM[d]; }
-    if (livep && n[0] > 0) {
-      const int idn = (1 << l) - 1 + zz;
-      double lg = 0.0;
+    for (int ps = 0; ps < PS; ++ps) {
+      const int zz = lane + 64 * ps;
+      const int c0 = (2 * lane) & 127, sl = kTwo ? (c0 >> 6) : 0, la = c0 & 63, lb = (la + 1) & 63;
+      constexpr int kLast = S - 1;
+      const int ce = 2 * ps, co = 2 * ps + 1 <= kLast ? 2 * ps + 1 : kLast;
+      int nl = __shfl(n[ce], la, 64), nr = __shfl(n[ce], lb, 64);
+      if constexpr (kTwo) { const int nl1 = __shfl(n[co], la, 64), nr1 = __shfl(n[co], lb, 64); nl = sl ? nl1 : nl; nr = sl ? nr1 : nr; }
+      plive[ps] = zz < (1 << l);
+      const double nt = (double)(nl + nr);
+      pinv[ps] = nl + nr > 0 ? fast_rcp(nt) : 0.0;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        const double v = M2[0][d] * inv_nt + h2[d];
-        T->mean[d][idn] = (float)m[0][d]; T->var[d][idn] = (float)v; T->ivar[d][idn] = (float)fast_rcp(v);
-        lg += fast_log(v);   // (fdlibm kernel, < 1 ulp: the library call is twice the instructions)
+        double ml = shfl_f64(m[ce][d], la), mr = shfl_f64(m[ce][d], lb), Ml = shfl_f64(M2[ce][d], la), Mr = shfl_f64(M2[ce][d], lb);
+        if constexpr (kTwo) {
+          const double ml1 = shfl_f64(m[co][d], la), mr1 = shfl_f64(m[co][d], lb), Ml1 = shfl_f64(M2[co][d], la), Mr1 = shfl_f64(M2[co][d], lb);
+          ml = sl ? ml1 : ml; mr = sl ? mr1 : mr; Ml = sl ? Ml1 : Ml; Mr = sl ? Mr1 : Mr;
+        }
+        double mm = 0.0, MM = 0.0;
+        if (nl + nr > 0) {
+          if (nr == 0) { mm = ml; MM = Ml; }
+          else if (nl == 0) { mm = mr; MM = Mr; }
+          else {
+            const double dl = ml - mr;
+            mm = ((double)nl * ml + (double)nr * mr) * pinv[ps];
+            MM = Ml + Mr + (double)nl * (double)nr * pinv[ps] * dl * dl;
+          }
+        }
+        pm[ps][d] = mm; pM[ps][d] = MM;
       }
-      T->cz[idn] = (float)(fast_log(nt * (1.0 / (double)N)) - 0.5 * lg);
+      pn[ps] = plive[ps] ? nl + nr : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) n[s] = 0;
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) {
+      n[ps] = pn[ps];
+#pragma unroll
+      for (int d = 0; d < D; ++d) { m[ps][d] = pm[ps][d]; M2[ps][d] = pM[ps][d]; }
+      if (plive[ps] && n[ps] > 0) {
+        const int idn = (1 << l) - 1 + lane + 64 * ps;
+        const double nt = (double)n[ps];
+        double lg = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const double v = M2[ps][d] * pinv[ps] + h2[d];
+          T->mean[d][idn] = (float)m[ps][d]; T->var[d][idn] = (float)v; T->ivar[d][idn] = (float)fast_rcp(v);
+          lg += fast_log(v);   // (fdlibm kernel, < 1 ulp: the library call is twice the instructions)
+        }
+        T->cz[idn] = (float)(fast_log(nt * (1.0 / (double)N)) - 0.5 * lg);
+      }
     }
   };
   if (L >= 1) merge_level(L - 1, std::true_type{});
-  for (int l = L - 2; l >= 0; --l) merge_level(l, std::false_type{});
+  for (int l = L - 2; l >= 0; --l) {
+    if ((2 << l) > 64) merge_level(l, std::true_type{});    // (only NM = 256: a child level of 128 nodes sits in two slots)
+    else merge_level(l, std::false_type{});
+  }
   if (lane == 0) {
     double lg = 0.0;
 #pragma unroll
@@ -263,16 +287,16 @@ __device__ void gibbs_build(GibbsTree<D>* __restrict__ T, const double* __restri
   }
 }
 
-template <int D>
+template <int D, int NM>
 __global__ void __launch_bounds__(256) k_gibbs_trees(const GibbsArgs a) {
-  __shared__ float ybuf[4][kGibbsMaxN * D];
-  __shared__ int ext[4][64 * 2 * D];
-  __shared__ uint64_t kb[4][kGibbsMaxN];
+  __shared__ float ybuf[4][NM * D];
+  __shared__ int ext[4][(NM / 2) * 2 * D];
+  __shared__ uint64_t kb[4][NM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
   if (row >= a.n_rows) return;   // wave-uniform; waves never synchronise with each other
-  GibbsTree<D>* T = reinterpret_cast<GibbsTree<D>*>(a.trees) + row;
-  gibbs_build<D>(T, a.prop + (size_t)row * D * a.N, a.prop_bw + (size_t)row * D, row, a.N, a.L, a.circ, lane, ybuf[wave], ext[wave], kb[wave]);
+  GibbsTree<D, NM>* T = reinterpret_cast<GibbsTree<D, NM>*>(a.trees) + row;
+  gibbs_build<D, NM>(T, a.prop + (size_t)row * D * a.N, a.prop_bw + (size_t)row * D, row, a.N, a.L, a.circ, lane, ybuf[wave], ext[wave], kb[wave]);
 }
 
 // ---- candidate arithmetic: IEEE single precision, every operation spelled out (explicit fma, contraction off), so that the
@@ -386,11 +410,11 @@ __device__ __forceinline__ void ratio_group(const f32x2* s, const f32x2* v, f32x
 }
 
 // LDS image of ONE level of one tree: what the candidate loops of that level read (wave-uniform -> LDS broadcasts, two nodes a read)
-template <int D>
+template <int D, int NM>
 struct GibbsLevel {
   union {
-    struct { float mean[D][64], var[D][64], ivar[D][64], cz[64], lnc[64]; } in;   // levels 1 .. L-1 (at most 64 nodes); lnc = log(count / N)
-    float ys[D][kGibbsMaxN];                                                     // level L: the sorted single points
+    struct { float mean[D][NM / 2], var[D][NM / 2], ivar[D][NM / 2], cz[NM / 2], lnc[NM / 2]; } in;   // levels 1 .. L-1 (at most NM / 2 nodes); lnc = log(count / N)
+    float ys[D][NM];                                                                                 // level L: the sorted single points
   };
 };
 template <int D>
@@ -398,9 +422,10 @@ struct GibbsConst { double ref[D], h[D], q0[4]; float lvar[D], livar[D]; int row
 
 // CM: the circular mask at compile time (-1: read from the arguments) -- with a run-time mask the compiler evaluates the wrap of
 // EVERY coordinate and selects (24 of the 54 instructions of a Pose2 candidate pair)
-template <int D, int CM>
-__global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs a) {
+template <int D, int CM, int NM>
+__global__ void __launch_bounds__(NM) k_product_gibbs(const GibbsArgs a) {
 #pragma clang fp contract(off)   // the candidate arithmetic below is a bit-exact specification
+  constexpr int kGibbsThreads = NM;   // lane = output sample
   extern __shared__ __align__(16) unsigned char smem[];
   if ((int)blockIdx.x >= a.V) return;
   const int v = a.order[blockIdx.x];
@@ -426,21 +451,21 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
     for (int q = tid; q < D * N; q += kGibbsThreads) { const double x = src[q]; if (src != ob) ob[q] = x; if (mo) mo[q] = x; }
     return;
   }
-  __shared__ float logn[kGibbsMaxN + 1];   // log(c / N): the weight of a node with c points
-  for (int c = tid; c <= kGibbsMaxN; c += kGibbsThreads) logn[c] = c > 0 ? (float)log((double)c / (double)N) : 0.0f;
+  __shared__ float logn[NM + 1];   // log(c / N): the weight of a node with c points
+  for (int c = tid; c <= NM; c += kGibbsThreads) logn[c] = c > 0 ? (float)log((double)c / (double)N) : 0.0f;
   // dynamic LDS: [k_lds] level images | [max_k] constants | [max_k][128] labels.  A variable with at most k_lds proposals keeps the
   // current level of all its trees resident; one with more STREAMS them: the image of the tree being scanned is staged into slot 0
   // before every categorical draw, and the statistics of selected nodes come from the trees in HBM / L2 (a handful of gathers per
   // draw).  Sizing every block for the hub variable of a pose graph (11 proposals: 28 kB) left 2.5 waves per SIMD; 12 kB give six
   // and the same work runs 24 % faster (profiles/r02_gibbs_occupancy.txt).
-  GibbsLevel<D>* lev = reinterpret_cast<GibbsLevel<D>*>(smem);
-  GibbsConst<D>* cst = reinterpret_cast<GibbsConst<D>*>(smem + sizeof(GibbsLevel<D>) * a.k_lds);
-  uint8_t* selbuf = smem + sizeof(GibbsLevel<D>) * a.k_lds + sizeof(GibbsConst<D>) * a.max_k;
+  GibbsLevel<D, NM>* lev = reinterpret_cast<GibbsLevel<D, NM>*>(smem);
+  GibbsConst<D>* cst = reinterpret_cast<GibbsConst<D>*>(smem + sizeof(GibbsLevel<D, NM>) * a.k_lds);
+  uint8_t* selbuf = smem + sizeof(GibbsLevel<D, NM>) * a.k_lds + sizeof(GibbsConst<D>) * a.max_k;
   const bool resident = K <= a.k_lds;
-  const GibbsTree<D>* __restrict__ W = reinterpret_cast<const GibbsTree<D>*>(a.trees);
+  const GibbsTree<D, NM>* __restrict__ W = reinterpret_cast<const GibbsTree<D, NM>*>(a.trees);
   for (int j = tid; j < K; j += kGibbsThreads) {
     const int row = a.prop_rows[k0 + j];
-    const GibbsTree<D>& T = W[row];
+    const GibbsTree<D, NM>& T = W[row];
     GibbsConst<D>& c = cst[j];
 #pragma unroll
     for (int d = 0; d < D; ++d) { c.ref[d] = T.ref[d]; c.h[d] = T.h[d]; c.lvar[d] = T.lvar[d]; c.livar[d] = T.livar[d]; }
@@ -450,8 +475,8 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
   __syncthreads();
   // cooperative copy of level l of tree j into image slot `slot` (coalesced: the level's nodes are contiguous in each array of the tree)
   auto copy_level = [&](int l, int j, int slot) {
-    const GibbsTree<D>& T = W[cst[j].row];
-    GibbsLevel<D>& G = lev[slot];
+    const GibbsTree<D, NM>& T = W[cst[j].row];
+    GibbsLevel<D, NM>& G = lev[slot];
     if (l < L) {
       const int n = 1 << l, o = n - 1;
       for (int q = tid; q < n * D; q += kGibbsThreads) {
@@ -463,7 +488,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
         G.in.cz[q] = T.cz[o + q]; G.in.lnc[q] = logn[rb - ra];
       }
     } else {
-      for (int q = tid; q < kGibbsMaxN * D; q += kGibbsThreads) (&G.ys[0][0])[q] = (&T.ys[0][0])[q];
+      for (int q = tid; q < NM * D; q += kGibbsThreads) (&G.ys[0][0])[q] = (&T.ys[0][0])[q];
     }
   };
   auto stage = [&](int l) {   // resident variables: level l of every tree
@@ -472,7 +497,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
     for (int j = 0; j < K; ++j) copy_level(l, j, j);
     __syncthreads();
   };
-  auto image = [&](int l, int j) -> const GibbsLevel<D>& {   // the image the candidate loops of (level l, tree j) read
+  auto image = [&](int l, int j) -> const GibbsLevel<D, NM>& {   // the image the candidate loops of (level l, tree j) read
     if (resident) return lev[j];
     __syncthreads();
     copy_level(l, j, 0);
@@ -482,7 +507,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
   // statistics of node sz of level l of tree i (a selected node: lane-divergent index): LDS image, or the tree itself when streaming
   auto node_mean = [&](int l, int i, int d, int sz) -> float {
     if (resident) return l < L ? lev[i].in.mean[d][sz] : lev[i].ys[d][sz];
-    const GibbsTree<D>& T = W[cst[i].row];
+    const GibbsTree<D, NM>& T = W[cst[i].row];
     return l < L ? T.mean[d][(1 << l) - 1 + sz] : T.ys[d][sz];
   };
   auto node_ivar = [&](int l, int i, int d, int sz) -> float {
@@ -507,7 +532,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
     const double r = (qn & 1u) ? npair1 : npair0; ++qn;
     return r;
   };
-  for (int j = 0; j < K; ++j) selbuf[j * 128 + tid] = 0;
+  for (int j = 0; j < K; ++j) selbuf[j * NM + tid] = 0;
   stage(0);
   double x[D];
   [[maybe_unused]] double xq[4] = {1.0, 0.0, 0.0, 0.0};   // D = 6: rotation of the current point
@@ -521,7 +546,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
       double prec = 0.0, num = 0.0, mu0 = 0.0;
       for (int j = 0; j < K; ++j) {
         const GibbsConst<D>& c = cst[j];
-        const int sz = selbuf[j * 128 + tid];
+        const int sz = selbuf[j * NM + tid];
         double mabs, iv;
         if (l - 1 == L) {   // the selected kernel itself: the particle at full precision, its bandwidth in double
           mabs = a.prop[(size_t)c.row * D * N + (size_t)d * N + W[c.row].perm[sz]];
@@ -539,7 +564,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
       double B[4] = {1.0, 0.0, 0.0, 0.0}, prec[3] = {0.0, 0.0, 0.0}, num[3] = {0.0, 0.0, 0.0};
       for (int j = 0; j < K; ++j) {
         const GibbsConst<D>& c = cst[j];
-        const int sz = selbuf[j * 128 + tid];
+        const int sz = selbuf[j * NM + tid];
         double Q[4], iv[3];
         if (l - 1 == L) {
           const int pi = W[c.row].perm[sz];
@@ -571,7 +596,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
     // (c) labels of level l given the point, which is expressed ONCE in the density's own chart (Euclidean there) and rounded
     for (int j = 0; j < K; ++j) {
       const GibbsConst<D>& c = cst[j];
-      const GibbsLevel<D>& G = image(l, j);
+      const GibbsLevel<D, NM>& G = image(l, j);
       Reservoir R; R.init(uniform_word());
       float e0[D];
       {
@@ -607,7 +632,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
           R.add2(p, p + 1, lp);
         }
       }
-      selbuf[j * 128 + tid] = (uint8_t)R.sel;
+      selbuf[j * NM + tid] = (uint8_t)R.sel;
     }
     // (d) Gibbs sweeps over the labels
     for (int it = 0; it < a.iters; ++it)
@@ -619,7 +644,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
           double prec = 0.0, num = 0.0, mu0 = 0.0; bool first = true;
           for (int i = 0; i < K; ++i) {
             if (i == j) continue;
-            const int sz = selbuf[i * 128 + tid];
+            const int sz = selbuf[i * NM + tid];
             double mean, iv;
             mean = (double)node_mean(l, i, d, sz); iv = (double)node_ivar(l, i, d, sz);
             const double mabs = cst[i].ref[d] + mean;
@@ -636,7 +661,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
           double B[4] = {1.0, 0.0, 0.0, 0.0}, prec[3] = {0.0, 0.0, 0.0}, num[3] = {0.0, 0.0, 0.0}; bool first = true;
           for (int i = 0; i < K; ++i) {
             if (i == j) continue;
-            const int sz = selbuf[i * 128 + tid];
+            const int sz = selbuf[i * NM + tid];
             double m[3], iv[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) { m[k] = (double)node_mean(l, i, 3 + k, sz); iv[k] = (double)node_ivar(l, i, 3 + k, sz); }
@@ -655,7 +680,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
         float mx[D], cx[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) { mx[d] = (float)Mx[d]; cx[d] = (float)Cx[d]; }
-        const GibbsLevel<D>& G = image(l, j);
+        const GibbsLevel<D, NM>& G = image(l, j);
         Reservoir R; R.init(uniform_word());
         if (l < L) {
           for (int z = 0; z < nz; z += 2) {
@@ -691,7 +716,7 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
             R.add2(p, p + 1, lp);
           }
         }
-        selbuf[j * 128 + tid] = (uint8_t)R.sel;
+        selbuf[j * NM + tid] = (uint8_t)R.sel;
       }
   }
   if constexpr (D == 6) quat_log(xq, x + 3);
@@ -705,11 +730,13 @@ __global__ void __launch_bounds__(kGibbsThreads) k_product_gibbs(const GibbsArgs
   }
 }
 
-static size_t tree_bytes(int dim, int n_rows) {
-  return (dim == 2 ? sizeof(GibbsTree<2>) : (dim == 3 ? sizeof(GibbsTree<3>) : sizeof(GibbsTree<6>))) * (size_t)(n_rows > 0 ? n_rows : 1);
+static size_t tree_bytes(int dim, int n_rows, int N) {
+  const size_t one = N <= 128 ? (dim == 2 ? sizeof(GibbsTree<2, 128>) : (dim == 3 ? sizeof(GibbsTree<3, 128>) : sizeof(GibbsTree<6, 128>)))
+                              : (dim == 2 ? sizeof(GibbsTree<2, 256>) : (dim == 3 ? sizeof(GibbsTree<3, 256>) : sizeof(GibbsTree<6, 256>)));
+  return one * (size_t)(n_rows > 0 ? n_rows : 1);
 }
 // workspace: one tree per proposal row | the variables ordered by their number of proposals
-size_t gibbs_workspace_bytes(int dim, int n_rows, int V) { return tree_bytes(dim, n_rows) + sizeof(int32_t) * (size_t)(V > 0 ? V : 1); }
+size_t gibbs_workspace_bytes(int dim, int n_rows, int V, int N) { return tree_bytes(dim, n_rows, N) + sizeof(int32_t) * (size_t)(V > 0 ? V : 1); }
 
 // Variables in descending order of their number of proposals (counting sort, one block): the blocks of the sampling kernel are
 // dispatched in this order, i.e. longest first (a block's run time is proportional to its variable's proposal count, 2 .. 11 on
@@ -727,6 +754,37 @@ __global__ void __launch_bounds__(1024) k_gibbs_order(int V, const int32_t* __re
   for (int v = threadIdx.x; v < V; v += 1024) { const int K = prop_ptr[v + 1] - prop_ptr[v]; order[atomicAdd(&start[K < 64 ? K : 64], 1)] = v; }
 }
 
+template <int NM>
+static hipError_t launch_product_gibbs_nm(GibbsArgs& a, int dim, int V, int N, int n_rows, uint32_t circ, int max_k, hipStream_t s) {
+  int32_t* order = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(a.trees) + tree_bytes(dim, n_rows, N));
+  a.order = order;
+  hipLaunchKernelGGL(k_gibbs_order, dim3(1), dim3(1024), 0, s, V, a.prop_ptr, order);
+  if (n_rows > 0) {
+    if (dim == 2) hipLaunchKernelGGL((k_gibbs_trees<2, NM>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
+    else if (dim == 3) hipLaunchKernelGGL((k_gibbs_trees<3, NM>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gibbs_trees<6, NM>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
+  }
+  // LDS of a block: kGibbsResident level images (variables with more proposals stream theirs through slot 0) + constants and labels
+  // for the variable with the most proposals
+  constexpr int kGibbsResident = 4;
+  a.k_lds = max_k < kGibbsResident ? max_k : kGibbsResident;
+  const size_t img = dim == 2 ? sizeof(GibbsLevel<2, NM>) : (dim == 3 ? sizeof(GibbsLevel<3, NM>) : sizeof(GibbsLevel<6, NM>));
+  const size_t per = (dim == 2 ? sizeof(GibbsConst<2>) : (dim == 3 ? sizeof(GibbsConst<3>) : sizeof(GibbsConst<6>))) + NM;
+  const size_t bytes = img * (size_t)a.k_lds + per * (size_t)max_k;
+  if (bytes > 150 * 1024) return hipErrorInvalidValue;
+  auto launch = [&](auto kernel) -> hipError_t {
+    if (bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(V), dim3(NM), bytes, s, a);
+    return hipGetLastError();
+  };
+  if (dim == 2) return circ == 0 ? launch(k_product_gibbs<2, 0, NM>) : launch(k_product_gibbs<2, -1, NM>);
+  if (dim == 3) return circ == 4u ? launch(k_product_gibbs<3, 4, NM>) : (circ == 0 ? launch(k_product_gibbs<3, 0, NM>) : launch(k_product_gibbs<3, -1, NM>));
+  return circ == 0 ? launch(k_product_gibbs<6, 0, NM>) : launch(k_product_gibbs<6, -1, NM>);
+}
+
 hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t* prop_ptr, const int32_t* prop_rows, const double* prop,
                                 const double* prop_bw, const double* bel_in, double* bel_out, void* trees, uint32_t circ, int iters, int max_k,
                                 uint64_t seed, uint64_t stream_offset, hipStream_t s, const GibbsPlace* place) {
@@ -737,36 +795,11 @@ hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t
   a.max_k = max_k; a.iters = iters < 1 ? 1 : iters; a.circ = circ;
   a.prop_ptr = prop_ptr; a.prop_rows = prop_rows; a.prop = prop; a.prop_bw = prop_bw; a.bel_in = bel_in; a.bel_out = bel_out;
   a.trees = trees; a.n_rows = n_rows;
-  int32_t* order = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(trees) + tree_bytes(dim, n_rows));
-  a.order = order;
-  hipLaunchKernelGGL(k_gibbs_order, dim3(1), dim3(1024), 0, s, V, prop_ptr, order);
   a.seed = seed; a.stream_offset = stream_offset;
   a.place = place ? *place : GibbsPlace{nullptr, nullptr, nullptr, nullptr, 0};
   if (!a.place.mirror_out) a.place.mirror_slot = nullptr;
-  if (n_rows > 0) {
-    if (dim == 2) hipLaunchKernelGGL((k_gibbs_trees<2>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
-    else if (dim == 3) hipLaunchKernelGGL((k_gibbs_trees<3>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gibbs_trees<6>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
-  }
-  // LDS of a block: kGibbsResident level images (variables with more proposals stream theirs through slot 0) + constants and labels
-  // for the variable with the most proposals
-  constexpr int kGibbsResident = 4;
-  a.k_lds = max_k < kGibbsResident ? max_k : kGibbsResident;
-  const size_t img = dim == 2 ? sizeof(GibbsLevel<2>) : (dim == 3 ? sizeof(GibbsLevel<3>) : sizeof(GibbsLevel<6>));
-  const size_t per = (dim == 2 ? sizeof(GibbsConst<2>) : (dim == 3 ? sizeof(GibbsConst<3>) : sizeof(GibbsConst<6>))) + 128;
-  const size_t bytes = img * (size_t)a.k_lds + per * (size_t)max_k;
-  if (bytes > 150 * 1024) return hipErrorInvalidValue;
-  auto launch = [&](auto kernel) -> hipError_t {
-    if (bytes > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kernel, dim3(V), dim3(kGibbsThreads), bytes, s, a);
-    return hipGetLastError();
-  };
-  if (dim == 2) return circ == 0 ? launch(k_product_gibbs<2, 0>) : launch(k_product_gibbs<2, -1>);
-  if (dim == 3) return circ == 4u ? launch(k_product_gibbs<3, 4>) : (circ == 0 ? launch(k_product_gibbs<3, 0>) : launch(k_product_gibbs<3, -1>));
-  return circ == 0 ? launch(k_product_gibbs<6, 0>) : launch(k_product_gibbs<6, -1>);
+  // N <= 128: the 128-thread / two-slot instantiation (what every measured number of the solve loop is quoted on); above: 256
+  return N <= 128 ? launch_product_gibbs_nm<128>(a, dim, V, N, n_rows, circ, max_k, s) : launch_product_gibbs_nm<256>(a, dim, V, N, n_rows, circ, max_k, s);
 }
 
 }  // namespace rome

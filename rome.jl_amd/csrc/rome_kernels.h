@@ -74,7 +74,7 @@ hipError_t launch_product(int dim, int V, int N, const int32_t* prop_ptr, const 
                           const double* prop_bw, const double* bel_in, double* bel_out, double c_n, uint64_t seed,
                           uint64_t stream_offset, hipStream_t s);
 
-size_t gibbs_workspace_bytes(int dim, int n_rows, int V);
+size_t gibbs_workspace_bytes(int dim, int n_rows, int V, int N);   // (N: 128-slot trees up to N = 128, 256-slot trees above)
 // GibbsPlace (optional): where the V variables of a launch live and what they draw -- var_block[v] = block of bel_in / bel_out
 // (nullptr: v; bel_in == bel_out is allowed then: a product only reads its own variable's block), var_stream[v] = Philox stream id
 // (nullptr: v), mirror_slot[v] = block of mirror_out (stride doubles apart) the new belief is ALSO written to (-1 / nullptr: none)

@@ -306,7 +306,7 @@ class DeviceGraph:
         """bel <- product of the proposals targeting each variable (Jacobi update: computed into bel_next, copied back in place
         so that launch plans holding the belief pointers stay valid).
         product:   "gibbs" = the reference's algorithm, ⚠AMP manifoldProduct / KDE.jl multiscale Gibbs sampling
-                   (rome_product_gibbs_dev; Point2 / Pose2 / Pose3, N <= 128; always on the `manikde!` bandwidths of the proposals);
+                   (rome_product_gibbs_dev; Point2 / Pose2 / Pose3, N <= 256; always on the `manikde!` bandwidths of the proposals);
                    "importance" = the round-1 importance-sampling stand-in (rome_product_bw_dev).
         bandwidth: "silverman" (in-kernel rule on the proposal spread; importance product only) or "lcv" (leave-one-out
                    likelihood bandwidths of every proposal by rome_kde_bandwidth_dev first -- what the reference's `manikde!`

@@ -60,7 +60,10 @@ def _problem(dim, N, Ks, rng, circ):
     return np.array(ptr, dtype=np.int32), rows, prop
 
 
-@pytest.mark.parametrize("dim,N,iters", [(3, 100, 1), (3, 100, 2), (2, 100, 1), (3, 64, 1), (3, 37, 1), (3, 128, 1), (2, 5, 1), (3, 2, 1)])
+@pytest.mark.parametrize("dim,N,iters", [(3, 100, 1), (3, 100, 2), (2, 100, 1), (3, 64, 1), (3, 37, 1), (3, 128, 1), (2, 5, 1), (3, 2, 1),
+                                         # 128 < N <= 256: the 256-slot instantiation (the reference runs N = 150 / 200 in places:
+                                         # test/testPoint2Point2Init.jl:12, test/testPartialRangeCrossCorrelations.jl:17)
+                                         (3, 129, 1), (3, 150, 1), (2, 200, 1), (3, 200, 2), (3, 255, 1), (3, 256, 1), (2, 256, 1)])
 def test_device_equals_oracle_sample_by_sample(dim, N, iters):
     rng = np.random.default_rng(100 * dim + N + iters)
     circ = 0b100 if dim == 3 else 0
@@ -285,13 +288,14 @@ def test_reference_solved_graph_product_consistency():
     assert 0.4 < g[2] < 1.6, res                      # ... with a comparable width
 
 
-def test_pose3_product_device_equals_oracle_and_gaussian_moments():
+@pytest.mark.parametrize("N", [100, 200])
+def test_pose3_product_device_equals_oracle_and_gaussian_moments(N):
     """SE(3): the rotation coordinates of every proposal live in the chart at the rotation of its point 0; trees and candidate
     evaluations are Euclidean there, the product Gaussians of selected nodes change charts by Exp / Log.  Device (quaternions) ==
     oracle (rotation matrices) sample by sample; the product of two Gaussian densities on SE(3) has the Gaussian-product moments."""
     from scipy.spatial.transform import Rotation as Rot
     rng = np.random.default_rng(2)
-    N, V = 100, 60
+    V = 60
 
     def make(mu, sd):
         t = np.asarray(mu[:3])[:, None] + np.asarray(sd[:3])[:, None] * rng.standard_normal((3, N))

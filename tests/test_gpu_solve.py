@@ -521,16 +521,16 @@ def test_manhattan3500_two_solve_iterations_equal_the_oracle_loop():
 
 
 def test_particle_limits_fail_before_the_first_launch():
-    """include/rome_mi355.h per-stage limits: the Gibbs product takes N <= 128, manikde! bandwidths and the importance product N <= 512;
-    DeviceGraph.solve / solveGraph name the stage and fail before any launch instead of part-way through an iteration."""
-    fg = R.generateGraph_Hexagonal(N=200)
+    """include/rome_mi355.h per-stage limits: the Gibbs product takes N <= 256 (round 4; 128 before), manikde! bandwidths and the importance
+    product N <= 512; DeviceGraph.solve / solveGraph name the stage and fail before any launch instead of part-way through an iteration."""
+    fg = R.generateGraph_Hexagonal(N=300)
     R.dead_reckon_init(fg, seed=5)
     dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
     before = dg.bel[R.Pose2].clone()
     with pytest.raises(ValueError, match="multiscale Gibbs product"):
-        dg.solve(R.make_opts(N=200, seed=3), n_sweeps=1, bandwidth="lcv", product="gibbs")
+        dg.solve(R.make_opts(N=300, seed=3), n_sweeps=1, bandwidth="lcv", product="gibbs")
     assert bool((dg.bel[R.Pose2] == before).all())
-    dg.solve(R.make_opts(N=200, seed=3), n_sweeps=1, bandwidth="lcv", product="importance")   # N = 200 is fine for these stages
+    dg.solve(R.make_opts(N=300, seed=3), n_sweeps=1, bandwidth="lcv", product="importance")   # N = 300 is fine for these stages
     fg2 = R.generateGraph_Hexagonal(N=600)
     R.dead_reckon_init(fg2, seed=5)
     dg2 = R.DeviceGraph(fg2); dg2.upload_beliefs(fg2)

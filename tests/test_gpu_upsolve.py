@@ -60,6 +60,23 @@ def test_hexagon_clique_by_clique_equals_the_oracle_loop(schedule):
         assert inside > 0.55, (l, inside)
 
 
+def test_upsolve_with_more_than_128_particles_equals_the_oracle_loop():
+    """N = 150 (test/testPoint2Point2Init.jl:12 runs that many) and N = 256: the 256-slot instantiation of the tree build / sampler and the
+    general-N bandwidth kernel inside rome_clique_upsolve, against the oracle's loop; N = 257 is refused before anything is launched."""
+    for N, fr in ((150, ["x0", "x1"]), (256, ["x6", "l1"])):
+        fg_d, fg_o = _hex(N), _hex(N)
+        res = R.upGibbsCliqueDensity(fg_d, fr, gibbsIters=2, seed=77)
+        ref = upsolve_ref(R, fg_o, fr, N, seed=77, gibbs_iters=2)
+        for l in fr:
+            pts, bw = res[l]
+            d = _wrapdiff(pts.copy(), ref[l], pts.shape[0])
+            assert np.mean(np.abs(d) < 1e-6) > 0.9 and np.abs(d.mean(1)).max() < 1e-3, (N, l, np.mean(np.abs(d) < 1e-6))
+            assert (bw > 0).all()
+    with pytest.raises(R.RomeError) as e:
+        R.upGibbsCliqueDensity(_hex(257), ["x1"], seed=1)
+    assert e.value.code == R._lib.ERR_UNSUPPORTED_N
+
+
 def test_upsolve_messages_and_layouts_and_errors():
     N = 100
     fg = _hex(N)
