@@ -15,7 +15,7 @@
 //           Node statistics bottom-up by Chan's pairwise update with the children fetched by lane shuffles (same arithmetic
 //           order as the oracle), stored in single precision as offsets from the proposal's point 0, [coordinate][node].
 //   order   k_gibbs_order: the variables by descending number of proposals (one block, counting sort) -- the dispatch order of
-//   sample  k_product_gibbs: one 128-thread block per variable, lane = output sample (N <= 128).  The current level of every tree
+//   sample  k_product_gibbs: one block per variable, lane = output sample (128 threads for N <= 128, 256 up to N = 256).  The current level of every tree
 //           of the variable is staged in LDS (2.8 kB per tree; the whole trees would pin 81 kB for a hub variable with 11
 //           proposals); every categorical draw walks the candidates of a level two at a time with WAVE-UNIFORM node statistics
 //           (8-byte LDS broadcasts) against the lane's own point / product Gaussian: no divergence; one-pass reservoir selection
