@@ -290,3 +290,56 @@ def test_store_wrapped_over_caller_memory_equals_the_owned_store():
         k = dg.packed.labels[R.Pose2].index(c[0])
         assert np.array_equal(bel[k], owned.get(c[0])) and not np.array_equal(bel[k], fg.getVal(c[0]))
     assert np.array_equal(wrapped.get(poses[0]), bel[0])
+
+
+def test_store_and_plan_edge_cases():
+    """empty inputs through the device-resident entries: a store without landmarks / Pose3, an up-solve plan with nothing to update, a
+    frontal without any usable factor (keeps its belief, still mirrored), an empty scatter plan; AoS and native-point uploads"""
+    import ctypes as C
+    import torch
+    from rome_jl_amd import _lib
+    from rome_jl_amd.clique import CliqueUpsolveHost
+    N = 64
+    fg = R.initfg(N)
+    rng = np.random.default_rng(0)
+    for k in range(3):
+        fg.addVariable("x%d" % k, R.Pose2)
+        fg.initVariable("x%d" % k, rng.standard_normal((3, N)) * np.array([[1.0], [1.0], [0.1]]) + np.array([[3.0 * k], [0.0], [0.0]]))
+    fg.addFactor(["x0", "x1"], R.Pose2Pose2(R.MvNormal([3.0, 0, 0], np.diag([0.1, 0.1, 0.01]) ** 2)))
+    store = DeviceStore(fg)                       # no Point2, no Pose3
+    assert store.device_ptr(R.Point2)[1] == 0 and store.device_ptr(R.Pose2)[1] == 3
+    lib, ctx = _lib.load(), store.ctx
+    # nothing to update
+    u = CliqueUpsolveHost(); u.gibbs_iters = 1; u.product_iters = 1
+    h = C.c_void_p()
+    o = R.make_opts(N=N, seed=1); o.layout = _lib.LAYOUT_SOA
+    _lib.check(lib.rome_upsolve_plan_create(ctx.handle, store.handle, C.byref(o), C.byref(u), C.byref(h)), ctx.handle)
+    _lib.check(lib.rome_upsolve_plan_run(h, C.byref(o), None, 0), ctx.handle)
+    lib.rome_upsolve_plan_destroy(h)
+    # x2 has no factor at all: its "up-solve" keeps the belief and still fills its mirror block
+    buf = torch.zeros(2 * 6 * N, dtype=torch.float64, device="cuda")
+    plan = UpsolvePlan(store, [["x2"], ["x1"]], gibbsIters=1, mirror={"x2": 1, "x1": 0})
+    plan.run(R.make_opts(N=N, seed=2), mirror_out=buf, mirror_stride=6 * N)
+    ctx.synchronize()
+    hb = buf.cpu().numpy().reshape(2, 6 * N)
+    assert np.array_equal(store.get("x2"), fg.getVal("x2")) and np.array_equal(hb[1, :3 * N].reshape(3, N), fg.getVal("x2"))
+    assert np.array_equal(hb[0, :3 * N].reshape(3, N), store.get("x1")) and not np.array_equal(store.get("x1"), fg.getVal("x1"))
+    ScatterPlan(store, [], [], stride=0).run(buf)          # empty: no launch
+    # uploads in the other layouts land as the same coordinates
+    aos = np.ascontiguousarray(fg.getVal("x0").T)          # [N][3]
+    PD = C.POINTER(C.c_double)
+    _lib.check(lib.rome_store_upload(store.handle, _lib.LAYOUT_AOS, 0, 2, 1, aos.ctypes.data_as(PD)), ctx.handle)
+    assert np.array_equal(store.get("x2"), fg.getVal("x0"))
+    pts = R.coords_to_points(3, aos)
+    if pts is not None:
+        pts = np.ascontiguousarray(pts)
+        _lib.check(lib.rome_store_upload(store.handle, _lib.LAYOUT_AOS_POINTS, 0, 1, 1, pts.ctypes.data_as(PD)), ctx.handle)
+        d = store.get("x1") - fg.getVal("x0"); d[2] = np.arctan2(np.sin(d[2]), np.cos(d[2]))
+        assert np.abs(d).max() < 1e-12
+        back = np.zeros_like(pts)
+        _lib.check(lib.rome_store_download(store.handle, _lib.LAYOUT_AOS_POINTS, 0, 1, 1, back.ctypes.data_as(PD)), ctx.handle)
+        assert np.abs(back - pts).max() < 1e-12
+    with pytest.raises(R.RomeError):
+        _lib.check(lib.rome_store_upload(store.handle, _lib.LAYOUT_SOA, 0, 2, 2, aos.ctypes.data_as(PD)), ctx.handle)   # past the end
+    with pytest.raises(R.RomeError):
+        _lib.check(lib.rome_store_upload(store.handle, _lib.LAYOUT_SOA, 1, 0, 1, aos.ctypes.data_as(PD)), ctx.handle)   # a type the store does not hold
