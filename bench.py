@@ -97,6 +97,14 @@ def rank_graph(R, args, rank, multi, strong, N):
     return fg, workload, last
 
 
+def pipe_depth(world):
+    """steps in flight of the weak-scaling pipeline (a ghost belief is `depth` steps old): the step period is
+    max(sweep, (sweep + exchange) / depth).  Each slot owns a stream, a send / receive buffer and a communicator -- and a HIP stream
+    maps to one of FOUR hardware queues: measured with one rank and the exchange forced (round 4), depth 2 reads 9.4 us per step,
+    depth 4 8.0 us, depth 8 12.7 us (eight streams multiplexed onto four queues).  Four it is, for every rank count."""
+    return int(os.environ.get("ROME_PIPE_DEPTH", "4"))
+
+
 def separator_rows(pk, args, last):
     """proposal rows that carry the updated separator estimates of a segment (odometry convolutions targeting its first / last pose)"""
     vf, vt = pk.p2p2["var_from"], pk.p2p2["var_to"]
@@ -119,7 +127,7 @@ def dry_run(args):
         checks[name] = bool(ok)
         if not ok:
             fails.append("%s: %s" % (name, detail))
-    depth = int(os.environ.get("ROME_PIPE_DEPTH", "4" if world > 2 else "2"))
+    depth = pipe_depth(world)
     # ---- weak scaling: a chain of Manhattan-sized segments, separator all-gather
     pipes = []
     for rank in range(world):
@@ -311,7 +319,7 @@ def main():
         # pipeline depth = steps in flight (a ghost belief is `depth` steps old): the step period is max(sweep, (sweep + exchange) /
         # depth).  One rank, exchange forced: 12.6–13.7 µs per step for every depth 2..6 (profiles/r02_bench_n1_forced_exchange.json); a
         # ring all-gather over more than two GPUs costs several sweeps of latency, so four slots there
-        depth = int(os.environ.get("ROME_PIPE_DEPTH", "4" if world > 2 else "2"))
+        depth = pipe_depth(world)
         # separator exchange through RCCL directly (one communicator per pipeline slot, enqueued on the sweep's own stream);
         # torch.distributed's collective is the fallback if the direct binding cannot be set up on every rank
         comms = None

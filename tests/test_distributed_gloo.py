@@ -145,7 +145,7 @@ def _pipe_worker(rank, world, port, ret, depth=2, steps=5):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,depth,steps", [(2, 2, 5), (3, 4, 9), (8, 4, 6)])
+@pytest.mark.parametrize("world,depth,steps", [(2, 4, 9), (3, 4, 9), (8, 4, 6)])
 def test_pipelined_segment_sweep_two_ranks_matches_single_process_emulation(world, depth, steps):
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_pipe_worker, args=(world, _free_port(), ret, depth, steps), nprocs=world, join=True)
