@@ -74,6 +74,8 @@ class OrderedSolve:
         sweeps update them like every other variable."""
         if kind not in ("colour", "levels"):
             raise ValueError("kind must be 'colour' or 'levels'")
+        if not 1 <= int(gibbsIters) <= 16:      # Philox stream of run k = k << 36: (iteration << 32) + family + row must stay below it
+            raise ValueError("gibbsIters must be in 1..16")
         if plan_cls is None:
             from .clique import UpsolvePlan
             plan_cls = UpsolvePlan
