@@ -1071,7 +1071,7 @@ void rome_store_destroy(rome_store* st) {
   delete st;
 }
 int rome_store_upload(rome_store* st, int32_t layout, int32_t type, int32_t first, int32_t count, const double* host) {
-  if (!st || type < 0 || type > 2 || first < 0 || count < 0 || first + count > st->nv[type] || (count > 0 && !host)) return ROME_ERR_INVALID_ARG;
+  if (!st || type < 0 || type > 2 || first < 0 || count < 0 || (int64_t)first + count > st->nv[type] || (count > 0 && !host)) return ROME_ERR_INVALID_ARG;
   if (layout != ROME_LAYOUT_SOA && layout != ROME_LAYOUT_AOS && layout != ROME_LAYOUT_AOS_POINTS) return ROME_ERR_INVALID_ARG;
   if (count == 0) return ROME_OK;
   rome_ctx* c = st->ctx;
@@ -1087,7 +1087,7 @@ int rome_store_upload(rome_store* st, int32_t layout, int32_t type, int32_t firs
   return ROME_OK;
 }
 int rome_store_download(rome_store* st, int32_t layout, int32_t type, int32_t first, int32_t count, double* host) {
-  if (!st || type < 0 || type > 2 || first < 0 || count < 0 || first + count > st->nv[type] || (count > 0 && !host)) return ROME_ERR_INVALID_ARG;
+  if (!st || type < 0 || type > 2 || first < 0 || count < 0 || (int64_t)first + count > st->nv[type] || (count > 0 && !host)) return ROME_ERR_INVALID_ARG;
   if (layout != ROME_LAYOUT_SOA && layout != ROME_LAYOUT_AOS && layout != ROME_LAYOUT_AOS_POINTS) return ROME_ERR_INVALID_ARG;
   rome_ctx* c = st->ctx;
   ROME_BIND(c);
