@@ -198,9 +198,17 @@ _batchable(fc) = (f = getFactorType(fc); f isa _accelerated &&
                   (_mh(fc) === nothing || (f isa Union{Pose2Pose2,Pose2Point2BearingRange} && length(_mh(fc)) == 3 && _mh(fc)[1] == 1.0)))
 
 # row tables of a list of (factor, destination) pairs over the variables they touch: what rome_clique_host carries
-function _clique_tables(dfg::AbstractDFG, pairs::AbstractVector; solveKey::Symbol=:default, extra_vars::AbstractVector{Symbol}=Symbol[])
+function _clique_tables(dfg::AbstractDFG, pairs::AbstractVector; solveKey::Symbol=:default, extra_vars::AbstractVector{Symbol}=Symbol[],
+                        index::Union{Nothing,Dict{Symbol,Int32}}=nothing)
+  # index === nothing: variables are numbered per type as they are met and their beliefs gathered (the one-shot entries);
+  # index = a RomeStore's numbering: the tables address the store's blocks and no belief leaves the graph
   vidx = Dict{Symbol,Int32}(); vars = Dict(Pose2 => Symbol[], Point2 => Symbol[], Pose3 => Symbol[])
-  var!(l) = get!(vidx, l) do; T = typeof(getVariableType(dfg, l)); push!(vars[T], l); Int32(length(vars[T]) - 1); end
+  function var!(l)
+    index === nothing || return (vidx[l] = index[l])
+    get!(vidx, l) do
+      T = typeof(getVariableType(dfg, l)); push!(vars[T], l); Int32(length(vars[T]) - 1)
+    end
+  end
   fams = (:p2p2, :br1, :br0, :p3p3, :prpt2)
   rows = Dict(f => Int32[] for f in fams)
   alt = Dict(f => Int32[] for f in fams); hw = Dict(f => Float64[] for f in fams); nh = Dict(f => Float64[] for f in fams)
@@ -246,8 +254,8 @@ function _clique_tables(dfg::AbstractDFG, pairs::AbstractVector; solveKey::Symbo
   (; vidx, vars, rows, alt, hw, nh, tabμ, tabΣ, nfac, order, b2 = blk(Pose2), bl = blk(Point2), b3 = blk(Pose3))
 end
 _p(x) = isempty(x) ? Ptr{eltype(x)}(C_NULL) : pointer(x)
-_clique_host(t, o2, o1, o0, o3, opt = Float64[]) =
-  RomeCliqueHost(length(t.vars[Pose2]), length(t.vars[Point2]), length(t.vars[Pose3]), 0, _p(t.b2), _p(t.bl), _p(t.b3),
+_clique_host(t, o2, o1, o0, o3, opt = Float64[], nv = (length(t.vars[Pose2]), length(t.vars[Point2]), length(t.vars[Pose3]))) =
+  RomeCliqueHost(nv[1], nv[2], nv[3], 0, _p(t.b2), _p(t.bl), _p(t.b3),
                  length(t.rows[:p2p2]) ÷ 4, t.nfac[:p2p2], _p(t.rows[:p2p2]), _p(t.tabμ[:p2p2]), _p(t.tabΣ[:p2p2]), _p(o2),
                  length(t.rows[:br1]) ÷ 4, length(t.rows[:br0]) ÷ 4, t.nfac[:br], 0, _p(t.rows[:br1]), _p(t.rows[:br0]), _p(t.tabμ[:br]), _p(t.tabΣ[:br]), _p(o1), _p(o0),
                  length(t.rows[:p3p3]) ÷ 4, t.nfac[:p3p3], _p(t.rows[:p3p3]), _p(t.tabμ[:p3p3]), _p(t.tabΣ[:p3p3]), _p(o3),
@@ -354,6 +362,129 @@ function upsolve_clique!(dfg::AbstractDFG, frontals::AbstractVector{Symbol}, fac
   end
   nothing
 end
+
+# ---- device-resident beliefs across clique up-solves: rome_store + rome_upsolve_plan (+ rome_scatter_plan) -----------------------------
+# A tree solve visits thousands of cliques, and the separator beliefs one clique writes are what its parent reads: with a store the
+# beliefs cross PCIe at upload! and download! only; a plan is validated and uploaded ONCE per clique (or per frontier of independent
+# cliques) and run! is kernel launches on the context's stream -- no copy, no synchronisation.  Python twins (what the tests drive):
+# rome_jl_amd.clique.DeviceStore / UpsolvePlan / ScatterPlan, tests/test_gpu_clique_hypo.py, tests/test_gpu_upsolve.py.
+_tcode(T) = T === Pose2 ? Int32(0) : T === Point2 ? Int32(1) : T === Pose3 ? Int32(2) : error("RoMEMI355Ext: variable type $T is not in the store")
+_ptlen(c) = (6, 2, 12)[c + 1]      # doubles per native point (ROME_LAYOUT_AOS_POINTS)
+const _VT = (Pose2, Point2, Pose3)
+
+mutable struct RomeStore
+  h::Ptr{Cvoid}
+  N::Int
+  labels::NTuple{3,Vector{Symbol}}          # per type code, in block order
+  index::Dict{Symbol,Int32}                 # label -> block within its type
+end
+
+function RomeStore(dfg::AbstractDFG, labels::AbstractVector{Symbol}=ls(dfg); solveKey::Symbol=:default, N::Integer=getSolverParams(dfg).N)
+  lab = (Symbol[], Symbol[], Symbol[]); idx = Dict{Symbol,Int32}()
+  for l in labels
+    c = _tcode(typeof(getVariableType(dfg, l))); idx[l] = Int32(length(lab[c + 1])); push!(lab[c + 1], l)
+  end
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  check(ccall((:rome_store_create, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
+              ctx().h, N, length(lab[1]), length(lab[2]), length(lab[3]), r))
+  st = RomeStore(r[], Int(N), lab, idx)
+  finalizer(s -> ccall((:rome_store_destroy, LIB), Cvoid, (Ptr{Cvoid},), s.h), st)   # (destroy the plans of a store before the store)
+  upload!(st, dfg; solveKey)
+  st
+end
+
+# beliefs graph -> store: the reference's point containers as they are, one copy per run of consecutive blocks
+function upload!(st::RomeStore, dfg::AbstractDFG, labels=nothing; solveKey::Symbol=:default)
+  for c in 0:2
+    want = [k for (k, l) in enumerate(st.labels[c + 1]) if (labels === nothing || l in labels) && isInitialized(dfg, l)]
+    k = 1
+    while k <= length(want)
+      j = k
+      while j < length(want) && want[j + 1] == want[j] + 1; j += 1; end
+      buf = reduce(vcat, [collect(reinterpret(Float64, getVal(dfg, st.labels[c + 1][i]; solveKey))) for i in want[k:j]])
+      length(buf) == (j - k + 1) * st.N * _ptlen(c) || error("RomeStore: every uploaded belief must hold N = $(st.N) points")
+      GC.@preserve buf check(ccall((:rome_store_upload, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ptr{Float64}),
+                                   st.h, 2, c, want[k] - 1, j - k + 1, buf))
+      k = j + 1
+    end
+  end
+  nothing
+end
+
+# beliefs store -> graph (setValKDE! with AMP's own bandwidth selection; synchronises the context's stream)
+function download!(st::RomeStore, dfg::AbstractDFG, labels::AbstractVector{Symbol}; solveKey::Symbol=:default)
+  for l in labels
+    T = typeof(getVariableType(dfg, l)); c = _tcode(T)
+    buf = Vector{Float64}(undef, st.N * _ptlen(c))
+    GC.@preserve buf check(ccall((:rome_store_download, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ptr{Float64}),
+                                 st.h, 2, c, st.index[l], 1, buf))
+    P = eltype(getVal(dfg, l; solveKey))
+    setValKDE!(dfg, l, manikde!(getManifold(T), collect(reinterpret(P, buf))), false, 1.0; solveKey)
+  end
+  nothing
+end
+
+# One clique (frontals in Gibbs order) or a frontier of independent cliques (`group`: frontals with the same group id are updated
+# together, groups in order) as a plan over the store.  mirror: label => block of a device exchange buffer the product kernel ALSO
+# writes the new belief to (run!(…; mirror_out, mirror_stride)); stream ids (`up_stream`, per-row streams) default to positions.
+mutable struct RomeUpsolvePlan
+  h::Ptr{Cvoid}
+  store::RomeStore
+  opts::RomeOpts
+  has_mirror::Bool
+end
+
+function RomeUpsolvePlan(st::RomeStore, dfg::AbstractDFG, frontals::AbstractVector{Symbol}, factors::AbstractVector{<:DFGFactor};
+                         gibbsIters::Integer=3, Niter::Integer=1, sequential::Bool=true, group::Union{Nothing,Vector{Int32}}=nothing,
+                         mirror::Union{Nothing,Dict{Symbol,Int}}=nothing, solveKey::Symbol=:default)
+  touching = [fc for fc in factors if any(in(getVariableOrder(fc)), frontals)]
+  bad = [getLabel(fc) for fc in touching if !_batchable(fc)]
+  isempty(bad) || throw(ArgumentError("RomeUpsolvePlan: factors $(bad) are outside the accelerated set; this clique stays with IIF"))
+  pairs = [(fc, l) for l in frontals for fc in touching if l in getVariableOrder(fc)]
+  t = _clique_tables(dfg, pairs; solveKey, index = st.index)
+  upt = Int32[_tcode(typeof(getVariableType(dfg, l))) for l in frontals]; upv = Int32[st.index[l] for l in frontals]
+  grp = group === nothing ? Int32[] : group
+  mir = mirror === nothing ? Int32[] : Int32[get(mirror, l, -1) for l in frontals]
+  o = _points_opts(dfg, st.N)
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve t upt upv grp mir begin
+    q = _clique_host(t, Float64[], Float64[], Float64[], Float64[], Float64[], (length(st.labels[1]), length(st.labels[2]), length(st.labels[3])))
+    u = RomeCliqueUpsolveHost(q, Int32(gibbsIters), Int32(Niter), Int32(sequential ? 0 : 1), Int32(length(frontals)), _p(upt), _p(upv),
+                              0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
+                              C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,          # no host outputs: run! copies nothing and does not wait
+                              _p(grp), Ptr{Int32}(C_NULL), _p(mir))
+    check(ccall((:rome_upsolve_plan_create, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{RomeOpts}, Ref{RomeCliqueUpsolveHost}, Ref{Ptr{Cvoid}}),
+                ctx().h, st.h, o, u, r))
+  end
+  p = RomeUpsolvePlan(r[], st, o, mirror !== nothing)
+  finalizer(x -> ccall((:rome_upsolve_plan_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), p)
+end
+
+# gibbs_iters x {proposals -> manikde! bandwidths -> multiscale Gibbs product -> in-place write}, asynchronous on the context's stream.
+# A fresh seed per run: the draws of two runs of a plan must differ.
+function run!(p::RomeUpsolvePlan; seed::Integer=rand(UInt64), stream_offset::Integer=0,
+              mirror_out::Ptr{Float64}=Ptr{Float64}(C_NULL), mirror_stride::Integer=0)
+  d = p.opts
+  o = RomeOpts(d.n_particles, d.solver, d.max_iters, d.inflate_cycles, d.tol, d.inflation, seed, stream_offset, d.layout, d.presampled, d.spread_nh, d.nullhypo)
+  check(ccall((:rome_upsolve_plan_run, LIB), Cint, (Ptr{Cvoid}, Ref{RomeOpts}, Ptr{Float64}, Int64), p.h, o, mirror_out, mirror_stride))
+end
+
+# The receive side of an exchange: blocks src_block[k] (of `stride` doubles; 0 = 6 N) of a device buffer -> the store's variables.
+mutable struct RomeScatterPlan
+  h::Ptr{Cvoid}
+  store::RomeStore
+end
+function RomeScatterPlan(st::RomeStore, dfg::AbstractDFG, labels::AbstractVector{Symbol}, src_blocks::AbstractVector{<:Integer}; stride::Integer=0)
+  ty = Int32[_tcode(typeof(getVariableType(dfg, l))) for l in labels]; va = Int32[st.index[l] for l in labels]; sb = Int32.(src_blocks)
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve ty va sb check(ccall((:rome_scatter_plan_create, LIB), Cint,
+      (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64, Ref{Ptr{Cvoid}}),
+      ctx().h, st.h, length(labels), _p(ty), _p(va), _p(sb), stride, r))
+  sp = RomeScatterPlan(r[], st)
+  finalizer(x -> ccall((:rome_scatter_plan_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), sp)
+end
+run!(sp::RomeScatterPlan, src_dev::Ptr{Float64}) = check(ccall((:rome_scatter_plan_run, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), sp.h, src_dev))
+synchronize() = check(ccall((:rome_ctx_synchronize, LIB), Cint, (Ptr{Cvoid},), ctx().h))
 
 # ---- parametric path: batched whitened residuals + Jacobians (rome_linearize) ------------------------------
 # kind: 0 PriorPose2, 1 Pose2Pose2, 2 Pose2Point2BearingRange, 3 PriorPoint2, 4 Pose3Pose3, 5 PriorPose3
