@@ -276,8 +276,10 @@ __device__ void gibbs_build(GibbsTree<D, NM>* __restrict__ T, const double* __re
   };
   if (L >= 1) merge_level(L - 1, std::true_type{});
   for (int l = L - 2; l >= 0; --l) {
-    if ((2 << l) > 64) merge_level(l, std::true_type{});    // (only NM = 256: a child level of 128 nodes sits in two slots)
-    else merge_level(l, std::false_type{});
+    if constexpr (NM > 128) {   // (only NM = 256: a child level of 128 nodes sits in two slots; not even compiled into the 128 build)
+      if ((2 << l) > 64) { merge_level(l, std::true_type{}); continue; }
+    }
+    merge_level(l, std::false_type{});
   }
   if (lane == 0) {
     double lg = 0.0;
