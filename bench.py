@@ -238,6 +238,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # ROME_BENCH_SHARED_DEVICE=1 (tests only, never a measurement): all ranks launch on device 0, the process group is gloo and the
+    # separator / belief exchange goes through rome_jl_amd.rccl.HostStagedComm -- RCCL refuses two ranks on one device, and this is
+    # how the N > 1 flow of this file (per-rank tables, pipeline, barriers, max-over-ranks timing, rank 0's JSON line) runs as N
+    # real processes on a one-GPU box (tests/test_gpu_two_ranks_one_device.py).  The line it prints says so.
+    shared = os.environ.get("ROME_BENCH_SHARED_DEVICE") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # ROME_BENCH_FORCE_EXCHANGE=1: exercise the multi-GPU code path (process group, ghost variables,
@@ -248,7 +255,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         if world == 1:
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != world:
             raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), world))
     if multi:
@@ -263,7 +273,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a number "
                          "for a different GPU count" % (args.gpus, world))
-    if torch.cuda.device_count() < (args.gpus if "LOCAL_WORLD_SIZE" not in os.environ else int(os.environ["LOCAL_WORLD_SIZE"])):
+    if not shared and torch.cuda.device_count() < (args.gpus if "LOCAL_WORLD_SIZE" not in os.environ else int(os.environ["LOCAL_WORLD_SIZE"])):
         raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) are visible" % (args.gpus, torch.cuda.device_count()))
 
     N = args.particles
@@ -291,7 +301,10 @@ def main():
     if strong:
         from rome_jl_amd.distributed import TargetShardedSweep
         comm = None
-        if os.environ.get("ROME_BENCH_TORCH_COLLECTIVE") != "1":
+        if shared:
+            from rome_jl_amd.rccl import HostStagedComm
+            comm = HostStagedComm(torch, dist, world, ctx)
+        elif os.environ.get("ROME_BENCH_TORCH_COLLECTIVE") != "1":
             try:
                 from rome_jl_amd.rccl import create_comms
                 cc = create_comms(torch, dist, world, rank, dev, 1)
@@ -323,7 +336,10 @@ def main():
         # separator exchange through RCCL directly (one communicator per pipeline slot, enqueued on the sweep's own stream);
         # torch.distributed's collective is the fallback if the direct binding cannot be set up on every rank
         comms = None
-        if os.environ.get("ROME_BENCH_TORCH_COLLECTIVE") != "1":
+        if shared:
+            from rome_jl_amd.rccl import HostStagedComm
+            comms = [HostStagedComm(torch, dist, world, ctx) for _ in range(depth)]
+        elif os.environ.get("ROME_BENCH_TORCH_COLLECTIVE") != "1":
             try:
                 from rome_jl_amd.rccl import create_comms
                 comms = create_comms(torch, dist, world, rank, dev, depth)
@@ -379,7 +395,7 @@ def main():
         t1 = time.perf_counter()
         el = t1 - t0
         if multi:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            tt = torch.tensor([el], dtype=torch.float64, device="cpu" if shared else dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         # N>1: even and odd steps run on side streams, which events on the caller's stream do not bracket: the launch period is
@@ -418,13 +434,14 @@ def main():
         "value": value, "unit": "convolutions/s", "n_gpus": (dist.get_world_size() if multi else 1), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "timed_blocks_ms_per_step": [1e3 * b[0] / args.steps for b in blocks],
         "timed_block": "median of %d blocks of exactly %d steps, each between barrier + synchronize%s" % (n_blocks, args.steps, ", after one untimed block; kernel_ms_per_launch from one more such block bracketed by two HIP events" if n_blocks > 1 else ""), "higher_is_better": True, "scaling": "strong" if strong else "weak",
-        "vs_baseline": None, "dtype": "f64", "data": data_kind,
+        "vs_baseline": None, "dtype": "f64", "data": data_kind if not shared else
+        data_kind + " [ROME_BENCH_SHARED_DEVICE=1: %d ranks on ONE device, host-staged exchange -- a flow test, NOT a measurement]" % world,
         "config": {"workload": workload, "poses_per_gpu": len(pk.labels[R.Pose2]), "pose2pose2_factors_per_gpu": tb["F"],
                    "convolutions_per_step_per_gpu": (pipe.n_rows if strong else n_conv_step), "particles": N, "solver": args.solver,
                    "inflate_cycles": int(opts.inflate_cycles), "inflation": float(opts.inflation), "noise": "in-kernel philox",
                    "parallelism": ("ONE graph, one %s per step: rows sharded by target ownership (%d of %d on rank 0), all_gather of the owned belief blocks (%s)"
-                                   % (strong_unit, pipe.n_rows, tb["C"], "RCCL direct, in place" if comms else "torch.distributed")) if strong else
-                                  (("1 graph segment per GPU, separator all_gather (%s, pipeline depth %d)" % ("RCCL direct" if comms else "torch.distributed", depth))
+                                   % (strong_unit, pipe.n_rows, tb["C"], ("host-staged (shared device)" if shared else "RCCL direct, in place") if comms else "torch.distributed")) if strong else
+                                  (("1 graph segment per GPU, separator all_gather (%s, pipeline depth %d)" % (("host-staged (shared device)" if shared else "RCCL direct") if comms else "torch.distributed", depth))
                                    if multi else "single GPU"),
                    "ranks_seen_by_rccl": (dist.get_world_size() if multi else 1)},
         "roofline": {"bound": "hbm", "kernel": ("rome::k_conv_flat<P2P2> (packed unique-root sweep)" if args.solver in ("newton", "closed_form")

@@ -65,6 +65,34 @@ class RcclComm:
             self.comm = C.c_void_p()
 
 
+class HostStagedComm:
+    """RcclComm's interface over the default process group of ANY backend, through host memory: synchronous device -> host -> collective
+    -> host -> device.  NOT a transport for production and never chosen implicitly -- it exists for the one situation RCCL refuses:
+    several ranks sharing ONE device (a one-GPU test box).  With it the multi-rank drivers and `bench.py --gpus N` run as N real
+    processes with the real kernels (tests/test_gpu_two_ranks_one_device.py, `ROME_BENCH_SHARED_DEVICE=1`); only the wire is replaced."""
+
+    def __init__(self, torch, dist, world, ctx):
+        from . import _lib
+        self.torch, self.dist, self.world, self.ctx, self._l, self._lib = torch, dist, world, ctx, _lib, _lib.load()
+        self.calls = 0
+
+    def all_gather_f64(self, send_ptr, recv_ptr, count, stream_ptr):
+        import numpy as np
+        torch = self.torch
+        torch.cuda.synchronize()                      # the producing launches, whatever stream they are on
+        send = np.empty(count, dtype=np.float64)
+        self._l.check(self._lib.rome_dev_download(self.ctx.handle, send.ctypes.data, C.c_void_p(send_ptr), send.nbytes), self.ctx.handle)
+        out = torch.empty(self.world * count, dtype=torch.float64)
+        self.dist.all_gather_into_tensor(out, torch.from_numpy(send))
+        host = out.numpy()
+        self._l.check(self._lib.rome_dev_upload(self.ctx.handle, C.c_void_p(recv_ptr), host.ctypes.data, host.nbytes), self.ctx.handle)
+        torch.cuda.synchronize()
+        self.calls += 1
+
+    def close(self):
+        pass
+
+
 def _init_group(torch, device, lib, world, rank, uids, out):
     """ALL n communicators inside ONE ncclGroupStart / ncclGroupEnd: every rank enters the same single collective initialisation
     (no rank can sit inside ncclCommInitRank of communicator k while another one has already given up on communicator k-1)."""

@@ -1,11 +1,10 @@
 """The N > 1 drivers with the REAL kernels in TWO PROCESSES.  The test box has one GPU and RCCL refuses two ranks on one device, so
-both ranks run their launches on cuda:0 and the communicator is a test double with RcclComm's interface (`all_gather_f64(send_ptr,
-recv_ptr, count, stream)`) whose transport is device -> host -> gloo -> host -> device.  Everything else is the shipped path: rank-
+both ranks run their launches on cuda:0 and the communicator is `rome_jl_amd.rccl.HostStagedComm`: RcclComm's interface
+(`all_gather_f64(send_ptr, recv_ptr, count, stream)`) with device -> host -> gloo -> host -> device as the transport.  Everything else is the shipped path: rank-
 dependent tables and shares, ghost blocks, mirror writes of the sweep / product kernels into the exchange buffer, the in-place receive
 layout, the scatter plan, the depth-fold buffered pipeline.  What the RCCL transport itself adds is covered by the one-rank direct-RCCL
 tests (test_gpu_pipeline.py, test_gpu_upsolve.py, test_gpu_config4.py); the same drivers over oracle stand-ins at world 2 / 3 / 8 run in
 tests/test_distributed_gloo.py."""
-import ctypes as C
 import os
 import socket
 import sys
@@ -21,28 +20,9 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-class HostStagedComm:
-    """RcclComm's interface over gloo: synchronous, through host memory (rome_dev_download / rome_dev_upload)"""
-
-    def __init__(self, torch, dist, world, ctx):
-        from rome_jl_amd import _lib
-        self.torch, self.dist, self.world, self.ctx, self._l, self.lib = torch, dist, world, ctx, _lib, _lib.load()
-        self.calls = 0
-
-    def all_gather_f64(self, send_ptr, recv_ptr, count, stream_ptr):
-        torch = self.torch
-        torch.cuda.synchronize()                                   # the producing launches (whatever stream they are on)
-        send = np.empty(count, dtype=np.float64)
-        self._l.check(self.lib.rome_dev_download(self.ctx.handle, send.ctypes.data, C.c_void_p(send_ptr), send.nbytes), self.ctx.handle)
-        out = torch.empty(self.world * count, dtype=torch.float64)
-        self.dist.all_gather_into_tensor(out, torch.from_numpy(send))
-        host = out.numpy()
-        self._l.check(self.lib.rome_dev_upload(self.ctx.handle, C.c_void_p(recv_ptr), host.ctypes.data, host.nbytes), self.ctx.handle)
-        torch.cuda.synchronize()
-        self.calls += 1
-
-    def close(self):
-        pass
+def HostStagedComm(torch, dist, world, ctx):
+    from rome_jl_amd.rccl import HostStagedComm as H
+    return H(torch, dist, world, ctx)
 
 
 def _init(rank, world, port):
@@ -247,3 +227,36 @@ def test_frontier_shard_processes_equal_the_single_unsharded_plan_real_kernels(w
         assert calls == 4
         for l in ref:
             assert np.array_equal(got[l], ref[l]), (world, r, l)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# bench.py under the launcher, exactly the driver's command line for N = 2 and N = 8, as N real processes (ROME_BENCH_SHARED_DEVICE=1: both on
+# device 0, gloo process group, host-staged exchange): per-rank graph segments and tables, the pipeline, the barriers, the
+# max-over-ranks reduction and rank 0's single JSON line all execute -- the flow an 8-GPU run takes, which no box available here can make.
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("scaling,world", [("weak", 2), ("strong", 2), ("weak", 8)])
+def test_bench_under_torchrun_ranks_share_one_device(scaling, world):
+    import json
+    import subprocess
+    env = dict(os.environ, ROME_BENCH_SHARED_DEVICE="1", ROME_BENCH_WATCHDOG_S="600")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "5",
+           "--settle-launches", "50", "--scaling", scaling]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1100, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                       # ONE JSON line, printed by rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == scaling
+    assert d["config"]["ranks_seen_by_rccl"] == world
+    assert "NOT a measurement" in d["data"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and len(d["timed_blocks_ms_per_step"]) == 9
+    assert "host-staged" in d["config"]["parallelism"]
+    per_gpu = d["config"]["convolutions_per_step_per_gpu"]
+    if scaling == "weak":      # whole-job units: both ranks' segments (10 907 + the two cut-edge rows each)
+        assert per_gpu >= 10907
+        assert abs(d["value"] - world * per_gpu * 20 / (d["ms_per_step"] * 20 * 1e-3)) <= 1e-6 * d["value"]
+    else:                      # ONE graph: the rows are split between the ranks
+        assert 0 < per_gpu < 10907
