@@ -260,3 +260,38 @@ def test_bench_under_torchrun_ranks_share_one_device(scaling, world):
         assert abs(d["value"] - world * per_gpu * 20 / (d["ms_per_step"] * 20 * 1e-3)) <= 1e-6 * d["value"]
     else:                      # ONE graph: the rows are split between the ranks
         assert 0 < per_gpu < 10907
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# create_comms when the communicator set-up FAILS on a real RCCL: two ranks on one device is exactly a configuration RCCL rejects
+# ("duplicate GPU").  Every rank must come back with None -- agreed through the process group, nobody left waiting inside the
+# collective initialisation -- and stay usable for the torch.distributed fallback.
+def _comms_fail_worker(rank, world, port, ret):
+    os.environ["ROME_RCCL_INIT_TIMEOUT_S"] = "60"
+    torch, dist, R = _init(rank, world, port)
+    try:
+        import time
+        from rome_jl_amd import rccl
+        dev = torch.device("cuda", 0)
+        t0 = time.perf_counter()
+        comms = rccl.create_comms(torch, dist, world, rank, dev, 2)
+        dt = time.perf_counter() - t0
+        # the process group still works afterwards (the fallback path needs it)
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        ret[rank] = (comms is None, dt, float(t.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_create_comms_failure_is_agreed_across_ranks_real_rccl():
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_comms_fail_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        none, dt, s = ret[r]
+        assert none, "rank %d got communicators for two ranks on one device" % r
+        assert dt < 100.0
+        assert s == 3.0
