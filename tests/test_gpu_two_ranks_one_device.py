@@ -325,3 +325,116 @@ def test_row_sharded_linearisation_processes_real_kernels(world):
         assert set(ret[r]) == set(ref)
         for l in ref:
             assert np.array_equal(ret[r][l], np.asarray(ref[l])), (r, l)        # every rank, bit for bit
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] sharded: the honeycomb lattice with multihypo re-sightings, one segment per rank, cut through the lattice -- SIX
+# pose separators and FIVE landmark separators per rank, both bearing-range directions with hypothesis columns (the fused multihypo
+# sweep kernel where the table shape allows), ONE all-gather per step carrying Pose2 and Point2 blocks.
+_BH_POSES = (2, 5, 8, 11, 14, 17)
+_BH_LMS = 5
+
+
+def _beehive_segment(R, rank, N):
+    rng = np.random.default_rng(90 + rank)
+    fg = R.synth_beehive_mh(20, N=N)
+    lms = [l for l, t in fg.variables.items() if t is R.Point2]
+    leg = R.Pose2Pose2(R.MvNormal([10.0, 0.0, np.pi / 3], np.diag(np.square([0.1, 0.1, 0.1]))))
+    sight = lambda: R.Pose2Point2BearingRange(R.Normal(0.0, 0.03), R.Normal(20.0, 0.5))   # noqa: E731
+    for k, p in enumerate(_BH_POSES):
+        fg.addVariable("gp%d" % k, R.Pose2)
+        fg.addFactor(["gp%d" % k, "x%d" % p], leg)
+    for k in range(_BH_LMS):
+        fg.addVariable("gl%d" % k, R.Point2)
+        if k % 2 == 0:
+            fg.addFactor(["x%d" % (3 * k + 1), lms[k], "gl%d" % k], sight(), multihypo=[1.0, 0.5, 0.5])
+        else:
+            fg.addFactor(["x%d" % (3 * k + 1), "gl%d" % k], sight())
+    R.dead_reckon_init(fg, seed=7 + rank)
+    sim = fg._sim
+    for l, t in fg.variables.items():
+        if t is R.Point2:
+            c = np.asarray(sim[l]) if l in sim else np.array([5.0 * rank, 3.0])
+            fg.initVariable(l, c[:, None] + 0.5 * rng.standard_normal((2, N)))
+    return fg
+
+
+def _beehive_layout(R, pk, dg):
+    rows_p = []
+    for p in _BH_POSES:
+        f = int(np.nonzero((pk.p2p2["var_from"] == pk.index["x%d" % (p - 1)]) & (pk.p2p2["var_to"] == pk.index["x%d" % p]))[0][0])
+        rows_p.append(2 * f)
+    r0 = dg.family_table("br0")["rows4"].cpu().numpy()
+    lm_idx = [pk.index[l] for l in pk.labels[R.Point2][:_BH_LMS]]
+    rows_l = [int(np.nonzero(r0[:, 3] == li)[0][0]) for li in lm_idx]
+    return rows_p, rows_l
+
+
+def _beehive_worker(rank, world, port, ret, N, steps):
+    torch, dist, R = _init(rank, world, port)
+    try:
+        from rome_jl_amd.distributed import SeparatorPipeline
+        dev = torch.device("cuda", 0)
+        fg = _beehive_segment(R, rank, N)
+        ctx = R.Context(0)
+        dg = R.DeviceGraph(fg, device=dev, ctx=ctx); dg.upload_beliefs(fg)
+        pk = dg.packed
+        rows_p, rows_l = _beehive_layout(R, pk, dg)
+        comms = [HostStagedComm(torch, dist, world, ctx) for _ in range(2)]
+        pipe = SeparatorPipeline(dg, R.make_opts(N=N, seed=3, stream_offset=rank << 32), dist, world, rank,
+                                 publish=[("p2p2", r) for r in rows_p] + [("br0", r) for r in rows_l],
+                                 ghosts=[(R.Pose2, pk.index["gp%d" % k], rank - 1, k) for k in range(len(_BH_POSES))] +
+                                        [(R.Point2, pk.index["gl%d" % k], rank - 1, k) for k in range(_BH_LMS)], rccl_comms=comms)
+        hist = []
+        for k in range(steps):
+            pipe.step()
+            torch.cuda.synchronize()
+            hist.append({f: pipe.out[k % 2][f].cpu().numpy().copy() for f in pipe.families})
+        pipe.drain()
+        ret[rank] = hist
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_beehive_multihypo_lattice_cut_two_processes_real_kernels():
+    import torch
+    import torch.multiprocessing as mp
+    import rome_jl_amd as R
+    world, N, steps = 2, 100, 4
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_beehive_worker, args=(world, _free_port(), ret, N, steps), nprocs=world, join=True)
+    dev = torch.device("cuda", 0)
+    dgs = []
+    for r in range(world):
+        fg = _beehive_segment(R, r, N)
+        dg = R.DeviceGraph(fg, device=dev); dg.upload_beliefs(fg)
+        dgs.append(dg)
+    lay = [_beehive_layout(R, d.packed, d) for d in dgs]
+    assert any(d.family_table("br1")["alt"] is not None for d in dgs)
+    hist = [[] for _ in range(world)]
+    for k in range(steps):
+        for r, d in enumerate(dgs):
+            pk = d.packed
+            bel = {vt: d.bel[vt].clone() for vt in (R.Pose2, R.Point2)}
+            if k >= 2:   # step k reads what the previous rank published in step k - 2
+                src = (r - 1) % world
+                for s, row in enumerate(lay[src][0]):
+                    bel[R.Pose2][pk.index["gp%d" % s]] = torch.as_tensor(hist[src][k - 2]["p2p2"][row], device=dev)
+                for s, row in enumerate(lay[src][1]):
+                    bel[R.Point2][pk.index["gl%d" % s]] = torch.as_tensor(hist[src][k - 2]["br0"][row], device=dev)
+            outs = {}
+            for f in d.families():
+                tb = d.family_table(f)
+                out = torch.zeros((tb["n"], tb["vt_target"].dim, N), dtype=torch.float64, device=dev)
+                mh = {} if tb["alt"] is None else dict(alt_var=tb["alt"], hypo_w=tb["w"])
+                d._plan(tb["fn"], R.make_opts(N=N, seed=3, stream_offset=r << 32), n_conv=tb["n"], dir_all=tb["dir_all"], rows4=tb["rows4"],
+                        mu=tb["mu"], L=tb["L"], bel_fixed=bel[tb["vt_fixed"]], bel_target=bel[tb["vt_target"]], out=out, **mh)()
+                torch.cuda.synchronize()
+                outs[f] = out.cpu().numpy()
+            hist[r].append(outs)
+    for r in range(world):
+        for k in range(steps):
+            for f in ("p2p2", "br1", "br0"):
+                assert np.array_equal(ret[r][k][f], hist[r][k][f]), (r, k, f)
+    assert not np.array_equal(ret[0][2]["p2p2"], ret[0][0]["p2p2"]) and not np.array_equal(ret[1][2]["br1"], ret[1][0]["br1"])
