@@ -804,7 +804,11 @@ __device__ __forceinline__ void conv_wave_body(const ConvArgs& a, int blk) {
   for (int cyc = 0; cyc < ncyc; ++cyc) {
     double spread = 0.0;
     if (cyc_on && a.inflation > 0.0 && N > 1) {
+#ifdef ROME_EXPERIMENT_NO_SPREAD   // experiment build (scripts/br1_bounds.py): no cross-particle statistic at all -- the bound on what
+      const double sd = a.inv_n * (double)N * 0.02;   // packing rows / cheaper reductions could ever save (a run-time constant)
+#else
       const double sd = FP::template spread<PPL>(t, aux, act, a.inv_n, a.inv_nm1);
+#endif
       spread = a.inflation * (sd > 1e-10 ? sd : 1.0);   // IIF calcStdBasicSpread: "if no std yet, set to 1"
     }
 #pragma unroll
@@ -812,7 +816,12 @@ __device__ __forceinline__ void conv_wave_body(const ConvArgs& a, int blk) {
       if (act[k] && sel[k] && !nullh[k]) {
         if (spread > 0.0) {
           double u[FP::DT];
+#ifdef ROME_EXPERIMENT_NO_ENTROPY_RNG   // experiment build: the jitter without its Philox call (the bound on a cheaper generator)
+#pragma unroll
+          for (int d = 0; d < FP::DT; ++d) u[d] = 0.25 + 0.125 * (double)((lane + 3 * d + cyc) & 3);
+#else
           rng_entropy_exact<FP::DT>(a.seed, stream, (uint32_t)slot_particle<PPL>(lane, k), cyc, u);
+#endif
           FP::add_entropy(t[k], aux[k], spread, u);
         }
         st[k] = FP::template solve<SOLVER>(K, prep[k], z[k], fx[k], t[k], aux[k], a.max_iters, a.tol);
