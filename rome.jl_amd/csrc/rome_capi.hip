@@ -22,6 +22,11 @@ struct rome_ctx {
   static constexpr int kHostBufs = 4;   // 0 fixed, 1 target (+ alternative landmark blocks), 2 noise, 3 out
   void* hbuf[kHostBufs] = {nullptr};
   size_t hcap[kHostBufs] = {0};
+  // fork / join inside an up-solve step (plan_run): independent launches of a step -- the row families' convolutions + bandwidths, then
+  // the products of the variable types -- go to side streams and re-join `stream`; created on first use
+  static constexpr int kSide = 5;
+  hipStream_t side[kSide] = {nullptr};
+  hipEvent_t ev_fork = nullptr, ev_side[kSide] = {nullptr};
 };
 
 namespace {
@@ -56,6 +61,16 @@ int ensure(rome_ctx* c, int idx, size_t bytes, void** out) {
   }
   *out = c->dbuf[idx];
   c->ws_used = true;
+  return ROME_OK;
+}
+
+int ensure_side(rome_ctx* c) {
+  if (c->ev_fork) return ROME_OK;
+  for (int i = 0; i < rome_ctx::kSide; ++i) {
+    ROME_HIP(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+    ROME_HIP(c, hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
+  }
+  ROME_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   return ROME_OK;
 }
 
@@ -366,6 +381,11 @@ void rome_ctx_destroy(rome_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < rome_ctx::kBufs; ++i) if (c->dbuf[i]) (void)hipFree(c->dbuf[i]);
   for (int i = 0; i < rome_ctx::kHostBufs; ++i) if (c->hbuf[i]) (void)hipHostFree(c->hbuf[i]);
+  for (int i = 0; i < rome_ctx::kSide; ++i) {
+    if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); }
+    if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -813,7 +833,8 @@ struct rome_upsolve_plan {
   double* new_host[3] = {nullptr, nullptr, nullptr}; double* bw_host[3] = {nullptr, nullptr, nullptr};
   bool has_mirror = false, has_upstream = false;
   void* arena = nullptr; bool arena_owned = false;
-  size_t tree_need = 8;
+  size_t tree_need = 8;               // the tree workspaces of the three types side by side (their products may run concurrently)
+  size_t tree_off[3] = {0, 0, 0};
 };
 
 namespace {
@@ -957,8 +978,9 @@ int plan_build(rome_ctx* c, rome_store* st, const rome_opts* o, const rome_cliqu
       ROME_HIP(c, rome::launch_kde_bandwidth(kVdim[t], n_msg[t], N, (const double*)mb, kCircBw[t], 1e-2, 1e-6,
                                              P->d_pbw[t] + (size_t)msg_base[t] * kVdim[t], nullptr, s));
     }
-    const size_t b = rome::gibbs_workspace_bytes(kVdim[t], P->prop_rows_t[t], (int)nu, N);
-    if (b > P->tree_need) P->tree_need = b;
+    P->tree_off[t] = t == 0 ? 0 : P->tree_need;
+    if (t == 0) P->tree_need = 0;
+    P->tree_need += al256(rome::gibbs_workspace_bytes(kVdim[t], P->prop_rows_t[t], (int)nu, N)) + 256;
   }
   for (int k4 = 0; k4 < NF; ++k4) if ((rc = upload_fam(c, P->fam[k4], arena, &used, Ls[k4], P->fd[k4]))) return rc;
   if (used > need) return ROME_ERR_ALLOC;
@@ -984,24 +1006,53 @@ int plan_run(rome_upsolve_plan* P, const rome_opts* o, double* mirror_out, int64
     const int nsteps = P->n_up > 0 ? (int)P->step_k.size() - 1 : 0;
     for (int stp = 0; stp < nsteps; ++stp) {
       const int k0 = P->step_k[stp], k1 = P->step_k[stp + 1];
+      // A step is two phases of mutually independent launches: (A) per row family {convolutions -> manikde! bandwidths of those
+      // proposals} -- they read the store, write disjoint proposal rows --, then (B) per variable type {ball trees -> multiscale Gibbs
+      // product} -- each writes its own type's blocks in place.  All of (A) precedes all of (B): a product of one type overwrites beliefs
+      // that another family's convolution reads.  With more than one family / type in the step the launches of a phase go to side
+      // streams and re-join (a small clique or frontier pays the LATENCY of its launches: the landmark product need not wait for the
+      // pose product; 1.1 -> 0.6 ms per Gibbs iteration on the 36-pose honeycomb, profiles/r04_small_frontier.txt); a phase with a
+      // single launch chain (Manhattan: one family, one type) stays on the context's stream.
+      int fam_a[NF], lo_a[NF], hi_a[NF], naf = 0;
       for (int k4 = 0; k4 < NF; ++k4) {
         const Fam& f = P->fam[k4];
         const int lo = P->fam_lo[k4][k0], hi = f.n == 0 ? 0 : (k1 < P->n_up ? P->fam_lo[k4][k1] : f.n);
-        if (hi <= lo) continue;
-        double* out = P->d_prop[f.vt] + (size_t)(f.base + lo) * f.dt * N;
-        ROME_HIP(c, launch_fam(f, P->fd[k4], o, base, lo, hi, st->bel[f.vf], st->bel[f.vt], out, s));
-        ROME_HIP(c, rome::launch_kde_bandwidth(f.dt, hi - lo, N, out, kCircBw[f.vt], 1e-2, 1e-6, P->d_pbw[f.vt] + (size_t)(f.base + lo) * f.dt, nullptr, s));
+        if (hi > lo) { fam_a[naf] = k4; lo_a[naf] = lo; hi_a[naf] = hi; ++naf; }
       }
+      int typ_a[3], nat = 0;
       for (int t = 0; t < 3; ++t) {
         const int pa = P->up_cnt_before[3 * (size_t)k0 + t], pb = P->up_cnt_before[3 * (size_t)k1 + t];
-        if (pb <= pa || P->prop_rows_t[t] == 0) continue;
+        if (pb > pa && P->prop_rows_t[t] > 0) typ_a[nat++] = t;
+      }
+      const bool fork_a = naf > 1, fork_b = nat > 1;
+      if (fork_a || fork_b) { if ((rc = ensure_side(c))) return rc; }
+      if (fork_a) ROME_HIP(c, hipEventRecord(c->ev_fork, s));
+      for (int i = 0; i < naf; ++i) {
+        const int k4 = fam_a[i], lo = lo_a[i], hi = hi_a[i];
+        const Fam& f = P->fam[k4];
+        hipStream_t sx = fork_a ? c->side[i] : s;
+        if (fork_a) ROME_HIP(c, hipStreamWaitEvent(sx, c->ev_fork, 0));
+        double* out = P->d_prop[f.vt] + (size_t)(f.base + lo) * f.dt * N;
+        ROME_HIP(c, launch_fam(f, P->fd[k4], o, base, lo, hi, st->bel[f.vf], st->bel[f.vt], out, sx));
+        ROME_HIP(c, rome::launch_kde_bandwidth(f.dt, hi - lo, N, out, kCircBw[f.vt], 1e-2, 1e-6, P->d_pbw[f.vt] + (size_t)(f.base + lo) * f.dt, nullptr, sx));
+        if (fork_a) ROME_HIP(c, hipEventRecord(c->ev_side[i], sx));
+      }
+      if (fork_a) for (int i = 0; i < naf; ++i) ROME_HIP(c, hipStreamWaitEvent(s, c->ev_side[i], 0));
+      if (fork_b) ROME_HIP(c, hipEventRecord(c->ev_fork, s));
+      for (int i = 0; i < nat; ++i) {
+        const int t = typ_a[i];
+        const int pa = P->up_cnt_before[3 * (size_t)k0 + t], pb = P->up_cnt_before[3 * (size_t)k1 + t];
+        hipStream_t sx = fork_b ? c->side[i] : s;
+        if (fork_b) ROME_HIP(c, hipStreamWaitEvent(sx, c->ev_fork, 0));
         // the product writes the new beliefs IN PLACE into the store (a product reads only proposals and its own variable's block)
         rome::GibbsPlace place{P->d_upblock[t] + pa, P->has_upstream ? P->d_upstream[t] + pa : nullptr,
                                (P->has_mirror && mirror_out) ? P->d_upmirror[t] + pa : nullptr, mirror_out, mirror_stride};
         ROME_HIP(c, rome::launch_product_gibbs(kVdim[t], pb - pa, N, P->prop_rows_t[t], P->d_ptr[t] + pa, P->d_rws[t], P->d_prop[t], P->d_pbw[t],
-                                               st->bel[t], st->bel[t], trees, kCircProd[t], P->pi, P->max_k[t],
-                                               o->seed, base + kProdOff[t] + (P->has_upstream ? 0ull : (uint64_t)pa), s, &place));
+                                               st->bel[t], st->bel[t], (unsigned char*)trees + P->tree_off[t], kCircProd[t], P->pi, P->max_k[t],
+                                               o->seed, base + kProdOff[t] + (P->has_upstream ? 0ull : (uint64_t)pa), sx, &place));
+        if (fork_b) ROME_HIP(c, hipEventRecord(c->ev_side[i], sx));
       }
+      if (fork_b) for (int i = 0; i < nat; ++i) ROME_HIP(c, hipStreamWaitEvent(s, c->ev_side[i], 0));
     }
   }
   if (P->has_mirror && P->gi > 0) {
@@ -1011,7 +1062,7 @@ int plan_run(rome_upsolve_plan* P, const rome_opts* o, double* mirror_out, int64
       if (P->n_upt[t] && P->prop_rows_t[t] == 0) {
         rome::GibbsPlace place{P->d_upblock[t], nullptr, P->d_upmirror[t], mirror_out, mirror_stride};
         ROME_HIP(c, rome::launch_product_gibbs(kVdim[t], P->n_upt[t], N, 0, P->d_ptr[t], P->d_rws[t], P->d_prop[t], P->d_pbw[t], st->bel[t], st->bel[t],
-                                               trees, kCircProd[t], 1, 1, o->seed, 0, s, &place));
+                                               (unsigned char*)trees + P->tree_off[t], kCircProd[t], 1, 1, o->seed, 0, s, &place));
       }
   }
   // ---- results (only when the plan was created with host outputs): the updated beliefs and their manikde! bandwidths

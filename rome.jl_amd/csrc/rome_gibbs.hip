@@ -769,9 +769,17 @@ static hipError_t launch_product_gibbs_nm(GibbsArgs& a, int dim, int V, int N, i
   // LDS of a block: kGibbsResident level images (variables with more proposals stream theirs through slot 0) + constants and labels
   // for the variable with the most proposals
   constexpr int kGibbsResident = 4;
-  a.k_lds = max_k < kGibbsResident ? max_k : kGibbsResident;
   const size_t img = dim == 2 ? sizeof(GibbsLevel<2, NM>) : (dim == 3 ? sizeof(GibbsLevel<3, NM>) : sizeof(GibbsLevel<6, NM>));
   const size_t per = (dim == 2 ? sizeof(GibbsConst<2>) : (dim == 3 ? sizeof(GibbsConst<3>) : sizeof(GibbsConst<6>))) + NM;
+  a.k_lds = max_k < kGibbsResident ? max_k : kGibbsResident;
+  // A launch that cannot fill the chip anyway (a clique, a small frontier: at most two blocks per CU) has no occupancy to protect: every
+  // level image resident, as far as 64 kB of LDS go -- the streaming path re-stages an image before every categorical draw, and a
+  // block's latency is all such a launch pays (same draws either way: the images hold the same numbers).
+  if (V <= 512 && max_k > kGibbsResident) {
+    const size_t room = 64 * 1024 - per * (size_t)max_k;
+    const int fit = (int)(room / img);
+    a.k_lds = max_k < fit ? max_k : (fit > kGibbsResident ? fit : kGibbsResident);
+  }
   const size_t bytes = img * (size_t)a.k_lds + per * (size_t)max_k;
   if (bytes > 150 * 1024) return hipErrorInvalidValue;
   auto launch = [&](auto kernel) -> hipError_t {
