@@ -346,7 +346,10 @@ int  rome_store_ptr(rome_store*, int32_t type, void** dev, int32_t* n_blocks);
  * run.  opts at creation fix n_particles and the host layout of new_* / msg_*; opts at run time give solver, seed, stream_offset,
  * inflation etc. (n_particles must match).
  * rome_upsolve_plan_run(plan, opts, mirror_out, mirror_stride): mirror_out = DEVICE buffer the up_mirror blocks are written to, block
- * m at mirror_out + m * mirror_stride doubles (stride >= dim * N; 0 = 6 N); NULL when the plan has no mirrors. */
+ * m at mirror_out + m * mirror_stride doubles (stride >= dim * N; 0 = 6 N); NULL when the plan has no mirrors.
+ * Stream semantics: everything a run issues is ordered after the work already queued on the context's stream, and work queued there
+ * afterwards is ordered after the run -- inside a run, independent launch chains of a step (per row family: convolutions -> bandwidths;
+ * per variable type: ball trees -> product) go to context-owned side streams that fork from and re-join the context's stream. */
 typedef struct rome_upsolve_plan rome_upsolve_plan;
 int  rome_upsolve_plan_create(rome_ctx*, rome_store*, const rome_opts*, const rome_clique_upsolve_host*, rome_upsolve_plan** out);
 int  rome_upsolve_plan_run(rome_upsolve_plan*, const rome_opts*, double* mirror_out, int64_t mirror_stride);
