@@ -1024,7 +1024,8 @@ int plan_run(rome_upsolve_plan* P, const rome_opts* o, double* mirror_out, int64
         const int pa = P->up_cnt_before[3 * (size_t)k0 + t], pb = P->up_cnt_before[3 * (size_t)k1 + t];
         if (pb > pa && P->prop_rows_t[t] > 0) typ_a[nat++] = t;
       }
-      const bool fork_a = naf > 1, fork_b = nat > 1;
+      static const bool no_fork = std::getenv("ROME_UPSOLVE_NO_FORK") != nullptr;   // (A/B measurements: everything on the one stream)
+      const bool fork_a = naf > 1 && !no_fork, fork_b = nat > 1 && !no_fork;
       if (fork_a || fork_b) { if ((rc = ensure_side(c))) return rc; }
       if (fork_a) ROME_HIP(c, hipEventRecord(c->ev_fork, s));
       for (int i = 0; i < naf; ++i) {
