@@ -411,6 +411,32 @@ __device__ __forceinline__ void ratio_group(const f32x2* s, const f32x2* v, f32x
   *pv = den;
 }
 
+// Candidate scan with the statistics of the NEXT pair of candidates loaded while the current pair is evaluated: the LDS broadcasts of
+// pair z + 2 are in flight during the ~80 dependent instructions of pair z (left to itself the compiler issues a pair's loads at the head
+// of its own iteration and waits for them three instructions later).  Two register sets in ping-pong (no copies); the candidates are
+// visited in the same order, so every draw is the one the plain loop makes.
+#ifndef ROME_GIBBS_PREFETCH
+#define ROME_GIBBS_PREFETCH 1   // 0: the plain loops (A/B on one box, scripts/gibbs_time.py: 2.545 -> 2.512 ms per bandwidth + tree + product pass,
+#endif                          // i.e. -33 us = 2.8 % of the product kernel; asking for five waves per SIMD (94 VGPRs) on top: no gain)
+template <class S, bool PREFETCH, class Load, class Body>
+__device__ __forceinline__ void scan_pairs(int n, Load&& load, Body&& body) {
+  if constexpr (!PREFETCH) {   // (Pose3: six coordinates -- the second register set would cost an occupancy step, 162 -> 170 VGPRs)
+    for (int z = 0; z < n; z += 2) { S a; load(z, a); body(z, a); }
+    return;
+  }
+  S a, b;
+  load(0, a);
+  for (int z = 0; z < n; z += 4) {
+    load(z + 2 < n ? z + 2 : z, b);
+    body(z, a);
+    if (z + 2 >= n) break;
+    load(z + 4 < n ? z + 4 : z + 2, a);
+    body(z + 2, b);
+  }
+}
+template <int D> struct PairIn { f32x2 m[D], v[D], c; };   // an inner level: means, (inverse) variances, log-weight constant of nodes z, z + 1
+template <int D> struct PairLeaf { f32x2 y[D]; };           // the leaf level: the sorted single points p, p + 1
+
 // LDS image of ONE level of one tree: what the candidate loops of that level read (wave-uniform -> LDS broadcasts, two nodes a read)
 template <int D, int NM>
 struct GibbsLevel {
@@ -609,30 +635,41 @@ __global__ void __launch_bounds__(NM) k_product_gibbs(const GibbsArgs a) {
 #pragma unroll
         for (int d = 0; d < D; ++d) e0[d] = (float)e0d[d];
       }
-      if (l < L) {
-        for (int z = 0; z < nz; z += 2) {   // wave-uniform candidates: node statistics are LDS broadcasts
-          f32x2 q = splat(0.0f);
+      if (l < L) {   // wave-uniform candidates: node statistics are LDS broadcasts
+        scan_pairs<PairIn<D>, (D <= 3 && ROME_GIBBS_PREFETCH)>(nz,
+          [&](int z, PairIn<D>& P) {
 #pragma unroll
-          for (int d = 0; d < D; ++d) {
-            f32x2 e = splat(e0[d]) - *reinterpret_cast<const f32x2*>(&G.in.mean[d][z]);
-            if (circ_bit(d)) e = wrap32(e);
-            q = __builtin_elementwise_fma(e * e, *reinterpret_cast<const f32x2*>(&G.in.ivar[d][z]), q);
-          }
-          R.add2(z, z + 1, __builtin_elementwise_fma(splat(-0.5f), q, *reinterpret_cast<const f32x2*>(&G.in.cz[z])));
-        }
+            for (int d = 0; d < D; ++d) { P.m[d] = *reinterpret_cast<const f32x2*>(&G.in.mean[d][z]); P.v[d] = *reinterpret_cast<const f32x2*>(&G.in.ivar[d][z]); }
+            P.c = *reinterpret_cast<const f32x2*>(&G.in.cz[z]);
+          },
+          [&](int z, const PairIn<D>& P) {
+            f32x2 q = splat(0.0f);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              f32x2 e = splat(e0[d]) - P.m[d];
+              if (circ_bit(d)) e = wrap32(e);
+              q = __builtin_elementwise_fma(e * e, P.v[d], q);
+            }
+            R.add2(z, z + 1, __builtin_elementwise_fma(splat(-0.5f), q, P.c));
+          });
       } else {   // single points: every candidate has the kernel's variance and the weight 1/N: constants of the draw drop out
-        for (int p = 0; p < N; p += 2) {
-          f32x2 q = splat(0.0f);
+        scan_pairs<PairLeaf<D>, (D <= 3 && ROME_GIBBS_PREFETCH)>(N,
+          [&](int p, PairLeaf<D>& P) {
 #pragma unroll
-          for (int d = 0; d < D; ++d) {
-            f32x2 e = splat(e0[d]) - *reinterpret_cast<const f32x2*>(&G.ys[d][p]);
-            if (circ_bit(d)) e = wrap32(e);
-            q = __builtin_elementwise_fma(e * e, splat(c.livar[d]), q);
-          }
-          f32x2 lp = q * -0.5f;
-          if (p + 1 >= N) lp.y = kAbsent;
-          R.add2(p, p + 1, lp);
-        }
+            for (int d = 0; d < D; ++d) P.y[d] = *reinterpret_cast<const f32x2*>(&G.ys[d][p]);
+          },
+          [&](int p, const PairLeaf<D>& P) {
+            f32x2 q = splat(0.0f);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              f32x2 e = splat(e0[d]) - P.y[d];
+              if (circ_bit(d)) e = wrap32(e);
+              q = __builtin_elementwise_fma(e * e, splat(c.livar[d]), q);
+            }
+            f32x2 lp = q * -0.5f;
+            if (p + 1 >= N) lp.y = kAbsent;
+            R.add2(p, p + 1, lp);
+          });
       }
       selbuf[j * NM + tid] = (uint8_t)R.sel;
     }
@@ -685,38 +722,49 @@ __global__ void __launch_bounds__(NM) k_product_gibbs(const GibbsArgs a) {
         const GibbsLevel<D, NM>& G = image(l, j);
         Reservoir R; R.init(uniform_word());
         if (l < L) {
-          for (int z = 0; z < nz; z += 2) {
-            f32x2 sq[D], vv[D];
+          scan_pairs<PairIn<D>, (D <= 3 && ROME_GIBBS_PREFETCH)>(nz,
+            [&](int z, PairIn<D>& P) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-              f32x2 e = *reinterpret_cast<const f32x2*>(&G.in.mean[d][z]) - splat(mx[d]);
-              if (circ_bit(d)) e = wrap32(e);
-              sq[d] = e * e;
-              vv[d] = *reinterpret_cast<const f32x2*>(&G.in.var[d][z]) + splat(cx[d]);
-            }
-            // Σ_d e_d² / v_d + Σ_d log v_d with one division and one logarithm per group of <= 3 coordinates
-            f32x2 q, pv;
-            ratio_group<(D == 2 ? 2 : 3)>(sq, vv, &q, &pv);
-            f32x2 t = q + ln32_pos(pv);
-            if constexpr (D == 6) { ratio_group<3>(sq + 3, vv + 3, &q, &pv); t = t + (q + ln32_pos(pv)); }
-            R.add2(z, z + 1, __builtin_elementwise_fma(splat(-0.5f), t, *reinterpret_cast<const f32x2*>(&G.in.lnc[z])));
-          }
+              for (int d = 0; d < D; ++d) { P.m[d] = *reinterpret_cast<const f32x2*>(&G.in.mean[d][z]); P.v[d] = *reinterpret_cast<const f32x2*>(&G.in.var[d][z]); }
+              P.c = *reinterpret_cast<const f32x2*>(&G.in.lnc[z]);
+            },
+            [&](int z, const PairIn<D>& P) {
+              f32x2 sq[D], vv[D];
+#pragma unroll
+              for (int d = 0; d < D; ++d) {
+                f32x2 e = P.m[d] - splat(mx[d]);
+                if (circ_bit(d)) e = wrap32(e);
+                sq[d] = e * e;
+                vv[d] = P.v[d] + splat(cx[d]);
+              }
+              // Σ_d e_d² / v_d + Σ_d log v_d with one division and one logarithm per group of <= 3 coordinates
+              f32x2 q, pv;
+              ratio_group<(D == 2 ? 2 : 3)>(sq, vv, &q, &pv);
+              f32x2 t = q + ln32_pos(pv);
+              if constexpr (D == 6) { ratio_group<3>(sq + 3, vv + 3, &q, &pv); t = t + (q + ln32_pos(pv)); }
+              R.add2(z, z + 1, __builtin_elementwise_fma(splat(-0.5f), t, P.c));
+            });
         } else {   // single points: every candidate has the variance h² + C and the weight 1/N
           float ivv[D];
 #pragma unroll
           for (int d = 0; d < D; ++d) ivv[d] = 1.0f / (c.lvar[d] + cx[d]);
-          for (int p = 0; p < N; p += 2) {
-            f32x2 q = splat(0.0f);
+          scan_pairs<PairLeaf<D>, (D <= 3 && ROME_GIBBS_PREFETCH)>(N,
+            [&](int p, PairLeaf<D>& P) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-              f32x2 e = *reinterpret_cast<const f32x2*>(&G.ys[d][p]) - splat(mx[d]);
-              if (circ_bit(d)) e = wrap32(e);
-              q = __builtin_elementwise_fma(e * e, splat(ivv[d]), q);
-            }
-            f32x2 lp = q * -0.5f;
-            if (p + 1 >= N) lp.y = kAbsent;
-            R.add2(p, p + 1, lp);
-          }
+              for (int d = 0; d < D; ++d) P.y[d] = *reinterpret_cast<const f32x2*>(&G.ys[d][p]);
+            },
+            [&](int p, const PairLeaf<D>& P) {
+              f32x2 q = splat(0.0f);
+#pragma unroll
+              for (int d = 0; d < D; ++d) {
+                f32x2 e = P.y[d] - splat(mx[d]);
+                if (circ_bit(d)) e = wrap32(e);
+                q = __builtin_elementwise_fma(e * e, splat(ivv[d]), q);
+              }
+              f32x2 lp = q * -0.5f;
+              if (p + 1 >= N) lp.y = kAbsent;
+              R.add2(p, p + 1, lp);
+            });
         }
         selbuf[j * NM + tid] = (uint8_t)R.sel;
       }
