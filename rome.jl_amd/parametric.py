@@ -104,7 +104,7 @@ def _pose2_two_stage_init(fg, x):
     labels = list(fg.variables); idx = {l: k for k, l in enumerate(labels)}
     n, F = len(labels), len(rel)
     i = np.array([idx[ls[0]] for ls, _ in rel]); j = np.array([idx[ls[1]] for ls, _ in rel])
-    mu = np.array([f.Z.mu for _, f in rel]); info = np.array([np.linalg.inv(f.Z.cov) for _, f in rel])
+    mu = np.array([f.Z.mu for _, f in rel]); info = np.linalg.inv(np.array([f.Z.cov for _, f in rel]))   # (one batched call)
     th0 = np.array([x[l][2] for l in labels])
     # ---- headings: θ_j − θ_i = z_θ + 2π k_ij
     k = np.round((th0[j] - th0[i] - mu[:, 2]) / (2 * np.pi))
