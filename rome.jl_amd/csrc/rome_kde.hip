@@ -413,6 +413,7 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
   if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = U(bx + Cg * (cx - bx)); }
   else { x2 = bx; x1 = U(bx - Cg * (bx - ax)); }
   const bool finish = tol < 1e-2;          // finer than the golden section is run in single precision: finish on the derivative
+  const bool nowrap = CIRC && (yhi - ylo) < 3.0;
   const double tol_gs = finish ? 1e-2 : tol;
   // ONE evaluation site (the unrolled B x B body is a few kB of code per instantiation): a small state machine asks for the next h.
   //   phase 0 / 1: the two interior points; 2: golden section (`upper`: the request replaces x2, else x1); 3: secant on g
@@ -423,8 +424,13 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
   double hq = x1;
   for (;;) {
     double fv, gv;
-    if (finish) lcv_eval_blk<CIRC, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
-    else lcv_eval_blk<CIRC, false, B>(pl, xs, M, N, lane, hq, &fv, &gv);
+    if (finish) {
+      // a circular coordinate whose particles all lie within 3 rad of each other: every staged difference has |d| < π, its wrap is
+      // the identity (rint(d / 2π) = 0, fma(-2π, 0, d) = d exactly) -- the Euclidean body evaluates the same bits with 3 of 12
+      // instructions per pair less (wave-uniform choice; headings of pose beliefs are almost always that concentrated)
+      if (CIRC && nowrap) lcv_eval_blk<false, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
+      else lcv_eval_blk<CIRC, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
+    } else lcv_eval_blk<CIRC, false, B>(pl, xs, M, N, lane, hq, &fv, &gv);
     ++ne;
     if (phase == 0) { f1 = fv; g1 = gv; hq = x2; phase = 1; continue; }
     if (phase == 1) { f2 = fv; g2 = gv; phase = 2; }
