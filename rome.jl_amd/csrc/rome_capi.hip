@@ -66,9 +66,9 @@ int ensure(rome_ctx* c, int idx, size_t bytes, void** out) {
 
 int ensure_side(rome_ctx* c) {
   if (c->ev_fork) return ROME_OK;
-  for (int i = 0; i < rome_ctx::kSide; ++i) {
-    ROME_HIP(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-    ROME_HIP(c, hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
+  for (int i = 0; i < rome_ctx::kSide; ++i) {   // (a failure half way leaves what exists for the next attempt and for rome_ctx_destroy)
+    if (!c->side[i]) ROME_HIP(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+    if (!c->ev_side[i]) ROME_HIP(c, hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
   }
   ROME_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   return ROME_OK;
