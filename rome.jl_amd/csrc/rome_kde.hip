@@ -243,7 +243,7 @@ __device__ __forceinline__ void lcv_cells_init(float* __restrict__ M, int N, int
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 #endif
 }
-template <bool WITH_T, int B>
+template <bool WITH_T, int B, bool FOLD64 = WITH_T>
 __device__ __forceinline__ void lcv_tail(const BlkPlan<B>& pl, const float (&r)[B], const float (&c)[B], const float (&tr)[B], const float (&tc)[B],
                                          float* __restrict__ M, int N, int lane, double h, double tscale, double* negll, double* g) {
   const int nb = pl.nb;
@@ -271,7 +271,7 @@ __device__ __forceinline__ void lcv_tail(const BlkPlan<B>& pl, const float (&r)[
       v0[4 * q] = a.x; v0[4 * q + 1] = a.y; v0[4 * q + 2] = a.z; v0[4 * q + 3] = a.w;
       v1[4 * q] = b.x; v1[4 * q + 1] = b.y; v1[4 * q + 2] = b.z; v1[4 * q + 3] = b.w;
     }
-    if (WITH_T) {   // the derivative finish resolves 1e-6: the <= 10 partials of a row are folded in double (as the ring scheme did)
+    if (FOLD64) {   // the derivative finish resolves 1e-6: the <= 10 partials of a row are folded in double (as the ring scheme did)
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int k = 0; k < 10; ++k) { s0 += (double)v0[k]; s1 += (double)v1[k]; }
@@ -300,7 +300,7 @@ __device__ __forceinline__ void lcv_tail(const BlkPlan<B>& pl, const float (&r)[
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    if (WITH_T) {
+    if (FOLD64) {
       double s0 = 0.0, s1 = 0.0;
       for (int k = 0; k < nb; ++k) { s0 += (double)row0[k * B]; s1 += (double)row1[k * B]; }
       *o0 = s0; *o1 = s1;
@@ -329,7 +329,7 @@ __device__ __forceinline__ void lcv_tail(const BlkPlan<B>& pl, const float (&r)[
   *negll = uniform_f64(-(ll - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528)));
 }
 
-template <bool CIRC, bool WITH_T, int B>
+template <bool CIRC, bool WITH_T, int B, bool FOLD64 = WITH_T>
 __device__ __forceinline__ void lcv_eval_blk(const BlkPlan<B>& pl, const float* __restrict__ xs, float* __restrict__ M, int N, int lane,
                                              double h, double* negll, double* g) {
   const float hf = (float)h;
@@ -363,7 +363,7 @@ __device__ __forceinline__ void lcv_eval_blk(const BlkPlan<B>& pl, const float* 
       asm volatile("" : "+v"(xi[ii + 1]));
     }
   }
-  if constexpr (!WITH_T) { lcv_tail<false, B>(pl, r, c, r, c, M, N, lane, h, 1.0, negll, g); }
+  if constexpr (!WITH_T) { lcv_tail<false, B, FOLD64>(pl, r, c, r, c, M, N, lane, h, 1.0, negll, g); }
   else { lcv_tail<true, B>(pl, r, c, tr, tc, M, N, lane, h, 1.0, negll, g); }
 }
 
@@ -428,8 +428,13 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
       // a circular coordinate whose particles all lie within 3 rad of each other: every staged difference has |d| < π, its wrap is
       // the identity (rint(d / 2π) = 0, fma(-2π, 0, d) = d exactly) -- the Euclidean body evaluates the same bits with 3 of 12
       // instructions per pair less (wave-uniform choice; headings of pose beliefs are almost always that concentrated)
-      if (CIRC && nowrap) lcv_eval_blk<false, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
-      else lcv_eval_blk<CIRC, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
+      // ... and its golden section needs likelihood VALUES only: the derivative sums T_i (3 of 9 instructions per pair, a second
+      // exchange, two reciprocals and a wave sum per evaluation) are left out of those ~17 evaluations -- same row sums, same double
+      // fold, same f bits -- and g is evaluated at the two interior points the secant starts from (phases 4, 5: two evaluations more)
+      if (CIRC && nowrap) {
+        if (phase <= 2) lcv_eval_blk<false, false, B, true>(pl, xs, M, N, lane, hq, &fv, &gv);
+        else lcv_eval_blk<false, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
+      } else lcv_eval_blk<CIRC, true, B>(pl, xs, M, N, lane, hq, &fv, &gv);
     } else lcv_eval_blk<CIRC, false, B>(pl, xs, M, N, lane, hq, &fv, &gv);
     ++ne;
     if (phase == 0) { f1 = fv; g1 = gv; hq = x2; phase = 1; continue; }
@@ -458,6 +463,11 @@ __device__ __forceinline__ double lcv_golden_fast(const double (&x)[2], const bo
 #endif
         break;
       }
+      if (CIRC && nowrap) { hq = x1; phase = 4; continue; }   // (the derivative at x1, then at x2)
+    }
+    if (phase == 4) { g1 = gv; hq = x2; phase = 5; continue; }
+    if (phase == 2 || phase == 5) {
+      if (phase == 5) g2 = gv;
       // secant steps on g from the two interior points; the iterate may leave the last bracket by its width (a near-tie decision
       // of the single-precision golden section), never further (flat or noisy g: keep the golden-section answer)
       const double wdt = x3 - x0;
