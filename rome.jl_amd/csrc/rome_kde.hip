@@ -323,10 +323,13 @@ __device__ __forceinline__ void lcv_tail(const BlkPlan<B>& pl, const float (&r)[
   double gg = 0.0;
   if (WITH_T) gg = tscale * ((act0 ? T0 * rcp_pos_f64(s0) : 0.0) + (act1 ? T1 * rcp_pos_f64(s1) : 0.0));
   wave_prod_frexp(&mant, &expo);
-  const double ll = uniform_f64(fast_log(mant) + (double)expo * 0.693147180559945309417);
+  // the evaluation's two logarithms -- of the mantissa product and of (N-1) h sqrt(2π), both wave-uniform -- in ONE pass of the
+  // logarithm kernel: even lanes take the first argument, odd lanes the second (the same function of the same argument: same bits)
+  const double lg = fast_log((lane & 1) ? (double)(N - 1) * h * 2.50662827463100050241576528 : mant);
+  const double ll = readlane_f64(lg, 0) + (double)expo * 0.693147180559945309417;
   if (WITH_T) *g = uniform_f64(wave_sum(gg) - (double)N * h * h); else *g = 0.0;
   // (wave-uniform by construction; saying so lets the search state live in scalar registers across the unrolled block body)
-  *negll = uniform_f64(-(ll - (double)N * fast_log((double)(N - 1) * h * 2.50662827463100050241576528)));
+  *negll = uniform_f64(-(ll - (double)N * readlane_f64(lg, 1)));
 }
 
 template <bool CIRC, bool WITH_T, int B, bool FOLD64 = WITH_T>
