@@ -26,7 +26,7 @@ struct rome_ctx {
   // the products of the variable types -- go to side streams and re-join `stream`; created on first use
   static constexpr int kSide = 5;
   hipStream_t side[kSide] = {nullptr};
-  hipEvent_t ev_fork = nullptr, ev_side[kSide] = {nullptr};
+  hipEvent_t ev_fork = nullptr, ev_side[kSide] = {nullptr}, ev_side2[kSide] = {nullptr};   // two event sets: the phases alternate
 };
 
 namespace {
@@ -69,6 +69,7 @@ int ensure_side(rome_ctx* c) {
   for (int i = 0; i < rome_ctx::kSide; ++i) {   // (a failure half way leaves what exists for the next attempt and for rome_ctx_destroy)
     if (!c->side[i]) ROME_HIP(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
     if (!c->ev_side[i]) ROME_HIP(c, hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
+    if (!c->ev_side2[i]) ROME_HIP(c, hipEventCreateWithFlags(&c->ev_side2[i], hipEventDisableTiming));
   }
   ROME_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   return ROME_OK;
@@ -384,6 +385,7 @@ void rome_ctx_destroy(rome_ctx* c) {
   for (int i = 0; i < rome_ctx::kSide; ++i) {
     if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); }
     if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
+    if (c->ev_side2[i]) (void)hipEventDestroy(c->ev_side2[i]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1001,18 +1003,43 @@ int plan_run(rome_upsolve_plan* P, const rome_opts* o, double* mirror_out, int64
   void* trees = nullptr;
   if ((rc = ensure(c, 10, P->tree_need, &trees))) return rc;
   hipStream_t s = c->stream;
+  // A step is two phases of mutually independent launch chains: (A) per row family {convolutions -> manikde! bandwidths of those
+  // proposals} -- they read the store, write disjoint proposal rows --, then (B) per variable type {ball trees -> multiscale Gibbs
+  // product} -- each writes its own type's blocks in place.  All of (A) precedes all of (B), and all of (B) the next step's (A): a
+  // product of one type overwrites beliefs that another family's convolution reads.  A phase with more than one chain runs its
+  // chains on side streams of the context (a small clique or frontier pays the LATENCY of its launches: the landmark product need
+  // not wait for the pose product; 1.1 -> 0.6 ms per Gibbs iteration on the 36-pose honeycomb, profiles/r04_small_frontier.txt),
+  // and consecutive phases are chained DIRECTLY by events -- every chain of a phase waits for the events of the previous phase's
+  // chains, one cross-stream hop, not a join into the context's stream followed by a fork out of it (each hop is 20-40 us of queue
+  // latency on this stack); the context's stream is joined once at the end.  A phase with a single chain after work that is
+  // already on the context's stream stays there: a Manhattan frontier (one family, one type) never leaves the one stream.
+  static const bool no_fork = std::getenv("ROME_UPSOLVE_NO_FORK") != nullptr;   // (A/B measurements: everything on the one stream)
+  hipEvent_t* ev_cur = c->ev_side;      // events of the phase whose completion the next phase waits for (when !on_main)
+  hipEvent_t* ev_nxt = c->ev_side2;
+  int n_cur = 0;
+  bool on_main = true;                  // everything issued so far is ordered on the context's stream itself
+  auto phase = [&](int n_chain, auto&& launch_chain) -> int {
+    if (n_chain == 0) return ROME_OK;
+    const bool side = n_chain > 1 && !no_fork;
+    int rc2;
+    if (side || !on_main) { if ((rc2 = ensure_side(c))) return rc2; }
+    if (side && on_main) ROME_HIP(c, hipEventRecord(c->ev_fork, s));
+    for (int i = 0; i < n_chain; ++i) {
+      hipStream_t sx = side ? c->side[i] : s;
+      if (on_main) { if (side) ROME_HIP(c, hipStreamWaitEvent(sx, c->ev_fork, 0)); }
+      else for (int e = 0; e < n_cur; ++e) ROME_HIP(c, hipStreamWaitEvent(sx, ev_cur[e], 0));
+      if ((rc2 = launch_chain(i, sx))) return rc2;
+      if (side) ROME_HIP(c, hipEventRecord(ev_nxt[i], sx));
+    }
+    if (side) { hipEvent_t* t_ = ev_cur; ev_cur = ev_nxt; ev_nxt = t_; n_cur = n_chain; on_main = false; }
+    else on_main = true;
+    return ROME_OK;
+  };
   for (int it = 0; it < P->gi; ++it) {
     const uint64_t base = o->stream_offset + ((uint64_t)it << 32);
     const int nsteps = P->n_up > 0 ? (int)P->step_k.size() - 1 : 0;
     for (int stp = 0; stp < nsteps; ++stp) {
       const int k0 = P->step_k[stp], k1 = P->step_k[stp + 1];
-      // A step is two phases of mutually independent launches: (A) per row family {convolutions -> manikde! bandwidths of those
-      // proposals} -- they read the store, write disjoint proposal rows --, then (B) per variable type {ball trees -> multiscale Gibbs
-      // product} -- each writes its own type's blocks in place.  All of (A) precedes all of (B): a product of one type overwrites beliefs
-      // that another family's convolution reads.  With more than one family / type in the step the launches of a phase go to side
-      // streams and re-join (a small clique or frontier pays the LATENCY of its launches: the landmark product need not wait for the
-      // pose product; 1.1 -> 0.6 ms per Gibbs iteration on the 36-pose honeycomb, profiles/r04_small_frontier.txt); a phase with a
-      // single launch chain (Manhattan: one family, one type) stays on the context's stream.
       int fam_a[NF], lo_a[NF], hi_a[NF], naf = 0;
       for (int k4 = 0; k4 < NF; ++k4) {
         const Fam& f = P->fam[k4];
@@ -1024,37 +1051,32 @@ int plan_run(rome_upsolve_plan* P, const rome_opts* o, double* mirror_out, int64
         const int pa = P->up_cnt_before[3 * (size_t)k0 + t], pb = P->up_cnt_before[3 * (size_t)k1 + t];
         if (pb > pa && P->prop_rows_t[t] > 0) typ_a[nat++] = t;
       }
-      static const bool no_fork = std::getenv("ROME_UPSOLVE_NO_FORK") != nullptr;   // (A/B measurements: everything on the one stream)
-      const bool fork_a = naf > 1 && !no_fork, fork_b = nat > 1 && !no_fork;
-      if (fork_a || fork_b) { if ((rc = ensure_side(c))) return rc; }
-      if (fork_a) ROME_HIP(c, hipEventRecord(c->ev_fork, s));
-      for (int i = 0; i < naf; ++i) {
+      rc = phase(naf, [&](int i, hipStream_t sx) -> int {
         const int k4 = fam_a[i], lo = lo_a[i], hi = hi_a[i];
         const Fam& f = P->fam[k4];
-        hipStream_t sx = fork_a ? c->side[i] : s;
-        if (fork_a) ROME_HIP(c, hipStreamWaitEvent(sx, c->ev_fork, 0));
         double* out = P->d_prop[f.vt] + (size_t)(f.base + lo) * f.dt * N;
         ROME_HIP(c, launch_fam(f, P->fd[k4], o, base, lo, hi, st->bel[f.vf], st->bel[f.vt], out, sx));
         ROME_HIP(c, rome::launch_kde_bandwidth(f.dt, hi - lo, N, out, kCircBw[f.vt], 1e-2, 1e-6, P->d_pbw[f.vt] + (size_t)(f.base + lo) * f.dt, nullptr, sx));
-        if (fork_a) ROME_HIP(c, hipEventRecord(c->ev_side[i], sx));
-      }
-      if (fork_a) for (int i = 0; i < naf; ++i) ROME_HIP(c, hipStreamWaitEvent(s, c->ev_side[i], 0));
-      if (fork_b) ROME_HIP(c, hipEventRecord(c->ev_fork, s));
-      for (int i = 0; i < nat; ++i) {
+        return ROME_OK;
+      });
+      if (rc) return rc;
+      rc = phase(nat, [&](int i, hipStream_t sx) -> int {
         const int t = typ_a[i];
         const int pa = P->up_cnt_before[3 * (size_t)k0 + t], pb = P->up_cnt_before[3 * (size_t)k1 + t];
-        hipStream_t sx = fork_b ? c->side[i] : s;
-        if (fork_b) ROME_HIP(c, hipStreamWaitEvent(sx, c->ev_fork, 0));
         // the product writes the new beliefs IN PLACE into the store (a product reads only proposals and its own variable's block)
         rome::GibbsPlace place{P->d_upblock[t] + pa, P->has_upstream ? P->d_upstream[t] + pa : nullptr,
                                (P->has_mirror && mirror_out) ? P->d_upmirror[t] + pa : nullptr, mirror_out, mirror_stride};
         ROME_HIP(c, rome::launch_product_gibbs(kVdim[t], pb - pa, N, P->prop_rows_t[t], P->d_ptr[t] + pa, P->d_rws[t], P->d_prop[t], P->d_pbw[t],
                                                st->bel[t], st->bel[t], (unsigned char*)trees + P->tree_off[t], kCircProd[t], P->pi, P->max_k[t],
                                                o->seed, base + kProdOff[t] + (P->has_upstream ? 0ull : (uint64_t)pa), sx, &place));
-        if (fork_b) ROME_HIP(c, hipEventRecord(c->ev_side[i], sx));
-      }
-      if (fork_b) for (int i = 0; i < nat; ++i) ROME_HIP(c, hipStreamWaitEvent(s, c->ev_side[i], 0));
+        return ROME_OK;
+      });
+      if (rc) return rc;
     }
+  }
+  if (!on_main) {   // the one join: everything after the run is ordered after it on the context's stream
+    for (int e = 0; e < n_cur; ++e) ROME_HIP(c, hipStreamWaitEvent(s, ev_cur[e], 0));
+    on_main = true;
   }
   if (P->has_mirror && P->gi > 0) {
     // updated variables whose product never ran (no proposals at all) still owe their block to the mirror: the product kernel handles
