@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define ROME_MI355_VERSION 120 /* 0.1.2: multihypo / nullhypo / stream-id columns in rome_clique_host; rome_store + rome_upsolve_plan
+#define ROME_MI355_VERSION 121 /* 0.1.2+: store-resident messages (smsg_*) in rome_clique_upsolve_host (a tree level reads its children's separator beliefs from HBM); multihypo / nullhypo / stream-id columns in rome_clique_host; rome_store + rome_upsolve_plan
                                  * (device-resident clique up-solves: beliefs stay in HBM across frontiers) */
 
 enum {
@@ -259,6 +259,14 @@ typedef struct rome_clique_host {
    * (one rank's share of a frontier, a clique of a graph-wide table) then draws exactly what the whole table draws: results do not
    * depend on how the work was partitioned. */
   const int32_t* p2p2_stream; const int32_t* br1_stream; const int32_t* br0_stream; const int32_t* p3p3_stream; const int32_t* prpt2_stream;
+  /* optional [n_p2p2], rome_upsolve_plan only: p2p2_meas[r] >= 0 makes row r a Pose2Pose2 factor whose measurement distribution is a set
+   * of N SAMPLES (IIF accepts any SamplableBelief as `Z`): the N tangent coordinates (x, y, theta) of Pose2 block p2p2_meas[r] of the
+   * plan's store, particle i of the fixed variable taking sample i; the row's factor entry is ignored.  -1: an ordinary row.  This is
+   * how the RELATIVE up-message of a child clique (samples of anchor^-1 * separator, rome_blockop RELATIVE) enters its parent's solve. */
+  const int32_t* p2p2_meas;
+  /* the same for bearing-range rows: br1_meas / br0_meas [rows] = POINT2 block whose N (x, y) entries are the row's (bearing, range)
+   * samples -- the relative message pose -> landmark of a child clique (ROME_BLOCKOP_RELATIVE with a Point2 source) */
+  const int32_t* br1_meas; const int32_t* br0_meas;
 } rome_clique_host;
 int rome_clique_proposals(rome_ctx*, const rome_opts*, const rome_clique_host*);
 
@@ -314,6 +322,15 @@ typedef struct rome_clique_upsolve_host {
    * of updated variable k is ALSO written to by the product kernel itself, -1 = none: new frontal beliefs land straight in an RCCL send
    * buffer (no gather kernel, no host copy). */
   const int32_t* up_mirror;
+  /* optional, rome_upsolve_plan only: messages that LIVE IN THE STORE (the device-resident form of msg_<type>): message m of a type is
+   * the belief block smsg_<type>_src[m] of the plan's store AS IT IS WHEN A RUN STARTS -- e.g. the separator belief a child clique's
+   * up-solve wrote one tree level earlier (IIF: the TreeBelief a child put!s on its up-message channel) -- and enters
+   * every product of the updated variable at position smsg_<type>_up[m] behind the factor proposals and the host messages; its
+   * manikde! bandwidths are computed at the start of every run.  The source block must not be a variable the plan updates. */
+  int32_t n_smsg_pose2, n_smsg_point2, n_smsg_pose3, reserved1;
+  const int32_t* smsg_pose2_src; const int32_t* smsg_pose2_up;
+  const int32_t* smsg_point2_src; const int32_t* smsg_point2_up;
+  const int32_t* smsg_pose3_src; const int32_t* smsg_pose3_up;
 } rome_clique_upsolve_host;
 int rome_clique_upsolve(rome_ctx*, const rome_opts*, const rome_clique_upsolve_host*);
 
@@ -354,6 +371,24 @@ typedef struct rome_upsolve_plan rome_upsolve_plan;
 int  rome_upsolve_plan_create(rome_ctx*, rome_store*, const rome_opts*, const rome_clique_upsolve_host*, rome_upsolve_plan** out);
 int  rome_upsolve_plan_run(rome_upsolve_plan*, const rome_opts*, double* mirror_out, int64_t mirror_stride);
 void rome_upsolve_plan_destroy(rome_upsolve_plan*);
+/* Block operations inside a store, as plans (index lists uploaded once, a run is ONE launch on the context's stream):
+ *   ROME_BLOCKOP_COPY      block dst[k] <- block a[k]                                    (same type)
+ *   ROME_BLOCKOP_ANCHOR    block dst[k] <- N copies of ONE point of belief a[k]: the mean (Pose2: circular mean heading; Pose3: mean
+ *                          translation, rotation of particle 0) -- the anchor of a relative message: a clique conditions on its anchor
+ *                          separator being exactly there
+ *   ROME_BLOCKOP_RELATIVE  ref = particle 0 of POSE2 block a[k] (an ANCHOR block).  type[k] = 0: Pose2 block dst[k] <- the tangent
+ *                          coordinates of ref^-1 * s_i for the N particles s_i of Pose2 block b[k] (what a p2p2_meas row consumes);
+ *                          type[k] = 1: Point2 block dst[k] <- (bearing, range) of the N landmarks of Point2 block b[k] seen from ref
+ *                          (what a br1_meas / br0_meas row consumes)
+ * type[k] = variable type of entry k (0 Pose2 / 1 Point2 / 2 Pose3; RELATIVE: of b and dst); b may be NULL except for RELATIVE.
+ * Replaces (with smsg_* and p2p2_meas): the up-message channels between cliques of IIF's solveTree! (put!/take! of
+ * TreeBelief messages), kept device-resident. */
+enum { ROME_BLOCKOP_COPY = 0, ROME_BLOCKOP_ANCHOR = 1, ROME_BLOCKOP_RELATIVE = 2 };
+typedef struct rome_blockop_plan rome_blockop_plan;
+int  rome_blockop_plan_create(rome_ctx*, rome_store*, int32_t op, int32_t n, const int32_t* type, const int32_t* a, const int32_t* b,
+                              const int32_t* dst, rome_blockop_plan** out);
+int  rome_blockop_plan_run(rome_blockop_plan*);
+void rome_blockop_plan_destroy(rome_blockop_plan*);
 /* A scatter plan: the receive side of a frontier exchange.  After an all-gather of the ranks' send buffers, block src_block[k] of the
  * receive buffer (units of `stride` doubles, 0 = 6 N) is the new belief of variable (type[k], var[k]) of the store; the lists are
  * uploaded once, a run is ONE launch on the context's stream. */

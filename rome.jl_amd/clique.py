@@ -34,7 +34,25 @@ class CliqueHost(C.Structure):
                 ("br0_alt", C.c_void_p), ("br0_hypo_w", C.c_void_p), ("br0_nullhypo", C.c_void_p),
                 ("p3p3_nullhypo", C.c_void_p),
                 ("p2p2_stream", C.c_void_p), ("br1_stream", C.c_void_p), ("br0_stream", C.c_void_p), ("p3p3_stream", C.c_void_p),
-                ("prpt2_stream", C.c_void_p)]
+                ("prpt2_stream", C.c_void_p), ("p2p2_meas", C.c_void_p), ("br1_meas", C.c_void_p), ("br0_meas", C.c_void_p)]
+
+
+class SampledPose2Pose2:
+    """A Pose2Pose2 factor whose measurement distribution is a set of N SAMPLES held in a belief block of a device-resident store (IIF
+    accepts any SamplableBelief as `Z`): `meas` = label of the Pose2 block with the tangent coordinates (x, y, theta).  This is what the
+    relative up-message of a child clique is to its parent (tree.TreeSolver, messages="relative"); only plans over a store take it."""
+    variable_types = (Pose2, Pose2)
+
+    def __init__(self, meas):
+        self.meas = meas
+
+
+class SampledBearingRange:
+    """The same for a pose -> landmark relation: `meas` = label of a POINT2 block whose N (x, y) entries are (bearing, range) samples."""
+    variable_types = (Pose2, Point2)
+
+    def __init__(self, meas):
+        self.meas = meas
 
 
 class CliqueBatch:
@@ -60,6 +78,7 @@ class CliqueBatch:
         self.fam_rows = {"p2p2": [], "br1": [], "br0": [], "p3p3": [], "prpt2": []}
         self.fam_hyp = {k: [] for k in self.fam_rows}      # per row: (alt, hypo_w, nullhypo)
         self.fam_sid = {k: [] for k in self.fam_rows}      # per row: Philox stream id (or None)
+        self.fam_meas = {k: [] for k in self.fam_rows}     # per row: store block of its measurement samples, -1 = ordinary
         nullh = getattr(fg, "nullhypo", {})
 
         def var(l):
@@ -91,7 +110,22 @@ class CliqueBatch:
                 else:
                     own, oth, hw = (c1, c2, mh[0]) if target == c1 else (c2, c1, mh[1])
                     d, other, alt = 0, first, var(oth)
-            if isinstance(f, (Pose2Pose2, Pose3Pose3)):
+            meas = -1
+            if isinstance(f, SampledPose2Pose2):
+                if mh is not None:
+                    raise TypeError("a sampled-measurement factor carries no multihypo")
+                d = 0 if labels[1] == target else 1
+                other = labels[0] if d == 0 else labels[1]
+                fam, meas = "p2p2", (var_index[f.meas] if var_index is not None else -2)   # (-2: no store -- only the oracle-side restatement)
+                row = (fac(fam, "<sampled>", np.zeros(3), np.eye(3)), d, var(other), var(target))
+            elif isinstance(f, SampledBearingRange):
+                if mh is not None:
+                    raise TypeError("a sampled-measurement factor carries no multihypo")
+                d = 0 if labels[1] == target else 1
+                other = labels[0] if d == 0 else labels[1]
+                fam, meas = ("br0" if d == 0 else "br1"), (var_index[f.meas] if var_index is not None else -2)
+                row = (fac("br", "<sampled>", [0.0, 0.0], [1.0, 1.0]), d, var(other), var(target))
+            elif isinstance(f, (Pose2Pose2, Pose3Pose3)):
                 fam = "p2p2" if isinstance(f, Pose2Pose2) else "p3p3"
                 if mh is None:
                     d = 0 if labels[1] == target else 1
@@ -115,6 +149,7 @@ class CliqueBatch:
             self.fam_rows[fam].append(row)
             self.fam_hyp[fam].append((alt, hw, float(nullh.get(flabel, 0.0)) if row[1] != 2 else 0.0))
             self.fam_sid[fam].append(None if stream_ids is None else stream_ids[(flabel, target)])
+            self.fam_meas[fam].append(meas)
         self.tabs = tabs
 
     def beliefs(self, vt):
@@ -158,6 +193,11 @@ class CliqueBatch:
         q.prpt2_mu, q.prpt2_cov = ptr(np.array(t["prpt2"]["mu"]).reshape(-1, 2)), ptr(np.array(t["prpt2"]["spread"]).reshape(-1, 4))
         q.out_p2p2, q.out_br1, q.out_br0, q.out_p3p3, q.out_prpt2 = (out[f].ctypes.data_as(C.c_void_p) if out[f].size else None
                                                                     for f in ("p2p2", "br1", "br0", "p3p3", "prpt2"))
+        for fam in ("p2p2", "br1", "br0"):
+            if any(m == -2 for m in self.fam_meas[fam]):
+                raise TypeError("a sampled-measurement factor needs a device-resident store (UpsolvePlan / tree.TreeLevelPlan)")
+            if any(m >= 0 for m in self.fam_meas[fam]):
+                setattr(q, fam + "_meas", ptr(np.array(self.fam_meas[fam], dtype=np.int32), np.int32))
         # hypothesis / stream-id columns, only where a row of the family carries one
         for fam in ("p2p2", "br1", "br0", "p3p3", "prpt2"):
             hyp, sid = self.fam_hyp[fam], self.fam_sid[fam]
@@ -249,7 +289,10 @@ class CliqueUpsolveHost(C.Structure):
                 ("msg_pose3", C.c_void_p), ("msg_pose3_up", C.c_void_p),
                 ("new_pose2", C.c_void_p), ("bw_pose2", C.c_void_p), ("new_point2", C.c_void_p), ("bw_point2", C.c_void_p),
                 ("new_pose3", C.c_void_p), ("bw_pose3", C.c_void_p), ("up_group", C.c_void_p), ("up_stream", C.c_void_p),
-                ("up_mirror", C.c_void_p)]
+                ("up_mirror", C.c_void_p),
+                ("n_smsg_pose2", C.c_int32), ("n_smsg_point2", C.c_int32), ("n_smsg_pose3", C.c_int32), ("reserved1", C.c_int32),
+                ("smsg_pose2_src", C.c_void_p), ("smsg_pose2_up", C.c_void_p), ("smsg_point2_src", C.c_void_p), ("smsg_point2_up", C.c_void_p),
+                ("smsg_pose3_src", C.c_void_p), ("smsg_pose3_up", C.c_void_p)]
 
 
 # ------------------------------------------------------------------------------------------ device-resident store + plans

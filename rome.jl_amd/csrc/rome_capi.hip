@@ -657,20 +657,21 @@ struct Fam {
   int n; const int32_t* rows4; int F; const double* mu; const double* spread; int dz, nL, dfx, dt; double* out; int vf, vt; int dir_all;
   uint64_t off; int kind; int base;
   const int32_t* alt; const double* hw; const double* nh; const int32_t* sid; int valt;
+  const int32_t* meas;   // per-row block of the measurement samples (Pose2Pose2 rows only), or nullptr
 };
 constexpr int NF = 5;
 void make_fams(const rome_clique_host* q, Fam (&fam)[NF]) {
   const Fam f[NF] = {
     {q->n_p2p2, q->p2p2_rows4, q->f_p2p2, q->p2p2_mu, q->p2p2_cov, 3, 6, 3, 3, q->out_p2p2, 0, 0, 0, 0ull, 0, 0,
-     q->p2p2_alt, q->p2p2_hypo_w, q->p2p2_nullhypo, q->p2p2_stream, 0},
+     q->p2p2_alt, q->p2p2_hypo_w, q->p2p2_nullhypo, q->p2p2_stream, 0, q->p2p2_meas},
     {q->n_br1, q->br1_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 2, 3, q->out_br1, 1, 0, 1, 1ull << 28, 1, q->n_p2p2,
-     q->br1_alt, q->br1_hypo_w, q->br1_nullhypo, q->br1_stream, 1},
+     q->br1_alt, q->br1_hypo_w, q->br1_nullhypo, q->br1_stream, 1, q->br1_meas},
     {q->n_br0, q->br0_rows4, q->f_br, q->br_mu, q->br_sigma, 2, 2, 3, 2, q->out_br0, 0, 1, 0, 2ull << 28, 1, 0,
-     q->br0_alt, q->br0_hypo_w, q->br0_nullhypo, q->br0_stream, 1},
+     q->br0_alt, q->br0_hypo_w, q->br0_nullhypo, q->br0_stream, 1, q->br0_meas},
     {q->n_p3p3, q->p3p3_rows4, q->f_p3p3, q->p3p3_mu, q->p3p3_cov, 6, 21, 6, 6, q->out_p3p3, 2, 2, 0, 5ull << 28, 2, 0,
-     nullptr, nullptr, q->p3p3_nullhypo, q->p3p3_stream, -1},
+     nullptr, nullptr, q->p3p3_nullhypo, q->p3p3_stream, -1, nullptr},
     {q->n_prpt2, q->prpt2_rows4, q->f_prpt2, q->prpt2_mu, q->prpt2_cov, 2, 3, 2, 2, q->out_prpt2, 1, 1, 0, 7ull << 28, 3, q->n_br0,
-     nullptr, nullptr, nullptr, q->prpt2_stream, -1}};
+     nullptr, nullptr, nullptr, q->prpt2_stream, -1, nullptr}};
   for (int k = 0; k < NF; ++k) fam[k] = f[k];
 }
 // table entries must address the arrays they index (nv = variables per type); hypothesis / stream columns in range
@@ -685,6 +686,7 @@ int check_fam_rows(const Fam& f, const int (&nv)[3]) {
     } else if (f.alt && f.alt[r] < -1) return ROME_ERR_INVALID_ARG;
     if (f.nh && !(f.nh[r] >= 0.0 && f.nh[r] <= 1.0)) return ROME_ERR_INVALID_ARG;
     if (f.sid && (f.sid[r] < 0 || f.sid[r] >= (1 << 28))) return ROME_ERR_INVALID_ARG;
+    if (f.meas && (f.meas[r] < -1 || f.meas[r] >= nv[f.kind == 1 ? 1 : 0] || (f.meas[r] >= 0 && e[1] == 2))) return ROME_ERR_INVALID_ARG;
   }
   return ROME_OK;
 }
@@ -692,10 +694,11 @@ inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 // bytes of a family's device tables (rows4, mu, L, the optional columns)
 size_t fam_table_bytes(const Fam& f) {
   return al256((size_t)f.n * 16) + al256((size_t)f.F * f.dz * 8) + al256((size_t)f.F * f.nL * 8) + 256 +
-         (f.alt ? al256((size_t)f.n * 4) + al256((size_t)f.n * 8) : 0) + (f.nh ? al256((size_t)f.n * 8) : 0) + (f.sid ? al256((size_t)f.n * 4) : 0);
+         (f.alt ? al256((size_t)f.n * 4) + al256((size_t)f.n * 8) : 0) + (f.nh ? al256((size_t)f.n * 8) : 0) + (f.sid ? al256((size_t)f.n * 4) : 0) +
+         (f.meas ? al256((size_t)f.n * 4) : 0);
 }
 struct FamDev { const int32_t* rows = nullptr; const double* mu = nullptr; const double* L = nullptr; const int32_t* alt = nullptr;
-                const double* hw = nullptr; const double* nh = nullptr; const int32_t* sid = nullptr; };
+                const double* hw = nullptr; const double* nh = nullptr; const int32_t* sid = nullptr; const int32_t* meas = nullptr; };
 // uploads a family's tables into `arena` (asynchronously: `Ls` must outlive the stream work); MvNormal factors get their packed Cholesky
 int upload_fam(rome_ctx* c, const Fam& f, unsigned char* arena, size_t* used, std::vector<double>& Ls, FamDev& d) {
   d = FamDev{};
@@ -721,12 +724,13 @@ int upload_fam(rome_ctx* c, const Fam& f, unsigned char* arena, size_t* used, st
   if (f.alt) { ROME_PUT(d.alt, int32_t, f.alt, (size_t)f.n * 4); ROME_PUT(d.hw, double, f.hw, (size_t)f.n * 8); }
   if (f.nh) ROME_PUT(d.nh, double, f.nh, (size_t)f.n * 8);
   if (f.sid) ROME_PUT(d.sid, int32_t, f.sid, (size_t)f.n * 4);
+  if (f.meas) ROME_PUT(d.meas, int32_t, f.meas, (size_t)f.n * 4);
 #undef ROME_PUT
   return ROME_OK;
 }
 // rows [lo, hi) of a family: one convolution launch into `out` (the block of row `lo`)
 hipError_t launch_fam(const Fam& f, const FamDev& d, const rome_opts* o, uint64_t stream_base, int lo, int hi, const double* bel_fixed,
-                      const double* bel_target, double* out, hipStream_t s) {
+                      const double* bel_target, double* out, hipStream_t s, const double* meas_base = nullptr) {
   rome::ConvArgs a;
   rome_opts of = *o;
   of.stream_offset = stream_base + f.off + (d.sid ? 0ull : (uint64_t)lo);   // family offsets of the device graph (DeviceGraph.STREAM_*)
@@ -737,6 +741,7 @@ hipError_t launch_fam(const Fam& f, const FamDev& d, const rome_opts* o, uint64_
   a.alt_var = d.alt ? d.alt + lo : nullptr; a.hypo_w = d.alt ? d.hw + lo : nullptr;
   a.nullhypo = d.nh ? d.nh + lo : nullptr;
   a.row_stream = d.sid ? d.sid + lo : nullptr;
+  if (d.meas && meas_base) { a.meas_block = d.meas + lo; a.meas_base = meas_base; }
   return f.kind == 0 ? rome::launch_conv_pose2pose2(a, o->solver, s) : (f.kind == 1 ? rome::launch_conv_bearingrange(a, o->solver, s)
                      : (f.kind == 2 ? rome::launch_conv_pose3pose3(a, o->solver, s) : rome::launch_sample_priorpoint2(a, s)));
 }
@@ -755,6 +760,7 @@ int rome_clique_proposals(rome_ctx* c, const rome_opts* o, const rome_clique_hos
   for (const Fam& f : fam) {
     if ((rc = check_fam_rows(f, nv))) return rc;
     if (f.n > 0 && !f.out) return ROME_ERR_INVALID_ARG;
+    if (f.meas) return ROME_ERR_INVALID_ARG;   // measurement-sample rows address a store (rome_upsolve_plan)
     need += al256((size_t)f.n * f.dt * N * 8) + fam_table_bytes(f);
   }
   ROME_BIND(c);
@@ -818,6 +824,11 @@ struct rome_scatter_plan {
   int n = 0; int64_t stride = 0;
   int32_t* d_ent = nullptr;   // [n][4] = (dim, var, src_block, type)
 };
+struct rome_blockop_plan {
+  rome_ctx* ctx = nullptr; rome_store* st = nullptr;
+  int op = 0, n = 0;
+  int32_t* d_ent = nullptr;   // [n][4] = (type, a, b, dst)
+};
 struct rome_upsolve_plan {
   rome_ctx* ctx = nullptr; rome_store* st = nullptr;
   int N = 0, layout = 0, gi = 3, pi = 1, n_up = 0;
@@ -834,6 +845,8 @@ struct rome_upsolve_plan {
   double* d_newout[3] = {nullptr, nullptr, nullptr}; double* d_bwout[3] = {nullptr, nullptr, nullptr};
   double* new_host[3] = {nullptr, nullptr, nullptr}; double* bw_host[3] = {nullptr, nullptr, nullptr};
   bool has_mirror = false, has_upstream = false;
+  int n_smsg[3] = {0, 0, 0}, smsg_base[3] = {0, 0, 0};   // store-resident messages: rows [smsg_base, smsg_base + n_smsg) of the type's proposal buffer
+  int32_t* d_smsg_ent[3] = {nullptr, nullptr, nullptr};  // (dim, source block, proposal row, type) per message: gathered at the start of every run
   void* arena = nullptr; bool arena_owned = false;
   size_t tree_need = 8;               // the tree workspaces of the three types side by side (their products may run concurrently)
   size_t tree_off[3] = {0, 0, 0};
@@ -876,6 +889,9 @@ int plan_build(rome_ctx* c, rome_store* st, const rome_opts* o, const rome_cliqu
   const int32_t* msg_up[3] = {u->msg_pose2_up, u->msg_point2_up, u->msg_pose3_up};
   double* new_host[3] = {u->new_pose2, u->new_point2, u->new_pose3};
   double* bw_host[3] = {u->bw_pose2, u->bw_point2, u->bw_pose3};
+  const int n_smsg[3] = {u->n_smsg_pose2, u->n_smsg_point2, u->n_smsg_pose3};
+  const int32_t* smsg_src[3] = {u->smsg_pose2_src, u->smsg_point2_src, u->smsg_pose3_src};
+  const int32_t* smsg_up[3] = {u->smsg_pose2_up, u->smsg_point2_up, u->smsg_pose3_up};
   int msg_base[3];
   int rc;
   for (int t = 0; t < 3; ++t) P->prop_rows_t[t] = 0;
@@ -885,6 +901,8 @@ int plan_build(rome_ctx* c, rome_store* st, const rome_opts* o, const rome_cliqu
     P->n_upt[t] = (int)uplist[t].size();
     P->new_host[t] = P->n_upt[t] ? new_host[t] : nullptr; P->bw_host[t] = P->n_upt[t] ? bw_host[t] : nullptr;
     msg_base[t] = P->prop_rows_t[t]; P->prop_rows_t[t] += n_msg[t];
+    if (n_smsg[t] < 0 || (n_smsg[t] > 0 && (!smsg_src[t] || !smsg_up[t]))) return ROME_ERR_INVALID_ARG;
+    P->n_smsg[t] = n_smsg[t]; P->smsg_base[t] = P->prop_rows_t[t]; P->prop_rows_t[t] += n_smsg[t];
   }
   P->has_mirror = u->up_mirror != nullptr; P->has_upstream = u->up_stream != nullptr;
   // ---- rows: every row targets an updated variable, rows grouped in update order; the row range of every update position; CSR
@@ -909,6 +927,14 @@ int plan_build(rome_ctx* c, rome_store* st, const rome_opts* o, const rome_cliqu
       const int k = msg_up[t][m];
       if (k < 0 || k >= u->n_up || u->up_type[k] != t) return ROME_ERR_INVALID_ARG;
       csr[t][(size_t)P->up_cnt_before[3 * (size_t)k + t]].push_back(msg_base[t] + m);
+    }
+  std::vector<int32_t> sm_h[3];
+  for (int t = 0; t < 3; ++t)
+    for (int m = 0; m < n_smsg[t]; ++m) {   // store-resident messages: source = a block of the store that this plan does not write
+      const int k = smsg_up[t][m], src = smsg_src[t][m];
+      if (k < 0 || k >= u->n_up || u->up_type[k] != t || src < 0 || src >= nv[t] || kpos[t][src] >= 0) return ROME_ERR_INVALID_ARG;
+      csr[t][(size_t)P->up_cnt_before[3 * (size_t)k + t]].push_back(P->smsg_base[t] + m);
+      sm_h[t].push_back(kVdim[t]); sm_h[t].push_back(src); sm_h[t].push_back(P->smsg_base[t] + m); sm_h[t].push_back(t);
     }
   std::vector<int32_t> ptr_h[3], rws_h[3], blk_h[3], sid_h[3], mir_h[3], gat_h[3];
   for (int t = 0; t < 3; ++t) {
@@ -941,7 +967,7 @@ int plan_build(rome_ctx* c, rome_store* st, const rome_opts* o, const rome_cliqu
   for (int t = 0; t < 3; ++t) {
     const size_t blk = (size_t)kVdim[t] * N * 8, nu = uplist[t].size();
     need += al256((size_t)P->prop_rows_t[t] * blk) + al256((size_t)P->prop_rows_t[t] * kVdim[t] * 8) + al256(ptr_h[t].size() * 4) + al256(rws_h[t].size() * 4)
-          + 3 * al256(nu * 4 + 4) + al256(nu * 16 + 16) + al256(nu * blk) + al256(nu * kVdim[t] * 8);
+          + 3 * al256(nu * 4 + 4) + al256(nu * 16 + 16) + al256(nu * blk) + al256(nu * kVdim[t] * 8) + al256((size_t)n_smsg[t] * 16 + 16);
   }
   for (const Fam& f : P->fam) need += fam_table_bytes(f);
   ROME_BIND(c);
@@ -973,6 +999,7 @@ int plan_build(rome_ctx* c, rome_store* st, const rome_opts* o, const rome_cliqu
     if ((rc = put(sid_h[t].data(), nu * 4, &p))) return rc; P->d_upstream[t] = (int32_t*)p;
     if ((rc = put(mir_h[t].data(), nu * 4, &p))) return rc; P->d_upmirror[t] = (int32_t*)p;
     if ((rc = put(gat_h[t].data(), nu * 16, &p))) return rc; P->d_gather[t] = (int32_t*)p;
+    if ((rc = put(sm_h[t].data(), (size_t)n_smsg[t] * 16, &p))) return rc; P->d_smsg_ent[t] = (int32_t*)p;
     if (n_msg[t] > 0) {   // upward messages: appended to the type's proposal buffer, bandwidths once
       void* dm = nullptr; size_t used_m = 0;
       unsigned char* mb = (unsigned char*)(P->d_prop[t] + (size_t)msg_base[t] * kVdim[t] * N);
@@ -987,7 +1014,7 @@ int plan_build(rome_ctx* c, rome_store* st, const rome_opts* o, const rome_cliqu
   for (int k4 = 0; k4 < NF; ++k4) if ((rc = upload_fam(c, P->fam[k4], arena, &used, Ls[k4], P->fd[k4]))) return rc;
   if (used > need) return ROME_ERR_ALLOC;
   // the host tables must not be referenced after creation (the caller's arrays may go away)
-  for (Fam& f : P->fam) { f.rows4 = nullptr; f.mu = f.spread = nullptr; f.alt = nullptr; f.hw = f.nh = nullptr; f.sid = nullptr; f.out = nullptr; }
+  for (Fam& f : P->fam) { f.rows4 = nullptr; f.mu = f.spread = nullptr; f.alt = nullptr; f.hw = f.nh = nullptr; f.sid = nullptr; f.out = nullptr; f.meas = nullptr; }
   return ROME_OK;   // (~DrainOnExit: the uploads have completed before Ls / tmp go away)
 }
 
@@ -1035,6 +1062,13 @@ int plan_run(rome_upsolve_plan* P, const rome_opts* o, double* mirror_out, int64
     else on_main = true;
     return ROME_OK;
   };
+  // store-resident messages: the source blocks as they are NOW -> their proposal rows, and their manikde! bandwidths (once per run)
+  for (int t = 0; t < 3; ++t)
+    if (P->n_smsg[t] > 0 && P->gi > 0) {
+      ROME_HIP(c, rome::launch_scatter_blocks(P->n_smsg[t], N, P->d_smsg_ent[t], P->d_prop[t], (int64_t)kVdim[t] * N, st->bel[0], st->bel[1], st->bel[2], s, /*to_store=*/0));
+      ROME_HIP(c, rome::launch_kde_bandwidth(kVdim[t], P->n_smsg[t], N, P->d_prop[t] + (size_t)P->smsg_base[t] * kVdim[t] * N, kCircBw[t], 1e-2, 1e-6,
+                                             P->d_pbw[t] + (size_t)P->smsg_base[t] * kVdim[t], nullptr, s));
+    }
   for (int it = 0; it < P->gi; ++it) {
     const uint64_t base = o->stream_offset + ((uint64_t)it << 32);
     const int nsteps = P->n_up > 0 ? (int)P->step_k.size() - 1 : 0;
@@ -1055,7 +1089,7 @@ int plan_run(rome_upsolve_plan* P, const rome_opts* o, double* mirror_out, int64
         const int k4 = fam_a[i], lo = lo_a[i], hi = hi_a[i];
         const Fam& f = P->fam[k4];
         double* out = P->d_prop[f.vt] + (size_t)(f.base + lo) * f.dt * N;
-        ROME_HIP(c, launch_fam(f, P->fd[k4], o, base, lo, hi, st->bel[f.vf], st->bel[f.vt], out, sx));
+        ROME_HIP(c, launch_fam(f, P->fd[k4], o, base, lo, hi, st->bel[f.vf], st->bel[f.vt], out, sx, st->bel[f.kind == 1 ? 1 : 0]));
         ROME_HIP(c, rome::launch_kde_bandwidth(f.dt, hi - lo, N, out, kCircBw[f.vt], 1e-2, 1e-6, P->d_pbw[f.vt] + (size_t)(f.base + lo) * f.dt, nullptr, sx));
         return ROME_OK;
       });
@@ -1219,6 +1253,39 @@ int rome_scatter_plan_create(rome_ctx* c, rome_store* st, int32_t n, const int32
   *out = S;
   return ROME_OK;
 }
+int rome_blockop_plan_create(rome_ctx* c, rome_store* st, int32_t op, int32_t n, const int32_t* type, const int32_t* a, const int32_t* b,
+                             const int32_t* dst, rome_blockop_plan** out) {
+  if (!c || !st || !out || st->ctx != c || n < 0 || op < ROME_BLOCKOP_COPY || op > ROME_BLOCKOP_RELATIVE) return ROME_ERR_INVALID_ARG;
+  if (n > 0 && (!type || !a || !dst || (op == ROME_BLOCKOP_RELATIVE && !b))) return ROME_ERR_INVALID_ARG;
+  std::vector<int32_t> ent((size_t)n * 4 + 4, 0);
+  for (int k = 0; k < n; ++k) {
+    const int t = type[k];
+    if (t < 0 || t > 2 || a[k] < 0 || a[k] >= st->nv[t] || dst[k] < 0 || dst[k] >= st->nv[t]) return ROME_ERR_INVALID_ARG;
+    if (op == ROME_BLOCKOP_RELATIVE && (t > 1 || b[k] < 0 || b[k] >= st->nv[t] || a[k] >= st->nv[0])) return ROME_ERR_INVALID_ARG;
+    ent[4 * (size_t)k] = t; ent[4 * (size_t)k + 1] = a[k]; ent[4 * (size_t)k + 2] = b ? b[k] : 0; ent[4 * (size_t)k + 3] = dst[k];
+  }
+  ROME_BIND(c);
+  rome_blockop_plan* B = new (std::nothrow) rome_blockop_plan();
+  if (!B) return ROME_ERR_ALLOC;
+  B->ctx = c; B->st = st; B->op = op; B->n = n;
+  if (hipMalloc((void**)&B->d_ent, (size_t)n * 16 + 16) != hipSuccess) { delete B; return hip_fail(c, hipGetLastError()); }
+  if (hipMemcpy(B->d_ent, ent.data(), (size_t)n * 16 + 16, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(B->d_ent); delete B; return hip_fail(c, hipGetLastError()); }
+  *out = B;
+  return ROME_OK;
+}
+int rome_blockop_plan_run(rome_blockop_plan* B) {
+  if (!B) return ROME_ERR_INVALID_ARG;
+  rome_ctx* c = B->ctx;
+  ROME_BIND(c);
+  ROME_HIP(c, rome::launch_block_ops(B->op, B->n, B->st->N, B->d_ent, B->st->bel[0], B->st->bel[1], B->st->bel[2], c->stream));
+  return ROME_OK;
+}
+void rome_blockop_plan_destroy(rome_blockop_plan* B) {
+  if (!B) return;
+  if (B->d_ent) (void)hipFree(B->d_ent);
+  delete B;
+}
+
 int rome_scatter_plan_run(rome_scatter_plan* S, const double* src_dev) {
   if (!S || (S->n > 0 && !src_dev)) return ROME_ERR_INVALID_ARG;
   rome_ctx* c = S->ctx;

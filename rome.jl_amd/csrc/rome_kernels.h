@@ -33,6 +33,9 @@ struct ConvArgs {
   int mirror_row[4];
   double* mirror_out;
   const int32_t* mirror_map;  // [C] block of mirror_out row c is ALSO written to (-1: none), or nullptr -> mirror_row; any number of rows
+  const int32_t* meas_block;  // [C] block of meas_base ([.][dz][N]) holding row c's MEASUREMENT samples (-1: sample the factor in-kernel), or
+                              // nullptr: a factor whose measurement distribution is a set of samples -- the relative message of a child clique
+  const double* meas_base;
   const int32_t* row_stream;  // [C] Philox stream id of row c (stream = stream_offset + id), or nullptr -> c.  Served by the wave-per-row
                               // kernels and the prior samplers (a table with this column does not take the packed sweep)
   int dir_all;
@@ -86,5 +89,8 @@ hipError_t launch_product_gibbs(int dim, int V, int N, int n_rows, const int32_t
 // <- block `block` of buf (stride doubles apart); else the reverse (a contiguous download buffer <- scattered beliefs)
 hipError_t launch_scatter_blocks(int n, int N, const int32_t* ent /*[n][4]*/, const double* buf, int64_t stride,
                                  double* st2, double* st_pt, double* st3, hipStream_t s, int to_store);
+
+// block operations inside a store (include/rome_mi355.h ROME_BLOCKOP_*): entry k = (type, a, b, dst); one 256-thread block per entry
+hipError_t launch_block_ops(int op, int n, int N, const int32_t* ent /*[n][4]*/, double* st2, double* st_pt, double* st3, hipStream_t s);
 
 }  // namespace rome

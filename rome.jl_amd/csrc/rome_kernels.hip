@@ -682,6 +682,7 @@ __device__ __forceinline__ void conv_wave_body(const ConvArgs& a, int blk) {
   const double* __restrict__ tb = a.bel_target + (size_t)tv * FP::DT * N;
   double* __restrict__ ob = a.out + (size_t)c * FP::DT * N;
   const uint64_t stream = a.stream_offset + (uint64_t)((!LEAN && a.row_stream) ? a.row_stream[c] : c);
+  [[maybe_unused]] const int meas_blk = (!LEAN && a.meas_block) ? a.meas_block[c] : -1;
 
   double fx[PPL][FP::DF], t[PPL][FP::DT], z[PPL][FP::DZ];
   typename FP::Prep prep[PPL];
@@ -696,7 +697,11 @@ __device__ __forceinline__ void conv_wave_body(const ConvArgs& a, int blk) {
     act[k] = i < N;
     const int ii = act[k] ? i : 0;  // idle lanes shadow particle 0 (keeps the math finite, never stored)
     double xi[FP::DZ];
-    if (!LEAN && a.noise) {
+    if (!LEAN && meas_blk >= 0) {   // the row's measurement samples live in a belief block (a message of a child clique)
+      const double* nb = a.meas_base + (size_t)meas_blk * FP::DZ * N;
+#pragma unroll
+      for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
+    } else if (!LEAN && a.noise) {
       const double* nb = a.noise + (size_t)c * FP::DZ * N;
 #pragma unroll
       for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
@@ -710,7 +715,7 @@ __device__ __forceinline__ void conv_wave_body(const ConvArgs& a, int blk) {
     } else {
       rng_normals<FP::DZ>(a.seed, stream, (uint32_t)ii, xi);
     }
-    if (!LEAN && a.noise && a.noise_is_meas) {   // the caller sampled the measurement model itself (any SamplableBelief)
+    if (!LEAN && ((a.noise && a.noise_is_meas) || meas_blk >= 0)) {   // the caller sampled the measurement model itself (any SamplableBelief)
 #pragma unroll
       for (int d = 0; d < FP::DZ; ++d) z[k][d] = xi[d];
     } else FP::measurement(K, xi, z[k]);
@@ -1136,6 +1141,7 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
   const double* tb = a.bel_target + (size_t)tv * FP::DT * N;
   double* ob = a.out + (size_t)c * FP::DT * N;
   const uint64_t stream = a.stream_offset + (uint64_t)(a.row_stream ? a.row_stream[c] : c);
+  const int meas_blk = a.meas_block ? a.meas_block[c] : -1;
   const bool cyc_on = FP::needs_cycles(SOLVER, K);
   const int ncyc = cyc_on ? (a.cycles < 1 ? 1 : a.cycles) : 1;
   if (!valid) return;   // (nothing below synchronises across waves; surplus waves of the last block have no row)
@@ -1184,7 +1190,11 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
 #pragma unroll
         for (int d = 0; d < FP::DT; ++d) t[k][d] = cur[d * N + ii];
         double xi[FP::DZ];
-        if (a.noise) {
+        if (meas_blk >= 0) {
+          const double* nb = a.meas_base + (size_t)meas_blk * FP::DZ * N;
+#pragma unroll
+          for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
+        } else if (a.noise) {
           const double* nb = a.noise + (size_t)c * FP::DZ * N;
 #pragma unroll
           for (int d = 0; d < FP::DZ; ++d) xi[d] = nb[d * N + ii];
@@ -1195,7 +1205,7 @@ __global__ void __launch_bounds__(64 * ROME_WPB) k_conv_big(const ConvArgs a) {
             for (int d = 0; d < FP::DZ; ++d) xi[d] = xi_odd[d];
           }
         }
-        if (a.noise && a.noise_is_meas) {
+        if ((a.noise && a.noise_is_meas) || meas_blk >= 0) {
 #pragma unroll
           for (int d = 0; d < FP::DZ; ++d) z[k][d] = xi[d];
         } else FP::measurement(K, xi, z[k]);
@@ -1415,7 +1425,8 @@ static hipError_t launch_flat(const ConvArgs& a, hipStream_t s) {
 }
 template <class FP, int SOLVER>
 static hipError_t launch_ppl(const ConvArgs& a, hipStream_t s) {
-  const bool lean = a.rows4 != nullptr && a.noise == nullptr && a.alt_var == nullptr && a.nullhypo == nullptr && a.row_stream == nullptr;
+  const bool lean = a.rows4 != nullptr && a.noise == nullptr && a.alt_var == nullptr && a.nullhypo == nullptr && a.row_stream == nullptr &&
+                    a.meas_block == nullptr;
   if constexpr (FP::kUniqueRoot && (SOLVER == kSolverClosedForm || SOLVER == kSolverNewton || SOLVER == kSolverGaussNewton)) {
     // plain sweep of a unique-root factor: the packed kernel (rows of >= 8 pair-threads; tiny N stays one wavefront per row) -- the
     // analytic root, or the Gauss-Newton iteration on the residual functor from the belief point (nothing couples the particles of a
@@ -1444,8 +1455,8 @@ hipError_t launch_conv_pose3pose3(const ConvArgs& a, int solver, hipStream_t s) 
 hipError_t launch_conv_bearingrange(const ConvArgs& a, int solver, hipStream_t s) {
   return a.dir_all == 0 ? launch_solver<BR<0>>(a, solver, s) : launch_solver<BR<1>>(a, solver, s);
 }
-static bool plain_rows(const ConvArgs& a) { return a.rows4 && !a.noise && !a.alt_var && !a.nullhypo && !a.status && !a.row_stream; }
-static bool hypo_rows(const ConvArgs& a) { return a.rows4 && !a.noise && !a.status && !a.row_stream && (a.alt_var || a.nullhypo); }
+static bool plain_rows(const ConvArgs& a) { return a.rows4 && !a.noise && !a.alt_var && !a.nullhypo && !a.status && !a.row_stream && !a.meas_block; }
+static bool hypo_rows(const ConvArgs& a) { return a.rows4 && !a.noise && !a.status && !a.row_stream && !a.meas_block && (a.alt_var || a.nullhypo); }
 // the whole sweep of a Pose2 / Point2 graph: fused into one launch when every family takes its plain kernel, else family by family
 hipError_t launch_sweep_pose2(const ConvArgs* p2p2, const ConvArgs* br1, const ConvArgs* br0, int solver, hipStream_t s) {
   const int N = p2p2 ? p2p2->N : (br1 ? br1->N : (br0 ? br0->N : 0));
@@ -1522,6 +1533,61 @@ hipError_t launch_scatter_blocks(int n, int N, const int32_t* ent, const double*
                                  hipStream_t s, int to_store) {
   if (n > 0) hipLaunchKernelGGL(k_scatter_blocks, dim3(n), dim3(256), 0, s, N, reinterpret_cast<const int4*>(ent), const_cast<double*>(buf), (long long)stride,
                                 st2, st_pt, st3, to_store);
+  return hipGetLastError();
+}
+
+// ---- block operations inside a store (copy / anchor / relative): one 256-thread block per entry (type, a, b, dst)
+__global__ void __launch_bounds__(256) k_block_ops(int op, int N, const int4* __restrict__ ent, double* d2, double* dpt, double* d3) {
+  const int4 e = ent[blockIdx.x];
+  const int dim = e.x == 0 ? 3 : (e.x == 1 ? 2 : 6);
+  double* base = e.x == 0 ? d2 : (e.x == 1 ? dpt : d3);
+  const double* A = base + (size_t)e.y * dim * N;
+  double* D = base + (size_t)e.w * dim * N;
+  const int i = threadIdx.x;
+  if (op == 0) { for (int q = i; q < dim * N; q += 256) D[q] = A[q]; return; }
+  if (op == 2) {   // relative to ref = particle 0 of the POSE2 block e.y: Pose2 -> tangent coordinates of ref^-1 * s_i; Point2 -> (bearing, range)
+    const double* Rf = d2 + (size_t)e.y * 3 * N;
+    const double* S = base + (size_t)e.z * dim * N;
+    const double rx = Rf[0], ry = Rf[N], rt = Rf[2 * N];
+    double sn, cs; sincos(rt, &sn, &cs);
+    for (int q = i; q < N; q += 256) {
+      const double dx = S[q] - rx, dy = S[N + q] - ry;
+      const double lx = cs * dx + sn * dy, ly = -sn * dx + cs * dy;
+      if (e.x == 0) {
+        double s2, c2; sincos(S[2 * N + q] - rt, &s2, &c2);
+        D[q] = lx; D[N + q] = ly; D[2 * N + q] = atan2(s2, c2);
+      } else { D[q] = atan2(ly, lx); D[N + q] = sqrt(lx * lx + ly * ly); }
+    }
+    return;
+  }
+  // anchor: the mean point, N times.  Sums in a fixed order (lane partials -> LDS tree) so that the result does not depend on scheduling.
+  __shared__ double red[8][256];
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = i; q < N; q += 256) {
+    if (e.x == 0) { double sn, cs; sincos(A[2 * N + q], &sn, &cs); acc[0] += A[q]; acc[1] += A[N + q]; acc[2] += sn; acc[3] += cs; }
+    else if (e.x == 1) { acc[0] += A[q]; acc[1] += A[N + q]; }
+    else { acc[0] += A[q]; acc[1] += A[N + q]; acc[2] += A[2 * N + q]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k][i] = acc[k];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (i < w) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][i] += red[k][i + w];
+    }
+    __syncthreads();
+  }
+  const double inv = 1.0 / (double)N;
+  double m[6];
+  if (e.x == 0) { m[0] = red[0][0] * inv; m[1] = red[1][0] * inv; m[2] = atan2(red[2][0], red[3][0]); }
+  else if (e.x == 1) { m[0] = red[0][0] * inv; m[1] = red[1][0] * inv; }
+  else { m[0] = red[0][0] * inv; m[1] = red[1][0] * inv; m[2] = red[2][0] * inv; m[3] = A[3 * N]; m[4] = A[4 * N]; m[5] = A[5 * N]; }
+  __syncthreads();
+  for (int q = i; q < dim * N; q += 256) D[q] = m[q / N];
+}
+hipError_t launch_block_ops(int op, int n, int N, const int32_t* ent, double* st2, double* st_pt, double* st3, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_block_ops, dim3(n), dim3(256), 0, s, op, N, reinterpret_cast<const int4*>(ent), st2, st_pt, st3);
   return hipGetLastError();
 }
 

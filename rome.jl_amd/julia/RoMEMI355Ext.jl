@@ -187,6 +187,9 @@ struct RomeCliqueHost            # include/rome_mi355.h: rome_clique_host
   p3p3_nullhypo::Ptr{Float64}
   # per-row Philox stream ids (C_NULL = the row's index): see the header
   p2p2_stream::Ptr{Int32}; br1_stream::Ptr{Int32}; br0_stream::Ptr{Int32}; p3p3_stream::Ptr{Int32}; prpt2_stream::Ptr{Int32}
+  # rome_upsolve_plan only: per-row store block holding the row's N MEASUREMENT samples (-1 = ordinary row): the relative up-message of a
+  # child clique as a sampled-measurement factor of its parent (C_NULL = none)
+  p2p2_meas::Ptr{Int32}; br1_meas::Ptr{Int32}; br0_meas::Ptr{Int32}
 end
 
 const _accelerated = Union{Pose2Pose2, PriorPose2, Pose2Point2BearingRange{<:Normal,<:Normal}, Pose3Pose3, PriorPose3, PriorPoint2}
@@ -262,7 +265,8 @@ _clique_host(t, o2, o1, o0, o3, opt = Float64[], nv = (length(t.vars[Pose2]), le
                  length(t.rows[:prpt2]) ÷ 4, t.nfac[:prpt2], _p(t.rows[:prpt2]), _p(t.tabμ[:prpt2]), _p(t.tabΣ[:prpt2]), _p(opt),
                  _p(t.alt[:p2p2]), _p(t.hw[:p2p2]), _p(t.nh[:p2p2]), _p(t.alt[:br1]), _p(t.hw[:br1]), _p(t.nh[:br1]),
                  _p(t.alt[:br0]), _p(t.hw[:br0]), _p(t.nh[:br0]), _p(t.nh[:p3p3]),
-                 Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL))
+                 Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL),
+                 Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL))
 _points_opts(dfg, N) = (d0 = default_opts(dfg);
   RomeOpts(Int32(N), d0.solver, d0.max_iters, d0.inflate_cycles, d0.tol, d0.inflation, d0.seed, d0.stream_offset, 2 #=points=#, 0, d0.spread_nh, 0.0))
 
@@ -324,7 +328,12 @@ struct RomeCliqueUpsolveHost     # include/rome_mi355.h: rome_clique_upsolve_hos
   up_group::Ptr{Int32}          # optional update groups (a frontier of independent cliques in one call); C_NULL: follow `schedule`
   up_stream::Ptr{Int32}         # optional product stream ids (partition-independent frontiers); C_NULL: position within the type
   up_mirror::Ptr{Int32}         # rome_upsolve_plan only: blocks of a device send buffer; C_NULL here
+  # rome_upsolve_plan only: messages that live in the store (a child clique's separator beliefs, written one tree level earlier)
+  n_smsg_pose2::Int32; n_smsg_point2::Int32; n_smsg_pose3::Int32; reserved1::Int32
+  smsg_pose2_src::Ptr{Int32}; smsg_pose2_up::Ptr{Int32}; smsg_point2_src::Ptr{Int32}; smsg_point2_up::Ptr{Int32}
+  smsg_pose3_src::Ptr{Int32}; smsg_pose3_up::Ptr{Int32}
 end
+
 
 function upsolve_clique!(dfg::AbstractDFG, frontals::AbstractVector{Symbol}, factors::AbstractVector{<:DFGFactor};
                          gibbsIters::Integer=3, Niter::Integer=1, sequential::Bool=true,
@@ -349,7 +358,8 @@ function upsolve_clique!(dfg::AbstractDFG, frontals::AbstractVector{Symbol}, fac
     u = RomeCliqueUpsolveHost(_clique_host(t, Float64[], Float64[], Float64[], Float64[]),
                               Int32(gibbsIters), Int32(Niter), Int32(sequential ? 0 : 1), Int32(length(frontals)), pointer(upt), pointer(upv),
                               0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
-                              _p(new2), _p(bw2), _p(newl), _p(bwl), _p(new3), _p(bw3), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL))
+                              _p(new2), _p(bw2), _p(newl), _p(bwl), _p(new3), _p(bw3), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL),
+                              Int32(0), Int32(0), Int32(0), Int32(0), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL))
     check(ccall((:rome_clique_upsolve, LIB), Cint, (Ptr{Cvoid}, Ref{RomeOpts}, Ref{RomeCliqueUpsolveHost}), ctx().h, o, u))
   end
   k = Dict(0 => 0, 1 => 0, 2 => 0)
@@ -452,7 +462,7 @@ function RomeUpsolvePlan(st::RomeStore, dfg::AbstractDFG, frontals::AbstractVect
     u = RomeCliqueUpsolveHost(q, Int32(gibbsIters), Int32(Niter), Int32(sequential ? 0 : 1), Int32(length(frontals)), _p(upt), _p(upv),
                               0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,
                               C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL,          # no host outputs: run! copies nothing and does not wait
-                              _p(grp), Ptr{Int32}(C_NULL), _p(mir))
+                              _p(grp), Ptr{Int32}(C_NULL), _p(mir), Int32(0), Int32(0), Int32(0), Int32(0), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL))
     check(ccall((:rome_upsolve_plan_create, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{RomeOpts}, Ref{RomeCliqueUpsolveHost}, Ref{Ptr{Cvoid}}),
                 ctx().h, st.h, o, u, r))
   end

@@ -138,3 +138,116 @@ class OracleScatter:
         for l, b in zip(self.labels, self.blocks):
             d = st.fg.variables[l].dim
             st.dev.vals[l] = src[b * self.stride:b * self.stride + d * st.N].numpy().reshape(d, st.N).copy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# stand-in backend for rome_jl_amd.tree.TreeSolver: the "HBM" is a dict over the lifted universe (home labels + separator copies), a
+# level plan is the oracle's restatement of rome_clique_upsolve over the level's own factor graph (same rows, groups, stream ids and
+# store-resident messages as tree.TreeLevelPlan hands the library).
+class OracleTreeStore:
+    def __init__(self, R, universe):
+        self.R, self.fg, self.N = R, universe, universe.N
+        self.vals = {}
+        self.index = {}
+        cnt = {}
+        for l, t in universe.variables.items():
+            self.index[l] = cnt.get(t, 0); cnt[t] = cnt.get(t, 0) + 1
+
+    def upload(self, fg, labels=None):
+        for l in self.fg.variables:
+            if fg.isInitialized(l) and (labels is None or l in labels):
+                self.vals[l] = np.array(fg.getVal(l), dtype=np.float64)
+
+    def download(self, fg, labels=None):
+        for l, v in self.vals.items():
+            if labels is None or l in labels:
+                fg.vals[l] = v.copy()
+
+    def get(self, label):
+        return self.vals[label]
+
+
+class OracleTreePlan:
+    def __init__(self, store, spec, share=None, mirror=None):
+        self.store, self.spec, self.share, self.mirror = store, spec, share, mirror
+        L = spec.fg
+        from rome_jl_amd.clique import CliqueBatch
+        full = CliqueBatch(L, spec.pairs)
+        self.sid = {pair: r for pair, (fam, r) in full.rows.items()}
+        types = (store.R.Pose2, store.R.Point2, store.R.Pose3)
+        self.pos_t, cnt = {}, {t: 0 for t in types}
+        for l in spec.order:
+            vt = L.variables[l]; self.pos_t[l] = cnt[vt]; cnt[vt] += 1
+        mine = None if share is None else set(share)
+        self.keep = [k for k in range(len(spec.order)) if mine is None or spec.owner[k] in mine]
+
+    def run(self, opts, mirror_out=None, mirror_stride=0):
+        from solve_ref import upsolve_ref
+        st, sp = self.store, self.spec
+        L = sp.fg
+        L.vals = {l: st.vals[l] for l in L.variables if l in st.vals}
+        order = [sp.order[k] for k in self.keep]
+        if not order:
+            return
+        oset = set(order)
+        msgs = {}
+        for src, dst in sp.smsgs:
+            if dst in oset:
+                msgs.setdefault(dst, []).append(st.vals[src])
+        # the share's own factor graph view: upsolve_ref enumerates the factors of its destinations itself
+        ref = upsolve_ref(st.R, L, order, st.N, seed=int(opts.seed), gibbs_iters=sp.gibbs_iters, product_iters=1,
+                          groups=[sp.groups[k] for k in self.keep], stream_offset=int(opts.stream_offset), stream_ids=self.sid,
+                          up_stream=self.pos_t, solver=int(opts.solver), messages=msgs, usable=lambda l: True, meas_vals=st.vals,
+                          pairs=[p for p in sp.pairs if p[1] in oset])
+        for l in order:
+            st.vals[l] = ref[l]
+            if self.mirror is not None and self.mirror.get(l, -1) >= 0:
+                blk = torch.as_tensor(ref[l].reshape(-1))
+                o = self.mirror[l] * int(mirror_stride or 6 * st.N)
+                mirror_out[o:o + blk.numel()].copy_(blk)
+
+
+class OracleTreeBlockOp:
+    """numpy restatement of rome_blockop_plan: copy / anchor (N copies of the mean; Pose2: circular mean heading; Pose3: rotation of
+    particle 0) / relative (tangent coordinates of ref^-1 * s_i, or (bearing, range) of a landmark seen from ref)"""
+
+    def __init__(self, store, op, entries):
+        self.store, self.op, self.entries = store, op, list(entries)
+
+    def run(self):
+        v, N = self.store.vals, self.store.N
+        for e in self.entries:
+            if self.op == "copy":
+                v[e[1]] = v[e[0]].copy()
+            elif self.op == "anchor":
+                b = v[e[0]]
+                m = b.mean(axis=1)
+                if b.shape[0] == 3:
+                    m[2] = np.arctan2(np.sin(b[2]).sum(), np.cos(b[2]).sum())
+                elif b.shape[0] == 6:
+                    m[3:] = b[3:, 0]
+                v[e[1]] = np.repeat(m[:, None], N, axis=1)
+            else:
+                ref, s = v[e[0]][:, 0], v[e[1]]
+                c, sn = np.cos(ref[2]), np.sin(ref[2])
+                dx, dy = s[0] - ref[0], s[1] - ref[1]
+                lx, ly = c * dx + sn * dy, -sn * dx + c * dy
+                if s.shape[0] == 3:
+                    dt = s[2] - ref[2]
+                    v[e[2]] = np.stack([lx, ly, np.arctan2(np.sin(dt), np.cos(dt))])
+                else:
+                    v[e[2]] = np.stack([np.arctan2(ly, lx), np.sqrt(lx * lx + ly * ly)])
+
+
+class OracleTreeBackend:
+    def __init__(self, R):
+        self.R = R
+
+    def Store(self, universe):
+        return OracleTreeStore(self.R, universe)
+
+    def Plan(self, store, spec, share=None, mirror=None):
+        return OracleTreePlan(store, spec, share=share, mirror=mirror)
+
+    def BlockOp(self, store, op, entries):
+        return OracleTreeBlockOp(store, op, entries)

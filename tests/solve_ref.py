@@ -94,18 +94,19 @@ def solve_ref(R, fg, n_sweeps, N, seed=0x524F4D45, solver=1, bandwidth="silverma
 
 
 def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iters=1, schedule="sequential", solver=1, messages=None,
-                groups=None, stream_offset=0, stream_ids=None, up_stream=None, usable=None):
+                groups=None, stream_offset=0, stream_ids=None, up_stream=None, usable=None, meas_vals=None, pairs=None):
     """Oracle-side restatement of rome_clique_upsolve / R.upGibbsCliqueDensity (IIF upGibbsCliqueDensity): same pairs, same row
     tables (multihypo / nullhypo columns included), same Philox streams; every convolution, bandwidth and product through oracle/
     (CPU).  stream_ids: {(factor, target): id within the family} / up_stream: {label: product stream id} (default: row index /
     position within the type, as the library).  -> {label: points (dim, N)}"""
     from rome_jl_amd.clique import CliqueBatch
     usable = usable or fg.isInitialized
-    pairs = []
-    for dest in frontals:
-        for flabel, labels, _ in fg.factors:
-            if dest in labels and all(usable(l) or l in frontals for l in labels if l != dest):
-                pairs.append((flabel, dest))
+    if pairs is None:     # (explicit pairs: a tree level hands over exactly the rows of its plan)
+        pairs = []
+        for dest in frontals:
+            for flabel, labels, _ in fg.factors:
+                if dest in labels and all(usable(l) or l in frontals for l in labels if l != dest):
+                    pairs.append((flabel, dest))
     batch = CliqueBatch(fg, pairs)
     for l in frontals:
         if l not in batch.vidx:
@@ -144,6 +145,10 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
             sel = [r for r in range(len(rw)) if rw[r, 3] in tv]
             for r in sel:
                 alt, hw, nh = batch.fam_hyp[fam][r]
+                nz = None
+                if batch.fam_meas[fam][r] != -1:   # sampled-measurement factor: z = 0 + I xi with xi = the samples themselves
+                    flab = next(p_[0] for p_, (fm, rr) in batch.rows.items() if fm == fam and rr == r)
+                    nz = np.asarray(meas_vals[fg.getFactor(flab)[2].meas], dtype=float)[None]
                 so = base + S[fam] + sid[fam][r]
                 o = ro.make_opts(N=N, solver=solver, seed=seed, stream_offset=so, nullhypo=nh)
                 mh = {} if alt < 0 else dict(alt_var=[alt], hypo_w=[hw])
@@ -151,7 +156,7 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
                 if fam == "p2p2" and d == 2:
                     p = ro.sample_priorpose2(ro.make_opts(N=N, seed=seed, stream_offset=so), mu2[f], L2[f])[0]
                 elif fam == "p2p2":
-                    p = ro.conv_pose2pose2(o, mu2, L2, bel[R.Pose2], [fx], [tg], [d], factor=[f], **mh)[0]
+                    p = ro.conv_pose2pose2(o, mu2, L2, bel[R.Pose2], [fx], [tg], [d], factor=[f], noise=nz, **mh)[0]
                 elif fam == "prpt2":
                     p = ro.sample_priorpoint2(ro.make_opts(N=N, seed=seed, stream_offset=so), mupt[f], Lpt[f])[0]
                 elif fam == "p3p3" and d == 2:
@@ -159,9 +164,9 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
                 elif fam == "p3p3":
                     p = ro.conv_pose3pose3(o, mu3, L3, bel[R.Pose3], [fx], [tg], [d], factor=[f])[0]
                 elif fam == "br1":
-                    p = ro.conv_pose2point2br(o, 1, mub, sgb, bel[R.Point2], bel[R.Pose2], [fx], [tg], factor=[f], **mh)[0]
+                    p = ro.conv_pose2point2br(o, 1, mub, sgb, bel[R.Point2], bel[R.Pose2], [fx], [tg], factor=[f], noise=nz, **mh)[0]
                 else:
-                    p = ro.conv_pose2point2br(o, 0, mub, sgb, bel[R.Pose2], bel[R.Point2], [fx], [tg], factor=[f], **mh)[0]
+                    p = ro.conv_pose2point2br(o, 0, mub, sgb, bel[R.Pose2], bel[R.Point2], [fx], [tg], factor=[f], noise=nz, **mh)[0]
                 out[tv[tg]].append(p)
         for l in targets:
             for pts in (messages or {}).get(l, []):

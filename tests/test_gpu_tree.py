@@ -1,0 +1,114 @@
+"""The Bayes-tree solve (rome_jl_amd.tree): ordering -> cliques -> levels -> up messages -> down pass, device-resident (one
+rome_upsolve_plan per tree level, store-resident messages, sampled-measurement rows, block operations), against the oracle's
+restatement of the same schedule (tests/dist_standin.py: OracleTreeBackend drives tests/solve_ref.py::upsolve_ref with the rows, groups,
+stream ids and messages of every level)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+import rome_jl_amd as R   # noqa: E402
+from rome_jl_amd.tree import BayesTree, TreeSolver, BlockOpPlan   # noqa: E402
+from rome_jl_amd.clique import DeviceStore   # noqa: E402
+from dist_standin import OracleTreeBackend, OracleTreeBlockOp, OracleTreeStore   # noqa: E402
+
+G2O = os.path.join(ROOT, "tests", "golden", "manhattan.g2o")
+HEX = {"x0": (0, 0), "x1": (10, 0), "x2": (15, 8.66), "x3": (10, 17.32), "x4": (0, 17.32), "x5": (-5, 8.66), "x6": (0, 0), "l1": (20, 0)}
+
+
+def _wd(a, b):
+    d = a - b
+    if d.shape[0] == 3:
+        d[2] = np.arctan2(np.sin(d[2]), np.cos(d[2]))
+    return d
+
+
+def test_block_operations_match_their_numpy_restatement():
+    N = 100
+    fg = R.initfg(N)
+    rng = np.random.default_rng(3)
+    for k in range(4):
+        fg.addVariable("x%d" % k, R.Pose2)
+    for k in range(3):
+        fg.addVariable("l%d" % k, R.Point2)
+    fg.addVariable("q0", R.Pose3); fg.addVariable("q1", R.Pose3)
+    fg.initVariable("x0", np.array([[3.0], [-2.0], [3.1]]) + np.array([[0.5], [0.5], [0.2]]) * rng.standard_normal((3, N)))   # heading across the cut
+    fg.initVariable("x1", np.array([[8.0], [1.0], [-3.0]]) + 0.3 * rng.standard_normal((3, N)))
+    fg.initVariable("l0", np.array([[12.0], [5.0]]) + 0.4 * rng.standard_normal((2, N)))
+    fg.initVariable("q0", rng.standard_normal((6, N)))
+    dev, orc = DeviceStore(fg), OracleTreeStore(R, fg)
+    orc.upload(fg)
+    steps = [("anchor", [("x0", "x2"), ("l0", "l1"), ("q0", "q1")]), ("relative", [("x2", "x1", "x3"), ("x2", "l0", "l2")]), ("copy", [("x3", "x1"), ("l2", "l1")])]
+    for op, ent in steps:
+        BlockOpPlan(dev, op, ent).run(); OracleTreeBlockOp(orc, op, ent).run()
+    for l in fg.variables:
+        if l in orc.vals:
+            assert np.abs(_wd(dev.get(l), orc.vals[l])).max() < 1e-12, l
+    z = dev.get("x1")          # = the relative samples: composing them onto the anchor gives the particles of the source back
+    ref = orc.vals["x2"][:, 0]
+    c, s = np.cos(ref[2]), np.sin(ref[2])
+    back = np.stack([ref[0] + c * z[0] - s * z[1], ref[1] + s * z[0] + c * z[1], ref[2] + z[2]])
+    assert np.abs(_wd(back, fg.getVal("x1"))).max() < 1e-12
+
+
+def _both(fg, messages, seed, passes=1, **kw):
+    N = fg.N
+    dev = TreeSolver(fg, messages=messages, **kw)
+    orc = TreeSolver(fg, tree=dev.tree, messages=messages, backend=OracleTreeBackend(R), **kw)
+    dev.upload(); orc.upload()
+    out = []
+    for ps in range(passes):
+        o = R.make_opts(N=N, seed=seed + ps)
+        dev.solve(o); orc.solve(o)
+        fr, dm = [], []
+        for l in fg.variables:
+            d = _wd(dev.store.get(l), orc.store.get(l))
+            fr.append(np.mean(np.abs(d) < 1e-6)); dm.append(np.abs(d.mean(axis=1)).max())
+        out.append((float(np.mean(fr)), float(np.max(dm))))
+    return dev, out
+
+
+@pytest.mark.parametrize("messages", ["marginal", "relative"])
+def test_hexagon_tree_solve_equals_the_oracle_tree_solve(messages):
+    fg = R.generateGraph_Hexagonal(N=100)
+    R.initAllOrdered(fg, seed=4)                                    # IIF: initAll! before solveTree!
+    dev, worst = _both(fg, messages, 31, passes=2)
+    assert dev.tree.cliques[0].parent == -1 and len(dev.tree.levels) >= 3
+    for frac, dmean in worst:
+        assert frac > 0.9 and dmean < 1e-3, worst                   # north_star tolerance on the belief means
+    # the windows of test/testHexagonal2D_CliqByCliq.jl:37-79 on the device's posterior
+    dev.download()
+    for l, (x, y) in HEX.items():
+        p = fg.getVal(l)
+        assert np.mean((np.abs(p[0] - x) < 3.0) & (np.abs(p[1] - y) < 3.0)) > 0.35, (l, p[:2].mean(1))
+
+
+@pytest.mark.parametrize("messages", ["marginal", "relative"])
+def test_manhattan_prefix_tree_solve_equals_the_oracle_tree_solve(messages):
+    """first 120 edges of manhattan.g2o (loop closures included): multi-frontal cliques, several separators, messages on both"""
+    fg = R.loadG2o(G2O, N=64, max_edges=120)
+    R.initAllOrdered(fg, seed=2)
+    dev, worst = _both(fg, messages, 41)
+    st = dev.stats()
+    assert st["levels"] > 5 and st["store_messages"] > 0 and (messages == "marginal" or st["relative_messages"] > 20), st
+    for frac, dmean in worst:
+        assert frac > 0.9 and dmean < 1e-3, worst
+
+
+def test_beehive_multihypo_tree_solve_runs_with_landmark_separators():
+    """BASELINE configs[3]: landmarks among the separators (relative messages pose -> landmark as sampled bearing-range rows), multihypo
+    sightings inside the cliques"""
+    fg = R.synth_beehive_mh(20, N=100)
+    R.initAllOrdered(fg, seed=2)
+    ts = TreeSolver(fg, messages="relative")
+    assert any(fg.variables[s] is R.Point2 for c in ts.tree.cliques for s in c.separators)
+    ts.upload(); ts.solve(R.make_opts(N=100, seed=3)); ts.download()
+    sim = fg._sim
+    err = [np.hypot(*(fg.getVal(l)[:2].mean(1) - np.asarray(sim[l])[:2])) for l in fg.variables if fg.variables[l] is R.Pose2]
+    assert np.isfinite(err).all() and np.median(err) < 3.0, np.median(err)
