@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--solver", default="newton", choices=["closed_form", "newton", "nelder_mead", "gauss_newton"])
+    ap.add_argument("--tree-messages", default="relative", choices=["relative", "marginal"], help="message form of the solve.from_tree leg")
     ap.add_argument("--poses", type=int, default=3500)
     ap.add_argument("--loops", type=int, default=1954)
     ap.add_argument("--particles", type=int, default=100)
@@ -418,7 +419,10 @@ def main():
         ev_block = blocks[0]
     order = sorted(range(n_blocks), key=lambda i: blocks[i][0])
     elapsed, _ = blocks[order[n_blocks // 2]]
-    kern_ms = ev_block[1]
+    # ONE period for `value` and for the roofline: the median block (N=1: a step IS one launch of the dominant kernel; the event-bracketed
+    # block is kept beside it as a cross-check -- round 4 quoted the roofline on that block alone, 7.8 us against a reproducible 8.6)
+    kern_ms_events = ev_block[1]
+    kern_ms = 1e3 * elapsed / args.steps
 
     data_kind = "synthetic" if (not args.g2o or args.g2o == "synthetic") else \
         "Manhattan M3500 dataset (measurements); beliefs synthetic: dead-reckoned means + N(0, sigma) particles"
@@ -437,7 +441,11 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": data_kind if not shared else
         data_kind + " [ROME_BENCH_SHARED_DEVICE=1: %d ranks on ONE device, host-staged exchange -- a flow test, NOT a measurement]" % world,
         "config": {"workload": workload, "poses_per_gpu": len(pk.labels[R.Pose2]), "pose2pose2_factors_per_gpu": tb["F"],
-                   "convolutions_per_step_per_gpu": (pipe.n_rows if strong else n_conv_step), "particles": N, "solver": args.solver,
+                   "convolutions_per_step_per_gpu": (pipe.n_rows if strong else n_conv_step), "particles": N,
+                   "solver": {"newton": "newton (analytic root: k_conv_flat<P2P2, 0>; no residual evaluation, no start point read, inflate_cycles inert)",
+                              "closed_form": "closed_form (analytic root: k_conv_flat<P2P2, 0>; inflate_cycles inert)",
+                              "gauss_newton": "gauss_newton (Gauss-Newton on the residual functor from the belief point: k_conv_flat<P2P2, 3>; one pass, inflate_cycles inert on unique-root factors)",
+                              "nelder_mead": "nelder_mead (the reference's Optim.NelderMead on the residual functor, inflate_cycles x entropy + solve)"}[args.solver],
                    "inflate_cycles": int(opts.inflate_cycles), "inflation": float(opts.inflation), "noise": "in-kernel philox",
                    "parallelism": ("ONE graph, one %s per step: rows sharded by target ownership (%d of %d on rank 0), all_gather of the owned belief blocks (%s)"
                                    % (strong_unit, pipe.n_rows, tb["C"], ("host-staged (shared device)" if shared else "RCCL direct, in place") if comms else "torch.distributed")) if strong else
@@ -449,7 +457,9 @@ def main():
                                                       else "rome::k_conv<P2P2,%s,PPL=2,lean>" % args.solver)),
                      "bytes_per_particle": BYTES_PER_PARTICLE_P2P2[args.solver],
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms, "traffic": None},
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms,
+                     "period": "ms_per_step of the median timed block (the period behind `value`)", "kernel_ms_event_bracketed_block": kern_ms_events,
+                     "traffic": None},
     }
     # counter-measured HBM traffic of the same kernel on the same table (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
     # scripts/profile_round.sh; PMC counters need rocprofv3 around the process, so this run quotes the stored pass)
@@ -487,7 +497,7 @@ def main():
             pass
 
     if rank == 0 and world == 1 and not args.no_modes:
-        modes = {}
+        modes, by_solver = {}, {}
         for name, sv in (("closed_form", R.SOLVER_CLOSED_FORM), ("newton", R.SOLVER_NEWTON), ("gauss_newton", R.SOLVER_GAUSS_NEWTON),
                          ("nelder_mead", R.SOLVER_NELDER_MEAD)):
             o2 = R.make_opts(N=N, solver=sv, seed=0x524F4D45)
@@ -498,7 +508,21 @@ def main():
             for _ in range(reps):
                 pl()
             torch.cuda.synchronize()
-            modes[name] = tb["C"] * reps / (time.perf_counter() - a)
+            dt_l = (time.perf_counter() - a) / reps
+            modes[name] = tb["C"] / dt_l
+            bts = tb["C_rel"] * N * BYTES_PER_PARTICLE_P2P2[name] + tb["P"] * N * 24
+            by_solver[name] = {"bytes_per_particle": BYTES_PER_PARTICLE_P2P2[name], "algorithmic_bytes_per_launch": bts, "kernel_ms_per_launch": 1e3 * dt_l,
+                               "achieved": bts / dt_l / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bts / dt_l / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
+                               "launches_timed": reps}
+            sqf = os.path.join(ROOT, "profiles", "r04_sq_counters_%s.json" % name)
+            if os.path.exists(sqf):   # secondary bound of the functor-iterating solvers: VALU issue (stored PMC pass of the same kernel and table)
+                try:
+                    with open(sqf) as f:
+                        sj = json.load(f)
+                    by_solver[name]["valu_busy_frac"] = 4.0 * sj["SQ_ACTIVE_INST_VALU_quadcycles"] / (256 * 4 * 2.4e9 * dt_l)
+                    by_solver[name]["valu_instructions_per_wave"] = sj["derived"]["valu_instructions_per_wave"]
+                except Exception:
+                    pass
         # the residual-EVALUATING default solver: NEWTON with a status array (k_conv_flat<P2P2, VERIFY>): the analytic root, then the RoME
         # residual functor (through points / rotation matrices) at every particle for the convergence status -- 48 B + 4 B status per particle
         status = torch.zeros((tb["C"], N), dtype=torch.int32, device=dev)
@@ -515,6 +539,9 @@ def main():
                                      "algorithmic_GBps": (tb["C_rel"] * N * 52 + tb["P"] * N * 28) / tv / 1e9,
                                      "frac_of_hbm_peak": (tb["C_rel"] * N * 52 + tb["P"] * N * 28) / tv / 1e9 / HBM_PEAK_GBS, "bytes_per_particle": 52}
         out["gpu_convolutions_per_s_by_solver"] = modes
+        # north_star's literal path is "residual + numerical root-find": gauss_newton (functor iteration) and nelder_mead (the reference's
+        # optimizer) beside the analytic-root headline, each with its own algorithmic bytes (start point read: 72 B) and measured period
+        out["roofline_by_solver"] = by_solver
         # the other half of the metric ("solveTree! wall-clock"): one iteration of the device-resident solve loop on the
         # same graph = all convolutions (one launch) + the proposal product of every variable (one launch); DESIGN.md §11
         o3 = R.make_opts(N=N, solver=R.SOLVER_NEWTON, seed=0x524F4D45)
@@ -631,6 +658,48 @@ def main():
                         "left by the init pass is frozen in (DESIGN.md section 11); the reference's own solveTree! result on Manhattan-500 sits metres from the MAP too"}
         except Exception as e:   # noqa: BLE001
             out["solve"]["from_init_all_ordered"] = {"error": repr(e)}
+
+        # ---- the TREE solve (solveTree!-shaped): initAll!-order init pass, then the Bayes tree up + down pass (rome_jl_amd.tree): elimination
+        # order -> cliques -> levels; one rome_upsolve_plan per level; no parametric start, no dead reckoning
+        try:
+            from rome_jl_amd.tree import TreeSolver
+            fg1 = R.loadG2o(args.g2o, N=N) if (args.g2o and args.g2o != "synthetic") else R.synth_manhattan(P=args.poses, loops=args.loops, seed=0x524F4D45 + rank, N=N)
+            a = time.perf_counter(); R.initAllOrdered(fg1, seed=1, ctx=ctx); t_ini = time.perf_counter() - a
+            ls1 = list(fg1.variables)
+            mp1 = np.array([xp[l] for l in ls1])
+
+            def rms_fg(aligned=False):
+                m, _ = R.belief_stats(np.stack([fg1.getVal(l) for l in ls1]))
+                A, B = m[:, :2], mp1[:, :2]
+                if aligned:       # after the best rigid transform (what remains is not a gauge error)
+                    A, B = A - A.mean(0), B - B.mean(0)
+                    U_, _, Vt = np.linalg.svd(A.T @ B); Rr = (U_ @ Vt).T
+                    if np.linalg.det(Rr) < 0:
+                        Rr = (U_ @ np.diag([1.0, -1.0]) @ Vt).T
+                    A = A @ Rr.T
+                return float(np.sqrt(np.mean(np.sum((A - B) ** 2, axis=1))))
+            r_init = rms_fg()
+            a = time.perf_counter(); tsv = TreeSolver(fg1, messages=args.tree_messages, ctx=ctx); t_build = time.perf_counter() - a
+            tsv.upload()
+            passes = []
+            for ps in range(3):
+                o4 = R.make_opts(N=N, seed=100 + ps)
+                ctx.synchronize(); a = time.perf_counter(); tsv.up(o4); ctx.synchronize(); tu = time.perf_counter() - a
+                a = time.perf_counter(); tsv.down(o4); ctx.synchronize(); td = time.perf_counter() - a
+                tsv.download()
+                passes.append({"up_s": tu, "down_s": td, "rms_to_parametric_m": rms_fg(), "rms_after_rigid_alignment_m": rms_fg(True)})
+            st_ = tsv.stats()
+            out["solve"]["from_tree"] = {
+                "what": "NO starting beliefs: initAll!-order init pass, then Bayes tree (minimum-degree elimination -> %d cliques -> %d levels, widest %d) up pass + "
+                        "down pass with '%s' messages, one rome_upsolve_plan per level, device-resident; each further pass re-solves from the previous posterior"
+                        % (st_["cliques"], st_["levels"], st_["width_max"], args.tree_messages),
+                "init_all_s": t_ini, "rms_to_parametric_m_after_init": r_init, "tree_and_plans_build_s": t_build, "passes": passes,
+                "wall_clock_s_first_pass": t_ini + t_build + passes[0]["up_s"] + passes[0]["down_s"], "tree": st_,
+                "frontier_width_by_level": [len(l) for l in tsv.tree.levels],
+                "note": "N = 100 particles: a pass is a stochastic estimate -- the spread over passes is its sampling noise (mostly a rigid transform of the whole "
+                        "map about the prior pose: see rms_after_rigid_alignment_m); DESIGN.md section 11"}
+        except Exception as e:   # noqa: BLE001
+            out["solve"]["from_tree"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R, pk, fg, N, args.cpu_seconds)

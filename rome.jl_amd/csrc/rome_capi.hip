@@ -1260,7 +1260,7 @@ int rome_blockop_plan_create(rome_ctx* c, rome_store* st, int32_t op, int32_t n,
   std::vector<int32_t> ent((size_t)n * 4 + 4, 0);
   for (int k = 0; k < n; ++k) {
     const int t = type[k];
-    if (t < 0 || t > 2 || a[k] < 0 || a[k] >= st->nv[t] || dst[k] < 0 || dst[k] >= st->nv[t]) return ROME_ERR_INVALID_ARG;
+    if (t < 0 || t > 2 || a[k] < 0 || a[k] >= st->nv[op == ROME_BLOCKOP_RELATIVE ? 0 : t] || dst[k] < 0 || dst[k] >= st->nv[t]) return ROME_ERR_INVALID_ARG;
     if (op == ROME_BLOCKOP_RELATIVE && (t > 1 || b[k] < 0 || b[k] >= st->nv[t] || a[k] >= st->nv[0])) return ROME_ERR_INVALID_ARG;
     ent[4 * (size_t)k] = t; ent[4 * (size_t)k + 1] = a[k]; ent[4 * (size_t)k + 2] = b ? b[k] : 0; ent[4 * (size_t)k + 3] = dst[k];
   }

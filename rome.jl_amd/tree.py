@@ -217,17 +217,20 @@ class TreeSolver:
     -> `.run(opts)`, BlockOp(store, op, entries) -> `.run()` (op "copy" / "anchor" / "relative").  Default: the device
     (`DeviceBackend`); the CPU tests inject an oracle-backed one.
     messages: "relative" or "marginal" (module docstring).  gibbsIters / downIters: iterations of the up / down clique solves in
-    "marginal" form (IIF: 3 / 1); the "relative" form solves every variable once per pass."""
+    "marginal" form (IIF: 3 / 1).  The "relative" form solves every variable ONCE outward (up and down); rootIters / refineIters add
+    Gibbs sweeps over the frontals of the root / of every clique in the down pass with ALL factors and messages of the clique (the
+    outward solve takes a variable's proposals from the neighbours solved before it only)."""
 
-    def __init__(self, fg, tree=None, order="mmd", last=(), messages="relative", gibbsIters=3, downIters=1, backend=None, ctx=None):
+    def __init__(self, fg, tree=None, order="mmd", last=(), messages="relative", gibbsIters=3, downIters=1, rootIters=0, refineIters=0,
+                 backend=None, ctx=None):
         from .graph import FactorGraph
         if messages not in ("relative", "marginal"):
             raise ValueError("messages must be 'relative' or 'marginal'")
         self.fg, self.N, self.messages = fg, fg.N, messages
         self.tree = tree or BayesTree.build(list(fg.variables), [(fl, tuple(ls)) for fl, ls, _ in fg.factors], order=order, last=last)
         self.backend = backend or DeviceBackend(ctx)
-        self.gibbsIters, self.downIters = int(gibbsIters), int(downIters)
-        if not (1 <= self.gibbsIters <= 16 and 1 <= self.downIters <= 16):
+        self.gibbsIters, self.downIters, self.rootIters, self.refineIters = int(gibbsIters), int(downIters), int(rootIters), int(refineIters)
+        if not (1 <= self.gibbsIters <= 16 and 1 <= self.downIters <= 16 and 0 <= self.rootIters <= 16 and 0 <= self.refineIters <= 16):
             raise ValueError("gibbsIters / downIters must be in 1..16")       # Philox: run k draws from k << 36
         self.findex = {fl: (fl, ls, f) for fl, ls, f in fg.factors}
         U = FactorGraph(fg.N)
@@ -246,6 +249,8 @@ class TreeSolver:
         self.up_plans = [B.Plan(self.store, s) if s.order else None for s in ups]
         self.up_post = [[B.BlockOp(self.store, "relative", s.relatives)] if s.relatives else [] for s in ups]
         self.down_plans = [B.Plan(self.store, s) if s.order else None for s in downs]
+        self.root_plans = [B.Plan(self.store, s) if s is not None and s.order else None for s in getattr(self, "root_specs", [None] * len(ups))]
+        self.refine_plans = [B.Plan(self.store, s) if s is not None and s.order else None for s in getattr(self, "refine_specs", [None] * len(ups))]
         self.runs = 0
 
     def _lift(self, L, fl, cid, tag, labels, factor):
@@ -418,6 +423,42 @@ class TreeSolver:
                 self.unreached += [(cid, v) for v in left]
                 cliques.append((upd, grp))
             downs.append(LevelSpec(L, cliques, pairs_of, smsgs, 1))
+        # ---- Gibbs sweeps over the frontals with every factor and message of the clique (roots after the up pass, the others after
+        #      their outward down solve): colour classes of the clique's own graph
+        def sweeps(lvl, roots, iters):
+            if iters <= 0:
+                return None
+            L = FactorGraph(fg.N)
+            cliques, pairs_of, smsgs = [], {}, []
+            for cid in lvl:
+                c = t.cliques[cid]
+                if (c.parent < 0) != roots:
+                    cliques.append(([], [])); continue
+                pw, pri, srcs = down_parts[cid]
+                F = list(c.frontals)
+                nb = {v: set() for v in F}
+                for _, ls, _ in pw:
+                    for v in ls:
+                        if v in nb:
+                            nb[v].update(o for o in ls if o != v and o in nb)
+                col = _colour(F, nb.__getitem__)
+                for v in F:
+                    self._need(L, v, fg.variables[v])
+                    rows = []
+                    for fid, ls, f in pw:
+                        if v in ls:
+                            for o in ls:
+                                self._need(L, o, fg.variables[o])
+                            rows.append(self._lift(L, fid, cid, "*" + v + ":", list(ls), f))
+                    rows += [self._lift(L, fl, cid, "*", [v], f) for fl, pv, f in pri if pv == v]
+                    for src, sv in srcs:
+                        if sv == v:
+                            self._need(L, src, fg.variables[v]); smsgs.append((src, v))
+                    pairs_of[v] = rows
+                cliques.append((F, [col[v] for v in F]))
+            return LevelSpec(L, cliques, pairs_of, smsgs, iters)
+        self.root_specs = [sweeps(lvl, True, self.rootIters) for lvl in t.levels]
+        self.refine_specs = [sweeps(lvl, False, self.refineIters) for lvl in t.levels]
         return ups, downs
 
     # ---------------------------------------------------------------- the solve
@@ -432,18 +473,22 @@ class TreeSolver:
         self.store.upload(fg or self.fg)
 
     def up(self, opts):
-        for pre, pl, post in zip(self.up_pre, self.up_plans, self.up_post):
+        for pre, pl, post, rp in zip(self.up_pre, self.up_plans, self.up_post, self.root_plans):
             for op in pre:
                 op.run()
             if pl is not None:
                 self._run(pl, opts)
             for op in post:
                 op.run()
+            if rp is not None:
+                self._run(rp, opts)
 
     def down(self, opts):
-        for pl in self.down_plans[::-1]:
+        for pl, rf in zip(self.down_plans[::-1], self.refine_plans[::-1]):
             if pl is not None:
                 self._run(pl, opts)
+            if rf is not None:
+                self._run(rf, opts)
 
     def solve(self, opts, passes=1):
         for _ in range(passes):

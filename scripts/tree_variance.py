@@ -1,0 +1,29 @@
+import os, sys, time
+import numpy as np
+sys.path.insert(0, "/root/repo")
+import rome_jl_amd as R
+from rome_jl_amd.tree import TreeSolver
+N = 100
+G2O = "/root/repo/tests/golden/manhattan.g2o"
+fg = R.loadG2o(G2O, N=N)
+xp = R.solveGraphParametric(R.dead_reckon_init(R.loadG2o(G2O, N=N), seed=1))
+labels = list(fg.variables); mp = np.array([xp[l] for l in labels])
+R.initAllOrdered(fg, seed=1)
+ts = TreeSolver(fg, messages="relative", rootIters=int(sys.argv[1]), refineIters=int(sys.argv[2]), last=(("x0",) if len(sys.argv) > 3 and sys.argv[3] == "last" else ()))
+print(ts.tree.summary())
+print("rootIters", sys.argv[1], "refineIters", sys.argv[2])
+root = [v for c in ts.tree.cliques if c.parent < 0 for v in c.frontals]
+ridx = [labels.index(v) for v in root]
+lvl_of = {v: c.level for c in ts.tree.cliques for v in c.frontals}
+lv = np.array([lvl_of[l] for l in labels])
+ts.upload()
+for ps in range(6):
+    ts.solve(R.make_opts(N=N, seed=500 + ps)); ts.download()
+    bel = np.stack([fg.getVal(l) for l in labels]); m, _ = R.belief_stats(bel)
+    e = np.sqrt(np.sum((m[:, :2] - mp[:, :2]) ** 2, axis=1))
+    A, Bm = m[:, :2] - m[:, :2].mean(0), mp[:, :2] - mp[:, :2].mean(0)
+    Uu, _, Vt = np.linalg.svd(A.T @ Bm); Rr = (Uu @ Vt).T
+    if np.linalg.det(Rr) < 0: Rr = (Uu @ np.diag([1, -1]) @ Vt).T
+    al = np.sqrt(np.mean(np.sum((A @ Rr.T - Bm) ** 2, axis=1)))
+    print("pass %d: RMS all %.3f aligned %.3f root %.3f | by level 39..30: %s | lvl 20 %.2f lvl 10 %.2f lvl 0 %.2f" % (ps, np.sqrt(np.mean(e**2)), al, np.sqrt(np.mean(e[ridx]**2)),
+          " ".join("%.2f" % np.sqrt(np.mean(e[lv == h]**2)) for h in range(39, 29, -1)), np.sqrt(np.mean(e[lv == 20]**2)), np.sqrt(np.mean(e[lv == 10]**2)), np.sqrt(np.mean(e[lv == 0]**2))), flush=True)

@@ -40,7 +40,35 @@ def test_bench_line_follows_the_contract():
     assert r["algorithmic_bytes_per_launch"] == 10906 * 100 * 48 + 100 * 24
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["kernel_ms_per_launch"] * 1e-3) / 1e9)
     assert r["kernel_ms_per_launch"] <= d["ms_per_step"] * 1.05   # the kernel's period cannot exceed the step it is part of
+    # ONE period behind `value` and `frac` (the line quoted 0.838 from a separate event-bracketed block while value came from the median block)
+    assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9 / r["peak"]) < 0.03 * r["frac"]
+    assert "analytic root" in cfg["solver"] and "inflate_cycles inert" in cfg["solver"]
     assert "traffic" in r                                          # counter-measured bytes of the stored PMC pass, or null
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "convolutions/s" and c["sample"]
     assert d["value"] > 20 * c["value"]                            # north_star's target: >= 20x the CPU reference path
+
+
+@pytest.mark.timeout(1500)
+def test_bench_line_carries_the_functor_iterating_solvers_and_the_tree_solve():
+    """the full default line (what the driver records): roofline_by_solver for gauss_newton / nelder_mead (north_star: "residual + numerical
+    root-find") and solve.from_tree (the solveTree!-shaped wall-clock from NO parametric start)"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ROME_BENCH_SHARED_DEVICE", "ROME_BENCH_FORCE_EXCHANGE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--cpu-seconds", "4"],
+                       env=env, capture_output=True, text=True, timeout=1400, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    rb = d["roofline_by_solver"]
+    for name, bpp in (("closed_form", 48), ("newton", 48), ("gauss_newton", 72), ("nelder_mead", 72)):
+        r = rb[name]
+        assert r["bytes_per_particle"] == bpp and r["frac"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["kernel_ms_per_launch"] * 1e-3) / 1e9 / 8000.0)
+    assert rb["gauss_newton"]["frac"] < rb["newton"]["frac"] and rb["nelder_mead"]["frac"] < rb["gauss_newton"]["frac"]
+    ft = d["solve"]["from_tree"]
+    assert "error" not in ft, ft
+    assert ft["tree"]["levels"] > 20 and ft["tree"]["cliques"] > 2500 and sum(ft["frontier_width_by_level"]) == ft["tree"]["cliques"]
+    best = min(p_["rms_to_parametric_m"] for p_ in ft["passes"])
+    assert best < ft["rms_to_parametric_m_after_init"]           # the tree pass improves on the init pass (5.3 m)
+    assert min(p_["rms_after_rigid_alignment_m"] for p_ in ft["passes"]) < 3.0
+    assert ft["passes"][0]["up_s"] + ft["passes"][0]["down_s"] < 2.0

