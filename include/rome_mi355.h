@@ -363,7 +363,9 @@ int  rome_store_ptr(rome_store*, int32_t type, void** dev, int32_t* n_blocks);
  * run.  opts at creation fix n_particles and the host layout of new_* / msg_*; opts at run time give solver, seed, stream_offset,
  * inflation etc. (n_particles must match).
  * rome_upsolve_plan_run(plan, opts, mirror_out, mirror_stride): mirror_out = DEVICE buffer the up_mirror blocks are written to, block
- * m at mirror_out + m * mirror_stride doubles (stride >= dim * N; 0 = 6 N); NULL when the plan has no mirrors.
+ * m at mirror_out + m * mirror_stride doubles (stride >= N; 0 = 6 N); NULL when the plan has no mirrors.  A block occupies dim * N doubles from
+ * its slot: with a stride below 6 N the CALLER lays the slots out so that blocks do not overlap -- e.g. stride N with a Pose2 block taking 3
+ * slots, a Point2 block 2 and a Pose3 block 6: an exchange buffer without padding (rome_scatter_plan reads the same layout).
  * Stream semantics: everything a run issues is ordered after the work already queued on the context's stream, and work queued there
  * afterwards is ordered after the run -- inside a run, independent launch chains of a step (per row family: convolutions -> bandwidths;
  * per variable type: ball trees -> product) go to context-owned side streams that fork from and re-join the context's stream. */
@@ -390,7 +392,7 @@ int  rome_blockop_plan_create(rome_ctx*, rome_store*, int32_t op, int32_t n, con
 int  rome_blockop_plan_run(rome_blockop_plan*);
 void rome_blockop_plan_destroy(rome_blockop_plan*);
 /* A scatter plan: the receive side of a frontier exchange.  After an all-gather of the ranks' send buffers, block src_block[k] of the
- * receive buffer (units of `stride` doubles, 0 = 6 N) is the new belief of variable (type[k], var[k]) of the store; the lists are
+ * receive buffer (units of `stride` doubles, stride >= N, 0 = 6 N) is the new belief of variable (type[k], var[k]) of the store; the lists are
  * uploaded once, a run is ONE launch on the context's stream. */
 typedef struct rome_scatter_plan rome_scatter_plan;
 int  rome_scatter_plan_create(rome_ctx*, rome_store*, int32_t n, const int32_t* type, const int32_t* var, const int32_t* src_block,

@@ -1025,7 +1025,7 @@ int plan_run(rome_upsolve_plan* P, const rome_opts* o, double* mirror_out, int64
   if (P->has_mirror && !mirror_out) return ROME_ERR_INVALID_ARG;
   if (mirror_stride == 0) mirror_stride = 6 * (int64_t)N;
   if (P->has_mirror)
-    for (int t = 0; t < 3; ++t) if (P->n_upt[t] && mirror_stride < (int64_t)kVdim[t] * N) return ROME_ERR_INVALID_ARG;
+    if (mirror_stride < (int64_t)N) return ROME_ERR_INVALID_ARG;   // (a block spans dim * N doubles from its slot: PACKED layouts use stride N)
   ROME_BIND(c);
   void* trees = nullptr;
   if ((rc = ensure(c, 10, P->tree_need, &trees))) return rc;
@@ -1240,7 +1240,7 @@ int rome_scatter_plan_create(rome_ctx* c, rome_store* st, int32_t n, const int32
   std::vector<int32_t> ent((size_t)n * 4 + 4);
   for (int k = 0; k < n; ++k) {
     const int t = type[k];
-    if (t < 0 || t > 2 || var[k] < 0 || var[k] >= st->nv[t] || src_block[k] < 0 || stride < (int64_t)kVdim[t] * st->N) return ROME_ERR_INVALID_ARG;
+    if (t < 0 || t > 2 || var[k] < 0 || var[k] >= st->nv[t] || src_block[k] < 0 || stride < (int64_t)st->N) return ROME_ERR_INVALID_ARG;
     ent[4 * (size_t)k] = kVdim[t]; ent[4 * (size_t)k + 1] = var[k]; ent[4 * (size_t)k + 2] = src_block[k]; ent[4 * (size_t)k + 3] = t;
   }
   ROME_BIND(c);

@@ -447,37 +447,68 @@ class FrontierShard:
     store_cls / plan_cls / scatter_cls: injected by the CPU tests (oracle-backed stand-ins over torch CPU tensors)."""
 
     def __init__(self, store, torch, dist, world, rank, device="cpu", comm=None, always_collective=False, plan_cls=None, scatter_cls=None):
+        device = torch.device(device)       # (a string such as "cuda:0" is a natural argument: the stream binding below tests .type)
         self.store, self.torch, self.dist, self.world, self.rank, self.device = store, torch, dist, world, rank, device
+        if comm is not None and not (device.type == "cuda" and hasattr(store, "ctx")):
+            raise ValueError("a direct RCCL communicator needs a CUDA device and a device store (the collective is ordered on the context's stream)")
         self.comm, self.always_collective = comm, always_collective
-        if plan_cls is None:
+        if plan_cls is None or scatter_cls is None:
             from .clique import UpsolvePlan, ScatterPlan
-            plan_cls, scatter_cls = UpsolvePlan, ScatterPlan
+            plan_cls, scatter_cls = plan_cls or UpsolvePlan, scatter_cls or ScatterPlan
         self.plan_cls, self.scatter_cls = plan_cls, scatter_cls
 
     def shares(self, n_cliques):
         return [list(range(r, n_cliques, self.world)) for r in range(self.world)]
 
-    def plan(self, cliques, gibbsIters=3, Niter=1, usable=None):
+    def _layout(self, labels, vartype_of):
+        """PACKED exchange layout: slots of N doubles, a belief of dimension d takes d consecutive slots (Pose2 3, Point2 2, Pose3 6: no
+        padding to the widest type); rank r's blocks start at slot r * width, width = the largest share.  Every rank derives the same
+        layout from the clique list, so no metadata travels.  -> (width, [{label: first slot} per rank])"""
+        offs, tot = [], []
+        for ls in labels:
+            o, k = {}, 0
+            for l in ls:
+                o[l] = k; k += vartype_of(l).dim
+            offs.append(o); tot.append(k)
+        width = max(1, max(tot))
+        return width, [{l: r * width + k for l, k in o.items()} for r, o in enumerate(offs)]
+
+    def _exchange_plan(self, labels, vartype_of, make_plan):
         torch, N = self.torch, self.store.N
+        width, slots = self._layout(labels, vartype_of)
+        recv = torch.zeros(self.world * width * N, dtype=torch.float64, device=self.device)
+        send = recv[self.rank * width * N:(self.rank + 1) * width * N]            # in place: this rank's slice of the receive buffer
+        up = make_plan({l: b - self.rank * width for l, b in slots[self.rank].items()}) if labels[self.rank] else None   # (slots within `send`)
+        # (always_collective: the one-rank measurement form -- the own blocks go through the exchange buffer and the scatter too)
+        others = [(l, b) for r in range(self.world) if r != self.rank or self.always_collective for l, b in slots[r].items()]
+        sc = self.scatter_cls(self.store, [l for l, _ in others], [b for _, b in others], stride=N) if others else None
+        return dict(up=up, scatter=sc, recv=recv, send=send, width=width, U=N, labels=labels)
+
+    def plan(self, cliques, gibbsIters=3, Niter=1, usable=None):
         cliques = [list(c) for c in cliques]
         shares = self.shares(len(cliques))
         labels = [[l for k in sh for l in cliques[k]] for sh in shares]
-        U = 6 * N
-        width = max(1, max(len(x) for x in labels))
-        recv = torch.zeros(self.world * width * U, dtype=torch.float64, device=self.device)
-        send = recv[self.rank * width * U:(self.rank + 1) * width * U]            # in place: this rank's slice of the receive buffer
-        mine = labels[self.rank]
-        up = self.plan_cls(self.store, cliques, share=shares[self.rank], gibbsIters=gibbsIters, Niter=Niter,
-                           mirror={l: k for k, l in enumerate(mine)}, usable=usable) if mine else None
-        # (always_collective: the one-rank measurement form -- the own blocks go through the exchange buffer and the scatter too)
-        others = [(l, r * width + k) for r in range(self.world) if r != self.rank or self.always_collective for k, l in enumerate(labels[r])]
-        sc = self.scatter_cls(self.store, [l for l, _ in others], [b for _, b in others], stride=U) if others else None
-        return dict(up=up, scatter=sc, recv=recv, send=send, width=width, U=U, labels=labels)
+        fgv = self.store.fg.variables
+        return self._exchange_plan(labels, fgv.__getitem__, lambda mirror: self.plan_cls(
+            self.store, cliques, share=shares[self.rank], gibbsIters=gibbsIters, Niter=Niter, mirror=mirror, usable=usable))
+
+    def plan_level(self, spec, level_plan_cls):
+        """One level of a Bayes tree (tree.LevelSpec: multi-frontal cliques, separator copies, messages of the children) dealt round-robin
+        by CLIQUE: a rank solves all updated variables of its cliques; what travels is every block the level writes (frontals, the
+        cliques' private copies) -- the next level's messages are read from them on every rank.  level_plan_cls(store, spec, share=,
+        mirror=) -> plan (tree.TreeLevelPlan; the CPU tests inject the oracle-backed one)."""
+        shares = self.shares(len(spec.cliques))
+        owner_rank = {k: r for r, sh in enumerate(shares) for k in sh}
+        labels = [[] for _ in range(self.world)]
+        for l, k in zip(spec.order, spec.owner):
+            labels[owner_rank[k]].append(l)
+        return self._exchange_plan(labels, spec.fg.variables.__getitem__, lambda mirror: level_plan_cls(
+            self.store, spec, share=shares[self.rank], mirror=mirror))
 
     def step(self, plan, opts):
         """up-solve this rank's share, exchange, scatter: afterwards every rank's store holds ALL new frontal beliefs"""
         st = None
-        if getattr(self.device, "type", str(self.device)) == "cuda" and hasattr(self.store, "ctx"):
+        if self.device.type == "cuda" and hasattr(self.store, "ctx"):
             st = self.torch.cuda.current_stream(self.device).cuda_stream       # launches, collective and scatter on ONE stream
             self.store.ctx.set_stream(st)
         if plan["up"] is not None:

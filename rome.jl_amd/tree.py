@@ -222,7 +222,10 @@ class TreeSolver:
     outward solve takes a variable's proposals from the neighbours solved before it only)."""
 
     def __init__(self, fg, tree=None, order="mmd", last=(), messages="relative", gibbsIters=3, downIters=1, rootIters=0, refineIters=0,
-                 backend=None, ctx=None):
+                 backend=None, ctx=None, shard=None):
+        """shard: a factory `store -> distributed.FrontierShard` (the store exists only once the lifted universe is known): every level is
+        then dealt to the ranks by clique -- share up-solve, ONE all-gather of the level's written blocks, one scatter; the block
+        operations between levels run on every rank (each holds the whole store)."""
         from .graph import FactorGraph
         if messages not in ("relative", "marginal"):
             raise ValueError("messages must be 'relative' or 'marginal'")
@@ -246,6 +249,10 @@ class TreeSolver:
         B = self.backend
         ops = lambda s: ([B.BlockOp(self.store, "copy", s.copies)] if s.copies else []) + ([B.BlockOp(self.store, "anchor", s.anchors)] if s.anchors else [])
         self.up_pre = [ops(s) for s in ups]
+        self.shard = shard(self.store) if shard is not None else None
+        if self.shard is not None:
+            base = B
+            B = _ShardedPlans(base, lambda s: self.shard.plan_level(s, base.Plan))
         self.up_plans = [B.Plan(self.store, s) if s.order else None for s in ups]
         self.up_post = [[B.BlockOp(self.store, "relative", s.relatives)] if s.relatives else [] for s in ups]
         self.down_plans = [B.Plan(self.store, s) if s.order else None for s in downs]
@@ -465,7 +472,10 @@ class TreeSolver:
     def _run(self, plan, opts):
         o = type(opts).from_buffer_copy(opts)
         o.stream_offset = opts.stream_offset + (self.runs << 36)     # (it << 32) + family / product offsets stay below 2^36
-        plan.run(o)
+        if self.shard is not None:
+            self.shard.step(plan, o)
+        else:
+            plan.run(o)
         self.runs += 1
 
     def upload(self, fg=None):
@@ -507,6 +517,19 @@ class TreeSolver:
                     up_rows=sum(len(s.pairs) for s in self.up_specs), down_rows=sum(len(s.pairs) for s in self.down_specs),
                     store_messages=sum(len(s.smsgs) for s in self.up_specs), relative_messages=sum(len(s.relatives) for s in self.up_specs),
                     blocks=len(self.universe.variables), unreached=len(getattr(self, "unreached", ())))
+
+
+class _ShardedPlans:
+    """backend view whose Plan() returns a FrontierShard level plan (share up-solve + exchange + scatter); block operations unchanged"""
+
+    def __init__(self, backend, make):
+        self.backend, self.make = backend, make
+
+    def Plan(self, store, spec):
+        return self.make(spec)
+
+    def BlockOp(self, store, op, entries):
+        return self.backend.BlockOp(store, op, entries)
 
 
 class DeviceBackend:

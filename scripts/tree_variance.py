@@ -8,6 +8,11 @@ G2O = "/root/repo/tests/golden/manhattan.g2o"
 fg = R.loadG2o(G2O, N=N)
 xp = R.solveGraphParametric(R.dead_reckon_init(R.loadG2o(G2O, N=N), seed=1))
 labels = list(fg.variables); mp = np.array([xp[l] for l in labels])
+if len(sys.argv) > 4 and sys.argv[4] == "tight":      # experiment: a prior that pins the gauge (what remains is not gauge noise)
+    for k, (fl, ls, f) in enumerate(fg.factors):
+        if isinstance(f, R.PriorPose2):
+            fg.factors[k] = (fl, ls, R.PriorPose2(R.MvNormal(f.Z.mu, np.diag([1e-6, 1e-6, 1e-6])))); fg._findex[fl] = fg.factors[k]
+    print("tight prior")
 R.initAllOrdered(fg, seed=1)
 ts = TreeSolver(fg, messages="relative", rootIters=int(sys.argv[1]), refineIters=int(sys.argv[2]), last=(("x0",) if len(sys.argv) > 3 and sys.argv[3] == "last" else ()))
 print(ts.tree.summary())

@@ -251,3 +251,17 @@ class OracleTreeBackend:
 
     def BlockOp(self, store, op, entries):
         return OracleTreeBlockOp(store, op, entries)
+
+
+class OracleTreeScatter:
+    """receive side of a level exchange over an OracleTreeStore: slot b (units of `stride` doubles) of the receive buffer -> the block of a
+    lifted label"""
+
+    def __init__(self, store, labels, src_blocks, stride=0):
+        self.store, self.labels, self.blocks, self.stride = store, list(labels), list(src_blocks), int(stride or 6 * store.N)
+
+    def run(self, src):
+        st = self.store
+        for l, b in zip(self.labels, self.blocks):
+            d = st.fg.variables[l].dim
+            st.vals[l] = src[b * self.stride:b * self.stride + d * st.N].numpy().reshape(d, st.N).copy()

@@ -653,3 +653,74 @@ def test_frontier_shard_validates_independence_over_the_whole_frontier():
         sh = FrontierShard(OracleStore(R, fg), torch, None, 2, rank, plan_cls=OraclePlan, scatter_cls=OracleScatter)
         with pytest.raises(ValueError):
             sh.plan([["x0"], ["x1"]])                          # x0 -- x1 share an odometry factor; each rank owns one of them
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The LEVELS of a Bayes tree through FrontierShard (rome_jl_amd.tree.TreeSolver(shard=...)): multi-frontal cliques, separator copies,
+# absolute and relative messages of the children, sampled-measurement rows -- every level dealt to the ranks by clique, the blocks it
+# writes exchanged in the PACKED per-type layout (Pose2 3 slots, Point2 2), block operations on every rank.  Any world size reproduces
+# the unsharded tree solve bit for bit (Philox streams = positions in the whole level's tables).
+def _tree_graph(R, kind, N):
+    if kind == "hexagon":            # Pose2 + a Point2 landmark among the separators (bearing-range relative messages)
+        fg = R.generateGraph_Hexagonal(N=N)
+        R.dead_reckon_init(fg, seed=5)
+        fg.initVariable("l1", np.array([[20.0], [0.0]]) + np.random.default_rng(1).standard_normal((2, N)))
+        return fg
+    fg = R.initfg(N)                 # the first 40 poses of manhattan.g2o with the loop closures between them
+    ids = set()
+    rows = []
+    for ln in open(os.path.join(ROOT, "tests", "golden", "manhattan.g2o")):
+        t = ln.split()
+        if t and t[0] == "EDGE_SE2" and int(t[1]) < 40 and int(t[2]) < 40:
+            rows.append(t); ids.update((int(t[1]), int(t[2])))
+    for k in sorted(ids):
+        fg.addVariable("x%d" % k, R.Pose2)
+    fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.zeros(3), np.diag([0.01, 0.01, 0.0025]))))
+    for t in rows:
+        u = [float(x) for x in t[6:12]]
+        info = np.array([[u[0], u[1], u[2]], [u[1], u[3], u[4]], [u[2], u[4], u[5]]])
+        C = np.linalg.inv(info)
+        fg.addFactor(["x%s" % t[1], "x%s" % t[2]], R.Pose2Pose2(R.MvNormal(np.array([float(x) for x in t[3:6]]), 0.5 * (C + C.T))))
+    R.dead_reckon_init(fg, seed=3)
+    return fg
+
+
+def _tree_solve(R, kind, messages, N, shard=None):
+    from rome_jl_amd.tree import TreeSolver
+    from dist_standin import OracleTreeBackend
+    fg = _tree_graph(R, kind, N)
+    ts = TreeSolver(fg, messages=messages, backend=OracleTreeBackend(R), shard=shard, gibbsIters=2)
+    ts.upload()
+    ts.solve(R.make_opts(N=N, seed=9), passes=2)
+    return ts, {l: ts.store.get(l).copy() for l in fg.variables}
+
+
+def _tree_worker(rank, world, port, kind, messages, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import rome_jl_amd as R
+        from rome_jl_amd.distributed import FrontierShard
+        from dist_standin import OracleTreeScatter
+        ts, out = _tree_solve(R, kind, messages, 16, shard=lambda store: FrontierShard(store, torch, dist, world, rank, scatter_cls=OracleTreeScatter))
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,kind,messages", [(2, "manhattan", "relative"), (8, "manhattan", "relative"), (2, "hexagon", "relative"), (2, "manhattan", "marginal")])
+def test_tree_levels_sharded_by_clique_equal_the_unsharded_tree_solve(world, kind, messages):
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_tree_worker, args=(world, _free_port(), kind, messages, ret), nprocs=world, join=True)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rome_jl_amd as R
+    ts, ref = _tree_solve(R, kind, messages, 16)
+    assert len(ts.tree.levels) >= 3 and any(len(c.frontals) + len(c.separators) >= 3 for c in ts.tree.cliques)
+    if messages == "relative":
+        assert ts.stats()["relative_messages"] > 0
+    for r in range(world):
+        assert set(ret[r]) == set(ref)
+        for l in ref:
+            assert np.array_equal(ret[r][l], ref[l]), (world, kind, r, l)

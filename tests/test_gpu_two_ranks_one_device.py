@@ -230,6 +230,71 @@ def test_frontier_shard_processes_equal_the_single_unsharded_plan_real_kernels(w
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
+# The LEVELS of a Bayes tree sharded by clique with the REAL kernels (rome_jl_amd.tree.TreeSolver(shard=FrontierShard)): multi-frontal
+# cliques, separator copies, store-resident and sampled-measurement messages; packed per-type exchange layout; block operations on
+# every rank.  2 and 4 processes on one device == the unsharded device solve, bit for bit.
+def _tree_fg(R, N):
+    fg = R.initfg(N)
+    rows, ids = [], set()
+    for ln in open(os.path.join(ROOT, "tests", "golden", "manhattan.g2o")):
+        t = ln.split()
+        if t and t[0] == "EDGE_SE2" and int(t[1]) < 60 and int(t[2]) < 60:
+            rows.append(t); ids.update((int(t[1]), int(t[2])))
+    for k in sorted(ids):
+        fg.addVariable("x%d" % k, R.Pose2)
+    fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.zeros(3), np.diag([0.01, 0.01, 0.0025]))))
+    for t in rows:
+        u = [float(x) for x in t[6:12]]
+        C = np.linalg.inv(np.array([[u[0], u[1], u[2]], [u[1], u[3], u[4]], [u[2], u[4], u[5]]]))
+        fg.addFactor(["x%s" % t[1], "x%s" % t[2]], R.Pose2Pose2(R.MvNormal(np.array([float(x) for x in t[3:6]]), 0.5 * (C + C.T))))
+    R.dead_reckon_init(fg, seed=3)
+    return fg
+
+
+def _tree_worker(rank, world, port, ret, N, messages):
+    torch, dist, R = _init(rank, world, port)
+    try:
+        from rome_jl_amd.distributed import FrontierShard
+        from rome_jl_amd.tree import TreeSolver
+        dev = torch.device("cuda", 0)
+        ctx = R.Context(0)
+        fg = _tree_fg(R, N)
+        box = {}
+
+        def shard(store):
+            box["comm"] = HostStagedComm(torch, dist, world, ctx)
+            return FrontierShard(store, torch, dist, world, rank, device=dev, comm=box["comm"])
+        ts = TreeSolver(fg, messages=messages, ctx=ctx, shard=shard)
+        ts.upload(); ts.solve(R.make_opts(N=N, seed=13), passes=2)
+        torch.cuda.synchronize()
+        ret[rank] = ({l: ts.store.get(l).copy() for l in fg.variables}, box["comm"].calls)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,messages", [(2, "relative"), (4, "relative"), (2, "marginal")])
+def test_tree_levels_sharded_by_clique_processes_equal_the_unsharded_tree_solve_real_kernels(world, messages):
+    import torch
+    import torch.multiprocessing as mp
+    import rome_jl_amd as R
+    from rome_jl_amd.tree import TreeSolver
+    N = 64
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_tree_worker, args=(world, _free_port(), ret, N, messages), nprocs=world, join=True)
+    fg = _tree_fg(R, N)
+    ts = TreeSolver(fg, messages=messages)
+    ts.upload(); ts.solve(R.make_opts(N=N, seed=13), passes=2)
+    torch.cuda.synchronize()
+    assert len(ts.tree.levels) > 5 and (messages == "marginal" or ts.stats()["relative_messages"] > 5)
+    for r in range(world):
+        got, calls = ret[r]
+        assert calls > len(ts.tree.levels)           # one exchange per level and pass (up and down)
+        for l in fg.variables:
+            assert np.array_equal(got[l], ts.store.get(l)), (world, r, l)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
 # bench.py under the launcher, exactly the driver's command line for N = 2 and N = 8, as N real processes (ROME_BENCH_SHARED_DEVICE=1: both on
 # device 0, gloo process group, host-staged exchange): per-rank graph segments and tables, the pipeline, the barriers, the
 # max-over-ranks reduction and rank 0's single JSON line all execute -- the flow an 8-GPU run takes, which no box available here can make.
