@@ -219,9 +219,10 @@ class TreeSolver:
     messages: "relative" or "marginal" (module docstring).  gibbsIters / downIters: iterations of the up / down clique solves in
     "marginal" form (IIF: 3 / 1).  The "relative" form solves every variable ONCE outward (up and down); rootIters / refineIters add
     Gibbs sweeps over the frontals of the root / of every clique in the down pass with ALL factors and messages of the clique (the
-    outward solve takes a variable's proposals from the neighbours solved before it only)."""
+    outward solve takes a variable's proposals from the neighbours solved before it only); relIters the same inside the relative solve
+    of the up pass (anchor fixed), before the samples of anchor^-1 * separator are taken."""
 
-    def __init__(self, fg, tree=None, order="mmd", last=(), messages="relative", gibbsIters=3, downIters=1, rootIters=0, refineIters=0,
+    def __init__(self, fg, tree=None, order="mmd", last=(), messages="relative", gibbsIters=3, downIters=1, rootIters=0, refineIters=0, relIters=0,
                  backend=None, ctx=None, shard=None):
         """shard: a factory `store -> distributed.FrontierShard` (the store exists only once the lifted universe is known): every level is
         then dealt to the ranks by clique -- share up-solve, ONE all-gather of the level's written blocks, one scatter; the block
@@ -233,6 +234,9 @@ class TreeSolver:
         self.tree = tree or BayesTree.build(list(fg.variables), [(fl, tuple(ls)) for fl, ls, _ in fg.factors], order=order, last=last)
         self.backend = backend or DeviceBackend(ctx)
         self.gibbsIters, self.downIters, self.rootIters, self.refineIters = int(gibbsIters), int(downIters), int(rootIters), int(refineIters)
+        self.relIters = int(relIters)
+        if not 0 <= self.relIters <= 16:
+            raise ValueError("relIters must be in 0..16")
         if not (1 <= self.gibbsIters <= 16 and 1 <= self.downIters <= 16 and 0 <= self.rootIters <= 16 and 0 <= self.refineIters <= 16):
             raise ValueError("gibbsIters / downIters must be in 1..16")       # Philox: run k draws from k << 36
         self.findex = {fl: (fl, ls, f) for fl, ls, f in fg.factors}
@@ -258,6 +262,7 @@ class TreeSolver:
         self.down_plans = [B.Plan(self.store, s) if s.order else None for s in downs]
         self.root_plans = [B.Plan(self.store, s) if s is not None and s.order else None for s in getattr(self, "root_specs", [None] * len(ups))]
         self.refine_plans = [B.Plan(self.store, s) if s is not None and s.order else None for s in getattr(self, "refine_specs", [None] * len(ups))]
+        self.rel_plans = [B.Plan(self.store, s) if s is not None and s.order else None for s in getattr(self, "rel_specs", [None] * len(ups))]
         self.runs = 0
 
     def _lift(self, L, fl, cid, tag, labels, factor):
@@ -327,7 +332,7 @@ class TreeSolver:
         ups, downs = [], []
         abs_msgs, rel_msgs = {}, {}          # clique -> [(source label, variable)] / [(anchor, separator, samples label)]
         self.anchor, self.unreached = {}, []
-        down_parts = {}
+        down_parts, rel_parts = {}, {}
         for lvl in t.levels:
             L = FactorGraph(fg.N)
             cliques, pairs_of, smsgs, anchors, relatives = [], {}, [], [], []
@@ -388,6 +393,7 @@ class TreeSolver:
                     rounds, left = _outward(list(F) + [s for s in S if s != anc], (anc,), pwl, ())
                     add(rounds, lab, "@", False)
                     reached = {v for rnd in rounds for v, _, _ in rnd}
+                    rel_parts[cid] = (pw, reached, anc)
                     for s in S:
                         if s != anc and s in reached and vt[s] in (Pose2, Point2):
                             zl = "%s~%d" % (s, cid)
@@ -464,6 +470,37 @@ class TreeSolver:
                     pairs_of[v] = rows
                 cliques.append((F, [col[v] for v in F]))
             return LevelSpec(L, cliques, pairs_of, smsgs, iters)
+        def rel_sweeps(lvl):
+            if self.relIters <= 0:
+                return None
+            L = FactorGraph(fg.N)
+            cliques, pairs_of = [], {}
+            for cid in lvl:
+                if cid not in rel_parts:
+                    cliques.append(([], [])); continue
+                pw, reached, anc = rel_parts[cid]
+                lab = lambda v: "%s@%d" % (v, cid)
+                known = reached | {anc}
+                T = [v for v in t.cliques[cid].frontals + t.cliques[cid].separators if v in reached]
+                nb = {v: set() for v in T}
+                use = [(fid, ls, f) for fid, ls, f in pw if all(o in known for o in ls)]
+                for _, ls, _ in use:
+                    for v in ls:
+                        if v in nb:
+                            nb[v].update(o for o in ls if o != v and o in nb)
+                col = _colour(T, nb.__getitem__)
+                for v in T:
+                    self._need(L, lab(v), fg.variables[v])
+                    rows = []
+                    for fid, ls, f in use:
+                        if v in ls:
+                            for o in ls:
+                                self._need(L, lab(o), fg.variables[o])
+                            rows.append(self._lift(L, fid, cid, "%" + v + ":", [lab(o) for o in ls], f))
+                    pairs_of[lab(v)] = rows
+                cliques.append(([lab(v) for v in T], [col[v] for v in T]))
+            return LevelSpec(L, cliques, pairs_of, [], self.relIters)
+        self.rel_specs = [rel_sweeps(lvl) for lvl in t.levels]
         self.root_specs = [sweeps(lvl, True, self.rootIters) for lvl in t.levels]
         self.refine_specs = [sweeps(lvl, False, self.refineIters) for lvl in t.levels]
         return ups, downs
@@ -483,11 +520,13 @@ class TreeSolver:
         self.store.upload(fg or self.fg)
 
     def up(self, opts):
-        for pre, pl, post, rp in zip(self.up_pre, self.up_plans, self.up_post, self.root_plans):
+        for pre, pl, post, rp, rl in zip(self.up_pre, self.up_plans, self.up_post, self.root_plans, self.rel_plans):
             for op in pre:
                 op.run()
             if pl is not None:
                 self._run(pl, opts)
+            if rl is not None:
+                self._run(rl, opts)
             for op in post:
                 op.run()
             if rp is not None:

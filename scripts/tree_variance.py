@@ -14,7 +14,7 @@ if len(sys.argv) > 4 and sys.argv[4] == "tight":      # experiment: a prior that
             fg.factors[k] = (fl, ls, R.PriorPose2(R.MvNormal(f.Z.mu, np.diag([1e-6, 1e-6, 1e-6])))); fg._findex[fl] = fg.factors[k]
     print("tight prior")
 R.initAllOrdered(fg, seed=1)
-ts = TreeSolver(fg, messages="relative", rootIters=int(sys.argv[1]), refineIters=int(sys.argv[2]), last=(("x0",) if len(sys.argv) > 3 and sys.argv[3] == "last" else ()))
+ts = TreeSolver(fg, messages="relative", rootIters=int(sys.argv[1]), refineIters=int(sys.argv[2]), relIters=int(os.environ.get("REL", "0")), last=(("x0",) if len(sys.argv) > 3 and sys.argv[3] == "last" else ()))
 print(ts.tree.summary())
 print("rootIters", sys.argv[1], "refineIters", sys.argv[2])
 root = [v for c in ts.tree.cliques if c.parent < 0 for v in c.frontals]

@@ -127,3 +127,40 @@ def test_belief_means_equal_reference_ppe_means():
     assert np.abs(wrap(mean[tight, 2] - ppe_mean[tight, 2])).max() < 2e-6
     # "suggested" = (mean x, mean y, max-density heading): translation part again the mean
     assert np.abs(mean[:, :2] - d["ppe"][:, 0, :2]).max() < 2e-6
+
+
+def test_tree_solve_of_the_reference_graph_sits_in_the_band_of_the_reference_solve():
+    """The reference's own Manhattan-500 graph (361 poses, 500 Pose2Pose2 + the prior) through `initAllOrdered` + the Bayes tree solve
+    (rome_jl_amd.tree, no parametric start): the distance of our pose means to the parametric optimum is within the distance of the
+    REFERENCE's solveTree! result to it (the statistical band the reference itself defines: < 3 m RMS, SURVEY §8(c) "Artefact")."""
+    from rome_jl_amd.tree import TreeSolver
+    d, ref, _ = _graph()
+    V, _, N = ref.shape
+    fg = R.initfg(N)
+    for k in range(V):
+        fg.addVariable("x%d" % k, R.Pose2)
+    fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(d["prior_mu"], d["prior_cov"])))
+    for (i, j), m, c in zip(d["edges"], d["mu"], d["cov"]):
+        fg.addFactor(["x%d" % i, "x%d" % j], R.Pose2Pose2(R.MvNormal(m, c)))
+    fgp = R.initfg(N)
+    fgp.variables, fgp.factors = fg.variables, fg.factors
+    xp = R.solveGraphParametric(R.dead_reckon_init(fgp, seed=1))
+    X = np.array([xp["x%d" % k] for k in range(V)])
+    rms = lambda M: float(np.sqrt(np.mean(np.sum((M[:, :2] - X[:, :2]) ** 2, axis=1))))   # noqa: E731
+    theirs = rms(d["ppe"][:, 2])                                   # the reference's ppe.mean against the parametric optimum
+    fg.vals = {}
+    R.initAllOrdered(fg, seed=3)
+    ts = TreeSolver(fg, messages="relative")
+    assert len(ts.tree.levels) > 10 and ts.stats()["relative_messages"] > 100
+    ts.upload()
+    ours = []
+    for ps in range(3):
+        ts.solve(R.make_opts(N=N, seed=40 + ps)); ts.download()
+        m, _ = R.belief_stats(np.stack([fg.getVal("x%d" % k) for k in range(V)]))
+        ours.append(rms(m))
+    assert 0.5 < theirs < 3.0, theirs
+    assert np.median(ours) < max(theirs, 1.0) and min(ours) < theirs, (ours, theirs)
+    # and against the reference's posterior itself: most of our pose means inside its particle clouds (3 standard deviations + 1 m)
+    mref, sref = stats(ref)
+    dz = m[:, :2] - mref[:, :2]
+    assert (np.abs(dz) < 3.0 * sref[:, :2] + 1.0).all(axis=1).mean() > 0.6

@@ -78,45 +78,46 @@ def test_beehive_multihypo_schedule_runs_from_nothing():
     assert np.isfinite(err).all() and np.median(err) < 3.0, np.median(err)
 
 
-def test_manhattan3500_from_init_all_trace():
-    """Manhattan-3500 from NOTHING (no dead reckoning, no parametric start): the init pass, then coloured Gauss-Seidel sweeps; RMS distance
-    of the pose means to the parametric solution per stage and the wall-clock of every stage -> gpurun_out/r04_ordered_solve.txt"""
-    import torch
+def test_manhattan3500_from_init_all_the_tree_solve_beats_the_sweeps():
+    """Manhattan-3500 from NOTHING (no dead reckoning, no parametric start): the init pass stalls at ~5.3 m RMS from the parametric solution
+    and coloured Gauss-Seidel sweeps stay there (profiles/r04_ordered_solve.txt); the Bayes tree solve (rome_jl_amd.tree, relative
+    messages) removes the loop error the init pass froze in.  A pass is a stochastic estimate (N = 100): asserted on three passes."""
+    from rome_jl_amd.tree import TreeSolver
     N = 100
-    fg = R.loadG2o(os.path.join(ROOT, "tests", "golden", "manhattan.g2o"), N=N)
-    t0 = time.perf_counter(); xp = R.solveGraphParametric(R.dead_reckon_init(R.loadG2o(os.path.join(ROOT, "tests", "golden", "manhattan.g2o"), N=N), seed=1))
-    t_par = time.perf_counter() - t0
-    labels = [l for l in fg.variables]
+    g2o = os.path.join(ROOT, "tests", "golden", "manhattan.g2o")
+    fg = R.loadG2o(g2o, N=N)
+    xp = R.solveGraphParametric(R.dead_reckon_init(R.loadG2o(g2o, N=N), seed=1))
+    labels = list(fg.variables)
     mp = np.array([xp[l] for l in labels])
-    store = DeviceStore(fg, upload=False)
-    t0 = time.perf_counter(); osv = OrderedSolve(store, kind="colour"); t_plan = time.perf_counter() - t0
-    ptr, _ = store.device_ptr(R.Pose2)
 
-    def rms():
-        bel = np.zeros((len(labels), 3, N))
-        R._lib.check(R._lib.load().rome_store_download(store.handle, 0, 0, 0, len(labels), bel.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double))), store.ctx.handle)
-        m, _ = R.belief_stats(bel)
-        return float(np.sqrt(np.mean(np.sum((m[:, :2] - mp[:, :2]) ** 2, axis=1)))), float(np.median(bel[:, :2].std(axis=2)))
-    lines = []
-    store.ctx.synchronize(); t0 = time.perf_counter()
-    osv.init(R.make_opts(N=N, seed=1)); store.ctx.synchronize()
-    t_init = time.perf_counter() - t0
-    r0, s0 = rms()
-    lines.append("init pass (%d levels, %d groups): %.3f s -> RMS to the parametric solution %.3f m, median belief std %.3f m" % (len(osv.levels), len(osv.init_plans), t_init, r0, s0))
-    trace = [r0]
-    t_sw = 0.0
-    for k in range(20):
-        store.ctx.synchronize(); t0 = time.perf_counter()
-        osv.sweep(R.make_opts(N=N, seed=100 + k)); store.ctx.synchronize()
-        t_sw += time.perf_counter() - t0
-        r, s = rms(); trace.append(r)
-        if k < 5 or k % 5 == 4:
-            lines.append("sweep %2d (%d colour classes): cumulative %.3f s -> RMS %.3f m, median belief std %.3f m" % (k + 1, len(osv.sweep_plans), t_sw, r, s))
-    assert np.isfinite(trace).all() and trace[0] < 8.0 and trace[-1] < 8.0     # dead reckoning: 21.9 m; whole-graph Jacobi from it: 21.4 m after 100 iterations
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r04_ordered_solve.txt"), "w") as f:
-        f.write("OrderedSolve on Manhattan-3500 (N=100), device-resident (DeviceStore + one rome_upsolve_plan per independent group), from NO beliefs:\n"
-                "plans built in %.2f s (host, once); parametric reference solution %.2f s\n" % (t_plan, t_par) + "\n".join(lines) + "\n")
+    def rms(aligned=False):
+        m, _ = R.belief_stats(np.stack([fg.getVal(l) for l in labels]))
+        A, B = m[:, :2], mp[:, :2]
+        if aligned:
+            A, B = A - A.mean(0), B - B.mean(0)
+            U, _, Vt = np.linalg.svd(A.T @ B); Rr = (U @ Vt).T
+            if np.linalg.det(Rr) < 0:
+                Rr = (U @ np.diag([1.0, -1.0]) @ Vt).T
+            A = A @ Rr.T
+        return float(np.sqrt(np.mean(np.sum((A - B) ** 2, axis=1))))
+    osv = R.initAllOrdered(fg, seed=1)
+    r_init = rms()
+    osv.sweep(R.make_opts(N=N, seed=100), 5); osv.store.download(fg)
+    r_sweeps = rms()
+    assert 4.0 < r_init < 7.0 and r_sweeps > 4.0              # the stall
+    ts = TreeSolver(fg, messages="relative")
+    st = ts.stats()
+    assert st["levels"] < 80 and st["width_max"] > 500 and st["unreached"] == 0, st
+    ts.upload()
+    raw, ali, secs = [], [], []
+    for ps in range(3):
+        store_ctx = ts.store.ctx
+        store_ctx.synchronize(); t0 = time.perf_counter()
+        ts.solve(R.make_opts(N=N, seed=100 + ps)); store_ctx.synchronize()
+        secs.append(time.perf_counter() - t0)
+        ts.download()
+        raw.append(rms()); ali.append(rms(True))
+    assert min(raw) < 0.6 * r_init and np.median(ali) < 2.5 and max(secs) < 1.5, (r_init, raw, ali, secs)
 
 
 def test_init_all_ordered_keeps_existing_beliefs_and_solve_graph_takes_it():
@@ -138,4 +139,3 @@ def test_init_all_ordered_keeps_existing_beliefs_and_solve_graph_takes_it():
     for l, (x, y) in want.items():
         p = fg2.getVal(l)
         assert np.mean((np.abs(p[0] - x) < 3.0) & (np.abs(p[1] - y) < 3.0)) > 0.55, (l, p[:2].mean(1))
-    assert hasattr(fg2, "ppe") or True
