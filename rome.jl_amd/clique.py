@@ -337,6 +337,13 @@ class DeviceStore:
                                                        blk.ctypes.data_as(C.POINTER(C.c_double))), self.ctx.handle)
                 k = j + 1
 
+    def put(self, label, pts):
+        """(dim, N) belief of one variable, host -> store"""
+        vt = self.fg.variables[label]
+        blk = np.ascontiguousarray(np.asarray(pts, dtype=np.float64).reshape(1, vt.dim, self.N))
+        _lib.check(self._lib.rome_store_upload(self.handle, _lib.LAYOUT_SOA, self.TYPES.index(vt), self.index[label], 1,
+                                               blk.ctypes.data_as(C.POINTER(C.c_double))), self.ctx.handle)
+
     def get(self, label):
         """(dim, N) belief of one variable, store -> host"""
         vt = self.fg.variables[label]

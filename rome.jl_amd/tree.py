@@ -141,6 +141,9 @@ class BayesTree:
 
 
 # ------------------------------------------------------------------------------------------------------------------ the solve
+ZERO = "0~"          # a Pose2 block that stays zero: the samples of an identity row (tree.TreeSolver max_product)
+
+
 def _colour(order, nbr):
     """greedy colouring of `order` (list) under adjacency nbr(v) -> iterable; -> {v: colour}"""
     col = {}
@@ -220,10 +223,15 @@ class TreeSolver:
     "marginal" form (IIF: 3 / 1).  The "relative" form solves every variable ONCE outward (up and down); rootIters / refineIters add
     Gibbs sweeps over the frontals of the root / of every clique in the down pass with ALL factors and messages of the clique (the
     outward solve takes a variable's proposals from the neighbours solved before it only); relIters the same inside the relative solve
-    of the up pass (anchor fixed), before the samples of anchor^-1 * separator are taken."""
+    of the up pass (anchor fixed), before the samples of anchor^-1 * separator are taken.
+    max_product ("relative" form): a Pose2 variable with more proposals than this takes its product in TWO stages -- partial products
+    over chunks of at most max_product proposals (scratch blocks, all chunks of all variables of the step in one launch), then the
+    product of the partial products (each enters through an identity row: a sampled-measurement Pose2Pose2 row whose samples are all
+    zero).  The multiscale Gibbs product is ONE two-wave block per variable and its time grows with the square of the number of
+    proposals (42 proposals: 14 ms with the rest of the chip idle; profiles/r05_tree_solve.txt); 0 = one product whatever the count."""
 
     def __init__(self, fg, tree=None, order="mmd", last=(), messages="relative", gibbsIters=3, downIters=1, rootIters=0, refineIters=0, relIters=0,
-                 backend=None, ctx=None, shard=None):
+                 max_product=8, backend=None, ctx=None, shard=None):
         """shard: a factory `store -> distributed.FrontierShard` (the store exists only once the lifted universe is known): every level is
         then dealt to the ranks by clique -- share up-solve, ONE all-gather of the level's written blocks, one scatter; the block
         operations between levels run on every rank (each holds the whole store)."""
@@ -234,7 +242,7 @@ class TreeSolver:
         self.tree = tree or BayesTree.build(list(fg.variables), [(fl, tuple(ls)) for fl, ls, _ in fg.factors], order=order, last=last)
         self.backend = backend or DeviceBackend(ctx)
         self.gibbsIters, self.downIters, self.rootIters, self.refineIters = int(gibbsIters), int(downIters), int(rootIters), int(refineIters)
-        self.relIters = int(relIters)
+        self.relIters, self.max_product = int(relIters), int(max_product or 0)
         if not 0 <= self.relIters <= 16:
             raise ValueError("relIters must be in 0..16")
         if not (1 <= self.gibbsIters <= 16 and 1 <= self.downIters <= 16 and 0 <= self.rootIters <= 16 and 0 <= self.refineIters <= 16):
@@ -250,6 +258,8 @@ class TreeSolver:
             ups, downs = self._specs_relative()
         self.up_specs, self.down_specs = ups, downs
         self.store = self.backend.Store(U)
+        if ZERO in U.variables:
+            self.store.put(ZERO, np.zeros((3, fg.N)))
         B = self.backend
         ops = lambda s: ([B.BlockOp(self.store, "copy", s.copies)] if s.copies else []) + ([B.BlockOp(self.store, "anchor", s.anchors)] if s.anchors else [])
         self.up_pre = [ops(s) for s in ups]
@@ -275,6 +285,54 @@ class TreeSolver:
         if fl in getattr(fg, "nullhypo", {}):
             L.nullhypo[nfl] = fg.nullhypo[fl]
         return nfl
+
+    def _split_products(self, L, cliques, pairs_of, smsgs):
+        """two-stage products for Pose2 variables with more than max_product proposals (class docstring): partial-product variables in
+        step 2g, everything else in step 2g + 1"""
+        from .factors import Pose2
+        from .clique import SampledPose2Pose2
+        G = self.max_product
+        by_dest = {}
+        for src, dst in smsgs:
+            by_dest.setdefault(dst, []).append(src)
+        if G <= 0 or not any(len(pairs_of.get(l, ())) + len(by_dest.get(l, ())) > G and L.variables[l] is Pose2 for upd, _ in cliques for l in upd):
+            return cliques, pairs_of, smsgs
+        out_cliques, out_smsgs = [], []
+        for upd, grp in cliques:
+            nu, ng = [], []
+            for l, g in zip(upd, grp):
+                items = [("f", fl) for fl in pairs_of.get(l, ())] + [("m", src) for src in by_dest.get(l, ())]
+                if len(items) <= G or L.variables[l] is not Pose2:
+                    nu.append(l); ng.append(2 * g + 1); out_smsgs += [(src, l) for src in by_dest.get(l, ())]
+                    continue
+                nch = -(-len(items) // G)
+                rows_v = []
+                for k in range(nch):
+                    pl = "%s^%d" % (l, k)
+                    self._need(L, pl, Pose2)
+                    rows = []
+                    for kind, x in items[k::nch]:
+                        if kind == "f":
+                            _, labels, f = L.getFactor(x)
+                            nfl = "%s^%d" % (x, k)
+                            L.factors.append((nfl, [pl if o == l else o for o in labels], f)); L._findex[nfl] = L.factors[-1]
+                            if x in L.multihypo:
+                                L.multihypo[nfl] = L.multihypo[x]
+                            if x in L.nullhypo:
+                                L.nullhypo[nfl] = L.nullhypo[x]
+                            rows.append(nfl)
+                        else:
+                            out_smsgs.append((x, pl))
+                    pairs_of[pl] = rows
+                    nu.append(pl); ng.append(2 * g)
+                    idf = "=%s" % pl                                   # identity row: proposal = the partial product itself
+                    self._need(L, ZERO, Pose2)
+                    L.factors.append((idf, [pl, l], SampledPose2Pose2(ZERO))); L._findex[idf] = L.factors[-1]
+                    rows_v.append(idf)
+                pairs_of[l] = rows_v
+                nu.append(l); ng.append(2 * g + 1)
+            out_cliques.append((nu, ng))
+        return out_cliques, pairs_of, out_smsgs
 
     def _need(self, L, label, vt):
         if label not in self.universe.variables:
@@ -402,6 +460,7 @@ class TreeSolver:
                             relatives.append((lab[anc], lab[s], zl)); rel_msgs[cid].append((anc, s, zl))
                 cliques.append((upd, grp))
                 down_parts[cid] = (pw, pri, srcs)
+            cliques, pairs_of, smsgs = self._split_products(L, cliques, pairs_of, smsgs)
             ups.append(LevelSpec(L, cliques, pairs_of, smsgs, 1, anchors=anchors, relatives=relatives))
         # ---- down pass: the frontals outward from the separators (at their posteriors), the priors and the children's anchor marginals
         for lvl in t.levels:
@@ -435,6 +494,7 @@ class TreeSolver:
                         upd.append(v); grp.append(r)
                 self.unreached += [(cid, v) for v in left]
                 cliques.append((upd, grp))
+            cliques, pairs_of, smsgs = self._split_products(L, cliques, pairs_of, smsgs)
             downs.append(LevelSpec(L, cliques, pairs_of, smsgs, 1))
         # ---- Gibbs sweeps over the frontals with every factor and message of the clique (roots after the up pass, the others after
         #      their outward down solve): colour classes of the clique's own graph
@@ -469,6 +529,7 @@ class TreeSolver:
                             self._need(L, src, fg.variables[v]); smsgs.append((src, v))
                     pairs_of[v] = rows
                 cliques.append((F, [col[v] for v in F]))
+            cliques, pairs_of, smsgs = self._split_products(L, cliques, pairs_of, smsgs)
             return LevelSpec(L, cliques, pairs_of, smsgs, iters)
         def rel_sweeps(lvl):
             if self.relIters <= 0:
@@ -499,7 +560,8 @@ class TreeSolver:
                             rows.append(self._lift(L, fid, cid, "%" + v + ":", [lab(o) for o in ls], f))
                     pairs_of[lab(v)] = rows
                 cliques.append(([lab(v) for v in T], [col[v] for v in T]))
-            return LevelSpec(L, cliques, pairs_of, [], self.relIters)
+            cliques, pairs_of, sm = self._split_products(L, cliques, pairs_of, [])
+            return LevelSpec(L, cliques, pairs_of, sm, self.relIters)
         self.rel_specs = [rel_sweeps(lvl) for lvl in t.levels]
         self.root_specs = [sweeps(lvl, True, self.rootIters) for lvl in t.levels]
         self.refine_specs = [sweeps(lvl, False, self.refineIters) for lvl in t.levels]

@@ -71,6 +71,17 @@ if a.levels:
             op.run()
         ctx.synchronize()
         say("  level %2d: width %4d, steps %2d, rows %5d, %.3f ms" % (h, w[h], len(set(sp.groups)) * sp.gibbs_iters, len(sp.pairs), 1e3 * (time.perf_counter() - t0)))
+if a.levels:
+    say("per level (down pass, root first): width, update steps, rows, largest product (proposals), ms")
+    for h in range(len(ts.down_plans) - 1, -1, -1):
+        pl, sp = ts.down_plans[h], ts.down_specs[h]
+        if pl is None:
+            continue
+        kmax = max((sum(1 for p in sp.pairs if p[1] == l) + sum(1 for m in sp.smsgs if m[1] == l)) for l in sp.order)
+        ctx.synchronize(); t0 = time.perf_counter()
+        ts._run(pl, o)
+        ctx.synchronize()
+        say("  level %2d: width %4d, steps %2d, rows %5d, largest product %3d, %.3f ms" % (h, w[h], len(set(sp.groups)) * sp.gibbs_iters, len(sp.pairs), kmax, 1e3 * (time.perf_counter() - t0)))
 if a.out:
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     with open(a.out, "a") as f:

@@ -166,6 +166,9 @@ class OracleTreeStore:
     def get(self, label):
         return self.vals[label]
 
+    def put(self, label, pts):
+        self.vals[label] = np.array(pts, dtype=np.float64)
+
 
 class OracleTreePlan:
     def __init__(self, store, spec, share=None, mirror=None):
