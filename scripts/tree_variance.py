@@ -22,10 +22,13 @@ ridx = [labels.index(v) for v in root]
 lvl_of = {v: c.level for c in ts.tree.cliques for v in c.frontals}
 lv = np.array([lvl_of[l] for l in labels])
 ts.upload()
-for ps in range(6):
+acc = None
+for ps in range(int(os.environ.get('PASSES', '6'))):
     ts.solve(R.make_opts(N=N, seed=500 + ps)); ts.download()
     bel = np.stack([fg.getVal(l) for l in labels]); m, _ = R.belief_stats(bel)
     e = np.sqrt(np.sum((m[:, :2] - mp[:, :2]) ** 2, axis=1))
+    acc = m[:, :2].copy() if acc is None else acc + m[:, :2]
+    print("   mean of the pose means over %d passes: RMS %.3f" % (ps + 1, np.sqrt(np.mean(np.sum((acc / (ps + 1) - mp[:, :2]) ** 2, axis=1)))))
     A, Bm = m[:, :2] - m[:, :2].mean(0), mp[:, :2] - mp[:, :2].mean(0)
     Uu, _, Vt = np.linalg.svd(A.T @ Bm); Rr = (Uu @ Vt).T
     if np.linalg.det(Rr) < 0: Rr = (Uu @ np.diag([1, -1]) @ Vt).T
