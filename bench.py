@@ -701,6 +701,29 @@ def main():
         except Exception as e:   # noqa: BLE001
             out["solve"]["from_tree"] = {"error": repr(e)}
 
+        # ---- BASELINE configs[4] ("synthetic SE(3) helix, 10k Pose3 + Pose3Pose3, parametric Gauss-Newton batched Jacobians"): where the time
+        # of the parametric solve goes.  The GPU part is the batched residual / Jacobian kernels (k_lin<...>, tables device-resident across
+        # iterations); the sparse normal equations are solved on the HOST (scipy) -- stated, so nobody reads the wall-clock as GPU work
+        try:
+            from rome_jl_amd.distributed import LinearizeShard
+            fgh = R.synth_helix3d(P=10000, N=8)
+            R.dead_reckon_init_pose3(fgh, seed=7)
+            lsh = LinearizeShard(torch, None, 1, 0, device=dev)
+            stt = {}
+            a = time.perf_counter(); R.solveGraphParametric(fgh, max_iters=40, ctx=ctx, shard=lsh, stats=stt); t_h = time.perf_counter() - a
+            sh_ = stt.get("shard", {})
+            out["parametric_helix10k"] = {
+                "what": "10 000 Pose3, %d Pose3Pose3 + 1 PriorPose3, Levenberg-Marquardt: every iteration = one k_lin launch per factor kind (rows of this rank) + "
+                        "host sparse solve of the 60 000-unknown normal equations" % (len(fgh.factors) - 1),
+                "wall_clock_s": t_h, "iterations": stt["iterations"], "linearizations": stt["linearizations"], "setup_s": stt["setup_s"],
+                "linearize_s": stt["linearize_s"], "host_solve_s": stt["host_solve_s"],
+                "linearize_split_ms": {k: sh_.get(k) for k in ("upload_ms", "kernel_ms", "exchange_ms", "download_ms")},
+                "host_fraction": stt["host_solve_s"] / max(t_h, 1e-9),
+                "note": "linearize_s includes the host-side gather X[ia], the upload of the gathered coordinates, the kernels, the download and the sparse assembly; "
+                        "kernel_ms is the synchronised launch time of the k_lin kernels alone (profiles/r05_linearize_trace.md has their rocprof rows)"}
+        except Exception as e:   # noqa: BLE001
+            out["parametric_helix10k"] = {"error": repr(e)}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R, pk, fg, N, args.cpu_seconds)
         gpu = dict(out.get("gpu_convolutions_per_s_by_solver", {}))

@@ -524,18 +524,83 @@ class FrontierShard:
 
 class LinearizeShard:
     """Row-sharded `rome_linearize` for the parametric solver (`solveGraphParametric(..., shard=LinearizeShard(...))`): rank k
-    evaluates rows shard_range(F, world, k) of every factor kind and an `all_gather` of the padded (r, Ja, Jb) blocks gives every
-    rank the full linearisation, so all ranks take the same Levenberg-Marquardt step.  `kernel` is the per-rank evaluator
-    (default: the HIP entry point through `api.linearize`; the CPU tests inject a stand-in)."""
+    evaluates rows shard_range(F, world, k) of every factor kind and an all-gather of the padded (r | Ja | Jb) blocks gives every
+    rank the full linearisation, so all ranks take the same Levenberg-Marquardt step.
+    On a CUDA device (default kernel) everything between the host's X[ia] gather and the final download stays on the device: the
+    factor tables mu / W of the rank's rows are uploaded ONCE, an iteration uploads the gathered coordinates (xa, xb), launches
+    `rome_linearize_dev` writing straight into this rank's slice of the receive buffer, all-gathers in place (`comm`: a direct RCCL
+    communicator, rome_jl_amd.rccl; else torch.distributed) and downloads the full blocks once.  `stats` accumulates where the time
+    went (ms): upload, kernel, exchange, download -- the host sparse solve is timed by solveGraphParametric.
+    `kernel` = a per-rank evaluator on HOST arrays (the CPU tests inject a stand-in): the round-trip form."""
 
-    def __init__(self, torch, dist, world, rank, device="cpu", kernel=None):
-        self.torch, self.dist, self.world, self.rank, self.device = torch, dist, world, rank, device
+    def __init__(self, torch, dist, world, rank, device="cpu", kernel=None, comm=None):
+        self.torch, self.dist, self.world, self.rank, self.device = torch, dist, world, rank, torch.device(device)
+        self.comm = comm
+        self.on_device = kernel is None and self.device.type == "cuda"
         if kernel is None:
             from . import api
             kernel = api.linearize
         self.kernel = kernel
+        self.cache = {}
+        self.stats = dict(calls=0, upload_ms=0.0, kernel_ms=0.0, exchange_ms=0.0, download_ms=0.0)
+
+    def _linearize_dev(self, kind, mu, W, xa, xb, ctx):
+        import ctypes as C
+        import time
+        from . import _lib, api
+        torch = self.torch
+        ctx = ctx or api.default_context()
+        dz, dr, da, db = api._LIN_DIMS[kind]
+        F = len(mu)
+        lo, hi = shard_range(F, self.world, self.rank)
+        n = hi - lo
+        q = -(-F // self.world)                                  # rows per rank, padded
+        per = dr * (1 + da + db)
+        key = (kind, id(mu), F)
+        if key not in self.cache:                                # the factor tables of this rank's rows: device-resident across iterations
+            t = lambda a: torch.as_tensor(np.ascontiguousarray(a[lo:hi], dtype=np.float64), device=self.device)   # noqa: E731
+            self.cache[key] = dict(mu=t(np.asarray(mu).reshape(F, dz)), W=t(np.asarray(W).reshape(F, dr * dr)),
+                                   recv=torch.zeros(self.world * q * per, dtype=torch.float64, device=self.device),
+                                   xa=torch.empty((max(n, 1), da), dtype=torch.float64, device=self.device),
+                                   xb=torch.empty((max(n, 1), max(db, 1)), dtype=torch.float64, device=self.device))
+        c = self.cache[key]
+        st = torch.cuda.current_stream(self.device)
+        ctx.set_stream(st.cuda_stream)
+        tick = time.perf_counter
+        t0 = tick()
+        if n:
+            c["xa"][:n].copy_(torch.as_tensor(np.ascontiguousarray(xa[lo:hi], dtype=np.float64)), non_blocking=False)
+            if db:
+                c["xb"][:n].copy_(torch.as_tensor(np.ascontiguousarray(xb[lo:hi], dtype=np.float64)), non_blocking=False)
+        st.synchronize(); t1 = tick()
+        send = c["recv"][self.rank * q * per:(self.rank + 1) * q * per]
+        base = send.data_ptr()
+        if n:
+            P = lambda x: C.c_void_p(x)                           # noqa: E731
+            _lib.check(_lib.load().rome_linearize_dev(ctx.handle, int(kind), n, P(c["mu"].data_ptr()), P(c["W"].data_ptr()), P(c["xa"].data_ptr()),
+                                                      P(c["xb"].data_ptr()) if db else None, P(base), P(base + 8 * q * dr),
+                                                      P(base + 8 * q * dr * (1 + da)) if db else None), ctx.handle)
+        st.synchronize(); t2 = tick()
+        if self.world > 1:
+            if self.comm is not None:
+                self.comm.all_gather_f64(send.data_ptr(), c["recv"].data_ptr(), send.numel(), st.cuda_stream)
+            else:
+                self.dist.all_gather_into_tensor(c["recv"], send.clone())
+            st.synchronize()
+        t3 = tick()
+        out = c["recv"].cpu().numpy().reshape(self.world, q * per)
+        t4 = tick()
+        S = self.stats
+        S["calls"] += 1; S["upload_ms"] += 1e3 * (t1 - t0); S["kernel_ms"] += 1e3 * (t2 - t1); S["exchange_ms"] += 1e3 * (t3 - t2); S["download_ms"] += 1e3 * (t4 - t3)
+        cnt = [shard_range(F, self.world, k)[1] - shard_range(F, self.world, k)[0] for k in range(self.world)]
+        r = np.concatenate([out[k, :q * dr].reshape(q, dr)[:cnt[k]] for k in range(self.world)])
+        Ja = np.concatenate([out[k, q * dr:q * dr * (1 + da)].reshape(q, dr, da)[:cnt[k]] for k in range(self.world)])
+        Jb = np.concatenate([out[k, q * dr * (1 + da):].reshape(q, dr, db)[:cnt[k]] for k in range(self.world)]) if db else None
+        return r, Ja, Jb
 
     def linearize(self, kind, mu, W, xa, xb, ctx=None):
+        if self.on_device:
+            return self._linearize_dev(kind, mu, W, xa, xb, ctx)
         torch = self.torch
         F = len(mu)
         lo, hi = shard_range(F, self.world, self.rank)

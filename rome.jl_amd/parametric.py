@@ -259,28 +259,46 @@ class _Problem:
         return r, J
 
 
-def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, return_cov=False, verbose=False, shard=None):
+def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, return_cov=False, verbose=False, shard=None, stats=None):
     """-> {label: coordinates} (and, if return_cov, {label: marginal covariance block} from (JᵀJ)⁻¹).
     Stops when the relative cost decrease of an accepted step falls below `tol` (small graphs converge
     quadratically; the low-frequency modes of a weakly anchored 3500-pose graph creep at 1e-4/iteration
-    long after the pose error has reached the measurement-noise floor) or the step is below 1e-8."""
+    long after the pose error has reached the measurement-noise floor) or the step is below 1e-8.
+    stats: a dict that receives where the time went -- {setup_s, linearize_s (rome_linearize calls: the batched residual / Jacobian
+    kernels, their transfers and, when sharded, the exchange), host_solve_s (normal equations + sparse Cholesky / LU on the host),
+    iterations, linearizations}: on a 10 000-pose helix the host solve is > 95 % of the wall-clock."""
+    import time
     import scipy.sparse as sp
     from scipy.sparse.linalg import spsolve
+    T = dict(setup_s=0.0, linearize_s=0.0, host_solve_s=0.0, iterations=0, linearizations=0)
+    t_ = time.perf_counter()
     P = _Problem(fg)
     X = P.pack(initParametric(fg) if init is None else init)
     lam = 1e-6
-    r, J = P.linearize(X, ctx, shard)
+    T["setup_s"] = time.perf_counter() - t_
+
+    def lin(Xv):
+        t0 = time.perf_counter()
+        out = P.linearize(Xv, ctx, shard)
+        T["linearize_s"] += time.perf_counter() - t0; T["linearizations"] += 1
+        return out
+    r, J = lin(X)
     cost = float(r @ r)
     for it in range(max_iters):
         if verbose:
             print('LM iter %d cost %.6g lambda %.1e' % (it, cost, lam))
+        t0 = time.perf_counter()
         H = (J.T @ J).tocsc(); g = J.T @ r
         D = sp.diags(H.diagonal() + 1e-12)
+        T["host_solve_s"] += time.perf_counter() - t0
+        T["iterations"] += 1
         while True:
+            t0 = time.perf_counter()
             d = np.empty(P.n)
             d[P.perm] = P.solve_spd(H + lam * D, -g)
             Xn = P.retract(X, d)
-            rn, Jn = P.linearize(Xn, ctx, shard)
+            T["host_solve_s"] += time.perf_counter() - t0
+            rn, Jn = lin(Xn)
             cn = float(rn @ rn)
             if cn <= cost or lam > 1e12:
                 break
@@ -293,6 +311,10 @@ def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, retur
         if done:
             break
     out = P.unpack(X)
+    if stats is not None:
+        stats.update(T)
+        if shard is not None and hasattr(shard, "stats"):
+            stats["shard"] = dict(shard.stats)
     if return_cov:
         C = np.empty((P.n, P.n))
         C[np.ix_(P.perm, P.perm)] = np.linalg.inv((J.T @ J).toarray())
