@@ -926,7 +926,10 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
 #define ROME_FLAT_GN_MINWAVES 4   // the functor-iterating packed sweep (Pose2 / Point2): <= 128 VGPRs
 #endif
 #ifndef ROME_FLAT_GN6_MINWAVES
-#define ROME_FLAT_GN6_MINWAVES 2   // SE(3) functor iteration: <= 256 VGPRs asked for; the sched barrier between a thread's two particles does the rest
+#define ROME_FLAT_GN6_MINWAVES 2   // SE(3) functor iteration: <= 256 VGPRs asked for; the sched barrier between a thread's two particles does the rest.
+                                   // (round 5 experiment, profiles/r05_p3p3_gn_one_particle.txt: ONE particle per thread -- each thread evaluating the pair's
+                                   //  Philox calls and keeping its half -- needs 168 VGPRs without spills (3 waves per SIMD): 165.5 us against this kernel's
+                                   //  155.8 us on the 10k helix; forced to 128 VGPRs it spills 164 B per lane: 301.7 us.  The pair per thread stays.)
 #endif
 template <class FP, int SOLVER, bool VERIFY, bool VEC2, int PP>
 __global__ void __launch_bounds__(kFlatThreads, FP::DT <= 3 ? ((SOLVER == kSolverClosedForm && !VERIFY) ? (PP == 1 ? ROME_FLAT_MINWAVES : 5) : ROME_FLAT_GN_MINWAVES)
