@@ -193,6 +193,7 @@ def dry_run(args):
 
     class _Store:
         N = args.particles
+    _Store.fg = fg
 
     seen_blocks, all_updated = {}, []
     plans = []
@@ -206,20 +207,21 @@ def dry_run(args):
         mine = pl["labels"][rank]
         all_updated += mine
         if pl["up"] is not None:
-            mir = pl["up"].kw["mirror"]
-            check("frontier.rank%d.mirror_slots" % rank, sorted(mir.values()) == list(range(len(mine))) and max(mir.values()) < width)
+            mir = pl["up"].kw["mirror"]     # PACKED layout: slots of N doubles, a Pose2 belief takes 3 consecutive slots
+            check("frontier.rank%d.mirror_slots" % rank, sorted(mir.values()) == list(range(0, 3 * len(mine), 3)) and max(mir.values()) + 3 <= width)
             check("frontier.rank%d.share" % rank, pl["up"].kw["share"] == list(range(rank, len(cliques), world)))
         if pl["scatter"] is not None:
             ls, bl = pl["scatter"].a[1], pl["scatter"].a[2]
-            want = [(l, r * width + k) for r in range(world) if r != rank for k, l in enumerate(pl["labels"][r])]
+            want = [(l, r * width + 3 * k) for r in range(world) if r != rank for k, l in enumerate(pl["labels"][r])]
             check("frontier.rank%d.scatter_list" % rank, list(zip(ls, bl)) == want)
-        check("frontier.rank%d.buffers" % rank, pl["recv"].numel() == world * width * 6 * N and pl["send"].numel() == width * 6 * N and
-              pl["send"].data_ptr() == pl["recv"].data_ptr() + rank * width * 6 * N * 8)
+        check("frontier.rank%d.buffers" % rank, pl["recv"].numel() == world * width * N and pl["send"].numel() == width * N and
+              pl["send"].data_ptr() == pl["recv"].data_ptr() + rank * width * N * 8 and pl["U"] == N)
     check("frontier.shares_partition_the_frontier", sorted(all_updated) == sorted(chosen))
     out = {"dry_run": True, "n_gpus": world, "depth": depth, "checks": len(checks), "failed": fails, "ok": not fails,
            "weak": {"payload_doubles": p0.payload, "arena_doubles_per_rank": p0.arena.numel()},
            "strong": {"rows_per_rank": [s_.n_rows for s_ in shards], "variables_per_rank": shards[0].q},
-           "frontier": {"cliques": len(cliques), "width": width, "exchange_bytes_per_rank": width * 6 * N * 8}}
+           "frontier": {"cliques": len(cliques), "width_slots": width, "exchange_bytes_per_rank": width * N * 8,
+                        "layout": "packed: slots of N doubles, Pose2 3 / Point2 2 / Pose3 6 slots per belief (round 4 padded every block to 6 N)"}}
     print(json.dumps(out), flush=True)
     return 0 if not fails else 1
 

@@ -308,6 +308,7 @@ class DeviceStore:
         self.fg, self.N = fg, fg.N
         self.labels = {vt: [] for vt in self.TYPES}
         self.index = {}
+        self.touched = set()                 # variables whose block holds a belief (uploaded, or written by a plan): what download() copies back
         for l, t in fg.variables.items():
             self.index[l] = len(self.labels[t]); self.labels[t].append(l)
         h = C.c_void_p()
@@ -332,6 +333,7 @@ class DeviceStore:
                 j = k
                 while j + 1 < len(want) and want[j + 1] == want[j] + 1:
                     j += 1
+                self.touched.update(ls[i] for i in want[k:j + 1])
                 blk = np.ascontiguousarray(np.stack([fg.getVal(ls[i]) for i in want[k:j + 1]]), dtype=np.float64)
                 _lib.check(self._lib.rome_store_upload(self.handle, _lib.LAYOUT_SOA, ti, want[k], j + 1 - k,
                                                        blk.ctypes.data_as(C.POINTER(C.c_double))), self.ctx.handle)
@@ -340,6 +342,7 @@ class DeviceStore:
     def put(self, label, pts):
         """(dim, N) belief of one variable, host -> store"""
         vt = self.fg.variables[label]
+        self.touched.add(label)
         blk = np.ascontiguousarray(np.asarray(pts, dtype=np.float64).reshape(1, vt.dim, self.N))
         _lib.check(self._lib.rome_store_upload(self.handle, _lib.LAYOUT_SOA, self.TYPES.index(vt), self.index[label], 1,
                                                blk.ctypes.data_as(C.POINTER(C.c_double))), self.ctx.handle)
@@ -353,8 +356,12 @@ class DeviceStore:
         return out[0]
 
     def download(self, fg=None, labels=None):
-        """store -> fg.vals (every variable, or `labels`)"""
+        """store -> fg.vals: `labels`, or (default) every variable whose block HOLDS a belief -- uploaded, or written by a plan over this
+        store.  A block that was never written is zero-initialised memory, not a belief: copying it back would make the variable count as
+        initialised (FactorGraph.isInitialized) with all-zero particles."""
         fg = fg or self.fg
+        if labels is None:
+            labels = self.touched
         for ti, vt in enumerate(self.TYPES):
             ls = self.labels[vt]
             if not ls:
@@ -363,7 +370,7 @@ class DeviceStore:
             _lib.check(self._lib.rome_store_download(self.handle, _lib.LAYOUT_SOA, ti, 0, len(ls), out.ctypes.data_as(C.POINTER(C.c_double))),
                        self.ctx.handle)
             for k, l in enumerate(ls):
-                if labels is None or l in labels:
+                if l in labels and l in fg.variables:
                     fg.vals[l] = out[k].copy()
 
     def device_ptr(self, vt):
@@ -413,6 +420,8 @@ def frontier_pairs(fg, cliques, order, usable=None):
             others = [l for l in labels if l != dest]
             if any(l in fset and owner[l] != owner[dest] for l in others):
                 raise ValueError("cliques of the frontier are not independent: %s links %s and a frontal of another clique" % (flabel, dest))
+            if flabel in fg.multihypo and dest != labels[0]:
+                others = [labels[0]]       # a candidate of a multihypo factor needs the certain variable only (schedule.init_rounds)
             if all(usable(l) or l in fset for l in others):
                 pairs.append((flabel, dest))
     return pairs
@@ -477,6 +486,7 @@ class UpsolvePlan:
         if hasattr(mirror_out, "data_ptr"):
             mirror_out = mirror_out.data_ptr()
         _lib.check(self._lib.rome_upsolve_plan_run(self.handle, C.byref(o), C.c_void_p(mirror_out or 0), int(mirror_stride)), self.ctx.handle)
+        self.store.touched.update(self.order)
         if self.res:
             return {l: (new[k].copy(), bw[k].copy()) for vt, (ls, new, bw) in self.res.items() for k, l in enumerate(ls)}
         return None
@@ -498,6 +508,7 @@ class ScatterPlan:
 
     def __init__(self, store, labels, src_blocks, stride=0):
         self.store, self.ctx, self._lib = store, store.ctx, _lib.load()
+        self.labels = list(labels)
         fg = store.fg
         ty = np.array([DeviceStore.TYPES.index(fg.variables[l]) for l in labels], dtype=np.int32)
         va = np.array([store.index[l] for l in labels], dtype=np.int32)
@@ -513,6 +524,7 @@ class ScatterPlan:
         if hasattr(src_dev, "data_ptr"):
             src_dev = src_dev.data_ptr()
         _lib.check(self._lib.rome_scatter_plan_run(self.handle, C.c_void_p(src_dev)), self.ctx.handle)
+        self.store.touched.update(self.labels)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -49,9 +49,16 @@ def init_rounds(fg, initialised=()):
     nothing more can be initialised.  On a pose chain this is the hop distance from the priors.  `initialised`: variables that already
     have a belief -- like IIF, the pass leaves them alone and starts from them.  -> (rounds, unreachable labels)"""
     by_var = {l: [] for l in fg.variables}
-    for _, labels, _ in fg.factors:
+    mh = getattr(fg, "multihypo", {})
+    for flabel, labels, _ in fg.factors:
         for l in labels:
-            by_var[l].append([o for o in labels if o != l])
+            others = [o for o in labels if o != l]
+            if flabel in mh and l != labels[0]:
+                # a candidate of a multihypo=[1, w, 1-w] factor needs the CERTAIN variable only: particles drawn for the other candidate
+                # keep their value (IIF initialises a fractional variable from the certain one) -- two candidates that are reachable
+                # through such sightings alone must not wait for each other
+                others = [labels[0]]
+            by_var[l].append(others)
     done, rounds = set(initialised), []
     pending = [l for l in fg.variables if l not in done]
     while pending:
@@ -70,8 +77,9 @@ class OrderedSolve:
     kind:  "colour" (sweep = the colour classes in order) or "levels" (sweep = the groups of the init rounds outward and back)."""
 
     def __init__(self, store, kind="colour", gibbsIters=1, Niter=1, plan_cls=None, keep=()):
-        """keep: labels whose beliefs in the store are to be KEPT by the init pass (IIF initAll! only touches uninitialised variables);
-        sweeps update them like every other variable."""
+        """keep: labels whose beliefs in the store are to be KEPT by the init pass (IIF initAll! only touches uninitialised variables).
+        kind="colour" sweeps update them like every other variable; kind="levels" sweeps visit the groups of the init pass only, so
+        the kept variables stay as they are there too."""
         if kind not in ("colour", "levels"):
             raise ValueError("kind must be 'colour' or 'levels'")
         if not 1 <= int(gibbsIters) <= 16:      # Philox stream of run k = k << 36: (iteration << 32) + family + row must stay below it

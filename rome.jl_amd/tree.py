@@ -665,6 +665,7 @@ class BlockOpPlan:
         a = np.array([store.index[e[0]] for e in entries], dtype=np.int32)
         b = np.array([store.index[e[1]] for e in entries], dtype=np.int32) if op == "relative" else None
         d = np.array([store.index[e[-1]] for e in entries], dtype=np.int32)
+        self.dst_labels = [e[-1] for e in entries]
         PI = C.POINTER(C.c_int32)
         h = C.c_void_p()
         _lib.check(self._lib.rome_blockop_plan_create(self.ctx.handle, store.handle, self.OPS[op], len(entries), ty.ctypes.data_as(PI), a.ctypes.data_as(PI),
@@ -674,6 +675,7 @@ class BlockOpPlan:
     def run(self):
         from . import _lib
         _lib.check(self._lib.rome_blockop_plan_run(self.handle), self.ctx.handle)
+        self.store.touched.update(self.dst_labels)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -741,6 +743,7 @@ class TreeLevelPlan:
         if hasattr(mirror_out, "data_ptr"):
             mirror_out = mirror_out.data_ptr()
         _lib.check(self._lib.rome_upsolve_plan_run(self.handle, C.byref(o), C.c_void_p(mirror_out or 0), int(mirror_stride)), self.ctx.handle)
+        self.store.touched.update(self.order)
         if self.res:
             return {l: (new[k].copy(), bw[k].copy()) for vt, (ls, new, bw) in self.res.items() for k, l in enumerate(ls)}
         return None

@@ -21,6 +21,12 @@ root = [v for c in ts.tree.cliques if c.parent < 0 for v in c.frontals]
 ridx = [labels.index(v) for v in root]
 lvl_of = {v: c.level for c in ts.tree.cliques for v in c.frontals}
 lv = np.array([lvl_of[l] for l in labels])
+from rome_jl_amd.parametric import _Problem
+Pb = _Problem(fg)
+def map_cost(m):
+    r, _ = Pb.linearize(Pb.pack({l: m[k] for k, l in enumerate(labels)}))
+    return float(r @ r)
+print("cost of the parametric solution %.1f" % map_cost(mp))
 ts.upload()
 acc = None
 for ps in range(int(os.environ.get('PASSES', '6'))):
@@ -33,5 +39,6 @@ for ps in range(int(os.environ.get('PASSES', '6'))):
     Uu, _, Vt = np.linalg.svd(A.T @ Bm); Rr = (Uu @ Vt).T
     if np.linalg.det(Rr) < 0: Rr = (Uu @ np.diag([1, -1]) @ Vt).T
     al = np.sqrt(np.mean(np.sum((A @ Rr.T - Bm) ** 2, axis=1)))
+    print("   MAP cost of the pose means: %.3e" % map_cost(m))
     print("pass %d: RMS all %.3f aligned %.3f root %.3f | by level 39..30: %s | lvl 20 %.2f lvl 10 %.2f lvl 0 %.2f" % (ps, np.sqrt(np.mean(e**2)), al, np.sqrt(np.mean(e[ridx]**2)),
           " ".join("%.2f" % np.sqrt(np.mean(e[lv == h]**2)) for h in range(39, 29, -1)), np.sqrt(np.mean(e[lv == 20]**2)), np.sqrt(np.mean(e[lv == 10]**2)), np.sqrt(np.mean(e[lv == 0]**2))), flush=True)

@@ -415,3 +415,19 @@ def test_bench_dry_run_builds_and_checks_every_rank_of_an_8_gpu_run():
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["ok"] and out["n_gpus"] == 8 and out["checks"] > 100 and not out["failed"]
     assert sum(out["strong"]["rows_per_rank"]) == 10907 and out["frontier"]["cliques"] > 900
+
+
+def test_init_rounds_multihypo_candidates_need_the_certain_variable_only():
+    """two candidate landmarks reachable only through [x, l1, l2] multihypo sightings, no priors of their own, must not block
+    each other (IIF initialises a fractional variable from the certain one)."""
+    from rome_jl_amd.schedule import init_rounds
+    fg = R.initfg(16)
+    fg.addVariable("x0", R.Pose2); fg.addVariable("l1", R.Point2); fg.addVariable("l2", R.Point2)
+    fg.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.zeros(3), 0.01 * np.eye(3))))
+    fg.addFactor(["x0", "l1", "l2"], R.Pose2Point2BearingRange(R.Normal(0.0, 0.03), R.Normal(20.0, 0.5)), multihypo=[1.0, 0.5, 0.5])
+    rounds, left = init_rounds(fg)
+    assert not left and rounds[0] == ["x0"] and set(rounds[1]) == {"l1", "l2"}
+    from rome_jl_amd.clique import frontier_pairs
+    for cand in ("l1", "l2"):     # (the two candidates share the factor: they are updated in different groups of the round)
+        pairs = frontier_pairs(fg, [[cand]], [cand], usable={"x0"}.__contains__)
+        assert [p[1] for p in pairs] == [cand]
