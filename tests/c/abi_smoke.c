@@ -134,6 +134,65 @@ int main(void) {
     q.br1_alt = alt_bad;
     if (rome_clique_proposals(ctx, &om, &q) != ROME_ERR_INVALID_ARG) { printf("FAIL multihypo argument check\n"); return 1; }
   }
+  /* (7) messages between tree levels from plain C: block operations (anchor, relative) and a parent plan that takes (a) the child's
+   *     anchor belief as a store-resident message and (b) a Pose2Pose2 row whose measurement samples are a block of the store.
+   *     Store: block 0 = belief of the anchor variable a, 1 = its anchor copy, 2 = belief of s, 3 = relative samples, 4 = the parent's
+   *     variable q, 5 = the child's message on a. */
+  {
+    static double b0[3 * N], b2[3 * N], back[3 * N], rel[3 * N];
+    rome_store* st = NULL;
+    CHECK(rome_store_create(ctx, N, 6, 0, 0, &st));
+    for (int i = 0; i < N; ++i) {
+      b0[i] = 2.0 + 0.1 * sin(0.9 * i); b0[N + i] = -1.0 + 0.1 * cos(1.3 * i); b0[2 * N + i] = 0.5 + 0.02 * sin(0.7 * i);
+      b2[i] = 7.0 + 0.2 * cos(0.4 * i); b2[N + i] = 3.0 + 0.2 * sin(1.9 * i); b2[2 * N + i] = 1.0 + 0.03 * cos(0.6 * i);
+    }
+    CHECK(rome_store_upload(st, ROME_LAYOUT_SOA, 0, 0, 1, b0));
+    CHECK(rome_store_upload(st, ROME_LAYOUT_SOA, 0, 2, 1, b2));
+    CHECK(rome_store_upload(st, ROME_LAYOUT_SOA, 0, 5, 1, b0));
+    const int32_t ty[1] = {0}, a0[1] = {0}, d1[1] = {1}, a1[1] = {1}, s2[1] = {2}, d3[1] = {3};
+    rome_blockop_plan *anc = NULL, *rl = NULL;
+    CHECK(rome_blockop_plan_create(ctx, st, ROME_BLOCKOP_ANCHOR, 1, ty, a0, NULL, d1, &anc));
+    CHECK(rome_blockop_plan_create(ctx, st, ROME_BLOCKOP_RELATIVE, 1, ty, a1, s2, d3, &rl));
+    CHECK(rome_blockop_plan_run(anc)); CHECK(rome_blockop_plan_run(rl)); CHECK(rome_ctx_synchronize(ctx));
+    CHECK(rome_store_download(st, ROME_LAYOUT_SOA, 0, 1, 1, back));
+    CHECK(rome_store_download(st, ROME_LAYOUT_SOA, 0, 3, 1, rel));
+    double mx = 0, my = 0, ss = 0, cc = 0;
+    for (int i = 0; i < N; ++i) { mx += b0[i]; my += b0[N + i]; ss += sin(b0[2 * N + i]); cc += cos(b0[2 * N + i]); }
+    mx /= N; my /= N; const double mt = atan2(ss, cc);
+    for (int i = 0; i < N; ++i) {
+      if (fabs(back[i] - mx) > 1e-12 || fabs(back[N + i] - my) > 1e-12 || fabs(back[2 * N + i] - mt) > 1e-12) { printf("FAIL anchor block at %d\n", i); return 1; }
+      const double dx = b2[i] - mx, dy = b2[N + i] - my;   /* anchor (+) rel_i must give particle i of s back */
+      const double ex = cos(mt) * dx + sin(mt) * dy, ey = -sin(mt) * dx + cos(mt) * dy;
+      if (fabs(rel[i] - ex) > 1e-12 || fabs(rel[N + i] - ey) > 1e-12) { printf("FAIL relative samples at %d\n", i); return 1; }
+    }
+    /* parent: q = a (+) z with z the relative samples (sampled-measurement row), beside the child's message on a (store-resident message) */
+    rome_opts op; rome_opts_default(&op, ROME_SOLVER_NEWTON); op.n_particles = N; op.layout = ROME_LAYOUT_SOA; op.seed = 3;
+    const int32_t rows[2 * 4] = {0, 0, 0, 4,   0, 1, 4, 0};   /* a -> q (dir 0), then q -> a (dir 1): both rows read block 3 as their samples */
+    const int32_t meas[2] = {3, 3};
+    const double mu0[3] = {0, 0, 0}, cov0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const int32_t upt[2] = {0, 0}, upv[2] = {4, 0}, msrc[1] = {5}, mup[1] = {1};
+    rome_clique_upsolve_host u; memset(&u, 0, sizeof(u));
+    u.clique.n_p2p2 = 2; u.clique.f_p2p2 = 1; u.clique.p2p2_rows4 = rows; u.clique.p2p2_mu = mu0; u.clique.p2p2_cov = cov0; u.clique.p2p2_meas = meas;
+    u.gibbs_iters = 1; u.product_iters = 1; u.schedule = ROME_UPSOLVE_SEQUENTIAL; u.n_up = 2; u.up_type = upt; u.up_var = upv;
+    u.n_smsg_pose2 = 1; u.smsg_pose2_src = msrc; u.smsg_pose2_up = mup;
+    rome_upsolve_plan* pl = NULL;
+    CHECK(rome_upsolve_plan_create(ctx, st, &op, &u, &pl));
+    CHECK(rome_upsolve_plan_run(pl, &op, NULL, 0)); CHECK(rome_ctx_synchronize(ctx));
+    CHECK(rome_store_download(st, ROME_LAYOUT_SOA, 0, 4, 1, back));
+    for (int i = 0; i < N; ++i) {   /* one proposal (K = 1): q_i = a_i (+) rel_i exactly */
+      const double ax = b0[i], ay = b0[N + i], at = b0[2 * N + i];
+      const double qx = ax + cos(at) * rel[i] - sin(at) * rel[N + i], qy = ay + sin(at) * rel[i] + cos(at) * rel[N + i];
+      if (fabs(back[i] - qx) > 1e-9 || fabs(back[N + i] - qy) > 1e-9) { printf("FAIL sampled-measurement row at %d: %g %g vs %g %g\n", i, back[i], back[N + i], qx, qy); return 1; }
+    }
+    CHECK(rome_store_download(st, ROME_LAYOUT_SOA, 0, 0, 1, back));   /* a: product of the q -> a proposal and the stored message: stays near a */
+    double ma = 0; for (int i = 0; i < N; ++i) ma += back[i]; ma /= N;
+    if (!(fabs(ma - mx) < 0.5)) { printf("FAIL product with a store-resident message: mean %g vs %g\n", ma, mx); return 1; }
+    const int32_t bad[1] = {0};   /* a message source must not be a variable the plan updates */
+    u.smsg_pose2_src = bad;
+    rome_upsolve_plan* pb = NULL;
+    if (rome_upsolve_plan_create(ctx, st, &op, &u, &pb) != ROME_ERR_INVALID_ARG) { printf("FAIL store-message argument check\n"); return 1; }
+    rome_upsolve_plan_destroy(pl); rome_blockop_plan_destroy(anc); rome_blockop_plan_destroy(rl); rome_store_destroy(st);
+  }
   rome_ctx_destroy(ctx);
   printf("abi_smoke ok (max |Δ| vs closed form %.2e)\n", worst);
   return 0;
