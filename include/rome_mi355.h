@@ -452,7 +452,7 @@ int rome_conv_pose3pose3_dev(rome_ctx*, const rome_opts*, const rome_conv_dev*);
  * call: the Pose2Pose2 (+ PriorPose2 rows) table, the bearing-range -> pose table (dir_all = 1) and the bearing-range -> landmark table
  * (dir_all = 0); any of them may be NULL.  Philox stream of row r of family k = opts->stream_offset + family_stream_offset[k] + r
  * (k = 0 p2p2, 1 br1, 2 br0; NULL = no family offsets).  When every table takes its plain kernel (rows4 given, in-kernel noise, no
- * multihypo / nullhypo / status, CLOSED_FORM or NEWTON, 64 < N <= 128) the three families run as ONE fused launch -- same proposals
+ * multihypo / nullhypo / status, CLOSED_FORM, NEWTON or GAUSS_NEWTON, 64 < N <= 128) the three families run as ONE fused launch -- same proposals
  * bit for bit as three rome_conv_*_dev calls, which is what happens otherwise. */
 int rome_sweep_pose2_dev(rome_ctx*, const rome_opts*, const rome_conv_dev* p2p2, const rome_conv_dev* br1, const rome_conv_dev* br0,
                          const uint64_t* family_stream_offset /*[3] or NULL*/);

@@ -1095,13 +1095,15 @@ struct FusedArgs {
   int H, CPB2, CPB0;                 // packed parts: pair-threads per row, rows per block
   uint32_t magic;
 };
-template <bool VEC2>
+// SOLVER: kSolverClosedForm (CLOSED_FORM / NEWTON) or kSolverGaussNewton -- the functor-iterating root-find of all three families in ONE
+// launch (round 5: as three launches the bearing-range tables of an MIT-shaped graph are sub-generation, VALU-busy 0.30 / 0.39)
+template <bool VEC2, int SOLVER>
 __global__ void __launch_bounds__(256) k_sweep_fused(const FusedArgs f) {
   __shared__ double s_K[kFlatMaxRows * (FlatStage<P2P2>::kLanes + 2)];
   const int b = blockIdx.x;
-  if (b < f.nb_br1) conv_wave_body<BR<1>, kSolverClosedForm, 2, true>(f.br1, xcd_contiguous_block(b, f.nb_br1));
-  else if (b < f.nb_br1 + f.nb_p2p2) conv_flat_body<P2P2, kSolverClosedForm, false, VEC2, 1>(f.p2p2, f.H, f.CPB2, f.magic, xcd_contiguous_block(b - f.nb_br1, f.nb_p2p2), s_K);
-  else conv_flat_body<BR<0>, kSolverClosedForm, false, VEC2, 1>(f.br0, f.H, f.CPB0, f.magic, xcd_contiguous_block(b - f.nb_br1 - f.nb_p2p2, f.nb_br0), s_K);
+  if (b < f.nb_br1) conv_wave_body<BR<1>, SOLVER, 2, true>(f.br1, xcd_contiguous_block(b, f.nb_br1));
+  else if (b < f.nb_br1 + f.nb_p2p2) conv_flat_body<P2P2, SOLVER, false, VEC2, 1>(f.p2p2, f.H, f.CPB2, f.magic, xcd_contiguous_block(b - f.nb_br1, f.nb_p2p2), s_K);
+  else conv_flat_body<BR<0>, SOLVER, false, VEC2, 1>(f.br0, f.H, f.CPB0, f.magic, xcd_contiguous_block(b - f.nb_br1 - f.nb_p2p2, f.nb_br0), s_K);
 }
 
 // The same with `multihypo` / `nullhypo` columns on the bearing-range tables (the beehive of BASELINE configs[3]: ambiguous re-sightings,
@@ -1464,10 +1466,10 @@ static bool hypo_rows(const ConvArgs& a) { return a.rows4 && !a.noise && !a.stat
 hipError_t launch_sweep_pose2(const ConvArgs* p2p2, const ConvArgs* br1, const ConvArgs* br0, int solver, hipStream_t s) {
   const int N = p2p2 ? p2p2->N : (br1 ? br1->N : (br0 ? br0->N : 0));
   const bool shape_ok = p2p2 && br1 && br0 && p2p2->n_conv > 0 && br1->n_conv > 0 && br0->n_conv > 0 &&
-                        (solver == kSolverClosedForm || solver == kSolverNewton) && N > 64 && N <= 128 && br1->N == N && br0->N == N &&
+                        (solver == kSolverClosedForm || solver == kSolverNewton || solver == kSolverGaussNewton) && N > 64 && N <= 128 && br1->N == N && br0->N == N &&
                         br1->dir_all == 1 && br0->dir_all == 0;
   // sighting tables with multihypo / nullhypo columns: the fused launch with the feature-complete wave bodies for both directions
-  const bool fusable_mh = shape_ok && plain_rows(*p2p2) && (hypo_rows(*br1) || plain_rows(*br1)) && (hypo_rows(*br0) || plain_rows(*br0)) &&
+  const bool fusable_mh = shape_ok && solver != kSolverGaussNewton && plain_rows(*p2p2) && (hypo_rows(*br1) || plain_rows(*br1)) && (hypo_rows(*br0) || plain_rows(*br0)) &&
                           (hypo_rows(*br1) || hypo_rows(*br0));
   const bool fusable = shape_ok &&
                        plain_rows(*p2p2) && plain_rows(*br1) && plain_rows(*br0) &&
@@ -1500,9 +1502,12 @@ hipError_t launch_sweep_pose2(const ConvArgs* p2p2, const ConvArgs* br1, const C
   if (fusable_mh) {
     if (vec2) hipLaunchKernelGGL((k_sweep_fused_mh<true>), dim3(nb), dim3(256), 0, s, f);
     else      hipLaunchKernelGGL((k_sweep_fused_mh<false>), dim3(nb), dim3(256), 0, s, f);
+  } else if (solver == kSolverGaussNewton) {
+    if (vec2) hipLaunchKernelGGL((k_sweep_fused<true, kSolverGaussNewton>), dim3(nb), dim3(256), 0, s, f);
+    else      hipLaunchKernelGGL((k_sweep_fused<false, kSolverGaussNewton>), dim3(nb), dim3(256), 0, s, f);
   } else {
-    if (vec2) hipLaunchKernelGGL((k_sweep_fused<true>), dim3(nb), dim3(256), 0, s, f);
-    else      hipLaunchKernelGGL((k_sweep_fused<false>), dim3(nb), dim3(256), 0, s, f);
+    if (vec2) hipLaunchKernelGGL((k_sweep_fused<true, kSolverClosedForm>), dim3(nb), dim3(256), 0, s, f);
+    else      hipLaunchKernelGGL((k_sweep_fused<false, kSolverClosedForm>), dim3(nb), dim3(256), 0, s, f);
   }
   return hipGetLastError();
 }

@@ -287,50 +287,66 @@ class TreeSolver:
         return nfl
 
     def _split_products(self, L, cliques, pairs_of, smsgs):
-        """two-stage products for Pose2 variables with more than max_product proposals (class docstring): partial-product variables in
-        step 2g, everything else in step 2g + 1"""
+        """staged products for Pose2 variables with more than max_product proposals (class docstring): a variable with K proposals is
+        the root of a tree of partial products with fan-in <= max_product; a variable of update group g is solved in step
+        g * (D + 1) + D, its partial products of depth d below it in step g * (D + 1) + D - d (D = the deepest tree of the level)"""
         from .factors import Pose2
         from .clique import SampledPose2Pose2
         G = self.max_product
         by_dest = {}
         for src, dst in smsgs:
             by_dest.setdefault(dst, []).append(src)
-        if G <= 0 or not any(len(pairs_of.get(l, ())) + len(by_dest.get(l, ())) > G and L.variables[l] is Pose2 for upd, _ in cliques for l in upd):
+        count = lambda l: len(pairs_of.get(l, ())) + len(by_dest.get(l, ()))     # noqa: E731
+
+        def depth(k):
+            d = 0
+            while k > G:
+                k = -(-k // G); d += 1
+            return d
+        D = max((depth(count(l)) for upd, _ in cliques for l in upd if L.variables[l] is Pose2), default=0) if G > 1 else 0
+        if D == 0:
             return cliques, pairs_of, smsgs
         out_cliques, out_smsgs = [], []
         for upd, grp in cliques:
             nu, ng = [], []
-            for l, g in zip(upd, grp):
-                items = [("f", fl) for fl in pairs_of.get(l, ())] + [("m", src) for src in by_dest.get(l, ())]
-                if len(items) <= G or L.variables[l] is not Pose2:
-                    nu.append(l); ng.append(2 * g + 1); out_smsgs += [(src, l) for src in by_dest.get(l, ())]
-                    continue
-                nch = -(-len(items) // G)
-                rows_v = []
-                for k in range(nch):
-                    pl = "%s^%d" % (l, k)
-                    self._need(L, pl, Pose2)
-                    rows = []
-                    for kind, x in items[k::nch]:
-                        if kind == "f":
+
+            def build(l, items, g, lvl):
+                """make `l` the product of `items` ((kind, id): a factor row, a store message, or a partial-product label) in step
+                g * (D + 1) + D - lvl"""
+                if len(items) > G and L.variables[l] is Pose2:
+                    nch = -(-len(items) // G)
+                    parts = []
+                    for k in range(nch):
+                        pl = "%s^%d" % (l, k)
+                        self._need(L, pl, Pose2)
+                        build(pl, [(kind, x, l) for kind, x, _ in items[k::nch]], g, lvl + 1)
+                        parts.append(("p", pl, l))
+                    items = parts
+                rows = []
+                for kind, x, owner in items:
+                    if kind == "f":          # a factor row of the ORIGINAL variable `owner`, retargeted to l
+                        if owner == l:
+                            rows.append(x)
+                        else:
                             _, labels, f = L.getFactor(x)
-                            nfl = "%s^%d" % (x, k)
-                            L.factors.append((nfl, [pl if o == l else o for o in labels], f)); L._findex[nfl] = L.factors[-1]
+                            nfl = "%s>%s" % (x, l)
+                            L.factors.append((nfl, [l if o == owner else o for o in labels], f)); L._findex[nfl] = L.factors[-1]
                             if x in L.multihypo:
                                 L.multihypo[nfl] = L.multihypo[x]
                             if x in L.nullhypo:
                                 L.nullhypo[nfl] = L.nullhypo[x]
                             rows.append(nfl)
-                        else:
-                            out_smsgs.append((x, pl))
-                    pairs_of[pl] = rows
-                    nu.append(pl); ng.append(2 * g)
-                    idf = "=%s" % pl                                   # identity row: proposal = the partial product itself
-                    self._need(L, ZERO, Pose2)
-                    L.factors.append((idf, [pl, l], SampledPose2Pose2(ZERO))); L._findex[idf] = L.factors[-1]
-                    rows_v.append(idf)
-                pairs_of[l] = rows_v
-                nu.append(l); ng.append(2 * g + 1)
+                    elif kind == "m":
+                        out_smsgs.append((x, l))
+                    else:                    # a partial product enters through an identity row (sampled row whose samples are zero)
+                        idf = "=%s" % x
+                        self._need(L, ZERO, Pose2)
+                        L.factors.append((idf, [x, l], SampledPose2Pose2(ZERO))); L._findex[idf] = L.factors[-1]
+                        rows.append(idf)
+                pairs_of[l] = rows
+                nu.append(l); ng.append(g * (D + 1) + D - lvl)
+            for l, g in zip(upd, grp):
+                build(l, [("f", fl, l) for fl in pairs_of.get(l, ())] + [("m", src, l) for src in by_dest.get(l, ())], g, 0)
             out_cliques.append((nu, ng))
         return out_cliques, pairs_of, out_smsgs
 

@@ -52,6 +52,14 @@ a0 = torch.empty((Fb0, 2, 100), dtype=torch.float64, device="cuda")
 def three():
     dg.sweep_pose2pose2(o, out=a2); dg.sweep_bearingrange(o, 1, out=a1); dg.sweep_bearingrange(o, 0, out=a0)
 alg = dg.tab["p2p2"]["C_rel"] * 100 * 48 + dg.tab["p2p2"]["P"] * 2400 + Fb * 100 * 64 + Fb0 * 100 * 40
+og = R.make_opts(N=100, solver=3)
+def three_gn():
+    dg.sweep_pose2pose2(og, out=a2); dg.sweep_bearingrange(og, 1, out=a1); dg.sweep_bearingrange(og, 0, out=a0)
+alg_gn = dg.tab["p2p2"]["C_rel"] * 100 * 72 + dg.tab["p2p2"]["P"] * 2400 + Fb * 100 * 64 + Fb0 * 100 * 56
+for name, fn in (("GAUSS_NEWTON three launches (per family)", three_gn), ("GAUSS_NEWTON ONE fused launch (k_sweep_fused<GN>)", lambda: dg.sweep_graph_pose2(og, a2, a1, a0))):
+    ms = timeit(fn, 3 if QUICK else 50)
+    n = C2 + Fb + Fb0
+    print("MIT-like graph sweep: %6d convs %-52s %9.4f ms/sweep  %.3e conv/s  %7.1f GB/s algorithmic = %.2f of 8 TB/s" % (n, name, ms, n / ms * 1e3, alg_gn / ms / 1e6, alg_gn / ms / 1e6 / 8000))
 for name, fn in (("three launches (per family)", three), ("ONE fused launch (k_sweep_fused)", lambda: dg.sweep_graph_pose2(o, a2, a1, a0))):
     ms = timeit(fn, 3 if QUICK else 50)
     n = C2 + Fb + Fb0

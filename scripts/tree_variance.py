@@ -14,7 +14,7 @@ if len(sys.argv) > 4 and sys.argv[4] == "tight":      # experiment: a prior that
             fg.factors[k] = (fl, ls, R.PriorPose2(R.MvNormal(f.Z.mu, np.diag([1e-6, 1e-6, 1e-6])))); fg._findex[fl] = fg.factors[k]
     print("tight prior")
 R.initAllOrdered(fg, seed=1)
-ts = TreeSolver(fg, messages="relative", rootIters=int(sys.argv[1]), refineIters=int(sys.argv[2]), relIters=int(os.environ.get("REL", "0")), last=(("x0",) if len(sys.argv) > 3 and sys.argv[3] == "last" else ()))
+ts = TreeSolver(fg, messages="relative", rootIters=int(sys.argv[1]), refineIters=int(sys.argv[2]), relIters=int(os.environ.get("REL", "0")), max_product=int(os.environ.get("MAXPROD", "8")), last=(("x0",) if len(sys.argv) > 3 and sys.argv[3] == "last" else ()))
 print(ts.tree.summary())
 print("rootIters", sys.argv[1], "refineIters", sys.argv[2])
 root = [v for c in ts.tree.cliques if c.parent < 0 for v in c.frontals]
@@ -28,9 +28,10 @@ def map_cost(m):
     return float(r @ r)
 print("cost of the parametric solution %.1f" % map_cost(mp))
 ts.upload()
+import time as _t
 acc = None
 for ps in range(int(os.environ.get('PASSES', '6'))):
-    ts.solve(R.make_opts(N=N, seed=500 + ps)); ts.download()
+    ts.store.ctx.synchronize(); _t0 = _t.perf_counter(); ts.solve(R.make_opts(N=N, seed=500 + ps)); ts.store.ctx.synchronize(); print("   pass %.4f s" % (_t.perf_counter() - _t0)); ts.download()
     bel = np.stack([fg.getVal(l) for l in labels]); m, _ = R.belief_stats(bel)
     e = np.sqrt(np.sum((m[:, :2] - mp[:, :2]) ** 2, axis=1))
     acc = m[:, :2].copy() if acc is None else acc + m[:, :2]

@@ -157,7 +157,7 @@ def test_fused_graph_sweep_equals_per_family_launches_bit_for_bit(N):
     R.dead_reckon_init(fg, seed=4)
     dg = R.DeviceGraph(fg); dg.upload_beliefs(fg)
     assert not dg.tab["br"]["mh"]
-    for solver in (R.SOLVER_NEWTON, R.SOLVER_CLOSED_FORM):
+    for solver in (R.SOLVER_NEWTON, R.SOLVER_CLOSED_FORM, R.SOLVER_GAUSS_NEWTON):   # (GAUSS_NEWTON: k_sweep_fused<., kSolverGaussNewton>, round 5)
         o = R.make_opts(N=N, solver=solver, seed=12, stream_offset=5 << 32)
         C2, Fb, Fb0 = dg.tab["p2p2"]["C"], dg.tab["br"]["F"], dg.tab["br"]["F0"]
         a2 = torch_empty(dg, (C2, 3, N)); a1 = torch_empty(dg, (Fb, 3, N)); a0 = torch_empty(dg, (Fb0, 2, N))
