@@ -128,3 +128,16 @@ def test_beehive_multihypo_tree_solve_runs_with_landmark_separators():
     sim = fg._sim
     err = [np.hypot(*(fg.getVal(l)[:2].mean(1) - np.asarray(sim[l])[:2])) for l in fg.variables if fg.variables[l] is R.Pose2]
     assert np.isfinite(err).all() and np.median(err) < 3.0, np.median(err)
+
+
+@pytest.mark.parametrize("messages", ["marginal", "relative"])
+def test_pose3_helix_tree_solve_equals_the_oracle_tree_solve(messages):
+    """SE(3): a 40-pose helix with loop closures between adjacent turns and its PriorPose3.  The relative form has no Pose2 anchor on a
+    Pose3 graph: its cliques send the marginals of the separators their priors / children informed (the documented fall-back)."""
+    fg = R.synth_helix3d(P=40, N=32, seed=4)
+    R.dead_reckon_init_pose3(fg, seed=2)
+    dev, worst = _both(fg, messages, 51, gibbsIters=2)
+    st = dev.stats()
+    assert st["levels"] >= 3 and st["relative_messages"] == 0 and st["store_messages"] > 0, st
+    for frac, dmean in worst:
+        assert frac > 0.9 and dmean < 1e-3, worst
