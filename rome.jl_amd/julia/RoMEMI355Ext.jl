@@ -494,6 +494,27 @@ function RomeScatterPlan(st::RomeStore, dfg::AbstractDFG, labels::AbstractVector
   finalizer(x -> ccall((:rome_scatter_plan_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), sp)
 end
 run!(sp::RomeScatterPlan, src_dev::Ptr{Float64}) = check(ccall((:rome_scatter_plan_run, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), sp.h, src_dev))
+
+# ---- block operations inside a store (rome_blockop_plan): the glue between tree levels that stays on the device --------------------------
+# op = :copy (a clique's sub-graph starts from the graph's current values), :anchor (N copies of the mean of a belief: the clique conditions
+# on its anchor separator being there), :relative (samples of anchor^-1 * s, or (bearing, range) of a landmark: the measurement samples a
+# p2p2_meas / br*_meas row of the parent consumes).  Entries are (a, [b,] dst) labels of the store; Python twin: rome_jl_amd.tree.BlockOpPlan.
+mutable struct RomeBlockOpPlan
+  h::Ptr{Cvoid}
+  store::RomeStore
+end
+const _BLOCKOPS = Dict(:copy => Int32(0), :anchor => Int32(1), :relative => Int32(2))
+function RomeBlockOpPlan(st::RomeStore, op::Symbol, types::AbstractVector{<:Integer}, a::AbstractVector{<:Integer}, b::AbstractVector{<:Integer},
+                         dst::AbstractVector{<:Integer})
+  ty = Int32.(types); va = Int32.(a); vb = Int32.(b); vd = Int32.(dst)
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve ty va vb vd check(ccall((:rome_blockop_plan_create, LIB), Cint,
+      (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ref{Ptr{Cvoid}}),
+      ctx().h, st.h, _BLOCKOPS[op], length(ty), _p(ty), _p(va), _p(vb), _p(vd), r))
+  bp = RomeBlockOpPlan(r[], st)
+  finalizer(x -> ccall((:rome_blockop_plan_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), bp)
+end
+run!(bp::RomeBlockOpPlan) = check(ccall((:rome_blockop_plan_run, LIB), Cint, (Ptr{Cvoid},), bp.h))
 synchronize() = check(ccall((:rome_ctx_synchronize, LIB), Cint, (Ptr{Cvoid},), ctx().h))
 
 # ---- parametric path: batched whitened residuals + Jacobians (rome_linearize) ------------------------------

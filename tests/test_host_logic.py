@@ -431,3 +431,74 @@ def test_init_rounds_multihypo_candidates_need_the_certain_variable_only():
     for cand in ("l1", "l2"):     # (the two candidates share the factor: they are updated in different groups of the round)
         pairs = frontier_pairs(fg, [[cand]], [cand], usable={"x0"}.__contains__)
         assert [p[1] for p in pairs] == [cand]
+
+
+# ------------------------------------------------------------------ Bayes tree (rome_jl_amd.tree)
+def test_bayes_tree_structure_on_manhattan_3500():
+    """elimination order -> cliques -> levels: every variable is frontal exactly once, every factor lives in a clique that holds all its
+    variables, the separators of a clique are members of its parent (running intersection), children sit on lower levels; a chain in
+    natural order gives the textbook cliques"""
+    from rome_jl_amd.tree import BayesTree
+    fg = R.loadG2o(os.path.join(ROOT, "tests", "golden", "manhattan.g2o"), N=8)
+    t = BayesTree.build(list(fg.variables), [(fl, tuple(ls)) for fl, ls, _ in fg.factors])
+    fr = [v for c in t.cliques for v in c.frontals]
+    assert sorted(fr) == sorted(fg.variables) and len(set(fr)) == len(fr)
+    members = [set(c.frontals) | set(c.separators) for c in t.cliques]
+    findex = {fl: ls for fl, ls, _ in fg.factors}
+    seen = 0
+    for c in t.cliques:
+        for fl in c.factors:
+            assert set(findex[fl]) <= members[c.id], (c, fl)
+            seen += 1
+        if c.parent >= 0:
+            assert set(c.separators) <= members[c.parent] and c.separators and t.cliques[c.parent].level > c.level
+            assert c.id in t.cliques[c.parent].children
+        else:
+            assert not c.separators
+    assert seen == len(fg.factors)
+    assert sum(len(l) for l in t.levels) == len(t.cliques) and all(t.cliques[c].level == h for h, l in enumerate(t.levels) for c in l)
+    assert len(t.levels) < 80 and max(len(l) for l in t.levels) > 500          # 40 levels, 1140 leaves: the frontier-width profile of DESIGN §12
+    # variables constrained to the end of the order land in a root
+    t2 = BayesTree.build(list(fg.variables), [(fl, tuple(ls)) for fl, ls, _ in fg.factors], last=("x0",))
+    assert t2.cliques[t2.clique_of["x0"]].parent == -1
+    # a chain in natural order: (x0 | x1), (x1 | x2), root (x2, x3)
+    ch = BayesTree.build(["x0", "x1", "x2", "x3"], [("p", ("x0",)), ("a", ("x0", "x1")), ("b", ("x1", "x2")), ("c", ("x2", "x3"))], order="natural")
+    got = sorted((tuple(c.frontals), tuple(c.separators)) for c in ch.cliques)
+    assert got == [(("x0",), ("x1",)), (("x1",), ("x2",)), (("x2", "x3"), ())], got
+    assert [len(l) for l in ch.levels] == [1, 1, 1] and ch.cliques[ch.clique_of["x0"]].factors == ["p", "a"]
+
+
+def test_tree_solver_edge_cases_over_the_oracle_backend():
+    """a forest (two disconnected components, each with its prior: two roots), a graph without any prior (the relative form refuses: no
+    gauge; IIF's form runs from the current values), a single variable"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_standin import OracleTreeBackend
+    from rome_jl_amd.tree import TreeSolver
+    N = 24
+    fg = R.initfg(N)
+    for c in "ab":
+        for k in range(4):
+            fg.addVariable("%s%d" % (c, k), R.Pose2)
+        fg.addFactor(["%s0" % c], R.PriorPose2(R.MvNormal(np.array([0.0 if c == "a" else 50.0, 0, 0]), 0.01 * np.eye(3))))
+        for k in range(3):
+            fg.addFactor(["%s%d" % (c, k), "%s%d" % (c, k + 1)], R.Pose2Pose2(R.MvNormal([10.0, 0, 0.1], 0.01 * np.eye(3))))
+        fg.addFactor(["%s0" % c, "%s3" % c], R.Pose2Pose2(R.MvNormal([29.5, 3.0, 0.3], 0.04 * np.eye(3))))
+    R.dead_reckon_init(fg, seed=1)
+    for msg in ("relative", "marginal"):
+        ts = TreeSolver(fg, messages=msg, backend=OracleTreeBackend(R)); ts.upload(); ts.solve(R.make_opts(N=N, seed=2))
+        assert sum(1 for c in ts.tree.cliques if c.parent < 0) == 2 and ts.stats()["unreached"] == 0
+        assert abs(ts.store.get("a3")[0].mean() - 29.5) < 1.5 and abs(ts.store.get("b3")[0].mean() - 79.5) < 1.5, msg
+    fg2 = R.initfg(N)
+    for k in range(3):
+        fg2.addVariable("x%d" % k, R.Pose2)
+    for k in range(2):
+        fg2.addFactor(["x%d" % k, "x%d" % (k + 1)], R.Pose2Pose2(R.MvNormal([1.0, 0, 0], 0.01 * np.eye(3))))
+    R.dead_reckon_init(fg2, seed=1)
+    with pytest.raises(ValueError, match="no gauge"):
+        TreeSolver(fg2, messages="relative", backend=OracleTreeBackend(R))
+    ts = TreeSolver(fg2, messages="marginal", backend=OracleTreeBackend(R)); ts.upload(); ts.solve(R.make_opts(N=N, seed=2))
+    fg3 = R.initfg(N); fg3.addVariable("x0", R.Pose2); fg3.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.zeros(3), 0.01 * np.eye(3))))
+    for msg in ("relative", "marginal"):
+        ts = TreeSolver(fg3, messages=msg, backend=OracleTreeBackend(R)); ts.upload(); ts.solve(R.make_opts(N=N, seed=2))
+        assert 0.05 < ts.store.get("x0")[0].std() < 0.2
