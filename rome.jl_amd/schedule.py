@@ -102,20 +102,29 @@ class OrderedSolve:
                 self.init_groups.append(grp)
                 self.init_plans.append(plan_cls(store, [[l] for l in grp], gibbsIters=gibbsIters, Niter=Niter, usable=snapshot.__contains__))
                 done.update(grp)
-        # ---- sweeps: every factor is usable
-        everything = frozenset(fg.variables)
+        # ---- sweeps: every factor is usable.  The groups are fixed here; their plans are built on the first sweep (an init pass that is
+        #      followed by a tree solve never sweeps: 0.1 s of host time on Manhattan-3500)
         if kind == "colour":
             self.sweep_groups = greedy_colouring(fg, None, nb)
         else:
             self.sweep_groups = self.init_groups + self.init_groups[-2::-1]     # outward, then back to the roots
-        cache = {}
-        self.sweep_plans = []
-        for grp in self.sweep_groups:
-            key = tuple(grp)
-            if key not in cache:
-                cache[key] = plan_cls(store, [[l] for l in grp], gibbsIters=gibbsIters, Niter=Niter, usable=everything.__contains__)
-            self.sweep_plans.append(cache[key])
+        self._sweep_plans = None
+        self._plan_args = (plan_cls, gibbsIters, Niter)
         self.runs = 0
+
+    @property
+    def sweep_plans(self):
+        if self._sweep_plans is None:
+            plan_cls, gibbsIters, Niter = self._plan_args
+            everything = frozenset(self.store.fg.variables)
+            cache = {}
+            self._sweep_plans = []
+            for grp in self.sweep_groups:
+                key = tuple(grp)
+                if key not in cache:
+                    cache[key] = plan_cls(self.store, [[l] for l in grp], gibbsIters=gibbsIters, Niter=Niter, usable=everything.__contains__)
+                self._sweep_plans.append(cache[key])
+        return self._sweep_plans
 
     def _run(self, plans, opts):
         for p in plans:
@@ -133,5 +142,5 @@ class OrderedSolve:
             self._run(self.sweep_plans, opts)
 
     def stats(self):
-        return dict(levels=len(self.levels), init_steps=len(self.init_plans), sweep_steps=len(self.sweep_plans),
+        return dict(levels=len(self.levels), init_steps=len(self.init_plans), sweep_steps=len(self.sweep_groups),
                     largest_group=max(len(g) for g in self.sweep_groups), colours=len(self.sweep_groups) if self.kind == "colour" else None)
