@@ -26,7 +26,8 @@ from .clique import proposalbeliefs, predictbelief, CliqueBatch, upGibbsCliqueDe
 from .serialization import loadDFG, saveDFG, packFactor, unpackFactor, packBelief, unpackBelief
 from .parametric import solveGraphParametric, initParametric
 from .device import DeviceGraph
-from .solve import initAll, initAllOrdered, solveGraph
+from .solve import initAll, initAllOrdered, solveGraph, solveTree
+from .tree import BayesTree, TreeSolver
 from . import distributed
 
 

@@ -89,3 +89,24 @@ def solveGraph(fg, n_sweeps=10, seed=0x524F4D45, init="graph", bandwidth="silver
     dg.download_beliefs(fg)
     setPPE(fg)
     return dg
+
+
+def solveTree(fg, tree=None, messages="relative", passes=1, seed=0x524F4D45, ctx=None, order="mmd", **kw):
+    """IIF `solveTree!(fg [, tree])` (examples/Hexagonal2D_SLAM.jl:24, examples/ManhattanDatasetBatch.jl:43, the incremental re-solves of
+    examples/ManhattanDatasetIncremental.jl:107): `initAll!` for whatever has no belief yet (`initAllOrdered`), Bayes tree (built here, or the
+    `tree.TreeSolver` of a previous call to re-solve from the current beliefs: plans are reused), up pass + down pass on the device,
+    beliefs written back, PPEs set.  messages: "relative" (default) or "marginal" = IIF's per-variable separator beliefs (tree.py).
+    -> the TreeSolver (its store keeps the beliefs on the device; pass it back as `tree=` after adding nothing to the graph)."""
+    from .api import make_opts
+    from .canonical import setPPE
+    from .tree import TreeSolver
+    if any(not fg.isInitialized(l) for l in fg.variables):
+        initAllOrdered(fg, seed=seed & 0xFFFF, ctx=ctx)
+    ts = tree if isinstance(tree, TreeSolver) else TreeSolver(fg, messages=messages, ctx=ctx, order=order, **kw)
+    if ts.fg is not fg:
+        raise ValueError("solveTree: the TreeSolver passed as `tree` belongs to another graph")
+    ts.upload(fg)
+    ts.solve(make_opts(N=fg.N, seed=seed), passes=passes)
+    ts.download(fg)
+    setPPE(fg)
+    return ts

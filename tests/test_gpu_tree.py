@@ -193,3 +193,20 @@ def test_tree_levels_through_frontier_shard_one_rank_rccl():
                     % ("direct ncclAllGather" if comm is not None else "torch.distributed all_gather", dt, nbytes / 1e6))
     finally:
         dist.destroy_process_group()
+
+
+def test_solve_tree_host_entry_like_the_reference_example():
+    """R.solveTree(fg) = the reference's `solveTree!(fg)` call of examples/Hexagonal2D_SLAM.jl:24 on a graph WITHOUT beliefs (initAll! inside),
+    and a second call with the returned tree re-solves from the current beliefs (examples/ManhattanDatasetIncremental.jl:107)"""
+    fg = R.generateGraph_Hexagonal(N=100)
+    assert not fg.vals
+    ts = R.solveTree(fg, messages="marginal", seed=3)
+    assert all(fg.isInitialized(l) for l in fg.variables) and hasattr(fg, "ppes")
+    for l, (x, y) in HEX.items():
+        p = fg.getVal(l)
+        assert np.mean((np.abs(p[0] - x) < 3.0) & (np.abs(p[1] - y) < 3.0)) > 0.35, (l, p[:2].mean(1))
+    before = {l: fg.getVal(l).copy() for l in fg.variables}
+    ts2 = R.solveTree(fg, tree=ts, seed=4)
+    assert ts2 is ts and any(not np.array_equal(before[l], fg.getVal(l)) for l in fg.variables)
+    with pytest.raises(ValueError):
+        R.solveTree(R.generateGraph_Hexagonal(N=100), tree=ts)
