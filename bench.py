@@ -728,6 +728,42 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R, pk, fg, N, args.cpu_seconds)
+        # the other half of the metric next to a CPU number: one Bayes-tree pass (up + down, relative messages) on a bounded SAMPLE -- the
+        # first 200 poses of the same g2o file with their loop closures -- by the oracle's restatement on the host (oracle/cpu_tree_bench.py,
+        # fresh process) and by the device path on the SAME sub-graph
+        if args.g2o and args.g2o != "synthetic" and not args.no_modes:
+            try:
+                import subprocess
+                p_ = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_tree_bench.py"), args.g2o, "--poses", "200", "--particles", str(N)],
+                                    capture_output=True, text=True, timeout=600)
+                cpu_t = json.loads(p_.stdout.strip().splitlines()[-1]) if p_.returncode == 0 else {"error": p_.stderr[-400:]}
+                from rome_jl_amd.tree import TreeSolver
+                fgs = R.initfg(N)
+                import re as _re
+                rows_ = [ln.split() for ln in open(args.g2o) if ln.startswith("EDGE_SE2")]
+                rows_ = [t for t in rows_ if int(t[1]) < 200 and int(t[2]) < 200]
+                for k in sorted({int(x) for t in rows_ for x in t[1:3]}):
+                    fgs.addVariable("x%d" % k, R.Pose2)
+                fgs.addFactor(["x0"], R.PriorPose2(R.MvNormal(np.zeros(3), np.diag([0.01, 0.01, 0.0025]))))
+                for t in rows_:
+                    u = [float(x) for x in t[6:12]]
+                    Cc = np.linalg.inv(np.array([[u[0], u[1], u[2]], [u[1], u[3], u[4]], [u[2], u[4], u[5]]]))
+                    fgs.addFactor(["x%s" % t[1], "x%s" % t[2]], R.Pose2Pose2(R.MvNormal(np.array([float(x) for x in t[3:6]]), 0.5 * (Cc + Cc.T))))
+                R.dead_reckon_init(fgs, seed=1)
+                tss = TreeSolver(fgs, messages="relative", ctx=ctx); tss.upload()
+                tss.solve(R.make_opts(N=N, seed=3)); ctx.synchronize()
+                a = time.perf_counter()
+                for ps in range(5):
+                    tss.solve(R.make_opts(N=N, seed=4 + ps))
+                ctx.synchronize()
+                g_t = (time.perf_counter() - a) / 5
+                out["cpu_baseline"]["tree_pass_sample"] = {
+                    "sample": "Bayes-tree pass (up + down, relative messages) of the first 200 poses of the same file with their loop closures (%s factors, N = %d)" % (cpu_t.get("factors"), N),
+                    "cpu_port": cpu_t, "gpu_seconds_per_pass": g_t, "ratio": (cpu_t["seconds_per_pass"] / g_t) if "seconds_per_pass" in cpu_t else None,
+                    "note": "the CPU side is the oracle's restatement driven row by row from Python (test infrastructure), not the reference's Julia: a scale, not a race; "
+                            "a 184-clique tree is 34 narrow levels, i.e. the GPU side is launch latency"}
+            except Exception as e:   # noqa: BLE001
+                out["cpu_baseline"]["tree_pass_sample"] = {"error": repr(e)}
         gpu = dict(out.get("gpu_convolutions_per_s_by_solver", {}))
         gpu[args.solver] = value
         # GPU/CPU ratios pair the SAME algorithm on both sides (the CPU side at its best thread count):
