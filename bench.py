@@ -735,7 +735,7 @@ def main():
             try:
                 import subprocess
                 p_ = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_tree_bench.py"), args.g2o, "--poses", "200", "--particles", str(N)],
-                                    capture_output=True, text=True, timeout=600)
+                                    capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))   # (row-by-row calls: one thread)
                 cpu_t = json.loads(p_.stdout.strip().splitlines()[-1]) if p_.returncode == 0 else {"error": p_.stderr[-400:]}
                 from rome_jl_amd.tree import TreeSolver
                 fgs = R.initfg(N)
