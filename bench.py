@@ -739,7 +739,6 @@ def main():
                 cpu_t = json.loads(p_.stdout.strip().splitlines()[-1]) if p_.returncode == 0 else {"error": p_.stderr[-400:]}
                 from rome_jl_amd.tree import TreeSolver
                 fgs = R.initfg(N)
-                import re as _re
                 rows_ = [ln.split() for ln in open(args.g2o) if ln.startswith("EDGE_SE2")]
                 rows_ = [t for t in rows_ if int(t[1]) < 200 and int(t[2]) < 200]
                 for k in sorted({int(x) for t in rows_ for x in t[1:3]}):
