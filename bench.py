@@ -684,7 +684,7 @@ def main():
             a = time.perf_counter(); tsv = TreeSolver(fg1, messages=args.tree_messages, ctx=ctx); t_build = time.perf_counter() - a
             tsv.upload()
             passes = []
-            for ps in range(3):
+            for ps in range(8):
                 o4 = R.make_opts(N=N, seed=100 + ps)
                 ctx.synchronize(); a = time.perf_counter(); tsv.up(o4); ctx.synchronize(); tu = time.perf_counter() - a
                 a = time.perf_counter(); tsv.down(o4); ctx.synchronize(); td = time.perf_counter() - a
@@ -697,6 +697,12 @@ def main():
                         % (st_["cliques"], st_["levels"], st_["width_max"], args.tree_messages),
                 "init_all_s": t_ini, "rms_to_parametric_m_after_init": r_init, "tree_and_plans_build_s": t_build, "passes": passes,
                 "wall_clock_s_first_pass": t_ini + t_build + passes[0]["up_s"] + passes[0]["down_s"], "tree": st_,
+                "rms_to_parametric_m_over_passes": {"min": min(p_["rms_to_parametric_m"] for p_ in passes), "median": float(np.median([p_["rms_to_parametric_m"] for p_ in passes])),
+                                                    "max": max(p_["rms_to_parametric_m"] for p_ in passes)},
+                "rms_after_rigid_alignment_m_over_passes": {"min": min(p_["rms_after_rigid_alignment_m"] for p_ in passes),
+                                                            "median": float(np.median([p_["rms_after_rigid_alignment_m"] for p_ in passes])),
+                                                            "max": max(p_["rms_after_rigid_alignment_m"] for p_ in passes)},
+                "seconds_per_pass": float(np.median([p_["up_s"] + p_["down_s"] for p_ in passes])),
                 "frontier_width_by_level": [len(l) for l in tsv.tree.levels],
                 "note": "N = 100 particles: a pass is a stochastic estimate -- the spread over passes is its sampling noise (mostly a rigid transform of the whole "
                         "map about the prior pose: see rms_after_rigid_alignment_m); DESIGN.md section 11"}
