@@ -32,10 +32,13 @@ def map_cost(m):
     r, _ = Pb.linearize(Pb.pack({l: m[k] for k, l in enumerate(labels)}))
     return float(r @ r)
 print("cost of the parametric solution %.1f" % map_cost(mp))
+init_vals = {l: v.copy() for l, v in fg.vals.items()}
 ts.upload()
 import time as _t
 acc = None
 for ps in range(int(os.environ.get('PASSES', '6'))):
+    if os.environ.get("FRESH") == "1":
+        fg.vals = {l: v.copy() for l, v in init_vals.items()}; ts.upload()      # every pass from the SAME init beliefs: independent estimates
     ts.store.ctx.synchronize(); _t0 = _t.perf_counter(); ts.solve(R.make_opts(N=N, seed=500 + ps)); ts.store.ctx.synchronize(); print("   pass %.4f s" % (_t.perf_counter() - _t0)); ts.download()
     bel = np.stack([fg.getVal(l) for l in labels]); m, _ = R.belief_stats(bel)
     e = np.sqrt(np.sum((m[:, :2] - mp[:, :2]) ** 2, axis=1))
