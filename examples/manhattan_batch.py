@@ -15,9 +15,18 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import rome_jl_amd as R  # noqa: E402
 
-path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "manhattan.g2o")
-out = sys.argv[2] if len(sys.argv) > 2 else "/tmp/manhattan_solved.g2o"
+argv = [a for a in sys.argv[1:] if a != "--tree"]
+path = argv[0] if len(argv) > 0 else os.path.join(ROOT, "tests", "golden", "manhattan.g2o")
+out = argv[1] if len(argv) > 1 else "/tmp/manhattan_solved.g2o"
 fg = R.loadG2o(path, N=100)                                   # x0 + PriorPose2(N(0, diag(0.1², 0.1², 0.05²))) + every EDGE_SE2
+if "--tree" in sys.argv:     # the reference's own call sequence (examples/ManhattanDatasetBatch.jl:43): tree = solveTree!(fg) -- no parametric start
+    t = time.perf_counter(); ts_ = R.solveTree(fg, seed=11); tt = time.perf_counter() - t
+    labels = sorted(fg.variables, key=lambda s: int(s[1:]))
+    mean, std = R.belief_stats(np.stack([fg.getVal(l) for l in labels]))
+    print("%d poses, %d factors: initAll + Bayes tree solve (%s) %.2f s wall-clock" % (len(labels), len(fg.factors), ts_.tree.summary(), tt))
+    R.exportG2o(fg, filename=out, estimates={l: mean[k] for k, l in enumerate(labels)}, varIntLabel={l: int(l[1:]) for l in labels})
+    print("wrote", out)
+    sys.exit(0)
 R.dead_reckon_init(fg, seed=1)
 t = time.perf_counter(); xp = R.solveGraphParametric(fg); tp = time.perf_counter() - t
 dg = R.DeviceGraph(fg)
