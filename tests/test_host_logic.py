@@ -502,3 +502,28 @@ def test_tree_solver_edge_cases_over_the_oracle_backend():
     for msg in ("relative", "marginal"):
         ts = TreeSolver(fg3, messages=msg, backend=OracleTreeBackend(R)); ts.upload(); ts.solve(R.make_opts(N=N, seed=2))
         assert 0.05 < ts.store.get("x0")[0].std() < 0.2
+
+
+def test_entropy_uniforms_law_independent_of_the_oracle_definition():
+    """device == oracle on the jitter draws is agreement of two implementations of ONE definition; this is the
+    counterweight -- the LAW of the entropy uniforms themselves: U(0, 1) marginally (KS on 1.2e5 draws per coordinate), no correlation
+    between the coordinates of a draw, between consecutive inflation cycles of a particle (lag 1 in the cycle index), between
+    neighbouring particles, or between neighbouring streams (rows); d = 6 uses a second Philox block: same checks across the blocks."""
+    from scipy import stats
+    P, Cy, S = 500, 6, 40
+    U = np.array([[[ro.rng_entropy(0x524F4D45, s, i, c, 6) for c in range(Cy)] for i in range(P)] for s in range(S)])   # [stream, particle, cycle, coord]
+    assert ((U > 0) & (U < 1)).all()
+    for d in range(6):
+        x = U[..., d].ravel()
+        assert stats.kstest(x, "uniform").pvalue > 1e-3, d
+        assert abs(x.mean() - 0.5) < 3e-3 and abs(x.var() - 1 / 12) < 1.5e-3
+    flat = U.reshape(-1, 6)
+    cc = np.corrcoef(flat.T)
+    assert np.abs(cc - np.eye(6)).max() < 0.012                                  # coordinates of one draw (incl. across the two blocks)
+    lag_cycle = np.corrcoef(U[:, :, :-1, :].ravel(), U[:, :, 1:, :].ravel())[0, 1]
+    lag_particle = np.corrcoef(U[:, :-1].ravel(), U[:, 1:].ravel())[0, 1]
+    lag_stream = np.corrcoef(U[:-1].ravel(), U[1:].ravel())[0, 1]
+    assert max(abs(lag_cycle), abs(lag_particle), abs(lag_stream)) < 0.006, (lag_cycle, lag_particle, lag_stream)
+    # the jitter a particle receives over the three default cycles: the sum of three uniforms per coordinate (Irwin-Hall): variance 3/12
+    s3 = (U[:, :, :3, :3] - 0.5).sum(axis=2).ravel()
+    assert abs(s3.var() - 0.25) < 4e-3 and abs(stats.skew(s3)) < 0.02
