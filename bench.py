@@ -691,6 +691,17 @@ def main():
                 tsv.download()
                 passes.append({"up_s": tu, "down_s": td, "rms_to_parametric_m": rms_fg(), "rms_after_rigid_alignment_m": rms_fg(True)})
             st_ = tsv.stats()
+            # IIF's own message form (per-variable separator beliefs, gibbsIters = 3 up / 1 down) on the same tree, from the same init
+            fg2 = R.loadG2o(args.g2o, N=N) if (args.g2o and args.g2o != "synthetic") else R.synth_manhattan(P=args.poses, loops=args.loops, seed=0x524F4D45 + rank, N=N)
+            R.initAllOrdered(fg2, seed=1, ctx=ctx)
+            tsm = TreeSolver(fg2, tree=tsv.tree, messages="marginal", ctx=ctx); tsm.upload()
+            o5 = R.make_opts(N=N, seed=100)
+            ctx.synchronize(); a = time.perf_counter(); tsm.solve(o5); ctx.synchronize(); t_marg = time.perf_counter() - a
+            tsm.download()
+            m_, _ = R.belief_stats(np.stack([fg2.getVal(l) for l in ls1]))
+            marg = {"seconds_per_pass": t_marg, "rms_to_parametric_m": float(np.sqrt(np.mean(np.sum((m_[:, :2] - mp1[:, :2]) ** 2, axis=1)))),
+                    "what": "IIF's message form (TreeBelief per separator variable; upGibbsCliqueDensity with 3 iterations, down pass 1): on a pose graph with ONE prior "
+                            "the cliques below the prior's clique hold no absolute information -- the solve stays where the init pass left it"}
             out["solve"]["from_tree"] = {
                 "what": "NO starting beliefs: initAll!-order init pass, then Bayes tree (minimum-degree elimination -> %d cliques -> %d levels, widest %d) up pass + "
                         "down pass with '%s' messages, one rome_upsolve_plan per level, device-resident; each further pass re-solves from the previous posterior"
@@ -702,7 +713,7 @@ def main():
                 "rms_after_rigid_alignment_m_over_passes": {"min": min(p_["rms_after_rigid_alignment_m"] for p_ in passes),
                                                             "median": float(np.median([p_["rms_after_rigid_alignment_m"] for p_ in passes])),
                                                             "max": max(p_["rms_after_rigid_alignment_m"] for p_ in passes)},
-                "seconds_per_pass": float(np.median([p_["up_s"] + p_["down_s"] for p_ in passes])),
+                "seconds_per_pass": float(np.median([p_["up_s"] + p_["down_s"] for p_ in passes])), "marginal_messages": marg,
                 "frontier_width_by_level": [len(l) for l in tsv.tree.levels],
                 "note": "N = 100 particles: a pass is a stochastic estimate -- the spread over passes is its sampling noise (mostly a rigid transform of the whole "
                         "map about the prior pose: see rms_after_rigid_alignment_m); DESIGN.md section 11"}
