@@ -210,3 +210,37 @@ def test_solve_tree_host_entry_like_the_reference_example():
     assert ts2 is ts and any(not np.array_equal(before[l], fg.getVal(l)) for l in fg.variables)
     with pytest.raises(ValueError):
         R.solveTree(R.generateGraph_Hexagonal(N=100), tree=ts)
+
+
+def test_staged_products_agree_with_the_single_product_in_law():
+    """A hub pose seen from 14 spokes (each spoke has its own prior and one Pose2Pose2 to the hub): the hub's product takes 14 proposals.
+    TreeSolver(max_product=8) takes it in two stages (partial products of <= 8, identity rows), max_product=0 in ONE multiscale Gibbs product;
+    both recover the information-weighted mean of the proposals (Gaussian case: known in closed form) within the sampling error, with
+    comparable spread."""
+    N = 100
+    rng = np.random.default_rng(4)
+    truth = np.array([12.0, -5.0, 0.7])
+    res = {}
+    for mp_ in (0, 8):
+        fg = R.initfg(N)
+        fg.addVariable("h", R.Pose2)
+        for k in range(14):
+            a = 2 * np.pi * k / 14
+            spoke = np.array([truth[0] + 6 * np.cos(a), truth[1] + 6 * np.sin(a), a])
+            c, s = np.cos(spoke[2]), np.sin(spoke[2])
+            z = np.array([c * (truth[0] - spoke[0]) + s * (truth[1] - spoke[1]), -s * (truth[0] - spoke[0]) + c * (truth[1] - spoke[1]), truth[2] - spoke[2]])
+            fg.addVariable("s%d" % k, R.Pose2)
+            fg.addFactor(["s%d" % k], R.PriorPose2(R.MvNormal(spoke, np.diag([0.01, 0.01, 0.0004]))))
+            fg.addFactor(["s%d" % k, "h"], R.Pose2Pose2(R.MvNormal(z, np.diag([0.04, 0.04, 0.0025]))))
+        R.initAllOrdered(fg, seed=1)
+        ts = TreeSolver(fg, messages="relative", max_product=mp_)
+        assert max(len(s_.pairs) for s_ in ts.up_specs + ts.down_specs) > 0
+        ts.upload(); ts.solve(R.make_opts(N=N, seed=9)); ts.download()
+        h = fg.getVal("h")
+        res[mp_] = (h[:2].mean(1), h[:2].std(1), np.arctan2(np.sin(h[2]).mean(), np.cos(h[2]).mean()))
+        staged = any("^" in l for s_ in ts.up_specs + ts.down_specs for l in s_.order)
+        assert staged == (mp_ == 8)
+    for mp_, (m, sd, th) in res.items():
+        assert np.abs(m - truth[:2]).max() < 0.15 and abs(th - truth[2]) < 0.05, (mp_, m, th)      # 14 proposals of sigma ~0.25: posterior sigma ~0.07
+        assert 0.02 < sd.max() < 0.3, (mp_, sd)
+    assert np.abs(res[0][0] - res[8][0]).max() < 0.15
