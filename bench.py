@@ -681,7 +681,7 @@ def main():
                     A = A @ Rr.T
                 return float(np.sqrt(np.mean(np.sum((A - B) ** 2, axis=1))))
             r_init = rms_fg()
-            a = time.perf_counter(); tsv = TreeSolver(fg1, messages=args.tree_messages, ctx=ctx); t_build = time.perf_counter() - a   # (defaults: one root / refine sweep)
+            a = time.perf_counter(); tsv = TreeSolver(fg1, messages=args.tree_messages, ctx=ctx); t_build = time.perf_counter() - a
             tsv.upload()
             passes = []
             for ps in range(8):
@@ -691,10 +691,6 @@ def main():
                 tsv.download()
                 passes.append({"up_s": tu, "down_s": td, "rms_to_parametric_m": rms_fg(), "rms_after_rigid_alignment_m": rms_fg(True)})
             st_ = tsv.stats()
-            # the same without the root / refine sweeps (the outward solves alone): half the time, the same pose means, wider beliefs
-            tsn = TreeSolver(fg1, tree=tsv.tree, messages=args.tree_messages, ctx=ctx, rootIters=0, refineIters=0); tsn.upload()
-            tsn.solve(R.make_opts(N=N, seed=99)); ctx.synchronize()
-            a = time.perf_counter(); tsn.solve(R.make_opts(N=N, seed=98)); ctx.synchronize(); t_norefine = time.perf_counter() - a
             # IIF's own message form (per-variable separator beliefs, gibbsIters = 3 up / 1 down) on the same tree, from the same init
             fg2 = R.loadG2o(args.g2o, N=N) if (args.g2o and args.g2o != "synthetic") else R.synth_manhattan(P=args.poses, loops=args.loops, seed=0x524F4D45 + rank, N=N)
             R.initAllOrdered(fg2, seed=1, ctx=ctx)
@@ -717,7 +713,7 @@ def main():
                 "rms_after_rigid_alignment_m_over_passes": {"min": min(p_["rms_after_rigid_alignment_m"] for p_ in passes),
                                                             "median": float(np.median([p_["rms_after_rigid_alignment_m"] for p_ in passes])),
                                                             "max": max(p_["rms_after_rigid_alignment_m"] for p_ in passes)},
-                "seconds_per_pass": float(np.median([p_["up_s"] + p_["down_s"] for p_ in passes])), "marginal_messages": marg, "seconds_per_pass_without_root_and_refine_sweeps": t_norefine,
+                "seconds_per_pass": float(np.median([p_["up_s"] + p_["down_s"] for p_ in passes])), "marginal_messages": marg,
                 "frontier_width_by_level": [len(l) for l in tsv.tree.levels],
                 "note": "N = 100 particles: a pass is a stochastic estimate -- the spread over passes is its sampling noise (mostly a rigid transform of the whole "
                         "map about the prior pose: see rms_after_rigid_alignment_m); DESIGN.md section 11"}

@@ -222,18 +222,15 @@ class TreeSolver:
     messages: "relative" or "marginal" (module docstring).  gibbsIters / downIters: iterations of the up / down clique solves in
     "marginal" form (IIF: 3 / 1).  The "relative" form solves every variable ONCE outward (up and down); rootIters / refineIters add
     Gibbs sweeps over the frontals of the root / of every clique in the down pass with ALL factors and messages of the clique (the
-    outward solve takes a variable's proposals from the neighbours solved before it only).  Default one sweep each: the beliefs then
-    have the spread the reference's acceptance windows expect (hexagon, test/testHexagonal2D_CliqByCliq.jl:37-79: >= 0.39 of the particles
-    in every box over five seeds; 0.21 - 0.33 without the sweep, scripts/tree_hexagon_windows.py); on Manhattan-3500 the pose means are
-    the same with or without them and a pass takes 0.20 s instead of 0.10 s.  relIters: the same inside the relative solve of the up
-    pass (anchor fixed), before the samples of anchor^-1 * separator are taken -- measured HARMFUL (over-confident messages), default 0.
+    outward solve takes a variable's proposals from the neighbours solved before it only); relIters the same inside the relative solve
+    of the up pass (anchor fixed), before the samples of anchor^-1 * separator are taken.
     max_product ("relative" form): a Pose2 variable with more proposals than this takes its product in TWO stages -- partial products
     over chunks of at most max_product proposals (scratch blocks, all chunks of all variables of the step in one launch), then the
     product of the partial products (each enters through an identity row: a sampled-measurement Pose2Pose2 row whose samples are all
     zero).  The multiscale Gibbs product is ONE two-wave block per variable and its time grows with the square of the number of
     proposals (42 proposals: 14 ms with the rest of the chip idle; profiles/r05_tree_solve.txt); 0 = one product whatever the count."""
 
-    def __init__(self, fg, tree=None, order="mmd", last=(), messages="relative", gibbsIters=3, downIters=1, rootIters=1, refineIters=1, relIters=0,
+    def __init__(self, fg, tree=None, order="mmd", last=(), messages="relative", gibbsIters=3, downIters=1, rootIters=0, refineIters=0, relIters=0,
                  max_product=8, backend=None, ctx=None, shard=None):
         """shard: a factory `store -> distributed.FrontierShard` (the store exists only once the lifted universe is known): every level is
         then dealt to the ranks by clique -- share up-solve, ONE all-gather of the level's written blocks, one scatter; the block
