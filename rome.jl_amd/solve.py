@@ -91,11 +91,12 @@ def solveGraph(fg, n_sweeps=10, seed=0x524F4D45, init="graph", bandwidth="silver
     return dg
 
 
-def solveTree(fg, tree=None, messages="relative", passes=1, seed=0x524F4D45, ctx=None, order="mmd", **kw):
+def solveTree(fg, tree=None, messages="marginal", passes=1, seed=0x524F4D45, ctx=None, order="mmd", **kw):
     """IIF `solveTree!(fg [, tree])` (examples/Hexagonal2D_SLAM.jl:24, examples/ManhattanDatasetBatch.jl:43, the incremental re-solves of
     examples/ManhattanDatasetIncremental.jl:107): `initAll!` for whatever has no belief yet (`initAllOrdered`), Bayes tree (built here, or the
     `tree.TreeSolver` of a previous call to re-solve from the current beliefs: plans are reused), up pass + down pass on the device,
-    beliefs written back, PPEs set.  messages: "relative" (default) or "marginal" = IIF's per-variable separator beliefs (tree.py).
+    beliefs written back, PPEs set.  messages: "marginal" (default) = IIF's per-variable separator beliefs, or "relative" (tree.py: the form
+    that moves a large single-prior pose graph off its init pass).
     -> the TreeSolver (its store keeps the beliefs on the device; pass it back as `tree=` after adding nothing to the graph)."""
     from .api import make_opts
     from .canonical import setPPE

@@ -13,7 +13,7 @@ Two message forms (`TreeSolver(messages=...)`):
               separator copy (IIF TreeBelief: N points + manikde! bandwidths per separator VARIABLE).  A pose graph with one prior has
               no absolute information below the prior's clique: such messages only restate the beliefs the init pass left, and the
               solve stays where `initAll!` put it (measured: DESIGN.md, scripts/tree_surrogate.py).
-  "relative"  the message keeps what a prior-free sub-tree DOES know -- where its separators are relative to each other: the clique
+  "relative"  (opt-in) the message keeps what a prior-free sub-tree DOES know -- where its separators are relative to each other: the clique
               conditions on its ANCHOR separator (the first Pose2 one) being exactly at its current mean, solves outward from it ONCE
               (every variable takes the product of the proposals from already-solved neighbours; no belief is used before the clique's
               own potential has informed it), and sends, per other separator s, the N samples of anchor^-1 * s -- a Pose2Pose2 /
@@ -219,7 +219,9 @@ class TreeSolver:
     backend: object with Store(universe_fg) -> store (`.index`, `.upload(fg)`, `.download(fg, labels)`), Plan(store, spec, share=None)
     -> `.run(opts)`, BlockOp(store, op, entries) -> `.run()` (op "copy" / "anchor" / "relative").  Default: the device
     (`DeviceBackend`); the CPU tests inject an oracle-backed one.
-    messages: "relative" or "marginal" (module docstring).  gibbsIters / downIters: iterations of the up / down clique solves in
+    messages: "marginal" (default: IIF's form -- the reference's semantics, and the more robust one on small or multimodal graphs: hexagon
+    windows, beehive, the reference's Manhattan-500 graph) or "relative" (what moves a LARGE pose graph with a single prior off its init
+    pass: Manhattan-3500 5.3 m -> metres; module docstring).  gibbsIters / downIters: iterations of the up / down clique solves in
     "marginal" form (IIF: 3 / 1).  The "relative" form solves every variable ONCE outward (up and down); rootIters / refineIters add
     Gibbs sweeps over the frontals of the root / of every clique in the down pass with ALL factors and messages of the clique (the
     outward solve takes a variable's proposals from the neighbours solved before it only); relIters the same inside the relative solve
@@ -230,7 +232,7 @@ class TreeSolver:
     zero).  The multiscale Gibbs product is ONE two-wave block per variable and its time grows with the square of the number of
     proposals (42 proposals: 14 ms with the rest of the chip idle; profiles/r05_tree_solve.txt); 0 = one product whatever the count."""
 
-    def __init__(self, fg, tree=None, order="mmd", last=(), messages="relative", gibbsIters=3, downIters=1, rootIters=0, refineIters=0, relIters=0,
+    def __init__(self, fg, tree=None, order="mmd", last=(), messages="marginal", gibbsIters=3, downIters=1, rootIters=0, refineIters=0, relIters=0,
                  max_product=8, backend=None, ctx=None, shard=None):
         """shard: a factory `store -> distributed.FrontierShard` (the store exists only once the lifted universe is known): every level is
         then dealt to the ranks by clique -- share up-solve, ONE all-gather of the level's written blocks, one scatter; the block
