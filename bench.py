@@ -244,7 +244,7 @@ def main():
     # ROME_BENCH_SHARED_DEVICE=1 (tests only, never a measurement): all ranks launch on device 0, the process group is gloo and the
     # separator / belief exchange goes through rome_jl_amd.rccl.HostStagedComm -- RCCL refuses two ranks on one device, and this is
     # how the N > 1 flow of this file (per-rank tables, pipeline, barriers, max-over-ranks timing, rank 0's JSON line) runs as N
-    # real processes on a one-GPU box (tests/test_gpu_two_ranks_one_device.py).  The line it prints says so.
+    # real processes on a one-GPU box (tests/test_gpu_zz_ranks_one_device.py).  The line it prints says so.
     shared = os.environ.get("ROME_BENCH_SHARED_DEVICE") == "1"
     if shared:
         local = 0

@@ -20,7 +20,9 @@ path = argv[0] if len(argv) > 0 else os.path.join(ROOT, "tests", "golden", "manh
 out = argv[1] if len(argv) > 1 else "/tmp/manhattan_solved.g2o"
 fg = R.loadG2o(path, N=100)                                   # x0 + PriorPose2(N(0, diag(0.1², 0.1², 0.05²))) + every EDGE_SE2
 if "--tree" in sys.argv:     # the reference's own call sequence (examples/ManhattanDatasetBatch.jl:43): tree = solveTree!(fg) -- no parametric start
-    t = time.perf_counter(); ts_ = R.solveTree(fg, messages="relative", seed=11)   # (the form that moves a 3500-pose single-prior graph off its init pass); tt = time.perf_counter() - t
+    t = time.perf_counter()
+    ts_ = R.solveTree(fg, messages="relative", seed=11)   # (the form that moves a 3500-pose single-prior graph off its init pass)
+    tt = time.perf_counter() - t
     labels = sorted(fg.variables, key=lambda s: int(s[1:]))
     mean, std = R.belief_stats(np.stack([fg.getVal(l) for l in labels]))
     print("%d poses, %d factors: initAll + Bayes tree solve (%s) %.2f s wall-clock" % (len(labels), len(fg.factors), ts_.tree.summary(), tt))

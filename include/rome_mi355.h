@@ -122,8 +122,10 @@ void rome_opts_default(rome_opts* o, int32_t solver);
 int  rome_ctx_create(rome_ctx** out, int device);
 void rome_ctx_destroy(rome_ctx* ctx);
 int  rome_ctx_set_stream(rome_ctx* ctx, void* hip_stream); /* launch on a caller-owned hipStream_t; NULL = HIP's default (null) stream.
-                                                             * When the stream CHANGES and a context-owned workspace is in use (the clique /
-                                                             * product / host-pointer entries), the previous stream is drained first */
+                                                             * When the stream CHANGES, the new stream is ordered after everything queued
+                                                             * on the previous one (event record + stream wait, no host synchronisation):
+                                                             * what is launched through ONE context is one sequence whatever the stream.
+                                                             * Concurrency takes one context per stream (SeparatorPipeline: one per slot) */
 int  rome_ctx_use_own_stream(rome_ctx* ctx);               /* back to the context's private non-blocking stream (the default) */
 int  rome_ctx_synchronize(rome_ctx* ctx);
 int  rome_device_count(void);

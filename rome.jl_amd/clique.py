@@ -317,6 +317,7 @@ class DeviceStore:
             _lib.check(self._lib.rome_store_create(self.ctx.handle, self.N, n[0], n[1], n[2], C.byref(h)), self.ctx.handle)
         else:
             self._keep = wrap
+            self.touched.update(fg.variables)        # caller-owned tensors already hold beliefs: download() returns all of them
             ptrs = [C.c_void_p(wrap[vt].data_ptr()) if n[k] else None for k, vt in enumerate(self.TYPES)]
             _lib.check(self._lib.rome_store_wrap(self.ctx.handle, self.N, n[0], ptrs[0], n[1], ptrs[1], n[2], ptrs[2], C.byref(h)), self.ctx.handle)
         self.handle = h
@@ -360,18 +361,18 @@ class DeviceStore:
         store.  A block that was never written is zero-initialised memory, not a belief: copying it back would make the variable count as
         initialised (FactorGraph.isInitialized) with all-zero particles."""
         fg = fg or self.fg
-        if labels is None:
-            labels = self.touched
+        labels = self.touched if labels is None else set(labels)
         for ti, vt in enumerate(self.TYPES):
             ls = self.labels[vt]
-            if not ls:
+            want = [k for k, l in enumerate(ls) if l in labels and l in fg.variables]
+            if not want:
                 continue
-            out = np.zeros((len(ls), vt.dim, self.N))
-            _lib.check(self._lib.rome_store_download(self.handle, _lib.LAYOUT_SOA, ti, 0, len(ls), out.ctypes.data_as(C.POINTER(C.c_double))),
+            lo, hi = want[0], want[-1] + 1          # only the index range that holds requested blocks crosses PCIe
+            out = np.zeros((hi - lo, vt.dim, self.N))
+            _lib.check(self._lib.rome_store_download(self.handle, _lib.LAYOUT_SOA, ti, lo, hi - lo, out.ctypes.data_as(C.POINTER(C.c_double))),
                        self.ctx.handle)
-            for k, l in enumerate(ls):
-                if l in labels and l in fg.variables:
-                    fg.vals[l] = out[k].copy()
+            for k in want:
+                fg.vals[ls[k]] = out[k - lo].copy()
 
     def device_ptr(self, vt):
         p, n = C.c_void_p(), C.c_int32()

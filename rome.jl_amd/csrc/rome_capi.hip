@@ -14,7 +14,6 @@ struct rome_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipError_t last_hip = hipSuccess;
-  bool ws_used = false;   // a context-owned device workspace has been handed to work on `stream` since the last drain
   static constexpr int kBufs = 13;   // 9 clique arena, 10 Gibbs trees, 11 / 12 temporary store / plan of the one-shot up-solve
   void* dbuf[kBufs] = {nullptr};
   size_t dcap[kBufs] = {0};
@@ -27,6 +26,7 @@ struct rome_ctx {
   static constexpr int kSide = 5;
   hipStream_t side[kSide] = {nullptr};
   hipEvent_t ev_fork = nullptr, ev_side[kSide] = {nullptr}, ev_side2[kSide] = {nullptr};   // two event sets: the phases alternate
+  hipEvent_t ev_order = nullptr;   // rome_ctx_set_stream: the new stream is ordered after everything queued on the previous one
 };
 
 namespace {
@@ -60,7 +60,6 @@ int ensure(rome_ctx* c, int idx, size_t bytes, void** out) {
     c->dcap[idx] = cap;
   }
   *out = c->dbuf[idx];
-  c->ws_used = true;
   return ROME_OK;
 }
 
@@ -388,19 +387,23 @@ void rome_ctx_destroy(rome_ctx* c) {
     if (c->ev_side2[i]) (void)hipEventDestroy(c->ev_side2[i]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_order) (void)hipEventDestroy(c->ev_order);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
 int rome_ctx_set_stream(rome_ctx* c, void* hip_stream) {
   if (!c) return ROME_ERR_INVALID_ARG;
-  if (c->stream != (hipStream_t)hip_stream && c->ws_used) {
-    // the context's workspaces (staging arenas, the Gibbs tree workspace) are shared by everything launched through it: work queued
-    // on the previous stream must be done with them before launches on another stream may touch them.  (Entries that use none --
-    // the rome_conv_*_dev sweeps a pipeline alternates between streams -- switch without a drain.)
+  if (c->stream != (hipStream_t)hip_stream) {
+    // Everything launched through a context is ONE logical sequence whatever stream it runs on: belief stores, plans' arenas, the
+    // context's workspaces and caller tensors written by an earlier entry are read by later ones.  A stream change therefore orders
+    // the new stream after ALL work queued on the previous one -- unconditionally, by an event (no host synchronisation, a few µs):
+    // the previous stream may be the private non-blocking one, which nothing else ever joins (round 5's race: a block operation on
+    // the private stream, then a plan run on the caller's stream reading its blocks).
     ROME_BIND(c);
-    ROME_HIP(c, hipStreamSynchronize(c->stream));
-    c->ws_used = false;
+    if (!c->ev_order) ROME_HIP(c, hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
+    ROME_HIP(c, hipEventRecord(c->ev_order, c->stream));
+    ROME_HIP(c, hipStreamWaitEvent((hipStream_t)hip_stream, c->ev_order, 0));
   }
   c->stream = (hipStream_t)hip_stream;  // NULL is HIP's default (null) stream, e.g. torch's default stream
   return ROME_OK;
@@ -412,7 +415,6 @@ int rome_ctx_use_own_stream(rome_ctx* c) {
 int rome_ctx_synchronize(rome_ctx* c) {
   if (!c) return ROME_ERR_INVALID_ARG;
   ROME_HIP(c, hipStreamSynchronize(c->stream));
-  c->ws_used = false;
   return ROME_OK;
 }
 

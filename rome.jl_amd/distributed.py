@@ -505,12 +505,19 @@ class FrontierShard:
         return self._exchange_plan(labels, spec.fg.variables.__getitem__, lambda mirror: level_plan_cls(
             self.store, spec, share=shares[self.rank], mirror=mirror))
 
-    def step(self, plan, opts):
-        """up-solve this rank's share, exchange, scatter: afterwards every rank's store holds ALL new frontal beliefs"""
+    def bind_stream(self):
+        """launches, collective and scatter on ONE stream -- torch's current stream, which the collective is enqueued on.  Callers that
+        launch through the store's context BETWEEN steps (TreeSolver's block operations) bind before their first launch, so the whole
+        pass is one in-order queue (rome_ctx_set_stream orders a stream change after the previous stream in any case)."""
         st = None
         if self.device.type == "cuda" and hasattr(self.store, "ctx"):
-            st = self.torch.cuda.current_stream(self.device).cuda_stream       # launches, collective and scatter on ONE stream
+            st = self.torch.cuda.current_stream(self.device).cuda_stream
             self.store.ctx.set_stream(st)
+        return st
+
+    def step(self, plan, opts):
+        """up-solve this rank's share, exchange, scatter: afterwards every rank's store holds ALL new frontal beliefs"""
+        st = self.bind_stream()
         if plan["up"] is not None:
             plan["up"].run(opts, mirror_out=plan["send"], mirror_stride=plan["U"])
         if self.world > 1 or self.always_collective:
@@ -556,10 +563,14 @@ class LinearizeShard:
         n = hi - lo
         q = -(-F // self.world)                                  # rows per rank, padded
         per = dr * (1 + da + db)
-        key = (kind, id(mu), F)
-        if key not in self.cache:                                # the factor tables of this rank's rows: device-resident across iterations
+        key = int(kind)
+        ent = self.cache.get(key)
+        # the factor tables of this rank's rows: device-resident across the iterations of ONE solve.  The entry HOLDS the host arrays it
+        # was built from (their ids cannot be recycled while it lives) and is valid only for exactly those objects: another problem
+        # with the same kind and row count replaces it -- one entry per kind, so repeated / incremental solves do not accumulate tensors.
+        if ent is None or ent["mu_host"] is not mu or ent["W_host"] is not W or ent["F"] != F:
             t = lambda a: torch.as_tensor(np.ascontiguousarray(a[lo:hi], dtype=np.float64), device=self.device)   # noqa: E731
-            self.cache[key] = dict(mu=t(np.asarray(mu).reshape(F, dz)), W=t(np.asarray(W).reshape(F, dr * dr)),
+            self.cache[key] = dict(mu_host=mu, W_host=W, F=F, mu=t(np.asarray(mu).reshape(F, dz)), W=t(np.asarray(W).reshape(F, dr * dr)),
                                    recv=torch.zeros(self.world * q * per, dtype=torch.float64, device=self.device),
                                    xa=torch.empty((max(n, 1), da), dtype=torch.float64, device=self.device),
                                    xb=torch.empty((max(n, 1), max(db, 1)), dtype=torch.float64, device=self.device))

@@ -69,7 +69,7 @@ class HostStagedComm:
     """RcclComm's interface over the default process group of ANY backend, through host memory: synchronous device -> host -> collective
     -> host -> device.  NOT a transport for production and never chosen implicitly -- it exists for the one situation RCCL refuses:
     several ranks sharing ONE device (a one-GPU test box).  With it the multi-rank drivers and `bench.py --gpus N` run as N real
-    processes with the real kernels (tests/test_gpu_two_ranks_one_device.py, `ROME_BENCH_SHARED_DEVICE=1`); only the wire is replaced."""
+    processes with the real kernels (tests/test_gpu_zz_ranks_one_device.py, `ROME_BENCH_SHARED_DEVICE=1`); only the wire is replaced."""
 
     def __init__(self, torch, dist, world, ctx):
         from . import _lib

@@ -103,9 +103,17 @@ def solveTree(fg, tree=None, messages="marginal", passes=1, seed=0x524F4D45, ctx
     from .tree import TreeSolver
     if any(not fg.isInitialized(l) for l in fg.variables):
         initAllOrdered(fg, seed=seed & 0xFFFF, ctx=ctx)
-    ts = tree if isinstance(tree, TreeSolver) else TreeSolver(fg, messages=messages, ctx=ctx, order=order, **kw)
-    if ts.fg is not fg:
-        raise ValueError("solveTree: the TreeSolver passed as `tree` belongs to another graph")
+    from .tree import BayesTree
+    sig = (tuple(fg.variables), tuple(fl for fl, _, _ in fg.factors))
+    if isinstance(tree, TreeSolver):
+        ts = tree
+        if ts.fg is not fg:
+            raise ValueError("solveTree: the TreeSolver passed as `tree` belongs to another graph")
+        if getattr(ts, "graph_signature", sig) != sig:      # variables / factors were added since: the plans cover a stale tree
+            ts = TreeSolver(fg, messages=ts.messages, ctx=ctx, order=order, **kw)
+    else:   # (a BayesTree -- what the reference's solveTree!(fg, tree) takes -- is solved as given; None: built here)
+        ts = TreeSolver(fg, tree=tree if isinstance(tree, BayesTree) else None, messages=messages, ctx=ctx, order=order, **kw)
+    ts.graph_signature = sig
     ts.upload(fg)
     ts.solve(make_opts(N=fg.N, seed=seed), passes=passes)
     ts.download(fg)

@@ -600,6 +600,8 @@ class TreeSolver:
         self.store.upload(fg or self.fg)
 
     def up(self, opts):
+        if self.shard is not None:
+            self.shard.bind_stream()      # before the first block operation: the pass is ONE in-order queue with the collectives
         for pre, pl, post, rp, rl in zip(self.up_pre, self.up_plans, self.up_post, self.root_plans, self.rel_plans):
             for op in pre:
                 op.run()
@@ -613,6 +615,8 @@ class TreeSolver:
                 self._run(rp, opts)
 
     def down(self, opts):
+        if self.shard is not None:
+            self.shard.bind_stream()
         for pl, rf in zip(self.down_plans[::-1], self.refine_plans[::-1]):
             if pl is not None:
                 self._run(pl, opts)

@@ -37,7 +37,7 @@ def _wrapdiff(a, b):
 
 
 def _close(got, ref, frac=0.9):
-    """the bars of tests/test_gpu_upsolve.py: > 90 % of the particle coordinates identical to 1e-6, belief means within 1e-3"""
+    """the bars of tests/test_gpu_clique_upsolve.py: > 90 % of the particle coordinates identical to 1e-6, belief means within 1e-3"""
     d = _wrapdiff(got.copy(), ref)
     assert np.mean(np.abs(d) < 1e-6) > frac, np.mean(np.abs(d) < 1e-6)
     assert np.abs(d.mean(axis=1)).max() < 1e-3, d.mean(axis=1)
@@ -357,7 +357,7 @@ def test_beehive_multihypo_frontier_device_resident_timing():
     from rome_jl_amd import rccl
     N = 100
     dev = torch.device("cuda", 0)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = "29587"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(__import__("portutil").free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     lines = []
     try:

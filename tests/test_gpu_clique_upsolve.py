@@ -191,7 +191,7 @@ def test_frontier_shard_one_rank_rccl_device_resident():
     frontiers = [[["x0", "x1"], ["x3"], ["x5"]], [["x2"], ["x4"], ["x6", "l1"]]]
     fg_a, fg_b, fg_c = _hex(N), _hex(N), _hex(N)
     dev = torch.device("cuda", 0)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = "29581"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(__import__("portutil").free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         comms = rccl.create_comms(torch, dist, 1, 0, dev, 1)

@@ -120,7 +120,7 @@ def test_cut_lattice_through_separator_pipeline_one_rank_rccl():
     o = R.make_opts(N=N, solver=1, seed=5)
     # publish the proposals of 6 Pose2Pose2 rows, 3 bearing-range -> pose rows and 5 bearing-range -> landmark rows
     publish = [("p2p2", r) for r in (1, 4, 7, 10, 13, 16)] + [("br1", r) for r in (0, 2, 5)] + [("br0", r) for r in (0, 1, 3, 6, 8)]
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = "29571"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(__import__("portutil").free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         pipe = SeparatorPipeline(dg, o, dist, 1, 0, publish, [], always_collective=True, depth=2)

@@ -143,6 +143,13 @@ def test_pose3_helix_tree_solve_equals_the_oracle_tree_solve(messages):
         assert frac > 0.9 and dmean < 1e-3, worst
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_tree_levels_through_frontier_shard_one_rank_rccl():
     """TreeSolver(shard=FrontierShard) with the DIRECT RCCL binding (one rank, collective forced): every level's written blocks go through
     the packed exchange buffer (mirror stride N), ONE in-place ncclAllGather on the context's stream, ONE scatter -- same beliefs as the
@@ -154,7 +161,7 @@ def test_tree_levels_through_frontier_shard_one_rank_rccl():
     from rome_jl_amd import rccl
     N = 64
     dev = torch.device("cuda", 0)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = "29587"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         comms = rccl.create_comms(torch, dist, 1, 0, dev, 1)

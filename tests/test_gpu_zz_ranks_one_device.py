@@ -3,7 +3,7 @@ both ranks run their launches on cuda:0 and the communicator is `rome_jl_amd.rcc
 (`all_gather_f64(send_ptr, recv_ptr, count, stream)`) with device -> host -> gloo -> host -> device as the transport.  Everything else is the shipped path: rank-
 dependent tables and shares, ghost blocks, mirror writes of the sweep / product kernels into the exchange buffer, the in-place receive
 layout, the scatter plan, the depth-fold buffered pipeline.  What the RCCL transport itself adds is covered by the one-rank direct-RCCL
-tests (test_gpu_pipeline.py, test_gpu_upsolve.py, test_gpu_config4.py); the same drivers over oracle stand-ins at world 2 / 3 / 8 run in
+tests (test_gpu_pipeline.py, test_gpu_clique_upsolve.py, test_gpu_config4.py); the same drivers over oracle stand-ins at world 2 / 3 / 8 run in
 tests/test_distributed_gloo.py."""
 import os
 import socket
@@ -273,7 +273,7 @@ def _tree_worker(rank, world, port, ret, N, messages):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,messages", [(2, "relative"), (4, "relative"), (2, "marginal")])
+@pytest.mark.parametrize("world,messages", [(2, "relative"), (4, "relative"), (2, "marginal"), (8, "relative")])
 def test_tree_levels_sharded_by_clique_processes_equal_the_unsharded_tree_solve_real_kernels(world, messages):
     import torch
     import torch.multiprocessing as mp
