@@ -384,10 +384,19 @@ void rome_upsolve_plan_destroy(rome_upsolve_plan*);
  *                          coordinates of ref^-1 * s_i for the N particles s_i of Pose2 block b[k] (what a p2p2_meas row consumes);
  *                          type[k] = 1: Point2 block dst[k] <- (bearing, range) of the N landmarks of Point2 block b[k] seen from ref
  *                          (what a br1_meas / br0_meas row consumes)
- * type[k] = variable type of entry k (0 Pose2 / 1 Point2 / 2 Pose3; RELATIVE: of b and dst); b may be NULL except for RELATIVE.
+ *   ROME_BLOCKOP_COMPOSE   Pose2 blocks of relative-pose samples, particle by particle: dst[k]_i <- A'_i (+) B'_i, A' = a[k] or its
+ *                          inverse (type[k] |= ROME_BLOCKOP_INVERT_A), B' likewise.  Eliminating a variable v of a pose graph with
+ *                          sampled edges z_c = v^-1 c, z_k = v^-1 k leaves c^-1 k = z_c^-1 (+) z_k: the pair marginal of the
+ *                          neighbours, exactly (elimination.py: variable elimination in relative-factor algebra)
+ *   ROME_BLOCKOP_MIX       pooling of independent passes: particle i of dst[k] <- particle i of a[k] unless i % p == p - 1, with
+ *                          p = type[k] >> 8 >= 1: after pass p wrote dst, a = the pool of the p - 1 passes before it -- dst becomes a
+ *                          mixture in which every pass holds ~N / p particles (its mean: the running average of the passes)
+ * type[k] = variable type of entry k (0 Pose2 / 1 Point2 / 2 Pose3; RELATIVE: of b and dst); b may be NULL except for RELATIVE / COMPOSE.
  * Replaces (with smsg_* and p2p2_meas): the up-message channels between cliques of IIF's solveTree! (put!/take! of
  * TreeBelief messages), kept device-resident. */
-enum { ROME_BLOCKOP_COPY = 0, ROME_BLOCKOP_ANCHOR = 1, ROME_BLOCKOP_RELATIVE = 2 };
+enum { ROME_BLOCKOP_COPY = 0, ROME_BLOCKOP_ANCHOR = 1, ROME_BLOCKOP_RELATIVE = 2, ROME_BLOCKOP_COMPOSE = 3, ROME_BLOCKOP_MIX = 4 };
+#define ROME_BLOCKOP_INVERT_A 0x100   /* COMPOSE: OR into type[k] -- take the inverse of every particle of block a[k] ... */
+#define ROME_BLOCKOP_INVERT_B 0x200   /* ... of block b[k] */
 typedef struct rome_blockop_plan rome_blockop_plan;
 int  rome_blockop_plan_create(rome_ctx*, rome_store*, int32_t op, int32_t n, const int32_t* type, const int32_t* a, const int32_t* b,
                               const int32_t* dst, rome_blockop_plan** out);

@@ -1257,14 +1257,17 @@ int rome_scatter_plan_create(rome_ctx* c, rome_store* st, int32_t n, const int32
 }
 int rome_blockop_plan_create(rome_ctx* c, rome_store* st, int32_t op, int32_t n, const int32_t* type, const int32_t* a, const int32_t* b,
                              const int32_t* dst, rome_blockop_plan** out) {
-  if (!c || !st || !out || st->ctx != c || n < 0 || op < ROME_BLOCKOP_COPY || op > ROME_BLOCKOP_RELATIVE) return ROME_ERR_INVALID_ARG;
-  if (n > 0 && (!type || !a || !dst || (op == ROME_BLOCKOP_RELATIVE && !b))) return ROME_ERR_INVALID_ARG;
+  if (!c || !st || !out || st->ctx != c || n < 0 || op < ROME_BLOCKOP_COPY || op > ROME_BLOCKOP_MIX) return ROME_ERR_INVALID_ARG;
+  if (n > 0 && (!type || !a || !dst || ((op == ROME_BLOCKOP_RELATIVE || op == ROME_BLOCKOP_COMPOSE) && !b))) return ROME_ERR_INVALID_ARG;
   std::vector<int32_t> ent((size_t)n * 4 + 4, 0);
   for (int k = 0; k < n; ++k) {
-    const int t = type[k];
-    if (t < 0 || t > 2 || a[k] < 0 || a[k] >= st->nv[op == ROME_BLOCKOP_RELATIVE ? 0 : t] || dst[k] < 0 || dst[k] >= st->nv[t]) return ROME_ERR_INVALID_ARG;
+    const int t = type[k] & 0xff, fl = type[k] >> 8;
+    if (type[k] < 0 || t > 2 || a[k] < 0 || a[k] >= st->nv[op == ROME_BLOCKOP_RELATIVE ? 0 : t] || dst[k] < 0 || dst[k] >= st->nv[t]) return ROME_ERR_INVALID_ARG;
+    if (op != ROME_BLOCKOP_COMPOSE && op != ROME_BLOCKOP_MIX && fl != 0) return ROME_ERR_INVALID_ARG;
+    if (op == ROME_BLOCKOP_MIX && (fl < 1 || dst[k] == a[k])) return ROME_ERR_INVALID_ARG;
     if (op == ROME_BLOCKOP_RELATIVE && (t > 1 || b[k] < 0 || b[k] >= st->nv[t] || a[k] >= st->nv[0])) return ROME_ERR_INVALID_ARG;
-    ent[4 * (size_t)k] = t; ent[4 * (size_t)k + 1] = a[k]; ent[4 * (size_t)k + 2] = b ? b[k] : 0; ent[4 * (size_t)k + 3] = dst[k];
+    if (op == ROME_BLOCKOP_COMPOSE && (t != 0 || fl > 3 || b[k] < 0 || b[k] >= st->nv[0] || dst[k] == a[k] || dst[k] == b[k])) return ROME_ERR_INVALID_ARG;
+    ent[4 * (size_t)k] = type[k]; ent[4 * (size_t)k + 1] = a[k]; ent[4 * (size_t)k + 2] = b ? b[k] : 0; ent[4 * (size_t)k + 3] = dst[k];
   }
   ROME_BIND(c);
   rome_blockop_plan* B = new (std::nothrow) rome_blockop_plan();

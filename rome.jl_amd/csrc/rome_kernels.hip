@@ -1544,15 +1544,37 @@ hipError_t launch_scatter_blocks(int n, int N, const int32_t* ent, const double*
   return hipGetLastError();
 }
 
-// ---- block operations inside a store (copy / anchor / relative): one 256-thread block per entry (type, a, b, dst)
+// ---- block operations inside a store (copy / anchor / relative / compose): one 256-thread block per entry (type | flags << 8, a, b, dst)
 __global__ void __launch_bounds__(256) k_block_ops(int op, int N, const int4* __restrict__ ent, double* d2, double* dpt, double* d3) {
-  const int4 e = ent[blockIdx.x];
+  int4 e = ent[blockIdx.x];
+  const int flags = e.x >> 8;   // (compose: bit 0 = take A^-1, bit 1 = take B^-1)
+  e.x &= 0xff;
   const int dim = e.x == 0 ? 3 : (e.x == 1 ? 2 : 6);
   double* base = e.x == 0 ? d2 : (e.x == 1 ? dpt : d3);
   const double* A = base + (size_t)e.y * dim * N;
   double* D = base + (size_t)e.w * dim * N;
   const int i = threadIdx.x;
   if (op == 0) { for (int q = i; q < dim * N; q += 256) D[q] = A[q]; return; }
+  if (op == 4) {   // mix: particle i of D <- particle i of A unless i % k == k - 1 (k = flags): D keeps every k-th particle of its own
+    const int k = flags < 1 ? 1 : flags;
+    for (int q = i; q < N; q += 256)
+      if (q % k != k - 1)
+        for (int d = 0; d < dim; ++d) D[(size_t)d * N + q] = A[(size_t)d * N + q];
+    return;
+  }
+  if (op == 3) {   // compose, particle by particle, Pose2 coordinates (x, y, theta): D_i = A'_i (+) B'_i with A' = A or A^-1, B' = B or B^-1
+    const double* Bq = d2 + (size_t)e.z * 3 * N;
+    for (int q = i; q < N; q += 256) {
+      double ax = A[q], ay = A[N + q], at = A[2 * N + q], bx = Bq[q], by = Bq[N + q], bt = Bq[2 * N + q];
+      double sn, cs;
+      if (flags & 1) { sincos(at, &sn, &cs); const double x = -(cs * ax + sn * ay), y = -(-sn * ax + cs * ay); ax = x; ay = y; at = -at; }
+      if (flags & 2) { sincos(bt, &sn, &cs); const double x = -(cs * bx + sn * by), y = -(-sn * bx + cs * by); bx = x; by = y; bt = -bt; }
+      sincos(at, &sn, &cs);
+      double s2, c2; sincos(at + bt, &s2, &c2);
+      D[q] = ax + cs * bx - sn * by; D[N + q] = ay + sn * bx + cs * by; D[2 * N + q] = atan2(s2, c2);
+    }
+    return;
+  }
   if (op == 2) {   // relative to ref = particle 0 of the POSE2 block e.y: Pose2 -> tangent coordinates of ref^-1 * s_i; Point2 -> (bearing, range)
     const double* Rf = d2 + (size_t)e.y * 3 * N;
     const double* S = base + (size_t)e.z * dim * N;

@@ -1,0 +1,373 @@
+"""`solveTree!` for pose graphs as VARIABLE ELIMINATION IN RELATIVE-FACTOR ALGEBRA (`R.solveTree(fg, messages="elimination")`).
+
+Why (round 6; docs/EXPERIMENTS.md, scripts/relative_elimination_surrogate.py, scripts/tree_gaussian_backend.py): the clique solves of
+tree.TreeSolver are one-shot outward solves and their down pass multiplies proposals whose spread is the neighbours' ABSOLUTE spread --
+the weights of a product then follow the (common, gauge-dominated) uncertainty of where the neighbours are instead of how tight each
+factor is, and the solve stays at the quality of the init pass (measured on Manhattan-3500 against the converged MAP: init pass 0.8 /
+tree solves 0.9 - 2.1 m after rigid alignment in the Gaussian restatement of the schedule; the exact elimination 0.18 m in ONE pass).
+What an elimination needs is (a) the marginal over the neighbours of the eliminated variable and (b) the conditional of the variable
+given its neighbours' VALUES.  For a pose graph both exist in sample form without any belief about where the poses are:
+
+  edges     every factor between a and b is N samples of the relative pose a^-1 b (Pose2Pose2: mu + L xi; any SamplableBelief would do)
+  merge     parallel edges between one pair multiply: the reference's `manifoldProduct` (manikde! bandwidths + multiscale Gibbs
+            product) on the relative-pose samples
+  eliminate v with neighbours u_1..u_m (edges z_k = v^-1 u_k): the pair marginal of (u_j, u_k) is EXACTLY the composition
+            z_j^-1 (+) z_k, particle by particle (ROME_BLOCKOP_COMPOSE).  The dense marginal over the m neighbours is kept as a TREE
+            (Chow-Liu node removal, as in pose-graph sparsification): the star about v's TIGHTEST neighbour c -- the minimum spanning
+            tree when a pair costs spread(z_j) + spread(z_k).  m <= 2 is exact; the edge count never grows.
+  order     rounds of independent (mutually non-adjacent) lowest-degree variables of the CURRENT graph, variables with priors last:
+            every round is one product launch chain + one compose launch whatever the number of variables in it
+  back      rounds in reverse: v = product over its neighbours of (mean of u_k) (+) z_k^-1 -- sampled-measurement convolutions from
+            ANCHOR blocks (N copies of the neighbour's posterior mean: conditioning on the neighbours' values), multiplied by the
+            reference's product.  A belief is therefore the conditional of a pose given its neighbours at their posterior means.
+
+No init pass, no linearisation point, no iteration: a pass is a function of the seed.  `passes > 1` pool the particles of
+independent passes (a belief is then a mixture over passes; its mean the running average).  Scope: Pose2 variables, Pose2Pose2 and
+PriorPose2 factors (BASELINE configs[0-1]); anything else -> tree.TreeSolver.  Structural decisions (which neighbour is tightest, the
+order) are taken on the host from first-order covariances of the edges ("shadow"), once per graph.
+
+Reference: examples/ManhattanDatasetBatch.jl:43 (`tree = solveTree!(fg)`); the operations are the hot path's own
+(sampled-measurement rows of `approxConvBelief`, `manikde!`, `manifoldProduct`)."""
+import numpy as np
+
+from .tree import LevelSpec, ZERO, DeviceBackend, TreeSolver
+
+
+def _inv(z):
+    c, s = np.cos(z[2]), np.sin(z[2])
+    return np.array([-(c * z[0] + s * z[1]), -(-s * z[0] + c * z[1]), -z[2]])
+
+
+def _comp(a, b):
+    c, s = np.cos(a[2]), np.sin(a[2])
+    t = a[2] + b[2]
+    return np.array([a[0] + c * b[0] - s * b[1], a[1] + s * b[0] + c * b[1], np.arctan2(np.sin(t), np.cos(t))])
+
+
+def _inv_cov(z, C):
+    c, s = np.cos(z[2]), np.sin(z[2])
+    J = np.array([[-c, -s, s * z[0] - c * z[1]], [s, -c, c * z[0] + s * z[1]], [0, 0, -1.0]])
+    return J @ C @ J.T
+
+
+def _comp_cov(a, Ca, b, Cb):
+    c, s = np.cos(a[2]), np.sin(a[2])
+    Ja = np.array([[1, 0, -s * b[0] - c * b[1]], [0, 1, c * b[0] - s * b[1]], [0, 0, 1.0]])
+    Jb = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    return Ja @ Ca @ Ja.T + Jb @ Cb @ Jb.T
+
+
+class _Edge:
+    """N samples of a^-1 b in store block `block`; (m, C) = first-order shadow used for structural decisions only"""
+    __slots__ = ("a", "b", "block", "m", "C")
+
+    def __init__(self, a, b, block, m, C):
+        self.a, self.b, self.block, self.m, self.C = a, b, block, np.asarray(m, float), np.asarray(C, float)
+
+    def seen_from(self, v):
+        """(mean, cov) of v^-1 other"""
+        if v == self.a:
+            return self.m, self.C
+        return _inv(self.m), _inv_cov(self.m, self.C)
+
+
+class RelativeEliminationSolver:
+    """interface of tree.TreeSolver (upload / solve / download / stats / store); backend as there (device by default)"""
+
+    def __init__(self, fg, backend=None, ctx=None, max_product=8, shard=None, loss_slack=1e9, loss_factor=1.0, priors_last=1, order_seed=0, structures=1):
+        from .factors import Pose2, Pose2Pose2, PriorPose2
+        from .graph import FactorGraph
+        for l, vt in fg.variables.items():
+            if vt is not Pose2:
+                raise TypeError("messages='elimination' covers Pose2 graphs (variable %s is %s): use messages='relative' / 'marginal'" % (l, vt.__name__))
+        for fl, ls, f in fg.factors:
+            if not isinstance(f, (Pose2Pose2, PriorPose2)) or fl in fg.multihypo or fl in getattr(fg, "nullhypo", {}):
+                raise TypeError("messages='elimination' covers Pose2Pose2 / PriorPose2 factors without hypotheses (factor %s)" % fl)
+        self.fg, self.N, self.messages = fg, fg.N, "elimination"
+        self.backend = backend or DeviceBackend(ctx)
+        self.max_product = int(max_product or 0)
+        self.loss_slack, self.loss_factor, self.priors_last = float(loss_slack), float(loss_factor), bool(priors_last)
+        self.order_seed = int(order_seed)
+        self.findex = {fl: (fl, ls, f) for fl, ls, f in fg.factors}
+        U = FactorGraph(fg.N)
+        for l, vt in fg.variables.items():
+            U.addVariable(l, vt)
+        U.addVariable(ZERO, Pose2)
+        self.universe = U
+        self.Pose2 = Pose2
+        for l in list(fg.variables):
+            U.addVariable(l + "^", Pose2)          # anchor block: N copies of the posterior mean
+            U.addVariable(l + "&", Pose2)          # pool block: the mixture over the passes so far (solve(passes > 1))
+        self.structures = max(1, int(structures))
+        schedules = [self._structure(k) for k in range(self.structures)]
+        self.store = self.backend.Store(U)
+        self.store.put(ZERO, np.zeros((3, fg.N)))
+        B = self.backend
+        self.shard = shard(self.store) if shard is not None else None
+        if self.shard is not None:
+            from .tree import _ShardedPlans
+            base = B
+            B = _ShardedPlans(base, lambda s: self.shard.plan_level(s, base.Plan))
+        self._B = B
+        self.steps = []
+        for sched in schedules:
+            st = []
+            for kind, x in sched:
+                st.append(("plan", B.Plan(self.store, x)) if kind == "plan" else ("op", B.BlockOp(self.store, kind, x)))
+            self.steps.append(st)
+        self._to_pool = self.backend.BlockOp(self.store, "copy", [(l, l + "&") for l in fg.variables])
+        self._mix = {}
+        self.runs = 0
+        self.passes_pooled = 0
+
+    # borrowed helpers (they use self.universe / self.max_product / self.fg only)
+    _need = TreeSolver._need
+    _lift = TreeSolver._lift
+    _split_products = TreeSolver._split_products
+
+    # ------------------------------------------------------------------------------------------------ structure (host, once per graph)
+    def _spec(self, L, entries, smsgs=()):
+        """entries: [(destination label, [factor labels])] -> a one-group LevelSpec (every destination its own 'clique': a level is dealt
+        to the ranks by variable), two-stage products where a destination has more than max_product proposals"""
+        cliques = [([l], [0]) for l, _ in entries]
+        pairs_of = {l: list(rows) for l, rows in entries}
+        cliques, pairs_of, sm = self._split_products(L, cliques, pairs_of, list(smsgs))
+        return LevelSpec(L, cliques, pairs_of, sm, 1)
+
+    @staticmethod
+    def _spread(C):
+        return float(np.linalg.det(C)) ** (1.0 / 3.0)
+
+    def _loss(self, v, adj):
+        """what eliminating v NOW costs: the star about its tightest neighbour c replaces the pair (j, k) of spread s_j + s_k by the path
+        j - c - k of spread s_j + s_k + 2 s_c; summed relative loss of information over the dropped pairs, discounted where the pair
+        already has a direct edge (scalar spreads: geometric mean of the shadow covariance's eigenvalues).  Degree <= 2: exact, 0."""
+        nb = adj[v]
+        if len(nb) <= 2:
+            return 0.0
+        s = {}
+        for u, es in nb.items():
+            s[u] = 1.0 / sum(1.0 / self._spread(e.C) for e in es)
+        c = min(s, key=s.__getitem__)
+        us = [u for u in s if u != c]
+        tot = 0.0
+        for a in range(len(us)):
+            for b in range(a + 1, len(us)):
+                j, k = us[a], us[b]
+                it, ia = 1.0 / (s[j] + s[k]), 1.0 / (s[j] + s[k] + 2 * s[c])
+                ex = sum(1.0 / self._spread(e.C) for e in adj[j].get(k, ()))
+                tot += (it - ia) / (it + ex)
+        return tot
+
+    def _structure(self, k_struct=0):
+        from .clique import SampledPose2Pose2
+        from .factors import Pose2Pose2, PriorPose2
+        from .graph import FactorGraph
+        fg, N, Pose2 = self.fg, self.N, self.Pose2
+        U = self.universe
+        n_edge = [0]
+
+        def new_block(prefix):
+            l = "%s%d.%d~" % (prefix, k_struct, n_edge[0]); n_edge[0] += 1
+            U.addVariable(l, Pose2)
+            return l
+
+        adj = {v: {} for v in fg.variables}            # v -> {u: [edges]}
+        unary = {v: [] for v in fg.variables}          # v -> [blocks of ABSOLUTE samples of v]: priors, and priors transported along edges
+        sched = []
+        # ---- step 0: the samples of every factor's measurement (a row from the ZERO block: 0 (+) z = z; a prior: its own row), ONE launch chain
+        L = FactorGraph(N); L.addVariable(ZERO, Pose2)
+        ent = []
+        for fl, ls, f in fg.factors:
+            if isinstance(f, PriorPose2):
+                blk = new_block("p")
+                L.addVariable(blk, Pose2)
+                ent.append((blk, [self._lift(L, fl, 0, "p", [blk], f)]))
+                unary[ls[0]].append(blk)
+                continue
+            a, b = ls
+            blk = new_block("e")
+            L.addVariable(blk, Pose2)
+            nfl = "s:" + fl
+            L.factors.append((nfl, [ZERO, blk], f)); L._findex[nfl] = L.factors[-1]
+            ent.append((blk, [nfl]))
+            e = _Edge(a, b, blk, f.Z.mu, f.Z.cov)
+            adj[a].setdefault(b, []).append(e); adj[b].setdefault(a, []).append(e)
+        pri = {v for v in fg.variables if unary[v]}
+        if not pri:
+            raise ValueError("the graph holds no prior: it has no gauge")
+        sched.append(("plan", self._spec(L, ent)))
+        self.n_factor_edges = len(ent) - sum(len(u) for u in unary.values())
+        # ---- rounds
+        alive = set(fg.variables)
+        hold = set(pri) if self.priors_last else set()
+        pos = {v: k for k, v in enumerate(fg.variables)}
+        if self.order_seed or k_struct:   # another tie-break among equal losses / degrees: another structure, another set of approximations
+            perm = np.random.default_rng(self.order_seed + 7919 * k_struct).permutation(len(pos))
+            pos = {v: int(perm[k]) for v, k in pos.items()}
+        rounds, down = [], []
+        n_merge = n_comp = n_approx = n_transport = 0
+
+        def identity_rows(Lx, dst, blocks, flip=()):
+            """rows that re-emit the samples of `blocks` as proposals of `dst` (0 (+) z = z; flipped: 0 (-) z = z^-1)"""
+            rows = []
+            for k, blk in enumerate(blocks):
+                if blk not in Lx.variables:
+                    Lx.addVariable(blk, Pose2)
+                nfl = "g:%s:%d" % (dst, k)
+                labels = [dst, ZERO] if k in flip else [ZERO, dst]
+                Lx.factors.append((nfl, labels, SampledPose2Pose2(blk))); Lx._findex[nfl] = Lx.factors[-1]
+                rows.append(nfl)
+            return rows
+
+        while alive:
+            pool = (alive - hold) or alive
+            loss = {v: self._loss(v, adj) for v in pool}
+            cand = sorted(pool, key=lambda v: (loss[v], len(adj[v]), pos[v]))
+            sel, blocked = [], set()
+            cap = loss[cand[0]] * self.loss_factor + self.loss_slack
+            for v in cand:
+                if loss[v] > cap:
+                    break
+                if v in blocked:
+                    continue
+                if not adj[v] and not unary[v]:
+                    raise ValueError("variable %s is not connected to a prior" % v)
+                sel.append(v); blocked.add(v); blocked.update(adj[v])
+            Lm = FactorGraph(N); Lm.addVariable(ZERO, Pose2)
+            Lt = FactorGraph(N)
+            merges, transports, comps, dn = [], [], [], []
+            for v in sel:
+                nb = {}
+                for u, es in adj[v].items():
+                    if len(es) > 1:     # parallel edges -> one: product of their samples, all seen from v
+                        blk = new_block("m")
+                        Lm.addVariable(blk, Pose2)
+                        Li, hi, m0 = np.zeros((3, 3)), np.zeros(3), es[0].seen_from(v)[0]
+                        for e in es:
+                            m_, C_ = e.seen_from(v)
+                            I = np.linalg.inv(C_)
+                            d = m_ - m0; d[2] = np.arctan2(np.sin(d[2]), np.cos(d[2]))
+                            Li += I; hi += I @ d
+                        C = np.linalg.inv(Li)
+                        merges.append((blk, identity_rows(Lm, blk, [e.block for e in es], flip={k for k, e in enumerate(es) if e.a != v})))
+                        n_merge += 1
+                        nb[u] = _Edge(v, u, blk, m0 + C @ hi, C)
+                    else:
+                        nb[u] = es[0]
+                if len(unary[v]) > 1:   # several absolute beliefs of v -> one
+                    blk = new_block("q")
+                    Lm.addVariable(blk, Pose2)
+                    merges.append((blk, identity_rows(Lm, blk, unary[v]))); n_merge += 1
+                    unary[v] = [blk]
+                for u in nb:
+                    del adj[u][v]
+                if nb:
+                    # tightest neighbour: smallest log det of the covariance of v^-1 u
+                    c = min(nb, key=lambda u: (np.linalg.slogdet(nb[u].seen_from(v)[1])[1], pos[u]))
+                    zc, Cc = nb[c].seen_from(v)
+                    zi, Ci = _inv(zc), _inv_cov(zc, Cc)
+                    for k, ek in nb.items():
+                        if k == c:
+                            continue
+                        zk, Ck = ek.seen_from(v)
+                        blk = new_block("c")
+                        e = _Edge(c, k, blk, _comp(zi, zk), _comp_cov(zi, Ci, zk, Ck))
+                        # c^-1 k = (v^-1 c)^-1 (+) (v^-1 k): invert the block of c when it holds v^-1 c, the block of k when it holds k^-1 v
+                        comps.append((nb[c].block, ek.block, blk, nb[c].a == v, ek.a != v))
+                        adj[c].setdefault(k, []).append(e); adj[k].setdefault(c, []).append(e)
+                        n_comp += 1
+                    if unary[v]:        # the absolute belief of v travels to c: p(c) = p(v) (+) z_c -- a convolution of BELIEF samples
+                        blk, pv, ec = new_block("a"), unary[v][0], nb[c]
+                        for l in (blk, pv, ec.block):
+                            if l not in Lt.variables:
+                                Lt.addVariable(l, Pose2)
+                        nfl = "t:%s" % blk
+                        Lt.factors.append((nfl, [pv, blk] if ec.a == v else [blk, pv], SampledPose2Pose2(ec.block))); Lt._findex[nfl] = Lt.factors[-1]
+                        transports.append((blk, [nfl])); unary[c].append(blk); n_transport += 1
+                    n_approx += len(nb) > 2
+                dn.append((v, list(nb.items()), list(unary[v])))
+                del adj[v]
+            if merges:
+                sched.append(("plan", self._spec(Lm, merges)))
+            if transports:
+                sched.append(("plan", self._spec(Lt, transports)))
+            if comps:
+                sched.append(("compose", comps))
+            rounds.append(len(sel)); down.append(dn)
+            alive -= set(sel)
+        # ---- back substitution: rounds in reverse; a variable = product of its own absolute beliefs (store-resident messages) and the
+        #      sampled-measurement convolutions from its neighbours' ANCHOR blocks
+        anchor = lambda v: v + "^"     # noqa: E731
+        anchored = set()
+        for dn in reversed(down):
+            Ld = FactorGraph(N)
+            need, ent, sm = [], [], []
+            for v, nbs, un in dn:
+                Ld.addVariable(v, Pose2)
+                rows = []
+                for u, e in nbs:
+                    if u not in anchored:
+                        anchored.add(u); need.append((u, anchor(u)))
+                    for l in (anchor(u), e.block):
+                        if l not in Ld.variables:
+                            Ld.addVariable(l, Pose2)
+                    nfl = "d:%s:%s:%s" % (v, u, e.block)
+                    labels = [v, anchor(u)] if e.a == v else [anchor(u), v]
+                    Ld.factors.append((nfl, labels, SampledPose2Pose2(e.block))); Ld._findex[nfl] = Ld.factors[-1]
+                    rows.append(nfl)
+                for blk in un:
+                    if blk not in Ld.variables:
+                        Ld.addVariable(blk, Pose2)
+                    sm.append((blk, v))
+                ent.append((v, rows))
+            if need:
+                sched.append(("anchor", need))
+            sched.append(("plan", self._spec(Ld, ent, sm)))
+        self.rounds = rounds
+        self._stats = dict(rounds=len(rounds), round_sizes=rounds[:16], merges=n_merge, compositions=n_comp, transports=n_transport,
+                           approximated_eliminations=n_approx, factor_edges=self.n_factor_edges, prior_variables=len(pri), blocks=len(U.variables),
+                           launch_steps=len(sched), plan_steps=sum(1 for k, _ in sched if k == "plan"), structures=self.structures)
+        return sched
+
+    # ------------------------------------------------------------------------------------------------ the solve
+    def _run(self, plan, opts):
+        o = type(opts).from_buffer_copy(opts)
+        o.stream_offset = opts.stream_offset + (self.runs << 36)
+        if self.shard is not None:
+            self.shard.step(plan, o)
+        else:
+            plan.run(o)
+        self.runs += 1
+
+    def upload(self, fg=None):
+        """(nothing to upload: the solve starts from the factors alone; present so that solveTree treats every solver alike)"""
+
+    def solve(self, opts, passes=1):
+        """passes > 1 (and repeated calls): independent passes -- other Philox streams, the next of the `structures` -- POOLED: after pass p
+        a belief holds ~N / p particles of every pass so far (ROME_BLOCKOP_MIX), its mean is the running average.  reset() starts over."""
+        for _ in range(passes):
+            if self.shard is not None:
+                self.shard.bind_stream()
+            p = self.passes_pooled + 1
+            if p > 1:
+                self._to_pool.run()
+            for kind, x in self.steps[(p - 1) % self.structures]:
+                if kind == "plan":
+                    self._run(x, opts)
+                else:
+                    x.run()
+            if p > 1:
+                if p not in self._mix:
+                    self._mix[p] = self.backend.BlockOp(self.store, "mix", [(l + "&", l, p) for l in self.fg.variables])
+                self._mix[p].run()
+            self.passes_pooled = p
+
+    def reset(self):
+        self.passes_pooled = 0
+
+    def download(self, fg=None):
+        self.store.download(fg or self.fg, labels=list(self.fg.variables))
+
+    def stats(self):
+        return dict(self._stats, messages=self.messages)

@@ -259,11 +259,12 @@ class _Problem:
         return r, J
 
 
-def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, return_cov=False, verbose=False, shard=None, stats=None):
+def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, return_cov=False, verbose=False, shard=None, stats=None, polish=6):
     """-> {label: coordinates} (and, if return_cov, {label: marginal covariance block} from (JᵀJ)⁻¹).
     Stops when the relative cost decrease of an accepted step falls below `tol` (small graphs converge
     quadratically; the low-frequency modes of a weakly anchored 3500-pose graph creep at 1e-4/iteration
-    long after the pose error has reached the measurement-noise floor) or the step is below 1e-8.
+    long after the pose error has reached the measurement-noise floor) or the step is below 1e-8; then up to `polish` undamped
+    Gauss-Newton steps take the iterate onto the optimum along the directions the cost barely sees (see below).
     stats: a dict that receives where the time went -- {setup_s, linearize_s (rome_linearize calls: the batched residual / Jacobian
     kernels, their transfers and, when sharded, the exchange), host_solve_s (normal equations + sparse Cholesky / LU on the host),
     iterations, linearizations}: on a 10 000-pose helix the host solve is > 95 % of the wall-clock."""
@@ -309,6 +310,27 @@ def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, retur
         X, r, J, cost = Xn, rn, Jn, cn
         lam = max(lam / 10.0, 1e-12)
         if done:
+            break
+    # ---- polish: UNDAMPED Gauss-Newton steps.  The damped iteration above stops on the cost decrease, and a weakly anchored graph has
+    # directions the cost barely sees: on Manhattan-3500 the rotation of the whole map about the prior pose costs ~1 unit of 3533 per
+    # prior sigma, and an LM run that stops at a relative decrease of 1e-4 ... 1e-9 sits 0.3 ... 1 m RMS from the optimum
+    # (scripts/tree_linear_surrogate.py: three starts, three "solutions" 0.7 - 1.5 m apart, ONE optimum after two undamped steps).
+    # lam * diag(H) is what slows exactly those directions; a full step resolves them at once.
+    for _ in range(int(polish)):
+        t0 = time.perf_counter()
+        H = (J.T @ J).tocsc(); g = J.T @ r
+        d = np.empty(P.n)
+        d[P.perm] = P.solve_spd(H + 1e-12 * sp.diags(H.diagonal() + 1e-12), -g)
+        Xn = P.retract(X, d)
+        T["host_solve_s"] += time.perf_counter() - t0
+        T["iterations"] += 1
+        rn, Jn = lin(Xn)
+        cn = float(rn @ rn)
+        if not cn <= cost * (1.0 + 1e-12):
+            break                                       # a full step that goes uphill: the damped iterate stands
+        small = np.abs(d).max() < 1e-7
+        X, r, J, cost = Xn, rn, Jn, cn
+        if small:
             break
     out = P.unpack(X)
     if stats is not None:

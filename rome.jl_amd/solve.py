@@ -95,16 +95,29 @@ def solveTree(fg, tree=None, messages="marginal", passes=1, seed=0x524F4D45, ctx
     """IIF `solveTree!(fg [, tree])` (examples/Hexagonal2D_SLAM.jl:24, examples/ManhattanDatasetBatch.jl:43, the incremental re-solves of
     examples/ManhattanDatasetIncremental.jl:107): `initAll!` for whatever has no belief yet (`initAllOrdered`), Bayes tree (built here, or the
     `tree.TreeSolver` of a previous call to re-solve from the current beliefs: plans are reused), up pass + down pass on the device,
-    beliefs written back, PPEs set.  messages: "marginal" (default) = IIF's per-variable separator beliefs, or "relative" (tree.py: the form
-    that moves a large single-prior pose graph off its init pass).
+    beliefs written back, PPEs set.  messages: "marginal" (default) = IIF's per-variable separator beliefs, "relative" (tree.py: relative
+    messages between the separators of a clique), or "elimination" (elimination.py; Pose2 graphs of Pose2Pose2 / PriorPose2 factors:
+    variable elimination in relative-factor algebra -- the form that SOLVES a large single-prior pose graph: Manhattan-3500 to 0.4 - 1.2 m
+    of the MAP in one pass from the factors alone, no init pass).
     -> the TreeSolver (its store keeps the beliefs on the device; pass it back as `tree=` after adding nothing to the graph)."""
     from .api import make_opts
     from .canonical import setPPE
     from .tree import TreeSolver
-    if any(not fg.isInitialized(l) for l in fg.variables):
-        initAllOrdered(fg, seed=seed & 0xFFFF, ctx=ctx)
     from .tree import BayesTree
     sig = (tuple(fg.variables), tuple(fl for fl, _, _ in fg.factors))
+    if messages == "elimination" or getattr(tree, "messages", None) == "elimination":
+        # variable elimination in relative-factor algebra (elimination.py): no init pass, no starting beliefs -- the factors alone
+        from .elimination import RelativeEliminationSolver
+        es = tree if isinstance(tree, RelativeEliminationSolver) and tree.fg is fg and getattr(tree, "graph_signature", None) == sig else None
+        if es is None:
+            es = RelativeEliminationSolver(fg, ctx=ctx, **kw)
+        es.graph_signature = sig
+        es.solve(make_opts(N=fg.N, seed=seed), passes=passes)
+        es.download(fg)
+        setPPE(fg)
+        return es
+    if any(not fg.isInitialized(l) for l in fg.variables):
+        initAllOrdered(fg, seed=seed & 0xFFFF, ctx=ctx)
     if isinstance(tree, TreeSolver):
         ts = tree
         if ts.fg is not fg:

@@ -233,13 +233,23 @@ class TreeSolver:
     proposals (42 proposals: 14 ms with the rest of the chip idle; profiles/r05_tree_solve.txt); 0 = one product whatever the count."""
 
     def __init__(self, fg, tree=None, order="mmd", last=(), messages="marginal", gibbsIters=3, downIters=1, rootIters=0, refineIters=0, relIters=0,
-                 max_product=8, backend=None, ctx=None, shard=None):
-        """shard: a factory `store -> distributed.FrontierShard` (the store exists only once the lifted universe is known): every level is
+                 max_product=8, backend=None, ctx=None, shard=None, message_tree="hop"):
+        """message_tree ("relative" form): the STRUCTURE of the message over a clique's separators -- a spanning tree T of relative
+        messages, p(root) * prod_{(j,k) in T} p(s_k | s_j).  "hop" (default): T keeps the tightest pairs -- Prim's tree from the anchor
+        over shortest-path lengths in the clique-local graph (the clique's factors + the tree edges of its children's messages), host
+        side, no beliefs needed; every internal node j of T is one more anchored outward solve of the clique (private copies, same
+        launches), 1.7 per message on Manhattan-3500.  "star": every separator tied to the ONE anchor (round 5) -- separators that are
+        tight to each other but far from the anchor lose their tie: in the linear-Gaussian surrogate of the schedule
+        (scripts/tree_linear_surrogate.py) the fixed point of the star sits 2 - 3 m from the MAP and wanders, the tree's 0.86 m and is stable.
+        shard: a factory `store -> distributed.FrontierShard` (the store exists only once the lifted universe is known): every level is
         then dealt to the ranks by clique -- share up-solve, ONE all-gather of the level's written blocks, one scatter; the block
         operations between levels run on every rank (each holds the whole store)."""
         from .graph import FactorGraph
         if messages not in ("relative", "marginal"):
             raise ValueError("messages must be 'relative' or 'marginal'")
+        if message_tree not in ("hop", "star"):
+            raise ValueError("message_tree must be 'hop' or 'star'")
+        self.message_tree = message_tree
         self.fg, self.N, self.messages = fg, fg.N, messages
         self.tree = tree or BayesTree.build(list(fg.variables), [(fl, tuple(ls)) for fl, ls, _ in fg.factors], order=order, last=last)
         self.backend = backend or DeviceBackend(ctx)
@@ -352,6 +362,46 @@ class TreeSolver:
             out_cliques.append((nu, ng))
         return out_cliques, pairs_of, out_smsgs
 
+    @staticmethod
+    def _message_tree(V, S, root, edges, can_anchor, star=False):
+        """Spanning tree of relative messages over the separators S, rooted at `root`: Prim over shortest-path lengths in the
+        clique-local graph (nodes V; edges [(u, v, length)]: the clique's own pairwise factors and the tree edges of its children's
+        messages).  A node may only hang below one that can be an anchor (`can_anchor`: Pose2 -- the relative block operation takes
+        its reference from a pose).  -> [(parent, child, length)] in attachment order; separators without a path are left out."""
+        others = [s for s in S if s != root]
+        if star:
+            return [(root, s, 1.0) for s in others]
+        adj = {v: [] for v in V}
+        for a, b, w in edges:
+            if a in adj and b in adj:
+                adj[a].append((b, w)); adj[b].append((a, w))
+        dist = {}
+        for s0 in S:
+            d = {s0: 0.0}; pq = [(0.0, 0, s0)]; n = 1
+            while pq:
+                d0, _, u = heapq.heappop(pq)
+                if d0 > d[u]:
+                    continue
+                for v, w in adj[u]:
+                    if d0 + w < d.get(v, np.inf):
+                        d[v] = d0 + w; heapq.heappush(pq, (d0 + w, n, v)); n += 1
+            dist[s0] = d
+        intree, out = [root], []
+        left = list(others)
+        while left:
+            best = None
+            for j in intree:
+                if not can_anchor(j):
+                    continue
+                for k in left:
+                    w = dist[j].get(k)
+                    if w is not None and (best is None or w < best[0]):
+                        best = (w, j, k)
+            if best is None:
+                break
+            out.append((best[1], best[2], best[0])); intree.append(best[2]); left.remove(best[2])
+        return out
+
     def _need(self, L, label, vt):
         if label not in self.universe.variables:
             self.universe.addVariable(label, vt)
@@ -407,6 +457,7 @@ class TreeSolver:
         fg, t = self.fg, self.tree
         ups, downs = [], []
         abs_msgs, rel_msgs = {}, {}          # clique -> [(source label, variable)] / [(anchor, separator, samples label)]
+        msg_len = {}                         # clique -> [(anchor, separator, path length)]: the message tree's edges, for the parent's own tree
         self.anchor, self.unreached = {}, []
         down_parts, rel_parts = {}, {}
         for lvl in t.levels:
@@ -461,21 +512,34 @@ class TreeSolver:
                     self.unreached += [(cid, v) for v in F if v not in reached]
                 elif c.parent < 0:
                     raise ValueError("the root clique %r holds no prior and receives no absolute message: the graph has no gauge" % c)
-                # ---- relative solve: outward from the anchor, fixed at its current mean
+                # ---- relative solves: outward from an anchor fixed at its current mean -- one per internal node of the message tree
+                msg_len[cid] = []
                 if anc is not None:
-                    lab = {v: "%s@%d" % (v, cid) for v in F + S}
-                    self._need(L, lab[anc], vt[anc])
-                    anchors.append((anc, lab[anc]))
-                    rounds, left = _outward(list(F) + [s for s in S if s != anc], (anc,), pwl, ())
-                    add(rounds, lab, "@", False)
-                    reached = {v for rnd in rounds for v, _, _ in rnd}
-                    rel_parts[cid] = (pw, reached, anc)
-                    for s in S:
-                        if s != anc and s in reached and vt[s] in (Pose2, Point2):
-                            zl = "%s~%d" % (s, cid)
-                            if zl not in self.universe.variables:
-                                self.universe.addVariable(zl, vt[s])
-                            relatives.append((lab[anc], lab[s], zl)); rel_msgs[cid].append((anc, s, zl))
+                    loc = [(ls[0], ls[1], 1.0) for fl in c.factors for ls in (self.findex[fl][1],) if len(ls) == 2]
+                    loc += [e for d in c.children for e in msg_len[d]]
+                    T = self._message_tree(list(F) + list(S), [s for s in S if vt[s] in (Pose2, Point2)], anc, loc,
+                                           lambda v: vt[v] is Pose2, star=self.message_tree == "star")
+                    kids = {}
+                    for j, k, w in T:
+                        kids.setdefault(j, []).append((k, w))
+                    for j in [anc] + [j for j in kids if j != anc]:          # (the anchor's own solve exists even without children: relIters)
+                        if j == anc:
+                            lab = {v: "%s@%d" % (v, cid) for v in F + S}
+                        else:
+                            lab = {v: "%s@%d^%s" % (v, cid, j) for v in F + S}
+                        self._need(L, lab[j], vt[j])
+                        anchors.append((j, lab[j]))
+                        rounds, left = _outward(list(F) + [s for s in S if s != j], (j,), pwl, ())
+                        add(rounds, lab, "@" if j == anc else "@^%s" % j, False)
+                        reached = {v for rnd in rounds for v, _, _ in rnd}
+                        if j == anc:
+                            rel_parts[cid] = (pw, reached, anc)
+                        for k, w in kids.get(j, ()):
+                            if k in reached:
+                                zl = "%s~%d" % (k, cid)
+                                if zl not in self.universe.variables:
+                                    self.universe.addVariable(zl, vt[k])
+                                relatives.append((lab[j], lab[k], zl)); rel_msgs[cid].append((j, k, zl)); msg_len[cid].append((j, k, w))
                 cliques.append((upd, grp))
                 down_parts[cid] = (pw, pri, srcs)
             cliques, pairs_of, smsgs = self._split_products(L, cliques, pairs_of, smsgs)
@@ -674,8 +738,9 @@ class DeviceBackend:
 
 class BlockOpPlan:
     """block operations inside a DeviceStore (rome_blockop_plan), ONE launch per run:
-    "copy" [(source, destination)], "anchor" [(belief, destination)], "relative" [(anchor block, separator block, destination)]"""
-    OPS = {"copy": 0, "anchor": 1, "relative": 2}
+    "copy" [(source, destination)], "anchor" [(belief, destination)], "relative" [(anchor block, separator block, destination)],
+    "compose" [(a, b, destination, invert a, invert b)], "mix" [(pool, destination, p)]"""
+    OPS = {"copy": 0, "anchor": 1, "relative": 2, "compose": 3, "mix": 4}
 
     def __init__(self, store, op, entries):
         import ctypes as C
@@ -683,9 +748,17 @@ class BlockOpPlan:
         from .clique import DeviceStore
         self.store, self.ctx, self._lib = store, store.ctx, _lib.load()
         U = store.fg
-        ty = np.array([DeviceStore.TYPES.index(U.variables[e[-1]]) for e in entries], dtype=np.int32)
+        if op == "compose":      # entries (a, b, destination, invert a, invert b)
+            flags = [(0x100 if e[3] else 0) | (0x200 if e[4] else 0) for e in entries]
+            entries = [e[:3] for e in entries]
+        elif op == "mix":        # entries (pool, destination, p)
+            flags = [int(e[2]) << 8 for e in entries]
+            entries = [e[:2] for e in entries]
+        else:
+            flags = [0] * len(entries)
+        ty = np.array([DeviceStore.TYPES.index(U.variables[e[-1]]) | f for e, f in zip(entries, flags)], dtype=np.int32)
         a = np.array([store.index[e[0]] for e in entries], dtype=np.int32)
-        b = np.array([store.index[e[1]] for e in entries], dtype=np.int32) if op == "relative" else None
+        b = np.array([store.index[e[1]] for e in entries], dtype=np.int32) if op in ("relative", "compose") else None
         d = np.array([store.index[e[-1]] for e in entries], dtype=np.int32)
         self.dst_labels = [e[-1] for e in entries]
         PI = C.POINTER(C.c_int32)

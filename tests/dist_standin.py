@@ -230,6 +230,17 @@ class OracleTreeBlockOp:
                 elif b.shape[0] == 6:
                     m[3:] = b[3:, 0]
                 v[e[1]] = np.repeat(m[:, None], N, axis=1)
+            elif self.op == "mix":
+                keep = (np.arange(N) % int(e[2])) == int(e[2]) - 1
+                v[e[1]] = np.where(keep[None, :], v[e[1]], v[e[0]])
+            elif self.op == "compose":
+                def inv(z):
+                    c, s = np.cos(z[2]), np.sin(z[2])
+                    return np.stack([-(c * z[0] + s * z[1]), -(-s * z[0] + c * z[1]), -z[2]])
+                A, B = (inv(v[e[0]]) if e[3] else v[e[0]]), (inv(v[e[1]]) if e[4] else v[e[1]])
+                c, s = np.cos(A[2]), np.sin(A[2])
+                t = A[2] + B[2]
+                v[e[2]] = np.stack([A[0] + c * B[0] - s * B[1], A[1] + s * B[0] + c * B[1], np.arctan2(np.sin(t), np.cos(t))])
             else:
                 ref, s = v[e[0]][:, 0], v[e[1]]
                 c, sn = np.cos(ref[2]), np.sin(ref[2])

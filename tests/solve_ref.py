@@ -182,16 +182,26 @@ def upsolve_ref(R, fg, frontals, N, seed=0x524F4D45, gibbs_iters=3, product_iter
         for group in steps:
             props = proposals_for(group, base)
             new = {}
-            for l in group:
-                vt = fg.variables[l]; v = batch.vidx[l]
-                P = props[l]
-                if not P:
+            for vt in types:   # one bandwidth call and (when the product streams are consecutive) one product call per variable type: the
+                ls = [l for l in group if fg.variables[l] is vt and props[l]]      # oracle's OpenMP loops run over the whole group
+                if not ls:
                     continue
-                P = np.stack(P)
+                P = np.concatenate([np.stack(props[l]) for l in ls])
+                ptr = np.concatenate([[0], np.cumsum([len(props[l]) for l in ls])]).astype(np.int32)
                 bw = ro.kde_bandwidths(P, circ_bw[vt])
-                o = ro.make_opts(N=N, seed=seed, stream_offset=base + PROD[vt] + pos_in_type[l])
-                new[l] = ro.product_msgibbs(o, vt.dim, np.array([0, len(P)], dtype=np.int32), np.arange(len(P), dtype=np.int32), P, bw,
-                                            bel[vt][v:v + 1], circ[vt], product_iters)[0]
+                pos = [pos_in_type[l] for l in ls]
+                B = np.stack([bel[vt][batch.vidx[l]] for l in ls])
+                if all(b - a == 1 for a, b in zip(pos, pos[1:])):
+                    o = ro.make_opts(N=N, seed=seed, stream_offset=base + PROD[vt] + pos[0])
+                    out = ro.product_msgibbs(o, vt.dim, ptr, np.arange(len(P), dtype=np.int32), P, bw, B, circ[vt], product_iters)
+                    for k, l in enumerate(ls):
+                        new[l] = out[k]
+                else:
+                    for k, l in enumerate(ls):
+                        o = ro.make_opts(N=N, seed=seed, stream_offset=base + PROD[vt] + pos[k])
+                        Pk, bk = P[ptr[k]:ptr[k + 1]], bw[ptr[k]:ptr[k + 1]]
+                        new[l] = ro.product_msgibbs(o, vt.dim, np.array([0, len(Pk)], dtype=np.int32), np.arange(len(Pk), dtype=np.int32), Pk, bk,
+                                                    B[k:k + 1], circ[vt], product_iters)[0]
             for l, b in new.items():
                 bel[fg.variables[l]][batch.vidx[l]] = b
     return {l: bel[fg.variables[l]][batch.vidx[l]].copy() for l in frontals}

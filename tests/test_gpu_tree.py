@@ -117,6 +117,37 @@ def test_manhattan_subgraph_tree_solve_equals_the_oracle_tree_solve(messages, tm
         assert frac > 0.9 and dmean < 1e-3, worst
 
 
+def test_manhattan_subgraph_star_messages_equal_the_oracle_tree_solve(tmp_path):
+    """message_tree="star" (round 5's structure: every separator tied to the one anchor) stays available and parity-checked"""
+    fg = manhattan_subgraph(150, 64, tmp_path)
+    R.initAllOrdered(fg, seed=2)
+    dev, worst = _both(fg, "relative", 41, message_tree="star")
+    assert dev.stats()["relative_messages"] > 20
+    for frac, dmean in worst:
+        assert frac > 0.9 and dmean < 1e-3, worst
+
+
+@pytest.mark.timeout(1500)
+def test_manhattan_1000_pose_prefix_tree_pass_equals_the_oracle_tree_pass(tmp_path):
+    """Row h's numerics on the headline graph: ONE up + down pass over the first 1000 poses of manhattan.g2o with their loop closures
+    (909 cliques, 45 levels, ~7500 rows, ~1700 relative messages over the message trees, two-stage products) at N = 100 -- device ==
+    the oracle's restatement of the same schedule: > 90 % of the particles to 1e-6, every pose mean < 1e-3 (north_star's tolerance)."""
+    import time
+    fg = manhattan_subgraph(1000, 100, tmp_path)
+    assert len(fg.variables) == 1000 and len(fg.factors) > 1300
+    R.initAllOrdered(fg, seed=2)
+    t0 = time.perf_counter()
+    dev, worst = _both(fg, "relative", 61)
+    st = dev.stats()
+    assert st["levels"] > 30 and st["relative_messages"] > 1000 and st["cliques"] > 700, st
+    (frac, dmean), = worst
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r06_tree_parity_1000.txt"), "w") as f:
+        f.write("Manhattan first 1000 poses, N=100, one up+down tree pass (message_tree=hop), device vs oracle restatement: %.4f of the particles "
+                "within 1e-6, worst |mean difference| %.3e; %s; %.1f s incl. the oracle pass\n" % (frac, dmean, st, time.perf_counter() - t0))
+    assert frac > 0.9 and dmean < 1e-3, worst
+
+
 def test_beehive_multihypo_tree_solve_runs_with_landmark_separators():
     """BASELINE configs[3]: landmarks among the separators (relative messages pose -> landmark as sampled bearing-range rows), multihypo
     sightings inside the cliques"""
