@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--solver", default="newton", choices=["closed_form", "newton", "nelder_mead", "gauss_newton"])
-    ap.add_argument("--tree-messages", default="relative", choices=["relative", "marginal"], help="message form of the solve.from_tree leg")
+    ap.add_argument("--tree-messages", default="relative", choices=["relative", "marginal"], help="message form of the solve.from_tree_clique_forms leg")
+    ap.add_argument("--tree-structures", type=int, default=1, help="elimination structures pooled by the solve.from_tree leg (1: one plan set)")
     ap.add_argument("--poses", type=int, default=3500)
     ap.add_argument("--loops", type=int, default=1954)
     ap.add_argument("--particles", type=int, default=100)
@@ -661,64 +662,99 @@ def main():
         except Exception as e:   # noqa: BLE001
             out["solve"]["from_init_all_ordered"] = {"error": repr(e)}
 
-        # ---- the TREE solve (solveTree!-shaped): initAll!-order init pass, then the Bayes tree up + down pass (rome_jl_amd.tree): elimination
-        # order -> cliques -> levels; one rome_upsolve_plan per level; no parametric start, no dead reckoning
+        # ---- the TREE solve (solveTree!-shaped), from the FACTORS ALONE: no parametric start, no dead reckoning, no init pass.
+        # Headline form: variable elimination in relative-factor algebra (rome_jl_amd.elimination; `R.solveTree(fg, messages="elimination")`):
+        # sampled relative edges, compositions for the pair marginals of an eliminated pose's neighbours, the reference's product for
+        # parallel edges, back substitution from anchor blocks.  Context: the clique forms of rome_jl_amd.tree (round 5) from initAll!.
+        def load_fg():
+            return R.loadG2o(args.g2o, N=N) if (args.g2o and args.g2o != "synthetic") else R.synth_manhattan(P=args.poses, loops=args.loops, seed=0x524F4D45 + rank, N=N)
+
+        def rms_of(fgx, lsx, mpx, aligned=False):
+            m, _ = R.belief_stats(np.stack([fgx.getVal(l) for l in lsx]))
+            A, B = m[:, :2], mpx[:, :2]
+            if aligned:       # after the best rigid transform (what remains is not a gauge error)
+                A, B = A - A.mean(0), B - B.mean(0)
+                U_, _, Vt = np.linalg.svd(A.T @ B); Rr = (U_ @ Vt).T
+                if np.linalg.det(Rr) < 0:
+                    Rr = (U_ @ np.diag([1.0, -1.0]) @ Vt).T
+                A = A @ Rr.T
+            return float(np.sqrt(np.mean(np.sum((A - B) ** 2, axis=1))))
+        try:
+            from rome_jl_amd.elimination import RelativeEliminationSolver
+            fg1 = load_fg()
+            ls1 = list(fg1.variables)
+            mp1 = np.array([xp[l] for l in ls1])
+            ctx.synchronize(); a = time.perf_counter()
+            esv = RelativeEliminationSolver(fg1, ctx=ctx, structures=args.tree_structures)
+            ctx.synchronize(); t_build = time.perf_counter() - a
+            passes = []
+            for ps in range(8):      # the pooled sequence: what solveTree(..., passes=8) leaves after each pass
+                o4 = R.make_opts(N=N, seed=100 + ps)
+                ctx.synchronize(); a = time.perf_counter(); esv.solve(o4); ctx.synchronize(); tp = time.perf_counter() - a
+                esv.download(fg1)
+                passes.append({"pass_s": tp, "rms_to_parametric_m": rms_of(fg1, ls1, mp1), "rms_after_rigid_alignment_m": rms_of(fg1, ls1, mp1, True)})
+            single = []
+            for ps in range(8):      # independent single passes (what ONE pass gives, seed by seed)
+                esv.reset(); esv.solve(R.make_opts(N=N, seed=300 + ps)); esv.download(fg1)
+                single.append(rms_of(fg1, ls1, mp1))
+            st_ = esv.stats()
+            rr = [p_["rms_to_parametric_m"] for p_ in passes]
+            out["solve"]["from_tree"] = {
+                "what": "Manhattan-3500 from the factors alone (NO starting beliefs, no init pass): variable elimination in relative-factor algebra -- %d rounds of "
+                        "independent lowest-loss variables (%d merges of parallel edges by the reference's product, %d compositions, %d eliminations kept as a star "
+                        "about the tightest neighbour), back substitution from anchor blocks; %d launch steps per pass, device-resident; passes pool their particles"
+                        % (st_["rounds"], st_["merges"], st_["compositions"], st_["approximated_eliminations"], st_["launch_steps"]),
+                "reference": "rms to the MAP = solveGraphParametric incl. its undamped polish steps (a damped LM run alone stops ~0.8 m RMS from the MAP on this graph)",
+                "structure_and_plans_build_s": t_build, "passes": passes, "wall_clock_s_first_pass": t_build + passes[0]["pass_s"],
+                "seconds_per_pass": float(np.median([p_["pass_s"] for p_ in passes])), "elimination": st_,
+                "rms_to_parametric_m_over_passes": {"min": min(rr), "median": float(np.median(rr)), "max": max(rr)},
+                "rms_after_rigid_alignment_m_over_passes": {"min": min(p_["rms_after_rigid_alignment_m"] for p_ in passes),
+                                                            "median": float(np.median([p_["rms_after_rigid_alignment_m"] for p_ in passes])),
+                                                            "max": max(p_["rms_after_rigid_alignment_m"] for p_ in passes)},
+                "independent_single_passes_rms_to_parametric_m": single,
+                "note": "N = 100 particles.  The error of a pass is the bias of the star approximations (deterministic given the elimination structure: 0.5 m in the "
+                        "Gaussian restatement of this schedule) plus sampling noise; pooling passes averages the noise, `structures` > 1 the bias as well"}
+            del esv
+        except Exception as e:   # noqa: BLE001
+            out["solve"]["from_tree"] = {"error": repr(e)}
         try:
             from rome_jl_amd.tree import TreeSolver
-            fg1 = R.loadG2o(args.g2o, N=N) if (args.g2o and args.g2o != "synthetic") else R.synth_manhattan(P=args.poses, loops=args.loops, seed=0x524F4D45 + rank, N=N)
+            fg1 = load_fg()
             a = time.perf_counter(); R.initAllOrdered(fg1, seed=1, ctx=ctx); t_ini = time.perf_counter() - a
             ls1 = list(fg1.variables)
             mp1 = np.array([xp[l] for l in ls1])
-
-            def rms_fg(aligned=False):
-                m, _ = R.belief_stats(np.stack([fg1.getVal(l) for l in ls1]))
-                A, B = m[:, :2], mp1[:, :2]
-                if aligned:       # after the best rigid transform (what remains is not a gauge error)
-                    A, B = A - A.mean(0), B - B.mean(0)
-                    U_, _, Vt = np.linalg.svd(A.T @ B); Rr = (U_ @ Vt).T
-                    if np.linalg.det(Rr) < 0:
-                        Rr = (U_ @ np.diag([1.0, -1.0]) @ Vt).T
-                    A = A @ Rr.T
-                return float(np.sqrt(np.mean(np.sum((A - B) ** 2, axis=1))))
-            r_init = rms_fg()
+            r_init, r_init_al = rms_of(fg1, ls1, mp1), rms_of(fg1, ls1, mp1, True)
             a = time.perf_counter(); tsv = TreeSolver(fg1, messages=args.tree_messages, ctx=ctx); t_build = time.perf_counter() - a
             tsv.upload()
             passes = []
-            for ps in range(8):
+            for ps in range(4):
                 o4 = R.make_opts(N=N, seed=100 + ps)
                 ctx.synchronize(); a = time.perf_counter(); tsv.up(o4); ctx.synchronize(); tu = time.perf_counter() - a
                 a = time.perf_counter(); tsv.down(o4); ctx.synchronize(); td = time.perf_counter() - a
                 tsv.download()
-                passes.append({"up_s": tu, "down_s": td, "rms_to_parametric_m": rms_fg(), "rms_after_rigid_alignment_m": rms_fg(True)})
+                passes.append({"up_s": tu, "down_s": td, "rms_to_parametric_m": rms_of(fg1, ls1, mp1), "rms_after_rigid_alignment_m": rms_of(fg1, ls1, mp1, True)})
             st_ = tsv.stats()
             # IIF's own message form (per-variable separator beliefs, gibbsIters = 3 up / 1 down) on the same tree, from the same init
-            fg2 = R.loadG2o(args.g2o, N=N) if (args.g2o and args.g2o != "synthetic") else R.synth_manhattan(P=args.poses, loops=args.loops, seed=0x524F4D45 + rank, N=N)
+            fg2 = load_fg()
             R.initAllOrdered(fg2, seed=1, ctx=ctx)
             tsm = TreeSolver(fg2, tree=tsv.tree, messages="marginal", ctx=ctx); tsm.upload()
             o5 = R.make_opts(N=N, seed=100)
             ctx.synchronize(); a = time.perf_counter(); tsm.solve(o5); ctx.synchronize(); t_marg = time.perf_counter() - a
             tsm.download()
-            m_, _ = R.belief_stats(np.stack([fg2.getVal(l) for l in ls1]))
-            marg = {"seconds_per_pass": t_marg, "rms_to_parametric_m": float(np.sqrt(np.mean(np.sum((m_[:, :2] - mp1[:, :2]) ** 2, axis=1)))),
+            marg = {"seconds_per_pass": t_marg, "rms_to_parametric_m": rms_of(fg2, ls1, mp1), "rms_after_rigid_alignment_m": rms_of(fg2, ls1, mp1, True),
                     "what": "IIF's message form (TreeBelief per separator variable; upGibbsCliqueDensity with 3 iterations, down pass 1): on a pose graph with ONE prior "
                             "the cliques below the prior's clique hold no absolute information -- the solve stays where the init pass left it"}
-            out["solve"]["from_tree"] = {
-                "what": "NO starting beliefs: initAll!-order init pass, then Bayes tree (minimum-degree elimination -> %d cliques -> %d levels, widest %d) up pass + "
-                        "down pass with '%s' messages, one rome_upsolve_plan per level, device-resident; each further pass re-solves from the previous posterior"
+            out["solve"]["from_tree_clique_forms"] = {
+                "what": "context (round 5's solver): initAll!-order init pass, then the Bayes tree (minimum-degree elimination -> %d cliques -> %d levels, widest %d) up + down "
+                        "pass with '%s' messages, one rome_upsolve_plan per level; one-shot outward clique solves and a belief-weighted down pass: no better than its init pass"
                         % (st_["cliques"], st_["levels"], st_["width_max"], args.tree_messages),
-                "init_all_s": t_ini, "rms_to_parametric_m_after_init": r_init, "tree_and_plans_build_s": t_build, "passes": passes,
+                "init_all_s": t_ini, "rms_to_parametric_m_after_init": r_init, "rms_after_rigid_alignment_m_after_init": r_init_al,
+                "tree_and_plans_build_s": t_build, "passes": passes,
                 "wall_clock_s_first_pass": t_ini + t_build + passes[0]["up_s"] + passes[0]["down_s"], "tree": st_,
-                "rms_to_parametric_m_over_passes": {"min": min(p_["rms_to_parametric_m"] for p_ in passes), "median": float(np.median([p_["rms_to_parametric_m"] for p_ in passes])),
-                                                    "max": max(p_["rms_to_parametric_m"] for p_ in passes)},
-                "rms_after_rigid_alignment_m_over_passes": {"min": min(p_["rms_after_rigid_alignment_m"] for p_ in passes),
-                                                            "median": float(np.median([p_["rms_after_rigid_alignment_m"] for p_ in passes])),
-                                                            "max": max(p_["rms_after_rigid_alignment_m"] for p_ in passes)},
                 "seconds_per_pass": float(np.median([p_["up_s"] + p_["down_s"] for p_ in passes])), "marginal_messages": marg,
-                "frontier_width_by_level": [len(l) for l in tsv.tree.levels],
-                "note": "N = 100 particles: a pass is a stochastic estimate -- the spread over passes is its sampling noise (mostly a rigid transform of the whole "
-                        "map about the prior pose: see rms_after_rigid_alignment_m); DESIGN.md section 11"}
+                "frontier_width_by_level": [len(l) for l in tsv.tree.levels]}
         except Exception as e:   # noqa: BLE001
-            out["solve"]["from_tree"] = {"error": repr(e)}
+            out["solve"]["from_tree_clique_forms"] = {"error": repr(e)}
 
         # ---- BASELINE configs[4] ("synthetic SE(3) helix, 10k Pose3 + Pose3Pose3, parametric Gauss-Newton batched Jacobians"): where the time
         # of the parametric solve goes.  The GPU part is the batched residual / Jacobian kernels (k_lin<...>, tables device-resident across

@@ -233,15 +233,16 @@ class TreeSolver:
     proposals (42 proposals: 14 ms with the rest of the chip idle; profiles/r05_tree_solve.txt); 0 = one product whatever the count."""
 
     def __init__(self, fg, tree=None, order="mmd", last=(), messages="marginal", gibbsIters=3, downIters=1, rootIters=0, refineIters=0, relIters=0,
-                 max_product=8, backend=None, ctx=None, shard=None, message_tree="hop"):
+                 max_product=8, backend=None, ctx=None, shard=None, message_tree="star"):
         """message_tree ("relative" form): the STRUCTURE of the message over a clique's separators -- a spanning tree T of relative
-        messages, p(root) * prod_{(j,k) in T} p(s_k | s_j).  "hop" (default): T keeps the tightest pairs -- Prim's tree from the anchor
-        over shortest-path lengths in the clique-local graph (the clique's factors + the tree edges of its children's messages), host
-        side, no beliefs needed; every internal node j of T is one more anchored outward solve of the clique (private copies, same
-        launches), 1.7 per message on Manhattan-3500.  "star": every separator tied to the ONE anchor (round 5) -- separators that are
-        tight to each other but far from the anchor lose their tie: in the linear-Gaussian surrogate of the schedule
-        (scripts/tree_linear_surrogate.py) the fixed point of the star sits 2 - 3 m from the MAP and wanders, the tree's 0.86 m and is stable.
-        shard: a factory `store -> distributed.FrontierShard` (the store exists only once the lifted universe is known): every level is
+        messages, p(root) * prod_{(j,k) in T} p(s_k | s_j).  "star" (default): every separator tied to the ONE anchor.  "hop": Prim's
+        tree from the anchor over shortest-path lengths in the clique-local graph (the clique's factors + the tree edges of its
+        children's messages), host side; every internal node j of T is one more anchored outward solve of the clique (private copies,
+        same launches; 1.7 per message on Manhattan-3500).  With EXACT pair marginals the tree halves the star's bias (linear-Gaussian
+        surrogate, scripts/tree_linear_surrogate.py: 0.86 m against 2 - 3 m); with the one-shot outward solves of this class it does
+        not (device, Manhattan-3500, after rigid alignment: 2.3 m against 1.3 m; profiles/r06_tree_forms.txt) -- what limits this
+        solver is the clique solve and the belief-weighted down pass, not the message structure: elimination.py replaces both.
+                shard: a factory `store -> distributed.FrontierShard` (the store exists only once the lifted universe is known): every level is
         then dealt to the ranks by clique -- share up-solve, ONE all-gather of the level's written blocks, one scatter; the block
         operations between levels run on every rank (each holds the whole store)."""
         from .graph import FactorGraph

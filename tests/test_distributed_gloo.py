@@ -689,7 +689,11 @@ def _tree_solve(R, kind, messages, N, shard=None):
     from rome_jl_amd.tree import TreeSolver
     from dist_standin import OracleTreeBackend
     fg = _tree_graph(R, kind, N)
-    ts = TreeSolver(fg, messages=messages, backend=OracleTreeBackend(R), shard=shard, gibbsIters=2)
+    if messages == "elimination":       # variable elimination in relative-factor algebra: every round's plans dealt to the ranks by variable,
+        from rome_jl_amd.elimination import RelativeEliminationSolver   # compose / anchor / mix block operations on every rank
+        ts = RelativeEliminationSolver(fg, backend=OracleTreeBackend(R), shard=shard, structures=2)
+    else:
+        ts = TreeSolver(fg, messages=messages, backend=OracleTreeBackend(R), shard=shard, gibbsIters=2)
     ts.upload()
     ts.solve(R.make_opts(N=N, seed=9), passes=2)
     return ts, {l: ts.store.get(l).copy() for l in fg.variables}
@@ -710,14 +714,18 @@ def _tree_worker(rank, world, port, kind, messages, ret):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,kind,messages", [(2, "manhattan", "relative"), (8, "manhattan", "relative"), (2, "hexagon", "relative"), (2, "manhattan", "marginal")])
+@pytest.mark.parametrize("world,kind,messages", [(2, "manhattan", "relative"), (8, "manhattan", "relative"), (2, "hexagon", "relative"), (2, "manhattan", "marginal"),
+                                                 (2, "manhattan", "elimination"), (8, "manhattan", "elimination")])
 def test_tree_levels_sharded_by_clique_equal_the_unsharded_tree_solve(world, kind, messages):
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_tree_worker, args=(world, _free_port(), kind, messages, ret), nprocs=world, join=True)
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import rome_jl_amd as R
     ts, ref = _tree_solve(R, kind, messages, 16)
-    assert len(ts.tree.levels) >= 3 and any(len(c.frontals) + len(c.separators) >= 3 for c in ts.tree.cliques)
+    if messages == "elimination":
+        assert ts.stats()["rounds"] >= 3 and ts.stats()["compositions"] > 5 and ts.passes_pooled == 2
+    else:
+        assert len(ts.tree.levels) >= 3 and any(len(c.frontals) + len(c.separators) >= 3 for c in ts.tree.cliques)
     if messages == "relative":
         assert ts.stats()["relative_messages"] > 0
     for r in range(world):

@@ -5,6 +5,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,8 +68,15 @@ def test_bench_line_carries_the_functor_iterating_solvers_and_the_tree_solve():
     assert rb["gauss_newton"]["frac"] < rb["newton"]["frac"] and rb["nelder_mead"]["frac"] < rb["gauss_newton"]["frac"]
     ft = d["solve"]["from_tree"]
     assert "error" not in ft, ft
-    assert ft["tree"]["levels"] > 20 and ft["tree"]["cliques"] > 2500 and sum(ft["frontier_width_by_level"]) == ft["tree"]["cliques"]
-    best = min(p_["rms_to_parametric_m"] for p_ in ft["passes"])
-    assert best < ft["rms_to_parametric_m_after_init"]           # the tree pass improves on the init pass (5.3 m)
-    assert min(p_["rms_after_rigid_alignment_m"] for p_ in ft["passes"]) < 3.0
-    assert ft["passes"][0]["up_s"] + ft["passes"][0]["down_s"] < 2.0
+    el = ft["elimination"]
+    assert el["rounds"] < 40 and el["compositions"] > 5000 and el["factor_edges"] == 5453 and el["launch_steps"] < 120, el
+    rr = [p_["rms_to_parametric_m"] for p_ in ft["passes"]]
+    # median raw RMS <= 2.3 m (the reference's own level on its Manhattan-500 solve), stable over the passes
+    assert len(rr) == 8 and np.median(rr) <= 2.3 and max(rr[2:]) / min(rr[2:]) <= 2.0, rr
+    assert np.median(ft["independent_single_passes_rms_to_parametric_m"]) <= 2.3
+    assert max(p_["rms_after_rigid_alignment_m"] for p_ in ft["passes"]) < 1.5
+    assert ft["seconds_per_pass"] < 0.2 and ft["wall_clock_s_first_pass"] < 2.5
+    cf = d["solve"]["from_tree_clique_forms"]
+    assert "error" not in cf, cf
+    assert cf["tree"]["levels"] > 20 and cf["tree"]["cliques"] > 2500 and sum(cf["frontier_width_by_level"]) == cf["tree"]["cliques"]
+    assert np.median(rr) < cf["rms_to_parametric_m_after_init"]       # the elimination solve improves on what initAll! leaves

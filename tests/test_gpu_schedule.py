@@ -78,11 +78,15 @@ def test_beehive_multihypo_schedule_runs_from_nothing():
     assert np.isfinite(err).all() and np.median(err) < 3.0, np.median(err)
 
 
-def test_manhattan3500_from_init_all_the_tree_solve_beats_the_sweeps():
-    """Manhattan-3500 from NOTHING (no dead reckoning, no parametric start): the init pass stalls at ~5.3 m RMS from the parametric solution
-    and coloured Gauss-Seidel sweeps stay there (profiles/r04_ordered_solve.txt); the Bayes tree solve (rome_jl_amd.tree, relative
-    messages) removes the loop error the init pass froze in.  A pass is a stochastic estimate (N = 100): asserted on three passes."""
+def test_manhattan3500_from_nothing_sweeps_stall_clique_tree_stays_elimination_solves():
+    """Manhattan-3500 from NOTHING (no dead reckoning, no parametric start), against the MAP (solveGraphParametric incl. its polish):
+      * the init pass leaves metres and coloured Gauss-Seidel sweeps stay there (profiles/r04_ordered_solve.txt);
+      * the clique-form tree solve (rome_jl_amd.tree, relative messages) does not improve on its init pass after rigid alignment -- one-shot
+        outward clique solves, belief-weighted down pass (profiles/r06_tree_forms.txt);
+      * variable elimination in relative-factor algebra (rome_jl_amd.elimination) solves it from the factors alone: every single pass
+        <= 2.3 m raw (the reference's own solveTree! sits 2.26 m from the MAP on its Manhattan-500 graph), <= 1.0 m after alignment."""
     from rome_jl_amd.tree import TreeSolver
+    from rome_jl_amd.elimination import RelativeEliminationSolver
     N = 100
     g2o = os.path.join(ROOT, "tests", "golden", "manhattan.g2o")
     fg = R.loadG2o(g2o, N=N)
@@ -101,25 +105,34 @@ def test_manhattan3500_from_init_all_the_tree_solve_beats_the_sweeps():
             A = A @ Rr.T
         return float(np.sqrt(np.mean(np.sum((A - B) ** 2, axis=1))))
     osv = R.initAllOrdered(fg, seed=1)
-    r_init = rms()
+    r_init, a_init = rms(), rms(True)
     osv.sweep(R.make_opts(N=N, seed=100), 5); osv.store.download(fg)
     r_sweeps = rms()
-    assert 4.0 < r_init < 7.0 and r_sweeps > 4.0              # the stall
+    assert 3.0 < r_init < 8.0 and r_sweeps > 3.0              # the stall
     ts = TreeSolver(fg, messages="relative")
     st = ts.stats()
     assert st["levels"] < 80 and st["width_max"] > 500 and st["unreached"] == 0, st
     ts.upload()
-    raw, ali, secs = [], [], []
-    for ps in range(5):
+    ali, secs = [], []
+    for ps in range(3):
         store_ctx = ts.store.ctx
         store_ctx.synchronize(); t0 = time.perf_counter()
         ts.solve(R.make_opts(N=N, seed=100 + ps)); store_ctx.synchronize()
         secs.append(time.perf_counter() - t0)
         ts.download()
-        raw.append(rms()); ali.append(rms(True))
-    # measured over 16 + 12 passes (profiles/r05_tree_solve.txt): raw 1.1 ... 8 m (median ~3.5: mostly a rigid transform of the whole map,
-    # the sampling noise of N = 100 particles on the long relative messages), after the best rigid alignment 0.75 ... 2.6 m (median 1.45)
-    assert min(raw) < r_init and np.median(ali) < 3.0 and min(ali) < 2.0 and max(secs) < 1.5, (r_init, raw, ali, secs)
+        ali.append(rms(True))
+    assert 0.4 < np.median(ali) < 3.0 and max(secs) < 1.5, (a_init, ali, secs)
+    es = RelativeEliminationSolver(fg)
+    raw, ali2, secs2 = [], [], []
+    for ps in range(6):
+        es.reset()
+        es.store.ctx.synchronize(); t0 = time.perf_counter()
+        es.solve(R.make_opts(N=N, seed=100 + ps)); es.store.ctx.synchronize()
+        secs2.append(time.perf_counter() - t0)
+        es.download(fg)
+        raw.append(rms()); ali2.append(rms(True))
+    assert max(raw) <= 2.3 and np.median(raw) < 1.6 and max(ali2) <= 1.0 and np.median(ali2) < min(a_init, np.median(ali)), (r_init, a_init, raw, ali2, ali)
+    assert np.median(secs2) < 0.2, secs2
 
 
 def test_init_all_ordered_keeps_existing_beliefs_and_solve_graph_takes_it():

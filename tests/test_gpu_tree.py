@@ -117,11 +117,11 @@ def test_manhattan_subgraph_tree_solve_equals_the_oracle_tree_solve(messages, tm
         assert frac > 0.9 and dmean < 1e-3, worst
 
 
-def test_manhattan_subgraph_star_messages_equal_the_oracle_tree_solve(tmp_path):
-    """message_tree="star" (round 5's structure: every separator tied to the one anchor) stays available and parity-checked"""
+def test_manhattan_subgraph_message_trees_equal_the_oracle_tree_solve(tmp_path):
+    """message_tree="hop": a spanning tree of relative messages over the separators (several anchored solves per clique)"""
     fg = manhattan_subgraph(150, 64, tmp_path)
     R.initAllOrdered(fg, seed=2)
-    dev, worst = _both(fg, "relative", 41, message_tree="star")
+    dev, worst = _both(fg, "relative", 41, message_tree="hop")
     assert dev.stats()["relative_messages"] > 20
     for frac, dmean in worst:
         assert frac > 0.9 and dmean < 1e-3, worst
@@ -137,7 +137,7 @@ def test_manhattan_1000_pose_prefix_tree_pass_equals_the_oracle_tree_pass(tmp_pa
     assert len(fg.variables) == 1000 and len(fg.factors) > 1300
     R.initAllOrdered(fg, seed=2)
     t0 = time.perf_counter()
-    dev, worst = _both(fg, "relative", 61)
+    dev, worst = _both(fg, "relative", 61, message_tree="hop")
     st = dev.stats()
     assert st["levels"] > 30 and st["relative_messages"] > 1000 and st["cliques"] > 700, st
     (frac, dmean), = worst

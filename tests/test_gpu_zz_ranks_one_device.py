@@ -264,7 +264,11 @@ def _tree_worker(rank, world, port, ret, N, messages):
         def shard(store):
             box["comm"] = HostStagedComm(torch, dist, world, ctx)
             return FrontierShard(store, torch, dist, world, rank, device=dev, comm=box["comm"])
-        ts = TreeSolver(fg, messages=messages, ctx=ctx, shard=shard)
+        if messages == "elimination":
+            from rome_jl_amd.elimination import RelativeEliminationSolver
+            ts = RelativeEliminationSolver(fg, ctx=ctx, shard=shard)
+        else:
+            ts = TreeSolver(fg, messages=messages, ctx=ctx, shard=shard)
         ts.upload(); ts.solve(R.make_opts(N=N, seed=13), passes=2)
         torch.cuda.synchronize()
         ret[rank] = ({l: ts.store.get(l).copy() for l in fg.variables}, box["comm"].calls)
@@ -273,7 +277,7 @@ def _tree_worker(rank, world, port, ret, N, messages):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,messages", [(2, "relative"), (4, "relative"), (2, "marginal"), (8, "relative")])
+@pytest.mark.parametrize("world,messages", [(2, "relative"), (4, "relative"), (2, "marginal"), (8, "relative"), (4, "elimination")])
 def test_tree_levels_sharded_by_clique_processes_equal_the_unsharded_tree_solve_real_kernels(world, messages):
     import torch
     import torch.multiprocessing as mp
@@ -283,13 +287,22 @@ def test_tree_levels_sharded_by_clique_processes_equal_the_unsharded_tree_solve_
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_tree_worker, args=(world, _free_port(), ret, N, messages), nprocs=world, join=True)
     fg = _tree_fg(R, N)
-    ts = TreeSolver(fg, messages=messages)
+    if messages == "elimination":
+        from rome_jl_amd.elimination import RelativeEliminationSolver
+        ts = RelativeEliminationSolver(fg)
+    else:
+        ts = TreeSolver(fg, messages=messages)
     ts.upload(); ts.solve(R.make_opts(N=N, seed=13), passes=2)
     torch.cuda.synchronize()
-    assert len(ts.tree.levels) > 5 and (messages == "marginal" or ts.stats()["relative_messages"] > 5)
+    if messages == "elimination":
+        n_ex = ts.stats()["plan_steps"]
+        assert ts.stats()["rounds"] >= 3
+    else:
+        n_ex = len(ts.tree.levels)
+        assert len(ts.tree.levels) > 5 and (messages == "marginal" or ts.stats()["relative_messages"] > 5)
     for r in range(world):
         got, calls = ret[r]
-        assert calls > len(ts.tree.levels)           # one exchange per level and pass (up and down)
+        assert calls > n_ex                          # one exchange per level / plan step and pass
         for l in fg.variables:
             assert np.array_equal(got[l], ts.store.get(l)), (world, r, l)
 
