@@ -57,24 +57,34 @@ def _comp_cov(a, Ca, b, Cb):
     return Ja @ Ca @ Ja.T + Jb @ Cb @ Jb.T
 
 
+def _det3(C):
+    return (C[0, 0] * (C[1, 1] * C[2, 2] - C[1, 2] * C[2, 1]) - C[0, 1] * (C[1, 0] * C[2, 2] - C[1, 2] * C[2, 0])
+            + C[0, 2] * (C[1, 0] * C[2, 1] - C[1, 1] * C[2, 0]))
+
+
 class _Edge:
-    """N samples of a^-1 b in store block `block`; (m, C) = first-order shadow used for structural decisions only"""
-    __slots__ = ("a", "b", "block", "m", "C")
+    """N samples of a^-1 b in store block `block`; (m, C) = first-order shadow used for structural decisions only; s = its scalar
+    spread (geometric mean of the eigenvalues of C; the inverse has the same determinant: |det J| = 1)"""
+    __slots__ = ("a", "b", "block", "m", "C", "s", "_rev")
 
     def __init__(self, a, b, block, m, C):
         self.a, self.b, self.block, self.m, self.C = a, b, block, np.asarray(m, float), np.asarray(C, float)
+        self.s = max(float(_det3(self.C)), 1e-300) ** (1.0 / 3.0)
+        self._rev = None
 
     def seen_from(self, v):
         """(mean, cov) of v^-1 other"""
         if v == self.a:
             return self.m, self.C
-        return _inv(self.m), _inv_cov(self.m, self.C)
+        if self._rev is None:
+            self._rev = (_inv(self.m), _inv_cov(self.m, self.C))
+        return self._rev
 
 
 class RelativeEliminationSolver:
     """interface of tree.TreeSolver (upload / solve / download / stats / store); backend as there (device by default)"""
 
-    def __init__(self, fg, backend=None, ctx=None, max_product=8, shard=None, loss_slack=1e9, loss_factor=1.0, priors_last=1, order_seed=0, structures=1):
+    def __init__(self, fg, backend=None, ctx=None, max_product=8, shard=None, loss_slack=1e9, loss_factor=1.0, priors_last=1, order_seed=0, structures=1, centre="tight"):
         from .factors import Pose2, Pose2Pose2, PriorPose2
         from .graph import FactorGraph
         for l, vt in fg.variables.items():
@@ -88,6 +98,7 @@ class RelativeEliminationSolver:
         self.max_product = int(max_product or 0)
         self.loss_slack, self.loss_factor, self.priors_last = float(loss_slack), float(loss_factor), bool(priors_last)
         self.order_seed = int(order_seed)
+        self.centre = centre
         self.findex = {fl: (fl, ls, f) for fl, ls, f in fg.factors}
         U = FactorGraph(fg.N)
         for l, vt in fg.variables.items():
@@ -134,30 +145,39 @@ class RelativeEliminationSolver:
         cliques, pairs_of, sm = self._split_products(L, cliques, pairs_of, list(smsgs))
         return LevelSpec(L, cliques, pairs_of, sm, 1)
 
-    @staticmethod
-    def _spread(C):
-        return float(np.linalg.det(C)) ** (1.0 / 3.0)
-
     def _loss(self, v, adj):
-        """what eliminating v NOW costs: the star about its tightest neighbour c replaces the pair (j, k) of spread s_j + s_k by the path
-        j - c - k of spread s_j + s_k + 2 s_c; summed relative loss of information over the dropped pairs, discounted where the pair
-        already has a direct edge (scalar spreads: geometric mean of the shadow covariance's eigenvalues).  Degree <= 2: exact, 0."""
+        """what eliminating v NOW costs, and the centre of its star: the star about neighbour c replaces the pair (j, k) of spread
+        s_j + s_k by the path j - c - k of spread s_j + s_k + 2 s_c; summed relative loss of information over the dropped pairs,
+        discounted where the pair already has a direct edge (scalar spreads of the shadow covariances).  c = the neighbour with the
+        smallest loss (centre="loss") or the tightest one (centre="tight").  Degree <= 2: exact, loss 0.  -> (loss, c)"""
         nb = adj[v]
+        s = {u: (es[0].s if len(es) == 1 else 1.0 / sum(1.0 / e.s for e in es)) for u, es in nb.items()}
+        if not s:
+            return 0.0, None
+        tight = min(s, key=lambda u: (s[u], self._pos[u]))
         if len(nb) <= 2:
-            return 0.0
-        s = {}
-        for u, es in nb.items():
-            s[u] = 1.0 / sum(1.0 / self._spread(e.C) for e in es)
-        c = min(s, key=s.__getitem__)
-        us = [u for u in s if u != c]
-        tot = 0.0
+            return 0.0, tight
+        us = list(s)
+        ex = {}
         for a in range(len(us)):
             for b in range(a + 1, len(us)):
-                j, k = us[a], us[b]
-                it, ia = 1.0 / (s[j] + s[k]), 1.0 / (s[j] + s[k] + 2 * s[c])
-                ex = sum(1.0 / self._spread(e.C) for e in adj[j].get(k, ()))
-                tot += (it - ia) / (it + ex)
-        return tot
+                es = adj[us[a]].get(us[b])
+                ex[(a, b)] = sum(1.0 / e.s for e in es) if es else 0.0
+        best = None
+        for ci in (range(len(us)) if self.centre == "loss" else [us.index(tight)]):
+            sc, tot = s[us[ci]], 0.0
+            for a in range(len(us)):
+                if a == ci:
+                    continue
+                for b in range(a + 1, len(us)):
+                    if b == ci:
+                        continue
+                    sj = s[us[a]] + s[us[b]]
+                    it = 1.0 / sj
+                    tot += (it - 1.0 / (sj + 2 * sc)) / (it + ex[(a, b)])
+            if best is None or (tot, self._pos[us[ci]]) < (best[0], self._pos[best[1]]):
+                best = (tot, us[ci])
+        return best
 
     def _structure(self, k_struct=0):
         from .clique import SampledPose2Pose2
@@ -205,6 +225,7 @@ class RelativeEliminationSolver:
         if self.order_seed or k_struct:   # another tie-break among equal losses / degrees: another structure, another set of approximations
             perm = np.random.default_rng(self.order_seed + 7919 * k_struct).permutation(len(pos))
             pos = {v: int(perm[k]) for v, k in pos.items()}
+        self._pos = pos
         rounds, down = [], []
         n_merge = n_comp = n_approx = n_transport = 0
 
@@ -222,7 +243,8 @@ class RelativeEliminationSolver:
 
         while alive:
             pool = (alive - hold) or alive
-            loss = {v: self._loss(v, adj) for v in pool}
+            lc = {v: self._loss(v, adj) for v in pool}
+            loss = {v: x[0] for v, x in lc.items()}
             cand = sorted(pool, key=lambda v: (loss[v], len(adj[v]), pos[v]))
             sel, blocked = [], set()
             cap = loss[cand[0]] * self.loss_factor + self.loss_slack
@@ -264,7 +286,7 @@ class RelativeEliminationSolver:
                     del adj[u][v]
                 if nb:
                     # tightest neighbour: smallest log det of the covariance of v^-1 u
-                    c = min(nb, key=lambda u: (np.linalg.slogdet(nb[u].seen_from(v)[1])[1], pos[u]))
+                    c = lc[v][1]
                     zc, Cc = nb[c].seen_from(v)
                     zi, Ci = _inv(zc), _inv_cov(zc, Cc)
                     for k, ek in nb.items():

@@ -207,7 +207,7 @@ def main():
         B0.update(new)
     M0 = np.array([B0[v][0] for v in range(n)])
     print("init pass: RMS %.3f m raw, %.3f m aligned" % (rms(M0), aligned(M0)))
-    kw = {k: float(v) if "." in v or "e" in v else int(v) for k, v in (kv.split("=") for kv in a.kw.split(",") if kv)}
+    kw = {k: (v if v.isalpha() else float(v) if "." in v or "e" in v else int(v)) for k, v in (kv.split("=") for kv in a.kw.split(",") if kv)}
     for form in a.forms.split(","):
         t0 = time.time()
         if form == "elimination":
