@@ -21,11 +21,11 @@ out = argv[1] if len(argv) > 1 else "/tmp/manhattan_solved.g2o"
 fg = R.loadG2o(path, N=100)                                   # x0 + PriorPose2(N(0, diag(0.1², 0.1², 0.05²))) + every EDGE_SE2
 if "--tree" in sys.argv:     # the reference's own call sequence (examples/ManhattanDatasetBatch.jl:43): tree = solveTree!(fg) -- no parametric start
     t = time.perf_counter()
-    ts_ = R.solveTree(fg, messages="relative", seed=11)   # (the form that moves a 3500-pose single-prior graph off its init pass)
+    ts_ = R.solveTree(fg, seed=11)   # (messages="auto": a Pose2Pose2 / PriorPose2 graph takes the elimination form -- no init pass)
     tt = time.perf_counter() - t
     labels = sorted(fg.variables, key=lambda s: int(s[1:]))
     mean, std = R.belief_stats(np.stack([fg.getVal(l) for l in labels]))
-    print("%d poses, %d factors: initAll + Bayes tree solve (%s) %.2f s wall-clock" % (len(labels), len(fg.factors), ts_.tree.summary(), tt))
+    print("%d poses, %d factors: solveTree (%s) %.2f s wall-clock" % (len(labels), len(fg.factors), ts_.stats(), tt))
     R.exportG2o(fg, filename=out, estimates={l: mean[k] for k, l in enumerate(labels)}, varIntLabel={l: int(l[1:]) for l in labels})
     print("wrote", out)
     sys.exit(0)

@@ -1092,7 +1092,8 @@ int plan_run(rome_upsolve_plan* P, const rome_opts* o, double* mirror_out, int64
         const Fam& f = P->fam[k4];
         double* out = P->d_prop[f.vt] + (size_t)(f.base + lo) * f.dt * N;
         ROME_HIP(c, launch_fam(f, P->fd[k4], o, base, lo, hi, st->bel[f.vf], st->bel[f.vt], out, sx, st->bel[f.kind == 1 ? 1 : 0]));
-        ROME_HIP(c, rome::launch_kde_bandwidth(f.dt, hi - lo, N, out, kCircBw[f.vt], 1e-2, 1e-6, P->d_pbw[f.vt] + (size_t)(f.base + lo) * f.dt, nullptr, sx));
+        if (P->max_k[f.vt] > 1)   // (a plan whose destinations take ONE proposal each -- sampling a graph's measurements, transporting a belief -- multiplies nothing: no manikde!)
+          ROME_HIP(c, rome::launch_kde_bandwidth(f.dt, hi - lo, N, out, kCircBw[f.vt], 1e-2, 1e-6, P->d_pbw[f.vt] + (size_t)(f.base + lo) * f.dt, nullptr, sx));
         return ROME_OK;
       });
       if (rc) return rc;

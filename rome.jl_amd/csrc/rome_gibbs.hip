@@ -809,7 +809,7 @@ static hipError_t launch_product_gibbs_nm(GibbsArgs& a, int dim, int V, int N, i
   int32_t* order = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(a.trees) + tree_bytes(dim, n_rows, N));
   a.order = order;
   hipLaunchKernelGGL(k_gibbs_order, dim3(1), dim3(1024), 0, s, V, a.prop_ptr, order);
-  if (n_rows > 0) {
+  if (n_rows > 0 && max_k > 1) {   // (no variable has two proposals: every product is a copy, no tree is read)
     if (dim == 2) hipLaunchKernelGGL((k_gibbs_trees<2, NM>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
     else if (dim == 3) hipLaunchKernelGGL((k_gibbs_trees<3, NM>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_gibbs_trees<6, NM>), dim3((n_rows + 3) / 4), dim3(256), 0, s, a);

@@ -85,14 +85,11 @@ class RelativeEliminationSolver:
     """interface of tree.TreeSolver (upload / solve / download / stats / store); backend as there (device by default)"""
 
     def __init__(self, fg, backend=None, ctx=None, max_product=8, shard=None, loss_slack=1e9, loss_factor=1.0, priors_last=1, order_seed=0, structures=1, centre="tight"):
-        from .factors import Pose2, Pose2Pose2, PriorPose2
+        from .factors import Pose2
         from .graph import FactorGraph
-        for l, vt in fg.variables.items():
-            if vt is not Pose2:
-                raise TypeError("messages='elimination' covers Pose2 graphs (variable %s is %s): use messages='relative' / 'marginal'" % (l, vt.__name__))
-        for fl, ls, f in fg.factors:
-            if not isinstance(f, (Pose2Pose2, PriorPose2)) or fl in fg.multihypo or fl in getattr(fg, "nullhypo", {}):
-                raise TypeError("messages='elimination' covers Pose2Pose2 / PriorPose2 factors without hypotheses (factor %s)" % fl)
+        why = self.covers(fg, why=True)
+        if why is not True:
+            raise TypeError("messages='elimination' covers Pose2 graphs of Pose2Pose2 / PriorPose2 factors without hypotheses (%s): use messages='relative' / 'marginal'" % why)
         self.fg, self.N, self.messages = fg, fg.N, "elimination"
         self.backend = backend or DeviceBackend(ctx)
         self.max_product = int(max_product or 0)
@@ -111,6 +108,7 @@ class RelativeEliminationSolver:
             U.addVariable(l + "&", Pose2)          # pool block: the mixture over the passes so far (solve(passes > 1))
         self.structures = max(1, int(structures))
         schedules = [self._structure(k) for k in range(self.structures)]
+        self.schedules = schedules
         self.store = self.backend.Store(U)
         self.store.put(ZERO, np.zeros((3, fg.N)))
         B = self.backend
@@ -130,6 +128,22 @@ class RelativeEliminationSolver:
         self._mix = {}
         self.runs = 0
         self.passes_pooled = 0
+
+    @staticmethod
+    def covers(fg, why=False):
+        """True when the graph is in this solver's scope (else False, or the reason with why=True)"""
+        from .factors import Pose2, Pose2Pose2, PriorPose2
+        bad = None
+        for l, vt in fg.variables.items():
+            if vt is not Pose2:
+                bad = "variable %s is %s" % (l, vt.__name__); break
+        if bad is None:
+            for fl, ls, f in fg.factors:
+                if not isinstance(f, (Pose2Pose2, PriorPose2)) or fl in fg.multihypo or fl in getattr(fg, "nullhypo", {}):
+                    bad = "factor %s" % fl; break
+        if bad is None and not any(isinstance(f, PriorPose2) for _, _, f in fg.factors):
+            bad = "no prior"
+        return (True if bad is None else bad) if why else bad is None
 
     # borrowed helpers (they use self.universe / self.max_product / self.fg only)
     _need = TreeSolver._need

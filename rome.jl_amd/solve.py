@@ -91,11 +91,12 @@ def solveGraph(fg, n_sweeps=10, seed=0x524F4D45, init="graph", bandwidth="silver
     return dg
 
 
-def solveTree(fg, tree=None, messages="marginal", passes=1, seed=0x524F4D45, ctx=None, order="mmd", **kw):
+def solveTree(fg, tree=None, messages="auto", passes=1, seed=0x524F4D45, ctx=None, order="mmd", **kw):
     """IIF `solveTree!(fg [, tree])` (examples/Hexagonal2D_SLAM.jl:24, examples/ManhattanDatasetBatch.jl:43, the incremental re-solves of
     examples/ManhattanDatasetIncremental.jl:107): `initAll!` for whatever has no belief yet (`initAllOrdered`), Bayes tree (built here, or the
     `tree.TreeSolver` of a previous call to re-solve from the current beliefs: plans are reused), up pass + down pass on the device,
-    beliefs written back, PPEs set.  messages: "marginal" (default) = IIF's per-variable separator beliefs, "relative" (tree.py: relative
+    beliefs written back, PPEs set.  messages: "auto" (default) = "elimination" where it applies, else "marginal"; "marginal" = IIF's
+    per-variable separator beliefs (the reference's semantics; hexagon windows, landmarks, multihypo, Pose3), "relative" (tree.py: relative
     messages between the separators of a clique), or "elimination" (elimination.py; Pose2 graphs of Pose2Pose2 / PriorPose2 factors:
     variable elimination in relative-factor algebra -- the form that SOLVES a large single-prior pose graph: Manhattan-3500 to 0.4 - 1.2 m
     of the MAP in one pass from the factors alone, no init pass).
@@ -105,6 +106,9 @@ def solveTree(fg, tree=None, messages="marginal", passes=1, seed=0x524F4D45, ctx
     from .tree import TreeSolver
     from .tree import BayesTree
     sig = (tuple(fg.variables), tuple(fl for fl, _, _ in fg.factors))
+    if messages == "auto":    # a pose graph the elimination form covers -> "elimination"; anything else -> IIF's own message form
+        from .elimination import RelativeEliminationSolver
+        messages = getattr(tree, "messages", None) or ("elimination" if RelativeEliminationSolver.covers(fg) else "marginal")
     if messages == "elimination" or getattr(tree, "messages", None) == "elimination":
         # variable elimination in relative-factor algebra (elimination.py): no init pass, no starting beliefs -- the factors alone
         from .elimination import RelativeEliminationSolver
