@@ -186,18 +186,42 @@ struct P2P2 {
     double r[3]; functor(K, functor_setup(K, z, fxc), z, t, r);
     return fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2]))) <= tol ? 0 : 1;
   }
-  // Gauss-Newton on the functor (the oracle's p2p2_newton): evaluate r at the current point; dir 0: J = -I; dir 1: J = [I, R'(θ) z_t; 0, 1]
+  // Gauss-Newton on the functor (the oracle's p2p2_newton): evaluate r at the current point; dir 0: J = -I; dir 1: J = [I, R'(θ) z_t; 0, 1].
+  // Round 6: the iterate carries (cos θ, sin θ) -- the heading residual is atan2(U21, U11) of a UNIT vector (U11, U21) = (cos r_θ, sin r_θ),
+  // so the heading update θ += r_θ is the rotation of (c, s) by (U11, U21): no sincos of the new iterate.  The ANGLE r_θ itself (the step
+  // of the linearised dir-1 translation update and the accumulated output heading) costs one atan2 on the first iterate; from the second
+  // iterate on |r_θ| < 1e-8 and r_θ = U21 to 1e-24.  One sincos (the start heading) + one atan2 per particle instead of one of each
+  // per iterate (three iterates: start -> root -> verification); the iterates agree with the fresh-sincos form to an ulp of the rotation.
   __device__ static __forceinline__ int gauss_newton(const Consts& K, const double (&z)[3], const double (&fxc)[3], double (&t)[3], int max_iters, double tol) {
     const Fn f = functor_setup(K, z, fxc);
+    Se2 T = se2_from_coords(t[0], t[1], t[2]);
     for (int it = 0; it < max_iters; ++it) {
-      double r[3], s, c; functor(K, f, z, t, r, &s, &c);
-      if (fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2]))) <= tol) return 0;
-      if (K.dir == 0) { t[0] += r[0]; t[1] += r[1]; t[2] += r[2]; }
-      else {
-        const double J13 = -s * z[0] - c * z[1], J23 = c * z[0] - s * z[1], dth = -r[2];
-        t[0] += -r[0] - J13 * dth; t[1] += -r[1] - J23 * dth; t[2] += dth;
+      double r0, r1, U11, U21;
+      if (K.dir == kDirPrior) {        // residual_priorpose2(f.F, T): log(T, m)
+        U11 = T.c * f.F.c + T.s * f.F.s; U21 = T.c * f.F.s - T.s * f.F.c;
+        r0 = f.F.x - T.x; r1 = f.F.y - T.y;
+      } else {                          // residual_pose2pose2(z, p, q) with (p, q) = (F, T) or (T, F)
+        const Se2& p = K.dir == 0 ? f.F : T;
+        const Se2& q = K.dir == 0 ? T : f.F;
+        const double qhx = p.x + p.c * z[0] - p.s * z[1], qhy = p.y + p.s * z[0] + p.c * z[1];
+        const double h11 = p.c * f.cz - p.s * f.sz, h21 = p.s * f.cz + p.c * f.sz;
+        U11 = q.c * h11 + q.s * h21; U21 = q.c * h21 - q.s * h11;
+        r0 = qhx - q.x; r1 = qhy - q.y;
+      }
+      const bool small = U11 > 0.0 && fabs(U21) < 1e-8;
+      const double r2 = small ? U21 : fast_atan2(U21, U11);
+      if (fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol) { t[0] = T.x; t[1] = T.y; return 0; }
+      const double c0 = T.c, s0 = T.s;
+      if (K.dir == 1) {
+        const double J13 = -s0 * z[0] - c0 * z[1], J23 = c0 * z[0] - s0 * z[1], dth = -r2;
+        T.x += -r0 - J13 * dth; T.y += -r1 - J23 * dth; t[2] += dth;
+        T.c = c0 * U11 + s0 * U21; T.s = s0 * U11 - c0 * U21;       // rotation by -r_θ
+      } else {
+        T.x += r0; T.y += r1; t[2] += r2;
+        T.c = c0 * U11 - s0 * U21; T.s = s0 * U11 + c0 * U21;       // rotation by +r_θ
       }
     }
+    t[0] = T.x; t[1] = T.y;
     return 1;
   }
 

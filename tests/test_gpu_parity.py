@@ -103,12 +103,14 @@ def _oracle_p2(solver, N, mu, cov, fixed, target, dirs, noise, **kw):
 
 
 @pytest.mark.parametrize("N", [1, 7, 64, 100, 128, 200, 256, 300, 512])
-@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("solver", [0, 1, 3])
 def test_pose2pose2_presampled_vs_oracle(N, solver):
+    """solver 3 = GAUSS_NEWTON: the functor iteration from the belief point (north_star's "residual + numerical root-find"; round 6: the
+    iterate carries (cos, sin) of its heading) against the oracle's Newton iteration on the same functor"""
     C_ = 37
     mu, cov, fixed, target, dirs, noise = _p2_inputs(C_, N, 100 + N)
     out, st = R.conv_pose2pose2(R.make_opts(N=N, solver=solver), mu, cov, fixed, target, dirs=dirs, noise=noise, want_status=True)
-    ref, rst = _oracle_p2(solver, N, mu, cov, fixed, target, dirs, noise)
+    ref, rst = _oracle_p2(min(solver, 1), N, mu, cov, fixed, target, dirs, noise)
     assert np.abs(wrapdiff(out, ref, [2])).max() < TOL
     assert (st == 0).all() and (rst == 0).all()
 
