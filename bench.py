@@ -466,7 +466,7 @@ def main():
     }
     # counter-measured HBM traffic of the same kernel on the same table (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
     # scripts/profile_round.sh; PMC counters need rocprofv3 around the process, so this run quotes the stored pass)
-    tfile = os.path.join(ROOT, "profiles", "r05_hbm_traffic_%s.json" % args.solver)
+    tfile = os.path.join(ROOT, "profiles", "r06_hbm_traffic_%s.json" % args.solver)
     if os.path.exists(tfile) and world == 1:
         try:
             with open(tfile) as f:
@@ -482,7 +482,7 @@ def main():
         except Exception:
             pass
 
-    sfile = os.path.join(ROOT, "profiles", "r05_sq_counters_%s.json" % args.solver)
+    sfile = os.path.join(ROOT, "profiles", "r06_sq_counters_%s.json" % args.solver)
     if os.path.exists(sfile) and world == 1:
         try:
             with open(sfile) as f:
@@ -495,7 +495,7 @@ def main():
             avail = 256 * 4 * clk * kern_ms * 1e-3
             out["roofline"]["secondary"] = {"bound": "valu_issue", "achieved": busy_cycles / (kern_ms * 1e-3) / 1e12,
                                             "peak": 256 * 4 * clk / 1e12, "unit": "T SIMD-cycles/s", "frac": busy_cycles / avail,
-                                            "source": "SQ_ACTIVE_INST_VALU (profiles/r05_sq_counters_%s.json) / (256 CUs x 4 SIMDs x 2.4 GHz x launch period of this run)" % args.solver}
+                                            "source": "SQ_ACTIVE_INST_VALU (profiles/r06_sq_counters_%s.json) / (256 CUs x 4 SIMDs x 2.4 GHz x launch period of this run)" % args.solver}
         except Exception:
             pass
 
@@ -517,7 +517,7 @@ def main():
             by_solver[name] = {"bytes_per_particle": BYTES_PER_PARTICLE_P2P2[name], "algorithmic_bytes_per_launch": bts, "kernel_ms_per_launch": 1e3 * dt_l,
                                "achieved": bts / dt_l / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bts / dt_l / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
                                "launches_timed": reps}
-            sqf = os.path.join(ROOT, "profiles", "r05_sq_counters_%s.json" % name)
+            sqf = os.path.join(ROOT, "profiles", "r06_sq_counters_%s.json" % name)
             if os.path.exists(sqf):   # secondary bound of the functor-iterating solvers: VALU issue (stored PMC pass of the same kernel and table)
                 try:
                     with open(sqf) as f:

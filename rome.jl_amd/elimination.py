@@ -28,63 +28,50 @@ order) are taken on the host from first-order covariances of the edges ("shadow"
 
 Reference: examples/ManhattanDatasetBatch.jl:43 (`tree = solveTree!(fg)`); the operations are the hot path's own
 (sampled-measurement rows of `approxConvBelief`, `manikde!`, `manifoldProduct`)."""
+import math
+
 import numpy as np
 
 from .tree import LevelSpec, ZERO, DeviceBackend, TreeSolver
 
 
 def _inv(z):
-    c, s = np.cos(z[2]), np.sin(z[2])
-    return np.array([-(c * z[0] + s * z[1]), -(-s * z[0] + c * z[1]), -z[2]])
+    c, s = math.cos(z[2]), math.sin(z[2])
+    return (-(c * z[0] + s * z[1]), -(-s * z[0] + c * z[1]), -z[2])
 
 
 def _comp(a, b):
-    c, s = np.cos(a[2]), np.sin(a[2])
+    c, s = math.cos(a[2]), math.sin(a[2])
     t = a[2] + b[2]
-    return np.array([a[0] + c * b[0] - s * b[1], a[1] + s * b[0] + c * b[1], np.arctan2(np.sin(t), np.cos(t))])
-
-
-def _inv_cov(z, C):
-    c, s = np.cos(z[2]), np.sin(z[2])
-    J = np.array([[-c, -s, s * z[0] - c * z[1]], [s, -c, c * z[0] + s * z[1]], [0, 0, -1.0]])
-    return J @ C @ J.T
-
-
-def _comp_cov(a, Ca, b, Cb):
-    c, s = np.cos(a[2]), np.sin(a[2])
-    Ja = np.array([[1, 0, -s * b[0] - c * b[1]], [0, 1, c * b[0] - s * b[1]], [0, 0, 1.0]])
-    Jb = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
-    return Ja @ Ca @ Ja.T + Jb @ Cb @ Jb.T
-
-
-def _det3(C):
-    return (C[0, 0] * (C[1, 1] * C[2, 2] - C[1, 2] * C[2, 1]) - C[0, 1] * (C[1, 0] * C[2, 2] - C[1, 2] * C[2, 0])
-            + C[0, 2] * (C[1, 0] * C[2, 1] - C[1, 1] * C[2, 0]))
+    return (a[0] + c * b[0] - s * b[1], a[1] + s * b[0] + c * b[1], math.atan2(math.sin(t), math.cos(t)))
 
 
 class _Edge:
-    """N samples of a^-1 b in store block `block`; (m, C) = first-order shadow used for structural decisions only; s = its scalar
-    spread (geometric mean of the eigenvalues of C; the inverse has the same determinant: |det J| = 1)"""
-    __slots__ = ("a", "b", "block", "m", "C", "s", "_rev")
+    """N samples of a^-1 b in store block `block`.  (m, vt, vth) = the SHADOW used for structural decisions only (which neighbour is
+    tightest, what an elimination loses): mean relative pose, an isotropic translation variance and the heading variance, propagated to
+    first order in plain float arithmetic (the lever arm |t|^2 * vth enters the translation variance of an inverse / a composition);
+    s = (vt^2 vth)^(1/3), the geometric mean of the eigenvalues of diag(vt, vt, vth)."""
+    __slots__ = ("a", "b", "block", "m", "vt", "vth", "s", "_rev")
 
-    def __init__(self, a, b, block, m, C):
-        self.a, self.b, self.block, self.m, self.C = a, b, block, np.asarray(m, float), np.asarray(C, float)
-        self.s = max(float(_det3(self.C)), 1e-300) ** (1.0 / 3.0)
+    def __init__(self, a, b, block, m, vt, vth):
+        self.a, self.b, self.block, self.m, self.vt, self.vth = a, b, block, m, vt, vth
+        self.s = (vt * vt * vth) ** (1.0 / 3.0)
         self._rev = None
 
     def seen_from(self, v):
-        """(mean, cov) of v^-1 other"""
+        """(mean, vt, vth) of v^-1 other"""
         if v == self.a:
-            return self.m, self.C
+            return self.m, self.vt, self.vth
         if self._rev is None:
-            self._rev = (_inv(self.m), _inv_cov(self.m, self.C))
+            m = self.m
+            self._rev = (_inv(m), self.vt + (m[0] * m[0] + m[1] * m[1]) * self.vth, self.vth)
         return self._rev
 
 
 class RelativeEliminationSolver:
     """interface of tree.TreeSolver (upload / solve / download / stats / store); backend as there (device by default)"""
 
-    def __init__(self, fg, backend=None, ctx=None, max_product=8, shard=None, loss_slack=1e9, loss_factor=1.0, priors_last=1, order_seed=0, structures=1, centre="tight"):
+    def __init__(self, fg, backend=None, ctx=None, max_product=8, shard=None, loss_slack=1e9, loss_factor=1.0, priors_last=1, order_seed=0, structures=1, centre="tight", near_weight=0.0):
         from .factors import Pose2
         from .graph import FactorGraph
         why = self.covers(fg, why=True)
@@ -96,6 +83,7 @@ class RelativeEliminationSolver:
         self.loss_slack, self.loss_factor, self.priors_last = float(loss_slack), float(loss_factor), bool(priors_last)
         self.order_seed = int(order_seed)
         self.centre = centre
+        self.near_weight = float(near_weight)
         self.findex = {fl: (fl, ls, f) for fl, ls, f in fg.factors}
         U = FactorGraph(fg.N)
         for l, vt in fg.variables.items():
@@ -106,9 +94,12 @@ class RelativeEliminationSolver:
         for l in list(fg.variables):
             U.addVariable(l + "^", Pose2)          # anchor block: N copies of the posterior mean
             U.addVariable(l + "&", Pose2)          # pool block: the mixture over the passes so far (solve(passes > 1))
+        import time
         self.structures = max(1, int(structures))
+        t0 = time.perf_counter()
         schedules = [self._structure(k) for k in range(self.structures)]
         self.schedules = schedules
+        t1 = time.perf_counter()
         self.store = self.backend.Store(U)
         self.store.put(ZERO, np.zeros((3, fg.N)))
         B = self.backend
@@ -124,6 +115,7 @@ class RelativeEliminationSolver:
             for kind, x in sched:
                 st.append(("plan", B.Plan(self.store, x)) if kind == "plan" else ("op", B.BlockOp(self.store, kind, x)))
             self.steps.append(st)
+        self.build_s = dict(structure=t1 - t0, store_and_plans=time.perf_counter() - t1)
         self._to_pool = self.backend.BlockOp(self.store, "copy", [(l, l + "&") for l in fg.variables])
         self._mix = {}
         self.runs = 0
@@ -225,7 +217,8 @@ class RelativeEliminationSolver:
             nfl = "s:" + fl
             L.factors.append((nfl, [ZERO, blk], f)); L._findex[nfl] = L.factors[-1]
             ent.append((blk, [nfl]))
-            e = _Edge(a, b, blk, f.Z.mu, f.Z.cov)
+            C = f.Z.cov
+            e = _Edge(a, b, blk, (float(f.Z.mu[0]), float(f.Z.mu[1]), float(f.Z.mu[2])), math.sqrt(max(float(C[0, 0] * C[1, 1] - C[0, 1] * C[1, 0]), 1e-300)), float(C[2, 2]))
             adj[a].setdefault(b, []).append(e); adj[b].setdefault(a, []).append(e)
         pri = {v for v in fg.variables if unary[v]}
         if not pri:
@@ -240,6 +233,17 @@ class RelativeEliminationSolver:
             perm = np.random.default_rng(self.order_seed + 7919 * k_struct).permutation(len(pos))
             pos = {v: int(perm[k]) for v, k in pos.items()}
         self._pos = pos
+        dist = {v: 0.0 for v in fg.variables}
+        if self.near_weight:      # hops to the nearest prior variable, scaled to [0, 1]
+            from collections import deque
+            dq = deque(pri); seen = {v: 0 for v in pri}
+            while dq:
+                v = dq.popleft()
+                for u in adj[v]:
+                    if u not in seen:
+                        seen[u] = seen[v] + 1; dq.append(u)
+            mx = max(seen.values()) or 1
+            dist = {v: seen.get(v, mx) / mx for v in fg.variables}
         rounds, down = [], []
         n_merge = n_comp = n_approx = n_transport = 0
 
@@ -259,7 +263,7 @@ class RelativeEliminationSolver:
             pool = (alive - hold) or alive
             lc = {v: self._loss(v, adj) for v in pool}
             loss = {v: x[0] for v, x in lc.items()}
-            cand = sorted(pool, key=lambda v: (loss[v], len(adj[v]), pos[v]))
+            cand = sorted(pool, key=lambda v: (loss[v] + self.near_weight * dist[v], len(adj[v]), pos[v]))
             sel, blocked = [], set()
             cap = loss[cand[0]] * self.loss_factor + self.loss_slack
             for v in cand:
@@ -279,16 +283,18 @@ class RelativeEliminationSolver:
                     if len(es) > 1:     # parallel edges -> one: product of their samples, all seen from v
                         blk = new_block("m")
                         Lm.addVariable(blk, Pose2)
-                        Li, hi, m0 = np.zeros((3, 3)), np.zeros(3), es[0].seen_from(v)[0]
+                        m0 = es[0].seen_from(v)[0]
+                        it = ith = hx = hy = hth = 0.0
                         for e in es:
-                            m_, C_ = e.seen_from(v)
-                            I = np.linalg.inv(C_)
-                            d = m_ - m0; d[2] = np.arctan2(np.sin(d[2]), np.cos(d[2]))
-                            Li += I; hi += I @ d
-                        C = np.linalg.inv(Li)
+                            m_, vt_, vth_ = e.seen_from(v)
+                            dth = m_[2] - m0[2]
+                            dth = math.atan2(math.sin(dth), math.cos(dth))
+                            it += 1.0 / vt_; ith += 1.0 / vth_
+                            hx += (m_[0] - m0[0]) / vt_; hy += (m_[1] - m0[1]) / vt_; hth += dth / vth_
+                        mm = (m0[0] + hx / it, m0[1] + hy / it, m0[2] + hth / ith)
                         merges.append((blk, identity_rows(Lm, blk, [e.block for e in es], flip={k for k, e in enumerate(es) if e.a != v})))
                         n_merge += 1
-                        nb[u] = _Edge(v, u, blk, m0 + C @ hi, C)
+                        nb[u] = _Edge(v, u, blk, mm, 1.0 / it, 1.0 / ith)
                     else:
                         nb[u] = es[0]
                 if len(unary[v]) > 1:   # several absolute beliefs of v -> one
@@ -301,14 +307,13 @@ class RelativeEliminationSolver:
                 if nb:
                     # tightest neighbour: smallest log det of the covariance of v^-1 u
                     c = lc[v][1]
-                    zc, Cc = nb[c].seen_from(v)
-                    zi, Ci = _inv(zc), _inv_cov(zc, Cc)
+                    zi, vti, vthi = nb[c].seen_from(c)             # c^-1 v
                     for k, ek in nb.items():
                         if k == c:
                             continue
-                        zk, Ck = ek.seen_from(v)
+                        zk, vtk, vthk = ek.seen_from(v)
                         blk = new_block("c")
-                        e = _Edge(c, k, blk, _comp(zi, zk), _comp_cov(zi, Ci, zk, Ck))
+                        e = _Edge(c, k, blk, _comp(zi, zk), vti + vtk + (zk[0] * zk[0] + zk[1] * zk[1]) * vthi, vthi + vthk)
                         # c^-1 k = (v^-1 c)^-1 (+) (v^-1 k): invert the block of c when it holds v^-1 c, the block of k when it holds k^-1 v
                         comps.append((nb[c].block, ek.block, blk, nb[c].a == v, ek.a != v))
                         adj[c].setdefault(k, []).append(e); adj[k].setdefault(c, []).append(e)
@@ -406,4 +411,4 @@ class RelativeEliminationSolver:
         self.store.download(fg or self.fg, labels=list(self.fg.variables))
 
     def stats(self):
-        return dict(self._stats, messages=self.messages)
+        return dict(self._stats, messages=self.messages, build_s=self.build_s)

@@ -244,13 +244,19 @@ class _Problem:
         every rank (factor rows are independent; BASELINE configs[4] "batched Jacobians on 8 GPUs")."""
         import scipy.sparse as sp
         r = np.empty(self.m); vals = []
+        indexed = shard is not None and hasattr(shard, "linearize_indexed")
+        if indexed:
+            shard.begin(X)          # X crosses PCIe once; the gathers X[ia] / X[ib] of every factor kind run on the device
         for k, g in self.groups.items():
-            xa = X[g["ia"]]
-            xb = X[g["ib"]] if g["ib"] is not None else None
-            if shard is None:
-                rk, Ja, Jb = api.linearize(k, g["mu"], g["W"], xa, xb, ctx=ctx)
+            if indexed:
+                rk, Ja, Jb = shard.linearize_indexed(k, g["mu"], g["W"], X, g["ia"], g["ib"], ctx)
             else:
-                rk, Ja, Jb = shard.linearize(k, g["mu"], g["W"], xa, xb, ctx)
+                xa = X[g["ia"]]
+                xb = X[g["ib"]] if g["ib"] is not None else None
+                if shard is None:
+                    rk, Ja, Jb = api.linearize(k, g["mu"], g["W"], xa, xb, ctx=ctx)
+                else:
+                    rk, Ja, Jb = shard.linearize(k, g["mu"], g["W"], xa, xb, ctx)
             r[g["rslice"]] = rk.ravel()
             vals.append(Ja.ravel())
             if Jb is not None:

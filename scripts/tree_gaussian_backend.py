@@ -20,6 +20,7 @@ from scripts.tree_surrogate import load, wrap, parametric, oplus, ominus, produc
 from scripts.tree_linear_surrogate import true_optimum, init_pass   # noqa: E402
 
 _SP = None
+TEMPER = 1.0      # experiment: the centre edge's spread scaled by this before a composition
 
 
 def _sigma(n):
@@ -132,7 +133,7 @@ class GBlockOp:
                 (ma, Sa), (mb, Sb) = v[e[0]], v[e[1]]
                 n = 6
                 _, lam, W = _sigma(n)
-                P = np.zeros((6, 6)); P[:3, :3] = Sa; P[3:, 3:] = Sb
+                P = np.zeros((6, 6)); P[:3, :3] = Sa * TEMPER; P[3:, 3:] = Sb
                 Lc = np.linalg.cholesky((n + lam) * (P + 1e-15 * np.eye(6)))
                 x0 = np.concatenate([ma, mb])
                 pts = [x0] + [x0 + Lc[:, k] for k in range(n)] + [x0 - Lc[:, k] for k in range(n)]
