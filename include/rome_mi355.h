@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define ROME_MI355_VERSION 121 /* 0.1.2+: store-resident messages (smsg_*) in rome_clique_upsolve_host (a tree level reads its children's separator beliefs from HBM); multihypo / nullhypo / stream-id columns in rome_clique_host; rome_store + rome_upsolve_plan
+#define ROME_MI355_VERSION 122 /* 0.1.22: ROME_BLOCKOP_COMPOSE / MIX, rome_blockop_plan_create_ex (round 6: solveTree as variable elimination in relative-factor algebra); rome_ctx_set_stream orders streams by event.  0.1.21: store-resident messages (smsg_*) in rome_clique_upsolve_host (a tree level reads its children's separator beliefs from HBM); multihypo / nullhypo / stream-id columns in rome_clique_host; rome_store + rome_upsolve_plan
                                  * (device-resident clique up-solves: beliefs stay in HBM across frontiers) */
 
 enum {
@@ -400,6 +400,11 @@ enum { ROME_BLOCKOP_COPY = 0, ROME_BLOCKOP_ANCHOR = 1, ROME_BLOCKOP_RELATIVE = 2
 typedef struct rome_blockop_plan rome_blockop_plan;
 int  rome_blockop_plan_create(rome_ctx*, rome_store*, int32_t op, int32_t n, const int32_t* type, const int32_t* a, const int32_t* b,
                               const int32_t* dst, rome_blockop_plan** out);
+/* COMPOSE with per-entry inflation: params[2k], params[2k + 1] > 0 scale the deviations of entry k's composed samples about their mean
+ * (translation, heading) -- the star-mesh transform of an eliminated star: the edge between two of its legs keeps the composed mean and takes
+ * the variance v_j + v_k + v_j v_k sum_{i != j,k} 1 / v_i.  params = NULL: plain compositions (rome_blockop_plan_create). */
+int  rome_blockop_plan_create_ex(rome_ctx*, rome_store*, int32_t op, int32_t n, const int32_t* type, const int32_t* a, const int32_t* b,
+                                 const int32_t* dst, const double* params, rome_blockop_plan** out);
 int  rome_blockop_plan_run(rome_blockop_plan*);
 void rome_blockop_plan_destroy(rome_blockop_plan*);
 /* A scatter plan: the receive side of a frontier exchange.  After an all-gather of the ranks' send buffers, block src_block[k] of the

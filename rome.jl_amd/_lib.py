@@ -109,6 +109,7 @@ SIGNATURES = {
     "rome_upsolve_plan_run": (C.c_int, [C.c_void_p, _PO, C.c_void_p, C.c_int64]),
     "rome_upsolve_plan_destroy": (None, [C.c_void_p]),
     "rome_blockop_plan_create": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32, _PI, _PI, _PI, _PI, C.POINTER(C.c_void_p)]),
+    "rome_blockop_plan_create_ex": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32, _PI, _PI, _PI, _PI, _PD, C.POINTER(C.c_void_p)]),
     "rome_blockop_plan_run": (C.c_int, [C.c_void_p]),
     "rome_blockop_plan_destroy": (None, [C.c_void_p]),
     "rome_scatter_plan_create": (C.c_int, [_CTX, C.c_void_p, C.c_int32, _PI, _PI, _PI, C.c_int64, C.POINTER(C.c_void_p)]),

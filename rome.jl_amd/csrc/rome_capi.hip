@@ -830,6 +830,7 @@ struct rome_blockop_plan {
   rome_ctx* ctx = nullptr; rome_store* st = nullptr;
   int op = 0, n = 0;
   int32_t* d_ent = nullptr;   // [n][4] = (type, a, b, dst)
+  double* d_prm = nullptr;    // COMPOSE: [n][2] = (translation, heading) inflation of the composed deviations, or NULL
 };
 struct rome_upsolve_plan {
   rome_ctx* ctx = nullptr; rome_store* st = nullptr;
@@ -1258,6 +1259,12 @@ int rome_scatter_plan_create(rome_ctx* c, rome_store* st, int32_t n, const int32
 }
 int rome_blockop_plan_create(rome_ctx* c, rome_store* st, int32_t op, int32_t n, const int32_t* type, const int32_t* a, const int32_t* b,
                              const int32_t* dst, rome_blockop_plan** out) {
+  return rome_blockop_plan_create_ex(c, st, op, n, type, a, b, dst, nullptr, out);
+}
+int rome_blockop_plan_create_ex(rome_ctx* c, rome_store* st, int32_t op, int32_t n, const int32_t* type, const int32_t* a, const int32_t* b,
+                                const int32_t* dst, const double* params, rome_blockop_plan** out) {
+  if (params && op != ROME_BLOCKOP_COMPOSE) return ROME_ERR_INVALID_ARG;
+  if (params) for (int k = 0; k < 2 * n; ++k) if (!(params[k] > 0.0) || !(params[k] < 1e6)) return ROME_ERR_INVALID_ARG;
   if (!c || !st || !out || st->ctx != c || n < 0 || op < ROME_BLOCKOP_COPY || op > ROME_BLOCKOP_MIX) return ROME_ERR_INVALID_ARG;
   if (n > 0 && (!type || !a || !dst || ((op == ROME_BLOCKOP_RELATIVE || op == ROME_BLOCKOP_COMPOSE) && !b))) return ROME_ERR_INVALID_ARG;
   std::vector<int32_t> ent((size_t)n * 4 + 4, 0);
@@ -1276,6 +1283,12 @@ int rome_blockop_plan_create(rome_ctx* c, rome_store* st, int32_t op, int32_t n,
   B->ctx = c; B->st = st; B->op = op; B->n = n;
   if (hipMalloc((void**)&B->d_ent, (size_t)n * 16 + 16) != hipSuccess) { delete B; return hip_fail(c, hipGetLastError()); }
   if (hipMemcpy(B->d_ent, ent.data(), (size_t)n * 16 + 16, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(B->d_ent); delete B; return hip_fail(c, hipGetLastError()); }
+  if (params && n > 0) {
+    if (hipMalloc((void**)&B->d_prm, (size_t)n * 16) != hipSuccess || hipMemcpy(B->d_prm, params, (size_t)n * 16, hipMemcpyHostToDevice) != hipSuccess) {
+      if (B->d_prm) (void)hipFree(B->d_prm);
+      (void)hipFree(B->d_ent); delete B; return hip_fail(c, hipGetLastError());
+    }
+  }
   *out = B;
   return ROME_OK;
 }
@@ -1283,12 +1296,13 @@ int rome_blockop_plan_run(rome_blockop_plan* B) {
   if (!B) return ROME_ERR_INVALID_ARG;
   rome_ctx* c = B->ctx;
   ROME_BIND(c);
-  ROME_HIP(c, rome::launch_block_ops(B->op, B->n, B->st->N, B->d_ent, B->st->bel[0], B->st->bel[1], B->st->bel[2], c->stream));
+  ROME_HIP(c, rome::launch_block_ops(B->op, B->n, B->st->N, B->d_ent, B->st->bel[0], B->st->bel[1], B->st->bel[2], c->stream, B->d_prm));
   return ROME_OK;
 }
 void rome_blockop_plan_destroy(rome_blockop_plan* B) {
   if (!B) return;
   if (B->d_ent) (void)hipFree(B->d_ent);
+  if (B->d_prm) (void)hipFree(B->d_prm);
   delete B;
 }
 

@@ -91,6 +91,6 @@ hipError_t launch_scatter_blocks(int n, int N, const int32_t* ent /*[n][4]*/, co
                                  double* st2, double* st_pt, double* st3, hipStream_t s, int to_store);
 
 // block operations inside a store (include/rome_mi355.h ROME_BLOCKOP_*): entry k = (type, a, b, dst); one 256-thread block per entry
-hipError_t launch_block_ops(int op, int n, int N, const int32_t* ent /*[n][4]*/, double* st2, double* st_pt, double* st3, hipStream_t s);
+hipError_t launch_block_ops(int op, int n, int N, const int32_t* ent /*[n][4]*/, double* st2, double* st_pt, double* st3, hipStream_t s, const double* prm /*[n][2] or NULL*/ = nullptr);
 
 }  // namespace rome

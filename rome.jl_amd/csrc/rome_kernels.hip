@@ -1569,7 +1569,7 @@ hipError_t launch_scatter_blocks(int n, int N, const int32_t* ent, const double*
 }
 
 // ---- block operations inside a store (copy / anchor / relative / compose): one 256-thread block per entry (type | flags << 8, a, b, dst)
-__global__ void __launch_bounds__(256) k_block_ops(int op, int N, const int4* __restrict__ ent, double* d2, double* dpt, double* d3) {
+__global__ void __launch_bounds__(256) k_block_ops(int op, int N, const int4* __restrict__ ent, double* d2, double* dpt, double* d3, const double* __restrict__ prm) {
   int4 e = ent[blockIdx.x];
   const int flags = e.x >> 8;   // (compose: bit 0 = take A^-1, bit 1 = take B^-1)
   e.x &= 0xff;
@@ -1596,6 +1596,30 @@ __global__ void __launch_bounds__(256) k_block_ops(int op, int N, const int4* __
       sincos(at, &sn, &cs);
       double s2, c2; sincos(at + bt, &s2, &c2);
       D[q] = ax + cs * bx - sn * by; D[N + q] = ay + sn * bx + cs * by; D[2 * N + q] = atan2(s2, c2);
+    }
+    const double gt = prm ? prm[2 * (size_t)blockIdx.x] : 1.0, gth = prm ? prm[2 * (size_t)blockIdx.x + 1] : 1.0;
+    if (gt == 1.0 && gth == 1.0) return;
+    // inflate the deviations of the composed samples about their mean (star-mesh transform: the edge's spread grows by what the pair
+    // shares with the other legs of the eliminated star): translation by gt, heading by gth.  Sums in a fixed order (as the anchor).
+    __shared__ double rs[4][256];
+    __syncthreads();
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int q = i; q < N; q += 256) { double sn, cs; sincos(D[2 * N + q], &sn, &cs); a0 += D[q]; a1 += D[N + q]; a2 += sn; a3 += cs; }
+    rs[0][i] = a0; rs[1][i] = a1; rs[2][i] = a2; rs[3][i] = a3;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (i < w) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rs[k][i] += rs[k][i + w];
+      }
+      __syncthreads();
+    }
+    const double inv = 1.0 / (double)N, mx = rs[0][0] * inv, my = rs[1][0] * inv, mt = atan2(rs[2][0], rs[3][0]);
+    for (int q = i; q < N; q += 256) {
+      double sn, cs; sincos(D[2 * N + q] - mt, &sn, &cs);
+      const double dt = atan2(sn, cs);
+      double s2, c2; sincos(mt + gth * dt, &s2, &c2);
+      D[q] = mx + gt * (D[q] - mx); D[N + q] = my + gt * (D[N + q] - my); D[2 * N + q] = atan2(s2, c2);
     }
     return;
   }
@@ -1640,8 +1664,8 @@ __global__ void __launch_bounds__(256) k_block_ops(int op, int N, const int4* __
   __syncthreads();
   for (int q = i; q < dim * N; q += 256) D[q] = m[q / N];
 }
-hipError_t launch_block_ops(int op, int n, int N, const int32_t* ent, double* st2, double* st_pt, double* st3, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_block_ops, dim3(n), dim3(256), 0, s, op, N, reinterpret_cast<const int4*>(ent), st2, st_pt, st3);
+hipError_t launch_block_ops(int op, int n, int N, const int32_t* ent, double* st2, double* st_pt, double* st3, hipStream_t s, const double* prm) {
+  if (n > 0) hipLaunchKernelGGL(k_block_ops, dim3(n), dim3(256), 0, s, op, N, reinterpret_cast<const int4*>(ent), st2, st_pt, st3, prm);
   return hipGetLastError();
 }
 

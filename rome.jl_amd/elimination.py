@@ -71,7 +71,7 @@ class _Edge:
 class RelativeEliminationSolver:
     """interface of tree.TreeSolver (upload / solve / download / stats / store); backend as there (device by default)"""
 
-    def __init__(self, fg, backend=None, ctx=None, max_product=8, shard=None, loss_slack=1e9, loss_factor=1.0, priors_last=1, order_seed=0, structures=1, centre="tight", near_weight=0.0):
+    def __init__(self, fg, backend=None, ctx=None, max_product=8, shard=None, loss_slack=1e9, loss_factor=1.0, priors_last=1, order_seed=0, structures=1, centre="tight", near_weight=0.0, mesh_max=0):
         from .factors import Pose2
         from .graph import FactorGraph
         why = self.covers(fg, why=True)
@@ -84,6 +84,7 @@ class RelativeEliminationSolver:
         self.order_seed = int(order_seed)
         self.centre = centre
         self.near_weight = float(near_weight)
+        self.mesh_max = int(mesh_max)
         self.findex = {fl: (fl, ls, f) for fl, ls, f in fg.factors}
         U = FactorGraph(fg.N)
         for l, vt in fg.variables.items():
@@ -128,7 +129,7 @@ class RelativeEliminationSolver:
         bad = None
         for l, vt in fg.variables.items():
             if vt is not Pose2:
-                bad = "variable %s is %s" % (l, vt.__name__); break
+                bad = "variable %s is %s" % (l, getattr(vt, "__name__", type(vt).__name__.lstrip("_"))); break
         if bad is None:
             for fl, ls, f in fg.factors:
                 if not isinstance(f, (Pose2Pose2, PriorPose2)) or fl in fg.multihypo or fl in getattr(fg, "nullhypo", {}):
@@ -161,8 +162,8 @@ class RelativeEliminationSolver:
         if not s:
             return 0.0, None
         tight = min(s, key=lambda u: (s[u], self._pos[u]))
-        if len(nb) <= 2:
-            return 0.0, tight
+        if len(nb) <= max(2, self.mesh_max):
+            return 1e-9 * (len(nb) > 2), tight
         us = list(s)
         ex = {}
         for a in range(len(us)):
@@ -304,7 +305,28 @@ class RelativeEliminationSolver:
                     unary[v] = [blk]
                 for u in nb:
                     del adj[u][v]
-                if nb:
+                if nb and 2 < len(nb) <= self.mesh_max:
+                    # STAR-MESH transform (Kron reduction): the marginal of a star with leg variances v_k is EXACTLY (commuting case) the
+                    # full mesh whose edge (j, k) has the composed mean and the variance v_j + v_k + v_j v_k sum_{i != j,k} 1 / v_i --
+                    # the composition's own spread, inflated by what the pair shares with the other legs
+                    us = list(nb)
+                    seen = {u: nb[u].seen_from(v) for u in us}
+                    it_all = sum(1.0 / seen[u][1] for u in us); ith_all = sum(1.0 / seen[u][2] for u in us)
+                    for ai in range(len(us)):
+                        for bi in range(ai + 1, len(us)):
+                            j, k = us[ai], us[bi]
+                            zj, vtj, vthj = seen[j]; zk, vtk, vthk = seen[k]
+                            zi = _inv(zj); vti = vtj + (zj[0] * zj[0] + zj[1] * zj[1]) * vthj
+                            vt0 = vti + vtk + (zk[0] * zk[0] + zk[1] * zk[1]) * vthj
+                            vth0 = vthj + vthk
+                            gt = 1.0 + vtj * vtk * (it_all - 1.0 / vtj - 1.0 / vtk) / (vtj + vtk)
+                            gth = 1.0 + vthj * vthk * (ith_all - 1.0 / vthj - 1.0 / vthk) / (vthj + vthk)
+                            blk = new_block("c")
+                            e = _Edge(j, k, blk, _comp(zi, zk), vt0 * gt, vth0 * gth)
+                            comps.append((nb[j].block, nb[k].block, blk, nb[j].a == v, nb[k].a != v, math.sqrt(gt), math.sqrt(gth)))
+                            adj[j].setdefault(k, []).append(e); adj[k].setdefault(j, []).append(e)
+                            n_comp += 1
+                elif nb:
                     # tightest neighbour: smallest log det of the covariance of v^-1 u
                     c = lc[v][1]
                     zi, vti, vthi = nb[c].seen_from(c)             # c^-1 v

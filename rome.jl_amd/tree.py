@@ -749,8 +749,11 @@ class BlockOpPlan:
         from .clique import DeviceStore
         self.store, self.ctx, self._lib = store, store.ctx, _lib.load()
         U = store.fg
-        if op == "compose":      # entries (a, b, destination, invert a, invert b)
+        prm = None
+        if op == "compose":      # entries (a, b, destination, invert a, invert b[, translation inflation, heading inflation])
             flags = [(0x100 if e[3] else 0) | (0x200 if e[4] else 0) for e in entries]
+            if any(len(e) > 5 for e in entries):
+                prm = np.ascontiguousarray([[e[5], e[6]] if len(e) > 5 else [1.0, 1.0] for e in entries], dtype=np.float64)
             entries = [e[:3] for e in entries]
         elif op == "mix":        # entries (pool, destination, p)
             flags = [int(e[2]) << 8 for e in entries]
@@ -764,8 +767,9 @@ class BlockOpPlan:
         self.dst_labels = [e[-1] for e in entries]
         PI = C.POINTER(C.c_int32)
         h = C.c_void_p()
-        _lib.check(self._lib.rome_blockop_plan_create(self.ctx.handle, store.handle, self.OPS[op], len(entries), ty.ctypes.data_as(PI), a.ctypes.data_as(PI),
-                                                      b.ctypes.data_as(PI) if b is not None else None, d.ctypes.data_as(PI), C.byref(h)), self.ctx.handle)
+        _lib.check(self._lib.rome_blockop_plan_create_ex(self.ctx.handle, store.handle, self.OPS[op], len(entries), ty.ctypes.data_as(PI), a.ctypes.data_as(PI),
+                                                         b.ctypes.data_as(PI) if b is not None else None, d.ctypes.data_as(PI),
+                                                         prm.ctypes.data_as(C.POINTER(C.c_double)) if prm is not None else None, C.byref(h)), self.ctx.handle)
         self.handle = h
 
     def run(self):

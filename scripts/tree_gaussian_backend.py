@@ -144,7 +144,11 @@ class GBlockOp:
                 Ed = D - dm
                 Cc = (Ed * W[:, None]).T @ Ed
                 out = y0 + dm; out[2] = wrap(out[2])
-                v[e[2]] = (out, 0.5 * (Cc + Cc.T) + 1e-15 * np.eye(3))
+                Cc = 0.5 * (Cc + Cc.T)
+                if len(e) > 5:      # star-mesh inflation of the composed spread (translation, heading)
+                    g = np.diag([e[5], e[5], e[6]])
+                    Cc = g @ Cc @ g
+                v[e[2]] = (out, Cc + 1e-15 * np.eye(3))
             else:
                 ref = v[e[0]][0]
                 m, S = v[e[1]]

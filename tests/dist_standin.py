@@ -240,7 +240,13 @@ class OracleTreeBlockOp:
                 A, B = (inv(v[e[0]]) if e[3] else v[e[0]]), (inv(v[e[1]]) if e[4] else v[e[1]])
                 c, s = np.cos(A[2]), np.sin(A[2])
                 t = A[2] + B[2]
-                v[e[2]] = np.stack([A[0] + c * B[0] - s * B[1], A[1] + s * B[0] + c * B[1], np.arctan2(np.sin(t), np.cos(t))])
+                D = np.stack([A[0] + c * B[0] - s * B[1], A[1] + s * B[0] + c * B[1], np.arctan2(np.sin(t), np.cos(t))])
+                if len(e) > 5 and (e[5] != 1.0 or e[6] != 1.0):     # star-mesh inflation of the deviations about the mean
+                    mx, my, mt = D[0].mean(), D[1].mean(), np.arctan2(np.sin(D[2]).sum(), np.cos(D[2]).sum())
+                    dt = np.arctan2(np.sin(D[2] - mt), np.cos(D[2] - mt))
+                    th = mt + e[6] * dt
+                    D = np.stack([mx + e[5] * (D[0] - mx), my + e[5] * (D[1] - my), np.arctan2(np.sin(th), np.cos(th))])
+                v[e[2]] = D
             else:
                 ref, s = v[e[0]][:, 0], v[e[1]]
                 c, sn = np.cos(ref[2]), np.sin(ref[2])

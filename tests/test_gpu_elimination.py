@@ -33,11 +33,16 @@ def test_compose_and_mix_block_operations_match_their_numpy_restatement():
     dev, orc = DeviceStore(fg), OracleTreeStore(R, fg)
     orc.upload(fg)
     steps = [("compose", [("x0", "x1", "x2", False, False), ("x0", "x1", "x3", True, False), ("x0", "x1", "x4", True, True)]),
-             ("compose", [("x2", "x3", "x5", False, True)]), ("mix", [("x0", "x1", 3)])]
+             ("compose", [("x2", "x3", "x5", False, True, 1.3, 0.8)]), ("mix", [("x0", "x1", 3)])]
     for op, ent in steps:
         BlockOpPlan(dev, op, ent).run(); OracleTreeBlockOp(orc, op, ent).run()
     for l in fg.variables:
         assert np.abs(_wd(dev.get(l), orc.vals[l])).max() < 1e-12, l
+    x5 = dev.get("x5")       # inflated composition: same mean, deviations x 1.3 (translation) / x 0.8 (heading)
+    plain = OracleTreeStore(R, fg); plain.vals = dict(orc.vals)
+    OracleTreeBlockOp(plain, "compose", [("x2", "x3", "x5", False, True)]).run()
+    p5 = plain.vals["x5"]
+    assert np.allclose(x5[:2].mean(1), p5[:2].mean(1), atol=1e-12) and np.allclose(x5[:2].std(1), 1.3 * p5[:2].std(1), rtol=1e-9)
     a, b = fg.getVal("x0"), fg.getVal("x1")
     x3 = dev.get("x3")       # a^-1 (+) b: composing a back on gives b
     c, s = np.cos(a[2]), np.sin(a[2])

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "librome_mi355.so does not export %s" % name
     assert declared == set(R._lib.SIGNATURES), declared ^ set(R._lib.SIGNATURES)
-    assert lib.rome_version() == 121
+    assert lib.rome_version() == 122
 
 
 def test_struct_layouts_match_header():
