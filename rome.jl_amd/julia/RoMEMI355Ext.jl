@@ -503,7 +503,22 @@ mutable struct RomeBlockOpPlan
   h::Ptr{Cvoid}
   store::RomeStore
 end
-const _BLOCKOPS = Dict(:copy => Int32(0), :anchor => Int32(1), :relative => Int32(2))
+# :compose (round 6: dst_i = A'_i (+) B'_i on Pose2 blocks of relative-pose samples; types[k] |= 0x100 / 0x200 takes A^-1 / B^-1 -- the pair
+# marginal c^-1 k = (v^-1 c)^-1 (+) (v^-1 k) of an eliminated pose's neighbours; `inflate` (n x 2: translation, heading) scales the composed
+# deviations about their mean: star-mesh transform) and :mix (pooling of independent passes: types[k] |= p << 8).  Python twin of the
+# elimination driver: rome_jl_amd.elimination.RelativeEliminationSolver.
+const _BLOCKOPS = Dict(:copy => Int32(0), :anchor => Int32(1), :relative => Int32(2), :compose => Int32(3), :mix => Int32(4))
+function RomeBlockOpPlan(st::RomeStore, op::Symbol, types::AbstractVector{<:Integer}, a::AbstractVector{<:Integer}, b::AbstractVector{<:Integer},
+                         dst::AbstractVector{<:Integer}, inflate::AbstractMatrix{Float64})
+  ty = Int32.(types); va = Int32.(a); vb = Int32.(b); vd = Int32.(dst)
+  pr = collect(transpose(inflate))       # (n, 2) row-major for the C side
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve ty va vb vd pr check(ccall((:rome_blockop_plan_create_ex, LIB), Cint,
+      (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+      ctx().h, st.h, _BLOCKOPS[op], length(ty), _p(ty), _p(va), _p(vb), _p(vd), pointer(pr), r))
+  bp = RomeBlockOpPlan(r[], st)
+  finalizer(x -> ccall((:rome_blockop_plan_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), bp)
+end
 function RomeBlockOpPlan(st::RomeStore, op::Symbol, types::AbstractVector{<:Integer}, a::AbstractVector{<:Integer}, b::AbstractVector{<:Integer},
                          dst::AbstractVector{<:Integer})
   ty = Int32.(types); va = Int32.(a); vb = Int32.(b); vd = Int32.(dst)
