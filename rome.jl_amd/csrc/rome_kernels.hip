@@ -567,38 +567,77 @@ struct P3P3 {
     return m <= tol ? 0 : 1;
   }
   // Gauss-Newton on the functor (the oracle's p3p3_newton_pt): right-perturbation updates on the group that zero the residual,
-  //   dir 0: R_q ← R_q Exp(r_ω), q.t += r_t;   dir 1: R_p ← R_p Exp(−Z r_ω), p.t ← q.t − R_p z_t
-  // The ITERATE lives as (translation, unit quaternion): every residual evaluation builds the target's 3x3 frame from it and calls the
-  // functor on frames, the update is a quaternion product -- 16 doubles of iterate state less than carrying R, Exp(·) and R·Exp(·) as
-  // matrices across the loop (228 -> ~150 VGPRs for the packed sweep: three waves per SIMD instead of two), and no Log/Exp round trip
-  // at the end.
+  //   dir 0: R_q <- R_q Exp(r_w), q.t += r_t;   dir 1: R_p <- R_p Exp(-Z r_w), p.t <- q.t - R_p z_t
+  // Round 6: the residual is evaluated ON UNIT QUATERNIONS -- r_w = Log(conj(q_q) (x) q_p (x) q_z), the same rotation as the functor's
+  // Log(R_q^T R_p Exp(z_w)) (src/factors/Pose3Pose3.jl:17-29; the 3x3 form stays in `functor` / `verify` and the residual entry points),
+  // r_t = p.t + R(q_p) z_t - q.t -- and the update is applied with the residual ROTATION e itself instead of Exp(Log(e)):
+  //   dir 0: q_q <- q_q (x) e;   dir 1: Exp(-Z r_w) = q_z (x) conj(e) (x) conj(q_z), so q_p <- (q_p (x) q_z) (x) conj(e) (x) conj(q_z)
+  // (the P2P2 iteration carries (cos, sin) the same way).  What an iterate costs: two or three quaternion products and one Log -- whose
+  // inverse-trigonometric branch is skipped when every lane of the wave is at |vec e| < 1e-8 (Log e = 2 vec e / e_w to 1e-24: the
+  // verification iterate) -- instead of a 3x3 frame from the quaternion, two 3x3 products, the matrix Log and an Exp per iterate
+  // (the packed sweep on the 10k helix: 154.5 -> 102 us with this alone; profiles/r06_p3p3_gn.md).
+  __device__ static __forceinline__ void quat_log_iter(const double (&q)[4], double* w) {
+    const double n2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (__builtin_amdgcn_ballot_w64(n2 > 1e-16) == 0) {   // wave-uniform: every active lane is at the root already
+      const double k = 2.0 * fast_rcp(q[0]);
+      w[0] = k * q[1]; w[1] = k * q[2]; w[2] = k * q[3];
+      return;
+    }
+    quat_log(q, w);
+  }
   __device__ static __forceinline__ int gauss_newton(const Consts& K, const double (&z)[6], const double (&fxc)[6], double (&t)[6], Aux& A, int max_iters, double tol) {
-    Se3 F; double Z[9];
-    se3_from_coords(fxc, F); so3_exp(&z[3], Z);
+    const bool back = K.dir == 1;
+    double qz[4], qF[4] = {1.0, 0.0, 0.0, 0.0}, Ft[3] = {0.0, 0.0, 0.0};
+    quat_exp(&z[3], qz);
+    if (K.dir != kDirPrior) { quat_exp(&fxc[3], qF); Ft[0] = fxc[0]; Ft[1] = fxc[1]; Ft[2] = fxc[2]; }   // (prior row: the identity pose)
+    // dir 0 / prior: the predicted pose (qh, th) = F o exp(z) does not depend on the iterate
+    double qh[4] = {1.0, 0.0, 0.0, 0.0}, th[3] = {0.0, 0.0, 0.0};
+    if (!back) {
+      double v[3];
+      quat_mul(qF, qz, qh); quat_rot(qF, z, v);
+      th[0] = Ft[0] + v[0]; th[1] = Ft[1] + v[1]; th[2] = Ft[2] + v[2];
+    }
     int st = 1;
     for (int it = 0; it < max_iters; ++it) {
-      Se3 T; double r[6];
-      T.t[0] = t[0]; T.t[1] = t[1]; T.t[2] = t[2]; quat_to_mat(A.q, T.R);
-      functor(K, z, Z, F, T, r);
-      double m = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) m = fmax(m, fabs(r[k]));
-      if (m <= tol) { st = 0; break; }
-      double qe[4], qn[4];
-      if (K.dir == 0) {
-        quat_exp(r + 3, qe); quat_mul(A.q, qe, qn);
-        t[0] += r[0]; t[1] += r[1]; t[2] += r[2];
+      double g[4], e[4], r[6];
+      if (back) {
+        double v[3];
+        quat_mul(A.q, qz, g); quat_cmul(qF, g, e); quat_rot(A.q, z, v);
+        r[0] = t[0] + v[0] - Ft[0]; r[1] = t[1] + v[1] - Ft[1]; r[2] = t[2] + v[2] - Ft[2];
       } else {
-        double d[3], v[3];
-        mat3_vec(Z, r + 3, d); d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2];
-        quat_exp(d, qe); quat_mul(A.q, qe, qn);
-        quat_rot(qn, z, v);
-        t[0] = F.t[0] - v[0]; t[1] = F.t[1] - v[1]; t[2] = F.t[2] - v[2];
+        quat_cmul(A.q, qh, e);
+        r[0] = th[0] - t[0]; r[1] = th[1] - t[1]; r[2] = th[2] - t[2];
       }
-      // (renormalised: a product of unit quaternions drifts by an ulp per step; |q|² = 1 + ε, 1/|q| = 3/2 − |q|²/2 to O(ε²))
-      const double nn = __builtin_fma(-0.5, qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3], 1.5);
+      // The coordinates Log(e) are needed only where the test max|r| <= tol can pass: |r_w|_inf >= theta / sqrt 3 >= 2 |vec e| / sqrt 3, so
+      // a lane with 4 |vec e|^2 > 3 tol^2 (or a translation residual above tol) is NOT converged whatever its Log is -- the same
+      // decision without the inverse-trigonometric evaluation.  Wave-uniform: the start iterate skips the Log, the verification
+      // iterate takes its small-angle branch (quat_log_iter); the full Log runs only for a wave with a lane in between.
+      const double mt = fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2])));
+      const double n2e = e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
+      const bool undecided = !(mt > tol) && !(4.0 * n2e > 3.0 * tol * tol);
+      if (__builtin_amdgcn_ballot_w64(undecided) != 0) {
+        quat_log_iter(e, r + 3);
+        if (fmax(mt, fmax(fabs(r[3]), fmax(fabs(r[4]), fabs(r[5])))) <= tol) { st = 0; break; }
+      }
+      double qn[4];
+      if (back) {
+        double h[4], v[3];
+        quat_mulc(g, e, h); quat_mulc(h, qz, qn);
+        const double nb = __builtin_fma(-0.5, qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3], 1.5);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) A.q[k] = qn[k] * nn;
+        for (int k = 0; k < 4; ++k) qn[k] *= nb;
+        quat_rot(qn, z, v);
+        t[0] = Ft[0] - v[0]; t[1] = Ft[1] - v[1]; t[2] = Ft[2] - v[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) A.q[k] = qn[k];
+      } else {
+        quat_mul(A.q, e, qn);
+        t[0] += r[0]; t[1] += r[1]; t[2] += r[2];
+        // (renormalised: a product of unit quaternions drifts by an ulp per step; |q|^2 = 1 + eps, 1/|q| = 3/2 - |q|^2/2 to O(eps^2))
+        const double nn = __builtin_fma(-0.5, qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3], 1.5);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) A.q[k] = qn[k] * nn;
+      }
     }
     return st;
   }
@@ -950,14 +989,16 @@ __device__ __forceinline__ void conv_flat_body(const ConvArgs& a, int H, int CPB
 #define ROME_FLAT_GN_MINWAVES 4   // the functor-iterating packed sweep (Pose2 / Point2): <= 128 VGPRs
 #endif
 #ifndef ROME_FLAT_GN6_MINWAVES
-#define ROME_FLAT_GN6_MINWAVES 2   // SE(3) functor iteration: <= 256 VGPRs asked for; the sched barrier between a thread's two particles does the rest.
-                                   // (round 5 experiment, profiles/r05_p3p3_gn_one_particle.txt: ONE particle per thread -- each thread evaluating the pair's
-                                   //  Philox calls and keeping its half -- needs 168 VGPRs without spills (3 waves per SIMD): 165.5 us against this kernel's
-                                   //  155.8 us on the 10k helix; forced to 128 VGPRs it spills 164 B per lane: 301.7 us.  The pair per thread stays.)
+#define ROME_FLAT_GN6_MINWAVES 3   // SE(3) functor iteration on unit quaternions (round 6): asked to fit 168 VGPRs (three waves per SIMD, 7 spilled registers)
+                                   // 85.4 us on the 10k helix against 88.4 us at 188 VGPRs / two waves; the sched barrier between a thread's two particles stays.
+                                   // (round 5, 3x3 frames, profiles/r05_p3p3_gn_one_particle.txt: ONE particle per thread measured slower, 165.5 against 155.8 us.)
+#endif
+#ifndef ROME_FLAT_CF6_MINWAVES
+#define ROME_FLAT_CF6_MINWAVES 1   // SE(3) closed form: 132 VGPRs (three waves per SIMD) 48.5 us on the 10k helix; pinned to 128 (four waves, 20 B of scratch) 49.7 us
 #endif
 template <class FP, int SOLVER, bool VERIFY, bool VEC2, int PP>
 __global__ void __launch_bounds__(kFlatThreads, FP::DT <= 3 ? ((SOLVER == kSolverClosedForm && !VERIFY) ? (PP == 1 ? ROME_FLAT_MINWAVES : 5) : ROME_FLAT_GN_MINWAVES)
-                                                            : (SOLVER == kSolverGaussNewton ? ROME_FLAT_GN6_MINWAVES : 1))
+                                                            : (SOLVER == kSolverGaussNewton ? ROME_FLAT_GN6_MINWAVES : (VERIFY ? 1 : ROME_FLAT_CF6_MINWAVES)))
 k_conv_flat(const ConvArgs a, int H, int CPB, uint32_t magic) {
   __shared__ double s_K[kFlatMaxRows * (FlatStage<FP>::kLanes + 2)];
   conv_flat_body<FP, SOLVER, VERIFY, VEC2, PP>(a, H, CPB, magic, xcd_contiguous_block(blockIdx.x, gridDim.x), s_K);

@@ -90,6 +90,15 @@ def test_helix3d_pose3pose3_sweep_vs_oracle_and_roundtrip():
     a = prop.cpu().numpy(); b = prop0.cpu().numpy()
     ang = (rv(a).inv() * rv(b)).magnitude(); theta = rv(b).magnitude()
     assert np.abs(a[:, :3] - b[:, :3]).max() < 1e-9 and ang[theta < 3.0].max() < 1e-9 and ang.max() < 1e-6
+    # ... and the functor ITERATION from the belief points (GAUSS_NEWTON: the packed sweep k_conv_flat<P3P3, 3>, residual on unit
+    # quaternions) reaches the same roots on the whole table, every root-find converged
+    st3 = torch.ones((tb["C"], N), dtype=torch.int32, device="cuda")
+    prop3 = dg.sweep_pose3pose3(R.make_opts(N=N, solver=3, seed=8), status=st3)
+    torch.cuda.synchronize()
+    assert int(st3.sum()) == 0
+    c = prop3.cpu().numpy()
+    ang = (rv(c).inv() * rv(b)).magnitude()
+    assert np.abs(c[:, :3] - b[:, :3]).max() < 1e-9 and ang[theta < 3.0].max() < 1e-9 and ang.max() < 1e-6
     # belief statistics of Pose3 beliefs vs oracle on a few variables
     mean, sd = dg.belief_stats(R.Pose3)
     for v in (0, 17, 4242, P - 1):
