@@ -450,11 +450,21 @@ struct GibbsConst { double ref[D], h[D], q0[4]; float lvar[D], livar[D]; int row
 
 // CM: the circular mask at compile time (-1: read from the arguments) -- with a run-time mask the compiler evaluates the wrap of
 // EVERY coordinate and selects (24 of the 54 instructions of a Pose2 candidate pair)
+#ifdef ROME_GIBBS_TRACE   // experiment build (scripts/gibbs_phase_trace.py): where a lone block spends its time, phase by phase (block 0, thread 0; 10 ns ticks)
+__device__ uint64_t g_gibbs_trace[16];
+#define GTRACE(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const uint64_t now_ = wall_clock64(); g_gibbs_trace[slot] += now_ - tr_last; tr_last = now_; } } while (0)
+#else
+#define GTRACE(slot) do { } while (0)
+#endif
 template <int D, int CM, int NM>
 __global__ void __launch_bounds__(NM) k_product_gibbs(const GibbsArgs a) {
 #pragma clang fp contract(off)   // the candidate arithmetic below is a bit-exact specification
   constexpr int kGibbsThreads = NM;   // lane = output sample
   extern __shared__ __align__(16) unsigned char smem[];
+#ifdef ROME_GIBBS_TRACE
+  uint64_t tr_last = wall_clock64();
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (int q = 0; q < 16; ++q) g_gibbs_trace[q] = 0;
+#endif
   if ((int)blockIdx.x >= a.V) return;
   const int v = a.order[blockIdx.x];
   const int tid = threadIdx.x;
@@ -468,8 +478,10 @@ __global__ void __launch_bounds__(NM) k_product_gibbs(const GibbsArgs a) {
   // Arguments of the public entry that would index out of bounds -- more proposals than the caller's max_proposals sized the LDS
   // for, or a proposal row outside the tree workspace -- fail LOUDLY: the variable's belief becomes NaN (block-uniform test, no
   // out-of-bounds access); nothing is silently truncated.
+  GTRACE(0);   // arguments
   bool bad = K < 0 || K > a.max_k;
   for (int j = 0; j < K && !bad; ++j) { const int r = a.prop_rows[k0 + j]; bad = r < 0 || r >= a.n_rows; }
+  GTRACE(1);   // row check
   if (bad) {
     for (int q = tid; q < D * N; q += kGibbsThreads) { ob[q] = __builtin_nan(""); if (mo) mo[q] = __builtin_nan(""); }
     return;
@@ -560,8 +572,10 @@ __global__ void __launch_bounds__(NM) k_product_gibbs(const GibbsArgs a) {
     const double r = (qn & 1u) ? npair1 : npair0; ++qn;
     return r;
   };
+  GTRACE(2);   // logn table, constants of the trees
   for (int j = 0; j < K; ++j) selbuf[j * NM + tid] = 0;
   stage(0);
+  GTRACE(3);   // labels, level 0
   double x[D];
   [[maybe_unused]] double xq[4] = {1.0, 0.0, 0.0, 0.0};   // D = 6: rotation of the current point
   constexpr int DE = D == 6 ? 3 : D;                      // coordinates handled one by one (Euclidean / circular)
@@ -618,8 +632,10 @@ __global__ void __launch_bounds__(NM) k_product_gibbs(const GibbsArgs a) {
       for (int k = 0; k < 3; ++k) { const double xi = normal(); e[k] = num[k] * fast_rcp(prec[k]) + xi * fast_rsqrt(prec[k]); }
       quat_exp(e, E); quat_mul(B, E, xq);
     }
+    GTRACE(4);   // (a) the point of level l - 1
     if (l == L + 1) break;
     stage(l);
+    GTRACE(5);   // staging level l
     const int nz = 1 << l;
     // (c) labels of level l given the point, which is expressed ONCE in the density's own chart (Euclidean there) and rounded
     for (int j = 0; j < K; ++j) {
@@ -673,6 +689,7 @@ __global__ void __launch_bounds__(NM) k_product_gibbs(const GibbsArgs a) {
       }
       selbuf[j * NM + tid] = (uint8_t)R.sel;
     }
+    GTRACE(6);   // (c) labels given the point
     // (d) Gibbs sweeps over the labels
     for (int it = 0; it < a.iters; ++it)
       for (int j = 0; j < K; ++j) {
@@ -768,6 +785,7 @@ __global__ void __launch_bounds__(NM) k_product_gibbs(const GibbsArgs a) {
         }
         selbuf[j * NM + tid] = (uint8_t)R.sel;
       }
+    GTRACE(7);   // (d) Gibbs sweep
   }
   if constexpr (D == 6) quat_log(xq, x + 3);
   if (live) {
@@ -780,6 +798,13 @@ __global__ void __launch_bounds__(NM) k_product_gibbs(const GibbsArgs a) {
   }
 }
 
+#ifdef ROME_GIBBS_TRACE
+}  // namespace rome
+extern "C" int rome_debug_gibbs_trace(unsigned long long* out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(rome::g_gibbs_trace), sizeof(unsigned long long) * 16);
+}
+namespace rome {
+#endif
 static size_t tree_bytes(int dim, int n_rows, int N) {
   const size_t one = N <= 128 ? (dim == 2 ? sizeof(GibbsTree<2, 128>) : (dim == 3 ? sizeof(GibbsTree<3, 128>) : sizeof(GibbsTree<6, 128>)))
                               : (dim == 2 ? sizeof(GibbsTree<2, 256>) : (dim == 3 ? sizeof(GibbsTree<3, 256>) : sizeof(GibbsTree<6, 256>)));
