@@ -346,7 +346,27 @@ __device__ __forceinline__ f32x2 exp32_neg(f32x2 x) {
   const i32x2 bits = (i32x2)y + (ki << 23);
   return (f32x2)bits;
 }
-__device__ __forceinline__ float exp32_neg(float x) { return exp32_neg(f32x2{x, x}).x; }
+// the same function on ONE value in plain (unpacked) instructions: a packed operation issues at half the rate of a plain one on gfx950
+// (profiles/r02_ubench_f32_issue.txt), so the rescale of the running total -- one value per lane -- through the packed form paid for a
+// second, discarded element (round 6; the same IEEE operations in the same order: the same bits)
+__device__ __forceinline__ float exp32_neg(float x) {
+#pragma clang fp contract(off)
+#if ROME_GIBBS_HWTRANS
+  return __builtin_amdgcn_exp2f(fmaxf(x, -80.0f) * 1.44269504f);
+#endif
+  const float xc = fmaxf(x, -80.0f);
+  const float k = __builtin_rintf(xc * 1.44269504f);
+  float r = __builtin_fmaf(k, -0.693359375f, xc);
+  r = __builtin_fmaf(k, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  const float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+  return __int_as_float(__float_as_int(y) + ((int)k << 23));
+}
 // ln(v), v > 0 normal: v = m 2^e, ln m the degree-7 polynomial in m - 1.5 of the Box-Muller radius (rome_device_math.hpp)
 __device__ __forceinline__ f32x2 ln32_pos(f32x2 v) {
 #pragma clang fp contract(off)
