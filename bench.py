@@ -774,8 +774,9 @@ def main():
                 "linearize_s": stt["linearize_s"], "host_solve_s": stt["host_solve_s"],
                 "linearize_split_ms": {k: sh_.get(k) for k in ("upload_ms", "kernel_ms", "exchange_ms", "download_ms")},
                 "host_fraction": stt["host_solve_s"] / max(t_h, 1e-9),
-                "note": "linearize_s includes the host-side gather X[ia], the upload of the gathered coordinates, the kernels, the download and the sparse assembly; "
-                        "kernel_ms is the synchronised launch time of the k_lin kernels alone (profiles/r05_linearize_trace.md has their rocprof rows)"}
+                "note": "linearize_s includes the host-side gather X[ia], the upload of the gathered coordinates, the kernels, the download and the sparse assembly "
+                        "(values permuted into the CSR structure computed once per problem); kernel_ms is the synchronised launch time of the k_lin kernels alone "
+                        "(profiles/r06_linearize_trace.md has their rocprof rows)"}
         except Exception as e:   # noqa: BLE001
             out["parametric_helix10k"] = {"error": repr(e)}
 

@@ -551,33 +551,20 @@ class LinearizeShard:
         self.cache = {}
         self.stats = dict(calls=0, upload_ms=0.0, kernel_ms=0.0, exchange_ms=0.0, download_ms=0.0)
 
-    # ---- round 6: X stays on the device for the whole linearisation (ONE upload of the n coordinates through a pinned buffer instead of
-    # the gathered (F, da) + (F, db) rows of every factor kind), the gather X[ia] / X[ib] runs on the device from index tensors uploaded
-    # once per problem, and the result blocks come down through a pinned buffer (a pageable 7.5 MB download ran at 0.75 GB/s:
-    # 10.3 ms of the 2.8 ms the kernels take, bench.py parametric_helix10k round 5)
+    # ---- round 6.  Measured on the box (scripts/pin_cost.py, bench.py parametric_helix10k): a 480 kB upload takes 0.05 ms and a 7.5 MB
+    # download 0.15 ms once the host pages exist (pinned or pageable alike; the FIRST touch of a fresh 7.5 MB host buffer costs 8.6 ms),
+    # so the transfers were never what linearize_s was made of -- the host's COO -> CSR assembly was (parametric._Problem.csr_perm).
+    # A device-side gather X[ia] through torch.index_select (tried first) pays ~80 ms for the lazy load of that operator's code object
+    # in a fresh process: the gather of the few thousand rows stays a host numpy take, the result blocks come down into ONE reused buffer.
     def begin(self, X):
-        """the coordinates of this linearisation -> device (called once per linearisation by parametric._Problem.linearize)"""
-        if not self.on_device:
-            self._X = X
-            return
-        import time
-        torch = self.torch
-        t0 = time.perf_counter()
-        n = len(X)
-        if getattr(self, "_xpin", None) is None or self._xpin.numel() != n:
-            self._xpin = torch.empty(n, dtype=torch.float64).pin_memory()
-            self._xdev = torch.empty(n, dtype=torch.float64, device=self.device)
-        self._xpin.numpy()[:] = X
-        self._xdev.copy_(self._xpin, non_blocking=True)
-        self.stats["upload_ms"] += 1e3 * (time.perf_counter() - t0)
+        """the coordinates of this linearisation (called once per linearisation by parametric._Problem.linearize)"""
+        self._X = X
 
     def linearize_indexed(self, kind, mu, W, X, ia, ib, ctx=None):
         """as linearize(), the coordinates given as index arrays into the X of begin()"""
-        if not self.on_device:
-            return self.linearize(kind, mu, W, X[ia], None if ib is None else X[ib], ctx)
-        return self._linearize_dev(kind, mu, W, None, None, ctx, ia=ia, ib=ib)
+        return self.linearize(kind, mu, W, X[ia], None if ib is None else X[ib], ctx)
 
-    def _linearize_dev(self, kind, mu, W, xa, xb, ctx, ia=None, ib=None):
+    def _linearize_dev(self, kind, mu, W, xa, xb, ctx):
         import ctypes as C
         import time
         from . import _lib, api
@@ -596,8 +583,7 @@ class LinearizeShard:
         # with the same kind and row count replaces it -- one entry per kind, so repeated / incremental solves do not accumulate tensors.
         if ent is None or ent["mu_host"] is not mu or ent["W_host"] is not W or ent["F"] != F:
             t = lambda a: torch.as_tensor(np.ascontiguousarray(a[lo:hi], dtype=np.float64), device=self.device)   # noqa: E731
-            ti = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a[lo:hi], dtype=np.int64), device=self.device)   # noqa: E731
-            self.cache[key] = dict(mu_host=mu, W_host=W, F=F, ia=ti(ia), ib=ti(ib) if db else None, pin=None, mu=t(np.asarray(mu).reshape(F, dz)), W=t(np.asarray(W).reshape(F, dr * dr)),
+            self.cache[key] = dict(mu_host=mu, W_host=W, F=F, pin=None, mu=t(np.asarray(mu).reshape(F, dz)), W=t(np.asarray(W).reshape(F, dr * dr)),
                                    recv=torch.zeros(self.world * q * per, dtype=torch.float64, device=self.device),
                                    xa=torch.empty((max(n, 1), da), dtype=torch.float64, device=self.device),
                                    xb=torch.empty((max(n, 1), max(db, 1)), dtype=torch.float64, device=self.device))
@@ -606,14 +592,7 @@ class LinearizeShard:
         ctx.set_stream(st.cuda_stream)
         tick = time.perf_counter
         t0 = tick()
-        if n and ia is not None:      # gather on the device from the resident X
-            if c["ia"] is None:
-                c["ia"] = torch.as_tensor(np.ascontiguousarray(ia[lo:hi], dtype=np.int64), device=self.device)
-                c["ib"] = torch.as_tensor(np.ascontiguousarray(ib[lo:hi], dtype=np.int64), device=self.device) if db else None
-            torch.index_select(self._xdev, 0, c["ia"].reshape(-1), out=c["xa"][:n].view(-1))
-            if db:
-                torch.index_select(self._xdev, 0, c["ib"].reshape(-1), out=c["xb"][:n].view(-1))
-        elif n:
+        if n:
             c["xa"][:n].copy_(torch.as_tensor(np.ascontiguousarray(xa[lo:hi], dtype=np.float64)), non_blocking=False)
             if db:
                 c["xb"][:n].copy_(torch.as_tensor(np.ascontiguousarray(xb[lo:hi], dtype=np.float64)), non_blocking=False)

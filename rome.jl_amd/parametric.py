@@ -191,6 +191,17 @@ class _Problem:
         self.perm = self._fill_reducing_order(groups)          # elimination order of the scalar unknowns
         self.pos = np.empty(self.n, dtype=np.int64); self.pos[self.perm] = np.arange(self.n)
         self.cols_p = self.pos[self.cols]                      # J is assembled directly in that order
+        # The sparsity pattern of J is fixed over the iterations: its CSR structure (row pointers, sorted column indices) and the
+        # position of every CSR slot in the concatenated value blocks are computed ONCE; a linearisation then only permutes values
+        # (scipy's COO -> CSR conversion of the 8.7e5 entries of the 10k helix cost ~5 ms per linearisation: most of linearize_s).
+        import scipy.sparse as sp
+        nnz = len(self.rows)
+        S = sp.csr_matrix((np.arange(1, nnz + 1, dtype=np.float64), (self.rows, self.cols_p)), shape=(self.m, self.n))
+        S.sort_indices()
+        if S.nnz != nnz:
+            raise AssertionError("duplicate (row, column) entries in the Jacobian pattern")
+        self.csr_perm = (S.data - 1.0).astype(np.int64)
+        self.csr_indices, self.csr_indptr = S.indices.copy(), S.indptr.copy()
         # retraction index sets
         self.pose2_th = np.array([self.off[i] + 2 for i, t in enumerate(self.vt) if t is Pose2], dtype=np.int64)
         self.pose3_w = np.array([self.off[i] + 3 for i, t in enumerate(self.vt) if t is Pose3], dtype=np.int64)
@@ -261,7 +272,8 @@ class _Problem:
             vals.append(Ja.ravel())
             if Jb is not None:
                 vals.append(Jb.ravel())
-        J = sp.csr_matrix((np.concatenate(vals), (self.rows, self.cols_p)), shape=(self.m, self.n))   # columns in elimination order
+        J = sp.csr_matrix((np.concatenate(vals)[self.csr_perm], self.csr_indices, self.csr_indptr), shape=(self.m, self.n))   # columns in elimination order
+        J.has_sorted_indices = True
         return r, J
 
 
