@@ -116,7 +116,8 @@ def _pose2_two_stage_init(fg, x):
         rows = np.r_[rows, F + r_]; cols = np.r_[cols, idx[ls[0]]]; vals = np.r_[vals, wp]
         rhs.append(wp * (f.Z.mu[2] + 2 * np.pi * np.round((th0[idx[ls[0]]] - f.Z.mu[2]) / (2 * np.pi))))
     A = sp.csr_matrix((vals, (rows, cols)), shape=(F + len(pri), n))
-    th = spsolve((A.T @ A).tocsc(), A.T @ np.array(rhs))
+    with _blas_single_thread():
+        th = spsolve((A.T @ A).tocsc(), A.T @ np.array(rhs))
     # ---- translations with R(θ_i) fixed: t_j − t_i = R(θ_i) z_t, whitened with the translation block of the information
     c, s_ = np.cos(th[i]), np.sin(th[i])
     d = np.stack([c * mu[:, 0] - s_ * mu[:, 1], s_ * mu[:, 0] + c * mu[:, 1]], 1)
@@ -136,8 +137,33 @@ def _pose2_two_stage_init(fg, x):
                 rows.append(np.array([m + a_])); cols.append(np.array([2 * idx[ls[0]] + b_])); vals.append(np.array([Wp[a_, b_]]))
         rhs += list(Wp @ f.Z.mu[:2]); m += 2
     B = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(m, 2 * n))
-    t = spsolve((B.T @ B).tocsc(), B.T @ np.array(rhs)).reshape(n, 2)
+    with _blas_single_thread():
+        t = spsolve((B.T @ B).tocsc(), B.T @ np.array(rhs)).reshape(n, 2)
     return {l: np.array([t[k_, 0], t[k_, 1], np.arctan2(np.sin(th[k_]), np.cos(th[k_]))]) for k_, l in enumerate(labels)}
+
+
+class _NoLimit:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_BLAS_CONTROLLER = []
+
+
+def _blas_single_thread():
+    """context manager: the BLAS pools of this process limited to one thread (threadpoolctl when importable, else a no-op).  The
+    controller is built ONCE: constructing it walks the loaded shared objects (tens of ms), limiting through it is microseconds."""
+    if not _BLAS_CONTROLLER:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _BLAS_CONTROLLER.append(ThreadpoolController())
+        except Exception:   # noqa: BLE001
+            _BLAS_CONTROLLER.append(None)
+    c = _BLAS_CONTROLLER[0]
+    return _NoLimit() if c is None else c.limit(limits=1, user_api="blas")
 
 
 class _Problem:
@@ -220,7 +246,8 @@ class _Problem:
             ii.append(a[k]); jj.append(b[k])
         ii = np.concatenate(ii) if ii else np.zeros(0, np.int64); jj = np.concatenate(jj) if jj else np.zeros(0, np.int64)
         A = sp.csc_matrix((np.ones(2 * len(ii)), (np.r_[ii, jj], np.r_[jj, ii])), shape=(V, V)) + (V + 1.0) * sp.identity(V, format="csc")
-        pc = splu(A.tocsc(), permc_spec="MMD_AT_PLUS_A", options=dict(SymmetricMode=True, DiagPivotThresh=0.0)).perm_c
+        with _blas_single_thread():
+            pc = splu(A.tocsc(), permc_spec="MMD_AT_PLUS_A", options=dict(SymmetricMode=True, DiagPivotThresh=0.0)).perm_c
         order = np.argsort(pc)            # perm_c[i] = position of column i  ->  variables in elimination order
         return np.concatenate([np.arange(self.off[v], self.off[v + 1]) for v in order]).astype(np.int64)
 
@@ -228,7 +255,11 @@ class _Problem:
         """x_p with Hp x_p = rhs_p for the symmetric positive definite damped normal matrix; Hp is already in the
         precomputed elimination order (columns of J are assembled in it), so SuperLU runs with NATURAL ordering."""
         from scipy.sparse.linalg import splu
-        return splu(Hp.tocsc(), permc_spec="NATURAL", options=dict(SymmetricMode=True, DiagPivotThresh=0.0)).solve(rhs_p)
+        # SuperLU hands its supernodes to BLAS in calls of a few hundred flops each; a multi-threaded OpenBLAS (64 threads by default on the
+        # GPU box, behind a cgroup quota of 16 CPUs) turns every one of them into a thread-pool round trip: the factorisation of the 10k
+        # helix takes 0.134 s with the default pool and 0.05 s on ONE BLAS thread (bench.py parametric_helix10k: 6.1 -> 2.35 s).
+        with _blas_single_thread():
+            return splu(Hp.tocsc(), permc_spec="NATURAL", options=dict(SymmetricMode=True, DiagPivotThresh=0.0)).solve(rhs_p)
 
     def pack(self, xdict):
         X = np.zeros(self.n)
@@ -254,7 +285,7 @@ class _Problem:
         contiguous slice of the rows of each factor kind on its own GPU and one all-gather per kind rebuilds the full blocks on
         every rank (factor rows are independent; BASELINE configs[4] "batched Jacobians on 8 GPUs")."""
         import scipy.sparse as sp
-        r = np.empty(self.m); vals = []
+        r = np.empty(self.m); vals = []; blocks = []
         indexed = shard is not None and hasattr(shard, "linearize_indexed")
         if indexed:
             shard.begin(X)          # X crosses PCIe once; the gathers X[ia] / X[ib] of every factor kind run on the device
@@ -272,9 +303,52 @@ class _Problem:
             vals.append(Ja.ravel())
             if Jb is not None:
                 vals.append(Jb.ravel())
+            blocks.append((Ja, Jb))
         J = sp.csr_matrix((np.concatenate(vals)[self.csr_perm], self.csr_indices, self.csr_indptr), shape=(self.m, self.n))   # columns in elimination order
         J.has_sorted_indices = True
+        self.blocks = blocks          # the whitened Jacobian blocks of THIS linearisation (normal_matrix)
         return r, J
+
+    # ---- the normal matrix H = J^T J from the factor blocks (round 6).  scipy's generic sparse product J.T @ J was 2/3 of the host time of
+    # an LM iteration on the 10k helix (0.11 of 0.17 s); H is the sum over the factors of [Ja Jb]^T [Ja Jb] -- a batched (da + db)^2 product
+    # per factor, scattered into the FIXED pattern of H through slot indices computed once.
+    def _normal_setup(self):
+        import scipy.sparse as sp
+        n = self.n
+        rows, cols = [], []
+        for k, g in self.groups.items():
+            idx = self.pos[g["ia"]] if g["ib"] is None else np.concatenate([self.pos[g["ia"]], self.pos[g["ib"]]], axis=1)   # (F, d)
+            d = idx.shape[1]
+            rows.append(np.repeat(idx[:, :, None], d, axis=2).ravel()); cols.append(np.repeat(idx[:, None, :], d, axis=1).ravel())
+        rows, cols = np.concatenate(rows).astype(np.int64), np.concatenate(cols).astype(np.int64)
+        S = sp.csc_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n))
+        S.sum_duplicates(); S.sort_indices()
+        keys = np.repeat(np.arange(n, dtype=np.int64), np.diff(S.indptr)) * n + S.indices       # ascending: column-major, rows sorted
+        self.h_slot = np.searchsorted(keys, cols * n + rows)
+        self.h_diag = np.searchsorted(keys, np.arange(n, dtype=np.int64) * (n + 1))
+        if not (np.array_equal(keys[self.h_diag], np.arange(n, dtype=np.int64) * (n + 1))):
+            raise AssertionError("an unknown without a diagonal entry in the normal matrix")
+        self.h_indices, self.h_indptr, self.h_nnz = S.indices.copy(), S.indptr.copy(), int(S.nnz)
+
+    def normal_matrix(self, blocks):
+        """H = J^T J (scipy csc, in the elimination order) from the whitened blocks [(Ja (F, dr, da), Jb (F, dr, db) | None)] of linearize()"""
+        import scipy.sparse as sp
+        if not hasattr(self, "h_slot"):
+            self._normal_setup()
+        vals = []
+        for Ja, Jb in blocks:
+            A = Ja if Jb is None else np.concatenate([Ja, Jb], axis=2)
+            vals.append(np.matmul(A.transpose(0, 2, 1), A).ravel())
+        data = np.bincount(self.h_slot, weights=np.concatenate(vals), minlength=self.h_nnz)
+        H = sp.csc_matrix((data, self.h_indices, self.h_indptr), shape=(self.n, self.n))
+        H.has_sorted_indices = True
+        return H
+
+    def damped(self, H, lam):
+        """H + lam * diag(diag(H) + 1e-12) on the fixed pattern (no sparse addition)"""
+        Hl = H.copy()
+        Hl.data[self.h_diag] += lam * (H.data[self.h_diag] + 1e-12)
+        return Hl
 
 
 def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, return_cov=False, verbose=False, shard=None, stats=None, polish=6):
@@ -285,7 +359,16 @@ def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, retur
     Gauss-Newton steps take the iterate onto the optimum along the directions the cost barely sees (see below).
     stats: a dict that receives where the time went -- {setup_s, linearize_s (rome_linearize calls: the batched residual / Jacobian
     kernels, their transfers and, when sharded, the exchange), host_solve_s (normal equations + sparse Cholesky / LU on the host),
-    iterations, linearizations}: on a 10 000-pose helix the host solve is > 95 % of the wall-clock."""
+    iterations, linearizations}: on a 10 000-pose helix the host solve is > 95 % of the wall-clock.
+    The host arithmetic of the whole solve runs with the BLAS pools limited to one thread: every BLAS call
+    of this loop is small -- SuperLU supernodes, 12 x 12 block products -- and the worker threads of a 64-thread OpenBLAS pool on a
+    16-CPU quota spin after each of them while the sequential parts of the factorisation want the cores: 10k helix 6.1 -> 2.4 s"""
+    with _blas_single_thread():
+        return _solve_graph_parametric(fg, init, max_iters, tol, ctx, return_cov, verbose, shard, stats, polish)
+
+
+def _solve_graph_parametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, return_cov=False, verbose=False, shard=None, stats=None, polish=6):
+    """the body of solveGraphParametric (run under the BLAS thread limit)"""
     import time
     import scipy.sparse as sp
     from scipy.sparse.linalg import spsolve
@@ -302,22 +385,23 @@ def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, retur
         T["linearize_s"] += time.perf_counter() - t0; T["linearizations"] += 1
         return out
     r, J = lin(X)
+    B = P.blocks
     cost = float(r @ r)
     for it in range(max_iters):
         if verbose:
             print('LM iter %d cost %.6g lambda %.1e' % (it, cost, lam))
         t0 = time.perf_counter()
-        H = (J.T @ J).tocsc(); g = J.T @ r
-        D = sp.diags(H.diagonal() + 1e-12)
+        H = P.normal_matrix(B); g = J.T @ r
         T["host_solve_s"] += time.perf_counter() - t0
         T["iterations"] += 1
         while True:
             t0 = time.perf_counter()
             d = np.empty(P.n)
-            d[P.perm] = P.solve_spd(H + lam * D, -g)
+            d[P.perm] = P.solve_spd(P.damped(H, lam), -g)
             Xn = P.retract(X, d)
             T["host_solve_s"] += time.perf_counter() - t0
             rn, Jn = lin(Xn)
+            Bn = P.blocks
             cn = float(rn @ rn)
             if cn <= cost or lam > 1e12:
                 break
@@ -325,7 +409,7 @@ def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, retur
         if cn > cost:   # damping exhausted without a descent step: keep the last accepted iterate (never commit an uphill one)
             break
         done = (cost - cn) <= tol * max(1.0, cost) or np.abs(d).max() < 1e-8
-        X, r, J, cost = Xn, rn, Jn, cn
+        X, r, J, B, cost = Xn, rn, Jn, Bn, cn
         lam = max(lam / 10.0, 1e-12)
         if done:
             break
@@ -336,18 +420,19 @@ def solveGraphParametric(fg, init=None, max_iters=100, tol=1e-4, ctx=None, retur
     # lam * diag(H) is what slows exactly those directions; a full step resolves them at once.
     for _ in range(int(polish)):
         t0 = time.perf_counter()
-        H = (J.T @ J).tocsc(); g = J.T @ r
+        H = P.normal_matrix(B); g = J.T @ r
         d = np.empty(P.n)
-        d[P.perm] = P.solve_spd(H + 1e-12 * sp.diags(H.diagonal() + 1e-12), -g)
+        d[P.perm] = P.solve_spd(P.damped(H, 1e-12), -g)
         Xn = P.retract(X, d)
         T["host_solve_s"] += time.perf_counter() - t0
         T["iterations"] += 1
         rn, Jn = lin(Xn)
+        Bn = P.blocks
         cn = float(rn @ rn)
         if not cn <= cost * (1.0 + 1e-12):
             break                                       # a full step that goes uphill: the damped iterate stands
         small = np.abs(d).max() < 1e-7
-        X, r, J, cost = Xn, rn, Jn, cn
+        X, r, J, B, cost = Xn, rn, Jn, Bn, cn
         if small:
             break
     out = P.unpack(X)
