@@ -342,22 +342,51 @@ struct BR {
     double r[2]; functor(z, fx, t, r);
     return fmax(fabs(r[0]), fabs(r[1])) <= tol ? 0 : 1;
   }
-  // Gauss-Newton on the functor (the oracle's br_newton): r through residual_bearingrange at the current point;
-  //   DIR 0: exact Newton step in the pose-frame polar chart of the landmark, (φ, n) += (r0, r1);  DIR 1: the block step along the ray
+  // Gauss-Newton on the functor (the oracle's br_newton): r = (sym_rem(b - atan2(pl)), rho - |pl|), pl = R(theta_p)^T (l - p.t), at every iterate;
+  //   DIR 0: exact Newton step in the pose-frame polar chart of the landmark, (phi, n) += (r0, r1);  DIR 1: the block step along the ray.
+  // Round 6 (as P2P2 / P3P3): an iterate is evaluated in the form its step needs.  The RANGE residual rho - |pl| comes first (one reciprocal
+  // square root, shared with the step); the BEARING residual is evaluated only where the test max|r| <= tol can pass (wave-uniform: a
+  // jittered start is never within 1e-12 of the measured range), and then as the angle of pl rotated by -b, whose small-angle branch
+  // (-w_y / w_x for |w_y| < 1e-8 w_x: the verification iterate) needs no atan2.  The frame of the next iterate is carried: DIR 1 -- the
+  // heading after the block step is (world bearing of the ray) - b, its (cos, sin) the unit ray rotated by -b: no sincos of the new
+  // heading; DIR 0 -- phi + r0 = b (mod 2 pi) and n + r1 = rho, so the step lands on rho (cos b, sin b) in the fixed pose's frame: no atan2.
+  // One sincos of the bearing sample per call; per cycle of the pose direction one atan2 (the heading itself, which the spread statistic and
+  // the output need) instead of three and no sincos instead of two (k_conv<BR<1>, 3>: profiles/r06_other_factors_trace.md).
   __device__ static __forceinline__ int gauss_newton(const double (&z)[2], const double (&fx)[DF], double (&t)[DT], int max_iters, double tol) {
-    [[maybe_unused]] double s = 0.0, c = 1.0;
-    if constexpr (DIR == 0) fast_sincos(fx[2], &s, &c);   // the fixed pose's frame: the same for every iterate
+    double sz, cz; fast_sincos(z[0], &sz, &cz);
+    double s = 0.0, c = 1.0;                                   // the frame the residual is taken in: the fixed pose (DIR 0) / the iterate (DIR 1)
+    if constexpr (DIR == 0) fast_sincos(fx[2], &s, &c);
+    bool fresh = true;                                         // DIR 1: (c, s) of the iterate's heading not carried yet (the start point)
     for (int it = 0; it < max_iters; ++it) {
-      double r[2]; functor(z, fx, t, r);
-      if (fmax(fabs(r[0]), fabs(r[1])) <= tol) return 0;
-      if constexpr (DIR == 0) {
-        const double dx = t[0] - fx[0], dy = t[1] - fx[1];
+      // landmark - pose translation in the world frame, its squared norm and 1 / norm
+      const double dx = DIR == 0 ? t[0] - fx[0] : fx[0] - t[0], dy = DIR == 0 ? t[1] - fx[1] : fx[1] - t[1];
+      const double n2 = dx * dx + dy * dy;
+      double y = __builtin_amdgcn_rsq(n2);
+      y = y * __builtin_fma(-0.5 * n2 * y, y, 1.5);
+      y = y * __builtin_fma(-0.5 * n2 * y, y, 1.5);
+      const bool ok = n2 > 0.0;
+      const double r1 = z[1] - (ok ? n2 * y : 0.0);
+      if (__builtin_amdgcn_ballot_w64(fabs(r1) <= tol) != 0) {   // somebody may be at a root: the bearing residual
+        if constexpr (DIR == 1) { if (fresh) fast_sincos(t[2], &s, &c); }
         const double plx = c * dx + s * dy, ply = c * dy - s * dx;
-        const double nn = fast_sqrt(plx * plx + ply * ply) + r[1], an = fast_atan2(ply, plx) + r[0];
-        double sa, ca; fast_sincos(an, &sa, &ca);
-        const double qx = nn * ca, qy = nn * sa;
+        const double wx = plx * cz + ply * sz, wy = ply * cz - plx * sz;     // pl rotated by -b: its angle is -(b - atan2(pl))
+        const bool small = wx > 0.0 && fabs(wy) < 1e-8 * wx;
+        double r0;
+        if (__builtin_amdgcn_ballot_w64(!small) == 0) r0 = -wy * fast_rcp(wx);
+        else r0 = small ? -wy * fast_rcp(wx) : sym_rem(z[0] - fast_atan2(ply, plx));
+        if (fmax(fabs(r0), fabs(r1)) <= tol) return 0;
+      }
+      if constexpr (DIR == 0) {       // (phi, n) += (r0, r1) = (b, rho) in the pose frame
+        const double qx = z[1] * cz, qy = z[1] * sz;
         t[0] = fx[0] + c * qx - s * qy; t[1] = fx[1] + s * qx + c * qy;
-      } else ring_step(z, fx, t);   // the block step along the ray (reciprocal square root, no FP64 division)
+      } else {                        // the block step along the ray (ring_step), the new heading's (cos, sin) = the unit ray rotated by -b
+        const double k = ok ? z[1] * y : 0.0;
+        t[0] = ok ? fx[0] - k * dx : fx[0] - z[1]; t[1] = fx[1] - k * dy;
+        if constexpr (DT == 3) t[2] = (ok ? fast_atan2(dy, dx) : 0.0) - z[0];
+        const double ux = ok ? dx * y : 1.0, uy = ok ? dy * y : 0.0;
+        c = ux * cz + uy * sz; s = uy * cz - ux * sz;
+        fresh = false;
+      }
     }
     return 1;
   }
