@@ -95,18 +95,10 @@ class RelativeEliminationSolver:
         for l in list(fg.variables):
             U.addVariable(l + "^", Pose2)          # anchor block: N copies of the posterior mean
             U.addVariable(l + "&", Pose2)          # pool block: the mixture over the passes so far (solve(passes > 1))
-        import gc
-        import time
+        from .graph import gc_paused
         self.structures = max(1, int(structures))
-        # The build allocates ~1e6 small objects that all stay alive (edges, rows, labels): the cyclic collector's generation scans find
-        # nothing to free and cost a third of the build (0.33 -> 0.23 s on Manhattan-3500) -- paused until the plans exist.
-        gc_was_on = gc.isenabled()
-        gc.disable()
-        try:
+        with gc_paused():     # (~1e6 live small objects, nothing to free: the generation scans cost a third of the build)
             self._build(fg, shard)
-        finally:
-            if gc_was_on:
-                gc.enable()
         self._to_pool = self.backend.BlockOp(self.store, "copy", [(l, l + "&") for l in fg.variables])
         self._mix = {}
         self.runs = 0

@@ -6,12 +6,28 @@ Mirrors the slice of the DistributedFactorGraphs / RoME API the hot path is driv
   generateGraph_Hexagonal / generateGraph_Circle                   src/canonical/GenerateCircular.jl:31-94
 and packs a graph into the flat factor / convolution tables the device sweep consumes.
 """
+import contextlib as _contextlib
+import gc as _gc
 from collections import OrderedDict
 
 import numpy as np
 
 from .factors import (MvNormal, Normal, Uniform, Pose2, Point2, Pose3, Pose2Pose2, PriorPose2, Pose2Point2BearingRange,
                       Pose3Pose3, PriorPose3, PriorPoint2)
+
+
+@_contextlib.contextmanager
+def gc_paused():
+    """the host-side plan builders (elimination structure, Bayes-tree levels, initAll! rounds) allocate ~1e5 - 1e6 small objects that all stay
+    alive: the cyclic collector's generation scans find nothing to free and cost a third of such a build (Manhattan-3500 elimination
+    structure 0.33 -> 0.23 s) -- paused for the duration, restored afterwards"""
+    on = _gc.isenabled()
+    _gc.disable()
+    try:
+        yield
+    finally:
+        if on:
+            _gc.enable()
 
 
 class FactorGraph:

@@ -46,11 +46,13 @@ def initAllOrdered(fg, seed=1, ctx=None, sweeps=0, kind="colour", solver=None):
     from .api import make_opts
     from .clique import DeviceStore
     from .schedule import OrderedSolve
+    from .graph import gc_paused
     keep = [l for l in fg.variables if fg.isInitialized(l)]
     store = DeviceStore(fg, ctx=ctx)
-    osv = OrderedSolve(store, kind=kind, keep=keep)
     kw = {} if solver is None else {"solver": solver}
-    osv.init(make_opts(N=fg.N, seed=seed, **kw))
+    with gc_paused():     # the rounds' plans: live objects only
+        osv = OrderedSolve(store, kind=kind, keep=keep)
+        osv.init(make_opts(N=fg.N, seed=seed, **kw))
     if sweeps:
         osv.sweep(make_opts(N=fg.N, seed=seed + 1, **kw), sweeps)
     store.download(fg)

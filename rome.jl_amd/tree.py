@@ -232,8 +232,13 @@ class TreeSolver:
     zero).  The multiscale Gibbs product is ONE two-wave block per variable and its time grows with the square of the number of
     proposals (42 proposals: 14 ms with the rest of the chip idle; profiles/r05_tree_solve.txt); 0 = one product whatever the count."""
 
-    def __init__(self, fg, tree=None, order="mmd", last=(), messages="marginal", gibbsIters=3, downIters=1, rootIters=0, refineIters=0, relIters=0,
-                 max_product=8, backend=None, ctx=None, shard=None, message_tree="star"):
+    def __init__(self, *a, **kw):
+        from .graph import gc_paused
+        with gc_paused():     # the level specs and plans are ~1e5 live objects: no cyclic garbage to find while they are built
+            self._init(*a, **kw)
+
+    def _init(self, fg, tree=None, order="mmd", last=(), messages="marginal", gibbsIters=3, downIters=1, rootIters=0, refineIters=0, relIters=0,
+              max_product=8, backend=None, ctx=None, shard=None, message_tree="star"):
         """message_tree ("relative" form): the STRUCTURE of the message over a clique's separators -- a spanning tree T of relative
         messages, p(root) * prod_{(j,k) in T} p(s_k | s_j).  "star" (default): every separator tied to the ONE anchor.  "hop": Prim's
         tree from the anchor over shortest-path lengths in the clique-local graph (the clique's factors + the tree edges of its

@@ -57,3 +57,26 @@ def test_blas_limit_is_a_cached_context_manager():
         assert PM._BLAS_CONTROLLER[0] is c                      # built once
         if c is not None:
             assert all(lib.num_threads == 1 for lib in c.lib_controllers if lib.user_api == "blas")
+
+
+def test_gc_paused_restores_the_collector_state():
+    import gc
+    from rome_jl_amd.graph import gc_paused
+    assert gc.isenabled()
+    with gc_paused():
+        assert not gc.isenabled()
+        with gc_paused():                                        # nested: the inner exit must not re-enable inside the outer pause
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    with pytest.raises(RuntimeError):
+        with gc_paused():
+            raise RuntimeError("x")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with gc_paused():
+            pass
+        assert not gc.isenabled()                                # a caller that runs without the collector keeps running without it
+    finally:
+        gc.enable()
