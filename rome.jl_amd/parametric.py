@@ -259,7 +259,9 @@ class _Problem:
         # GPU box, behind a cgroup quota of 16 CPUs) turns every one of them into a thread-pool round trip: the factorisation of the 10k
         # helix takes 0.134 s with the default pool and 0.05 s on ONE BLAS thread (bench.py parametric_helix10k: 6.1 -> 2.35 s).
         with _blas_single_thread():
-            return splu(Hp.tocsc(), permc_spec="NATURAL", options=dict(SymmetricMode=True, DiagPivotThresh=0.0)).solve(rhs_p)
+            # (panel_size = 1, relax = 4: the supernodes of a pose graph's factor are 3 - 6 columns wide; SuperLU's default panels of 10 / 20
+            #  columns and relaxed supernodes of 10 cost 49 ms per factorisation of the 10k helix against 35 ms -- scripts/splu_options.py)
+            return splu(Hp.tocsc(), permc_spec="NATURAL", panel_size=1, relax=4, options=dict(SymmetricMode=True, DiagPivotThresh=0.0)).solve(rhs_p)
 
     def pack(self, xdict):
         X = np.zeros(self.n)
