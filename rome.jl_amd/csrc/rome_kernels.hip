@@ -614,29 +614,37 @@ struct P3P3 {
     }
     quat_log(q, w);
   }
+  // ONE loop body for both directions (a wave of the packed sweep spans rows of both: two branches would run one after the other).  The
+  // iteration lives in the PREDICTED pose of q: (s, u) with target (Ts, Tu),
+  //   dir 0 / prior:  (s, u) = (q.t, q_q) itself,                         target = F o exp(z) = (F.t + R_F z_t, q_F (x) q_z)
+  //   dir 1:          (s, u) = (p.t + R_p z_t, q_p (x) q_z) of the iterate p,  target = the fixed q = (F.t, q_F)
+  // residual e = conj(u) (x) Tu, r_t = Ts - s (dir 1: the functor's residual up to the sign of both parts -- the test is on max|r|);
+  // update u <- u (x) e, s <- s + r_t.  In dir 1 this IS R_p <- R_p Exp(-Z r_w), p.t <- q.t - R_p z_t: u (x) e (x) conj(q_z) = q_p (x) q_z
+  // (x) conj(e') (x) conj(q_z) with e' the functor's rotation.  The iterate p is recovered from (s, u) once, after the loop.
   __device__ static __forceinline__ int gauss_newton(const Consts& K, const double (&z)[6], const double (&fxc)[6], double (&t)[6], Aux& A, int max_iters, double tol) {
-    const bool back = K.dir == 1;
-    double qz[4], qF[4] = {1.0, 0.0, 0.0, 0.0}, Ft[3] = {0.0, 0.0, 0.0};
+    const bool back = K.dir == 1, prior = K.dir == kDirPrior;
+    double qz[4], qF[4], Ft[3];
     quat_exp(&z[3], qz);
-    if (K.dir != kDirPrior) { quat_exp(&fxc[3], qF); Ft[0] = fxc[0]; Ft[1] = fxc[1]; Ft[2] = fxc[2]; }   // (prior row: the identity pose)
-    // dir 0 / prior: the predicted pose (qh, th) = F o exp(z) does not depend on the iterate
-    double qh[4] = {1.0, 0.0, 0.0, 0.0}, th[3] = {0.0, 0.0, 0.0};
-    if (!back) {
-      double v[3];
-      quat_mul(qF, qz, qh); quat_rot(qF, z, v);
-      th[0] = Ft[0] + v[0]; th[1] = Ft[1] + v[1]; th[2] = Ft[2] + v[2];
-    }
+    quat_exp(&fxc[3], qF);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qF[k] = prior ? (k == 0 ? 1.0 : 0.0) : qF[k];   // (prior row: the identity pose)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Ft[k] = prior ? 0.0 : fxc[k];
+    // M = X (x) q_z, v = R(X) z_t with X = the fixed rotation (dir 0: the target's) or the start iterate's (dir 1: the state's)
+    double X[4], M[4], v[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) X[k] = back ? A.q[k] : qF[k];
+    quat_mul(X, qz, M); quat_rot(X, z, v);
+    double u[4], Tu[4], s[3], Ts[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { u[k] = back ? M[k] : A.q[k]; Tu[k] = back ? qF[k] : M[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { s[k] = back ? t[k] + v[k] : t[k]; Ts[k] = back ? Ft[k] : Ft[k] + v[k]; }
     int st = 1;
     for (int it = 0; it < max_iters; ++it) {
-      double g[4], e[4], r[6];
-      if (back) {
-        double v[3];
-        quat_mul(A.q, qz, g); quat_cmul(qF, g, e); quat_rot(A.q, z, v);
-        r[0] = t[0] + v[0] - Ft[0]; r[1] = t[1] + v[1] - Ft[1]; r[2] = t[2] + v[2] - Ft[2];
-      } else {
-        quat_cmul(A.q, qh, e);
-        r[0] = th[0] - t[0]; r[1] = th[1] - t[1]; r[2] = th[2] - t[2];
-      }
+      double e[4], r[6];
+      quat_cmul(u, Tu, e);
+      r[0] = Ts[0] - s[0]; r[1] = Ts[1] - s[1]; r[2] = Ts[2] - s[2];
       // The coordinates Log(e) are needed only where the test max|r| <= tol can pass: |r_w|_inf >= theta / sqrt 3 >= 2 |vec e| / sqrt 3, so
       // a lane with 4 |vec e|^2 > 3 tol^2 (or a translation residual above tol) is NOT converged whatever its Log is -- the same
       // decision without the inverse-trigonometric evaluation.  Wave-uniform: the start iterate skips the Log, the verification
@@ -649,25 +657,20 @@ struct P3P3 {
         if (fmax(mt, fmax(fabs(r[3]), fmax(fabs(r[4]), fabs(r[5])))) <= tol) { st = 0; break; }
       }
       double qn[4];
-      if (back) {
-        double h[4], v[3];
-        quat_mulc(g, e, h); quat_mulc(h, qz, qn);
-        const double nb = __builtin_fma(-0.5, qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3], 1.5);
+      quat_mul(u, e, qn);
+      s[0] += r[0]; s[1] += r[1]; s[2] += r[2];
+      // (renormalised: a product of unit quaternions drifts by an ulp per step; |q|^2 = 1 + eps, 1/|q| = 3/2 - |q|^2/2 to O(eps^2))
+      const double nn = __builtin_fma(-0.5, qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3], 1.5);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) qn[k] *= nb;
-        quat_rot(qn, z, v);
-        t[0] = Ft[0] - v[0]; t[1] = Ft[1] - v[1]; t[2] = Ft[2] - v[2];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) A.q[k] = qn[k];
-      } else {
-        quat_mul(A.q, e, qn);
-        t[0] += r[0]; t[1] += r[1]; t[2] += r[2];
-        // (renormalised: a product of unit quaternions drifts by an ulp per step; |q|^2 = 1 + eps, 1/|q| = 3/2 - |q|^2/2 to O(eps^2))
-        const double nn = __builtin_fma(-0.5, qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3], 1.5);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) A.q[k] = qn[k] * nn;
-      }
+      for (int k = 0; k < 4; ++k) u[k] = qn[k] * nn;
     }
+    // the iterate itself: dir 0 / prior (s, u); dir 1  q_p = u (x) conj(q_z), p.t = s - R(q_p) z_t
+    double qp[4], w[3];
+    quat_mulc(u, qz, qp); quat_rot(qp, z, w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A.q[k] = back ? qp[k] : u[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = back ? s[k] - w[k] : s[k];
     return st;
   }
   template <int SOLVER>
