@@ -549,17 +549,19 @@ struct P3P3 {
       for (int k = 0; k < 4; ++k) P.qa[k] = qz[k];
       return P;
     }
-    double qF[4], v[3];
+    // both directions in ONE branch-free form (a wave of the packed sweep spans rows of both; cf. P2P2::prepare):
+    //   qa = q_F (x) (dir 1 ? conj(q_z) : q_z),   a = F.t +- R(dir 1 ? qa : q_F) z_t
+    double qF[4], v[3], qs[4], qr[4];
     quat_exp(&fxc[3], qF);
-    if (K.dir == 0) {
-      quat_mul(qF, qz, P.qa); quat_rot(qF, z, v);
+    const bool back = K.dir != 0;
+    const double sg = back ? -1.0 : 1.0;
+    qs[0] = qz[0]; qs[1] = sg * qz[1]; qs[2] = sg * qz[2]; qs[3] = sg * qz[3];
+    quat_mul(qF, qs, P.qa);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) P.a[k] = fxc[k] + v[k];
-    } else {
-      quat_mulc(qF, qz, P.qa); quat_rot(P.qa, z, v);
+    for (int k = 0; k < 4; ++k) qr[k] = back ? P.qa[k] : qF[k];
+    quat_rot(qr, z, v);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) P.a[k] = fxc[k] - v[k];
-    }
+    for (int k = 0; k < 3; ++k) P.a[k] = __builtin_fma(sg, v[k], fxc[k]);
     return P;
   }
   // u0 ∘ exp_ϵ(hat e), e = spread·(u − ½):  t += R e_t,  R ← R Exp(e_ω)
