@@ -186,43 +186,43 @@ struct P2P2 {
     double r[3]; functor(K, functor_setup(K, z, fxc), z, t, r);
     return fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2]))) <= tol ? 0 : 1;
   }
-  // Gauss-Newton on the functor (the oracle's p2p2_newton): evaluate r at the current point; dir 0: J = -I; dir 1: J = [I, R'(θ) z_t; 0, 1].
-  // Round 6: the iterate carries (cos θ, sin θ) -- the heading residual is atan2(U21, U11) of a UNIT vector (U11, U21) = (cos r_θ, sin r_θ),
-  // so the heading update θ += r_θ is the rotation of (c, s) by (U11, U21): no sincos of the new iterate.  The ANGLE r_θ itself (the step
-  // of the linearised dir-1 translation update and the accumulated output heading) costs one atan2 on the first iterate; from the second
-  // iterate on |r_θ| < 1e-8 and r_θ = U21 to 1e-24.  One sincos (the start heading) + one atan2 per particle instead of one of each
-  // per iterate (three iterates: start -> root -> verification); the iterates agree with the fresh-sincos form to an ulp of the rotation.
+  // Gauss-Newton on the functor (the oracle's p2p2_newton): evaluate r at the current point, step on the group.
+  // Round 6 (i): the iterate carries (cos θ, sin θ) -- the heading residual is atan2(U21, U11) of a UNIT vector (U11, U21) = (cos r_θ, sin r_θ),
+  // so the heading update θ += r_θ is the rotation of (c, s) by (U11, U21): no sincos of the new iterate; the ANGLE r_θ (the accumulated
+  // output heading) costs one atan2 on the first iterate, from the second on |r_θ| < 1e-8 and r_θ = U21 to 1e-24.
+  // Round 6 (ii): ONE loop body for both directions (a wave of the packed sweep spans rows of both), as P3P3::gauss_newton: the iteration
+  // lives in the PREDICTED pose of q -- dir 0 / prior: the state S is q itself, the target G = F ∘ exp(z); dir 1: S = p ∘ exp(z) of the
+  // iterate p, G = the fixed q -- with r = (G.t − S.t, angle of R_Sᵀ R_G) (dir 1: the functor's residual with both signs flipped; the
+  // test is on max|r|) and the exact group update S.t += r_t, R_S ← R_S R(r_θ).  The oracle's dir-1 step linearises the translation
+  // (J13, J23) and needs a third evaluation whenever the heading moved; this one lands on the root from any start: two evaluations.
   __device__ static __forceinline__ int gauss_newton(const Consts& K, const double (&z)[3], const double (&fxc)[3], double (&t)[3], int max_iters, double tol) {
-    const Fn f = functor_setup(K, z, fxc);
-    Se2 T = se2_from_coords(t[0], t[1], t[2]);
+    const bool back = K.dir == 1, prior = K.dir == kDirPrior;
+    const Fn f = functor_setup(K, z, fxc);                     // (prior row: F = the sample point, z's rotation the identity)
+    const Se2 T = se2_from_coords(t[0], t[1], t[2]);
+    const double zx = prior ? 0.0 : z[0], zy = prior ? 0.0 : z[1];
+    // M = X ∘ exp(z), X = the fixed pose (dir 0: the target is predicted from it) or the start iterate (dir 1: the state is)
+    const double Xx = back ? T.x : f.F.x, Xy = back ? T.y : f.F.y, Xc = back ? T.c : f.F.c, Xs = back ? T.s : f.F.s;
+    const double Mx = Xx + Xc * zx - Xs * zy, My = Xy + Xs * zx + Xc * zy, Mc = Xc * f.cz - Xs * f.sz, Ms = Xs * f.cz + Xc * f.sz;
+    double Sx = back ? Mx : T.x, Sy = back ? My : T.y, Sc = back ? Mc : T.c, Ss = back ? Ms : T.s;
+    const double Gx = back ? f.F.x : Mx, Gy = back ? f.F.y : My, Gc = back ? f.F.c : Mc, Gs = back ? f.F.s : Ms;
+    double ang = back ? t[2] + z[2] : t[2];                    // the state's heading as an angle (the output accumulates the steps)
+    int st = 1;
     for (int it = 0; it < max_iters; ++it) {
-      double r0, r1, U11, U21;
-      if (K.dir == kDirPrior) {        // residual_priorpose2(f.F, T): log(T, m)
-        U11 = T.c * f.F.c + T.s * f.F.s; U21 = T.c * f.F.s - T.s * f.F.c;
-        r0 = f.F.x - T.x; r1 = f.F.y - T.y;
-      } else {                          // residual_pose2pose2(z, p, q) with (p, q) = (F, T) or (T, F)
-        const Se2& p = K.dir == 0 ? f.F : T;
-        const Se2& q = K.dir == 0 ? T : f.F;
-        const double qhx = p.x + p.c * z[0] - p.s * z[1], qhy = p.y + p.s * z[0] + p.c * z[1];
-        const double h11 = p.c * f.cz - p.s * f.sz, h21 = p.s * f.cz + p.c * f.sz;
-        U11 = q.c * h11 + q.s * h21; U21 = q.c * h21 - q.s * h11;
-        r0 = qhx - q.x; r1 = qhy - q.y;
-      }
+      const double U11 = Sc * Gc + Ss * Gs, U21 = Sc * Gs - Ss * Gc;
+      const double r0 = Gx - Sx, r1 = Gy - Sy;
       const bool small = U11 > 0.0 && fabs(U21) < 1e-8;
       const double r2 = small ? U21 : fast_atan2(U21, U11);
-      if (fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol) { t[0] = T.x; t[1] = T.y; return 0; }
-      const double c0 = T.c, s0 = T.s;
-      if (K.dir == 1) {
-        const double J13 = -s0 * z[0] - c0 * z[1], J23 = c0 * z[0] - s0 * z[1], dth = -r2;
-        T.x += -r0 - J13 * dth; T.y += -r1 - J23 * dth; t[2] += dth;
-        T.c = c0 * U11 + s0 * U21; T.s = s0 * U11 - c0 * U21;       // rotation by -r_θ
-      } else {
-        T.x += r0; T.y += r1; t[2] += r2;
-        T.c = c0 * U11 - s0 * U21; T.s = s0 * U11 + c0 * U21;       // rotation by +r_θ
-      }
+      if (fmax(fabs(r0), fmax(fabs(r1), fabs(r2))) <= tol) { st = 0; break; }
+      const double c0 = Sc, s0 = Ss;
+      Sx += r0; Sy += r1; ang += r2;
+      Sc = c0 * U11 - s0 * U21; Ss = s0 * U11 + c0 * U21;       // rotation by +r_θ
     }
-    t[0] = T.x; t[1] = T.y;
-    return 1;
+    // the iterate itself: dir 0 / prior S; dir 1  R_p = R_S R(z_θ)ᵀ, p.t = S.t − R_p z_t, θ_p = θ_S − z_θ
+    const double Pc = Sc * f.cz + Ss * f.sz, Ps = Ss * f.cz - Sc * f.sz;
+    t[0] = back ? Sx - (Pc * zx - Ps * zy) : Sx;
+    t[1] = back ? Sy - (Ps * zx + Pc * zy) : Sy;
+    t[2] = back ? ang - z[2] : ang;
+    return st;
   }
 
   template <int SOLVER>
