@@ -183,8 +183,20 @@ struct P2P2 {
   }
   // status of a directly returned root: max|r| of the functor there against tol
   __device__ static __forceinline__ int verify(const Consts& K, const double (&z)[3], const double (&fxc)[3], const double (&t)[3], const Aux&, double tol) {
-    double r[3]; functor(K, functor_setup(K, z, fxc), z, t, r);
-    return fmax(fabs(r[0]), fmax(fabs(r[1]), fabs(r[2]))) <= tol ? 0 : 1;
+    // ONE branch-free evaluation for the three row kinds (the packed sweep's waves span rows of both directions): the residual of
+    // gauss_newton's predicted-pose form -- S = the pose the factor predicts for q (dir 1: from the returned p), G = q -- which is the
+    // functor's residual up to the sign of both parts; |r_θ| <= tol is decided on the unit vector (U11, U21) itself when it is small
+    const bool back = K.dir == 1, prior = K.dir == kDirPrior;
+    const Fn f = functor_setup(K, z, fxc);
+    const Se2 T = se2_from_coords(t[0], t[1], t[2]);
+    const double zx = prior ? 0.0 : z[0], zy = prior ? 0.0 : z[1];
+    const double Xx = back ? T.x : f.F.x, Xy = back ? T.y : f.F.y, Xc = back ? T.c : f.F.c, Xs = back ? T.s : f.F.s;
+    const double Mx = Xx + Xc * zx - Xs * zy, My = Xy + Xs * zx + Xc * zy, Mc = Xc * f.cz - Xs * f.sz, Ms = Xs * f.cz + Xc * f.sz;
+    const double Gx = back ? f.F.x : T.x, Gy = back ? f.F.y : T.y, Gc = back ? f.F.c : T.c, Gs = back ? f.F.s : T.s;
+    const double U11 = Mc * Gc + Ms * Gs, U21 = Mc * Gs - Ms * Gc;
+    const bool small = U11 > 0.0 && fabs(U21) < 1e-8;
+    const double r2 = small ? U21 : fast_atan2(U21, U11);
+    return fmax(fabs(Gx - Mx), fmax(fabs(Gy - My), fabs(r2))) <= tol ? 0 : 1;
   }
   // Gauss-Newton on the functor (the oracle's p2p2_newton): evaluate r at the current point, step on the group.
   // Round 6 (i): the iterate carries (cos θ, sin θ) -- the heading residual is atan2(U21, U11) of a UNIT vector (U11, U21) = (cos r_θ, sin r_θ),
