@@ -81,7 +81,8 @@ enum {
  *                 updates, iterated to max|r| <= tol.  The rotation part of an iterate is carried in the form the residual needs --
  *                 (cos, sin) of a Pose2 heading, a unit quaternion of a Pose3 rotation: r_w = Log(conj(q_q) (x) q_p (x) q_z) is the
  *                 rotation of the functor's Log(R_q^T R_p Exp(z_w)) -- and its coordinates (atan2 / Log) are evaluated where the
- *                 step or the convergence test needs them; NEWTON's `status` evaluates the literal 3x3 functor.  Unique-root
+ *                 step or the convergence test needs them (NEWTON's `status` evaluates the same residual once, at the returned
+ *                 root; the literal point / 3x3 forms are the rome_residual_* entry points).  Unique-root
  *                 factors: from the start points (the target's current belief), ONE pass -- a converged unique root does not
  *                 depend on the start beyond `tol`, so the entropy / re-solve rounds of inflate_cycles are not run (a converged
  *                 proposal is start- and cycle-count-independent only to `tol`: compared with the oracle's Newton mode, which
